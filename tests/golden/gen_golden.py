@@ -1,0 +1,399 @@
+"""Generate golden vectors by running the UNMODIFIED reference (build container only).
+
+    cd /root/repo && python tests/golden/gen_golden.py
+
+Imports /root/reference through tests/golden/ref_harness.py (stand-ins for absent third-party
+deps only), fills the reference model with name-seeded weights
+(oracle.seeded_tensor — a numpy legacy-RandomState stream, reproducible anywhere), runs the
+reference and stores inputs + expected outputs as small .npz fixtures in tests/golden/.
+Fixtures are data only: no reference source text is stored.
+
+Dropout (box_head.py:88-90) is patched to identity, or to a recorded mask sequence for the
+`*_dropmask` case, because torch's global RNG cannot be matched on the GPU.
+"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.abspath(os.path.join(HERE, "..", "..")))
+
+import ref_harness as rh  # noqa: E402
+
+rh.install()
+from oracle import wsod_oracle as O  # noqa: E402
+
+import torch.nn.functional as F  # noqa: E402
+from detectron2.structures import Boxes, Instances  # noqa: E402
+from detectron2.utils.events import EventStorage  # noqa: E402
+
+_real_dropout = F.dropout
+
+
+class DropoutPatch:
+    def __init__(self, masks=None):
+        self.masks = masks
+        self.i = 0
+
+    def __call__(self, x, p=0.5, training=True, inplace=False):
+        if not training:
+            return x
+        if self.masks is None:
+            return x
+        m = self.masks[self.i % len(self.masks)]
+        self.i += 1
+        return x * m
+
+    def __enter__(self):
+        F.dropout = self
+        torch.nn.functional.dropout = self
+        return self
+
+    def __exit__(self, *a):
+        F.dropout = _real_dropout
+        torch.nn.functional.dropout = _real_dropout
+
+
+def fill_reference(model, seed):
+    sd = model.state_dict()
+    new = {}
+    for n, t in sd.items():
+        if n in ("pixel_mean", "pixel_std"):
+            new[n] = t
+            continue
+        new[n] = O.seeded_tensor(n, tuple(t.shape), seed)
+    model.load_state_dict(new)
+    return {n: tuple(t.shape) for n, t in sd.items() if n not in ("pixel_mean", "pixel_std")}
+
+
+def make_inputs(n_img, R, K, H, W, seed, n_gt=None):
+    rs = np.random.RandomState(seed)
+    batch = []
+    for i in range(n_img):
+        h = H - 8 * i  # ragged image sizes exercise the zero padding of ImageList.from_tensors
+        w = W - 4 * i
+        img = rs.randint(0, 256, size=(3, h, w)).astype(np.float32)
+        x0 = rs.rand(R) * (w - 24)
+        y0 = rs.rand(R) * (h - 24)
+        bw = 12 + rs.rand(R) * (w - x0 - 12)
+        bh = 12 + rs.rand(R) * (h - y0 - 12)
+        boxes = np.stack([x0, y0, np.minimum(x0 + bw, w), np.minimum(y0 + bh, h)], 1).astype(np.float32)
+        obj = np.sort(rs.rand(R).astype(np.float32))[::-1].copy()
+        G = n_gt or rs.randint(1, 4)
+        cls = rs.permutation(K)[:G].astype(np.int64)
+        # gt boxes only feed logging in the reference (first label_and_sample_proposals call)
+        gtb = boxes[rs.permutation(R)[:G]].copy()
+        batch.append({"image": img, "proposal_boxes": boxes, "objectness_logits": obj, "gt_classes": cls,
+                      "gt_boxes": gtb})
+    return batch
+
+
+def to_ref_inputs(batch):
+    out = []
+    for b in batch:
+        h, w = b["image"].shape[1:]
+        prop = Instances((h, w))
+        prop.proposal_boxes = Boxes(torch.from_numpy(b["proposal_boxes"]))
+        prop.objectness_logits = torch.from_numpy(b["objectness_logits"])
+        inst = Instances((h, w))
+        inst.gt_boxes = Boxes(torch.from_numpy(b["gt_boxes"]))
+        inst.gt_classes = torch.from_numpy(b["gt_classes"])
+        out.append({"image": torch.from_numpy(b["image"]), "proposals": prop, "instances": inst, "height": h,
+                    "width": w})
+    return out
+
+
+def flat_batch(batch, d):
+    d["n_img"] = np.int64(len(batch))
+    for i, b in enumerate(batch):
+        for k, v in b.items():
+            d["in%d_%s" % (i, k)] = v
+
+
+def case_full_model(name, yaml_rel, opts, seed, n_img, R, H, W, dropmask=False, also_infer=True, steps=2):
+    """Whole GeneralizedRCNNWSL: losses, grads of trainable params, 2 SGD steps, inference."""
+    from detectron2.solver import build_optimizer
+
+    cfg, model = rh.build_reference_model(yaml_rel, opts)
+    shapes = fill_reference(model, seed)
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    batch = make_inputs(n_img, R, K, H, W, seed + 17)
+    d = {"seed": np.int64(seed)}
+    flat_batch(batch, d)
+    d1, d2 = cfg.MODEL.ROI_BOX_HEAD.DAN_DIM
+    masks = None
+    if dropmask:
+        rs = np.random.RandomState(seed + 5)
+        masks = [torch.from_numpy((rs.rand(n_img * R, dd) > 0.5).astype(np.float32) * 2.0) for dd in (d1, d2)]
+        d["dropmask0"] = masks[0].numpy()
+        d["dropmask1"] = masks[1].numpy()
+    model.train()
+    opt = build_optimizer(cfg, model)
+    tnames = [n for n, p in model.named_parameters() if p.requires_grad]
+    d["trainable"] = np.array(tnames)
+    with EventStorage() as storage, DropoutPatch(masks):
+        for step in range(steps):
+            opt.zero_grad()
+            losses = model(to_ref_inputs(batch))
+            total = sum(losses.values())
+            total.backward()
+            for k, v in losses.items():
+                d["step%d_%s" % (step, k)] = np.float64(v.item())
+            if step == 0:
+                # intermediate activations for op-level parity
+                for n, p in model.named_parameters():
+                    if p.requires_grad and p.grad is not None and p.numel() <= 70000:
+                        d["grad0." + n] = p.grad.detach().numpy().copy()
+                    elif p.requires_grad and p.grad is not None:
+                        g = p.grad.detach().reshape(-1)
+                        d["gradhead0." + n] = g[:4096].numpy().copy()
+                        d["gradsum0." + n] = np.float64(g.double().sum().item())
+                        d["gradabs0." + n] = np.float64(g.double().abs().sum().item())
+                    elif p.requires_grad:
+                        d["gradnone0." + n] = np.int64(1)
+            opt.step()
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                f = p.detach().reshape(-1)
+                d["after%d.head." % steps + n] = f[:2048].numpy().copy()
+                d["after%d.sum." % steps + n] = np.float64(f.double().sum().item())
+    # features / inference with the UPDATED weights
+    if also_infer:
+        model.eval()
+        with torch.no_grad(), EventStorage():
+            ins = to_ref_inputs(batch)
+            for x in ins:
+                x.pop("instances")
+            results, all_scores, all_boxes = model.inference(ins, do_postprocess=False)
+            images = model.preprocess_image(ins)
+            feats = model.backbone(images.tensor)
+            fk = list(feats.keys())[0]
+            d["feat_name"] = np.array(fk)
+            d["feat"] = feats[fk].numpy().copy()
+        for i, r in enumerate(results):
+            d["det%d_boxes" % i] = r.pred_boxes.tensor.numpy().copy()
+            d["det%d_scores" % i] = r.scores.numpy().copy()
+            d["det%d_classes" % i] = r.pred_classes.numpy().copy()
+            d["all_scores%d" % i] = all_scores[i].numpy().copy()
+        # the reference returns all_scores with a leading unsqueeze(0) per image (fast_rcnn.py:104-107)
+    d["cfg_opts"] = np.array([yaml_rel] + list(opts))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: v for k, v in d.items() if k.startswith("step")})
+
+
+def case_heads_detail(name, seed, K=4, R=40, n_img=2):
+    """OICRROIHeads through explicit kwargs (every class is @configurable): op-level intermediates —
+    WSDDN scores, pgt indices incl. a forced TIE, labels, per-refinement losses, grads wrt logits."""
+    from detectron2.layers import ShapeSpec
+    from detectron2.modeling.box_regression import Box2BoxTransform
+    from detectron2.modeling.matcher import Matcher
+    from detectron2.modeling.poolers import ROIPooler
+    from wsl.modeling.roi_heads.box_head import DiscriminativeAdaptionNeck
+    from wsl.modeling.roi_heads.fast_rcnn import OICROutputLayers, WSDDNOutputLayers
+    from wsl.modeling.roi_heads.roi_heads_oicr import OICRROIHeads
+
+    C, P, D1, D2 = 6, 3, 24, 32
+    for reg in (False, True):
+        refine_reg = [False, False, reg]
+        b2b = Box2BoxTransform((10.0, 10.0, 5.0, 5.0))
+        neck = DiscriminativeAdaptionNeck(ShapeSpec(channels=C, height=P, width=P), conv_dims=[], fc_dims=[D1, D2])
+        pred = WSDDNOutputLayers(ShapeSpec(channels=D2), box2box_transform=b2b, num_classes=K, mean_loss=True)
+        refs = [OICROutputLayers(ShapeSpec(channels=D2), box2box_transform=b2b, num_classes=K, refine_k=k,
+                                 refine_reg=refine_reg) for k in range(3)]
+        heads = OICRROIHeads(box_in_features=["f"], box_pooler=ROIPooler(P, (0.125,), 0, "ROIPool"), box_head=neck,
+                             box_predictor=pred, refine_K=3, refine_reg=refine_reg, box_refinery=refs,
+                             num_classes=K, batch_size_per_image=4096, positive_fraction=1.0,
+                             proposal_matcher=Matcher([0.5], [0, 1], False), proposal_append_gt=False)
+        sd = heads.state_dict()
+        heads.load_state_dict({n: O.seeded_tensor("roi_heads." + n, tuple(t.shape), seed) for n, t in sd.items()})
+        heads.train()
+        H = W = 96
+        batch = make_inputs(n_img, R, K, H, W, seed + 3, n_gt=2)
+        # force an exact tie for pgt mining: duplicate a proposal row (same box => same features => same score)
+        for b in batch:
+            b["image"] = b["image"][:, :H, :W] if b["image"].shape[1] >= H else b["image"]
+            b["proposal_boxes"][7] = b["proposal_boxes"][3]
+            b["objectness_logits"][7] = b["objectness_logits"][3]
+        rs = np.random.RandomState(seed + 9)
+        feat = rs.standard_normal((n_img, C, H // 8, W // 8)).astype(np.float32)
+        ins = to_ref_inputs(batch)
+        props = [x["proposals"] for x in ins]
+        tg = [x["instances"] for x in ins]
+
+        class _IL:
+            pass
+
+        d = {"seed": np.int64(seed), "feat": feat, "K": np.int64(K), "refine_reg": np.array(refine_reg)}
+        flat_batch(batch, d)
+        grads = {}
+        with EventStorage(), DropoutPatch(None):
+            logits_store = []
+            hooks = []
+            for k in range(3):
+                def mk(k):
+                    def hook(mod, inp, out):
+                        out[0].retain_grad()
+                        logits_store.append(out)
+                    return hook
+                hooks.append(refs[k].register_forward_hook(mk(k)))
+            wsc = []
+            def wsddn_hook(m, i, o):
+                o[0].retain_grad()
+                wsc.append(o[0])
+
+            hooks.append(pred.register_forward_hook(wsddn_hook))
+            _, losses = heads(None, {"f": torch.from_numpy(feat)}, props, tg)
+            total = sum(losses.values())
+            total.backward()
+        for k, v in losses.items():
+            d[k] = np.float64(v.item())
+        d["wsddn_scores"] = wsc[0].detach().numpy().copy()
+        d["wsddn_scores_grad"] = wsc[0].grad.numpy().copy()
+        for k in range(3):
+            d["logits_r%d" % k] = logits_store[k][0].detach().numpy().copy()
+            d["logits_r%d_grad" % k] = logits_store[k][0].grad.numpy().copy()
+            if refine_reg[k]:
+                d["deltas_r%d" % k] = logits_store[k][1].detach().numpy().copy()
+        d["img_scores"] = heads.pred_class_img_logits.numpy().copy()
+        for n, p in heads.named_parameters():
+            if p.grad is not None:
+                d["grad.roi_heads." + n] = p.grad.numpy().copy()
+            else:
+                d["gradnone.roi_heads." + n] = np.int64(1)
+        path = os.path.join(HERE, "%s_reg%d.npz" % (name, int(reg)))
+        np.savez_compressed(path, **d)
+        print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: float(v) for k, v in losses.items()})
+
+
+def case_ops(name, seed):
+    """Op-level vectors from reference code that needs no model: ROIAlign (compiled reference C++,
+    incl. tests/layers/test_roi_align.py ramp case), pairwise_iou, Matcher, Box2BoxTransform,
+    FrozenBatchNorm2d, fast_rcnn_inference_single_image, apply_deltas with zero deltas."""
+    from detectron2.layers import FrozenBatchNorm2d
+    from detectron2.layers.roi_align import ROIAlign
+    from detectron2.modeling.box_regression import Box2BoxTransform
+    from detectron2.modeling.matcher import Matcher
+    from detectron2.structures import pairwise_iou
+    from wsl.modeling.roi_heads.fast_rcnn import fast_rcnn_inference_single_image
+
+    rs = np.random.RandomState(seed)
+    d = {}
+    # ROIAlign ramp KAT (tests/layers/test_roi_align.py:13-45)
+    ramp = np.arange(25, dtype=np.float32).reshape(1, 1, 5, 5)
+    rois = np.array([[0, 1, 1, 3, 3]], dtype=np.float32)
+    for al in (False, True):
+        out = ROIAlign((4, 4), 1.0, 0, aligned=al)(torch.from_numpy(ramp), torch.from_numpy(rois))
+        d["ra_ramp_aligned%d" % int(al)] = out.numpy().copy()
+    # random ROIAlign cases fwd + bwd
+    feat = rs.standard_normal((2, 5, 13, 17)).astype(np.float32)
+    R = 24
+    x0 = rs.rand(R) * 100
+    y0 = rs.rand(R) * 70
+    rois = np.stack([rs.randint(0, 2, R).astype(np.float32), x0, y0, x0 + 2 + rs.rand(R) * 120, y0 + 2 + rs.rand(R) * 90],
+                    1).astype(np.float32)
+    rois[0, 1:] = [-20, -10, 400, 300]  # far outside the map
+    rois[1, 1:] = [30, 30, 30, 30]  # empty box
+    d["ra_feat"] = feat
+    d["ra_rois"] = rois
+    for al in (False, True):
+        for sr in (0, 2):
+            ft = torch.from_numpy(feat).clone().requires_grad_(True)
+            out = ROIAlign((7, 7), 0.125, sr, aligned=al)(ft, torch.from_numpy(rois))
+            gout = torch.from_numpy(rs.standard_normal(tuple(out.shape)).astype(np.float32))
+            out.backward(gout)
+            key = "ra_al%d_sr%d" % (int(al), sr)
+            d[key + "_out"] = out.detach().numpy().copy()
+            d[key + "_gout"] = gout.numpy().copy()
+            d[key + "_gin"] = ft.grad.numpy().copy()
+    # pairwise_iou / matcher
+    b1 = np.array([[0, 0, 10, 10], [5, 5, 20, 25], [30, 30, 31, 31], [0, 0, 0, 0]], dtype=np.float32)
+    x0 = rs.rand(50) * 30
+    y0 = rs.rand(50) * 30
+    b2 = np.stack([x0, y0, x0 + rs.rand(50) * 20, y0 + rs.rand(50) * 20], 1).astype(np.float32)
+    b2[0] = b1[0]
+    b2[1] = [100, 100, 110, 110]  # zero-IoU column
+    iou = pairwise_iou(Boxes(torch.from_numpy(b1)), Boxes(torch.from_numpy(b2)))
+    m, l = Matcher([0.5], [0, 1], False)(iou)
+    d.update(iou_b1=b1, iou_b2=b2, iou=iou.numpy().copy(), match_idx=m.numpy().copy(), match_label=l.numpy().copy())
+    # tests/modeling/test_matcher.py:14-28 golden (RPN thresholds, low-quality on) kept as a KAT of the argmax path
+    mq = torch.tensor([[0.15, 0.45, 0.2, 0.6], [0.3, 0.65, 0.05, 0.1], [0.05, 0.4, 0.25, 0.4]])
+    m2, l2 = Matcher([0.3, 0.7], [0, -1, 1], True)(mq)
+    d.update(mq=mq.numpy(), mq_idx=m2.numpy().copy(), mq_label=l2.numpy().copy())
+    # Box2BoxTransform
+    t = Box2BoxTransform((10.0, 10.0, 5.0, 5.0))
+    src = b2[:20].copy()
+    src[:, 2:] += 1.0
+    dst = b2[20:40].copy()
+    dst[:, 2:] += 1.0
+    deltas = t.get_deltas(torch.from_numpy(src), torch.from_numpy(dst))
+    d.update(b2b_src=src, b2b_dst=dst, b2b_deltas=deltas.numpy().copy())
+    dd = torch.from_numpy(rs.standard_normal((20, 12)).astype(np.float32) * 2)
+    dd[0, 2] = 50.0  # hits the scale clamp
+    d["b2b_apply_in"] = dd.numpy().copy()
+    d["b2b_apply_out"] = t.apply_deltas(dd, torch.from_numpy(src)).numpy().copy()
+    d["b2b_apply_zero"] = t.apply_deltas(torch.zeros(20, 8), torch.from_numpy(src)).numpy().copy()
+    # FrozenBN
+    bn = FrozenBatchNorm2d(5)
+    bn.load_state_dict({k: O.seeded_tensor("x.norm." + k, (5,), seed) for k in ("weight", "bias", "running_mean", "running_var")})
+    d["fbn_out"] = bn(torch.from_numpy(feat)).numpy().copy()
+    # inference tail incl. non-finite rows
+    R, K = 300, 6
+    x0 = rs.rand(R) * 150
+    y0 = rs.rand(R) * 100
+    pb = np.stack([x0, y0, x0 + 5 + rs.rand(R) * 80, y0 + 5 + rs.rand(R) * 60], 1).astype(np.float32)
+    boxes = np.tile(pb, (1, K)).astype(np.float32) + rs.standard_normal((R, 4 * K)).astype(np.float32)
+    sc = torch.softmax(torch.from_numpy(rs.standard_normal((R, K + 1)).astype(np.float32) * 3), 1).numpy()
+    sc[5, 2] = np.nan
+    boxes[9, 1] = np.inf
+    sc[20] = sc[21]  # tied scores
+    boxes[20] = boxes[21]
+    res, kept, _, _ = fast_rcnn_inference_single_image(torch.from_numpy(boxes.copy()), torch.from_numpy(sc.copy()),
+                                                       (120, 200), 1e-5, 0.3, 100)
+    d.update(inf_boxes=boxes, inf_scores=sc, inf_out_boxes=res.pred_boxes.tensor.numpy().copy(),
+             inf_out_scores=res.scores.numpy().copy(), inf_out_classes=res.pred_classes.numpy().copy(),
+             inf_out_rows=kept.numpy().copy())
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB")
+
+
+TINY_R50 = ["MODEL.RESNETS.STEM_OUT_CHANNELS", "8", "MODEL.RESNETS.RES2_OUT_CHANNELS", "32",
+            "MODEL.RESNETS.WIDTH_PER_GROUP", "8", "MODEL.ROI_BOX_HEAD.DAN_DIM", "[48, 64]",
+            "MODEL.ROI_HEADS.NUM_CLASSES", "5"]
+C4 = ["MODEL.RESNETS.OUT_FEATURES", "['res4']", "MODEL.ROI_HEADS.IN_FEATURES", "['res4']",
+      "MODEL.RESNETS.RES5_DILATION", "1"]
+
+if __name__ == "__main__":
+    torch.manual_seed(0)
+    torch.set_num_threads(8)
+    which = sys.argv[1:] or ["ops", "heads", "r50dc5", "r50c4", "r50c4_align", "r18", "vgg", "r50c4_drop", "r50c4_reg"]
+    if "ops" in which:
+        case_ops("ops", 11)
+    if "heads" in which:
+        case_heads_detail("heads", 21)
+    if "r50dc5" in which:
+        case_full_model("model_r50dc5_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50, 31, 2, 48, 96, 80)
+    if "r50c4" in which:
+        case_full_model("model_r50c4_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 32, 2, 48,
+                        128, 96)
+    if "r50c4_align" in which:
+        case_full_model("model_r50c4_align_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml",
+                        TINY_R50 + C4 + ["MODEL.ROI_BOX_HEAD.POOLER_TYPE", "ROIAlignV2", "MODEL.BACKBONE.FREEZE_AT", "3"],
+                        33, 1, 40, 128, 96)
+    if "r18" in which:
+        case_full_model("model_r18dc5_tiny", "PascalVOC-Detection/oicr_WSR_18_DC5_1x.yaml",
+                        ["MODEL.RESNETS.STEM_OUT_CHANNELS", "8", "MODEL.ROI_BOX_HEAD.DAN_DIM", "[48, 64]",
+                         "MODEL.ROI_HEADS.NUM_CLASSES", "5"], 34, 1, 40, 96, 96)
+    if "vgg" in which:
+        case_full_model("model_vgg16_small", "PascalVOC-Detection/oicr_V_16_DC5_1x.yaml",
+                        ["MODEL.ROI_BOX_HEAD.DAN_DIM", "[64, 64]", "MODEL.ROI_HEADS.NUM_CLASSES", "5"], 35, 1, 32, 64, 64)
+    if "r50c4_drop" in which:
+        case_full_model("model_r50c4_dropmask_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 36,
+                        1, 40, 96, 96, dropmask=True)
+    if "r50c4_reg" in which:
+        case_full_model("model_r50c4_reg_tiny", "PascalVOC-Detection/reg/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 37,
+                        1, 40, 96, 96)

@@ -1,0 +1,25 @@
+class Registry(object):
+    def __init__(self, name):
+        self._name = name
+        self._obj_map = {}
+
+    def _do_register(self, name, obj):
+        assert name not in self._obj_map, name
+        self._obj_map[name] = obj
+
+    def register(self, obj=None):
+        if obj is None:
+            def deco(fn):
+                self._do_register(fn.__name__, fn)
+                return fn
+            return deco
+        self._do_register(obj.__name__, obj)
+
+    def get(self, name):
+        ret = self._obj_map.get(name)
+        if ret is None:
+            raise KeyError("No object named '{}' found in '{}' registry!".format(name, self._name))
+        return ret
+
+    def __contains__(self, name):
+        return name in self._obj_map
