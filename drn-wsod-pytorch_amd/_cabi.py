@@ -1,0 +1,99 @@
+"""ctypes binding of include/drn_wsod.h (libdrn_wsod_hip.so).  There is NO fallback: if the HIP
+library is missing or a call fails, this raises — the product path never routes through a CPU or
+eager-PyTorch substitute."""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libdrn_wsod_hip.so")
+
+F32, BF16 = 0, 1
+
+_T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "Q": ctypes.c_ulonglong}
+
+# signature strings follow include/drn_wsod.h argument for argument
+_SIGS = {
+    "drn_preprocess_nhwc": "piiipiiippip",
+    "drn_conv2d_nhwc": "pppppp" + "iiiiiiiiii" + "lll" + "iip",
+    "drn_maxpool2x2_nhwc": "ppiiiiiip",
+    "drn_roi_pool_nhwc": "ppppp" + "iiiiii" + "f" + "l" + "iiiiip",
+    "drn_transpose2d": "ppiilliip",
+    "drn_gemm_nt": "pppiiillliilip",
+    "drn_bias_act_fwd": "pilppQfplpliiliip",
+    "drn_bias_act_bwd": "plpppfplplpiiiip",
+    "drn_cast2d": "ppiilliip",
+    "drn_wsddn_fwd_bwd": "pliiipippppplifp",
+    "drn_oicr_targets": "plpi" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",
+    "drn_softmax_ce": "pliipppplpifp",
+    "drn_mean_softmax": "plpiipip",
+    "drn_apply_deltas": "plppiipfp",
+    "drn_sum_small": "pifpp",
+    "drn_sgd_step": "ppppipififp",
+    "drn_detect_topk": "ppiii" + "ffff" + "i" + "pl" + "i" + "ppp",
+    "drn_detect_gather": "plippippppp",
+}
+
+_lib = None
+
+
+class DrnError(RuntimeError):
+    pass
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise DrnError(
+                "HIP library %s not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(there is no CPU fallback on the product path)" % LIB_PATH)
+        _lib = ctypes.CDLL(LIB_PATH)
+        for name, sig in _SIGS.items():
+            fn = getattr(_lib, name)
+            fn.argtypes = [_T[c] for c in sig]
+            fn.restype = ctypes.c_int
+        _lib.drn_detect_workspace_bytes.argtypes = [ctypes.c_int]
+        _lib.drn_detect_workspace_bytes.restype = ctypes.c_long
+    return _lib
+
+
+def exported_symbols():
+    return sorted(list(_SIGS) + ["drn_detect_workspace_bytes"])
+
+
+_ERR = {-1: "invalid argument", -2: "kernel launch failure", -3: "unsupported"}
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise DrnError("%s failed: %s (%d)" % (name, _ERR.get(rc, "error"), rc))
+
+
+def ptr(t):
+    if t is None:
+        return None
+    assert t.is_cuda, "drn ops need device tensors (no CPU path)"
+    return t.data_ptr()
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(dtype):
+    if dtype == torch.float32:
+        return F32
+    if dtype == torch.bfloat16:
+        return BF16
+    raise DrnError("unsupported dtype %s" % dtype)
+
+
+def host_floats(vals):
+    return (ctypes.c_float * len(vals))(*[float(v) for v in vals])
+
+
+def host_ints(vals):
+    return (ctypes.c_int * len(vals))(*[int(v) for v in vals])

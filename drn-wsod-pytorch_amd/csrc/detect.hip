@@ -1,0 +1,247 @@
+// Inference tail for gfx950: score threshold + compaction in row-major (nonzero) order, stable
+// descending sort, class-offset greedy NMS with early exit at top-k.  Indices must be bit-exact
+// vs the CPU path, so every float op follows the oracle's order (built with -ffp-contract=off).
+//
+// Replaces fast_rcnn_inference_single_image (projects/WSL/wsl/modeling/roi_heads/fast_rcnn.py:88-141)
+// and batched_nms (detectron2/layers/nms.py:10-29 over torchvision nms / batched_nms).
+//
+// Design: the reference sorts and suppresses ALL candidates (up to R*K = 40k-320k) and then keeps
+// keep[:100].  Greedy NMS is order-causal: whether candidate i survives depends only on survivors
+// before it, so we walk the sorted list 64 candidates (one wave) at a time against the <= topk
+// survivors held in LDS and stop as soon as topk are kept - identical output, O(n*topk) work.
+#include "drn_common.h"
+#include <hipcub/hipcub.hpp>
+
+namespace {
+
+struct CandParams {
+  const float* boxes;   // [R][4*nreg]
+  const float* scores;  // [R][K+1]
+  int R, K, nreg;
+  float img_h, img_w, thresh;
+  float* c_box;   // [cap][4] clipped boxes
+  float* c_score; // [cap]
+  int* c_row; int* c_cls;  // [cap]
+  int* count;     // [1]
+  float* maxcoord;  // [1] max over candidate box coordinates
+  int cap;
+};
+
+// single block; ordered compaction via wave ballots + block prefix over 1024-element chunks
+__global__ __launch_bounds__(1024) void candidates_kernel(CandParams p) {
+  __shared__ int wcnt[16];
+  __shared__ int base;
+  __shared__ float wmax[16];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  float mymax = -INFINITY;
+  __syncthreads();
+  const long total = (long)p.R * p.K;
+  for (long start = 0; start < total; start += 1024) {
+    const long i = start + threadIdx.x;
+    bool flag = false;
+    int r = 0, c = 0;
+    float s = 0.f;
+    if (i < total) {
+      r = i / p.K; c = i - (long)r * p.K;
+      // finite-row filter (fast_rcnn.py:108-111): rows with any non-finite box or score are dropped
+      bool finite = true;
+      const float* srow = p.scores + (long)r * (p.K + 1);
+      for (int k = 0; k <= p.K && finite; ++k) finite = isfinite(srow[k]);
+      const float* brow = p.boxes + (long)r * 4 * p.nreg;
+      for (int k = 0; k < 4 * p.nreg && finite; ++k) finite = isfinite(brow[k]);
+      s = srow[c];
+      flag = finite && s > p.thresh;
+    }
+    const unsigned long long bal = __ballot(flag);
+    const int wprefix = __popcll(bal & ((1ULL << lane) - 1ULL));
+    if (lane == 0) wcnt[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0;
+    for (int q = 0; q < w; ++q) woff += wcnt[q];
+    int tot = 0;
+    for (int q = 0; q < 16; ++q) tot += wcnt[q];
+    const int pos = base + woff + wprefix;
+    if (flag && pos < p.cap) {
+      const float* b = p.boxes + (long)r * 4 * p.nreg + (p.nreg == 1 ? 0 : 4 * c);
+      const float x1 = fminf(fmaxf(b[0], 0.f), p.img_w), y1 = fminf(fmaxf(b[1], 0.f), p.img_h);
+      const float x2 = fminf(fmaxf(b[2], 0.f), p.img_w), y2 = fminf(fmaxf(b[3], 0.f), p.img_h);
+      p.c_box[4 * (long)pos] = x1; p.c_box[4 * (long)pos + 1] = y1; p.c_box[4 * (long)pos + 2] = x2; p.c_box[4 * (long)pos + 3] = y2;
+      p.c_score[pos] = s; p.c_row[pos] = r; p.c_cls[pos] = c;
+      mymax = fmaxf(mymax, fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) base += tot;
+    __syncthreads();
+  }
+  mymax = wave_max(mymax);
+  if (lane == 0) wmax[w] = mymax;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float m = -INFINITY;
+    for (int q = 0; q < 16; ++q) m = fmaxf(m, wmax[q]);
+    p.maxcoord[0] = m;
+    p.count[0] = base < p.cap ? base : p.cap;
+  }
+}
+
+__global__ void iota_kernel(int* v, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) v[i] = i;
+}
+
+struct NmsParams {
+  const float* c_box; const float* c_score; const int* c_cls;
+  const int* order;  // candidate ids sorted by descending score (stable)
+  const int* count; const float* maxcoord;
+  float thr; int topk; int per_class_from;
+  int* keep;       // [topk] candidate ids
+  int* n_keep;     // [1]
+};
+
+constexpr int NMS_MAXK = 1024;
+
+// one wave per image
+__global__ __launch_bounds__(64) void nms_topk_kernel(NmsParams p) {
+  __shared__ float kb[NMS_MAXK][4];
+  __shared__ float ka[NMS_MAXK];
+  __shared__ int kc[NMS_MAXK];
+  const int lane = threadIdx.x;
+  const int n = p.count[0];
+  // detectron2/layers/nms.py:19-29: >= 40000 boxes => per-class NMS on the raw boxes, no offsets
+  const bool per_class = n >= p.per_class_from;
+  const float offs = per_class ? 0.f : p.maxcoord[0] + 1.f;
+  int nk = 0;
+  for (int start = 0; start < n && nk < p.topk; start += 64) {
+    const int i = start + lane;
+    const bool valid = i < n;
+    float x1 = 0, y1 = 0, x2 = 0, y2 = 0, area = 0;
+    int id = -1, cls = -1;
+    bool alive = valid;
+    if (valid) {
+      id = p.order[i];
+      cls = p.c_cls[id];
+      const float off = (float)cls * offs;  // idxs.to(boxes) * (boxes.max() + 1)
+      x1 = p.c_box[4 * (long)id] + off; y1 = p.c_box[4 * (long)id + 1] + off;
+      x2 = p.c_box[4 * (long)id + 2] + off; y2 = p.c_box[4 * (long)id + 3] + off;
+      area = (x2 - x1) * (y2 - y1);
+      for (int k = 0; k < nk && alive; ++k) {
+        if (per_class && kc[k] != cls) continue;
+        const float w = fmaxf(0.f, fminf(kb[k][2], x2) - fmaxf(kb[k][0], x1));
+        const float h = fmaxf(0.f, fminf(kb[k][3], y2) - fmaxf(kb[k][1], y1));
+        const float inter = w * h;
+        if (inter / (ka[k] + area - inter) > p.thr) alive = false;
+      }
+    }
+    // resolve the chunk in order: the lowest alive lane is kept and suppresses later lanes
+    unsigned long long pending = __ballot(alive);
+    while (pending && nk < p.topk) {
+      const int l = __ffsll((long long)pending) - 1;
+      const float bx1 = __shfl(x1, l, 64), by1 = __shfl(y1, l, 64), bx2 = __shfl(x2, l, 64), by2 = __shfl(y2, l, 64);
+      const float ba = __shfl(area, l, 64);
+      const int bid = __shfl(id, l, 64);
+      const int bcls = __shfl(cls, l, 64);
+      if (lane == 0) { kc[nk] = bcls; kb[nk][0] = bx1; kb[nk][1] = by1; kb[nk][2] = bx2; kb[nk][3] = by2; ka[nk] = ba; p.keep[nk] = bid; }
+      ++nk;
+      if (alive && lane > l && (!per_class || bcls == cls)) {
+        const float w = fmaxf(0.f, fminf(bx2, x2) - fmaxf(bx1, x1));
+        const float h = fmaxf(0.f, fminf(by2, y2) - fmaxf(by1, y1));
+        const float inter = w * h;
+        if (inter / (ba + area - inter) > p.thr) alive = false;
+      }
+      if (lane == l) alive = false;
+      pending = __ballot(alive);
+    }
+    __syncthreads();
+  }
+  if (lane == 0) p.n_keep[0] = nk;
+}
+
+}  // namespace
+
+namespace {
+
+__global__ void fill_tail_kernel(float* c_score, const int* count, int cap) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < cap && i >= count[0]) c_score[i] = -INFINITY;  // unused slots sort last
+}
+
+__global__ void gather_kernel(const float* c_box, const float* c_score, const int* c_row, const int* c_cls,
+                              const int* keep, const int* n_keep, float* ob, float* os, int* oc, int* orow) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_keep[0]) return;
+  const int id = keep[i];
+  for (int e = 0; e < 4; ++e) ob[4 * i + e] = c_box[4 * (long)id + e];
+  os[i] = c_score[id]; oc[i] = c_cls[id]; orow[i] = c_row[id];
+}
+
+struct Ws {
+  float* c_box; float* c_score; float* s_score; int* c_row; int* c_cls; int* iota; int* order; int* count;
+  float* maxcoord; char* cub; size_t cub_bytes;
+};
+
+inline long ws_fixed_bytes(int cap) { return (long)cap * (16 + 4 * 6) + 256; }
+
+inline Ws carve(void* workspace, long bytes, int cap) {
+  Ws k;
+  char* w = (char*)workspace;
+  k.c_box = (float*)w; w += (long)cap * 16;
+  k.c_score = (float*)w; w += (long)cap * 4;
+  k.s_score = (float*)w; w += (long)cap * 4;
+  k.c_row = (int*)w; w += (long)cap * 4;
+  k.c_cls = (int*)w; w += (long)cap * 4;
+  k.iota = (int*)w; w += (long)cap * 4;
+  k.order = (int*)w; w += (long)cap * 4;
+  k.count = (int*)w; k.maxcoord = (float*)(w + 8); w += 256;
+  k.cub = w; k.cub_bytes = (size_t)(bytes - ws_fixed_bytes(cap));
+  return k;
+}
+
+}  // namespace
+
+extern "C" {
+
+// bytes of scratch drn_detect_topk needs for up to `cap` candidates (cap = R*K is always enough)
+long drn_detect_workspace_bytes(int cap) {
+  size_t tmp = 0;
+  float* kf = nullptr; int* vi = nullptr;
+  (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, kf, kf, vi, vi, cap);
+  return ws_fixed_bytes(cap) + (long)tmp + 256;
+}
+
+// Single image.  boxes [R][4*nreg], scores [R][K+1] (last column = background).  Leaves the kept
+// candidate ids (descending score) in keep_ids[0..n_keep) on the device; drn_detect_gather expands them.
+int drn_detect_topk(const float* boxes, const float* scores, int R, int K, int nreg, float img_h, float img_w,
+                    float score_thresh, float nms_thresh, int topk, void* workspace, long workspace_bytes, int cap,
+                    int* keep_ids, int* n_keep, void* stream) {
+  if (!boxes || !scores || !workspace || !keep_ids || !n_keep || topk < 1 || topk > NMS_MAXK || cap < 1 || R < 0)
+    return DRN_ERR_ARG;
+  if (nreg != 1 && nreg != K) return DRN_ERR_ARG;
+  if (workspace_bytes < drn_detect_workspace_bytes(cap)) return DRN_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  Ws k = carve(workspace, workspace_bytes, cap);
+  CandParams cp{boxes, scores, R, K, nreg, img_h, img_w, score_thresh, k.c_box, k.c_score, k.c_row, k.c_cls, k.count,
+                k.maxcoord, cap};
+  hipLaunchKernelGGL(candidates_kernel, dim3(1), dim3(1024), 0, st, cp);
+  hipLaunchKernelGGL(iota_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, k.iota, cap);
+  hipLaunchKernelGGL(fill_tail_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, k.c_score, k.count, cap);
+  if (hipcub::DeviceRadixSort::SortPairsDescending((void*)k.cub, k.cub_bytes, k.c_score, k.s_score, k.iota, k.order,
+                                                   cap, 0, 32, st) != hipSuccess)
+    return DRN_ERR_LAUNCH;
+  NmsParams np{k.c_box, k.c_score, k.c_cls, k.order, k.count, k.maxcoord, nms_thresh, topk, 40000, keep_ids, n_keep};
+  hipLaunchKernelGGL(nms_topk_kernel, dim3(1), dim3(64), 0, st, np);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_detect_gather(const void* workspace, long workspace_bytes, int cap, const int* keep_ids, const int* n_keep,
+                      int topk, float* out_boxes, float* out_scores, int* out_classes, int* out_rows, void* stream) {
+  if (!workspace || !keep_ids || !n_keep || !out_boxes || !out_scores || !out_classes || !out_rows) return DRN_ERR_ARG;
+  Ws k = carve((void*)workspace, workspace_bytes, cap);
+  hipLaunchKernelGGL(gather_kernel, dim3((topk + 63) / 64), dim3(64), 0, (hipStream_t)stream, k.c_box, k.c_score,
+                     k.c_row, k.c_cls, keep_ids, n_keep, out_boxes, out_scores, out_classes, out_rows);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,69 @@
+// Common device/host helpers for the DRN-WSOD gfx950 kernels (CDNA4 only; wave = 64).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define DRN_OK 0
+#define DRN_ERR_ARG (-1)
+#define DRN_ERR_LAUNCH (-2)
+#define DRN_ERR_UNSUPPORTED (-3)
+
+#define DRN_F32 0
+#define DRN_BF16 1
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(4))) float f32x4_t;
+typedef __attribute__((ext_vector_type(4))) int i32x4_t;
+typedef unsigned short bf16_t;  // storage type
+
+#define DRN_CHECK_LAUNCH()                                  \
+  do {                                                      \
+    hipError_t e__ = hipGetLastError();                     \
+    if (e__ != hipSuccess) return DRN_ERR_LAUNCH;           \
+  } while (0)
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t v) {
+  return __builtin_bit_cast(float, (uint32_t)v << 16);
+}
+// round-to-nearest-even, NaN preserved (same as torch's float->bfloat16)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  uint32_t u = __builtin_bit_cast(uint32_t, f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <int DT> struct ElemOf;
+template <> struct ElemOf<DRN_F32> {
+  using type = float;
+  static __device__ __forceinline__ float ld(const float* p) { return *p; }
+  static __device__ __forceinline__ void st(float* p, float v) { *p = v; }
+};
+template <> struct ElemOf<DRN_BF16> {
+  using type = bf16_t;
+  static __device__ __forceinline__ float ld(const bf16_t* p) { return bf16_to_f32(*p); }
+  static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
+};
+
+static inline int drn_esize(int dtype) { return dtype == DRN_BF16 ? 2 : 4; }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// XCD-aware bijective remap of a linear workgroup id: the dispatcher places block b on XCD b % 8;
+// give every XCD a contiguous chunk of the logical id space (speed only, never correctness).
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, idx = bid >> 3;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + idx;
+}

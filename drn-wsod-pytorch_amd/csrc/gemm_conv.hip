@@ -1,0 +1,354 @@
+// MFMA GEMM (NT) and implicit-GEMM NHWC convolution for gfx950.
+//
+// One mainloop serves both and both compute dtypes:
+//   * bf16 : v_mfma_f32_32x32x16_bf16, fp32 accumulate  (fast mode; BASELINE configs[1])
+//   * fp32 : v_mfma_f32_32x32x2_f32 (exact fp32 fma chain; parity mode, losses within 1e-4)
+// Tile BMxBN outputs, K consumed in 128-BYTE slabs per row (64 bf16 / 32 f32), so the LDS image
+// and the global->LDS staging are byte-identical for both dtypes; only the MFMA issue differs.
+// 256 threads = 4 waves (2x2), each wave owns (BM/2)x(BN/2) as 32x32 MFMA tiles.
+// Staging: 16-B buffer loads (hardware bounds check => free zero fill of ragged M/N edges) into
+// registers, issued one K-slab ahead, written to a 2-stage XOR-swizzled LDS ring after the MFMAs
+// (issue-early / write-late), one barrier per slab. ds_read_b128 is conflict-free under the
+// swizzle slot ^= (row>>1)&7 (rows are 128 B, a 256-B bank row holds two).
+//
+// Replaces on the reference path: F.linear of fc6/fc7 and the predictor Linears
+// (projects/WSL/wsl/modeling/roi_heads/box_head.py:82-91, fast_rcnn.py:493-527, :1363-1387) and
+// F.conv2d + FrozenBatchNorm2d + relu_ + residual add (detectron2/layers/wrappers.py:94-99,
+// detectron2/layers/batch_norm.py:45-65, projects/WSL/wsl/modeling/backbone/resnet_ws.py:217-237).
+#include "drn_common.h"
+
+namespace {
+
+struct GemmParams {
+  const char* A;
+  const char* B;
+  float* C;
+  int M, N, K;
+  long lda, ldb, ldc;  // elements
+  int k_slabs_per_split;
+  long c_split_stride;  // elements
+  int accumulate;
+};
+
+struct ConvParams {
+  const char* X;
+  const char* Wt;   // [Cout][ldw] K-major, k = (kh*KW + kw)*Cin + ci
+  char* Y;          // [Nb*Ho*Wo][ldy]
+  const float* scale;  // per Cout (FrozenBN folded) or null => 1
+  const float* bias;   // per Cout or null => 0
+  const char* residual;  // same layout as Y, or null
+  int Nb, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, relu;
+  int Ktot;  // KH*KW*Cin
+  long ldw, ldy, ldres;
+};
+
+template <int DT>
+__device__ __forceinline__ void mma_step(f32x16_t& acc, const i32x4_t& a, const i32x4_t& b) {
+  if constexpr (DT == DRN_BF16) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
+                                                  acc, 0, 0, 0);
+  } else {
+    const f32x4_t af = __builtin_bit_cast(f32x4_t, a), bf = __builtin_bit_cast(f32x4_t, b);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
+  }
+}
+
+__device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
+
+template <int ROWS>
+__device__ __forceinline__ void lds_store_tile(char* lds, const i32x4_t (&r)[ROWS / 32], int tid) {
+  const int slot = tid & 7, r0 = tid >> 3;
+#pragma unroll
+  for (int p = 0; p < ROWS / 32; ++p) *(i32x4_t*)(lds + swz(r0 + 32 * p, slot)) = r[p];
+}
+
+// Plain row-major operand [rows][ld] read through a bounds-checked buffer descriptor.
+struct RowLoader {
+  __amdgpu_buffer_rsrc_t rsrc;
+  unsigned ld_bytes;
+  template <int ROWS>
+  __device__ __forceinline__ void load(i32x4_t (&r)[ROWS / 32], int slab, int tid) const {
+    const unsigned slot = tid & 7, r0 = tid >> 3;
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p)
+      r[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (r0 + 32 * p) * ld_bytes + slot * 16, slab * 128, 0);
+  }
+};
+
+__device__ __forceinline__ RowLoader make_row_loader(const char* base, long row0, int rows_total, int rows_tile,
+                                                     long ld_bytes) {
+  RowLoader l;
+  long rem = (long)rows_total - row0;
+  if (rem > rows_tile) rem = rows_tile;
+  if (rem < 0) rem = 0;
+  l.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(base + row0 * ld_bytes), 0, (unsigned)(rem * ld_bytes), 0x00020000);
+  l.ld_bytes = (unsigned)ld_bytes;
+  return l;
+}
+
+// im2col-on-the-fly operand of an NHWC convolution: row = output pixel, k = (kh, kw, ci).
+template <int DT, int ROWS>
+struct ConvLoader {
+  static constexpr int ES = DT == DRN_BF16 ? 2 : 4;
+  const char* x;
+  int H, W, Cin, KW, dil, ntaps;
+  int hi0[ROWS / 32], wi0[ROWS / 32];
+  long nbase[ROWS / 32];  // byte offset of image n, or -1 for rows beyond M
+  template <int R>
+  __device__ __forceinline__ void load(i32x4_t (&r)[R / 32], int slab, int tid) const {
+    static_assert(R == ROWS, "tile rows");
+    const int slot = tid & 7;
+    const int k = (slab * 128 + slot * 16) / ES;
+    const int tap = k / Cin, ci = k - tap * Cin;
+    const int kh = tap / KW, kw = tap - kh * KW;
+#pragma unroll
+    for (int p = 0; p < ROWS / 32; ++p) {
+      const int hi = hi0[p] + kh * dil, wi = wi0[p] + kw * dil;
+      i32x4_t v = {0, 0, 0, 0};
+      if (nbase[p] >= 0 && tap < ntaps && hi >= 0 && hi < H && wi >= 0 && wi < W)
+        v = *(const i32x4_t*)(x + nbase[p] + ((long)(hi * W + wi) * Cin + ci) * ES);
+      r[p] = v;
+    }
+  }
+};
+
+template <int DT, int BM, int BN, class ALoader, class BLoader>
+__device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char* smem, const ALoader& la,
+                                         const BLoader& lb, int s0, int s1) {
+  constexpr int MI = BM / 64, NJ = BN / 64;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  i32x4_t ra[BM / 32], rb[BN / 32];
+  if (s0 >= s1) return;
+  la.template load<BM>(ra, s0, tid);
+  lb.template load<BN>(rb, s0, tid);
+  lds_store_tile<BM>(smem, ra, tid);
+  lds_store_tile<BN>(smem + A_BYTES, rb, tid);
+  __syncthreads();
+  for (int s = s0; s < s1; ++s) {
+    char* cur = smem + ((s - s0) & 1) * STAGE;
+    char* nxt = smem + (((s - s0) & 1) ^ 1) * STAGE;
+    const bool more = s + 1 < s1;
+    if (more) {
+      la.template load<BM>(ra, s + 1, tid);
+      lb.template load<BN>(rb, s + 1, tid);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      i32x4_t fa[MI], fb[NJ];
+      const int slot = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int i = 0; i < MI; ++i) fa[i] = *(const i32x4_t*)(cur + swz(wm * (BM / 2) + i * 32 + (lane & 31), slot));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        fb[j] = *(const i32x4_t*)(cur + A_BYTES + swz(wn * (BN / 2) + j * 32 + (lane & 31), slot));
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[i][j], fa[i], fb[j]);
+    }
+    if (more) {
+      lds_store_tile<BM>(nxt, ra, tid);
+      lds_store_tile<BN>(nxt + A_BYTES, rb, tid);
+    }
+    __syncthreads();
+  }
+}
+
+// logical tile id -> (tm, tn), grouped so that a contiguous id range (one XCD's share) covers a
+// compact 2-D patch of tiles and re-reads its operand panels from that XCD's L2.
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
+  constexpr int GM = 4;
+  const int group_sz = GM * tiles_n;
+  const int g = id / group_sz, in_g = id - g * group_sz;
+  const int first_m = g * GM;
+  const int gm = tiles_m - first_m < GM ? tiles_m - first_m : GM;
+  tm = first_m + in_g % gm;
+  tn = in_g / gm;
+}
+
+template <int DT, int BM, int BN>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = DT == DRN_BF16 ? 2 : 4;
+  constexpr int MI = BM / 64, NJ = BN / 64;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+  const int bm = tm * BM, bn = tn * BN;
+  const int split = blockIdx.y;
+  const int nslab = p.K * ES / 128;
+  const int s0 = split * p.k_slabs_per_split;
+  const int s1 = s0 + p.k_slabs_per_split < nslab ? s0 + p.k_slabs_per_split : nslab;
+  const RowLoader la = make_row_loader(p.A, bm, p.M, BM, p.lda * ES);
+  const RowLoader lb = make_row_loader(p.B, bn, p.N, BN, p.ldb * ES);
+  f32x16_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  mainloop<DT, BM, BN>(acc, smem, la, lb, s0, s1);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  float* C = p.C + (long)split * p.c_split_stride;
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int n = bn + wn * (BN / 2) + j * 32 + (lane & 31);
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < p.M && n < p.N) {
+          float* dst = C + (long)m * p.ldc + n;
+          *dst = p.accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
+        }
+      }
+    }
+}
+
+template <int DT, int BM, int BN>
+__global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = DT == DRN_BF16 ? 2 : 4;
+  constexpr int MI = BM / 64, NJ = BN / 64;
+  using E = ElemOf<DT>;
+  using T = typename E::type;
+  const int Mtot = p.Nb * p.Ho * p.Wo;
+  const int tiles_m = (Mtot + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+  const int bm = tm * BM, bn = tn * BN;
+  ConvLoader<DT, BM> la;
+  la.x = p.X; la.H = p.H; la.W = p.W; la.Cin = p.Cin; la.KW = p.KW; la.dil = p.dil; la.ntaps = p.KH * p.KW;
+  const int r0 = threadIdx.x >> 3;
+#pragma unroll
+  for (int q = 0; q < BM / 32; ++q) {
+    const int m = bm + r0 + 32 * q;
+    if (m < Mtot) {
+      const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      la.hi0[q] = ho * p.stride - p.pad;
+      la.wi0[q] = wo * p.stride - p.pad;
+      la.nbase[q] = (long)n * p.H * p.W * p.Cin * ES;
+    } else {
+      la.hi0[q] = 0; la.wi0[q] = 0; la.nbase[q] = -1;
+    }
+  }
+  const RowLoader lb = make_row_loader(p.Wt, bn, p.Cout, BN, p.ldw * ES);
+  f32x16_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nslab = (p.Ktot * ES + 127) / 128;
+  mainloop<DT, BM, BN>(acc, smem, la, lb, 0, nslab);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    const int n = bn + wn * (BN / 2) + j * 32 + (lane & 31);
+    if (n >= p.Cout) continue;
+    const float sc = p.scale ? p.scale[n] : 1.f;
+    const float bi = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int m = bm + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+        if (m < Mtot) {
+          float v = acc[i][j][r] * sc + bi;
+          if (p.residual) v += E::ld((const T*)p.residual + (long)m * p.ldres + n);
+          if (p.relu) v = fmaxf(v, 0.f);
+          E::st((T*)p.Y + (long)m * p.ldy + n, v);
+        }
+      }
+  }
+}
+
+template <int DT, int BM, int BN>
+int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
+  const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto k = gemm_nt_kernel<DT, BM, BN>;
+  static bool attr = false;
+  if (!attr && smem > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DRN_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(256), smem, st, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+template <int DT, int BM, int BN>
+int launch_conv(const ConvParams& p, hipStream_t st) {
+  const int Mtot = p.Nb * p.Ho * p.Wo;
+  const int tiles = ((Mtot + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
+  constexpr int smem = 2 * (BM + BN) * 128;
+  auto k = conv_nhwc_kernel<DT, BM, BN>;
+  static bool attr = false;
+  if (!attr && smem > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DRN_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, st, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// C[split][M,N] (fp32) = A[M,K] * B[N,K]^T over this split's K range.  See include/drn_wsod.h.
+int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
+                int splits, long c_split_stride, int accumulate, void* stream) {
+  if (!A || !B || !C || M < 0 || N < 0 || K < 0) return DRN_ERR_ARG;
+  if (M == 0 || N == 0) return DRN_OK;
+  const int es = drn_esize(dtype);
+  if (dtype != DRN_F32 && dtype != DRN_BF16) return DRN_ERR_ARG;
+  if ((K * es) % 128 != 0 || (lda * es) % 16 != 0 || (ldb * es) % 16 != 0 || lda < K || ldb < K) return DRN_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)B) & 15) return DRN_ERR_ARG;
+  if (splits < 1) return DRN_ERR_ARG;
+  if (splits > 1 && accumulate) return DRN_ERR_ARG;
+  const int nslab = K * es / 128;
+  GemmParams p{(const char*)A, (const char*)B, C, M, N, K, lda, ldb, ldc, (nslab + splits - 1) / splits,
+               c_split_stride, accumulate};
+  hipStream_t st = (hipStream_t)stream;
+  const bool small = (long)((M + 127) / 128) * ((N + 127) / 128) * splits < 128;
+  if (dtype == DRN_BF16) return small ? launch_gemm<DRN_BF16, 64, 64>(p, splits, st) : launch_gemm<DRN_BF16, 128, 128>(p, splits, st);
+  return small ? launch_gemm<DRN_F32, 64, 64>(p, splits, st) : launch_gemm<DRN_F32, 128, 128>(p, splits, st);
+}
+
+// NHWC conv + per-channel affine (folded FrozenBN or bias) + optional residual + optional ReLU.
+int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                    const void* residual, int Nb, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                    int pad, int dil, long ldw, long ldy, long ldres, int relu, int dtype, void* stream) {
+  if (!x || !w || !y) return DRN_ERR_ARG;
+  if (dtype != DRN_F32 && dtype != DRN_BF16) return DRN_ERR_ARG;
+  const int es = drn_esize(dtype);
+  if ((Cin * es) % 16 != 0 || (ldw * es) % 16 != 0) return DRN_ERR_ARG;  // 16-B chunks never straddle taps
+  const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  const int Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  if (Ho <= 0 || Wo <= 0 || Nb <= 0) return DRN_ERR_ARG;
+  const int Ktot = KH * KW * Cin;
+  if (ldw * es < ((Ktot * es + 127) / 128) * 128) return DRN_ERR_ARG;  // weight rows zero-padded to 128-B slabs
+  ConvParams p{(const char*)x, (const char*)w, (char*)y, scale, bias, (const char*)residual, Nb, H, W, Cin, Ho, Wo,
+               Cout, KH, KW, stride, pad, dil, relu, Ktot, ldw, ldy, ldres};
+  hipStream_t st = (hipStream_t)stream;
+  const long Mtot = (long)Nb * Ho * Wo;
+  const bool small = ((Mtot + 127) / 128) * ((Cout + 127) / 128) < 128;
+  if (dtype == DRN_BF16) return small ? launch_conv<DRN_BF16, 64, 64>(p, st) : launch_conv<DRN_BF16, 128, 128>(p, st);
+  return small ? launch_conv<DRN_F32, 64, 64>(p, st) : launch_conv<DRN_F32, 128, 128>(p, st);
+}
+
+}  // extern "C"

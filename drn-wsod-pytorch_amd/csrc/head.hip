@@ -1,0 +1,533 @@
+// MIL / OICR head kernels for gfx950 (latency-bound, fp32 arithmetic, deterministic reductions:
+// fixed-order LDS trees, no float atomics).  Built with -ffp-contract=off.
+//
+// Replaces (reference file:line):
+//   bias_act_fwd/bwd   relu_(fc(x)) + dropout and its autograd   box_head.py:82-91
+//   wsddn_fwd_bwd      WSDDNOutputLayers.forward + predict_probs_img + BCE   fast_rcnn.py:493-527,
+//                      :317-343, and the autograd of that chain (clamp gradient = 0 outside (1e-6,1-1e-6))
+//   oicr_targets       get_pgt (roi_heads_oicr.py:491-567) + label_and_sample_proposals
+//                      (roi_heads.py:255-353: pairwise_iou boxes.py:329-361, Matcher matcher.py:61-103)
+//   softmax_ce         OICROutputs.softmax_cross_entropy_loss fast_rcnn.py:1087-1096,1128-1144,
+//                      predict_probs :1561-1575 and its backward
+//   apply_deltas       Box2BoxTransform.apply_deltas box_regression.py:73-110
+//   sgd_step           torch.optim.SGD as built by detectron2/solver/build.py:93-137
+#include "drn_common.h"
+#include <float.h>
+
+namespace {
+
+// ---------------------------------------------------------------- counter-based dropout mask
+__device__ __forceinline__ uint32_t hash32(uint64_t x) {
+  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+  return (uint32_t)x;
+}
+__device__ __forceinline__ float drop_mult(uint64_t seed, uint64_t idx, float p) {
+  const float u = (hash32(seed * 0x9E3779B97F4A7C15ULL + idx) >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : 1.f / (1.f - p);
+}
+
+struct ActParams {
+  const float* in;     // fwd: split-K partials [splits][M][ld_in]; bwd: upstream grad [M][ld_in]
+  int splits; long split_stride;
+  const float* bias;   // fwd: [N] or null
+  const float* mask;   // explicit dropout multipliers [M][N] or null
+  unsigned long long seed; float drop_p;  // used when mask == null and drop_p > 0
+  const char* saved;   // bwd: forward output [M][ld_out] (post relu+dropout) or null (no activation)
+  char* out; long ld_out;     // [M][ld_out] in out_dtype
+  char* outT; long ld_outT;   // [N][ld_outT] in out_dtype or null
+  float* colsum;       // bwd: [N] column sums (bias gradient) or null
+  const float* colscale;  // bwd: [N] per-column multiplier of grad_out (per-loss upstream grads) or null
+  int M, N; long ld_in; int relu; int accumulate_colsum;
+};
+
+// 64x64 tile per block; fwd: grid (N/64, M/64); bwd: grid (N/64, 1) looping over all rows so the
+// column sums come out of one block in a fixed order.
+template <int DT_OUT, int DT_SAVED, bool BWD>
+__global__ __launch_bounds__(256) void act_kernel(ActParams p) {
+  using EO = ElemOf<DT_OUT>;
+  using TO = typename EO::type;
+  using ES = ElemOf<DT_SAVED>;
+  __shared__ float t[64][65];
+  __shared__ float cs[4][64];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + tx;
+  const int mb0 = BWD ? 0 : blockIdx.y * 64;
+  const int mb1 = BWD ? p.M : min(mb0 + 64, p.M);
+  float csum = 0.f;
+  for (int mb = mb0; mb < mb1; mb += 64) {
+    for (int i = ty; i < 64; i += 4) {
+      const int m = mb + i;
+      float v = 0.f;
+      if (m < p.M && n < p.N) {
+        if (!BWD) {
+          for (int s = 0; s < p.splits; ++s) v += p.in[(long)s * p.split_stride + (long)m * p.ld_in + n];
+          if (p.bias) v += p.bias[n];
+          if (p.relu) v = fmaxf(v, 0.f);
+          if (p.mask) v *= p.mask[(long)m * p.N + n];
+          else if (p.drop_p > 0.f) v *= drop_mult(p.seed, (uint64_t)m * p.N + n, p.drop_p);
+        } else {
+          v = p.in[(long)m * p.ld_in + n];
+          if (p.colscale) v *= p.colscale[n];
+          if (p.saved) {
+            const float o = ES::ld((const typename ES::type*)p.saved + (long)m * p.ld_out + n);
+            float mult = o > 0.f ? 1.f : 0.f;
+            if (o > 0.f) {
+              if (p.mask) mult = p.mask[(long)m * p.N + n];
+              else if (p.drop_p > 0.f) mult = 1.f / (1.f - p.drop_p);
+            }
+            v *= mult;
+          }
+          csum += v;
+        }
+        if (p.out) EO::st((TO*)p.out + (long)m * p.ld_out + n, v);
+      }
+      t[i][tx] = v;
+    }
+    if (p.outT) {
+      __syncthreads();
+      for (int i = ty; i < 64; i += 4) {
+        const int nn = blockIdx.x * 64 + i, m = mb + tx;
+        if (nn < p.N && m < p.M) EO::st((TO*)p.outT + (long)nn * p.ld_outT + m, t[tx][i]);
+      }
+      __syncthreads();
+    }
+  }
+  if (BWD && p.colsum) {
+    cs[ty][tx] = csum;
+    __syncthreads();
+    if (ty == 0 && n < p.N) {
+      const float s = ((cs[0][tx] + cs[1][tx]) + cs[2][tx]) + cs[3][tx];
+      p.colsum[n] = p.accumulate_colsum ? p.colsum[n] + s : s;
+    }
+  }
+}
+
+// ---------------------------------------------------------------- block reductions (1024 threads)
+__device__ __forceinline__ float block_sum_1024(float v, float* sh) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  __syncthreads();
+  if (lane == 0) sh[w] = v;
+  __syncthreads();
+  float r = 0.f;
+  const int nw = blockDim.x >> 6;
+  for (int i = 0; i < nw; ++i) r += sh[i];
+  return r;
+}
+
+struct WsddnParams {
+  const float* logits; long ld;   // [M][ld]; cls at col c_cls, det at col c_det
+  int c_cls, c_det, K;
+  const int* img_off;              // [n_img+1] row offsets
+  const float* gt_onehot;          // [n_img][K]
+  float* scores;                   // [M][K]
+  float* img_scores;               // [n_img][K] clamped
+  float* loss_part;                // [n_img]
+  float* dlogits; long ld_d;       // [M][ld_d] (same column offsets) or null
+  int n_img; int mean_loss; float loss_scale;
+};
+
+// one block (1024 threads) per image; thread -> (column c = t % K, row phase t / K)
+__global__ __launch_bounds__(1024) void wsddn_kernel(WsddnParams p) {
+  __shared__ float red[1024];
+  __shared__ float colv[128], colg[128], cold[128];
+  const int img = blockIdx.x;
+  const int r0 = p.img_off[img], r1 = p.img_off[img + 1];
+  const int K = p.K, nph = 1024 / K;
+  const int c = threadIdx.x % K, ph = threadIdx.x / K;
+  const bool act = ph < nph;
+  // 1. column max of det logits
+  float mx = -FLT_MAX;
+  if (act) for (int r = r0 + ph; r < r1; r += nph) mx = fmaxf(mx, p.logits[(long)r * p.ld + p.c_det + c]);
+  red[threadIdx.x] = mx;
+  __syncthreads();
+  if (threadIdx.x < K) { float m = -FLT_MAX; for (int q = 0; q < nph; ++q) m = fmaxf(m, red[q * K + threadIdx.x]); colv[threadIdx.x] = m; }
+  __syncthreads();
+  const float cmax = colv[c];
+  // 2. column sum of exp
+  float se = 0.f;
+  if (act) for (int r = r0 + ph; r < r1; r += nph) se += expf(p.logits[(long)r * p.ld + p.c_det + c] - cmax);
+  __syncthreads();
+  red[threadIdx.x] = se;
+  __syncthreads();
+  if (threadIdx.x < K) { float s = 0.f; for (int q = 0; q < nph; ++q) s += red[q * K + threadIdx.x]; colg[threadIdx.x] = s; }
+  __syncthreads();
+  const float csum = colg[c];
+  // 3. scores = rowsoftmax(cls) * colsoftmax(det); column sums. Row softmax: each row's K threads
+  //    recompute the row max/sum serially (K <= 128, tiny).
+  float ss = 0.f;
+  if (act)
+    for (int r = r0 + ph; r < r1; r += nph) {
+      const float* row = p.logits + (long)r * p.ld + p.c_cls;
+      float rm = -FLT_MAX;
+      for (int k = 0; k < K; ++k) rm = fmaxf(rm, row[k]);
+      float rs = 0.f;
+      for (int k = 0; k < K; ++k) rs += expf(row[k] - rm);
+      const float a = expf(row[c] - rm) / rs;
+      const float b = expf(p.logits[(long)r * p.ld + p.c_det + c] - cmax) / csum;
+      const float s = a * b;
+      p.scores[(long)r * K + c] = s;
+      ss += s;
+    }
+  __syncthreads();
+  red[threadIdx.x] = ss;
+  __syncthreads();
+  if (threadIdx.x < K) {
+    float s = 0.f;
+    for (int q = 0; q < nph; ++q) s += red[q * K + threadIdx.x];
+    const float sc = fminf(fmaxf(s, 1e-6f), 1.0f - 1e-6f);
+    cold[threadIdx.x] = s;  // unclamped column sum S_c, reused by the backward
+    p.img_scores[img * K + threadIdx.x] = sc;
+    const float y = p.gt_onehot[img * K + threadIdx.x];
+    // F.binary_cross_entropy: -(y*log(s) + (1-y)*log(1-s)), logs clamped at -100
+    const float l = -(y * fmaxf(logf(sc), -100.f) + (1.f - y) * fmaxf(logf(1.f - sc), -100.f));
+    colv[threadIdx.x] = l;
+    const float norm = (p.mean_loss ? 1.f / (float)(p.n_img * K) : 1.f) / (float)p.n_img;
+    // d loss / d (unclamped sum); clamp passes gradient only inside [1e-6, 1-1e-6]
+    float g = (s >= 1e-6f && s <= 1.0f - 1e-6f) ? (-(y / sc) + (1.f - y) / (1.f - sc)) * norm * p.loss_scale : 0.f;
+    colg[threadIdx.x] = g;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float l = 0.f;
+    for (int k = 0; k < K; ++k) l += colv[k];
+    const float norm = (p.mean_loss ? 1.f / (float)(p.n_img * K) : 1.f) / (float)p.n_img;
+    p.loss_part[img] = l * norm;
+  }
+  if (!p.dlogits) return;
+  // backward. s = a*b; ds = g[c] for every row.  d cls = a*(g*b - sum_k g_k b_k a_k);
+  // d det = b*(g*a - sum_r g a b) = b*g*(a - S_c) with S_c = sum_r a*b = unclamped column sum.
+  if (act)
+    for (int r = r0 + ph; r < r1; r += nph) {
+      const float* row = p.logits + (long)r * p.ld + p.c_cls;
+      float rm = -FLT_MAX;
+      for (int k = 0; k < K; ++k) rm = fmaxf(rm, row[k]);
+      float rs = 0.f;
+      for (int k = 0; k < K; ++k) rs += expf(row[k] - rm);
+      float dot = 0.f;  // sum_k g_k * s_rk  (= sum_k da_k * a_k with da_k = g_k*b_k)
+      for (int k = 0; k < K; ++k) dot += colg[k] * p.scores[(long)r * K + k];
+      const float a = expf(row[c] - rm) / rs;
+      const float s = p.scores[(long)r * K + c];
+      const float b = expf(p.logits[(long)r * p.ld + p.c_det + c] - cmax) / csum;
+      p.dlogits[(long)r * p.ld_d + p.c_cls + c] = colg[c] * s - a * dot;
+      p.dlogits[(long)r * p.ld_d + p.c_det + c] = colg[c] * (s - b * cold[c]);
+    }
+}
+
+struct TargetParams {
+  const float* prev_scores; long ld_s;  // [M][ld_s], class columns 0..K-1 (bg column, if any, ignored)
+  const float* prev_boxes; int box_cols;  // [M][box_cols], box_cols = 4 or 4K
+  const float* props;                  // [M][4]
+  const int* img_off;                  // [n_img+1]
+  const int* gt_classes; const int* gt_count; int gmax;  // [n_img][gmax], [n_img]
+  const float* img_scores;             // [n_img][K]
+  int K;
+  float thr[3]; int lab[4]; int nthr;  // Matcher thresholds/labels (config IOU_THRESHOLDS / IOU_LABELS)
+  int* labels; float* weights; int* matched; float* gt_boxes;  // [M], [M], [M], [M][4]
+  int* pgt_idx; float* pgt_boxes;      // [n_img][gmax], [n_img][gmax][4]
+};
+
+__global__ __launch_bounds__(1024) void oicr_targets_kernel(TargetParams p) {
+  __shared__ float sv[16];
+  __shared__ int si[16];
+  __shared__ float gbox[128][4];
+  __shared__ float gw[128];
+  __shared__ int gcls[128];
+  const int img = blockIdx.x;
+  const int r0 = p.img_off[img], r1 = p.img_off[img + 1];
+  const int G = p.gt_count[img];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int g = 0; g < G; ++g) {
+    const int cls = p.gt_classes[img * p.gmax + g];
+    float best = -FLT_MAX; int bi = 0x7fffffff;
+    for (int r = r0 + threadIdx.x; r < r1; r += 1024) {
+      const float v = p.prev_scores[(long)r * p.ld_s + cls];
+      if (v > best) { best = v; bi = r; }  // ascending r per thread => first index kept on ties
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
+      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
+    }
+    __syncthreads();
+    if (lane == 0) { sv[w] = best; si[w] = bi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      for (int q = 1; q < 16; ++q) if (sv[q] > best || (sv[q] == best && si[q] < bi)) { best = sv[q]; bi = si[q]; }
+      if (bi == 0x7fffffff) bi = r0;
+      const float* bx = p.prev_boxes + (long)bi * p.box_cols + (p.box_cols == 4 ? 0 : 4 * cls);
+      for (int e = 0; e < 4; ++e) { gbox[g][e] = bx[e]; p.pgt_boxes[((long)img * p.gmax + g) * 4 + e] = bx[e]; }
+      gw[g] = p.img_scores[img * p.K + cls];
+      gcls[g] = cls;
+      p.pgt_idx[img * p.gmax + g] = bi - r0;
+    }
+  }
+  __syncthreads();
+  for (int r = r0 + threadIdx.x; r < r1; r += 1024) {
+    const float x1 = p.props[4 * (long)r], y1 = p.props[4 * (long)r + 1], x2 = p.props[4 * (long)r + 2], y2 = p.props[4 * (long)r + 3];
+    const float a2 = (x2 - x1) * (y2 - y1);
+    float best = -1.f; int bg = 0;
+    for (int g = 0; g < G; ++g) {
+      const float a1 = (gbox[g][2] - gbox[g][0]) * (gbox[g][3] - gbox[g][1]);
+      const float iw = fmaxf(fminf(gbox[g][2], x2) - fmaxf(gbox[g][0], x1), 0.f);
+      const float ih = fmaxf(fminf(gbox[g][3], y2) - fmaxf(gbox[g][1], y1), 0.f);
+      const float inter = iw * ih;
+      const float iou = inter > 0.f ? inter / (a1 + a2 - inter) : 0.f;
+      if (iou > best) { best = iou; bg = g; }
+    }
+    int ml = 1;  // Matcher: labels default 1, then per-interval assignment over [-inf, thr.., +inf]
+    if (G == 0) { ml = p.lab[0]; best = 0.f; }
+    else {
+      for (int q = 0; q <= p.nthr; ++q) {
+        const float lo = q == 0 ? -INFINITY : p.thr[q - 1];
+        const float hi = q == p.nthr ? INFINITY : p.thr[q];
+        if (best >= lo && best < hi) ml = p.lab[q];
+      }
+    }
+    int cls = G > 0 ? gcls[bg] : p.K;
+    if (ml == 0) cls = p.K;
+    if (ml == -1) cls = -1;
+    p.labels[r] = cls;
+    p.matched[r] = bg;
+    p.weights[r] = (G > 0 && cls != -1) ? gw[bg] : 0.f;
+    for (int e = 0; e < 4; ++e) p.gt_boxes[4 * (long)r + e] = G > 0 ? gbox[bg][e] : 0.f;
+  }
+}
+
+struct CeParams {
+  const float* logits; long ld; int col0; int C;  // C = K+1 columns starting at col0
+  const int* labels; const float* weights;         // [M] (null => inference: probs only)
+  float* probs;                                    // [M][C]
+  float* dlogits; long ld_d;                       // [M][ld_d] at col0, or null
+  float* loss;                                     // scalar
+  int M; float loss_scale;
+};
+
+// single block: rows strided over 1024 threads; deterministic tree for sum(w*CE) and sum(valid)
+__global__ __launch_bounds__(1024) void softmax_ce_kernel(CeParams p) {
+  __shared__ float sh[16];
+  float lsum = 0.f, vsum = 0.f;
+  for (int r = threadIdx.x; r < p.M; r += 1024) {
+    const float* row = p.logits + (long)r * p.ld + p.col0;
+    float mx = -FLT_MAX;
+    for (int c = 0; c < p.C; ++c) mx = fmaxf(mx, row[c]);
+    float se = 0.f;
+    for (int c = 0; c < p.C; ++c) se += expf(row[c] - mx);
+    for (int c = 0; c < p.C; ++c) p.probs[(long)r * p.C + c] = expf(row[c] - mx) / se;
+    if (p.labels) {
+      const int lab = p.labels[r];
+      const float w = lab == -1 ? 0.f : p.weights[r];
+      if (lab >= 0) lsum += (logf(se) - (row[lab] - mx)) * w;
+      vsum += w > 1e-12f ? 1.f : 0.f;
+    }
+  }
+  if (!p.labels) return;
+  const float L = block_sum_1024(lsum, sh);
+  const float V = block_sum_1024(vsum, sh);
+  if (threadIdx.x == 0) p.loss[0] = L / V;
+  if (!p.dlogits) return;
+  for (int r = threadIdx.x; r < p.M; r += 1024) {
+    const int lab = p.labels[r];
+    const float w = lab < 0 ? 0.f : p.weights[r];
+    const float f = w / V * p.loss_scale;
+    for (int c = 0; c < p.C; ++c)
+      p.dlogits[(long)r * p.ld_d + p.col0 + c] = f * (p.probs[(long)r * p.C + c] - (c == lab ? 1.f : 0.f));
+  }
+}
+
+// mean over n_heads of row softmaxes (fast_rcnn.py:1577-1594)
+__global__ void mean_softmax_kernel(const float* logits, long ld, const int* col0s, int n_heads, int C, float* probs,
+                                    int M) {
+  const int r = blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= M) return;
+  for (int c = 0; c < C; ++c) probs[(long)r * C + c] = 0.f;
+  for (int h = 0; h < n_heads; ++h) {
+    const float* row = logits + (long)r * ld + col0s[h];
+    float mx = -FLT_MAX;
+    for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
+    for (int c = 0; c < C; ++c) probs[(long)r * C + c] += expf(row[c] - mx) / se;
+  }
+  for (int c = 0; c < C; ++c) probs[(long)r * C + c] = probs[(long)r * C + c] / (float)n_heads;
+}
+
+// Box2BoxTransform.apply_deltas; deltas == null means all-zero deltas (non-regressing heads)
+__global__ void apply_deltas_kernel(const float* deltas, long ld_d, const float* boxes, float* out, int M, int K,
+                                    float wx, float wy, float ww, float wh, float clampv) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i >= (long)M * K) return;
+  const int r = i / K, k = i - (long)r * K;
+  const float x1 = boxes[4 * (long)r], y1 = boxes[4 * (long)r + 1], x2 = boxes[4 * (long)r + 2], y2 = boxes[4 * (long)r + 3];
+  const float w = x2 - x1, h = y2 - y1;
+  const float cx = x1 + 0.5f * w, cy = y1 + 0.5f * h;
+  float dx = 0.f, dy = 0.f, dw = 0.f, dh = 0.f;
+  if (deltas) {
+    const float* d = deltas + (long)r * ld_d + 4 * k;
+    dx = d[0] / wx; dy = d[1] / wy; dw = fminf(d[2] / ww, clampv); dh = fminf(d[3] / wh, clampv);
+  }
+  const float pcx = dx * w + cx, pcy = dy * h + cy;
+  const float pw = expf(dw) * w, ph = expf(dh) * h;
+  float* o = out + (long)r * 4 * K + 4 * k;
+  o[0] = pcx - 0.5f * pw; o[1] = pcy - 0.5f * ph; o[2] = pcx + 0.5f * pw; o[3] = pcy + 0.5f * ph;
+}
+
+struct SgdSeg { long off; long cnt; float lr; float wd; };
+
+// p -= lr * (buf = mom*buf + (g + wd*p)); first step: buf = g + wd*p.  One launch over the flat
+// parameter arena; the bf16/f32 compute shadow is refreshed in the same pass.
+template <int DT_SHADOW>
+__global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ mom, const float* __restrict__ g,
+                           typename ElemOf<DT_SHADOW>::type* shadow, const SgdSeg* segs, int nseg, float momentum,
+                           int first_step, float grad_scale) {
+  for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
+    const SgdSeg sg = segs[s];
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < sg.cnt; i += (long)gridDim.x * blockDim.x) {
+      const long j = sg.off + i;
+      const float pw = w[j];
+      float d = g[j] * grad_scale;
+      if (sg.wd != 0.f) d = d + sg.wd * pw;
+      const float b = first_step ? d : momentum * mom[j] + d;
+      mom[j] = b;
+      const float nw = pw - sg.lr * b;
+      w[j] = nw;
+      if (shadow) ElemOf<DT_SHADOW>::st(shadow + j, nw);
+    }
+  }
+}
+
+__global__ void sum_small_kernel(const float* in, int n, float scale, float* out) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) {
+    float s = 0.f;
+    for (int i = 0; i < n; ++i) s += in[i];
+    out[0] = s * scale;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const float* bias, const float* mask,
+                     unsigned long long seed, float drop_p, void* out, long ld_out, void* outT, long ld_outT, int M,
+                     int N, long ld_in, int relu, int out_dtype, void* stream) {
+  if (!partials || M < 0 || N < 0 || splits < 1 || (!out && !outT)) return DRN_ERR_ARG;
+  if (M == 0 || N == 0) return DRN_OK;
+  ActParams p{partials, splits, split_stride, bias, mask, seed, drop_p, nullptr, (char*)out, ld_out, (char*)outT,
+              ld_outT, nullptr, nullptr, M, N, ld_in, relu, 0};
+  dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == DRN_BF16) hipLaunchKernelGGL((act_kernel<DRN_BF16, DRN_BF16, false>), grid, block, 0, st, p);
+  else if (out_dtype == DRN_F32) hipLaunchKernelGGL((act_kernel<DRN_F32, DRN_F32, false>), grid, block, 0, st, p);
+  else return DRN_ERR_ARG;
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const void* saved_out,
+                     const float* mask, float drop_p,
+                     void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, int accumulate_colsum, int M,
+                     int N, int out_dtype, void* stream) {
+  if (!grad_out || M < 0 || N < 0) return DRN_ERR_ARG;
+  if (M == 0 || N == 0) return DRN_OK;
+  ActParams p{grad_out, 1, 0, nullptr, mask, 0ULL, drop_p, (const char*)saved_out, (char*)dpre, ld_out, (char*)dpreT,
+              ld_outT, colsum, colscale, M, N, ld_in, 1, accumulate_colsum};
+  dim3 grid((N + 63) / 64, 1), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (out_dtype == DRN_BF16) hipLaunchKernelGGL((act_kernel<DRN_BF16, DRN_BF16, true>), grid, block, 0, st, p);
+  else if (out_dtype == DRN_F32) hipLaunchKernelGGL((act_kernel<DRN_F32, DRN_F32, true>), grid, block, 0, st, p);
+  else return DRN_ERR_ARG;
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K, const int* img_off, int n_img,
+                      const float* gt_onehot, float* scores, float* img_scores, float* loss_part, float* dlogits,
+                      long ld_d, int mean_loss, float loss_scale, void* stream) {
+  if (!logits || !img_off || !gt_onehot || !scores || !img_scores || !loss_part || K < 1 || K > 128 || n_img < 1)
+    return DRN_ERR_ARG;
+  WsddnParams p{logits, ld, c_cls, c_det, K, img_off, gt_onehot, scores, img_scores, loss_part, dlogits, ld_d, n_img,
+                mean_loss, loss_scale};
+  hipLaunchKernelGGL(wsddn_kernel, dim3(n_img), dim3(1024), 0, (hipStream_t)stream, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxes, int box_cols, const float* props,
+                     const int* img_off, int n_img, const int* gt_classes, const int* gt_count, int gmax,
+                     const float* img_scores, int K, const float* thresholds, const int* thr_labels, int nthr,
+                     int* labels, float* weights, int* matched, float* gt_boxes, int* pgt_idx, float* pgt_boxes,
+                     void* stream) {
+  if (!prev_scores || !prev_boxes || !props || !img_off || !gt_classes || !gt_count || !img_scores || !labels ||
+      !weights || !matched || !gt_boxes || !pgt_idx || !pgt_boxes)
+    return DRN_ERR_ARG;
+  if (gmax < 1 || gmax > 128 || nthr < 1 || nthr > 3 || (box_cols != 4 && box_cols != 4 * K)) return DRN_ERR_ARG;
+  TargetParams p;
+  p.prev_scores = prev_scores; p.ld_s = ld_s; p.prev_boxes = prev_boxes; p.box_cols = box_cols; p.props = props;
+  p.img_off = img_off; p.gt_classes = gt_classes; p.gt_count = gt_count; p.gmax = gmax; p.img_scores = img_scores;
+  p.K = K; p.nthr = nthr;
+  for (int i = 0; i < 3; ++i) p.thr[i] = i < nthr ? thresholds[i] : 0.f;
+  for (int i = 0; i < 4; ++i) p.lab[i] = i <= nthr ? thr_labels[i] : 0;
+  p.labels = labels; p.weights = weights; p.matched = matched; p.gt_boxes = gt_boxes; p.pgt_idx = pgt_idx;
+  p.pgt_boxes = pgt_boxes;
+  hipLaunchKernelGGL(oicr_targets_kernel, dim3(n_img), dim3(1024), 0, (hipStream_t)stream, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_softmax_ce(const float* logits, long ld, int col0, int C, const int* labels, const float* weights,
+                   float* probs, float* dlogits, long ld_d, float* loss, int M, float loss_scale, void* stream) {
+  if (!logits || !probs || C < 1 || M < 0) return DRN_ERR_ARG;
+  if (labels && (!weights || !loss)) return DRN_ERR_ARG;
+  CeParams p{logits, ld, col0, C, labels, weights, probs, dlogits, ld_d, loss, M, loss_scale};
+  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_mean_softmax(const float* logits, long ld, const int* col0s_dev, int n_heads, int C, float* probs, int M,
+                     void* stream) {
+  if (!logits || !col0s_dev || !probs || n_heads < 1) return DRN_ERR_ARG;
+  if (M == 0) return DRN_OK;
+  hipLaunchKernelGGL(mean_softmax_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, ld,
+                     col0s_dev, n_heads, C, probs, M);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_apply_deltas(const float* deltas, long ld_d, const float* boxes, float* out, int M, int K, const float* w4,
+                     float scale_clamp, void* stream) {
+  if (!boxes || !out || !w4 || K < 1) return DRN_ERR_ARG;
+  if (M == 0) return DRN_OK;
+  const long tot = (long)M * K;
+  hipLaunchKernelGGL(apply_deltas_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     deltas, ld_d, boxes, out, M, K, w4[0], w4[1], w4[2], w4[3], scale_clamp);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// segs_dev: device array of {int64 off, int64 cnt, float lr, float wd} (24 bytes each)
+int drn_sgd_step(float* weights, float* momentum_buf, const float* grads, void* shadow, int shadow_dtype,
+                 const void* segs_dev, int nseg, float momentum, int first_step, float grad_scale, void* stream) {
+  if (!weights || !momentum_buf || !grads || !segs_dev || nseg < 1) return DRN_ERR_ARG;
+  dim3 grid(512, nseg < 64 ? nseg : 64), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (shadow && shadow_dtype == DRN_BF16)
+    hipLaunchKernelGGL(sgd_kernel<DRN_BF16>, grid, block, 0, st, weights, momentum_buf, grads, (bf16_t*)shadow,
+                       (const SgdSeg*)segs_dev, nseg, momentum, first_step, grad_scale);
+  else
+    hipLaunchKernelGGL(sgd_kernel<DRN_F32>, grid, block, 0, st, weights, momentum_buf, grads,
+                       shadow_dtype == DRN_F32 ? (float*)shadow : nullptr, (const SgdSeg*)segs_dev, nseg, momentum,
+                       first_step, grad_scale);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_sum_small(const float* in, int n, float scale, float* out, void* stream) {
+  if (!in || !out || n < 0) return DRN_ERR_ARG;
+  hipLaunchKernelGGL(sum_small_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, in, n, scale, out);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+}  // extern "C"

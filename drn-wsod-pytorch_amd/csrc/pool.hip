@@ -1,0 +1,321 @@
+// HBM-bound feature-map kernels for gfx950: input normalisation, 2x2 max-pool, ROIPool / ROIAlign
+// (fused with the OICR objectness scaling and written straight into the fc6 GEMM operand layout),
+// and a tiled cast+transpose.  NHWC everywhere: a wave reads 64 consecutive channels = one
+// 128-B (bf16) / 256-B (f32) line per spatial tap; ROI outputs are re-ordered through LDS so the
+// [roi][c*P*P + bin] rows (the reference's NCHW flatten order, box_head.py:85-86) are written in
+// full lines too.  Built with -ffp-contract=off: the arithmetic is the oracle's, op for op.
+//
+// Replaces: GeneralizedRCNNWSL.preprocess_image (projects/WSL/wsl/modeling/meta_arch/rcnn.py:242-249),
+// nn.MaxPool2d(2, stride) (resnet_ws.py:214-215,403; vgg.py:99-100), torchvision RoIPool
+// (detectron2/modeling/poolers.py:162-165), ROIAlign (detectron2/layers/csrc/ROIAlign/ROIAlign_cuda.cu:65-139)
+// and the objectness scaling of roi_heads_oicr.py:342-343.
+#include "drn_common.h"
+#include <float.h>
+
+namespace {
+
+template <int DT>
+__global__ void preprocess_kernel(const float* __restrict__ img, int C, int H, int W, typename ElemOf<DT>::type* out,
+                                  int Hp, int Wp, int Cp, float m0, float m1, float m2, float s0, float s1, float s2) {
+  const long total = (long)Hp * Wp * Cp;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % Cp;
+    const long hw = i / Cp;
+    const int w = hw % Wp, h = hw / Wp;
+    float v = 0.f;
+    if (c < C && h < H && w < W) {
+      const float mean = c == 0 ? m0 : (c == 1 ? m1 : m2);
+      const float sd = c == 0 ? s0 : (c == 1 ? s1 : s2);
+      v = (img[((long)c * H + h) * W + w] - mean) / sd;
+    }
+    ElemOf<DT>::st(out + i, v);
+  }
+}
+
+// one thread = one 16-B channel vector of one output pixel
+template <int DT>
+__global__ void maxpool2x2_kernel(const char* __restrict__ x, char* __restrict__ y, int Nb, int H, int W, int C,
+                                  int Ho, int Wo, int stride) {
+  constexpr int ES = DT == DRN_BF16 ? 2 : 4;
+  constexpr int V = 16 / ES;
+  const int cv = C / V;
+  const long total = (long)Nb * Ho * Wo * cv;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = (i % cv) * V;
+    long t = i / cv;
+    const int wo = t % Wo; t /= Wo;
+    const int ho = t % Ho;
+    const int n = t / Ho;
+    float best[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) best[e] = -FLT_MAX;
+#pragma unroll
+    for (int dh = 0; dh < 2; ++dh)
+#pragma unroll
+      for (int dw = 0; dw < 2; ++dw) {
+        const int h = ho * stride + dh, w = wo * stride + dw;
+        const i32x4_t v = *(const i32x4_t*)(x + (((long)(n * H + h) * W + w) * C + c) * ES);
+        if constexpr (DT == DRN_BF16) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t u = (uint32_t)v[e];
+            best[2 * e] = fmaxf(best[2 * e], __builtin_bit_cast(float, u << 16));
+            best[2 * e + 1] = fmaxf(best[2 * e + 1], __builtin_bit_cast(float, u & 0xffff0000u));
+          }
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], __builtin_bit_cast(float, v[e]));
+        }
+      }
+    i32x4_t o;
+    if constexpr (DT == DRN_BF16) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        o[e] = (int)((__builtin_bit_cast(uint32_t, best[2 * e]) >> 16) |
+                     (__builtin_bit_cast(uint32_t, best[2 * e + 1]) & 0xffff0000u));
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(int, best[e]);
+    }
+    *(i32x4_t*)(y + (((long)(n * Ho + ho) * Wo + wo) * C + c) * ES) = o;
+  }
+}
+
+struct RoiParams {
+  const char* feat;  // NHWC
+  const float* rois;  // [M][5]
+  const float* obj;   // [M] objectness logits or null; output is scaled by (obj + 1)
+  char* out;          // [M][ld_out], k = c*P*P + ph*P + pw
+  int32_t* argmax;    // [M][C*P*P] (h*W + w, or -1) or null  (ROIPool only)
+  int N, H, W, C, P, M;
+  float scale;
+  long ld_out;
+  int sampling_ratio, aligned;
+};
+
+constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
+constexpr int RP_MAXBIN = 64;  // P*P <= 64 (P <= 8)
+
+// MODE 0: RoIPool   MODE 1: ROIAlign (ROIAlign_cuda.cu:65-139 semantics)
+template <int DT_IN, int DT_OUT, int MODE>
+__global__ __launch_bounds__(256) void roi_kernel(RoiParams p) {
+  using EI = ElemOf<DT_IN>;
+  using TI = typename EI::type;
+  using EO = ElemOf<DT_OUT>;
+  using TO = typename EO::type;
+  __shared__ float tile[RP_CH][RP_MAXBIN + 1];
+  __shared__ int atile[RP_CH][RP_MAXBIN + 1];
+  const int m = blockIdx.x;
+  const int c0 = blockIdx.y * RP_CH;
+  const int cl = threadIdx.x & 63, bg = threadIdx.x >> 6;  // lane = channel, 4 bin groups
+  const int c = c0 + cl;
+  const float* roi = p.rois + 5 * (long)m;
+  const int b = (int)roi[0];
+  const int PP = p.P * p.P;
+  const float mul = p.obj ? p.obj[m] + 1.f : 1.f;
+  const TI* fb = (const TI*)p.feat + (long)b * p.H * p.W * p.C;
+  if (MODE == 0) {
+    const int x1 = (int)roundf(roi[1] * p.scale), y1 = (int)roundf(roi[2] * p.scale);
+    const int x2 = (int)roundf(roi[3] * p.scale), y2 = (int)roundf(roi[4] * p.scale);
+    const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+    const float bin_h = (float)rh / (float)p.P, bin_w = (float)rw / (float)p.P;
+    for (int bin = bg; bin < PP; bin += 4) {
+      const int ph = bin / p.P, pw = bin - ph * p.P;
+      int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
+      int ws = (int)floorf((float)pw * bin_w), we = (int)ceilf((float)(pw + 1) * bin_w);
+      hs = min(max(hs + y1, 0), p.H); he = min(max(he + y1, 0), p.H);
+      ws = min(max(ws + x1, 0), p.W); we = min(max(we + x1, 0), p.W);
+      const bool empty = he <= hs || we <= ws;
+      float best = empty ? 0.f : -FLT_MAX;
+      int besti = -1;
+      if (c < p.C)
+        for (int h = hs; h < he; ++h)
+          for (int w = ws; w < we; ++w) {
+            const float v = EI::ld(fb + ((long)h * p.W + w) * p.C + c);
+            if (v > best) { best = v; besti = h * p.W + w; }
+          }
+      tile[cl][bin] = best * mul;
+      atile[cl][bin] = besti;
+    }
+  } else {
+    const float off = p.aligned ? 0.5f : 0.f;
+    const float sw = roi[1] * p.scale - off, sh = roi[2] * p.scale - off;
+    const float ew = roi[3] * p.scale - off, eh = roi[4] * p.scale - off;
+    float rw = ew - sw, rh = eh - sh;
+    if (!p.aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+    const float bin_h = rh / (float)p.P, bin_w = rw / (float)p.P;
+    const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(rh / p.P);
+    const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(rw / p.P);
+    const float count = (float)max(gh * gw, 1);
+    for (int bin = bg; bin < PP; bin += 4) {
+      const int ph = bin / p.P, pw = bin - ph * p.P;
+      float acc = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float yy = sh + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float xx = sw + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
+          float x = xx, y = yy;
+          if (y < -1.0f || y > p.H || x < -1.0f || x > p.W) continue;
+          if (y <= 0) y = 0;
+          if (x <= 0) x = 0;
+          int yl = (int)y, xl = (int)x, yh, xh;
+          if (yl >= p.H - 1) { yh = yl = p.H - 1; y = (float)yl; } else yh = yl + 1;
+          if (xl >= p.W - 1) { xh = xl = p.W - 1; x = (float)xl; } else xh = xl + 1;
+          const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+          if (c < p.C) {
+            const float v1 = EI::ld(fb + ((long)yl * p.W + xl) * p.C + c), v2 = EI::ld(fb + ((long)yl * p.W + xh) * p.C + c);
+            const float v3 = EI::ld(fb + ((long)yh * p.W + xl) * p.C + c), v4 = EI::ld(fb + ((long)yh * p.W + xh) * p.C + c);
+            acc += hy * hx * v1 + hy * lx * v2 + ly * hx * v3 + ly * lx * v4;
+          }
+        }
+      }
+      tile[cl][bin] = acc / count * mul;
+    }
+  }
+  __syncthreads();
+  // coalesced write-out: k = c*PP + bin is contiguous over this block's 64 channels
+  const int nvalid = min(RP_CH, p.C - c0) * PP;
+  TO* orow = (TO*)p.out + (long)m * p.ld_out + (long)c0 * PP;
+  for (int i = threadIdx.x; i < nvalid; i += 256) {
+    const int lc = i / PP, bin = i - lc * PP;
+    EO::st(orow + i, tile[lc][bin]);
+    if (MODE == 0 && p.argmax) p.argmax[(long)m * p.C * PP + (long)c0 * PP + i] = atile[lc][bin];
+  }
+}
+
+// out[c][r] = (T_OUT) in[r][c]; 64x64 tiles through LDS, both sides coalesced.
+template <int DT_IN, int DT_OUT>
+__global__ __launch_bounds__(256) void transpose_kernel(const char* __restrict__ in, char* __restrict__ out, int rows,
+                                                        int cols, long ld_in, long ld_out) {
+  using EI = ElemOf<DT_IN>;
+  using EO = ElemOf<DT_OUT>;
+  __shared__ float t[64][65];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    t[i][tx] = (r < rows && c < cols) ? EI::ld((const typename EI::type*)in + (long)r * ld_in + c) : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) EO::st((typename EO::type*)out + (long)c * ld_out + r, t[tx][i]);
+  }
+}
+
+template <int DT_IN, int DT_OUT>
+__global__ void cast2d_kernel(const char* __restrict__ in, char* __restrict__ out, int rows, int cols, long ld_in,
+                              long ld_out) {
+  using EI = ElemOf<DT_IN>;
+  using EO = ElemOf<DT_OUT>;
+  const long total = (long)rows * cols;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const long r = i / cols, c = i - r * cols;
+    EO::st((typename EO::type*)out + r * ld_out + c, EI::ld((const typename EI::type*)in + r * ld_in + c));
+  }
+}
+
+inline int grid_for(long total, int block) {
+  long g = (total + block - 1) / block;
+  return (int)(g > 2048 ? 2048 : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+extern "C" {
+
+int drn_preprocess_nhwc(const float* img_chw, int C, int H, int W, void* out_nhwc, int Hp, int Wp, int Cp,
+                        const float* mean3, const float* std3, int dtype, void* stream) {
+  if (!img_chw || !out_nhwc || C > 3 || C < 1 || Cp < C || H > Hp || W > Wp) return DRN_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const long total = (long)Hp * Wp * Cp;
+  if (dtype == DRN_BF16)
+    hipLaunchKernelGGL(preprocess_kernel<DRN_BF16>, dim3(grid_for(total, 256)), dim3(256), 0, st, img_chw, C, H, W,
+                       (bf16_t*)out_nhwc, Hp, Wp, Cp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  else if (dtype == DRN_F32)
+    hipLaunchKernelGGL(preprocess_kernel<DRN_F32>, dim3(grid_for(total, 256)), dim3(256), 0, st, img_chw, C, H, W,
+                       (float*)out_nhwc, Hp, Wp, Cp, mean3[0], mean3[1], mean3[2], std3[0], std3[1], std3[2]);
+  else
+    return DRN_ERR_ARG;
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_maxpool2x2_nhwc(const void* x, void* y, int Nb, int H, int W, int C, int stride, int dtype, void* stream) {
+  if (!x || !y || (stride != 1 && stride != 2) || H < 2 || W < 2) return DRN_ERR_ARG;
+  const int es = drn_esize(dtype);
+  if ((C * es) % 16) return DRN_ERR_ARG;
+  const int Ho = (H - 2) / stride + 1, Wo = (W - 2) / stride + 1;
+  const long total = (long)Nb * Ho * Wo * (C * es / 16);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DRN_BF16)
+    hipLaunchKernelGGL(maxpool2x2_kernel<DRN_BF16>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const char*)x,
+                       (char*)y, Nb, H, W, C, Ho, Wo, stride);
+  else if (dtype == DRN_F32)
+    hipLaunchKernelGGL(maxpool2x2_kernel<DRN_F32>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const char*)x,
+                       (char*)y, Nb, H, W, C, Ho, Wo, stride);
+  else
+    return DRN_ERR_ARG;
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// mode 0 = RoIPool, 1 = ROIAlign. in_dtype = feature dtype, out_dtype = pooled dtype.
+int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectness, void* out, int32_t* argmax, int N,
+                      int H, int W, int C, int P, int M, float spatial_scale, long ld_out, int mode,
+                      int sampling_ratio, int aligned, int in_dtype, int out_dtype, void* stream) {
+  if (!feat || !rois || !out || P < 1 || P * P > RP_MAXBIN || M < 0 || (mode != 0 && mode != 1)) return DRN_ERR_ARG;
+  if (ld_out < (long)C * P * P) return DRN_ERR_ARG;
+  if (M == 0) return DRN_OK;
+  RoiParams p{(const char*)feat, rois, objectness, (char*)out, argmax, N, H, W, C, P, M, spatial_scale, ld_out,
+              sampling_ratio, aligned};
+  dim3 grid(M, (C + RP_CH - 1) / RP_CH), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define RP_LAUNCH(DI, DO, MD) hipLaunchKernelGGL((roi_kernel<DI, DO, MD>), grid, block, 0, st, p)
+  if (in_dtype == DRN_BF16 && out_dtype == DRN_BF16) { if (mode == 0) RP_LAUNCH(DRN_BF16, DRN_BF16, 0); else RP_LAUNCH(DRN_BF16, DRN_BF16, 1); }
+  else if (in_dtype == DRN_F32 && out_dtype == DRN_F32) { if (mode == 0) RP_LAUNCH(DRN_F32, DRN_F32, 0); else RP_LAUNCH(DRN_F32, DRN_F32, 1); }
+  else if (in_dtype == DRN_F32 && out_dtype == DRN_BF16) { if (mode == 0) RP_LAUNCH(DRN_F32, DRN_BF16, 0); else RP_LAUNCH(DRN_F32, DRN_BF16, 1); }
+  else if (in_dtype == DRN_BF16 && out_dtype == DRN_F32) { if (mode == 0) RP_LAUNCH(DRN_BF16, DRN_F32, 0); else RP_LAUNCH(DRN_BF16, DRN_F32, 1); }
+  else return DRN_ERR_ARG;
+#undef RP_LAUNCH
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_transpose2d(const void* in, void* out, int rows, int cols, long ld_in, long ld_out, int in_dtype,
+                    int out_dtype, void* stream) {
+  if (!in || !out || rows < 0 || cols < 0) return DRN_ERR_ARG;
+  if (rows == 0 || cols == 0) return DRN_OK;
+  dim3 grid((cols + 63) / 64, (rows + 63) / 64), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define TR_LAUNCH(DI, DO) hipLaunchKernelGGL((transpose_kernel<DI, DO>), grid, block, 0, st, (const char*)in, (char*)out, rows, cols, ld_in, ld_out)
+  if (in_dtype == DRN_BF16 && out_dtype == DRN_BF16) TR_LAUNCH(DRN_BF16, DRN_BF16);
+  else if (in_dtype == DRN_F32 && out_dtype == DRN_F32) TR_LAUNCH(DRN_F32, DRN_F32);
+  else if (in_dtype == DRN_F32 && out_dtype == DRN_BF16) TR_LAUNCH(DRN_F32, DRN_BF16);
+  else if (in_dtype == DRN_BF16 && out_dtype == DRN_F32) TR_LAUNCH(DRN_BF16, DRN_F32);
+  else return DRN_ERR_ARG;
+#undef TR_LAUNCH
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// out[r][c] = cast(in[r][c]) with independent leading dimensions (refreshes padded compute shadows).
+int drn_cast2d(const void* in, void* out, int rows, int cols, long ld_in, long ld_out, int in_dtype, int out_dtype,
+               void* stream) {
+  if (!in || !out || rows < 0 || cols < 0) return DRN_ERR_ARG;
+  if (rows == 0 || cols == 0) return DRN_OK;
+  const long total = (long)rows * cols;
+  dim3 grid(grid_for(total, 256)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define CA_LAUNCH(DI, DO) hipLaunchKernelGGL((cast2d_kernel<DI, DO>), grid, block, 0, st, (const char*)in, (char*)out, rows, cols, ld_in, ld_out)
+  if (in_dtype == DRN_BF16 && out_dtype == DRN_BF16) CA_LAUNCH(DRN_BF16, DRN_BF16);
+  else if (in_dtype == DRN_F32 && out_dtype == DRN_F32) CA_LAUNCH(DRN_F32, DRN_F32);
+  else if (in_dtype == DRN_F32 && out_dtype == DRN_BF16) CA_LAUNCH(DRN_F32, DRN_BF16);
+  else if (in_dtype == DRN_BF16 && out_dtype == DRN_F32) CA_LAUNCH(DRN_BF16, DRN_F32);
+  else return DRN_ERR_ARG;
+#undef CA_LAUNCH
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,222 @@
+"""Tensor-level wrappers over the C ABI (include/drn_wsod.h).  torch is used only to own device
+memory and streams; every computation below is a hand-written HIP kernel.  No CPU path exists:
+passing CPU tensors raises."""
+import ctypes
+import math
+
+import torch
+
+from . import _cabi as C
+
+SCALE_CLAMP = math.log(1000.0 / 16)  # detectron2/modeling/box_regression.py:9
+
+
+def esize(dtype):
+    return 2 if dtype == torch.bfloat16 else 4
+
+
+def kpad(k, dtype):
+    """K rounded up to a whole number of 128-byte slabs (GEMM contract)."""
+    q = 128 // esize(dtype)
+    return (k + q - 1) // q * q
+
+
+def _2d(t):
+    assert t.dim() == 2 and t.stride(1) == 1, "row-major 2-D tensor expected"
+    return t.stride(0)
+
+
+def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
+    """C[s,M,N] (fp32) = A[M,:K] @ B[N,:K]^T.  A, B: 2-D row-major device tensors of the compute dtype
+    whose leading dimension may exceed K (zero padded up to kpad)."""
+    lda, ldb = _2d(A), _2d(B)
+    assert A.dtype == B.dtype
+    if out is None:
+        out = torch.empty((splits, M, N), dtype=torch.float32, device=A.device)
+    ldc = out.stride(-2)
+    sstride = out.stride(0) if out.dim() == 3 else 0
+    assert out.dim() == 3 or splits == 1
+    C.call("drn_gemm_nt", C.ptr(A), C.ptr(B), C.ptr(out), M, N, K, lda, ldb, ldc, C.dt(A.dtype), splits, sstride,
+           int(accumulate), C.stream())
+    return out
+
+
+def conv2d_nhwc(x, w_packed, cout, kh, kw, stride=1, pad=0, dil=1, scale=None, bias=None, residual=None, relu=False):
+    """x [N,H,W,Cin] NHWC contiguous; w_packed [Cout, ldw]; returns y [N,Ho,Wo,Cout]."""
+    assert x.is_contiguous() and x.dim() == 4
+    n, h, w, cin = x.shape
+    ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=x.dtype, device=x.device)
+    if residual is not None:
+        assert residual.shape == y.shape and residual.is_contiguous()
+    C.call("drn_conv2d_nhwc", C.ptr(x), C.ptr(w_packed), C.ptr(y), C.ptr(scale), C.ptr(bias), C.ptr(residual), n, h, w,
+           cin, cout, kh, kw, stride, pad, dil, _2d(w_packed), cout, cout, int(relu), C.dt(x.dtype), C.stream())
+    return y
+
+
+def maxpool2x2_nhwc(x, stride):
+    n, h, w, c = x.shape
+    ho, wo = (h - 2) // stride + 1, (w - 2) // stride + 1
+    y = torch.empty((n, ho, wo, c), dtype=x.dtype, device=x.device)
+    C.call("drn_maxpool2x2_nhwc", C.ptr(x), C.ptr(y), n, h, w, c, stride, C.dt(x.dtype), C.stream())
+    return y
+
+
+def preprocess_nhwc(images, mean, std, dtype, cpad):
+    """images: list of [3,H,W] f32 device tensors -> ([N,Hmax,Wmax,cpad] NHWC, sizes)."""
+    hmax = max(int(i.shape[1]) for i in images)
+    wmax = max(int(i.shape[2]) for i in images)
+    out = torch.empty((len(images), hmax, wmax, cpad), dtype=dtype, device=images[0].device)
+    m, s = C.host_floats(mean), C.host_floats(std)
+    for k, im in enumerate(images):
+        im = im.contiguous().float()
+        C.call("drn_preprocess_nhwc", C.ptr(im), im.shape[0], im.shape[1], im.shape[2], C.ptr(out[k]), hmax, wmax, cpad,
+               ctypes.cast(m, ctypes.c_void_p), ctypes.cast(s, ctypes.c_void_p), C.dt(dtype), C.stream())
+    return out, [(int(i.shape[1]), int(i.shape[2])) for i in images]
+
+
+def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, aligned=False, out=None, out_dtype=None,
+                  want_argmax=False):
+    """feat [N,H,W,C]; rois [M,5] f32; -> out [M, ld] (first C*P*P columns valid, k = c*P*P + bin)."""
+    n, h, w, c = feat.shape
+    m = rois.shape[0]
+    out_dtype = out_dtype or feat.dtype
+    if out is None:
+        out = torch.zeros((m, kpad(c * P * P, out_dtype)), dtype=out_dtype, device=feat.device)
+    arg = torch.empty((m, c * P * P), dtype=torch.int32, device=feat.device) if want_argmax else None
+    C.call("drn_roi_pool_nhwc", C.ptr(feat), C.ptr(rois), C.ptr(objectness), C.ptr(out), C.ptr(arg), n, h, w, c, P, m,
+           float(scale), _2d(out), mode, sampling_ratio, int(aligned), C.dt(feat.dtype), C.dt(out.dtype), C.stream())
+    return (out, arg) if want_argmax else out
+
+
+def transpose2d(inp, rows, cols, out=None, out_dtype=None):
+    out_dtype = out_dtype or inp.dtype
+    if out is None:
+        out = torch.zeros((cols, kpad(rows, out_dtype)), dtype=out_dtype, device=inp.device)
+    C.call("drn_transpose2d", C.ptr(inp), C.ptr(out), rows, cols, _2d(inp), _2d(out), C.dt(inp.dtype), C.dt(out.dtype),
+           C.stream())
+    return out
+
+
+def cast2d(inp, rows, cols, out):
+    C.call("drn_cast2d", C.ptr(inp), C.ptr(out), rows, cols, _2d(inp), _2d(out), C.dt(inp.dtype), C.dt(out.dtype),
+           C.stream())
+    return out
+
+
+def bias_act_fwd(partials, M, N, bias=None, relu=True, mask=None, seed=0, drop_p=0.0, out=None, outT=None):
+    splits = partials.shape[0] if partials.dim() == 3 else 1
+    sstride = partials.stride(0) if partials.dim() == 3 else 0
+    ref = out if out is not None else outT
+    C.call("drn_bias_act_fwd", C.ptr(partials), splits, sstride, C.ptr(bias), C.ptr(mask), int(seed), float(drop_p),
+           C.ptr(out), _2d(out) if out is not None else 0, C.ptr(outT), _2d(outT) if outT is not None else 0, M, N,
+           partials.stride(-2), int(relu), C.dt(ref.dtype), C.stream())
+
+
+def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=None, dpre=None, dpreT=None, colsum=None,
+                 accumulate_colsum=False):
+    ref = dpre if dpre is not None else dpreT
+    if saved is not None and dpre is not None:
+        assert _2d(saved) == _2d(dpre)
+    ld_out = _2d(dpre) if dpre is not None else (_2d(saved) if saved is not None else 0)
+    C.call("drn_bias_act_bwd", C.ptr(grad_out), _2d(grad_out), C.ptr(colscale), C.ptr(saved), C.ptr(mask), float(drop_p),
+           C.ptr(dpre), ld_out, C.ptr(dpreT), _2d(dpreT) if dpreT is not None else 0, C.ptr(colsum),
+           int(accumulate_colsum), M, N, C.dt(ref.dtype), C.stream())
+
+
+def wsddn_fwd_bwd(logits, c_cls, c_det, K, img_off, n_img, gt_onehot, dlogits=None, mean_loss=True, loss_scale=1.0):
+    M = logits.shape[0]
+    dev = logits.device
+    scores = torch.empty((M, K), dtype=torch.float32, device=dev)
+    img_scores = torch.empty((n_img, K), dtype=torch.float32, device=dev)
+    loss_part = torch.empty((n_img,), dtype=torch.float32, device=dev)
+    C.call("drn_wsddn_fwd_bwd", C.ptr(logits), _2d(logits), c_cls, c_det, K, C.ptr(img_off), n_img, C.ptr(gt_onehot),
+           C.ptr(scores), C.ptr(img_scores), C.ptr(loss_part), C.ptr(dlogits), _2d(dlogits) if dlogits is not None else 0,
+           int(mean_loss), float(loss_scale), C.stream())
+    return scores, img_scores, loss_part
+
+
+def oicr_targets(prev_scores, prev_boxes, props, img_off, n_img, gt_classes, gt_count, img_scores, K,
+                 thresholds=(0.5,), labels=(0, 1)):
+    M = props.shape[0]
+    dev = props.device
+    gmax = gt_classes.shape[1]
+    out = dict(labels=torch.empty((M,), dtype=torch.int32, device=dev),
+               weights=torch.empty((M,), dtype=torch.float32, device=dev),
+               matched=torch.empty((M,), dtype=torch.int32, device=dev),
+               gt_boxes=torch.empty((M, 4), dtype=torch.float32, device=dev),
+               pgt_idx=torch.zeros((n_img, gmax), dtype=torch.int32, device=dev),
+               pgt_boxes=torch.zeros((n_img, gmax, 4), dtype=torch.float32, device=dev))
+    th, lb = C.host_floats(thresholds), C.host_ints(labels)
+    C.call("drn_oicr_targets", C.ptr(prev_scores), _2d(prev_scores), C.ptr(prev_boxes), prev_boxes.shape[1], C.ptr(props),
+           C.ptr(img_off), n_img, C.ptr(gt_classes), C.ptr(gt_count), gmax, C.ptr(img_scores), K,
+           ctypes.cast(th, ctypes.c_void_p), ctypes.cast(lb, ctypes.c_void_p), len(thresholds), C.ptr(out["labels"]),
+           C.ptr(out["weights"]), C.ptr(out["matched"]), C.ptr(out["gt_boxes"]), C.ptr(out["pgt_idx"]),
+           C.ptr(out["pgt_boxes"]), C.stream())
+    return out
+
+
+def softmax_ce(logits, col0, ncol, labels=None, weights=None, dlogits=None, loss_scale=1.0):
+    M = logits.shape[0]
+    probs = torch.empty((M, ncol), dtype=torch.float32, device=logits.device)
+    loss = torch.zeros((1,), dtype=torch.float32, device=logits.device) if labels is not None else None
+    C.call("drn_softmax_ce", C.ptr(logits), _2d(logits), col0, ncol, C.ptr(labels), C.ptr(weights), C.ptr(probs),
+           C.ptr(dlogits), _2d(dlogits) if dlogits is not None else 0, C.ptr(loss), M, float(loss_scale), C.stream())
+    return probs, loss
+
+
+def mean_softmax(logits, col0s, ncol):
+    M = logits.shape[0]
+    probs = torch.empty((M, ncol), dtype=torch.float32, device=logits.device)
+    cd = torch.tensor(list(col0s), dtype=torch.int32, device=logits.device)
+    C.call("drn_mean_softmax", C.ptr(logits), _2d(logits), C.ptr(cd), len(col0s), ncol, C.ptr(probs), M, C.stream())
+    return probs
+
+
+def apply_deltas(deltas, boxes, K, weights=(10.0, 10.0, 5.0, 5.0), col0=0):
+    """deltas: [M, ld] fp32 (class-specific deltas start at column col0) or None (zeros) -> [M, 4K]."""
+    M = boxes.shape[0]
+    out = torch.empty((M, 4 * K), dtype=torch.float32, device=boxes.device)
+    w = C.host_floats(weights)
+    dp = None if deltas is None else deltas.data_ptr() + 4 * col0
+    C.call("drn_apply_deltas", dp, _2d(deltas) if deltas is not None else 0, C.ptr(boxes), C.ptr(out), M, K,
+           ctypes.cast(w, ctypes.c_void_p), float(SCALE_CLAMP), C.stream())
+    return out
+
+
+def sum_small(x, scale=1.0):
+    out = torch.empty((1,), dtype=torch.float32, device=x.device)
+    C.call("drn_sum_small", C.ptr(x), x.numel(), float(scale), C.ptr(out), C.stream())
+    return out
+
+
+def sgd_step(weights, momentum_buf, grads, segs_dev, nseg, momentum, first_step, grad_scale=1.0, shadow=None):
+    C.call("drn_sgd_step", C.ptr(weights), C.ptr(momentum_buf), C.ptr(grads), C.ptr(shadow),
+           C.dt(shadow.dtype) if shadow is not None else -1, C.ptr(segs_dev), nseg, float(momentum), int(first_step),
+           float(grad_scale), C.stream())
+
+
+def detect_topk(boxes, scores, image_shape, score_thresh, nms_thresh, topk):
+    """Single image: boxes [R, 4*nreg] f32, scores [R, K+1] f32 -> (boxes [n,4], scores [n], classes [n] i64,
+    rows [n] i64) exactly as fast_rcnn_inference_single_image."""
+    R, K = scores.shape[0], scores.shape[1] - 1
+    nreg = boxes.shape[1] // 4
+    dev = boxes.device
+    cap = max(R * K, 1)
+    nbytes = C.lib().drn_detect_workspace_bytes(cap)
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=dev)
+    keep = torch.empty((topk,), dtype=torch.int32, device=dev)
+    nk = torch.zeros((1,), dtype=torch.int32, device=dev)
+    boxes = boxes.contiguous().float()
+    scores = scores.contiguous().float()
+    C.call("drn_detect_topk", C.ptr(boxes), C.ptr(scores), R, K, nreg, float(image_shape[0]), float(image_shape[1]),
+           float(score_thresh), float(nms_thresh), topk, C.ptr(ws), nbytes, cap, C.ptr(keep), C.ptr(nk), C.stream())
+    ob = torch.empty((topk, 4), dtype=torch.float32, device=dev)
+    os_ = torch.empty((topk,), dtype=torch.float32, device=dev)
+    oc = torch.empty((topk,), dtype=torch.int32, device=dev)
+    orow = torch.empty((topk,), dtype=torch.int32, device=dev)
+    C.call("drn_detect_gather", C.ptr(ws), nbytes, cap, C.ptr(keep), C.ptr(nk), topk, C.ptr(ob), C.ptr(os_), C.ptr(oc),
+           C.ptr(orow), C.stream())
+    n = int(nk.item())
+    return ob[:n], os_[:n], oc[:n].long(), orow[:n].long()

@@ -1,0 +1,147 @@
+/*
+ * drn_wsod.h — C ABI of the MI355X-native DRN-WSOD / OICR hot path (libdrn_wsod_hip.so).
+ *
+ * Boundary contract:
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless a name ends in _host;
+ *   - every entry point enqueues work on the given hipStream_t (passed as void*), never
+ *     synchronises, never allocates, retains no pointers after returning; graph-capturable;
+ *   - returns 0 (DRN_OK) or a negative code: -1 invalid argument, -2 launch failure,
+ *     -3 unsupported; never throws across the ABI;
+ *   - dtype codes: 0 = fp32 (parity mode, exact fp32 MFMA), 1 = bf16 (fast mode, fp32 accumulate);
+ *   - feature maps are NHWC, matrices row-major with an explicit leading dimension in ELEMENTS.
+ *
+ * Each declaration cites the reference interface it replaces (paths relative to the reference
+ * repository root).  INTEGRATION.md shows the Python-side binding a maintainer would add.
+ */
+#ifndef DRN_WSOD_H_
+#define DRN_WSOD_H_
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DRN_OK 0
+#define DRN_ERR_ARG (-1)
+#define DRN_ERR_LAUNCH (-2)
+#define DRN_ERR_UNSUPPORTED (-3)
+#define DRN_F32 0
+#define DRN_BF16 1
+
+/* ---- backbone -------------------------------------------------------------------------------- */
+
+/* GeneralizedRCNNWSL.preprocess_image, projects/WSL/wsl/modeling/meta_arch/rcnn.py:242-249 +
+ * ImageList.from_tensors, detectron2/structures/image_list.py:57-119.
+ * img_chw [C][H][W] f32 -> out_nhwc [Hp][Wp][Cp] (one image slot), (x-mean)/std, zero padded. */
+int drn_preprocess_nhwc(const float* img_chw, int C, int H, int W, void* out_nhwc, int Hp, int Wp, int Cp,
+                        const float* mean3_host, const float* std3_host, int dtype, void* stream);
+
+/* Conv2d.forward = F.conv2d -> FrozenBatchNorm2d -> relu_ [+ residual add before the relu],
+ * detectron2/layers/wrappers.py:94-99, detectron2/layers/batch_norm.py:45-65,
+ * projects/WSL/wsl/modeling/backbone/resnet_ws.py:217-237, vgg.py:104-122.
+ * x NHWC [Nb][H][W][Cin]; w [Cout][ldw] with k = (kh*KW + kw)*Cin + ci, rows zero-padded to a
+ * multiple of 128 bytes; y [Nb*Ho*Wo][ldy]; y = act(conv*scale[c] + bias[c] (+ residual)). */
+int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                    const void* residual, int Nb, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                    int pad, int dil, long ldw, long ldy, long ldres, int relu, int dtype, void* stream);
+
+/* nn.MaxPool2d(kernel_size=2, stride=s, padding=0), resnet_ws.py:214-215,403; vgg.py:99-100. */
+int drn_maxpool2x2_nhwc(const void* x, void* y, int Nb, int H, int W, int C, int stride, int dtype, void* stream);
+
+/* ---- region pooling -------------------------------------------------------------------------- */
+
+/* ROIPooler.forward single-level path, detectron2/modeling/poolers.py:191-226:
+ * mode 0 = torchvision RoIPool (poolers.py:162-165),
+ * mode 1 = ROIAlign (detectron2/layers/csrc/ROIAlign/ROIAlign.h:54-128 roi_align_forward),
+ * fused with `box_features * (objectness_logits + 1)` (roi_heads_oicr.py:342-343) when objectness != NULL.
+ * feat NHWC; rois [M][5] = (batch_idx, x0, y0, x1, y1); out [M][ld_out] with column
+ * c*P*P + ph*P + pw (the NCHW flatten order of box_head.py:85-86); argmax [M][C*P*P] or NULL. */
+int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectness, void* out, int32_t* argmax, int N,
+                      int H, int W, int C, int P, int M, float spatial_scale, long ld_out, int mode,
+                      int sampling_ratio, int aligned, int in_dtype, int out_dtype, void* stream);
+
+/* out[c][r] = cast(in[r][c]) — builds the K-major operands of the dW GEMMs. */
+int drn_transpose2d(const void* in, void* out, int rows, int cols, long ld_in, long ld_out, int in_dtype,
+                    int out_dtype, void* stream);
+
+/* out[r][c] = cast(in[r][c]) with independent leading dimensions (padded compute shadows of weights). */
+int drn_cast2d(const void* in, void* out, int rows, int cols, long ld_in, long ld_out, int in_dtype, int out_dtype,
+               void* stream);
+
+/* ---- dense contractions ---------------------------------------------------------------------- */
+
+/* nn.Linear / F.linear and its autograd (fc6/fc7 of box_head.py:82-91, predictors of
+ * fast_rcnn.py:453-461,1316-1327).  C[s][M][N] (fp32) = A[M][K] * B[N][K]^T over K-split s.
+ * K*esize must be a multiple of 128 bytes (callers zero-pad K), lda/ldb multiples of 16 bytes. */
+int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
+                int splits, long c_split_stride, int accumulate, void* stream);
+
+/* relu_(fc(x)) + F.dropout(p), box_head.py:88-90: sums split-K partials, adds bias, ReLU, dropout
+ * (explicit multiplier mask [M][N] if given, else counter-based mask from seed when drop_p > 0);
+ * writes out [M][ld_out] and/or its transpose outT [N][ld_outT]. */
+int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const float* bias, const float* mask,
+                     unsigned long long seed, float drop_p, void* out, long ld_out, void* outT, long ld_outT, int M,
+                     int N, long ld_in, int relu, int out_dtype, void* stream);
+
+/* autograd of the above: dpre = grad_out * dropout_mult * (saved_out > 0); colsum[n] = sum_m dpre (bias
+ * gradient, fixed summation order); saved_out == NULL means "no activation"; colscale [N] (optional)
+ * multiplies grad_out per column (per-loss upstream gradients stay on the device). */
+int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const void* saved_out,
+                     const float* mask, float drop_p,
+                     void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, int accumulate_colsum, int M,
+                     int N, int out_dtype, void* stream);
+
+/* ---- MIL / OICR head ------------------------------------------------------------------------- */
+
+/* WSDDNOutputLayers.forward (fast_rcnn.py:493-527) + predict_probs_img (:689-700) +
+ * WSDDNOutputs.binary_cross_entropy_loss (:317-329) + their autograd.  logits [M][ld] fp32 with the
+ * cls / det heads at columns c_cls / c_det; img_off [n_img+1] row offsets.  loss = sum(loss_part). */
+int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K, const int* img_off, int n_img,
+                      const float* gt_onehot, float* scores, float* img_scores, float* loss_part, float* dlogits,
+                      long ld_d, int mean_loss, float loss_scale, void* stream);
+
+/* OICRROIHeads.get_pgt (roi_heads_oicr.py:491-567) + ROIHeads.label_and_sample_proposals
+ * (roi_heads.py:255-353; pairwise_iou structures/boxes.py:329-361; Matcher modeling/matcher.py:61-103).
+ * prev_boxes [M][box_cols] with box_cols = 4 (Boxes path) or 4K (class-specific decoded boxes). */
+int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxes, int box_cols, const float* props,
+                     const int* img_off, int n_img, const int* gt_classes, const int* gt_count, int gmax,
+                     const float* img_scores, int K, const float* thresholds_host, const int* thr_labels_host,
+                     int nthr, int* labels, float* weights, int* matched, float* gt_boxes, int* pgt_idx,
+                     float* pgt_boxes, void* stream);
+
+/* OICROutputs.softmax_cross_entropy_loss (fast_rcnn.py:1087-1096,1128-1144), predict_probs (:1561-1575)
+ * and the backward: loss = sum_r w_r CE_r / #{w_r > 1e-12}.  labels == NULL => probabilities only. */
+int drn_softmax_ce(const float* logits, long ld, int col0, int C, const int* labels, const float* weights,
+                   float* probs, float* dlogits, long ld_d, float* loss, int M, float loss_scale, void* stream);
+
+/* OICROutputLayers.predict_probs_K, fast_rcnn.py:1577-1594. */
+int drn_mean_softmax(const float* logits, long ld, const int* col0s_dev, int n_heads, int C, float* probs, int M,
+                     void* stream);
+
+/* Box2BoxTransform.apply_deltas, detectron2/modeling/box_regression.py:73-110 (deltas NULL = zeros). */
+int drn_apply_deltas(const float* deltas, long ld_d, const float* boxes, float* out, int M, int K,
+                     const float* weights4_host, float scale_clamp, void* stream);
+
+int drn_sum_small(const float* in, int n, float scale, float* out, void* stream);
+
+/* ---- optimizer ------------------------------------------------------------------------------- */
+
+/* torch.optim.SGD(momentum) with the per-parameter groups of detectron2/solver/build.py:93-137, applied to a
+ * flat parameter arena.  segs_dev: array of {int64 offset, int64 count, float lr, float weight_decay}. */
+int drn_sgd_step(float* weights, float* momentum_buf, const float* grads, void* shadow, int shadow_dtype,
+                 const void* segs_dev, int nseg, float momentum, int first_step, float grad_scale, void* stream);
+
+/* ---- inference tail -------------------------------------------------------------------------- */
+
+/* fast_rcnn_inference_single_image, fast_rcnn.py:88-141 + batched_nms, detectron2/layers/nms.py:10-29. */
+long drn_detect_workspace_bytes(int cap);
+int drn_detect_topk(const float* boxes, const float* scores, int R, int K, int nreg, float img_h, float img_w,
+                    float score_thresh, float nms_thresh, int topk, void* workspace, long workspace_bytes, int cap,
+                    int* keep_ids, int* n_keep, void* stream);
+int drn_detect_gather(const void* workspace, long workspace_bytes, int cap, const int* keep_ids, const int* n_keep,
+                      int topk, float* out_boxes, float* out_scores, int* out_classes, int* out_rows, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DRN_WSOD_H_ */

@@ -1,0 +1,426 @@
+"""GPU parity tests, op by op: every HIP kernel (called through the C ABI) against the oracle on the
+same seeded inputs.  Integer / index outputs must be bit-exact; fp32-mode floats within the
+tolerance written at each check; bf16-mode is compared with the oracle run on bf16-rounded operands."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import golden_util as G
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+O = G.O
+
+
+@pytest.fixture(scope="module")
+def drn():
+    assert torch.cuda.is_available(), "GPU tests need a GPU (run with -m gpu on the MI355X box)"
+    pkg = load_package()
+    pkg._cabi.lib()  # raises if the HIP library is missing: no fallback
+    import importlib
+
+    return importlib.import_module("drn_wsod_pytorch_amd.ops")
+
+
+DEV = "cuda"
+DTYPES = [torch.float32, torch.bfloat16]
+
+
+def _rnd(shape, seed, scale=1.0):
+    return torch.from_numpy(np.random.RandomState(seed).standard_normal(shape).astype(np.float32) * scale)
+
+
+def _q(x, dtype):
+    """value an operand has once stored in the compute dtype (fp32 copy of it)"""
+    return x.to(dtype).float()
+
+
+def _padded(x2d, dtype, drn):
+    """[R, K] fp32 cpu -> device tensor [R, kpad(K)] of dtype, zero padded"""
+    r, k = x2d.shape
+    out = torch.zeros((r, drn.kpad(k, dtype)), dtype=dtype, device=DEV)
+    out[:, :k] = x2d.to(DEV).to(dtype)
+    return out
+
+
+# ------------------------------------------------------------------------------------------- GEMM
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(200, 103, 192), (64, 64, 64), (333, 257, 1000), (2048, 128, 4096), (5, 7, 54)])
+def test_gemm_nt(drn, dtype, shape):
+    M, N, K = shape
+    A, B = _rnd((M, K), 1), _rnd((N, K), 2)
+    Ad, Bd = _padded(A, dtype, drn), _padded(B, dtype, drn)
+    Kp = Ad.shape[1]
+    ref = (_q(A, dtype).double() @ _q(B, dtype).double().t())
+    mag = (_q(A, dtype).abs().double() @ _q(B, dtype).abs().double().t())
+    for splits in (1, 3):
+        Cd = drn.gemm_nt(Ad, Bd, M, N, Kp, splits=splits)
+        torch.cuda.synchronize()
+        got = Cd.sum(0).cpu().double()
+        # fp32 accumulation of exact products: error <= ~K * 2^-24 * sum|a*b| (loose factor 4)
+        tol = 4 * 2.0 ** -24 * math.sqrt(K) * mag + 1e-6
+        assert ((got - ref).abs() <= tol).all(), float(((got - ref).abs() / (mag + 1e-9)).max())
+    # accumulate flag: C += A B^T
+    C0 = _rnd((M, N), 3).to(DEV)
+    Cacc = C0.clone().unsqueeze(0)
+    drn.gemm_nt(Ad, Bd, M, N, Kp, out=Cacc, accumulate=True)
+    assert torch.allclose(Cacc[0].cpu().double(), C0.cpu().double() + ref, rtol=1e-4, atol=1e-3)
+
+
+def test_gemm_asymmetric_identity(drn):
+    """A = I with an ASYMMETRIC B catches a transposed C write (cdna guide rule 16)."""
+    n = 128
+    B = torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251  # exact in bf16? no -> use f32
+    A = torch.eye(n)
+    Cd = drn.gemm_nt(A.to(DEV), B.to(DEV), n, n, n)
+    assert torch.equal(Cd[0].cpu(), B.t().contiguous())  # C[i][j] = sum_k I[i][k] B[j][k] = B[j][i]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_gemm_full_size_sampled(drn, dtype):
+    """BASELINE configs[1] fc6 shape (R=2000 padded to 2048, K=50176, N=2048): spot-check 256 entries
+    against fp64, plus linearity C(2A) = 2 C(A) (exact in binary floating point)."""
+    M, N, K = 2000, 2048, 50176
+    g = torch.Generator(device=DEV).manual_seed(0)
+    A = (torch.randn((M, K), device=DEV, generator=g) * 0.5).to(dtype)
+    B = (torch.randn((N, K), device=DEV, generator=g) * 0.02).to(dtype)
+    C1 = drn.gemm_nt(A, B, M, N, K, splits=4).sum(0)
+    C2 = drn.gemm_nt((A.float() * 2).to(dtype), B, M, N, K, splits=4).sum(0)
+    assert torch.equal(C2, 2 * C1)
+    rs = np.random.RandomState(0)
+    ii, jj = rs.randint(0, M, 256), rs.randint(0, N, 256)
+    a = A[torch.from_numpy(ii).to(DEV)].double()
+    b = B[torch.from_numpy(jj).to(DEV)].double()
+    ref = (a * b).sum(1)
+    mag = (a.abs() * b.abs()).sum(1)
+    got = C1[torch.from_numpy(ii).to(DEV), torch.from_numpy(jj).to(DEV)].double()
+    assert ((got - ref).abs() <= 4 * 2.0 ** -24 * math.sqrt(K) * mag + 1e-6).all()
+
+
+# ------------------------------------------------------------------------------------------- conv
+def _pack_w(w, dtype, drn, cin_pad=None):
+    cout, cin, kh, kw = w.shape
+    cp = cin_pad or cin
+    wp = torch.zeros((cout, kh, kw, cp))
+    wp[..., :cin] = w.permute(0, 2, 3, 1)
+    return _padded(wp.reshape(cout, -1), dtype, drn)
+
+
+CONV_CASES = [
+    # (N, H, W, Cin, Cout, k, stride, pad, dil, residual, relu)
+    (1, 27, 27, 32, 48, 1, 1, 0, 1, False, True),
+    (2, 14, 14, 64, 64, 3, 1, 1, 1, True, True),
+    (1, 27, 27, 16, 40, 3, 1, 2, 2, False, True),
+    (1, 33, 31, 3, 8, 3, 2, 1, 1, False, True),
+    (1, 56, 56, 64, 256, 1, 1, 0, 1, True, False),
+    (3, 9, 11, 8, 136, 3, 1, 1, 1, False, False),
+]
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_nhwc(drn, dtype, case):
+    n, h, w, cin, cout, k, stride, pad, dil, has_res, relu = case
+    x = _rnd((n, cin, h, w), 5)
+    wt = _rnd((cout, cin, k, k), 6, math.sqrt(2.0 / (cin * k * k)))
+    scale, bias = 0.8 + 0.2 * torch.rand(cout), _rnd((cout,), 7, 0.1)
+    cin_pad = (8 if dtype == torch.bfloat16 else 4) if cin == 3 else cin
+    xd = torch.zeros((n, h, w, cin_pad), dtype=dtype, device=DEV)
+    xd[..., :cin] = x.permute(0, 2, 3, 1).to(DEV).to(dtype)
+    ref = F.conv2d(_q(x, dtype), _q(wt, dtype), None, stride, pad, dil) * scale.view(1, -1, 1, 1) + bias.view(1, -1, 1, 1)
+    res = None
+    if has_res:
+        res = _rnd(tuple(ref.shape), 8)
+        ref = ref + _q(res, dtype)
+        res = res.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    if relu:
+        ref = F.relu(ref)
+    y = drn.conv2d_nhwc(xd, _pack_w(wt, dtype, drn, cin_pad), cout, k, k, stride, pad, dil, scale.to(DEV), bias.to(DEV),
+                        res, relu)
+    got = y.float().cpu().permute(0, 3, 1, 2)
+    if dtype == torch.float32:
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4), float((got - ref).abs().max())
+    else:  # output rounded to bf16: half-ulp = 2^-9 relative
+        assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stride,hw", [(2, (56, 56)), (1, (28, 28)), (2, (13, 9)), (1, (5, 7))])
+def test_maxpool(drn, dtype, stride, hw):
+    x = _rnd((2, 16, hw[0], hw[1]), 9)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    y = drn.maxpool2x2_nhwc(xd, stride)
+    ref = F.max_pool2d(_q(x, dtype), 2, stride)
+    assert torch.equal(y.float().cpu().permute(0, 3, 1, 2), ref)  # max is exact
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_preprocess(drn, dtype):
+    cfg = O.OracleCfg()
+    ims = [torch.randint(0, 256, (3, 40, 52)).float(), torch.randint(0, 256, (3, 33, 60)).float()]
+    ref, sizes = O.preprocess_image(ims, cfg)
+    cp = 8 if dtype == torch.bfloat16 else 4
+    out, sz = drn.preprocess_nhwc([i.to(DEV) for i in ims], cfg.pixel_mean, cfg.pixel_std, dtype, cp)
+    assert sz == sizes
+    got = out.float().cpu()
+    assert torch.equal(got[..., :3].permute(0, 3, 1, 2), _q(ref, dtype))
+    assert (got[..., 3:] == 0).all()
+
+
+# ------------------------------------------------------------------------------------------- ROI ops
+def _rois(R, n_img, H, W, seed):
+    rs = np.random.RandomState(seed)
+    x0, y0 = rs.rand(R) * (W - 24), rs.rand(R) * (H - 24)
+    r = np.stack([rs.randint(0, n_img, R), x0, y0, x0 + 12 + rs.rand(R) * (W - x0 - 12), y0 + 12 + rs.rand(R) * (H - y0 - 12)], 1)
+    r[0, 1:] = [-50, -50, -40, -40]
+    r[1, 1:] = [12.0, 20.0, 12.0, 20.0]  # .5 rounding cases at scale 1/8
+    return torch.from_numpy(r.astype(np.float32))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,P,scale", [(96, 7, 0.125), (6, 3, 0.125), (130, 7, 0.0625)])
+def test_roi_pool(drn, dtype, C, P, scale):
+    n_img, H, W = 2, 23, 29
+    feat = _rnd((n_img, C, H, W), 11)
+    rois = _rois(80, n_img, W / scale, H / scale, 12)
+    obj = torch.rand(80)
+    ref, rarg = O.roi_pool_forward(_q(feat, dtype), rois, P, scale)
+    ref = _q(ref * (obj + 1).view(-1, 1, 1, 1), dtype).reshape(80, -1)
+    fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    out, arg = drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale, want_argmax=True)
+    k = C * P * P
+    assert torch.equal(out[:, :k].float().cpu(), ref)  # bit-exact: max + one fp32 multiply + rounding
+    assert (out[:, k:] == 0).all()
+    assert torch.equal(arg.cpu(), rarg.reshape(80, -1))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("aligned,sr", [(False, 0), (True, 0), (True, 2)])
+def test_roi_align(drn, dtype, aligned, sr):
+    n_img, C, H, W, P, scale = 2, 70, 19, 23, 7, 0.125
+    feat = _rnd((n_img, C, H, W), 13)
+    rois = _rois(64, n_img, W / scale, H / scale, 14)
+    ref = O.roi_align_forward(_q(feat, dtype), rois, P, scale, sr, aligned).reshape(64, -1)
+    fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    out = drn.roi_pool_nhwc(fd, rois.to(DEV), None, P, scale, mode=1, sampling_ratio=sr, aligned=aligned,
+                            out_dtype=torch.float32)
+    got = out[:, : C * P * P].cpu()
+    assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_transpose_cast(drn, dtype):
+    x = _rnd((130, 75), 15)
+    xd = x.to(DEV)
+    t = drn.transpose2d(xd, 130, 75, out_dtype=dtype)
+    assert torch.equal(t[:, :130].float().cpu(), _q(x, dtype).t())
+    assert (t[:, 130:] == 0).all()
+    out = torch.zeros((130, drn.kpad(75, dtype)), dtype=dtype, device=DEV)
+    drn.cast2d(xd, 130, 75, out)
+    assert torch.equal(out[:, :75].float().cpu(), _q(x, dtype))
+
+
+# ------------------------------------------------------------------------------------------- epilogues
+@pytest.mark.parametrize("dtype", DTYPES)
+def test_bias_act_fwd_bwd(drn, dtype):
+    M, N, S = 150, 100, 3
+    parts = _rnd((S, M, N), 16)
+    bias = _rnd((N,), 17)
+    mask = (torch.rand(M, N) > 0.5).float() * 2
+    out = torch.zeros((M, drn.kpad(N, dtype)), dtype=dtype, device=DEV)
+    outT = torch.zeros((N, drn.kpad(M, dtype)), dtype=dtype, device=DEV)
+    drn.bias_act_fwd(parts.to(DEV), M, N, bias.to(DEV), True, mask.to(DEV), out=out, outT=outT)
+    pre = ((parts[0] + parts[1]) + parts[2]) + bias
+    ref = F.relu(pre) * mask
+    assert torch.equal(out[:, :N].float().cpu(), _q(ref, dtype))
+    assert torch.equal(outT[:, :M].float().cpu(), _q(ref, dtype).t())
+    g = _rnd((M, N), 18)
+    cs = _rnd((N,), 19, 0.1) * 0 + 0.25
+    dpre = torch.zeros_like(out)
+    dpreT = torch.zeros_like(outT)
+    colsum = torch.zeros((N,), device=DEV)
+    drn.bias_act_bwd(g.to(DEV), M, N, saved=out, mask=mask.to(DEV), colscale=cs.to(DEV), dpre=dpre, dpreT=dpreT,
+                     colsum=colsum)
+    refg = g * cs * mask * (ref > 0).float()
+    assert torch.equal(dpre[:, :N].float().cpu(), _q(refg, dtype))
+    assert torch.equal(dpreT[:, :M].float().cpu(), _q(refg, dtype).t())
+    assert torch.allclose(colsum.cpu(), refg.sum(0), rtol=1e-4, atol=1e-4)
+    # counter-based dropout: same mask in fwd and (implicitly) bwd, keep-rate ~ 1-p
+    o2 = torch.zeros((M, drn.kpad(N, torch.float32)), dtype=torch.float32, device=DEV)
+    drn.bias_act_fwd(torch.ones((1, M, N), device=DEV), M, N, None, True, None, seed=123, drop_p=0.5, out=o2)
+    vals = o2[:, :N].cpu()
+    assert set(vals.unique().tolist()) <= {0.0, 2.0}
+    assert abs(float((vals > 0).float().mean()) - 0.5) < 0.03
+
+
+# ------------------------------------------------------------------------------------------- MIL head
+def _head_inputs(M_per, K, seed):
+    rs = np.random.RandomState(seed)
+    M = sum(M_per)
+    ld = 2 * K + 3 * (K + 1) + 5
+    logits = torch.from_numpy(rs.standard_normal((M, ld)).astype(np.float32) * 2)
+    off = torch.tensor([0] + list(np.cumsum(M_per)), dtype=torch.int32)
+    return logits, off, ld
+
+
+@pytest.mark.parametrize("K,M_per", [(20, [300]), (5, [40, 35, 61]), (80, [500, 123])])
+def test_wsddn_fwd_bwd(drn, K, M_per):
+    logits, off, ld = _head_inputs(M_per, K, 21)
+    n_img = len(M_per)
+    oh = torch.zeros(n_img, K)
+    for i in range(n_img):
+        oh[i, (3 * i + 1) % K] = 1
+        oh[i, (7 * i + 2) % K] = 1
+    lg = logits.clone().requires_grad_(True)
+    sc = torch.cat([F.softmax(x[:, :K], 1) * F.softmax(x[:, K:2 * K], 0) for x in lg.split(M_per)], 0)
+    loss = O.wsddn_loss(sc, M_per, oh, True)
+    loss.backward()
+    dl = torch.zeros((sum(M_per), ld), device=DEV)
+    scores, img_scores, lp = drn.wsddn_fwd_bwd(logits.to(DEV), 0, K, K, off.to(DEV), n_img, oh.to(DEV), dlogits=dl)
+    assert torch.allclose(scores.cpu(), sc.detach(), rtol=1e-5, atol=1e-9)
+    assert torch.allclose(img_scores.cpu(), O.predict_probs_img(sc.detach(), M_per), rtol=1e-5)
+    assert abs(float(lp.sum()) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert torch.allclose(dl.cpu()[:, :2 * K], lg.grad[:, :2 * K], rtol=1e-4, atol=1e-8)
+
+
+def _boxes(R, seed, W=200, H=150):
+    rs = np.random.RandomState(seed)
+    x0, y0 = rs.rand(R) * (W - 30), rs.rand(R) * (H - 30)
+    return torch.from_numpy(np.stack([x0, y0, x0 + 10 + rs.rand(R) * (W - x0 - 10), y0 + 10 + rs.rand(R) * (H - y0 - 10)],
+                                     1).astype(np.float32))
+
+
+@pytest.mark.parametrize("K,M_per,with_bg", [(20, [700], False), (6, [90, 77], True), (20, [2000], True)])
+def test_oicr_targets(drn, K, M_per, with_bg):
+    M, n_img = sum(M_per), len(M_per)
+    rs = np.random.RandomState(31)
+    ncol = K + 1 if with_bg else K
+    prev = torch.from_numpy(rs.rand(M, ncol).astype(np.float32))
+    props = _boxes(M, 32)
+    prev[5] = prev[3]
+    props[5] = props[3]  # exact tie -> first index
+    if with_bg:
+        pb = O.apply_deltas(torch.zeros(M, 4 * K), props)
+    else:
+        pb = props
+    gts = [torch.unique(torch.from_numpy(rs.randint(0, K, 3))).long() for _ in range(n_img)]
+    img_scores = torch.from_numpy(rs.rand(n_img, K).astype(np.float32))
+    cfg = O.OracleCfg(num_classes=K)
+    pgt = O.get_pgt(list(pb.split(M_per)), list(prev.split(M_per)), gts, img_scores, K)
+    rl, rw, rm, rb = [], [], [], []
+    for (b, c, s, w, idx), p in zip(pgt, props.split(M_per)):
+        gc, matched, gb = O.label_proposals(p, b, c, K, cfg)
+        rl.append(gc); rm.append(matched); rw.append(w[matched]); rb.append(gb)
+    gmax = 4
+    gcl = torch.zeros((n_img, gmax), dtype=torch.int32)
+    gcn = torch.zeros((n_img,), dtype=torch.int32)
+    for i, g in enumerate(gts):
+        gcl[i, : len(g)] = g.int()
+        gcn[i] = len(g)
+    off = torch.tensor([0] + list(np.cumsum(M_per)), dtype=torch.int32)
+    out = drn.oicr_targets(prev.to(DEV), pb.to(DEV), props.to(DEV), off.to(DEV), n_img, gcl.to(DEV), gcn.to(DEV),
+                           img_scores.to(DEV), K)
+    assert torch.equal(out["labels"].cpu().long(), torch.cat(rl))
+    assert torch.equal(out["matched"].cpu().long(), torch.cat(rm))
+    assert torch.equal(out["weights"].cpu(), torch.cat(rw))
+    assert torch.equal(out["gt_boxes"].cpu(), torch.cat(rb))
+    for i, (b, c, s, w, idx) in enumerate(pgt):
+        assert out["pgt_idx"][i, : len(idx)].cpu().tolist() == idx.tolist()
+
+
+@pytest.mark.parametrize("K,M", [(20, 2000), (5, 77), (80, 4000)])
+def test_softmax_ce(drn, K, M):
+    rs = np.random.RandomState(41)
+    ld, col0 = K + 12, 7
+    logits = torch.from_numpy(rs.standard_normal((M, ld)).astype(np.float32) * 3)
+    labels = torch.from_numpy(rs.randint(0, K + 1, M)).long()
+    labels[::17] = -1
+    w = torch.from_numpy(rs.rand(M).astype(np.float32))
+    w[::5] = 0
+    lg = logits.clone().requires_grad_(True)
+    loss = O.oicr_cls_loss(lg[:, col0: col0 + K + 1], labels, w)
+    loss.backward()
+    dl = torch.zeros((M, ld), device=DEV)
+    probs, l = drn.softmax_ce(logits.to(DEV), col0, K + 1, labels.int().to(DEV), w.to(DEV), dlogits=dl)
+    assert torch.allclose(probs.cpu(), F.softmax(logits[:, col0: col0 + K + 1], -1), rtol=1e-5, atol=1e-9)
+    assert abs(float(l) - float(loss)) <= 2e-5 * abs(float(loss))
+    assert torch.allclose(dl.cpu(), lg.grad, rtol=1e-4, atol=1e-9)
+    p2 = drn.mean_softmax(logits.to(DEV), [0, 3, 7], K + 1).cpu()
+    ref = sum(F.softmax(logits[:, c: c + K + 1], -1) for c in (0, 3, 7)) / 3
+    assert torch.allclose(p2, ref, rtol=1e-5, atol=1e-9)
+
+
+def test_apply_deltas_bit_exact(drn):
+    K = 6
+    props = _boxes(500, 51)
+    d = torch.from_numpy(np.random.RandomState(52).standard_normal((500, 4 * K + 3)).astype(np.float32))
+    d[0, 3 + 2] = 60.0  # hits the scale clamp
+    ref = O.apply_deltas(d[:, 3: 3 + 4 * K].contiguous(), props)
+    out = drn.apply_deltas(d.to(DEV), props.to(DEV), K, col0=3)  # deltas start at column 3 of a wider buffer
+    assert torch.allclose(out.cpu(), ref, rtol=2e-6, atol=1e-4)  # expf may differ by <= 2 ulp from the CPU's
+    z = drn.apply_deltas(None, props.to(DEV), K)
+    assert torch.equal(z.cpu(), O.apply_deltas(torch.zeros(500, 4 * K), props))  # zero-delta path: bit-exact
+
+
+def test_sgd_step(drn):
+    cfg = O.OracleCfg()
+    rs = np.random.RandomState(61)
+    sizes = [1000, 37, 5000, 64]
+    names = ["a.weight", "a.bias", "b.weight", "b.bias"]
+    p = {n: torch.from_numpy(rs.standard_normal(s).astype(np.float32)) for n, s in zip(names, sizes)}
+    flat = torch.cat([p[n] for n in names]).to(DEV)
+    mom = torch.zeros_like(flat)
+    segs = np.zeros(len(names), dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+    o = 0
+    for i, (n, s) in enumerate(zip(names, sizes)):
+        b = n.endswith("bias")
+        segs[i] = (o, s, cfg.base_lr * (cfg.bias_lr_factor if b else 1), cfg.weight_decay_bias if b else cfg.weight_decay)
+        o += s
+    segs_dev = torch.from_numpy(segs.view(np.uint8)).to(DEV)
+    opt = O.SGDState(cfg)
+    shadow = torch.zeros(flat.shape, dtype=torch.bfloat16, device=DEV)
+    for step in range(3):
+        g = {n: torch.from_numpy(rs.standard_normal(s).astype(np.float32)) for n, s in zip(names, sizes)}
+        opt.step(p, g)
+        drn.sgd_step(flat, mom, torch.cat([g[n] for n in names]).to(DEV), segs_dev, len(names), cfg.momentum, step == 0,
+                     shadow=shadow)
+        ref = torch.cat([p[n] for n in names])
+        assert torch.equal(flat.cpu(), ref)  # same fp32 op order => bit-exact
+        assert torch.equal(shadow.float().cpu(), ref.to(torch.bfloat16).float())
+
+
+# ------------------------------------------------------------------------------------------- inference tail
+def test_detect_golden_indices(drn):
+    d = G.load("ops")
+    b, s, c, rows = drn.detect_topk(torch.from_numpy(d["inf_boxes"]).to(DEV), torch.from_numpy(d["inf_scores"]).to(DEV),
+                                    (120, 200), 1e-5, 0.3, 100)
+    assert np.array_equal(rows.cpu().numpy(), d["inf_out_rows"])
+    assert np.array_equal(c.cpu().numpy(), d["inf_out_classes"])
+    assert np.array_equal(s.cpu().numpy(), d["inf_out_scores"])
+    assert np.array_equal(b.cpu().numpy(), d["inf_out_boxes"])
+
+
+@pytest.mark.parametrize("R,K,thr", [(2000, 20, 0.3), (500, 5, 0.5), (1, 3, 0.3), (64, 20, 0.8)])
+def test_detect_random(drn, R, K, thr):
+    rs = np.random.RandomState(71)
+    props = _boxes(R, 72)
+    boxes = O.apply_deltas(torch.from_numpy(rs.standard_normal((R, 4 * K)).astype(np.float32) * 0.5), props)
+    scores = F.softmax(torch.from_numpy(rs.standard_normal((R, K + 1)).astype(np.float32) * 3), 1)
+    if R > 10:
+        scores[7] = scores[3]
+        boxes[7] = boxes[3]
+    rb, rs_, rc, rr = O.fast_rcnn_inference_single_image(boxes.clone(), scores.clone(), (150, 200), 1e-5, thr, 100)
+    b, s, c, rows = drn.detect_topk(boxes.to(DEV), scores.to(DEV), (150, 200), 1e-5, thr, 100)
+    assert torch.equal(rows.cpu(), rr) and torch.equal(c.cpu(), rc)
+    assert torch.equal(s.cpu(), rs_) and torch.equal(b.cpu(), rb)
+
+
+def test_detect_empty_and_all_filtered(drn):
+    boxes = torch.zeros((10, 8)) + torch.tensor([0, 0, 5, 5, 0, 0, 5, 5.0])
+    scores = torch.zeros((10, 3))
+    scores[:, 2] = 1.0  # everything is background => no candidates
+    b, s, c, rows = drn.detect_topk(boxes.to(DEV), scores.to(DEV), (20, 20), 1e-5, 0.3, 100)
+    assert b.shape == (0, 4) and s.numel() == 0 and rows.numel() == 0
