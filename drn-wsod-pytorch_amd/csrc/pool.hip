@@ -32,6 +32,8 @@ __global__ void preprocess_kernel(const float* __restrict__ img, int C, int H, i
   }
 }
 
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
+
 // one thread = one 16-B channel vector of one output pixel
 template <int DT>
 __global__ void maxpool2x2_kernel(const char* __restrict__ x, char* __restrict__ y, int Nb, int H, int W, int C,
@@ -46,38 +48,36 @@ __global__ void maxpool2x2_kernel(const char* __restrict__ x, char* __restrict__
     const int wo = t % Wo; t /= Wo;
     const int ho = t % Ho;
     const int n = t / Ho;
-    float best[V];
-#pragma unroll
-    for (int e = 0; e < V; ++e) best[e] = -FLT_MAX;
-#pragma unroll
-    for (int dh = 0; dh < 2; ++dh)
-#pragma unroll
-      for (int dw = 0; dw < 2; ++dw) {
-        const int h = ho * stride + dh, w = wo * stride + dw;
-        const i32x4_t v = *(const i32x4_t*)(x + (((long)(n * H + h) * W + w) * C + c) * ES);
-        if constexpr (DT == DRN_BF16) {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const uint32_t u = (uint32_t)v[e];
-            best[2 * e] = fmaxf(best[2 * e], __builtin_bit_cast(float, u << 16));
-            best[2 * e + 1] = fmaxf(best[2 * e + 1], __builtin_bit_cast(float, u & 0xffff0000u));
-          }
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e) best[e] = fmaxf(best[e], __builtin_bit_cast(float, v[e]));
-        }
-      }
-    i32x4_t o;
-    if constexpr (DT == DRN_BF16) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e)
-        o[e] = (int)((__builtin_bit_cast(uint32_t, best[2 * e]) >> 16) |
-                     (__builtin_bit_cast(uint32_t, best[2 * e + 1]) & 0xffff0000u));
+    const char* p00 = x + (((long)(n * H + ho * stride) * W + wo * stride) * C + c) * ES;
+    const long dw = (long)C * ES, dh = (long)W * C * ES;
+    char* dst = y + (((long)(n * Ho + ho) * Wo + wo) * C + c) * ES;
+    if constexpr (DT == DRN_F32) {
+      const f32x4_t a = *(const f32x4_t*)p00, b = *(const f32x4_t*)(p00 + dw);
+      const f32x4_t d = *(const f32x4_t*)(p00 + dh), e = *(const f32x4_t*)(p00 + dh + dw);
+      f32x4_t o;
+      o.x = fmaxf(fmaxf(a.x, b.x), fmaxf(d.x, e.x));
+      o.y = fmaxf(fmaxf(a.y, b.y), fmaxf(d.y, e.y));
+      o.z = fmaxf(fmaxf(a.z, b.z), fmaxf(d.z, e.z));
+      o.w = fmaxf(fmaxf(a.w, b.w), fmaxf(d.w, e.w));
+      *(f32x4_t*)dst = o;
     } else {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(int, best[e]);
+      const u32x4_t a = *(const u32x4_t*)p00, b = *(const u32x4_t*)(p00 + dw);
+      const u32x4_t d = *(const u32x4_t*)(p00 + dh), e = *(const u32x4_t*)(p00 + dh + dw);
+      auto mx = [](unsigned ua, unsigned ub, unsigned ud, unsigned ue) -> unsigned {
+        // two packed bf16 per dword; bf16 -> f32 is a shift, the max of bf16 values is again bf16
+        const float lo = fmaxf(fmaxf(__builtin_bit_cast(float, ua << 16), __builtin_bit_cast(float, ub << 16)),
+                               fmaxf(__builtin_bit_cast(float, ud << 16), __builtin_bit_cast(float, ue << 16)));
+        const float hi = fmaxf(fmaxf(__builtin_bit_cast(float, ua & 0xffff0000u), __builtin_bit_cast(float, ub & 0xffff0000u)),
+                               fmaxf(__builtin_bit_cast(float, ud & 0xffff0000u), __builtin_bit_cast(float, ue & 0xffff0000u)));
+        return (__builtin_bit_cast(unsigned, lo) >> 16) | (__builtin_bit_cast(unsigned, hi) & 0xffff0000u);
+      };
+      u32x4_t o;
+      o.x = mx(a.x, b.x, d.x, e.x);
+      o.y = mx(a.y, b.y, d.y, e.y);
+      o.z = mx(a.z, b.z, d.z, e.z);
+      o.w = mx(a.w, b.w, d.w, e.w);
+      *(u32x4_t*)dst = o;
     }
-    *(i32x4_t*)(y + (((long)(n * Ho + ho) * Wo + wo) * C + c) * ES) = o;
   }
 }
 

@@ -1,0 +1,233 @@
+"""Trainer-side pieces the hot path sits inside:
+
+  build_optimizer / FusedSGD   torch.optim.SGD with the per-parameter groups of detectron2/solver/build.py:93-137
+                               (bias lr x BIAS_LR_FACTOR, bias wd = WEIGHT_DECAY_BIAS), as ONE HIP kernel over the
+                               head engine's flat parameter arena (fp32 master + momentum).
+  WarmupMultiStepLR            detectron2/solver/lr_scheduler.py:16-49
+  DataParallel                 replaces DistributedDataParallel(broadcast_buffers=False, find_unused_parameters=True)
+                               of detectron2/engine/defaults.py:279-282: one process per GPU, gradients of the flat
+                               arena are all-reduced (RCCL over xGMI) on a side stream, bucketed so that the small
+                               tensors and then each fc6-gradient slab are on the wire while the next dW slab is
+                               still being computed; unused bbox_pred parameters never enter a bucket.
+  Trainer.run_step             projects/WSL/tools/train_net.py:65-117 (ITER_SIZE accumulation, loss dict keys) without
+                               the per-iteration host syncs (anomaly check / metric gather are deferred)."""
+import bisect
+import math
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import ops
+from ._cabi import DrnError
+from .events import EventStorage
+
+
+class FusedSGD:
+    def __init__(self, model, base_lr, momentum, weight_decay, bias_lr_factor=1.0, weight_decay_bias=None,
+                 weight_decay_norm=0.0, nesterov=False):
+        if nesterov:
+            raise DrnError("nesterov SGD is not used by any DRN-WSOD config")
+        self.model = model
+        self.engine = model.roi_heads._engine
+        extra = [n for n, p in model.named_parameters() if p.requires_grad and not n.startswith("roi_heads.")]
+        if extra:
+            raise DrnError("trainable backbone parameters (%s ...): conv backward is not built yet; use "
+                           "MODEL.BACKBONE.FREEZE_AT=5 as every shipped config does" % extra[0])
+        self.momentum = momentum
+        wdb = weight_decay if weight_decay_bias is None else weight_decay_bias
+        self.engine.ensure(next(model.roi_heads.parameters()).device)
+        self.param_groups = []
+        for name, p, off, n, used in self.engine.segments:
+            is_bias = name.endswith(".bias")
+            self.param_groups.append({"params": [p], "name": name, "off": off, "cnt": n, "used": used,
+                                      "lr": base_lr * (bias_lr_factor if is_bias else 1.0),
+                                      "initial_lr": base_lr * (bias_lr_factor if is_bias else 1.0),
+                                      "weight_decay": wdb if is_bias else weight_decay, "momentum": momentum})
+        self._mom = None
+        self._segs_key = None
+        self._segs_dev = None
+        self._steps = 0
+
+    def _segs(self):
+        groups = [g for g in self.param_groups if g["used"]]
+        key = tuple((g["lr"], g["weight_decay"]) for g in groups)
+        if key != self._segs_key:
+            arr = np.zeros(len(groups), dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+            for i, g in enumerate(groups):
+                arr[i] = (g["off"], g["cnt"], g["lr"], g["weight_decay"])
+            self._segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(self.engine.arena_w.device)
+            self._segs_key, self._nseg = key, len(groups)
+        return self._segs_dev, self._nseg
+
+    def zero_grad(self, set_to_none=True):
+        for g in self.param_groups:
+            for p in g["params"]:
+                p.grad = None
+        self.engine._grads_valid = False
+
+    def step(self, grad_scale=1.0):
+        e = self.engine
+        if not e._grads_valid:
+            raise DrnError("optimizer.step() before any backward()")
+        if self._mom is None:
+            self._mom = torch.zeros_like(e.arena_w)
+        segs, nseg = self._segs()
+        ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, grad_scale)
+        self._steps += 1
+        e.mark_dirty()
+
+    def state_dict(self):
+        return {"momentum_buffer": self._mom, "steps": self._steps,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
+
+    def load_state_dict(self, sd):
+        self._mom, self._steps = sd["momentum_buffer"], sd["steps"]
+        for g, s in zip(self.param_groups, sd["param_groups"]):
+            g.update(s)
+        self._segs_key = None
+
+
+def build_optimizer(cfg, model):
+    """detectron2/solver/build.py:93-137."""
+    return FusedSGD(model, cfg.SOLVER.BASE_LR, cfg.SOLVER.MOMENTUM, cfg.SOLVER.WEIGHT_DECAY, cfg.SOLVER.BIAS_LR_FACTOR,
+                    cfg.SOLVER.WEIGHT_DECAY_BIAS, cfg.SOLVER.WEIGHT_DECAY_NORM, cfg.SOLVER.NESTEROV)
+
+
+class WarmupMultiStepLR:
+    """detectron2/solver/lr_scheduler.py:16-49 + _get_warmup_factor_at_iter :83-113."""
+
+    def __init__(self, optimizer, milestones, gamma=0.1, warmup_factor=0.001, warmup_iters=1000, warmup_method="linear",
+                 last_epoch=-1):
+        if not list(milestones) == sorted(milestones):
+            raise ValueError("Milestones should be a list of increasing integers. Got {}".format(milestones))
+        self.optimizer, self.milestones, self.gamma = optimizer, list(milestones), gamma
+        self.warmup_factor, self.warmup_iters, self.warmup_method = warmup_factor, warmup_iters, warmup_method
+        self.base_lrs = [g["initial_lr"] for g in optimizer.param_groups]
+        self.last_epoch = last_epoch
+        self.step()
+
+    def _warm(self, it):
+        if it >= self.warmup_iters:
+            return 1.0
+        if self.warmup_method == "constant":
+            return self.warmup_factor
+        alpha = it / self.warmup_iters
+        return self.warmup_factor * (1 - alpha) + alpha
+
+    def get_lr(self):
+        f = self._warm(self.last_epoch)
+        return [b * f * self.gamma ** bisect.bisect_right(self.milestones, self.last_epoch) for b in self.base_lrs]
+
+    def step(self):
+        self.last_epoch += 1
+        for g, lr in zip(self.optimizer.param_groups, self.get_lr()):
+            g["lr"] = lr
+
+
+def build_lr_scheduler(cfg, optimizer):
+    assert cfg.SOLVER.LR_SCHEDULER_NAME == "WarmupMultiStepLR"
+    return WarmupMultiStepLR(optimizer, cfg.SOLVER.STEPS, cfg.SOLVER.GAMMA, warmup_factor=cfg.SOLVER.WARMUP_FACTOR,
+                             warmup_iters=cfg.SOLVER.WARMUP_ITERS, warmup_method=cfg.SOLVER.WARMUP_METHOD)
+
+
+class DataParallel:
+    """Gradient exchange of the data-parallel step.  Images shard across ranks (rank g takes elements g, g+W, ...
+    of the stream, detectron2/data/samplers/distributed_sampler.py:43-45); nothing crosses GPUs in forward; per
+    optimizer step the trainable gradients are summed over ranks and the SGD kernel applies 1/W (= DDP's mean).
+    Buckets follow the order gradients become final in the explicit backward: [all small tensors] then the fc6
+    weight gradient in `slabs` row slabs, each launched on a side stream as soon as its dW GEMM has been queued."""
+
+    def __init__(self, model, process_group=None, slabs=4, backend_stream=True):
+        self.model = model
+        self.engine = model.roi_heads._engine
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        self.engine.fc1_grad_slabs = slabs if self.world > 1 else 1
+        self.engine.grad_ready_hook = self._on_ready if self.world > 1 else None
+        self._use_stream = backend_stream and torch.cuda.is_available()
+        self._comm = None
+        self._pending = []
+
+    def broadcast_parameters(self, src=0):
+        if self.world > 1:
+            self.engine.ensure(next(self.model.roi_heads.parameters()).device)
+            dist.broadcast(self.engine.arena_w, src, group=self.group)
+            self.engine.mark_dirty()
+
+    def _reduce(self, t):
+        if self._use_stream and t.is_cuda:
+            if self._comm is None:
+                self._comm = torch.cuda.Stream()
+            ev = torch.cuda.Event()
+            ev.record(torch.cuda.current_stream())
+            self._comm.wait_event(ev)
+            with torch.cuda.stream(self._comm):
+                dist.all_reduce(t, group=self.group)
+        else:
+            dist.all_reduce(t, group=self.group)
+
+    def _on_ready(self, what):
+        e = self.engine
+        if what == "small":
+            o_fc1, _ = e._seg["fc1.weight"]
+            self._reduce(e.arena_g[:o_fc1])  # arena order: heads, fc2, fc1.bias come before fc1.weight
+        else:
+            _, r0, r1 = what
+            o, n = e._seg["fc1.weight"]
+            k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
+            self._reduce(e.arena_g[o + r0 * k1: o + r1 * k1])
+
+    def finish(self):
+        """make the optimizer stream wait for the exchanged gradients"""
+        if self.world > 1 and self._comm is not None:
+            torch.cuda.current_stream().wait_stream(self._comm)
+
+    @property
+    def grad_scale(self):
+        return 1.0 / self.world
+
+
+class Trainer:
+    """projects/WSL/tools/train_net.py:41-117 (run_step) over detectron2/engine/train_loop.py:170-289."""
+
+    def __init__(self, cfg, model, data_loader_iter, optimizer=None, scheduler=None, parallel=None):
+        self.cfg, self.model = cfg, model
+        self._it = data_loader_iter
+        self.optimizer = optimizer or build_optimizer(cfg, model)
+        self.scheduler = scheduler
+        self.dp = parallel or DataParallel(model)
+        self.iter_size = cfg.WSL.ITER_SIZE
+        self.iter = self.start_iter = 0
+        self.storage = EventStorage(0)
+        self.last_losses = None
+
+    def run_step(self):
+        assert self.model.training, "[Trainer] model was changed to eval mode!"
+        while True:  # train_net.py:74-81: re-draw batches that contain an image without GT
+            data = next(self._it)
+            if all(len(x["instances"]) > 0 for x in data):
+                break
+        with self.storage:
+            loss_dict = self.model(data)
+        losses = sum(loss_dict.values())
+        if self.iter == self.start_iter:
+            self.optimizer.zero_grad()
+        (losses / self.iter_size).backward()
+        if self.iter % self.iter_size == 0:
+            self.dp.finish()
+            self.optimizer.step(self.dp.grad_scale)
+            self.optimizer.zero_grad()
+            if self.scheduler is not None:
+                self.scheduler.step()
+        self.last_losses = loss_dict  # device scalars; float() them only when you need to look (no per-iter sync)
+        self.iter += 1
+        self.storage.step()
+        return loss_dict
+
+    def check_finite(self):
+        """SimpleTrainer._detect_anomaly (train_loop.py:252-258), on demand instead of every iteration."""
+        if self.last_losses is not None:
+            tot = float(sum(v.detach() for v in self.last_losses.values()))
+            if not math.isfinite(tot):
+                raise FloatingPointError("Loss became infinite or NaN at iteration={}!".format(self.iter))

@@ -1,0 +1,258 @@
+"""The `detectron2.layers` operator surface this path uses (detectron2/layers/__init__.py:2-11):
+Conv2d (+norm +activation), FrozenBatchNorm2d, Linear, ROIAlign, ShapeSpec, CNNBlockBase, get_norm,
+cat, nonzero_tuple — same names, constructor arguments and state_dict keys, executing on the HIP
+kernels.  Feature maps travel NHWC in the compute dtype; the [N,C,H,W] tensors handed across module
+boundaries are channels-last views of those buffers (shape-compatible with the reference)."""
+from collections import namedtuple
+
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from . import compute_dtype, ops
+from ._cabi import DrnError
+
+
+class ShapeSpec(namedtuple("_ShapeSpec", ["channels", "height", "width", "stride"])):
+    """detectron2/layers/shape_spec.py."""
+
+    def __new__(cls, *, channels=None, height=None, width=None, stride=None):
+        return super().__new__(cls, channels, height, width, stride)
+
+
+def cat(tensors, dim=0):
+    """detectron2/layers/wrappers.py:14-22."""
+    assert isinstance(tensors, (list, tuple))
+    if len(tensors) == 1:
+        return tensors[0]
+    return torch.cat(tensors, dim)
+
+
+def nonzero_tuple(x):
+    if x.dim() == 0:
+        return x.unsqueeze(0).nonzero().unbind(1)
+    return x.nonzero().unbind(1)
+
+
+def to_nhwc(x, dtype=None, cpad_to=None):
+    """[N,C,H,W] (any memory format) -> contiguous [N,H,W,Cp] in `dtype` (plumbing copy; free when x
+    already is a channels-last view of an NHWC buffer)."""
+    dtype = dtype or compute_dtype()
+    y = x.permute(0, 2, 3, 1)
+    c = y.shape[-1]
+    if cpad_to and c % cpad_to:
+        cp = (c + cpad_to - 1) // cpad_to * cpad_to
+        out = torch.zeros(y.shape[:-1] + (cp,), dtype=dtype, device=x.device)
+        out[..., :c] = y
+        return out
+    return y.to(dtype).contiguous()
+
+
+def from_nhwc(y):
+    """contiguous [N,H,W,C] -> [N,C,H,W] channels-last view (no copy)."""
+    return y.permute(0, 3, 1, 2)
+
+
+class FrozenBatchNorm2d(nn.Module):
+    """detectron2/layers/batch_norm.py:14-124: fixed statistics + affine as BUFFERS named weight, bias,
+    running_mean, running_var.  On the hot path it is folded into the preceding Conv2d's epilogue."""
+
+    _version = 3
+
+    def __init__(self, num_features, eps=1e-5):
+        super().__init__()
+        self.num_features = num_features
+        self.eps = eps
+        self.register_buffer("weight", torch.ones(num_features))
+        self.register_buffer("bias", torch.zeros(num_features))
+        self.register_buffer("running_mean", torch.zeros(num_features))
+        self.register_buffer("running_var", torch.ones(num_features) - eps)
+
+    def folded(self):
+        """(scale, bias) of y = x*scale + bias, batch_norm.py:46-50."""
+        scale = self.weight * (self.running_var + self.eps).rsqrt()
+        return scale.float().contiguous(), (self.bias - self.running_mean * scale).float().contiguous()
+
+    def forward(self, x):
+        scale, bias = self.folded()
+        return x * scale.reshape(1, -1, 1, 1).to(x.dtype) + bias.reshape(1, -1, 1, 1).to(x.dtype)
+
+    def __repr__(self):
+        return "FrozenBatchNorm2d(num_features={}, eps={})".format(self.num_features, self.eps)
+
+    @classmethod
+    def convert_frozen_batchnorm(cls, module):
+        """batch_norm.py:92-124: recursively replace BatchNorm layers by FrozenBatchNorm2d."""
+        bn_module = (nn.modules.batchnorm.BatchNorm2d, nn.modules.batchnorm.SyncBatchNorm)
+        res = module
+        if isinstance(module, bn_module):
+            res = cls(module.num_features)
+            if module.affine:
+                res.weight.data = module.weight.data.clone().detach()
+                res.bias.data = module.bias.data.clone().detach()
+            res.running_mean.data = module.running_mean.data
+            res.running_var.data = module.running_var.data
+            res.eps = module.eps
+        else:
+            for name, child in module.named_children():
+                new_child = cls.convert_frozen_batchnorm(child)
+                if new_child is not child:
+                    res.add_module(name, new_child)
+        return res
+
+
+def get_norm(norm, out_channels):
+    """detectron2/layers/batch_norm.py:127-149 (the WSL path only ever asks for "FrozenBN" or none)."""
+    if isinstance(norm, str):
+        if len(norm) == 0:
+            return None
+        if norm != "FrozenBN":
+            raise DrnError("norm '%s' is off the DRN-WSOD hot path (only FrozenBN / none are built)" % norm)
+        return FrozenBatchNorm2d(out_channels)
+    return norm(out_channels)
+
+
+class Conv2d(nn.Conv2d):
+    """detectron2/layers/wrappers.py:41-99: torch.nn.Conv2d + `norm` + `activation`; forward = conv -> norm ->
+    activation.  Runs as ONE implicit-GEMM MFMA kernel with the frozen-BN affine, an optional residual add and
+    the ReLU in the epilogue."""
+
+    def __init__(self, *args, **kwargs):
+        norm = kwargs.pop("norm", None)
+        activation = kwargs.pop("activation", None)
+        super().__init__(*args, **kwargs)
+        self.norm = norm
+        self.activation = activation
+        self._pack_key = None
+        self._pack = None
+        assert self.groups == 1 and self.kernel_size[0] == self.kernel_size[1], "off the DRN-WSOD path"
+        assert self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]
+
+    def cin_pad(self, dtype):
+        q = 8 if dtype == torch.bfloat16 else 4
+        return (self.in_channels + q - 1) // q * q
+
+    def packed(self, dtype):
+        """(w [Cout, ldw] K-major with k = (kh*KW + kw)*Cin_pad + ci, scale [Cout], bias [Cout]) cached until
+        a parameter / buffer changes (load_state_dict bumps _version)."""
+        srcs = [self.weight] + ([self.bias] if self.bias is not None else [])
+        if self.norm is not None:
+            srcs += [self.norm.weight, self.norm.bias, self.norm.running_mean, self.norm.running_var]
+        key = (dtype, self.weight.device) + tuple((t.data_ptr(), t._version) for t in srcs)
+        if key != self._pack_key:
+            with torch.no_grad():
+                cout, cin, kh, kw = self.weight.shape
+                cp = self.cin_pad(dtype)
+                w = torch.zeros((cout, kh, kw, cp), dtype=torch.float32, device=self.weight.device)
+                w[..., :cin] = self.weight.detach().float().permute(0, 2, 3, 1)
+                k = kh * kw * cp
+                wp = torch.zeros((cout, ops.kpad(k, dtype)), dtype=dtype, device=w.device)
+                wp[:, :k] = w.reshape(cout, k).to(dtype)
+                if self.norm is not None:
+                    assert isinstance(self.norm, FrozenBatchNorm2d), "only FrozenBN is built on this path"
+                    scale, bias = self.norm.folded()
+                    if self.bias is not None:
+                        bias = bias + self.bias.detach().float() * scale
+                else:
+                    scale = None
+                    bias = self.bias.detach().float().contiguous() if self.bias is not None else None
+                self._pack = (wp, scale, bias)
+                self._pack_key = key
+        return self._pack
+
+    def run_nhwc(self, x, residual=None, relu=False):
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            raise DrnError("conv dgrad/wgrad are not built yet: run the backbone frozen (MODEL.BACKBONE.FREEZE_AT=5, "
+                           "as every shipped projects/WSL config does) — see DESIGN.md 'out of scope this round'")
+        wp, scale, bias = self.packed(x.dtype)
+        assert x.shape[-1] == self.cin_pad(x.dtype), (x.shape, self.in_channels)
+        return ops.conv2d_nhwc(x, wp, self.out_channels, self.kernel_size[0], self.kernel_size[1], self.stride[0],
+                               self.padding[0], self.dilation[0], scale, bias, residual, relu)
+
+    def forward(self, x):
+        dtype = compute_dtype()
+        fuse_relu = self.activation in (F.relu, F.relu_)
+        y = self.run_nhwc(to_nhwc(x, dtype, 8 if dtype == torch.bfloat16 else 4), None, fuse_relu)
+        y = from_nhwc(y)
+        if self.activation is not None and not fuse_relu:
+            y = self.activation(y)
+        return y
+
+
+class Linear(nn.Linear):
+    """torch.nn.Linear (detectron2/layers/wrappers.py re-exports it).  Standalone forward runs the MFMA GEMM +
+    bias epilogue; inside the ROI heads the fused head engine reads the parameters directly."""
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            raise DrnError("stand-alone Linear has no autograd on this path; train through OICRROIHeads")
+        dtype = compute_dtype()
+        m, k = x.shape
+        kp = ops.kpad(k, dtype)
+        a = torch.zeros((m, kp), dtype=dtype, device=x.device)
+        a[:, :k] = x
+        w = torch.zeros((self.out_features, kp), dtype=dtype, device=x.device)
+        w[:, :k] = self.weight.detach()
+        out = torch.zeros((m, self.out_features), dtype=torch.float32, device=x.device)
+        ops.bias_act_fwd(ops.gemm_nt(a, w, m, self.out_features, kp), m, self.out_features,
+                         self.bias.detach().float().contiguous() if self.bias is not None else None, False, out=out)
+        return out
+
+
+class ROIAlign(nn.Module):
+    """detectron2/layers/roi_align.py:63-117."""
+
+    def __init__(self, output_size, spatial_scale, sampling_ratio, aligned=True):
+        super().__init__()
+        self.output_size = output_size if isinstance(output_size, (tuple, list)) else (output_size, output_size)
+        self.spatial_scale = spatial_scale
+        self.sampling_ratio = sampling_ratio
+        self.aligned = aligned
+
+    def forward(self, input, rois):
+        assert rois.dim() == 2 and rois.size(1) == 5
+        p = self.output_size[0]
+        x = to_nhwc(input, input.dtype if input.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+        out = ops.roi_pool_nhwc(x, rois.float().contiguous(), None, p, self.spatial_scale, mode=1,
+                                sampling_ratio=self.sampling_ratio, aligned=self.aligned)
+        c = input.shape[1]
+        return out[:, : c * p * p].reshape(rois.shape[0], c, p, p)
+
+    def __repr__(self):
+        return "ROIAlign(output_size={}, spatial_scale={}, sampling_ratio={}, aligned={})".format(
+            self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
+
+
+class RoIPool(nn.Module):
+    """torchvision.ops.RoIPool interface (constructed at detectron2/modeling/poolers.py:162-165)."""
+
+    def __init__(self, output_size, spatial_scale):
+        super().__init__()
+        self.output_size = output_size if isinstance(output_size, (tuple, list)) else (output_size, output_size)
+        self.spatial_scale = spatial_scale
+
+    def forward(self, input, rois):
+        p = self.output_size[0]
+        x = to_nhwc(input, input.dtype if input.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+        out = ops.roi_pool_nhwc(x, rois.float().contiguous(), None, p, self.spatial_scale, mode=0)
+        c = input.shape[1]
+        return out[:, : c * p * p].reshape(rois.shape[0], c, p, p)
+
+    def __repr__(self):
+        return "RoIPool(output_size={}, spatial_scale={})".format(self.output_size, self.spatial_scale)
+
+
+class CNNBlockBase(nn.Module):
+    """detectron2/layers/blocks.py:12-48."""
+
+    def __init__(self, in_channels, out_channels, stride):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.stride = stride
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        FrozenBatchNorm2d.convert_frozen_batchnorm(self)
+        return self

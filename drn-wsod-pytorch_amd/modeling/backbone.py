@@ -1,0 +1,334 @@
+"""DRN-WSOD backbones behind the reference's registry names:
+`build_ws_resnet_backbone` (projects/WSL/wsl/modeling/backbone/resnet_ws.py:616-703; BasicStem :357-416,
+BasicBlock :32-112, BottleneckBlock :115-237, ResNet :419-600) and `build_vgg_backbone`
+(projects/WSL/wsl/modeling/backbone/vgg.py:125-244).  Same module tree => same state_dict keys
+(`backbone.stem.conv1.norm.weight`, `backbone.res4.2.conv2.weight`, `backbone.plain5.0.conv3.bias`, ...).
+
+Execution is MI355X-first: every block runs NHWC, each conv is one implicit-GEMM MFMA launch with the
+FrozenBN affine + residual add + ReLU fused in its epilogue, pools are vectorised NHWC kernels; the
+[N,C,H,W] tensors returned by forward() are channels-last views of those buffers."""
+import numpy as np
+import torch
+from torch import nn
+
+from .. import compute_dtype, ops
+from ..layers import CNNBlockBase, Conv2d, FrozenBatchNorm2d, ShapeSpec, from_nhwc, get_norm, to_nhwc
+from ..registry import BACKBONE_REGISTRY
+
+__all__ = ["Backbone", "BasicStem", "BasicBlock", "BottleneckBlock", "ResNet", "PlainBlock", "VGG16",
+           "build_ws_resnet_backbone", "build_vgg_backbone", "build_backbone"]
+
+
+def c2_msra_fill(module):
+    """fvcore.nn.weight_init.c2_msra_fill."""
+    nn.init.kaiming_normal_(module.weight, mode="fan_out", nonlinearity="relu")
+    if module.bias is not None:
+        nn.init.constant_(module.bias, 0)
+
+
+class Backbone(nn.Module):
+    """detectron2/modeling/backbone/backbone.py."""
+
+    @property
+    def size_divisibility(self):
+        return 0
+
+    def output_shape(self):
+        return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
+                for name in self._out_features}
+
+    def _input_nhwc(self, x):
+        """accept an ImageList-produced padded NHWC buffer (fast path) or any [N,3,H,W] tensor"""
+        dtype = compute_dtype()
+        nhwc = getattr(x, "_drn_nhwc", None)
+        if nhwc is not None and nhwc.dtype == dtype:
+            return nhwc
+        return to_nhwc(x, dtype, 8 if dtype == torch.bfloat16 else 4)
+
+
+class BasicStem(CNNBlockBase):
+    def __init__(self, in_channels=3, out_channels=64, norm="BN"):
+        super().__init__(in_channels, out_channels, 4)
+        self.in_channels = in_channels
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=3, stride=2, padding=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        self.conv3 = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        for l in (self.conv1, self.conv2, self.conv3):
+            c2_msra_fill(l)
+        self.pool = nn.MaxPool2d(kernel_size=2, stride=2, padding=0)
+
+    def forward_nhwc(self, x):
+        x = self.conv1.run_nhwc(x, relu=True)
+        x = self.conv2.run_nhwc(x, relu=True)
+        x = self.conv3.run_nhwc(x, relu=True)
+        return ops.maxpool2x2_nhwc(x, 2)
+
+    def forward(self, x):
+        return from_nhwc(self.forward_nhwc(to_nhwc(x, compute_dtype(), 8 if compute_dtype() == torch.bfloat16 else 4)))
+
+
+class BasicBlock(CNNBlockBase):
+    def __init__(self, in_channels, out_channels, *, stride=1, norm="BN", dilation=1, has_pool=False):
+        super().__init__(in_channels, out_channels, stride)
+        self.has_pool = has_pool
+        self.pool_stride = stride
+        if in_channels != out_channels:
+            self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False,
+                                   norm=get_norm(norm, out_channels))
+        else:
+            self.shortcut = None
+        self.conv1 = Conv2d(in_channels, out_channels, kernel_size=3, stride=1, padding=dilation, bias=False,
+                            dilation=dilation, norm=get_norm(norm, out_channels))
+        self.conv2 = Conv2d(out_channels, out_channels, kernel_size=3, stride=1, padding=dilation, bias=False,
+                            dilation=dilation, norm=get_norm(norm, out_channels))
+        for layer in (self.conv1, self.conv2, self.shortcut):
+            if layer is not None:
+                c2_msra_fill(layer)
+        if self.has_pool:
+            self.pool = nn.MaxPool2d(kernel_size=2, stride=self.pool_stride, padding=0)
+
+    def forward_nhwc(self, x):
+        out = self.conv1.run_nhwc(x, relu=True)
+        sc = self.shortcut.run_nhwc(x) if self.shortcut is not None else x
+        out = self.conv2.run_nhwc(out, residual=sc, relu=True)  # out += shortcut; relu_
+        if self.has_pool:
+            out = ops.maxpool2x2_nhwc(out, self.pool_stride)
+        return out
+
+    def forward(self, x):
+        return from_nhwc(self.forward_nhwc(to_nhwc(x)))
+
+
+class BottleneckBlock(CNNBlockBase):
+    def __init__(self, in_channels, out_channels, *, bottleneck_channels, stride=1, num_groups=1, norm="BN",
+                 stride_in_1x1=False, dilation=1, has_pool=False):
+        super().__init__(in_channels, out_channels, stride)
+        assert num_groups == 1, "grouped convs are off the DRN-WSOD path"
+        self.has_pool = has_pool
+        self.pool_stride = stride
+        if in_channels != out_channels:
+            self.shortcut = Conv2d(in_channels, out_channels, kernel_size=1, stride=1, bias=False,
+                                   norm=get_norm(norm, out_channels))
+        else:
+            self.shortcut = None
+        # every conv stride is forced to 1 (resnet_ws.py:148-150); down-sampling is the 2x2 pool below
+        self.conv1 = Conv2d(in_channels, bottleneck_channels, kernel_size=1, stride=1, bias=False,
+                            norm=get_norm(norm, bottleneck_channels))
+        self.conv2 = Conv2d(bottleneck_channels, bottleneck_channels, kernel_size=3, stride=1, padding=dilation,
+                            bias=False, groups=num_groups, dilation=dilation, norm=get_norm(norm, bottleneck_channels))
+        self.conv3 = Conv2d(bottleneck_channels, out_channels, kernel_size=1, bias=False,
+                            norm=get_norm(norm, out_channels))
+        for layer in (self.conv1, self.conv2, self.conv3, self.shortcut):
+            if layer is not None:
+                c2_msra_fill(layer)
+        if self.has_pool:
+            self.pool = nn.MaxPool2d(kernel_size=2, stride=self.pool_stride, padding=0)
+
+    def forward_nhwc(self, x):
+        out = self.conv1.run_nhwc(x, relu=True)
+        out = self.conv2.run_nhwc(out, relu=True)
+        sc = self.shortcut.run_nhwc(x) if self.shortcut is not None else x
+        out = self.conv3.run_nhwc(out, residual=sc, relu=True)
+        if self.has_pool:
+            out = ops.maxpool2x2_nhwc(out, self.pool_stride)
+        return out
+
+    def forward(self, x):
+        return from_nhwc(self.forward_nhwc(to_nhwc(x)))
+
+
+class ResNet(Backbone):
+    def __init__(self, stem, stages, num_classes=None, out_features=None):
+        super().__init__()
+        assert num_classes is None, "classification head is off the DRN-WSOD path"
+        self.stem = stem
+        self.num_classes = num_classes
+        current_stride = self.stem.stride
+        self._out_feature_strides = {"stem": current_stride}
+        self._out_feature_channels = {"stem": self.stem.out_channels}
+        self.stages_and_names = []
+        for i, blocks in enumerate(stages):
+            assert len(blocks) > 0, len(blocks)
+            name = "res" + str(i + 2)
+            stage = nn.Sequential(*blocks)
+            self.add_module(name, stage)
+            self.stages_and_names.append((stage, name))
+            self._out_feature_strides[name] = current_stride = int(current_stride * np.prod([k.stride for k in blocks]))
+            self._out_feature_channels[name] = blocks[-1].out_channels
+        if out_features is None:
+            out_features = [name]
+        self._out_features = out_features
+        children = [x[0] for x in self.named_children()]
+        for f in self._out_features:
+            assert f in children, "Available children: {}".format(", ".join(children))
+
+    def forward(self, x):
+        assert x.dim() == 4, "ResNet takes an input of shape (N, C, H, W). Got {} instead!".format(x.shape)
+        outputs = {}
+        with torch.no_grad() if not any(p.requires_grad for p in self.parameters()) else torch.enable_grad():
+            y = self.stem.forward_nhwc(self._input_nhwc(x))
+            if "stem" in self._out_features:
+                outputs["stem"] = from_nhwc(y)
+            for stage, name in self.stages_and_names:
+                for block in stage:
+                    y = block.forward_nhwc(y)
+                if name in self._out_features:
+                    outputs[name] = from_nhwc(y)
+        return outputs
+
+    def freeze(self, freeze_at=0):
+        if freeze_at >= 1:
+            self.stem.freeze()
+        for idx, (stage, _) in enumerate(self.stages_and_names, start=2):
+            if freeze_at >= idx:
+                for block in stage.children():
+                    block.freeze()
+        return self
+
+    @staticmethod
+    def make_stage(block_class, num_blocks, *, in_channels, out_channels, **kwargs):
+        blocks = []
+        for i in range(num_blocks):
+            curr = {}
+            for k, v in kwargs.items():
+                if k.endswith("_per_block"):
+                    assert len(v) == num_blocks
+                    curr[k[: -len("_per_block")]] = v[i]
+                else:
+                    curr[k] = v
+            blocks.append(block_class(in_channels=in_channels, out_channels=out_channels, **curr))
+            in_channels = out_channels
+        return blocks
+
+
+@BACKBONE_REGISTRY.register()
+def build_ws_resnet_backbone(cfg, input_shape):
+    norm = cfg.MODEL.RESNETS.NORM
+    stem = BasicStem(in_channels=input_shape.channels, out_channels=cfg.MODEL.RESNETS.STEM_OUT_CHANNELS, norm=norm)
+    freeze_at = cfg.MODEL.BACKBONE.FREEZE_AT
+    out_features = cfg.MODEL.RESNETS.OUT_FEATURES
+    depth = cfg.MODEL.RESNETS.DEPTH
+    num_groups = cfg.MODEL.RESNETS.NUM_GROUPS
+    bottleneck_channels = num_groups * cfg.MODEL.RESNETS.WIDTH_PER_GROUP
+    in_channels = cfg.MODEL.RESNETS.STEM_OUT_CHANNELS
+    out_channels = cfg.MODEL.RESNETS.RES2_OUT_CHANNELS
+    stride_in_1x1 = cfg.MODEL.RESNETS.STRIDE_IN_1X1
+    res5_dilation = cfg.MODEL.RESNETS.RES5_DILATION
+    assert not any(cfg.MODEL.RESNETS.DEFORM_ON_PER_STAGE), "deformable convs are off the DRN-WSOD path"
+    assert res5_dilation in {1, 2}, "res5_dilation cannot be {}.".format(res5_dilation)
+    num_blocks_per_stage = {18: [2, 2, 2, 2], 34: [3, 4, 6, 3], 50: [3, 4, 6, 3], 101: [3, 4, 23, 3],
+                            152: [3, 8, 36, 3]}[depth]
+    if depth in [18, 34]:
+        assert out_channels == 64, "Must set MODEL.RESNETS.RES2_OUT_CHANNELS = 64 for R18/R34"
+        assert num_groups == 1, "Must set MODEL.RESNETS.NUM_GROUPS = 1 for R18/R34"
+    stages = []
+    max_stage_idx = max({"res2": 2, "res3": 3, "res4": 4, "res5": 5}[f] for f in out_features)
+    for idx, stage_idx in enumerate(range(2, max_stage_idx + 1)):
+        dilation = res5_dilation if stage_idx in (4, 5) else 1
+        first_stride = 2 if idx == 0 or (stage_idx == 3 and res5_dilation == 1) else 1
+        has_pool = stage_idx in (2, 3)
+        n = num_blocks_per_stage[idx]
+        kargs = {"num_blocks": n, "stride_per_block": [1] * (n - 1) + [first_stride],
+                 "has_pool_per_block": [False] * (n - 1) + [has_pool], "in_channels": in_channels,
+                 "out_channels": out_channels, "norm": norm, "dilation": dilation}
+        if depth in [18, 34]:
+            kargs["block_class"] = BasicBlock
+        else:
+            kargs.update(block_class=BottleneckBlock, bottleneck_channels=bottleneck_channels,
+                         stride_in_1x1=stride_in_1x1, num_groups=num_groups)
+        stages.append(ResNet.make_stage(**kargs))
+        in_channels = out_channels
+        out_channels *= 2
+        bottleneck_channels *= 2
+    return ResNet(stem, stages, out_features=out_features).freeze(freeze_at)
+
+
+class PlainBlock(nn.Module):
+    """vgg.py:34-122."""
+
+    def __init__(self, in_channels, out_channels, num_conv=3, dilation=1, stride=1, has_pool=False):
+        super().__init__()
+        self.in_channels, self.out_channels, self.stride = in_channels, out_channels, stride
+        self.num_conv, self.dilation, self.has_pool, self.pool_stride = num_conv, dilation, has_pool, stride
+        assert num_conv < 5
+        cin = in_channels
+        for i in range(num_conv):
+            conv = Conv2d(cin, out_channels, kernel_size=3, stride=1, padding=dilation, bias=True, groups=1,
+                          dilation=dilation, norm=None)
+            c2_msra_fill(conv)
+            setattr(self, "conv%d" % (i + 1), conv)
+            cin = out_channels
+        if has_pool:
+            self.pool = nn.MaxPool2d(kernel_size=2, stride=self.pool_stride, padding=0)
+
+    def freeze(self):
+        for p in self.parameters():
+            p.requires_grad = False
+        FrozenBatchNorm2d.convert_frozen_batchnorm(self)
+        return self
+
+    def forward_nhwc(self, x):
+        for i in range(self.num_conv):
+            x = getattr(self, "conv%d" % (i + 1)).run_nhwc(x, relu=True)
+        if self.has_pool:
+            x = ops.maxpool2x2_nhwc(x, self.pool_stride)
+        return x
+
+    def forward(self, x):
+        return from_nhwc(self.forward_nhwc(to_nhwc(x, compute_dtype(), 8 if compute_dtype() == torch.bfloat16 else 4)))
+
+
+class VGG16(Backbone):
+    """vgg.py:125-231."""
+
+    def __init__(self, conv5_dilation, freeze_at, num_classes=None, out_features=None):
+        super().__init__()
+        self.num_classes = num_classes
+        self._out_feature_strides, self._out_feature_channels = {}, {}
+        self.stages_and_names = []
+        d2 = conv5_dilation == 2
+        spec = [("plain1", PlainBlock(3, 64, num_conv=2, stride=2, has_pool=True), 2),
+                ("plain2", PlainBlock(64, 128, num_conv=2, stride=2, has_pool=True), 4),
+                ("plain3", PlainBlock(128, 256, num_conv=3, stride=2, has_pool=True), 8),
+                ("plain4", PlainBlock(256, 512, num_conv=3, stride=1 if d2 else 2, has_pool=True), 8 if d2 else 16),
+                ("plain5", PlainBlock(512, 512, num_conv=3, stride=1, dilation=conv5_dilation, has_pool=False),
+                 8 if d2 else 16)]
+        for i, (name, block, stride) in enumerate(spec):
+            stage = nn.Sequential(block)
+            self.add_module(name, stage)
+            self.stages_and_names.append((stage, name))
+            self._out_feature_strides[name] = stride
+            self._out_feature_channels[name] = block.out_channels
+            if freeze_at >= i + 1:
+                block.freeze()
+        self._out_features = out_features or [name]
+
+    def forward(self, x):
+        outputs = {}
+        with torch.no_grad() if not any(p.requires_grad for p in self.parameters()) else torch.enable_grad():
+            y = self._input_nhwc(x)
+            for stage, name in self.stages_and_names:
+                for block in stage:
+                    y = block.forward_nhwc(y)
+                if name in self._out_features:
+                    outputs[name] = from_nhwc(y)
+        return outputs
+
+
+@BACKBONE_REGISTRY.register()
+def build_vgg_backbone(cfg, input_shape):
+    if cfg.MODEL.VGG.DEPTH == 16:
+        return VGG16(cfg.MODEL.VGG.CONV5_DILATION, cfg.MODEL.BACKBONE.FREEZE_AT)
+    raise ValueError("VGG depth {} not supported".format(cfg.MODEL.VGG.DEPTH))
+
+
+def build_backbone(cfg, input_shape=None):
+    """detectron2/modeling/backbone/build.py."""
+    if input_shape is None:
+        input_shape = ShapeSpec(channels=len(cfg.MODEL.PIXEL_MEAN))
+    backbone = BACKBONE_REGISTRY.get(cfg.MODEL.BACKBONE.NAME)(cfg, input_shape)
+    assert isinstance(backbone, Backbone)
+    return backbone

@@ -1,0 +1,118 @@
+"""GeneralizedRCNNWSL (projects/WSL/wsl/modeling/meta_arch/rcnn.py:23-325) — same registry name, constructor
+and call contract: `model(batched_inputs) -> dict[str, Tensor]` when training, `list[{"instances": Instances}]`
+in eval, `model.inference(batched_inputs, detected_instances=None, do_postprocess=True)`."""
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from .. import compute_dtype, ops
+from .._cabi import DrnError
+from ..config import configurable
+from ..registry import META_ARCH_REGISTRY
+from ..structures import Boxes, ImageList, Instances
+from .backbone import build_backbone
+from .roi_heads import build_roi_heads
+
+__all__ = ["GeneralizedRCNNWSL", "build_model", "detector_postprocess"]
+
+
+def detector_postprocess(results: Instances, output_height: int, output_width: int):
+    """projects/WSL/wsl/modeling/postprocessing.py: rescale boxes to the requested output size, clip, drop
+    empty ones (<= 100 boxes: plumbing)."""
+    sx, sy = output_width / results.image_size[1], output_height / results.image_size[0]
+    out = Instances((output_height, output_width), **results.get_fields())
+    boxes = out.pred_boxes.clone()
+    boxes.scale(sx, sy)
+    boxes.clip(out.image_size)
+    out.pred_boxes = boxes
+    return out[boxes.nonempty()]
+
+
+@META_ARCH_REGISTRY.register()
+class GeneralizedRCNNWSL(nn.Module):
+    @configurable
+    def __init__(self, *, backbone, proposal_generator, load_proposals: bool, roi_heads, pixel_mean: Tuple[float],
+                 pixel_std: Tuple[float], input_format: Optional[str] = None, vis_period: int = 0, cpg: bool = False):
+        super().__init__()
+        if proposal_generator is not None:
+            raise DrnError("learned proposal generators are off the DRN-WSOD path (precomputed proposals only)")
+        if cpg:
+            raise DrnError("CPG (CSC / WSJDS heads) needs input-image gradients: off this path")
+        self.backbone = backbone
+        self.proposal_generator = None
+        self.load_proposals = load_proposals
+        self.roi_heads = roi_heads
+        self.input_format = input_format
+        self.vis_period = vis_period
+        self.register_buffer("pixel_mean", torch.Tensor(pixel_mean).view(-1, 1, 1))
+        self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1))
+        self._mean, self._std = tuple(float(v) for v in pixel_mean), tuple(float(v) for v in pixel_std)
+        self.cpg = cpg
+
+    @classmethod
+    def from_config(cls, cfg):
+        backbone = build_backbone(cfg)
+        name = cfg.MODEL.ROI_HEADS.NAME
+        return {"backbone": backbone, "proposal_generator": None, "load_proposals": cfg.MODEL.LOAD_PROPOSALS,
+                "roi_heads": build_roi_heads(cfg, backbone.output_shape()), "input_format": cfg.INPUT.FORMAT,
+                "vis_period": cfg.VIS_PERIOD, "pixel_mean": cfg.MODEL.PIXEL_MEAN, "pixel_std": cfg.MODEL.PIXEL_STD,
+                "cpg": ("CSC" in name or "WSJDS" in name or "XROIHeads" in name)}
+
+    @property
+    def device(self):
+        return self.pixel_mean.device
+
+    def preprocess_image(self, batched_inputs):
+        """rcnn.py:242-249: one fused kernel per image: (x - mean) / std, zero pad to the batch max, NCHW -> NHWC,
+        cast to the compute dtype."""
+        dtype = compute_dtype()
+        images = [x["image"].to(self.device, non_blocking=True) for x in batched_inputs]
+        nhwc, sizes = ops.preprocess_nhwc(images, self._mean, self._std, dtype, 8 if dtype == torch.bfloat16 else 4)
+        view = nhwc[..., : len(self._mean)].permute(0, 3, 1, 2)
+        view._drn_nhwc = nhwc
+        return ImageList(view, sizes, nhwc)
+
+    def _proposals(self, batched_inputs):
+        assert self.load_proposals and "proposals" in batched_inputs[0], "this path uses precomputed proposals"
+        return [x["proposals"].to(self.device) for x in batched_inputs]
+
+    def forward(self, batched_inputs):
+        if not self.training:
+            return self.inference(batched_inputs)
+        images = self.preprocess_image(batched_inputs)
+        # image-level labels are read on the host (they come from the loader there): no device round trip
+        gt_instances = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
+        features = self.backbone(images.tensor)
+        proposals = self._proposals(batched_inputs)
+        _, detector_losses = self.roi_heads(images, features, proposals, gt_instances)
+        losses = {}
+        losses.update(detector_losses)
+        return losses
+
+    def inference(self, batched_inputs, detected_instances=None, do_postprocess=True):
+        assert not self.training
+        assert detected_instances is None, "forward_with_given_boxes is off this path"
+        with torch.no_grad():
+            images = self.preprocess_image(batched_inputs)
+            features = self.backbone(images.tensor)
+            proposals = self._proposals(batched_inputs)
+            results, _, all_scores, all_boxes = self.roi_heads(images, features, proposals, None)
+        if do_postprocess:
+            return GeneralizedRCNNWSL._postprocess(results, batched_inputs, images.image_sizes)
+        return results, all_scores, all_boxes
+
+    @staticmethod
+    def _postprocess(instances, batched_inputs, image_sizes):
+        processed = []
+        for r, inp, size in zip(instances, batched_inputs, image_sizes):
+            h, w = inp.get("height", size[0]), inp.get("width", size[1])
+            processed.append({"instances": detector_postprocess(r, h, w)})
+        return processed
+
+
+def build_model(cfg):
+    """detectron2/modeling/meta_arch/build.py:16-23."""
+    model = META_ARCH_REGISTRY.get(cfg.MODEL.META_ARCHITECTURE)(cfg)
+    model.to(torch.device(cfg.MODEL.DEVICE))
+    return model

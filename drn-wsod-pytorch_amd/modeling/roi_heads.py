@@ -1,0 +1,707 @@
+"""ROI heads of the DRN-WSOD / OICR path behind the reference's names and constructor arguments:
+
+  ROIPooler                    detectron2/modeling/poolers.py:99-246
+  Matcher                      detectron2/modeling/matcher.py:8-126
+  Box2BoxTransform             detectron2/modeling/box_regression.py:17-110
+  DiscriminativeAdaptionNeck   projects/WSL/wsl/modeling/roi_heads/box_head.py:14-103
+  WSDDNOutputLayers            projects/WSL/wsl/modeling/roi_heads/fast_rcnn.py:396-700
+  OICROutputLayers             projects/WSL/wsl/modeling/roi_heads/fast_rcnn.py:1267-1594
+  ROIHeads / OICRROIHeads / WSDDNROIHeads
+                               projects/WSL/wsl/modeling/roi_heads/{roi_heads.py:156-353, roi_heads_oicr.py:33-567,
+                               roi_heads_wsddn.py}
+
+Same module tree => same state_dict keys (roi_heads.box_head.fc1.weight, roi_heads.box_predictor.cls.weight,
+roi_heads.box_refinery_0.cls_score.weight, ...).  The arithmetic does not run module by module: OICRROIHeads
+drives one fused schedule of HIP kernels (`_HeadEngine`) — ROIPool fused with the objectness scaling writes
+the fc6 operand, three MFMA GEMM groups (fc6, fc7, all predictor Linears concatenated), the MIL/OICR kernels,
+and an explicit backward (dW/dX GEMMs) that writes gradients straight into a flat fp32 arena shared with the
+fused SGD kernel and the gradient all-reduce.  No host synchronisation happens inside a step."""
+import inspect
+import math
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from .. import compute_dtype, ops
+from .._cabi import DrnError
+from ..config import configurable
+from ..events import get_event_storage, has_event_storage
+from ..layers import Linear, ROIAlign, RoIPool, ShapeSpec, to_nhwc
+from ..registry import ROI_BOX_HEAD_REGISTRY, ROI_HEADS_REGISTRY
+from ..structures import Boxes, Instances
+
+
+# ------------------------------------------------------------------------------------------------
+class Matcher:
+    """Config holder with the reference's constructor checks (matcher.py:24-59).  The matching itself
+    (column arg-max over GT + threshold labelling, no low-quality matches on this path) runs inside
+    drn_oicr_targets."""
+
+    def __init__(self, thresholds: List[float], labels: List[int], allow_low_quality_matches: bool = False):
+        thresholds = thresholds[:]
+        assert thresholds[0] > 0
+        thresholds.insert(0, -float("inf"))
+        thresholds.append(float("inf"))
+        assert all(low <= high for (low, high) in zip(thresholds[:-1], thresholds[1:]))
+        assert all(l in [-1, 0, 1] for l in labels)
+        assert len(labels) == len(thresholds) - 1
+        if allow_low_quality_matches:
+            raise DrnError("allow_low_quality_matches is off the OICR path (roi_heads.py:207-211 passes False)")
+        self.thresholds = thresholds
+        self.labels = labels
+        self.allow_low_quality_matches = allow_low_quality_matches
+
+
+class Box2BoxTransform:
+    """box_regression.py:17-110 (weights + scale clamp; apply_deltas executes drn_apply_deltas)."""
+
+    def __init__(self, weights, scale_clamp: float = math.log(1000.0 / 16)):
+        self.weights = tuple(weights)
+        self.scale_clamp = scale_clamp
+
+    def apply_deltas(self, deltas, boxes):
+        k = deltas.shape[1] // 4
+        return ops.apply_deltas(deltas.float().contiguous(), boxes.float().contiguous(), k, self.weights)
+
+
+def convert_boxes_to_pooler_format(box_lists: List[Boxes]):
+    """poolers.py:62-96 -> [M,5] (batch index, x0, y0, x1, y1)."""
+    return torch.cat([torch.cat((torch.full((len(b), 1), float(i), dtype=b.tensor.dtype, device=b.tensor.device),
+                                 b.tensor), dim=1) for i, b in enumerate(box_lists)], dim=0)
+
+
+class ROIPooler(nn.Module):
+    """poolers.py:99-246, single feature level (the only case on this path)."""
+
+    def __init__(self, output_size, scales, sampling_ratio, pooler_type, canonical_box_size=224, canonical_level=4):
+        super().__init__()
+        if isinstance(output_size, int):
+            output_size = (output_size, output_size)
+        assert len(output_size) == 2 and output_size[0] == output_size[1]
+        self.output_size = output_size
+        if len(scales) != 1:
+            raise DrnError("multi-level (FPN) pooling is off the DRN-WSOD path")
+        self.pooler_type, self.sampling_ratio, self.scales = pooler_type, sampling_ratio, tuple(scales)
+        if pooler_type == "ROIAlign":
+            self.level_poolers = nn.ModuleList(ROIAlign(output_size, s, sampling_ratio, aligned=False) for s in scales)
+        elif pooler_type == "ROIAlignV2":
+            self.level_poolers = nn.ModuleList(ROIAlign(output_size, s, sampling_ratio, aligned=True) for s in scales)
+        elif pooler_type == "ROIPool":
+            self.level_poolers = nn.ModuleList(RoIPool(output_size, spatial_scale=s) for s in scales)
+        else:
+            raise ValueError("Unknown pooler type: {}".format(pooler_type))
+        min_level = -(math.log2(scales[0]))
+        assert math.isclose(min_level, int(min_level)), "Featuremap stride is not power of 2!"
+
+    def kernel_args(self):
+        mode = 0 if self.pooler_type == "ROIPool" else 1
+        return dict(P=self.output_size[0], scale=self.scales[0], mode=mode, sampling_ratio=self.sampling_ratio,
+                    aligned=self.pooler_type == "ROIAlignV2")
+
+    def forward(self, x: List[torch.Tensor], box_lists: List[Boxes]):
+        assert isinstance(x, list) and isinstance(box_lists, list), "Arguments to pooler must be lists"
+        assert len(x) == 1 and len(box_lists) == x[0].size(0)
+        return self.level_poolers[0](x[0], convert_boxes_to_pooler_format(box_lists))
+
+
+# ------------------------------------------------------------------------------------------------
+@ROI_BOX_HEAD_REGISTRY.register()
+class DiscriminativeAdaptionNeck(nn.Module):
+    """box_head.py:14-103: flatten -> fc1 -> ReLU -> dropout(0.5) -> fc2 -> ReLU -> dropout(0.5)."""
+
+    @configurable
+    def __init__(self, input_shape: ShapeSpec, *, conv_dims: List[int], fc_dims: List[int], conv_norm=""):
+        super().__init__()
+        assert len(conv_dims) + len(fc_dims) > 0
+        if len(conv_dims):
+            raise DrnError("DAN conv layers (NUM_CONV > 0) are not used by any DRN-WSOD config")
+        self._output_size = (input_shape.channels, input_shape.height, input_shape.width)
+        self.conv_norm_relus = []
+        self.fcs = []
+        for k, fc_dim in enumerate(fc_dims):
+            size = self._output_size if isinstance(self._output_size, int) else int(
+                self._output_size[0] * self._output_size[1] * self._output_size[2])
+            fc = Linear(size, fc_dim)
+            self.add_module("fc{}".format(k + 1), fc)
+            self.fcs.append(fc)
+            self._output_size = fc_dim
+        for layer in self.fcs:
+            torch.nn.init.normal_(layer.weight, std=0.005)
+            torch.nn.init.constant_(layer.bias, 0.1)
+        self.dropout_p = 0.5          # box_head.py:90 hard-codes p=0.5
+        self.dropout_masks = None     # test hook: explicit [M, fc_dim] multiplier masks
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        return {"input_shape": input_shape, "conv_dims": [cfg.MODEL.ROI_BOX_HEAD.CONV_DIM] * cfg.MODEL.ROI_BOX_HEAD.NUM_CONV,
+                "fc_dims": cfg.MODEL.ROI_BOX_HEAD.DAN_DIM, "conv_norm": cfg.MODEL.ROI_BOX_HEAD.NORM}
+
+    @property
+    def output_shape(self):
+        o = self._output_size
+        return ShapeSpec(channels=o) if isinstance(o, int) else ShapeSpec(channels=o[0], height=o[1], width=o[2])
+
+    def forward(self, x):
+        raise DrnError("DiscriminativeAdaptionNeck runs inside the fused OICRROIHeads schedule; call the ROI heads")
+
+
+def build_box_head(cfg, input_shape):
+    return ROI_BOX_HEAD_REGISTRY.get(cfg.MODEL.ROI_BOX_HEAD.NAME)(cfg, input_shape)
+
+
+class _OutputLayersBase(nn.Module):
+    def _common(self, box2box_transform, test_score_thresh, test_nms_thresh, test_topk_per_image, smooth_l1_beta,
+                box_reg_loss_type, loss_weight, mean_loss):
+        self.box2box_transform = box2box_transform
+        self.smooth_l1_beta = smooth_l1_beta
+        self.test_score_thresh = test_score_thresh
+        self.test_nms_thresh = test_nms_thresh
+        self.test_topk_per_image = test_topk_per_image
+        self.box_reg_loss_type = box_reg_loss_type
+        if isinstance(loss_weight, float):
+            loss_weight = {"loss_cls": loss_weight, "loss_box_reg": loss_weight}
+        self.loss_weight = loss_weight
+        self.mean_loss = mean_loss
+
+    @staticmethod
+    def _cfg_common(cfg):
+        return {
+            "box2box_transform": Box2BoxTransform(weights=cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_WEIGHTS),
+            "num_classes": cfg.MODEL.ROI_HEADS.NUM_CLASSES,
+            "cls_agnostic_bbox_reg": cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG,
+            "smooth_l1_beta": cfg.MODEL.ROI_BOX_HEAD.SMOOTH_L1_BETA,
+            "test_score_thresh": cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+            "test_nms_thresh": cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST,
+            "test_topk_per_image": cfg.TEST.DETECTIONS_PER_IMAGE,
+            "box_reg_loss_type": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_TYPE,
+            "loss_weight": {"loss_box_reg": cfg.MODEL.ROI_BOX_HEAD.BBOX_REG_LOSS_WEIGHT},
+            "mean_loss": cfg.WSL.MEAN_LOSS,
+        }
+
+
+class WSDDNOutputLayers(_OutputLayersBase):
+    """fast_rcnn.py:396-700: `cls` and `det` Linear(input, K), Xavier-uniform, zero bias."""
+
+    @configurable
+    def __init__(self, input_shape, *, box2box_transform, num_classes, test_score_thresh=0.0, test_nms_thresh=0.5,
+                 test_topk_per_image=100, cls_agnostic_bbox_reg=False, smooth_l1_beta=0.0,
+                 box_reg_loss_type="smooth_l1", loss_weight=1.0, mean_loss=True):
+        super().__init__()
+        if isinstance(input_shape, int):
+            input_shape = ShapeSpec(channels=input_shape)
+        input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        self.num_bbox_reg_classes = 1 if cls_agnostic_bbox_reg else num_classes
+        self.box_dim = len(box2box_transform.weights)
+        self.num_classes = num_classes
+        self.cls = Linear(input_size, num_classes)
+        self.det = Linear(input_size, num_classes)
+        nn.init.xavier_uniform_(self.cls.weight)
+        nn.init.xavier_uniform_(self.det.weight)
+        for l in [self.cls, self.det]:
+            nn.init.constant_(l.bias, 0)
+        self._common(box2box_transform, test_score_thresh, test_nms_thresh, test_topk_per_image, smooth_l1_beta,
+                     box_reg_loss_type, loss_weight, mean_loss)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        d = cls._cfg_common(cfg)
+        d["input_shape"] = input_shape
+        return d
+
+
+class OICROutputLayers(_OutputLayersBase):
+    """fast_rcnn.py:1267-1594: `cls_score` Linear(input, K+1) (std 0.01) and `bbox_pred` Linear(input, 4K)
+    (std 0.001; only used when WSL.REFINE_REG[k])."""
+
+    @configurable
+    def __init__(self, input_shape, *, box2box_transform, num_classes, test_score_thresh=0.0, test_nms_thresh=0.5,
+                 test_topk_per_image=100, cls_agnostic_bbox_reg=False, smooth_l1_beta=0.0,
+                 box_reg_loss_type="smooth_l1", loss_weight=1.0, mean_loss=True, refine_k=None, refine_reg=False):
+        super().__init__()
+        if isinstance(input_shape, int):
+            input_shape = ShapeSpec(channels=input_shape)
+        input_size = input_shape.channels * (input_shape.width or 1) * (input_shape.height or 1)
+        if cls_agnostic_bbox_reg:
+            raise DrnError("class-agnostic box regression is not used by any DRN-WSOD config")
+        self.num_classes = num_classes
+        self.cls_score = Linear(input_size, num_classes + 1)
+        self.num_bbox_reg_classes = num_classes
+        self.box_dim = len(box2box_transform.weights)
+        self.bbox_pred = Linear(input_size, self.num_bbox_reg_classes * self.box_dim)
+        nn.init.normal_(self.cls_score.weight, std=0.01)
+        nn.init.normal_(self.bbox_pred.weight, std=0.001)
+        for l in [self.cls_score, self.bbox_pred]:
+            nn.init.constant_(l.bias, 0)
+        self._common(box2box_transform, test_score_thresh, test_nms_thresh, test_topk_per_image, smooth_l1_beta,
+                     box_reg_loss_type, loss_weight, mean_loss)
+        self.refine_k = refine_k
+        self.refine_reg = refine_reg
+
+    @classmethod
+    def from_config(cls, cfg, input_shape, refine_k):
+        d = cls._cfg_common(cfg)
+        d.update(input_shape=input_shape, refine_reg=cfg.WSL.REFINE_REG, refine_k=refine_k)
+        return d
+
+
+# ------------------------------------------------------------------------------------------------
+class _TrainFn(torch.autograd.Function):
+    """Hooks the fused schedule into autograd: `sum(loss_dict.values()).backward()` (the reference trainer,
+    projects/WSL/tools/train_net.py:92-107) lands here with one upstream gradient per loss."""
+
+    @staticmethod
+    def forward(ctx, anchor, engine, state):
+        ctx.engine, ctx.state = engine, state
+        return tuple(l.clone() for l in state["loss_list"])
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        ctx.engine.backward(ctx.state, gouts)
+        return None, None, None
+
+
+class _HeadEngine:
+    """Flat parameter arena + the fused fwd/bwd kernel schedule of the DAN / WSDDN / OICR heads."""
+
+    def __init__(self, heads):
+        self.h = heads
+        self.arena_w = None
+        self.arena_g = None
+        self.segments = []       # (name, param, offset, numel, used)
+        self._shadow_key = None
+        self._dirty = True
+        self._ws = {}
+        self._grads_valid = False
+        self._drop_iter = 0
+        self.anchor = None
+
+    # ---- layout --------------------------------------------------------------------------------
+    def _layout(self):
+        h = self.h
+        K = h.num_classes
+        cols, off = [], 0
+        cols.append(("cls", h.box_predictor.cls, off, K)); off += K
+        cols.append(("det", h.box_predictor.det, off, K)); off += K
+        for k in range(h.refine_K):
+            cols.append(("r%d" % k, h.box_refinery[k].cls_score, off, K + 1)); off += K + 1
+        for k in range(h.refine_K):
+            if h.refine_reg[k]:
+                cols.append(("b%d" % k, h.box_refinery[k].bbox_pred, off, 4 * K)); off += 4 * K
+        return cols, off
+
+    def ensure(self, device):
+        h = self.h
+        fc1 = h.box_head.fc1
+        if (self.arena_w is not None and self.arena_w.device == device and
+                fc1.weight.data_ptr() == self.arena_w.data_ptr() + 4 * self._fc1_off):
+            return
+        cols, NH = self._layout()
+        self.cols, self.NH = cols, NH
+        order = [(n + ".weight", m.weight, True) for n, m, _, _ in cols]
+        order += [(n + ".bias", m.bias, True) for n, m, _, _ in cols]
+        order += [("fc2.weight", h.box_head.fc2.weight, True), ("fc2.bias", h.box_head.fc2.bias, True),
+                  ("fc1.bias", fc1.bias, True), ("fc1.weight", fc1.weight, True)]
+        for k in range(h.refine_K):
+            if not h.refine_reg[k]:  # unused parameters: kept in the arena, never touched
+                order += [("u%d.weight" % k, h.box_refinery[k].bbox_pred.weight, False),
+                          ("u%d.bias" % k, h.box_refinery[k].bbox_pred.bias, False)]
+        total = sum(p.numel() for _, p, _ in order)
+        w = torch.empty((total,), dtype=torch.float32, device=device)
+        g = torch.zeros((total,), dtype=torch.float32, device=device)
+        self.segments, off = [], 0
+        for name, p, used in order:
+            n = p.numel()
+            w[off: off + n].copy_(p.detach().reshape(-1).to(device))
+            p.data = w[off: off + n].view(p.shape)
+            p.grad = None
+            self.segments.append((name, p, off, n, used))
+            if name == "fc1.weight":
+                self._fc1_off = off
+            off += n
+        self.n_used = sum(n for _, _, _, n, u in self.segments if u)
+        self.arena_w, self.arena_g = w, g
+        self._seg = {name: (o, n) for name, _, o, n, _ in self.segments}
+        self._dirty = True
+        self._ws = {}
+        self._grads_valid = False
+        self.anchor = torch.zeros((), device=device, requires_grad=True)
+
+    def _gview(self, name, shape=None):
+        o, n = self._seg[name]
+        v = self.arena_g[o: o + n]
+        return v.view(shape) if shape is not None else v
+
+    def _wview(self, name, shape=None):
+        o, n = self._seg[name]
+        v = self.arena_w[o: o + n]
+        return v.view(shape) if shape is not None else v
+
+    def mark_dirty(self):
+        self._dirty = True
+
+    # ---- compute-dtype shadows of the weights -----------------------------------------------------
+    def refresh_shadows(self, dtype):
+        key = (dtype,) + tuple(p._version for _, p, _, _, u in self.segments if u)
+        if not self._dirty and key == self._shadow_key:
+            return
+        h = self.h
+        dev = self.arena_w.device
+        fc1, fc2 = h.box_head.fc1, h.box_head.fc2
+        D1, K1 = fc1.weight.shape
+        D2 = fc2.weight.shape[0]
+        NH = self.NH
+        kp = lambda k: ops.kpad(k, dtype)
+        if not hasattr(self, "sh") or self.sh.get("dtype") != dtype:
+            z = lambda r, c: torch.zeros((r, c), dtype=dtype, device=dev)
+            self.sh = dict(dtype=dtype, W2=z(D2, kp(D1)), W2T=z(D1, kp(D2)), Wh=z(NH, kp(D2)), WhT=z(D2, kp(NH)))
+            self.sh["W1"] = None if (dtype == torch.float32 and kp(K1) == K1) else z(D1, kp(K1))
+        sh = self.sh
+        if sh["W1"] is None:
+            sh["W1v"] = fc1.weight.data  # fp32 mode, unpadded: the master IS the operand
+        else:
+            ops.cast2d(fc1.weight.data, D1, K1, sh["W1"])
+            sh["W1v"] = sh["W1"]
+        ops.cast2d(fc2.weight.data, D2, D1, sh["W2"])
+        ops.transpose2d(fc2.weight.data, D2, D1, out=sh["W2T"])
+        o, _ = self._seg[self.cols[0][0] + ".weight"]
+        wh = self.arena_w[o: o + NH * D2].view(NH, D2)
+        ops.cast2d(wh, NH, D2, sh["Wh"])
+        ops.transpose2d(wh, NH, D2, out=sh["WhT"])
+        self._shadow_key, self._dirty = key, False
+
+    # ---- workspaces ---------------------------------------------------------------------------------
+    def ws(self, M, dtype, training):
+        key = (M, dtype, training)
+        if key in self._ws:
+            return self._ws[key]
+        if len(self._ws) >= 2:
+            self._ws.clear()
+        h = self.h
+        dev = self.arena_w.device
+        D1, K1 = h.box_head.fc1.weight.shape
+        D2 = h.box_head.fc2.weight.shape[0]
+        kp = lambda k: ops.kpad(k, dtype)
+        z = lambda r, c, dt=dtype: torch.zeros((r, c), dtype=dt, device=dev)
+        NHp = kp(self.NH)
+        w = dict(A=z(M, kp(K1)), H1=z(M, kp(D1)), H2=z(M, kp(D2)), logits=z(M, NHp, torch.float32))
+        if training:
+            Mp = kp(M)
+            w.update(AT=z(K1, Mp), H1T=z(D1, Mp), H2T=z(D2, Mp), dlogits=z(M, NHp, torch.float32), dS=z(M, NHp),
+                     dST=z(self.NH, Mp), dH2=z(M, D2, torch.float32), dP2=z(M, kp(D2)), dP2T=z(D2, Mp),
+                     dH1=z(M, D1, torch.float32), dP1T=z(D1, Mp))
+        self._ws[key] = w
+        return w
+
+    @staticmethod
+    def _splits(M, N, K, dtype):
+        tiles = ((M + 127) // 128) * ((N + 127) // 128)
+        nslab = K * ops.esize(dtype) // 128
+        return max(1, min(1024 // max(tiles, 1), max(1, nslab // 8), 16))
+
+    def _linear_fwd(self, A, Wt, M, N, K, bias, relu, out, outT, mask, seed, drop_p):
+        s = self._splits(M, N, K, A.dtype)
+        part = ops.gemm_nt(A, Wt, M, N, K, splits=s)
+        ops.bias_act_fwd(part, M, N, bias, relu, mask, seed, drop_p, out=out, outT=outT)
+
+    # ---- forward -------------------------------------------------------------------------------------
+    def forward(self, feat_nhwc, rois, objectness, training, img_off=None, n_img=1, gt=None):
+        h = self.h
+        dev = feat_nhwc.device
+        self.ensure(dev)
+        dtype = feat_nhwc.dtype
+        self.refresh_shadows(dtype)
+        M = rois.shape[0]
+        w = self.ws(M, dtype, training)
+        sh = self.sh
+        fc1, fc2 = h.box_head.fc1, h.box_head.fc2
+        D1, K1 = fc1.weight.shape
+        D2 = fc2.weight.shape[0]
+        K, NH = h.num_classes, self.NH
+        kp = lambda k: ops.kpad(k, dtype)
+        ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=w["A"], **h.box_pooler.kernel_args())
+        drop_p = h.box_head.dropout_p if training else 0.0
+        masks = h.box_head.dropout_masks if training else None
+        seed = 0
+        if training and masks is None and drop_p > 0:
+            self._drop_iter += 1
+            seed = (torch.initial_seed() + 7919 * self._drop_iter) & 0xFFFFFFFFFFFF
+        if training:
+            ops.transpose2d(w["A"], M, K1, out=w["AT"])
+        self._linear_fwd(w["A"], sh["W1v"], M, D1, kp(K1), fc1.bias.data, True, w["H1"], w["H1T"] if training else None,
+                         masks[0] if masks else None, seed, drop_p)
+        self._linear_fwd(w["H1"], sh["W2"], M, D2, kp(D1), fc2.bias.data, True, w["H2"], w["H2T"] if training else None,
+                         masks[1] if masks else None, seed + 1, drop_p)
+        bo, _ = self._seg[self.cols[0][0] + ".bias"]
+        self._linear_fwd(w["H2"], sh["Wh"], M, NH, kp(D2), self.arena_w[bo: bo + NH], False, w["logits"], None, None, 0, 0.0)
+        col = {n: c for n, _, c, _ in self.cols}
+        if not training:
+            return w, col
+        # ---- losses (fused with their dlogits) ----
+        dl = w["dlogits"]
+        scores, img_scores, loss_part = ops.wsddn_fwd_bwd(w["logits"], col["cls"], col["det"], K, img_off, n_img,
+                                                         gt["onehot"], dlogits=dl, mean_loss=h.box_predictor.mean_loss)
+        for m in [h.box_predictor] + list(h.box_refinery[: h.refine_K]):
+            assert m.loss_weight.get("loss_cls", 1.0) == 1.0, "loss_cls weight != 1 is not used by any config"
+        loss_names = ["loss_cls"]
+        loss_list = [ops.sum_small(loss_part).view(())]
+        head_cols = [("cls", 0), ("det", 0)]
+        prev_scores, prev_boxes = scores, gt["props"]
+        aux = dict(scores=scores, img_scores=img_scores, targets=[])
+        thr = h.proposal_matcher.thresholds[1:-1]
+        for k in range(h.refine_K):
+            if h.refine_reg[k]:
+                raise DrnError("WSL.REFINE_REG training (box-regression refinement loss) is not built yet; "
+                               "the BASELINE configs do not use it")
+            tg = ops.oicr_targets(prev_scores, prev_boxes, gt["props"], img_off, n_img, gt["classes"], gt["count"],
+                                  img_scores, K, thr, h.proposal_matcher.labels)
+            probs, loss = ops.softmax_ce(w["logits"], col["r%d" % k], K + 1, tg["labels"], tg["weights"], dlogits=dl)
+            loss_names.append("loss_cls_r%d" % k)
+            loss_list.append(loss.view(()))
+            head_cols.append(("r%d" % k, len(loss_list) - 1))
+            aux["targets"].append(tg)
+            prev_scores = probs
+            prev_boxes = ops.apply_deltas(None, gt["props"], K, h.box_refinery[k].box2box_transform.weights)
+        state = dict(w=w, M=M, dtype=dtype, loss_list=loss_list, head_cols=head_cols, masks=masks, drop_p=drop_p,
+                     aux=aux)
+        outs = _TrainFn.apply(self.anchor, self, state)
+        return dict(zip(loss_names, outs)), state
+
+    # ---- backward ------------------------------------------------------------------------------------
+    def backward(self, st, gouts):
+        h = self.h
+        w, M, dtype = st["w"], st["M"], st["dtype"]
+        sh = self.sh
+        fc1, fc2 = h.box_head.fc1, h.box_head.fc2
+        D1, K1 = fc1.weight.shape
+        D2 = fc2.weight.shape[0]
+        NH = self.NH
+        kp = lambda k: ops.kpad(k, dtype)
+        Mp = kp(M)
+        dev = self.arena_w.device
+        # per-loss upstream gradients -> per-column scale of dlogits (stays on the device)
+        g = [torch.zeros((), device=dev) if x is None else x.float().reshape(()) for x in gouts]
+        width = {n: c for n, _, _, c in self.cols}
+        colscale = torch.cat([g[li].expand(width[n]) for n, li in st["head_cols"]] +
+                             [torch.zeros(NH - sum(width[n] for n, _ in st["head_cols"]), device=dev)]).contiguous()
+        acc = self._grads_valid and fc1.weight.grad is not None
+        bo, _ = self._seg[self.cols[0][0] + ".bias"]
+        wo, _ = self._seg[self.cols[0][0] + ".weight"]
+        # heads: dS, dS^T, bias grads
+        ops.bias_act_bwd(w["dlogits"], M, NH, colscale=colscale, dpre=w["dS"], dpreT=w["dST"],
+                         colsum=self.arena_g[bo: bo + NH], accumulate_colsum=acc)
+        ops.gemm_nt(w["dST"], w["H2T"], NH, D2, Mp, out=self.arena_g[wo: wo + NH * D2].view(1, NH, D2), accumulate=acc)
+        ops.gemm_nt(w["dS"], sh["WhT"], M, D2, kp(NH), out=w["dH2"].view(1, M, D2))
+        # fc7
+        ops.bias_act_bwd(w["dH2"], M, D2, saved=w["H2"], mask=st["masks"][1] if st["masks"] else None,
+                         drop_p=st["drop_p"], dpre=w["dP2"], dpreT=w["dP2T"], colsum=self._gview("fc2.bias"),
+                         accumulate_colsum=acc)
+        ops.gemm_nt(w["dP2T"], w["H1T"], D2, D1, Mp, out=self._gview("fc2.weight", (1, D2, D1)), accumulate=acc)
+        ops.gemm_nt(w["dP2"], sh["W2T"], M, D1, kp(D2), out=w["dH1"].view(1, M, D1))
+        # fc6 (the backbone is frozen: no dX)
+        ops.bias_act_bwd(w["dH1"], M, D1, saved=w["H1"], mask=st["masks"][0] if st["masks"] else None,
+                         drop_p=st["drop_p"], dpreT=w["dP1T"], colsum=self._gview("fc1.bias"), accumulate_colsum=acc)
+        hook = getattr(self, "grad_ready_hook", None)
+        if hook is not None:
+            hook("small")  # everything except fc1.weight is final: the DP engine starts reducing it now
+        nslab = getattr(self, "fc1_grad_slabs", 1)
+        gw = self._gview("fc1.weight", (D1, K1))
+        rows = (D1 + nslab - 1) // nslab
+        for s in range(nslab):
+            r0, r1 = s * rows, min(D1, (s + 1) * rows)
+            if r0 >= r1:
+                break
+            ops.gemm_nt(w["dP1T"][r0:r1], w["AT"], r1 - r0, K1, Mp, out=gw[r0:r1].unsqueeze(0), accumulate=acc)
+            if hook is not None:
+                hook(("fc1", r0, r1))
+        self._grads_valid = True
+        for name, p, o, n, used in self.segments:
+            if used and p.grad is None:
+                p.grad = self.arena_g[o: o + n].view(p.shape)
+
+
+# ------------------------------------------------------------------------------------------------
+class ROIHeads(nn.Module):
+    """roi_heads.py:156-212 (constructor / from_config)."""
+
+    @configurable
+    def __init__(self, *, num_classes, batch_size_per_image, positive_fraction, proposal_matcher,
+                 proposal_append_gt=True):
+        super().__init__()
+        self.batch_size_per_image = batch_size_per_image
+        self.positive_fraction = positive_fraction
+        self.num_classes = num_classes
+        self.proposal_matcher = proposal_matcher
+        self.proposal_append_gt = proposal_append_gt
+
+    @classmethod
+    def from_config(cls, cfg):
+        return {
+            "batch_size_per_image": cfg.MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE,
+            "positive_fraction": cfg.MODEL.ROI_HEADS.POSITIVE_FRACTION,
+            "num_classes": cfg.MODEL.ROI_HEADS.NUM_CLASSES,
+            "proposal_append_gt": cfg.MODEL.ROI_HEADS.PROPOSAL_APPEND_GT,
+            "proposal_matcher": Matcher(cfg.MODEL.ROI_HEADS.IOU_THRESHOLDS, cfg.MODEL.ROI_HEADS.IOU_LABELS,
+                                        allow_low_quality_matches=False),
+        }
+
+
+def get_image_level_gt(targets, num_classes):
+    """roi_heads.py:137-153.  `unique(sorted=True)` of a handful of ints: done on the host copy of the labels
+    (they arrive from the data loader on the host), so no device sync is introduced."""
+    if targets is None:
+        return None, None, None
+    ints = [torch.unique(t.gt_classes.detach().cpu(), sorted=True).to(torch.int64) for t in targets]
+    oh = torch.zeros((len(ints), num_classes), dtype=torch.float32)
+    for i, g in enumerate(ints):
+        oh[i, g] = 1
+    return ints, ints, oh
+
+
+@ROI_HEADS_REGISTRY.register()
+class OICRROIHeads(ROIHeads):
+    """roi_heads_oicr.py:33-567."""
+
+    @configurable
+    def __init__(self, *, box_in_features, box_pooler, box_head, box_predictor, mask_in_features=None,
+                 mask_pooler=None, mask_head=None, keypoint_in_features=None, keypoint_pooler=None,
+                 keypoint_head=None, train_on_pred_boxes=False, output_dir=None, vis_test=False, vis_period=0,
+                 refine_K=4, refine_reg=(False, False, False, False), box_refinery=(None, None, None, None),
+                 cls_agnostic_bbox_reg=False, **kwargs):
+        super().__init__(**kwargs)
+        if mask_in_features is not None or keypoint_in_features is not None or train_on_pred_boxes:
+            raise DrnError("mask / keypoint heads and train_on_pred_boxes are off the DRN-WSOD path")
+        self.in_features = self.box_in_features = box_in_features
+        self.box_pooler = box_pooler
+        self.box_head = box_head
+        self.box_predictor = box_predictor
+        self.mask_on = self.keypoint_on = False
+        self.train_on_pred_boxes = train_on_pred_boxes
+        self.iter = self.iter_test = self.epoch_test = 0
+        self.output_dir, self.vis_test, self.vis_period = output_dir, vis_test, vis_period
+        self.refine_K = refine_K
+        self.refine_reg = list(refine_reg)
+        self.box_refinery = list(box_refinery)
+        for k in range(self.refine_K):
+            self.add_module("box_refinery_{}".format(k), self.box_refinery[k])
+        self.cls_agnostic_bbox_reg = cls_agnostic_bbox_reg
+        self._engine = _HeadEngine(self)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        ret = super().from_config(cfg)
+        ret["train_on_pred_boxes"] = cfg.MODEL.ROI_BOX_HEAD.TRAIN_ON_PRED_BOXES
+        if inspect.ismethod(cls._init_box_head):
+            ret.update(cls._init_box_head(cfg, input_shape))
+        return ret
+
+    _refine_from_cfg = True
+
+    @classmethod
+    def _init_box_head(cls, cfg, input_shape):
+        in_features = cfg.MODEL.ROI_HEADS.IN_FEATURES
+        pooler_resolution = cfg.MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION
+        pooler_scales = tuple(1.0 / input_shape[k].stride for k in in_features)
+        in_channels = [input_shape[f].channels for f in in_features]
+        assert len(set(in_channels)) == 1, in_channels
+        in_channels = in_channels[0]
+        box_pooler = ROIPooler(output_size=pooler_resolution, scales=pooler_scales,
+                               sampling_ratio=cfg.MODEL.ROI_BOX_HEAD.POOLER_SAMPLING_RATIO,
+                               pooler_type=cfg.MODEL.ROI_BOX_HEAD.POOLER_TYPE)
+        box_head = build_box_head(cfg, ShapeSpec(channels=in_channels, height=pooler_resolution, width=pooler_resolution))
+        box_predictor = WSDDNOutputLayers(cfg, box_head.output_shape)
+        refine_K = cfg.WSL.REFINE_NUM if cls._refine_from_cfg else 0
+        box_refinery = [OICROutputLayers(cfg, box_head.output_shape, k) for k in range(refine_K)]
+        return {"box_in_features": in_features, "box_pooler": box_pooler, "box_head": box_head,
+                "box_predictor": box_predictor, "output_dir": cfg.OUTPUT_DIR, "vis_test": cfg.WSL.VIS_TEST,
+                "vis_period": cfg.VIS_PERIOD, "refine_K": refine_K, "refine_reg": cfg.WSL.REFINE_REG,
+                "box_refinery": box_refinery, "cls_agnostic_bbox_reg": cfg.MODEL.ROI_BOX_HEAD.CLS_AGNOSTIC_BBOX_REG}
+
+    # ---- helpers --------------------------------------------------------------------------------------
+    def _gather_inputs(self, features, proposals):
+        feat = features[self.box_in_features[0]]
+        nhwc = feat.permute(0, 2, 3, 1)
+        if not nhwc.is_contiguous() or nhwc.dtype != compute_dtype():
+            nhwc = to_nhwc(feat, compute_dtype())
+        rois = convert_boxes_to_pooler_format([p.proposal_boxes for p in proposals]).float().contiguous()
+        obj = torch.cat([p.objectness_logits for p in proposals], dim=0).float().contiguous()
+        return nhwc, rois, obj
+
+    def forward(self, images, features, proposals, targets=None):
+        """roi_heads_oicr.py:248-291."""
+        self.images = images
+        if self.training:
+            assert targets
+            losses = self._forward_box(features, proposals, targets)
+            self.iter += 1
+            if self.iter_test > 0:
+                self.epoch_test += 1
+            self.iter_test = 0
+            return proposals, losses
+        pred_instances, all_scores, all_boxes = self._forward_box(features, proposals, None)
+        self.iter_test += 1
+        return pred_instances, {}, all_scores, all_boxes
+
+    def _forward_box(self, features, proposals, targets):
+        """roi_heads_oicr.py:320-421."""
+        nhwc, rois, obj = self._gather_inputs(features, proposals)
+        dev = nhwc.device
+        nper = [len(p) for p in proposals]
+        n_img = len(proposals)
+        K = self.num_classes
+        if self.training:
+            ints, _, oh = get_image_level_gt(targets, K)
+            self.gt_classes_img_int, self.gt_classes_img_oh = ints, oh
+            gmax = max(1, max(len(g) for g in ints))
+            gcl = torch.zeros((n_img, gmax), dtype=torch.int32)
+            for i, g in enumerate(ints):
+                gcl[i, : len(g)] = g.to(torch.int32)
+            off = torch.tensor([0] + list(torch.tensor(nper).cumsum(0).tolist()), dtype=torch.int32)
+            gt = dict(onehot=oh.to(dev, non_blocking=True), classes=gcl.to(dev, non_blocking=True),
+                      count=torch.tensor([len(g) for g in ints], dtype=torch.int32).to(dev, non_blocking=True),
+                      props=rois[:, 1:].contiguous())
+            losses, state = self._engine.forward(nhwc, rois, obj, True, off.to(dev, non_blocking=True), n_img, gt)
+            self.pred_class_img_logits = state["aux"]["img_scores"]
+            self._last_state = state
+            if has_event_storage():  # kept as device scalars: no sync (the reference syncs 3x here)
+                st = get_event_storage()
+                o1 = obj + 1
+                st.put_scalar("proposals/objectness_logits+1 mean", o1.mean())
+                st.put_scalar("proposals/objectness_logits+1 max", o1.max())
+                st.put_scalar("proposals/objectness_logits+1 min", o1.min())
+            return losses
+        w, col = self._engine.forward(nhwc, rois, obj, False)
+        heads = [k for k in range(self.refine_K)]
+        props = rois[:, 1:].contiguous()
+        if self.refine_K == 0:
+            raise DrnError("WSDDN-only inference is not built yet")
+        last = self.box_refinery[-1]
+        if self.refine_reg[-1]:
+            probs, _ = ops.softmax_ce(w["logits"], col["r%d" % heads[-1]], K + 1)
+            boxes = ops.apply_deltas(w["logits"], props, K, last.box2box_transform.weights, col0=col["b%d" % heads[-1]])
+        else:
+            probs = ops.mean_softmax(w["logits"], [col["r%d" % k] for k in heads], K + 1)
+            boxes = ops.apply_deltas(None, props, K, last.box2box_transform.weights)
+        results, all_scores, all_boxes = [], [], []
+        for p, s, b in zip(proposals, probs.split(nper), boxes.split(nper)):
+            ob, os_, oc, _ = ops.detect_topk(b, s, p.image_size, last.test_score_thresh, last.test_nms_thresh,
+                                             last.test_topk_per_image)
+            r = Instances(p.image_size)
+            r.pred_boxes = Boxes(ob)
+            r.scores = os_
+            r.pred_classes = oc
+            results.append(r)
+            all_scores.append(s.unsqueeze(0))
+            all_boxes.append(b.unsqueeze(0))
+        return results, all_scores, all_boxes
+
+
+@ROI_HEADS_REGISTRY.register()
+class WSDDNROIHeads(OICRROIHeads):
+    """roi_heads_wsddn.py: the OICR heads without refinement branches (training only on this path)."""
+
+    _refine_from_cfg = False
+
+
+def build_roi_heads(cfg, input_shape):
+    return ROI_HEADS_REGISTRY.get(cfg.MODEL.ROI_HEADS.NAME)(cfg, input_shape)

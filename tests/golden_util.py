@@ -47,3 +47,83 @@ def dropmasks_from(d):
     if "dropmask0" in d:
         return [torch.from_numpy(d["dropmask0"]), torch.from_numpy(d["dropmask1"])]
     return None
+
+
+# --------------------------------------------------------------------------------------------
+# Product-side helpers (HIP path)
+# --------------------------------------------------------------------------------------------
+_YAML = {"wsr50": "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", "wsr18": "PascalVOC-Detection/oicr_WSR_18_DC5_1x.yaml",
+         "wsr101": "PascalVOC-Detection/oicr_WSR_101_DC5_1x.yaml", "vgg16": "PascalVOC-Detection/oicr_V_16_DC5_1x.yaml"}
+
+
+def drn_cfg(ocfg, device="cuda", freeze_at=5):
+    """Product config equal to what the reference yaml + the fixture's overrides produce.  The yaml files are
+    not available on the GPU box, so the values the shipped oicr_* yamls set are spelled out here;
+    tests/test_surface_cpu.py checks (in the build container) that loading the unmodified yaml gives the same."""
+    from __graft_entry__ import load_package
+
+    load_package()
+    from drn_wsod_pytorch_amd.config import add_wsl_config, get_cfg
+
+    cfg = get_cfg()
+    add_wsl_config(cfg)
+    vgg = ocfg.arch == "vgg16"
+    feat = ocfg.out_feature
+    L = ["MODEL.META_ARCHITECTURE", "GeneralizedRCNNWSL", "MODEL.DEVICE", device, "MODEL.LOAD_PROPOSALS", "True",
+         "MODEL.PIXEL_MEAN", str(list(ocfg.pixel_mean)), "MODEL.BACKBONE.FREEZE_AT", str(freeze_at),
+         "MODEL.BACKBONE.NAME", "build_vgg_backbone" if vgg else "build_ws_resnet_backbone",
+         "MODEL.ROI_HEADS.NAME", "OICRROIHeads", "MODEL.ROI_HEADS.NUM_CLASSES", str(ocfg.num_classes),
+         "MODEL.ROI_HEADS.IN_FEATURES", str([feat]), "MODEL.ROI_HEADS.SCORE_THRESH_TEST", "0.00001",
+         "MODEL.ROI_HEADS.NMS_THRESH_TEST", "0.3", "MODEL.ROI_HEADS.PROPOSAL_APPEND_GT", "False",
+         "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", "4096", "MODEL.ROI_HEADS.POSITIVE_FRACTION", "1.0",
+         "MODEL.ROI_BOX_HEAD.NAME", "DiscriminativeAdaptionNeck", "MODEL.ROI_BOX_HEAD.POOLER_TYPE", ocfg.pooler_type,
+         "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", str(ocfg.pooler_res), "MODEL.ROI_BOX_HEAD.NUM_CONV", "0",
+         "MODEL.ROI_BOX_HEAD.NUM_FC", "2", "MODEL.ROI_BOX_HEAD.DAN_DIM", str(list(ocfg.dan_dim)),
+         "WSL.REFINE_NUM", str(ocfg.refine_num), "WSL.REFINE_REG", str(list(ocfg.refine_reg)),
+         "SOLVER.BASE_LR", str(ocfg.base_lr), "SOLVER.WEIGHT_DECAY", "0.0005", "SOLVER.BIAS_LR_FACTOR", "2.0",
+         "SOLVER.WEIGHT_DECAY_BIAS", "0.0", "SOLVER.WARMUP_ITERS", "0", "SOLVER.STEPS", "(35000, 50000)",
+         "SOLVER.MAX_ITER", "50000", "SOLVER.IMS_PER_BATCH", "4"]
+    if vgg:
+        L += ["MODEL.VGG.DEPTH", "16", "MODEL.VGG.CONV5_DILATION", str(ocfg.res5_dilation)]
+    else:
+        L += ["MODEL.RESNETS.DEPTH", ocfg.arch[3:], "MODEL.RESNETS.OUT_FEATURES", str([feat]),
+              "MODEL.RESNETS.RES5_DILATION", str(ocfg.res5_dilation), "MODEL.RESNETS.STEM_OUT_CHANNELS",
+              str(ocfg.stem_out), "MODEL.RESNETS.RES2_OUT_CHANNELS", str(ocfg.res2_out),
+              "MODEL.RESNETS.WIDTH_PER_GROUP", str(ocfg.width_per_group)]
+    cfg.merge_from_list(L)
+    return cfg
+
+
+def drn_model(ocfg, seed, device="cuda", freeze_at=5, precision="fp32"):
+    """Build the product model and fill it with the same name-seeded weights as the reference / oracle."""
+    from __graft_entry__ import load_package
+
+    pkg = load_package()
+    pkg.set_precision(precision)
+    from drn_wsod_pytorch_amd.modeling import build_model
+
+    cfg = drn_cfg(ocfg, device, freeze_at)
+    model = build_model(cfg)
+    sd = model.state_dict()
+    new = {n: (t if n in ("pixel_mean", "pixel_std") else O.seeded_tensor(n, tuple(t.shape), seed)) for n, t in sd.items()}
+    model.load_state_dict(new)
+    return cfg, model
+
+
+def drn_inputs(batch, with_gt=True):
+    from drn_wsod_pytorch_amd.structures import Boxes, Instances
+
+    out = []
+    for b in batch:
+        h, w = b["image"].shape[1:]
+        prop = Instances((h, w))
+        prop.proposal_boxes = Boxes(b["proposal_boxes"])
+        prop.objectness_logits = b["objectness_logits"]
+        d = {"image": b["image"], "proposals": prop, "height": h, "width": w}
+        if with_gt:
+            inst = Instances((h, w))
+            inst.gt_boxes = Boxes(b["gt_boxes"]) if "gt_boxes" in b else Boxes(torch.zeros(len(b["gt_classes"]), 4))
+            inst.gt_classes = b["gt_classes"]
+            d["instances"] = inst
+        out.append(d)
+    return out

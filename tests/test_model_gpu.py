@@ -1,0 +1,176 @@
+"""GPU parity of the whole path (GeneralizedRCNNWSL -> backbone -> OICRROIHeads -> losses -> backward ->
+fused SGD -> inference) against golden vectors of the unmodified reference and against the oracle.
+
+fp32 parity mode: losses within 1e-4 (BASELINE north star), gradients within 2e-3 of their scale,
+feature maps within 1e-4.  bf16 fast mode: compared with the same goldens at the looser tolerance
+stated at the check (bf16 operands carry 2^-9 relative rounding per element)."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as G
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+O = G.O
+FROZEN_CASES = [n for n in sorted(G.MODEL_CASES) if G.FREEZE_AT.get(n, 5) == 5 and "reg" not in n]
+
+
+def _relerr(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+
+
+def _setup(name, precision):
+    assert torch.cuda.is_available()
+    ocfg = G.MODEL_CASES[name]
+    d = G.load(name)
+    cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, precision)
+    masks = G.dropmasks_from(d)
+    model.roi_heads.box_head.dropout_masks = [m.cuda() for m in masks] if masks else None
+    if masks is None:
+        model.roi_heads.box_head.dropout_p = 0.0  # fixtures were generated with dropout patched to identity
+    return ocfg, d, cfg, model
+
+
+@pytest.mark.parametrize("name", FROZEN_CASES)
+def test_train_two_steps_fp32(name):
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    ocfg, d, cfg, model = _setup(name, "fp32")
+    batch = G.drn_inputs(G.batch_from(d))
+    model.train()
+    opt = build_optimizer(cfg, model)
+    before = {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}
+    for step in range(2):
+        opt.zero_grad()
+        losses = model(batch)
+        sum(losses.values()).backward()
+        got = {k: float(v) for k, v in losses.items()}
+        for k, v in got.items():
+            ref = float(d["step%d_%s" % (step, k)])
+            tol = 1e-4 if step == 0 else 2e-2  # step 1 sits behind one lr=0.01 SGD step on an ill-conditioned toy net
+            assert abs(v - ref) <= tol * max(abs(ref), 1e-3), (step, k, v, ref)
+        if step == 0:
+            for n, p in model.named_parameters():
+                if not p.requires_grad:
+                    continue
+                if "gradnone0." + n in d:
+                    assert p.grad is None  # unused bbox_pred
+                    continue
+                g = p.grad.detach().cpu().numpy()
+                if "grad0." + n in d:
+                    assert _relerr(g, d["grad0." + n]) < 2e-3, n
+                else:
+                    assert _relerr(g.reshape(-1)[:4096], d["gradhead0." + n]) < 2e-3, n
+                    ref_abs = float(d["gradabs0." + n])
+                    assert abs(float(np.abs(g.astype(np.float64)).sum()) - ref_abs) < 2e-3 * ref_abs, n
+        opt.step()
+        if step == 0:  # parameter delta of the first step = -lr * (g + wd * p): checks the fused SGD end to end
+            for n, p in model.named_parameters():
+                if p.requires_grad and p.grad is not None:
+                    lr = cfg.SOLVER.BASE_LR * (2.0 if n.endswith("bias") else 1.0)
+                    wd = 0.0 if n.endswith("bias") else cfg.SOLVER.WEIGHT_DECAY
+                    exp = before[n] - lr * (p.grad + wd * before[n])
+                    assert torch.allclose(p.detach(), exp, rtol=1e-5, atol=1e-7), n
+    for n, p in model.named_parameters():
+        if p.requires_grad and ("after2.head." + n) in d:
+            got = p.detach().reshape(-1)[:2048].cpu().numpy()
+            assert _relerr(got, d["after2.head." + n]) < 5e-3, n
+
+
+@pytest.mark.parametrize("name", FROZEN_CASES)
+def test_backbone_features_and_inference_fp32(name):
+    ocfg, d, cfg, model = _setup(name, "fp32")
+    batch = G.batch_from(d)
+    model.eval()
+    with torch.no_grad():
+        images = model.preprocess_image(G.drn_inputs(batch, False))
+        feats = model.backbone(images.tensor)
+    f = feats[str(d["feat_name"])].float().cpu().numpy()
+    assert f.shape == d["feat"].shape
+    assert _relerr(f, d["feat"]) < 1e-4
+    # inference with the step-0 weights against the oracle on the same weights (the fixture's detections were
+    # taken after two SGD steps; those are covered by test_train_two_steps + the bit-exact tail tests)
+    p = O.seeded_params(O.param_shapes(ocfg), int(d["seed"]))
+    ocfg.dropout = 0.0
+    ref, ref_scores, ref_boxes = O.model_inference(p, batch, ocfg)
+    res, all_scores, all_boxes = model.inference(G.drn_inputs(batch, False), do_postprocess=False)
+    for i in range(len(batch)):
+        assert _relerr(all_scores[i][0].cpu().numpy(), ref_scores[i].numpy()) < 1e-4
+        assert torch.equal(all_boxes[i][0].cpu(), ref_boxes[i])  # zero-delta decode: bit-exact
+        rb, rs, rc, rr = ref[i]
+        # detections: identical classes / order wherever the oracle's score gaps exceed the fp32 noise
+        n = min(len(rs), len(res[i]))
+        gs = res[i].scores.cpu()
+        assert abs(len(rs) - len(res[i])) <= 2
+        assert torch.allclose(gs[:n], rs[:n], rtol=1e-3, atol=1e-6)
+        gaps = (rs[:-1] - rs[1:]).abs() if len(rs) > 1 else torch.zeros(0)
+        stable = torch.ones(n, dtype=torch.bool)
+        if n > 1:
+            small = gaps[: n - 1] < 1e-5 * rs[: n - 1].abs()
+            stable[:-1] &= ~small
+            stable[1:] &= ~small
+        assert torch.equal(res[i].pred_classes.cpu()[stable], rc[:n][stable])
+    out = model(G.drn_inputs(batch, False))
+    assert len(out) == len(batch) and "instances" in out[0]
+
+
+def test_roialign_pooler_model_fp32():
+    """ROIAlignV2 pooling inside the full model (frozen backbone) against the oracle run live."""
+    name = "model_r50c4_align_tiny"
+    ocfg = G.MODEL_CASES[name]
+    d = G.load(name)
+    cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, "fp32")
+    model.roi_heads.box_head.dropout_p = 0.0
+    batch = G.batch_from(d)
+    p = O.seeded_params(O.param_shapes(ocfg), int(d["seed"]))
+    ocfg.dropout = 0.0
+    ref = O.model_train_losses(p, batch, ocfg)
+    model.train()
+    losses = model(G.drn_inputs(batch))
+    for k, v in losses.items():
+        assert abs(float(v) - float(ref[k])) <= 1e-4 * max(abs(float(ref[k])), 1e-3), (k, float(v), float(ref[k]))
+
+
+def test_unfrozen_backbone_fails_loudly():
+    from drn_wsod_pytorch_amd._cabi import DrnError
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    name = "model_r50c4_align_tiny"
+    ocfg = G.MODEL_CASES[name]
+    cfg, model = G.drn_model(ocfg, 1, "cuda", 3, "fp32")
+    with pytest.raises(DrnError):
+        build_optimizer(cfg, model)
+    model.train()
+    with pytest.raises(DrnError):
+        model(G.drn_inputs(G.batch_from(G.load(name))))
+
+
+@pytest.mark.parametrize("name", ["model_r50c4_tiny", "model_vgg16_small"])
+def test_train_step_bf16(name):
+    """bf16 fast mode on the same fixture: loss agreement within 3e-2 relative (bf16 operands), finite grads."""
+    ocfg, d, cfg, model = _setup(name, "bf16")
+    model.train()
+    losses = model(G.drn_inputs(G.batch_from(d)))
+    sum(losses.values()).backward()
+    for k, v in losses.items():
+        ref = float(d["step0_%s" % k])
+        assert abs(float(v) - ref) <= 3e-2 * max(abs(ref), 1e-2), (k, float(v), ref)
+    for n, p in model.named_parameters():
+        if p.requires_grad and p.grad is not None:
+            assert torch.isfinite(p.grad).all(), n
+    load_package().set_precision("fp32")
+
+
+def test_grad_accumulation_iter_size():
+    """WSL.ITER_SIZE semantics (train_net.py:100-113): two backward() calls accumulate before one step."""
+    ocfg, d, cfg, model = _setup("model_r50c4_tiny", "fp32")
+    batch = G.drn_inputs(G.batch_from(d))
+    model.train()
+    sum(model(batch).values()).backward()
+    g1 = model.roi_heads.box_head.fc1.weight.grad.clone()
+    b1 = model.roi_heads.box_refinery_0.cls_score.bias.grad.clone()
+    (sum(model(batch).values()) * 0.5).backward()
+    assert torch.allclose(model.roi_heads.box_head.fc1.weight.grad, 1.5 * g1, rtol=1e-4, atol=1e-7)
+    assert torch.allclose(model.roi_heads.box_refinery_0.cls_score.bias.grad, 1.5 * b1, rtol=1e-4, atol=1e-7)

@@ -1,0 +1,128 @@
+"""CPU tests of the host-side operator surface: registries, config loading of the UNMODIFIED reference yaml
+files (when /root/reference is present), state_dict keys/shapes equal to the reference's (through the
+reference-pinned oracle table), optimizer parameter groups, LR schedule, and loud failure off the path."""
+import os
+
+import pytest
+import torch
+
+import golden_util as G
+from __graft_entry__ import load_package
+
+O = G.O
+REF_CFG = "/root/reference/projects/WSL/configs"
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_package()
+
+
+def _build(ocfg, freeze_at=5):
+    from drn_wsod_pytorch_amd.modeling import build_model
+
+    return build_model(G.drn_cfg(ocfg, "cpu", freeze_at))
+
+
+@pytest.mark.parametrize("name", sorted(G.MODEL_CASES))
+def test_state_dict_matches_reference_names(pkg, name):
+    ocfg = G.MODEL_CASES[name]
+    model = _build(ocfg)
+    sd = {k: tuple(v.shape) for k, v in model.state_dict().items() if k not in ("pixel_mean", "pixel_std")}
+    assert sd == {k: tuple(v) for k, v in O.param_shapes(ocfg).items()}
+    trainable = sorted(n for n, p in model.named_parameters() if p.requires_grad)
+    d = G.load(name)
+    if G.FREEZE_AT.get(name, 5) == 5:
+        assert trainable == sorted(d["trainable"].tolist())
+
+
+def test_full_size_r50_c4_shapes(pkg):
+    """BASELINE configs[1]: R50-WS truncated at res4 -> fc6 = Linear(50176, 2048); 112,560,471 trainable."""
+    ocfg = O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1)
+    model = _build(ocfg)
+    assert tuple(model.roi_heads.box_head.fc1.weight.shape) == (2048, 50176)
+    assert sum(p.numel() for p in model.parameters() if p.requires_grad) == 112560471
+    assert model.backbone.output_shape()["res4"].stride == 16 and model.backbone.output_shape()["res4"].channels == 1024
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_CFG), reason="reference yaml files only exist in the build container")
+@pytest.mark.parametrize("arch,yaml_rel", [("wsr50", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml"),
+                                            ("wsr18", "PascalVOC-Detection/oicr_WSR_18_DC5_1x.yaml"),
+                                            ("wsr101", "PascalVOC-Detection/oicr_WSR_101_DC5_1x.yaml"),
+                                            ("vgg16", "PascalVOC-Detection/oicr_V_16_DC5_1x.yaml"),
+                                            ("wsr50", "COCO-Detection/oicr_WSR_50_DC5_1x.yaml"),
+                                            ("wsr50", "PascalVOC-Detection/reg/oicr_WSR_50_DC5_1x.yaml")])
+def test_unmodified_reference_yaml_loads(pkg, arch, yaml_rel):
+    from drn_wsod_pytorch_amd.config import add_wsl_config, get_cfg
+    from drn_wsod_pytorch_amd.modeling import build_model
+
+    path = os.path.join(REF_CFG, yaml_rel)
+    if not os.path.exists(path):
+        pytest.skip(yaml_rel)
+    cfg = get_cfg()
+    add_wsl_config(cfg)
+    cfg.merge_from_file(path)
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu"])
+    assert cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNNWSL" and cfg.MODEL.ROI_HEADS.NAME == "OICRROIHeads"
+    assert cfg.MODEL.BACKBONE.FREEZE_AT == 5 and cfg.SOLVER.BIAS_LR_FACTOR == 2.0 and cfg.SOLVER.WEIGHT_DECAY_BIAS == 0.0
+    assert tuple(cfg.SOLVER.STEPS) == (35000, 50000) or "COCO" in yaml_rel
+    if "COCO" not in yaml_rel and "reg/" not in yaml_rel:
+        K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+        feat = "plain5" if arch == "vgg16" else "res5"
+        ocfg = O.OracleCfg(arch=arch, out_feature=feat, res5_dilation=2, num_classes=K,
+                           dan_dim=tuple(cfg.MODEL.ROI_BOX_HEAD.DAN_DIM), res2_out=cfg.MODEL.RESNETS.RES2_OUT_CHANNELS,
+                           pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN), base_lr=cfg.SOLVER.BASE_LR)
+        ref = G.drn_cfg(ocfg, "cpu")
+        for key in ("MODEL.ROI_HEADS", "MODEL.ROI_BOX_HEAD", "MODEL.BACKBONE", "WSL"):
+            a, b = cfg, ref
+            for part in key.split("."):
+                a, b = a[part], b[part]
+            for k in b:
+                assert a[k] == b[k] or list(a[k]) == list(b[k]), (key, k, a[k], b[k])
+    if arch in ("wsr18",):
+        m = build_model(cfg)
+        assert "backbone.res5.1.conv2.weight" in m.state_dict()
+
+
+def test_optimizer_groups_and_schedule(pkg):
+    from drn_wsod_pytorch_amd.engine import WarmupMultiStepLR
+
+    class _Opt:
+        param_groups = [{"lr": 0.01, "initial_lr": 0.01}, {"lr": 0.02, "initial_lr": 0.02}]
+
+    sched = WarmupMultiStepLR(_Opt, (3, 5), 0.1, warmup_factor=0.001, warmup_iters=2)
+    lrs = [_Opt.param_groups[0]["lr"]]
+    for _ in range(6):
+        sched.step()
+        lrs.append(_Opt.param_groups[0]["lr"])
+    exp = [0.01 * 0.001, 0.01 * (0.001 * 0.5 + 0.5), 0.01, 0.001, 0.001, 0.0001, 0.0001]
+    assert all(abs(a - b) < 1e-12 for a, b in zip(lrs, exp)), lrs
+
+
+def test_off_path_fails_loudly(pkg):
+    from drn_wsod_pytorch_amd._cabi import DrnError
+    from drn_wsod_pytorch_amd.config import add_wsl_config, get_cfg
+    from drn_wsod_pytorch_amd.modeling import build_model
+
+    ocfg = G.MODEL_CASES["model_r50c4_tiny"]
+    cfg = G.drn_cfg(ocfg, "cpu")
+    cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "PCLROIHeads"])
+    with pytest.raises(KeyError):
+        build_model(cfg)
+    model = _build(ocfg)
+    model.train()
+    batch = G.drn_inputs(G.batch_from(G.load("model_r50c4_tiny")))
+    with pytest.raises((DrnError, AssertionError)):  # CPU tensors: the product has no CPU path
+        model(batch)
+
+
+def test_instances_boxes_api(pkg):
+    from drn_wsod_pytorch_amd.structures import Boxes, Instances
+
+    b = Boxes(torch.tensor([[0.0, 0, 10, 10], [5, 5, 5, 9]]))
+    assert b.area().tolist() == [100.0, 0.0] and b.nonempty().tolist() == [True, False]
+    i = Instances((20, 30), pred_boxes=b, scores=torch.tensor([0.5, 0.2]))
+    assert len(i) == 2 and len(i[i.scores > 0.3]) == 1 and i.image_size == (20, 30)
+    with pytest.raises(AssertionError):
+        i.bad = torch.zeros(3)
+    assert len(Instances.cat([i, i])) == 4
