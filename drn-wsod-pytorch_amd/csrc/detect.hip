@@ -25,6 +25,7 @@ struct CandParams {
   int* count;     // [1]
   float* maxcoord;  // [1] max over candidate box coordinates
   int cap;
+  int* rowmap;    // [R] scratch: index of row r among the finite rows, or -1
 };
 
 // single block; ordered compaction via wave ballots + block prefix over 1024-element chunks
@@ -36,6 +37,31 @@ __global__ __launch_bounds__(1024) void candidates_kernel(CandParams p) {
   if (threadIdx.x == 0) base = 0;
   float mymax = -INFINITY;
   __syncthreads();
+  // finite-row filter (fast_rcnn.py:108-111): rows with any non-finite box or score are dropped BEFORE
+  // indexing, so every later row index refers to the compacted arrays
+  for (int start = 0; start < p.R; start += 1024) {
+    const int r = start + threadIdx.x;
+    bool finite = false;
+    if (r < p.R) {
+      finite = true;
+      const float* srow = p.scores + (long)r * (p.K + 1);
+      for (int k = 0; k <= p.K && finite; ++k) finite = isfinite(srow[k]);
+      const float* brow = p.boxes + (long)r * 4 * p.nreg;
+      for (int k = 0; k < 4 * p.nreg && finite; ++k) finite = isfinite(brow[k]);
+    }
+    const unsigned long long bal = __ballot(finite);
+    const int wprefix = __popcll(bal & ((1ULL << lane) - 1ULL));
+    if (lane == 0) wcnt[w] = __popcll(bal);
+    __syncthreads();
+    int woff = 0, tot = 0;
+    for (int q = 0; q < 16; ++q) { if (q < w) woff += wcnt[q]; tot += wcnt[q]; }
+    if (r < p.R) p.rowmap[r] = finite ? base + woff + wprefix : -1;
+    __syncthreads();
+    if (threadIdx.x == 0) base += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
   const long total = (long)p.R * p.K;
   for (long start = 0; start < total; start += 1024) {
     const long i = start + threadIdx.x;
@@ -44,14 +70,8 @@ __global__ __launch_bounds__(1024) void candidates_kernel(CandParams p) {
     float s = 0.f;
     if (i < total) {
       r = i / p.K; c = i - (long)r * p.K;
-      // finite-row filter (fast_rcnn.py:108-111): rows with any non-finite box or score are dropped
-      bool finite = true;
-      const float* srow = p.scores + (long)r * (p.K + 1);
-      for (int k = 0; k <= p.K && finite; ++k) finite = isfinite(srow[k]);
-      const float* brow = p.boxes + (long)r * 4 * p.nreg;
-      for (int k = 0; k < 4 * p.nreg && finite; ++k) finite = isfinite(brow[k]);
-      s = srow[c];
-      flag = finite && s > p.thresh;
+      s = p.scores[(long)r * (p.K + 1) + c];
+      flag = p.rowmap[r] >= 0 && s > p.thresh;
     }
     const unsigned long long bal = __ballot(flag);
     const int wprefix = __popcll(bal & ((1ULL << lane) - 1ULL));
@@ -67,7 +87,7 @@ __global__ __launch_bounds__(1024) void candidates_kernel(CandParams p) {
       const float x1 = fminf(fmaxf(b[0], 0.f), p.img_w), y1 = fminf(fmaxf(b[1], 0.f), p.img_h);
       const float x2 = fminf(fmaxf(b[2], 0.f), p.img_w), y2 = fminf(fmaxf(b[3], 0.f), p.img_h);
       p.c_box[4 * (long)pos] = x1; p.c_box[4 * (long)pos + 1] = y1; p.c_box[4 * (long)pos + 2] = x2; p.c_box[4 * (long)pos + 3] = y2;
-      p.c_score[pos] = s; p.c_row[pos] = r; p.c_cls[pos] = c;
+      p.c_score[pos] = s; p.c_row[pos] = p.rowmap[r]; p.c_cls[pos] = c;
       mymax = fmaxf(mymax, fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
     }
     __syncthreads();
@@ -217,11 +237,12 @@ int drn_detect_topk(const float* boxes, const float* scores, int R, int K, int n
   if (!boxes || !scores || !workspace || !keep_ids || !n_keep || topk < 1 || topk > NMS_MAXK || cap < 1 || R < 0)
     return DRN_ERR_ARG;
   if (nreg != 1 && nreg != K) return DRN_ERR_ARG;
+  if (cap < R) return DRN_ERR_ARG;
   if (workspace_bytes < drn_detect_workspace_bytes(cap)) return DRN_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   Ws k = carve(workspace, workspace_bytes, cap);
   CandParams cp{boxes, scores, R, K, nreg, img_h, img_w, score_thresh, k.c_box, k.c_score, k.c_row, k.c_cls, k.count,
-                k.maxcoord, cap};
+                k.maxcoord, cap, (int*)k.s_score};  // s_score doubles as the row map until the sort overwrites it
   hipLaunchKernelGGL(candidates_kernel, dim3(1), dim3(1024), 0, st, cp);
   hipLaunchKernelGGL(iota_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, k.iota, cap);
   hipLaunchKernelGGL(fill_tail_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, k.c_score, k.count, cap);

@@ -13,12 +13,15 @@ from __graft_entry__ import load_package
 
 pytestmark = pytest.mark.gpu
 O = G.O
+load_package()  # registers the hyphen-named package directory as drn_wsod_pytorch_amd
 FROZEN_CASES = [n for n in sorted(G.MODEL_CASES) if G.FREEZE_AT.get(n, 5) == 5 and "reg" not in n]
 
 
-def _relerr(a, b):
+def _relerr(a, b, floor=1e-6):
+    """max |a-b| relative to the scale of b; `floor` keeps tensors whose true value is exactly zero (e.g. the
+    det-branch bias gradient: a column softmax is shift invariant) from dividing rounding noise by noise"""
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
-    return float(np.abs(a - b).max() / (np.abs(b).max() + 1e-12))
+    return float(np.abs(a - b).max() / (np.abs(b).max() + floor))
 
 
 def _setup(name, precision):
@@ -46,7 +49,7 @@ def test_train_two_steps_fp32(name):
         opt.zero_grad()
         losses = model(batch)
         sum(losses.values()).backward()
-        got = {k: float(v) for k, v in losses.items()}
+        got = {k: float(v.detach()) for k, v in losses.items()}
         for k, v in got.items():
             ref = float(d["step%d_%s" % (step, k)])
             tol = 1e-4 if step == 0 else 2e-2  # step 1 sits behind one lr=0.01 SGD step on an ill-conditioned toy net
@@ -60,7 +63,11 @@ def test_train_two_steps_fp32(name):
                     continue
                 g = p.grad.detach().cpu().numpy()
                 if "grad0." + n in d:
-                    assert _relerr(g, d["grad0." + n]) < 2e-3, n
+                    ref_g = d["grad0." + n]
+                    if np.abs(ref_g).max() < 1e-6:  # analytically zero (det bias): both sides are rounding noise
+                        assert np.abs(g).max() < 1e-5, n
+                    else:
+                        assert _relerr(g, ref_g) < 2e-3, n
                 else:
                     assert _relerr(g.reshape(-1)[:4096], d["gradhead0." + n]) < 2e-3, n
                     ref_abs = float(d["gradabs0." + n])
@@ -130,7 +137,7 @@ def test_roialign_pooler_model_fp32():
     model.train()
     losses = model(G.drn_inputs(batch))
     for k, v in losses.items():
-        assert abs(float(v) - float(ref[k])) <= 1e-4 * max(abs(float(ref[k])), 1e-3), (k, float(v), float(ref[k]))
+        assert abs(float(v.detach()) - float(ref[k])) <= 1e-4 * max(abs(float(ref[k])), 1e-3), (k, float(v.detach()), float(ref[k]))
 
 
 def test_unfrozen_backbone_fails_loudly():
@@ -156,7 +163,7 @@ def test_train_step_bf16(name):
     sum(losses.values()).backward()
     for k, v in losses.items():
         ref = float(d["step0_%s" % k])
-        assert abs(float(v) - ref) <= 3e-2 * max(abs(ref), 1e-2), (k, float(v), ref)
+        assert abs(float(v.detach()) - ref) <= 3e-2 * max(abs(ref), 1e-2), (k, float(v.detach()), ref)
     for n, p in model.named_parameters():
         if p.requires_grad and p.grad is not None:
             assert torch.isfinite(p.grad).all(), n

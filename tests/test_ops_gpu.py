@@ -282,7 +282,7 @@ def test_wsddn_fwd_bwd(drn, K, M_per):
     scores, img_scores, lp = drn.wsddn_fwd_bwd(logits.to(DEV), 0, K, K, off.to(DEV), n_img, oh.to(DEV), dlogits=dl)
     assert torch.allclose(scores.cpu(), sc.detach(), rtol=1e-5, atol=1e-9)
     assert torch.allclose(img_scores.cpu(), O.predict_probs_img(sc.detach(), M_per), rtol=1e-5)
-    assert abs(float(lp.sum()) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert abs(float(lp.sum()) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach()))
     assert torch.allclose(dl.cpu()[:, :2 * K], lg.grad[:, :2 * K], rtol=1e-4, atol=1e-8)
 
 
@@ -346,7 +346,7 @@ def test_softmax_ce(drn, K, M):
     dl = torch.zeros((M, ld), device=DEV)
     probs, l = drn.softmax_ce(logits.to(DEV), col0, K + 1, labels.int().to(DEV), w.to(DEV), dlogits=dl)
     assert torch.allclose(probs.cpu(), F.softmax(logits[:, col0: col0 + K + 1], -1), rtol=1e-5, atol=1e-9)
-    assert abs(float(l) - float(loss)) <= 2e-5 * abs(float(loss))
+    assert abs(float(l) - float(loss.detach())) <= 2e-5 * abs(float(loss.detach()))
     assert torch.allclose(dl.cpu(), lg.grad, rtol=1e-4, atol=1e-9)
     p2 = drn.mean_softmax(logits.to(DEV), [0, 3, 7], K + 1).cpu()
     ref = sum(F.softmax(logits[:, c: c + K + 1], -1) for c in (0, 3, 7)) / 3
