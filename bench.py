@@ -1,0 +1,224 @@
+"""bench.py — training images/sec of the DRN-WSOD hot path on MI355X.
+
+  python bench.py --gpus 1 --steps 20 --warmup 5
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+Workload = BASELINE.json configs[1]: DRN-WSOD ResNet50-WS truncated at res4 ("R50-C4"), VOC07-shaped
+synthetic input: one 224x224 image per GPU per iteration (the reference's operating point, IMS_PER_BATCH = #GPUs),
+2000 random proposals, K = 20, 3 OICR refinements, frozen backbone (FREEZE_AT = 5 as shipped), bf16 operands with
+fp32 accumulation.  One step = forward + backward + gradient all-reduce (N > 1) + fused SGD step.
+Inputs are generated once and are resident in HBM before the timed region starts.
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the fc6 MFMA GEMM, timed live with HIP events on
+its own stream) and `cpu_baseline` (the oracle — a port — timed on this box's host cores on the same workload)."""
+import argparse
+import json
+import math
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+from __graft_entry__ import load_package  # noqa: E402
+
+METRIC = "images/sec training, VOC07 DRN-WSOD R50-C4 2k proposals, 1/2/4/8 GPUs"
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+def build_cfg(pkg, device, R50_C4=True):
+    from drn_wsod_pytorch_amd.config import add_wsl_config, get_cfg
+
+    cfg = get_cfg()
+    add_wsl_config(cfg)
+    # = projects/WSL/configs/PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml + the C4 override of SURVEY F1
+    cfg.merge_from_list([
+        "MODEL.META_ARCHITECTURE", "GeneralizedRCNNWSL", "MODEL.DEVICE", device, "MODEL.LOAD_PROPOSALS", "True",
+        "MODEL.PIXEL_MEAN", "[102.9801, 115.9465, 122.7717]", "MODEL.BACKBONE.NAME", "build_ws_resnet_backbone",
+        "MODEL.BACKBONE.FREEZE_AT", "5", "MODEL.RESNETS.DEPTH", "50", "MODEL.RESNETS.OUT_FEATURES", "['res4']",
+        "MODEL.RESNETS.RES5_DILATION", "1", "MODEL.ROI_HEADS.NAME", "OICRROIHeads", "MODEL.ROI_HEADS.IN_FEATURES",
+        "['res4']", "MODEL.ROI_HEADS.NUM_CLASSES", "20", "MODEL.ROI_HEADS.SCORE_THRESH_TEST", "0.00001",
+        "MODEL.ROI_HEADS.NMS_THRESH_TEST", "0.3", "MODEL.ROI_HEADS.PROPOSAL_APPEND_GT", "False",
+        "MODEL.ROI_BOX_HEAD.NAME", "DiscriminativeAdaptionNeck", "MODEL.ROI_BOX_HEAD.POOLER_TYPE", "ROIPool",
+        "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", "7", "MODEL.ROI_BOX_HEAD.NUM_CONV", "0", "MODEL.ROI_BOX_HEAD.NUM_FC", "2",
+        "MODEL.ROI_BOX_HEAD.DAN_DIM", "[2048, 4096]", "SOLVER.BASE_LR", "0.01", "SOLVER.WEIGHT_DECAY", "0.0005",
+        "SOLVER.BIAS_LR_FACTOR", "2.0", "SOLVER.WEIGHT_DECAY_BIAS", "0.0", "SOLVER.WARMUP_ITERS", "0",
+        "WSL.REFINE_NUM", "3", "WSL.REFINE_REG", "[False, False, False]", "WSL.ITER_SIZE", "1"])
+    return cfg
+
+
+@torch.no_grad()
+def init_weights(model, seed):
+    """Seeded, rescaled random weights (identical on every rank): default inits saturate the MIL head,
+    so scales are chosen to keep the frozen, un-normalised backbone and fc6/fc7 outputs O(1)."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    for name, t in model.state_dict().items():
+        if name in ("pixel_mean", "pixel_std"):
+            continue
+        leaf = name.rsplit(".", 1)[1]
+        z = torch.randn(t.shape, generator=g)
+        if ".norm." in name:
+            v = {"weight": 0.85 + 0.1 * torch.tanh(z), "bias": 0.05 * z, "running_mean": 0.05 * z,
+                 "running_var": 1.0 + 0.2 * torch.tanh(z)}[leaf]
+            if ".conv3.norm.weight" in name:
+                v = 0.35 * v
+            elif ".conv2.norm.weight" in name:
+                v = 0.6 * v
+        elif leaf == "bias":
+            v = 0.1 + 0.02 * z if "box_head" in name else 0.02 * z
+        elif t.dim() == 4:
+            v = z * math.sqrt(2.0 / (t.shape[1] * t.shape[2] * t.shape[3]))
+            if t.shape[1] == 3:
+                v = v / 64.0
+        else:
+            gain = {"fc1": 1.4, "fc2": 1.4, "cls": 4.0, "det": 4.0, "cls_score": 3.0, "bbox_pred": 0.3}[name.split(".")[-2]]
+            v = z * (gain / math.sqrt(t.shape[1]))
+        t.copy_(v.to(t.device))
+
+
+def synthetic_batches(n_batches, R, K, device, rank, pkg):
+    """image uint8-valued f32 [3,224,224]; proposals x0,y0 ~ U[0,184), w,h ~ U[20, 224-x0|y0];
+    objectness ~ U[0,1) sorted descending; 1..3 distinct GT classes; seed = 1234 + 1000*rank + iter."""
+    from drn_wsod_pytorch_amd.structures import Boxes, Instances
+
+    out = []
+    for it in range(n_batches):
+        g = torch.Generator().manual_seed(1234 + 1000 * rank + it)
+        img = torch.randint(0, 256, (3, 224, 224), generator=g).float()
+        x0, y0 = torch.rand(R, generator=g) * 184, torch.rand(R, generator=g) * 184
+        bw = 20 + torch.rand(R, generator=g) * (224 - x0 - 20)
+        bh = 20 + torch.rand(R, generator=g) * (224 - y0 - 20)
+        boxes = torch.stack([x0, y0, (x0 + bw).clamp(max=224), (y0 + bh).clamp(max=224)], 1)
+        obj = torch.sort(torch.rand(R, generator=g), descending=True).values
+        G = int(torch.randint(1, 4, (1,), generator=g))
+        cls = torch.randperm(K, generator=g)[:G].to(torch.int64)
+        prop = Instances((224, 224))
+        prop.proposal_boxes = Boxes(boxes.to(device))
+        prop.objectness_logits = obj.to(device)
+        inst = Instances((224, 224))
+        inst.gt_boxes = Boxes(boxes[:G].clone())
+        inst.gt_classes = cls  # image-level labels stay on the host (that is where the loader produces them)
+        out.append([{"image": img.to(device), "proposals": prop, "instances": inst, "height": 224, "width": 224,
+                     "_cpu": {"image": img, "proposal_boxes": boxes, "objectness_logits": obj, "gt_classes": cls}}])
+    return out
+
+
+def cpu_baseline(batches, n_steps=2):
+    """The oracle (CPU restatement, a 'port') on the same workload and step definition, bounded to a few steps."""
+    from oracle import wsod_oracle as O
+
+    torch.set_num_threads(os.cpu_count() or 1)
+    cfg = O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1, dropout=0.5)
+    p = O.init_params(cfg, seed=0)
+    opt = O.SGDState(cfg)
+    b = [batches[0][0]["_cpu"]]
+    O.train_step(p, b, cfg, opt)  # warm-up (thread pools, allocator)
+    t0 = time.perf_counter()
+    for i in range(n_steps):
+        O.train_step(p, [batches[(i + 1) % len(batches)][0]["_cpu"]], cfg, opt)
+    dt = time.perf_counter() - t0
+    return {"value": n_steps / dt, "unit": "images/sec", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "%d full train steps (fwd+bwd+SGD) of the same R50-C4 / R=2000 / 224x224 workload, fp32, after "
+                      "1 warm-up step; oracle/wsod_oracle.py on torch-CPU + oracle/roi_ops.c" % n_steps}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--proposals", type=int, default=2000)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
+    import torch.distributed as dist
+
+    torch.cuda.set_device(local_rank)
+    device = "cuda:%d" % local_rank
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+
+    pkg = load_package()
+    pkg._cabi.lib()  # fail loudly if the HIP library is missing
+    pkg.set_precision("bf16")
+    from drn_wsod_pytorch_amd import ops
+    from drn_wsod_pytorch_amd.engine import DataParallel, build_optimizer
+    from drn_wsod_pytorch_amd.modeling import build_model
+
+    cfg = build_cfg(pkg, device)
+    model = build_model(cfg)
+    init_weights(model, seed=0)
+    model.train()
+    opt = build_optimizer(cfg, model)
+    dp = DataParallel(model)
+    dp.broadcast_parameters(0)
+    R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    batches = synthetic_batches(8, R, K, device, rank, pkg)
+
+    def step(i):
+        losses = model(batches[i % len(batches)])
+        sum(losses.values()).backward()
+        dp.finish()
+        opt.step(dp.grad_scale)
+        opt.zero_grad()
+        return losses
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        last = step(i)
+    barrier()
+    ops.GEMM_TIMING = []  # HIP events around every fc6-sized GEMM launch, on the launching stream
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        last = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    timing, ops.GEMM_TIMING = ops.GEMM_TIMING, None
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    loss_vals = {k: float(v.detach()) for k, v in last.items()}
+    assert all(math.isfinite(v) for v in loss_vals.values()), loss_vals
+
+    if rank == 0:
+        # dominant kernel: gemm_nt_kernel<bf16,128,128> at the fc6 forward shape [R x 50176] . [2048 x 50176]^T
+        D1, K1 = model.roi_heads.box_head.fc1.weight.shape
+        fwd = [(a.elapsed_time(b), fl) for (a, b, fl, shape) in timing if shape == (R, D1, K1)]
+        roof = None
+        if fwd:
+            ms = sum(t for t, _ in fwd) / len(fwd)
+            achieved = fwd[0][1] / (ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_kernel<bf16,128,128> (fc6 fwd)",
+                    "avg_launch_ms": ms, "launches_timed": len(fwd)}
+        out = {"metric": METRIC, "value": world * args.steps / dt, "unit": "images/sec", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "config": {"workload": "DRN-WSOD ResNet50-WS C4 (res4 out, stride 16), VOC07-shaped synthetic 224x224, "
+                                      "%d proposals/img, 1 img/GPU/iter, K=20, 3 OICR refinements, frozen backbone "
+                                      "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % R,
+                          "global_batch": world, "proposals": R, "parallelism": "dp%d" % world},
+               "losses_last_step": loss_vals, "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(batches)
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -9,6 +9,7 @@ import torch
 from . import _cabi as C
 
 SCALE_CLAMP = math.log(1000.0 / 16)  # detectron2/modeling/box_regression.py:9
+GEMM_TIMING = None  # set to a list by bench.py to time GEMM launches with HIP events
 
 
 def esize(dtype):
@@ -36,8 +37,14 @@ def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
     ldc = out.stride(-2)
     sstride = out.stride(0) if out.dim() == 3 else 0
     assert out.dim() == 3 or splits == 1
+    if GEMM_TIMING is not None:  # bench.py: HIP events on the launching stream around this launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     C.call("drn_gemm_nt", C.ptr(A), C.ptr(B), C.ptr(out), M, N, K, lda, ldb, ldc, C.dt(A.dtype), splits, sstride,
            int(accumulate), C.stream())
+    if GEMM_TIMING is not None:
+        e1.record()
+        GEMM_TIMING.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
     return out
 
 
