@@ -22,11 +22,11 @@ _SIGS = {
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliilip",
     "drn_bias_act_fwd": "pilppQfplpliiliip",
-    "drn_bias_act_bwd": "plpppfplplpiiiip",
+    "drn_bias_act_bwd": "plpppfplplppiiiip",
     "drn_cast2d": "ppiilliip",
-    "drn_wsddn_fwd_bwd": "pliiipippppplifp",
+    "drn_wsddn_fwd_bwd": "pliiipipppppplifp",
     "drn_oicr_targets": "plpi" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",
-    "drn_softmax_ce": "pliipppplpifp",
+    "drn_softmax_ce": "pliipppplppifp",
     "drn_mean_softmax": "plpiipip",
     "drn_apply_deltas": "plppiipfp",
     "drn_sum_small": "pifpp",

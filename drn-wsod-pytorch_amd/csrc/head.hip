@@ -37,11 +37,15 @@ struct ActParams {
   char* outT; long ld_outT;   // [N][ld_outT] in out_dtype or null
   float* colsum;       // bwd: [N] column sums (bias gradient) or null
   const float* colscale;  // bwd: [N] per-column multiplier of grad_out (per-loss upstream grads) or null
+  float* colpart;      // bwd: [ceil(M/ACT_ROWS)][N] scratch for the two-stage column sums
   int M, N; long ld_in; int relu; int accumulate_colsum;
 };
 
-// 64x64 tile per block; fwd: grid (N/64, M/64); bwd: grid (N/64, 1) looping over all rows so the
-// column sums come out of one block in a fixed order.
+// 64 columns x ROWS_PER_BLOCK rows per block (64x64 tiles through LDS for the transposed copy).
+// bwd: per-block partial column sums go to colpart[blockIdx.y][N]; colsum_reduce_kernel adds them in a
+// fixed order (deterministic bias gradients, no float atomics).
+constexpr int ACT_ROWS = 256;
+
 template <int DT_OUT, int DT_SAVED, bool BWD>
 __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
   using EO = ElemOf<DT_OUT>;
@@ -51,10 +55,12 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
   __shared__ float cs[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + tx;
-  const int mb0 = BWD ? 0 : blockIdx.y * 64;
-  const int mb1 = BWD ? p.M : min(mb0 + 64, p.M);
+  const int mb0 = blockIdx.y * ACT_ROWS;
+  const int mb1 = min(mb0 + ACT_ROWS, p.M);
   float csum = 0.f;
+  const float cscale = (BWD && p.colscale && n < p.N) ? p.colscale[n] : 1.f;
   for (int mb = mb0; mb < mb1; mb += 64) {
+#pragma unroll 4
     for (int i = ty; i < 64; i += 4) {
       const int m = mb + i;
       float v = 0.f;
@@ -66,8 +72,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
           if (p.mask) v *= p.mask[(long)m * p.N + n];
           else if (p.drop_p > 0.f) v *= drop_mult(p.seed, (uint64_t)m * p.N + n, p.drop_p);
         } else {
-          v = p.in[(long)m * p.ld_in + n];
-          if (p.colscale) v *= p.colscale[n];
+          v = p.in[(long)m * p.ld_in + n] * cscale;
           if (p.saved) {
             const float o = ES::ld((const typename ES::type*)p.saved + (long)m * p.ld_out + n);
             float mult = o > 0.f ? 1.f : 0.f;
@@ -85,6 +90,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
     }
     if (p.outT) {
       __syncthreads();
+#pragma unroll 4
       for (int i = ty; i < 64; i += 4) {
         const int nn = blockIdx.x * 64 + i, m = mb + tx;
         if (nn < p.N && m < p.M) EO::st((TO*)p.outT + (long)nn * p.ld_outT + m, t[tx][i]);
@@ -95,11 +101,16 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
   if (BWD && p.colsum) {
     cs[ty][tx] = csum;
     __syncthreads();
-    if (ty == 0 && n < p.N) {
-      const float s = ((cs[0][tx] + cs[1][tx]) + cs[2][tx]) + cs[3][tx];
-      p.colsum[n] = p.accumulate_colsum ? p.colsum[n] + s : s;
-    }
+    if (ty == 0 && n < p.N) p.colpart[(long)blockIdx.y * p.N + n] = ((cs[0][tx] + cs[1][tx]) + cs[2][tx]) + cs[3][tx];
   }
+}
+
+__global__ void colsum_reduce_kernel(const float* colpart, int nparts, int N, float* colsum, int accumulate) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  float s = 0.f;
+  for (int q = 0; q < nparts; ++q) s += colpart[(long)q * N + n];
+  colsum[n] = accumulate ? colsum[n] + s : s;
 }
 
 // ---------------------------------------------------------------- block reductions (1024 threads)
@@ -121,49 +132,55 @@ struct WsddnParams {
   const int* img_off;              // [n_img+1] row offsets
   const float* gt_onehot;          // [n_img][K]
   float* scores;                   // [M][K]
+  float* rowsm;                    // [M][K] softmax over classes of the cls logits (kept for the backward)
   float* img_scores;               // [n_img][K] clamped
   float* loss_part;                // [n_img]
   float* dlogits; long ld_d;       // [M][ld_d] (same column offsets) or null
   int n_img; int mean_loss; float loss_scale;
 };
 
-// one block (1024 threads) per image; thread -> (column c = t % K, row phase t / K)
+// one block (1024 threads) per image.  Pass 0: thread per ROW computes the row softmax once and parks it in
+// the scores buffer.  Passes 1-3: thread -> (column c = t % K, row phase t / K) for the column softmax, the
+// product, the image scores / BCE and the analytic backward (fixed-order LDS trees).
 __global__ __launch_bounds__(1024) void wsddn_kernel(WsddnParams p) {
   __shared__ float red[1024];
-  __shared__ float colv[128], colg[128], cold[128];
+  __shared__ float colv[128], colg[128], cold[128], colm[128];
   const int img = blockIdx.x;
   const int r0 = p.img_off[img], r1 = p.img_off[img + 1];
   const int K = p.K, nph = 1024 / K;
   const int c = threadIdx.x % K, ph = threadIdx.x / K;
   const bool act = ph < nph;
+  // 0. a[r][:] = softmax over classes of the cls logits
+  for (int r = r0 + threadIdx.x; r < r1; r += 1024) {
+    const float* row = p.logits + (long)r * p.ld + p.c_cls;
+    float rm = -FLT_MAX;
+    for (int k = 0; k < K; ++k) rm = fmaxf(rm, row[k]);
+    float rs = 0.f;
+    for (int k = 0; k < K; ++k) rs += expf(row[k] - rm);
+    for (int k = 0; k < K; ++k) p.rowsm[(long)r * K + k] = expf(row[k] - rm) / rs;
+  }
+  __syncthreads();
   // 1. column max of det logits
   float mx = -FLT_MAX;
   if (act) for (int r = r0 + ph; r < r1; r += nph) mx = fmaxf(mx, p.logits[(long)r * p.ld + p.c_det + c]);
   red[threadIdx.x] = mx;
   __syncthreads();
-  if (threadIdx.x < K) { float m = -FLT_MAX; for (int q = 0; q < nph; ++q) m = fmaxf(m, red[q * K + threadIdx.x]); colv[threadIdx.x] = m; }
+  if (threadIdx.x < K) { float m = -FLT_MAX; for (int q = 0; q < nph; ++q) m = fmaxf(m, red[q * K + threadIdx.x]); colm[threadIdx.x] = m; }
   __syncthreads();
-  const float cmax = colv[c];
+  const float cmax = colm[c];
   // 2. column sum of exp
   float se = 0.f;
   if (act) for (int r = r0 + ph; r < r1; r += nph) se += expf(p.logits[(long)r * p.ld + p.c_det + c] - cmax);
-  __syncthreads();
   red[threadIdx.x] = se;
   __syncthreads();
-  if (threadIdx.x < K) { float s = 0.f; for (int q = 0; q < nph; ++q) s += red[q * K + threadIdx.x]; colg[threadIdx.x] = s; }
+  if (threadIdx.x < K) { float s = 0.f; for (int q = 0; q < nph; ++q) s += red[q * K + threadIdx.x]; colv[threadIdx.x] = s; }
   __syncthreads();
-  const float csum = colg[c];
-  // 3. scores = rowsoftmax(cls) * colsoftmax(det); column sums. Row softmax: each row's K threads
-  //    recompute the row max/sum serially (K <= 128, tiny).
+  const float csum = colv[c];
+  // 3. scores = a * b ; column sums
   float ss = 0.f;
   if (act)
     for (int r = r0 + ph; r < r1; r += nph) {
-      const float* row = p.logits + (long)r * p.ld + p.c_cls;
-      float rm = -FLT_MAX;
-      for (int k = 0; k < K; ++k) rm = fmaxf(rm, row[k]);
-      float rs = 0.f;
-      for (int k = 0; k < K; ++k) rs += expf(row[k] - rm);
-      const float a = expf(row[c] - rm) / rs;
+      const float a = p.rowsm[(long)r * K + c];
       const float b = expf(p.logits[(long)r * p.ld + p.c_det + c] - cmax) / csum;
       const float s = a * b;
       p.scores[(long)r * K + c] = s;
@@ -184,8 +201,7 @@ __global__ __launch_bounds__(1024) void wsddn_kernel(WsddnParams p) {
     colv[threadIdx.x] = l;
     const float norm = (p.mean_loss ? 1.f / (float)(p.n_img * K) : 1.f) / (float)p.n_img;
     // d loss / d (unclamped sum); clamp passes gradient only inside [1e-6, 1-1e-6]
-    float g = (s >= 1e-6f && s <= 1.0f - 1e-6f) ? (-(y / sc) + (1.f - y) / (1.f - sc)) * norm * p.loss_scale : 0.f;
-    colg[threadIdx.x] = g;
+    colg[threadIdx.x] = (s >= 1e-6f && s <= 1.0f - 1e-6f) ? (-(y / sc) + (1.f - y) / (1.f - sc)) * norm * p.loss_scale : 0.f;
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -195,23 +211,26 @@ __global__ __launch_bounds__(1024) void wsddn_kernel(WsddnParams p) {
     p.loss_part[img] = l * norm;
   }
   if (!p.dlogits) return;
-  // backward. s = a*b; ds = g[c] for every row.  d cls = a*(g*b - sum_k g_k b_k a_k);
-  // d det = b*(g*a - sum_r g a b) = b*g*(a - S_c) with S_c = sum_r a*b = unclamped column sum.
-  if (act)
-    for (int r = r0 + ph; r < r1; r += nph) {
-      const float* row = p.logits + (long)r * p.ld + p.c_cls;
-      float rm = -FLT_MAX;
-      for (int k = 0; k < K; ++k) rm = fmaxf(rm, row[k]);
-      float rs = 0.f;
-      for (int k = 0; k < K; ++k) rs += expf(row[k] - rm);
-      float dot = 0.f;  // sum_k g_k * s_rk  (= sum_k da_k * a_k with da_k = g_k*b_k)
-      for (int k = 0; k < K; ++k) dot += colg[k] * p.scores[(long)r * K + k];
-      const float a = expf(row[c] - rm) / rs;
-      const float s = p.scores[(long)r * K + c];
+  // backward. s = a*b, ds = g[c] for every row.  d cls = g_c*s - a*dot with dot = sum_k g_k s_rk;
+  // d det = g_c*(s - b*S_c) with S_c the unclamped column sum.  dot is computed once per row by the row's
+  // first thread (c == 0) and parked in `red` (rows of this pass are distinct per phase).
+  for (int rb = r0; rb < r1; rb += nph) {
+    const int r = rb + ph;
+    const bool ok = act && r < r1;
+    float s = 0.f;
+    if (ok) s = p.scores[(long)r * K + c];
+    red[threadIdx.x] = ok ? colg[c] * s : 0.f;
+    __syncthreads();
+    if (ok) {
+      float dot = 0.f;
+      for (int k = 0; k < K; ++k) dot += red[ph * K + k];
       const float b = expf(p.logits[(long)r * p.ld + p.c_det + c] - cmax) / csum;
+      const float a = p.rowsm[(long)r * K + c];
       p.dlogits[(long)r * p.ld_d + p.c_cls + c] = colg[c] * s - a * dot;
       p.dlogits[(long)r * p.ld_d + p.c_det + c] = colg[c] * (s - b * cold[c]);
     }
+    __syncthreads();
+  }
 }
 
 struct TargetParams {
@@ -303,34 +322,63 @@ struct CeParams {
   int M; float loss_scale;
 };
 
-// single block: rows strided over 1024 threads; deterministic tree for sum(w*CE) and sum(valid)
-__global__ __launch_bounds__(1024) void softmax_ce_kernel(CeParams p) {
-  __shared__ float sh[16];
+// One wave per row (lane = class column, C <= 128), CE_ROWS rows per 256-thread block.  Kernel 1 writes the
+// probabilities and per-block partial (sum w*CE, #valid); kernel 2 re-adds the partials in a fixed order
+// (every block gets the same total), writes the loss and the gradient of the logits.
+constexpr int CE_ROWS = 16;
+
+__global__ __launch_bounds__(256) void ce_rows_kernel(CeParams p, float* partial) {
+  __shared__ float sl[4], sv[4];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float lsum = 0.f, vsum = 0.f;
-  for (int r = threadIdx.x; r < p.M; r += 1024) {
+  for (int i = w; i < CE_ROWS; i += 4) {
+    const int r = blockIdx.x * CE_ROWS + i;
+    if (r >= p.M) break;
     const float* row = p.logits + (long)r * p.ld + p.col0;
-    float mx = -FLT_MAX;
-    for (int c = 0; c < p.C; ++c) mx = fmaxf(mx, row[c]);
-    float se = 0.f;
-    for (int c = 0; c < p.C; ++c) se += expf(row[c] - mx);
-    for (int c = 0; c < p.C; ++c) p.probs[(long)r * p.C + c] = expf(row[c] - mx) / se;
-    if (p.labels) {
+    const float x0 = lane < p.C ? row[lane] : -FLT_MAX;
+    const float x1 = lane + 64 < p.C ? row[lane + 64] : -FLT_MAX;
+    const float mx = wave_max(fmaxf(x0, x1));
+    const float e0 = lane < p.C ? expf(x0 - mx) : 0.f, e1 = lane + 64 < p.C ? expf(x1 - mx) : 0.f;
+    const float se = wave_sum(e0 + e1);
+    if (lane < p.C) p.probs[(long)r * p.C + lane] = e0 / se;
+    if (lane + 64 < p.C) p.probs[(long)r * p.C + lane + 64] = e1 / se;
+    if (p.labels && lane == 0) {
       const int lab = p.labels[r];
-      const float w = lab == -1 ? 0.f : p.weights[r];
-      if (lab >= 0) lsum += (logf(se) - (row[lab] - mx)) * w;
-      vsum += w > 1e-12f ? 1.f : 0.f;
+      const float wt = lab == -1 ? 0.f : p.weights[r];
+      if (lab >= 0) lsum += (logf(se) - (row[lab] - mx)) * wt;
+      vsum += wt > 1e-12f ? 1.f : 0.f;
     }
   }
   if (!p.labels) return;
-  const float L = block_sum_1024(lsum, sh);
-  const float V = block_sum_1024(vsum, sh);
-  if (threadIdx.x == 0) p.loss[0] = L / V;
+  if (lane == 0) { sl[w] = lsum; sv[w] = vsum; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[2 * blockIdx.x] = ((sl[0] + sl[1]) + sl[2]) + sl[3];
+    partial[2 * blockIdx.x + 1] = ((sv[0] + sv[1]) + sv[2]) + sv[3];
+  }
+}
+
+__global__ __launch_bounds__(256) void ce_grad_kernel(CeParams p, const float* partial, int nparts) {
+  __shared__ float sh[2][256];
+  float l = 0.f, v = 0.f;
+  for (int q = threadIdx.x; q < nparts; q += 256) { l += partial[2 * q]; v += partial[2 * q + 1]; }
+  sh[0][threadIdx.x] = l; sh[1][threadIdx.x] = v;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) { sh[0][threadIdx.x] += sh[0][threadIdx.x + o]; sh[1][threadIdx.x] += sh[1][threadIdx.x + o]; }
+    __syncthreads();
+  }
+  const float L = sh[0][0], V = sh[1][0];
+  if (blockIdx.x == 0 && threadIdx.x == 0) p.loss[0] = L / V;
   if (!p.dlogits) return;
-  for (int r = threadIdx.x; r < p.M; r += 1024) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int i = w; i < CE_ROWS; i += 4) {
+    const int r = blockIdx.x * CE_ROWS + i;
+    if (r >= p.M) break;
     const int lab = p.labels[r];
-    const float w = lab < 0 ? 0.f : p.weights[r];
-    const float f = w / V * p.loss_scale;
-    for (int c = 0; c < p.C; ++c)
+    const float wt = lab < 0 ? 0.f : p.weights[r];
+    const float f = wt / V * p.loss_scale;
+    for (int c = lane; c < p.C; c += 64)
       p.dlogits[(long)r * p.ld_d + p.col0 + c] = f * (p.probs[(long)r * p.C + c] - (c == lab ? 1.f : 0.f));
   }
 }
@@ -374,15 +422,45 @@ __global__ void apply_deltas_kernel(const float* deltas, long ld_d, const float*
 
 struct SgdSeg { long off; long cnt; float lr; float wd; };
 
-// p -= lr * (buf = mom*buf + (g + wd*p)); first step: buf = g + wd*p.  One launch over the flat
-// parameter arena; the bf16/f32 compute shadow is refreshed in the same pass.
-template <int DT_SHADOW>
-__global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ mom, const float* __restrict__ g,
-                           typename ElemOf<DT_SHADOW>::type* shadow, const SgdSeg* segs, int nseg, float momentum,
-                           int first_step, float grad_scale) {
+// p -= lr * (buf = mom*buf + (g + wd*p)); first step: buf = g + wd*p.  One launch over the flat parameter
+// arena (blockIdx.y walks the segments, float4 lanes when the segment offset is 16-B aligned); the bf16
+// compute shadow (same flat layout) is refreshed in the same pass, so the weights are read once per step.
+template <bool SHADOW>
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ mom,
+                                                  const float* __restrict__ g, bf16_t* __restrict__ shadow,
+                                                  const SgdSeg* segs, int nseg, float momentum, int first_step,
+                                                  float grad_scale) {
   for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
     const SgdSeg sg = segs[s];
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < sg.cnt; i += (long)gridDim.x * blockDim.x) {
+    const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
+    long done = 0;
+    if ((sg.off & 3) == 0) {
+      const long nvec = sg.cnt >> 2;
+      for (long i = tid; i < nvec; i += nthr) {
+        const long j = sg.off + 4 * i;
+        const f32x4_t pw = *(const f32x4_t*)(w + j), gg = *(const f32x4_t*)(g + j);
+        f32x4_t mm = {0.f, 0.f, 0.f, 0.f};
+        if (!first_step) mm = *(const f32x4_t*)(mom + j);
+        f32x4_t nb, nw;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float d = gg[e] * grad_scale;
+          if (sg.wd != 0.f) d = d + sg.wd * pw[e];
+          nb[e] = first_step ? d : momentum * mm[e] + d;
+          nw[e] = pw[e] - sg.lr * nb[e];
+        }
+        *(f32x4_t*)(mom + j) = nb;
+        *(f32x4_t*)(w + j) = nw;
+        if (SHADOW) {
+          uint2 o;
+          o.x = (uint32_t)f32_to_bf16(nw[0]) | ((uint32_t)f32_to_bf16(nw[1]) << 16);
+          o.y = (uint32_t)f32_to_bf16(nw[2]) | ((uint32_t)f32_to_bf16(nw[3]) << 16);
+          *(uint2*)(shadow + j) = o;
+        }
+      }
+      done = nvec << 2;
+    }
+    for (long i = done + tid; i < sg.cnt; i += nthr) {
       const long j = sg.off + i;
       const float pw = w[j];
       float d = g[j] * grad_scale;
@@ -391,7 +469,7 @@ __global__ void sgd_kernel(float* __restrict__ w, float* __restrict__ mom, const
       mom[j] = b;
       const float nw = pw - sg.lr * b;
       w[j] = nw;
-      if (shadow) ElemOf<DT_SHADOW>::st(shadow + j, nw);
+      if (SHADOW) shadow[j] = f32_to_bf16(nw);
     }
   }
 }
@@ -414,8 +492,8 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
   if (!partials || M < 0 || N < 0 || splits < 1 || (!out && !outT)) return DRN_ERR_ARG;
   if (M == 0 || N == 0) return DRN_OK;
   ActParams p{partials, splits, split_stride, bias, mask, seed, drop_p, nullptr, (char*)out, ld_out, (char*)outT,
-              ld_outT, nullptr, nullptr, M, N, ld_in, relu, 0};
-  dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
+              ld_outT, nullptr, nullptr, nullptr, M, N, ld_in, relu, 0};
+  dim3 grid((N + 63) / 64, (M + ACT_ROWS - 1) / ACT_ROWS), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == DRN_BF16) hipLaunchKernelGGL((act_kernel<DRN_BF16, DRN_BF16, false>), grid, block, 0, st, p);
   else if (out_dtype == DRN_F32) hipLaunchKernelGGL((act_kernel<DRN_F32, DRN_F32, false>), grid, block, 0, st, p);
@@ -426,27 +504,33 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
 
 int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const void* saved_out,
                      const float* mask, float drop_p,
-                     void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, int accumulate_colsum, int M,
-                     int N, int out_dtype, void* stream) {
+                     void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
+                     int accumulate_colsum, int M, int N, int out_dtype, void* stream) {
   if (!grad_out || M < 0 || N < 0) return DRN_ERR_ARG;
+  if (colsum && !colpart) return DRN_ERR_ARG;  // colpart: ceil(M/256)*N floats of scratch
   if (M == 0 || N == 0) return DRN_OK;
   ActParams p{grad_out, 1, 0, nullptr, mask, 0ULL, drop_p, (const char*)saved_out, (char*)dpre, ld_out, (char*)dpreT,
-              ld_outT, colsum, colscale, M, N, ld_in, 1, accumulate_colsum};
-  dim3 grid((N + 63) / 64, 1), block(256);
+              ld_outT, colsum, colscale, colpart, M, N, ld_in, 1, accumulate_colsum};
+  const int nparts = (M + ACT_ROWS - 1) / ACT_ROWS;
+  dim3 grid((N + 63) / 64, nparts), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == DRN_BF16) hipLaunchKernelGGL((act_kernel<DRN_BF16, DRN_BF16, true>), grid, block, 0, st, p);
   else if (out_dtype == DRN_F32) hipLaunchKernelGGL((act_kernel<DRN_F32, DRN_F32, true>), grid, block, 0, st, p);
   else return DRN_ERR_ARG;
+  if (colsum)
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, colpart, nparts, N, colsum,
+                       accumulate_colsum);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }
 
 int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K, const int* img_off, int n_img,
-                      const float* gt_onehot, float* scores, float* img_scores, float* loss_part, float* dlogits,
-                      long ld_d, int mean_loss, float loss_scale, void* stream) {
-  if (!logits || !img_off || !gt_onehot || !scores || !img_scores || !loss_part || K < 1 || K > 128 || n_img < 1)
+                      const float* gt_onehot, float* scores, float* row_softmax, float* img_scores, float* loss_part,
+                      float* dlogits, long ld_d, int mean_loss, float loss_scale, void* stream) {
+  if (!logits || !img_off || !gt_onehot || !scores || !row_softmax || !img_scores || !loss_part || K < 1 || K > 128 ||
+      n_img < 1)
     return DRN_ERR_ARG;
-  WsddnParams p{logits, ld, c_cls, c_det, K, img_off, gt_onehot, scores, img_scores, loss_part, dlogits, ld_d, n_img,
+  WsddnParams p{logits, ld, c_cls, c_det, K, img_off, gt_onehot, scores, row_softmax, img_scores, loss_part, dlogits, ld_d, n_img,
                 mean_loss, loss_scale};
   hipLaunchKernelGGL(wsddn_kernel, dim3(n_img), dim3(1024), 0, (hipStream_t)stream, p);
   DRN_CHECK_LAUNCH();
@@ -475,12 +559,18 @@ int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxe
   return DRN_OK;
 }
 
+// scratch: 2*ceil(M/16) floats (needed when labels != NULL)
 int drn_softmax_ce(const float* logits, long ld, int col0, int C, const int* labels, const float* weights,
-                   float* probs, float* dlogits, long ld_d, float* loss, int M, float loss_scale, void* stream) {
-  if (!logits || !probs || C < 1 || M < 0) return DRN_ERR_ARG;
-  if (labels && (!weights || !loss)) return DRN_ERR_ARG;
+                   float* probs, float* dlogits, long ld_d, float* loss, float* scratch, int M, float loss_scale,
+                   void* stream) {
+  if (!logits || !probs || C < 1 || C > 128 || M < 0) return DRN_ERR_ARG;
+  if (labels && (!weights || !loss || !scratch)) return DRN_ERR_ARG;
+  if (M == 0) return DRN_OK;
   CeParams p{logits, ld, col0, C, labels, weights, probs, dlogits, ld_d, loss, M, loss_scale};
-  hipLaunchKernelGGL(softmax_ce_kernel, dim3(1), dim3(1024), 0, (hipStream_t)stream, p);
+  const int nb = (M + CE_ROWS - 1) / CE_ROWS;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_rows_kernel, dim3(nb), dim3(256), 0, st, p, scratch);
+  if (labels) hipLaunchKernelGGL(ce_grad_kernel, dim3(nb), dim3(256), 0, st, p, (const float*)scratch, nb);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }
@@ -506,19 +596,20 @@ int drn_apply_deltas(const float* deltas, long ld_d, const float* boxes, float* 
   return DRN_OK;
 }
 
-// segs_dev: device array of {int64 off, int64 cnt, float lr, float wd} (24 bytes each)
+// segs_dev: device array of {int64 off, int64 cnt, float lr, float wd} (24 bytes each).  shadow (optional):
+// bf16 array with the arena's flat layout, refreshed in the same pass.
 int drn_sgd_step(float* weights, float* momentum_buf, const float* grads, void* shadow, int shadow_dtype,
                  const void* segs_dev, int nseg, float momentum, int first_step, float grad_scale, void* stream) {
   if (!weights || !momentum_buf || !grads || !segs_dev || nseg < 1) return DRN_ERR_ARG;
-  dim3 grid(512, nseg < 64 ? nseg : 64), block(256);
+  if (shadow && shadow_dtype != DRN_BF16) return DRN_ERR_ARG;
+  dim3 grid(1024, nseg < 32 ? nseg : 32), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (shadow && shadow_dtype == DRN_BF16)
-    hipLaunchKernelGGL(sgd_kernel<DRN_BF16>, grid, block, 0, st, weights, momentum_buf, grads, (bf16_t*)shadow,
+  if (shadow)
+    hipLaunchKernelGGL(sgd_kernel<true>, grid, block, 0, st, weights, momentum_buf, grads, (bf16_t*)shadow,
                        (const SgdSeg*)segs_dev, nseg, momentum, first_step, grad_scale);
   else
-    hipLaunchKernelGGL(sgd_kernel<DRN_F32>, grid, block, 0, st, weights, momentum_buf, grads,
-                       shadow_dtype == DRN_F32 ? (float*)shadow : nullptr, (const SgdSeg*)segs_dev, nseg, momentum,
-                       first_step, grad_scale);
+    hipLaunchKernelGGL(sgd_kernel<false>, grid, block, 0, st, weights, momentum_buf, grads, (bf16_t*)nullptr,
+                       (const SgdSeg*)segs_dev, nseg, momentum, first_step, grad_scale);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

@@ -91,6 +91,7 @@ struct RoiParams {
   float scale;
   long ld_out;
   int sampling_ratio, aligned;
+  int lds_px;  // pixels of staging LDS available per block (0 = direct path only)
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -119,6 +120,41 @@ __global__ __launch_bounds__(256) void roi_kernel(RoiParams p) {
     const int x2 = (int)roundf(roi[3] * p.scale), y2 = (int)roundf(roi[4] * p.scale);
     const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
     const float bin_h = (float)rh / (float)p.P, bin_w = (float)rw / (float)p.P;
+    // LDS path: the union of all bins is the clipped box [y1, y1+rh) x [x1, x1+rw); stage those pixels of this
+    // block's 64 channels with 16-B loads (all independent => all in flight), then scan bins out of LDS.
+    const int ry0 = min(max(y1, 0), p.H), ry1 = min(max(y1 + rh, 0), p.H);
+    const int rx0 = min(max(x1, 0), p.W), rx1 = min(max(x1 + rw, 0), p.W);
+    const int rww = rx1 - rx0, npx = (ry1 - ry0) * rww;
+    if (p.lds_px > 0 && npx <= p.lds_px && c0 + RP_CH <= p.C) {
+      extern __shared__ __attribute__((aligned(16))) char stage[];
+      constexpr int ESI = DT_IN == DRN_BF16 ? 2 : 4;
+      constexpr int VPL = RP_CH * ESI / 16;  // lanes (16 B each) per pixel
+      for (int i = threadIdx.x; i < npx * VPL; i += 256) {
+        const int px = i / VPL, v = i - px * VPL;
+        const int h = ry0 + px / rww, w = rx0 + px % rww;
+        *(i32x4_t*)(stage + ((long)px * RP_CH) * ESI + v * 16) =
+            *(const i32x4_t*)((const char*)(fb + ((long)h * p.W + w) * p.C + c0) + v * 16);
+      }
+      __syncthreads();
+      const TI* st = (const TI*)stage;
+      for (int bin = bg; bin < PP; bin += 4) {
+        const int ph = bin / p.P, pw = bin - ph * p.P;
+        int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
+        int ws = (int)floorf((float)pw * bin_w), we = (int)ceilf((float)(pw + 1) * bin_w);
+        hs = min(max(hs + y1, 0), p.H); he = min(max(he + y1, 0), p.H);
+        ws = min(max(ws + x1, 0), p.W); we = min(max(we + x1, 0), p.W);
+        const bool empty = he <= hs || we <= ws;
+        float best = empty ? 0.f : -FLT_MAX;
+        int besti = -1;
+        for (int h = hs; h < he; ++h)
+          for (int w = ws; w < we; ++w) {
+            const float v = EI::ld(st + ((h - ry0) * rww + (w - rx0)) * RP_CH + cl);
+            if (v > best) { best = v; besti = h * p.W + w; }
+          }
+        tile[cl][bin] = best * mul;
+        atile[cl][bin] = besti;
+      }
+    } else
     for (int bin = bg; bin < PP; bin += 4) {
       const int ph = bin / p.P, pw = bin - ph * p.P;
       int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
@@ -268,10 +304,19 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
   if (ld_out < (long)C * P * P) return DRN_ERR_ARG;
   if (M == 0) return DRN_OK;
   RoiParams p{(const char*)feat, rois, objectness, (char*)out, argmax, N, H, W, C, P, M, spatial_scale, ld_out,
-              sampling_ratio, aligned};
+              sampling_ratio, aligned, 0};
   dim3 grid(M, (C + RP_CH - 1) / RP_CH), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define RP_LAUNCH(DI, DO, MD) hipLaunchKernelGGL((roi_kernel<DI, DO, MD>), grid, block, 0, st, p)
+  // ROIPool on a full 64-channel chunk stages the box window in LDS: up to 256 pixels (25 KB bf16 / 64 KB f32... capped)
+  size_t smem = 0;
+  if (mode == 0 && C % RP_CH == 0) {
+    const int es = drn_esize(in_dtype);
+    int px = H * W < 256 ? H * W : 256;
+    if ((size_t)px * RP_CH * es > 32 * 1024) px = 32 * 1024 / (RP_CH * es);
+    p.lds_px = px;
+    smem = (size_t)px * RP_CH * es;
+  }
+#define RP_LAUNCH(DI, DO, MD) hipLaunchKernelGGL((roi_kernel<DI, DO, MD>), grid, block, smem, st, p)
   if (in_dtype == DRN_BF16 && out_dtype == DRN_BF16) { if (mode == 0) RP_LAUNCH(DRN_BF16, DRN_BF16, 0); else RP_LAUNCH(DRN_BF16, DRN_BF16, 1); }
   else if (in_dtype == DRN_F32 && out_dtype == DRN_F32) { if (mode == 0) RP_LAUNCH(DRN_F32, DRN_F32, 0); else RP_LAUNCH(DRN_F32, DRN_F32, 1); }
   else if (in_dtype == DRN_F32 && out_dtype == DRN_BF16) { if (mode == 0) RP_LAUNCH(DRN_F32, DRN_BF16, 0); else RP_LAUNCH(DRN_F32, DRN_BF16, 1); }

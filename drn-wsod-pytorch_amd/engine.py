@@ -73,9 +73,10 @@ class FusedSGD:
         if self._mom is None:
             self._mom = torch.zeros_like(e.arena_w)
         segs, nseg = self._segs()
-        ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, grad_scale)
+        ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, grad_scale,
+                     shadow=e.arena_s)
         self._steps += 1
-        e.mark_dirty()
+        e.mark_dirty(shadow_fresh=e.arena_s is not None)
 
     def state_dict(self):
         return {"momentum_buffer": self._mom, "steps": self._steps,

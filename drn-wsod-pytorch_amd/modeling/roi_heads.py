@@ -306,11 +306,20 @@ class _HeadEngine:
             if not h.refine_reg[k]:  # unused parameters: kept in the arena, never touched
                 order += [("u%d.weight" % k, h.box_refinery[k].bbox_pred.weight, False),
                           ("u%d.bias" % k, h.box_refinery[k].bbox_pred.bias, False)]
-        total = sum(p.numel() for _, p, _ in order)
-        w = torch.empty((total,), dtype=torch.float32, device=device)
-        g = torch.zeros((total,), dtype=torch.float32, device=device)
-        self.segments, off = [], 0
+        # the concatenated head weights / biases must stay contiguous (they are ONE GEMM operand); every other
+        # segment starts on a 16-byte boundary so the SGD kernel runs float4 lanes over it
+        contiguous = {n + ".weight" for n, _, _, _ in cols[1:]} | {n + ".bias" for n, _, _, _ in cols[1:]}
+        offs, off = [], 0
         for name, p, used in order:
+            if name not in contiguous:
+                off = (off + 3) // 4 * 4
+            offs.append(off)
+            off += p.numel()
+        total = (off + 3) // 4 * 4
+        w = torch.zeros((total,), dtype=torch.float32, device=device)
+        g = torch.zeros((total,), dtype=torch.float32, device=device)
+        self.segments = []
+        for (name, p, used), off in zip(order, offs):
             n = p.numel()
             w[off: off + n].copy_(p.detach().reshape(-1).to(device))
             p.data = w[off: off + n].view(p.shape)
@@ -318,7 +327,8 @@ class _HeadEngine:
             self.segments.append((name, p, off, n, used))
             if name == "fc1.weight":
                 self._fc1_off = off
-            off += n
+        self.arena_s = None  # bf16 shadow of the arena (same flat layout), refreshed by the fused SGD kernel
+        self._shadow_from_sgd = False
         self.n_used = sum(n for _, _, _, n, u in self.segments if u)
         self.arena_w, self.arena_g = w, g
         self._seg = {name: (o, n) for name, _, o, n, _ in self.segments}
@@ -337,8 +347,10 @@ class _HeadEngine:
         v = self.arena_w[o: o + n]
         return v.view(shape) if shape is not None else v
 
-    def mark_dirty(self):
+    def mark_dirty(self, shadow_fresh=False):
+        """weights changed; shadow_fresh: the fused SGD kernel already rewrote the flat bf16 shadow"""
         self._dirty = True
+        self._shadow_from_sgd = shadow_fresh
 
     # ---- compute-dtype shadows of the weights -----------------------------------------------------
     def refresh_shadows(self, dtype):
@@ -352,23 +364,30 @@ class _HeadEngine:
         D2 = fc2.weight.shape[0]
         NH = self.NH
         kp = lambda k: ops.kpad(k, dtype)
-        if not hasattr(self, "sh") or self.sh.get("dtype") != dtype:
-            z = lambda r, c: torch.zeros((r, c), dtype=dtype, device=dev)
-            self.sh = dict(dtype=dtype, W2=z(D2, kp(D1)), W2T=z(D1, kp(D2)), Wh=z(NH, kp(D2)), WhT=z(D2, kp(NH)))
-            self.sh["W1"] = None if (dtype == torch.float32 and kp(K1) == K1) else z(D1, kp(K1))
-        sh = self.sh
-        if sh["W1"] is None:
-            sh["W1v"] = fc1.weight.data  # fp32 mode, unpadded: the master IS the operand
-        else:
-            ops.cast2d(fc1.weight.data, D1, K1, sh["W1"])
-            sh["W1v"] = sh["W1"]
-        ops.cast2d(fc2.weight.data, D2, D1, sh["W2"])
-        ops.transpose2d(fc2.weight.data, D2, D1, out=sh["W2T"])
         o, _ = self._seg[self.cols[0][0] + ".weight"]
         wh = self.arena_w[o: o + NH * D2].view(NH, D2)
-        ops.cast2d(wh, NH, D2, sh["Wh"])
+        if not hasattr(self, "sh") or self.sh.get("dtype") != dtype:
+            z = lambda r, c: torch.zeros((r, c), dtype=dtype, device=dev)
+            self.sh = dict(dtype=dtype, W2T=z(D1, kp(D2)), WhT=z(D2, kp(NH)))
+            # operands whose padded layout equals the master layout live in the flat shadow arena (bf16) or ARE the
+            # master (fp32); only padded ones get their own buffer
+            self.arena_s = torch.zeros_like(self.arena_w, dtype=torch.bfloat16) if dtype == torch.bfloat16 else None
+            self._shadow_from_sgd = False
+            flat = self.arena_s if dtype == torch.bfloat16 else self.arena_w
+            for nm, pnt, rows, cols_ in (("W1", fc1.weight, D1, K1), ("W2", fc2.weight, D2, D1), ("Wh", wh, NH, D2)):
+                if kp(cols_) == cols_:
+                    so = (pnt.data_ptr() - self.arena_w.data_ptr()) // 4
+                    self.sh[nm], self.sh[nm + "_own"] = flat[so: so + rows * cols_].view(rows, cols_), False
+                else:
+                    self.sh[nm], self.sh[nm + "_own"] = z(rows, kp(cols_)), True
+        sh = self.sh
+        for nm, src, rows, cols_ in (("W1", fc1.weight.data, D1, K1), ("W2", fc2.weight.data, D2, D1), ("Wh", wh, NH, D2)):
+            if sh[nm + "_own"] or (dtype == torch.bfloat16 and not self._shadow_from_sgd):
+                ops.cast2d(src, rows, cols_, sh[nm])
+        sh["W1v"] = sh["W1"]
+        ops.transpose2d(fc2.weight.data, D2, D1, out=sh["W2T"])
         ops.transpose2d(wh, NH, D2, out=sh["WhT"])
-        self._shadow_key, self._dirty = key, False
+        self._shadow_key, self._dirty, self._shadow_from_sgd = key, False, False
 
     # ---- workspaces ---------------------------------------------------------------------------------
     def ws(self, M, dtype, training):
@@ -389,7 +408,8 @@ class _HeadEngine:
             Mp = kp(M)
             w.update(AT=z(K1, Mp), H1T=z(D1, Mp), H2T=z(D2, Mp), dlogits=z(M, NHp, torch.float32), dS=z(M, NHp),
                      dST=z(self.NH, Mp), dH2=z(M, D2, torch.float32), dP2=z(M, kp(D2)), dP2T=z(D2, Mp),
-                     dH1=z(M, D1, torch.float32), dP1T=z(D1, Mp))
+                     dH1=z(M, D1, torch.float32), dP1T=z(D1, Mp),
+                     colpart=z((M + 255) // 256, max(D1, D2, self.NH), torch.float32))
         self._ws[key] = w
         return w
 
@@ -489,18 +509,19 @@ class _HeadEngine:
         wo, _ = self._seg[self.cols[0][0] + ".weight"]
         # heads: dS, dS^T, bias grads
         ops.bias_act_bwd(w["dlogits"], M, NH, colscale=colscale, dpre=w["dS"], dpreT=w["dST"],
-                         colsum=self.arena_g[bo: bo + NH], accumulate_colsum=acc)
+                         colsum=self.arena_g[bo: bo + NH], accumulate_colsum=acc, colpart=w["colpart"])
         ops.gemm_nt(w["dST"], w["H2T"], NH, D2, Mp, out=self.arena_g[wo: wo + NH * D2].view(1, NH, D2), accumulate=acc)
         ops.gemm_nt(w["dS"], sh["WhT"], M, D2, kp(NH), out=w["dH2"].view(1, M, D2))
         # fc7
         ops.bias_act_bwd(w["dH2"], M, D2, saved=w["H2"], mask=st["masks"][1] if st["masks"] else None,
                          drop_p=st["drop_p"], dpre=w["dP2"], dpreT=w["dP2T"], colsum=self._gview("fc2.bias"),
-                         accumulate_colsum=acc)
+                         accumulate_colsum=acc, colpart=w["colpart"])
         ops.gemm_nt(w["dP2T"], w["H1T"], D2, D1, Mp, out=self._gview("fc2.weight", (1, D2, D1)), accumulate=acc)
         ops.gemm_nt(w["dP2"], sh["W2T"], M, D1, kp(D2), out=w["dH1"].view(1, M, D1))
         # fc6 (the backbone is frozen: no dX)
         ops.bias_act_bwd(w["dH1"], M, D1, saved=w["H1"], mask=st["masks"][0] if st["masks"] else None,
-                         drop_p=st["drop_p"], dpreT=w["dP1T"], colsum=self._gview("fc1.bias"), accumulate_colsum=acc)
+                         drop_p=st["drop_p"], dpreT=w["dP1T"], colsum=self._gview("fc1.bias"), accumulate_colsum=acc,
+                         colpart=w["colpart"])
         hook = getattr(self, "grad_ready_hook", None)
         if hook is not None:
             hook("small")  # everything except fc1.weight is final: the DP engine starts reducing it now

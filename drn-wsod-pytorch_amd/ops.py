@@ -122,13 +122,15 @@ def bias_act_fwd(partials, M, N, bias=None, relu=True, mask=None, seed=0, drop_p
 
 
 def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=None, dpre=None, dpreT=None, colsum=None,
-                 accumulate_colsum=False):
+                 accumulate_colsum=False, colpart=None):
     ref = dpre if dpre is not None else dpreT
     if saved is not None and dpre is not None:
         assert _2d(saved) == _2d(dpre)
     ld_out = _2d(dpre) if dpre is not None else (_2d(saved) if saved is not None else 0)
+    if colsum is not None and colpart is None:
+        colpart = torch.empty(((M + 255) // 256, N), dtype=torch.float32, device=grad_out.device)
     C.call("drn_bias_act_bwd", C.ptr(grad_out), _2d(grad_out), C.ptr(colscale), C.ptr(saved), C.ptr(mask), float(drop_p),
-           C.ptr(dpre), ld_out, C.ptr(dpreT), _2d(dpreT) if dpreT is not None else 0, C.ptr(colsum),
+           C.ptr(dpre), ld_out, C.ptr(dpreT), _2d(dpreT) if dpreT is not None else 0, C.ptr(colsum), C.ptr(colpart),
            int(accumulate_colsum), M, N, C.dt(ref.dtype), C.stream())
 
 
@@ -138,9 +140,10 @@ def wsddn_fwd_bwd(logits, c_cls, c_det, K, img_off, n_img, gt_onehot, dlogits=No
     scores = torch.empty((M, K), dtype=torch.float32, device=dev)
     img_scores = torch.empty((n_img, K), dtype=torch.float32, device=dev)
     loss_part = torch.empty((n_img,), dtype=torch.float32, device=dev)
+    rowsm = torch.empty((M, K), dtype=torch.float32, device=dev)
     C.call("drn_wsddn_fwd_bwd", C.ptr(logits), _2d(logits), c_cls, c_det, K, C.ptr(img_off), n_img, C.ptr(gt_onehot),
-           C.ptr(scores), C.ptr(img_scores), C.ptr(loss_part), C.ptr(dlogits), _2d(dlogits) if dlogits is not None else 0,
-           int(mean_loss), float(loss_scale), C.stream())
+           C.ptr(scores), C.ptr(rowsm), C.ptr(img_scores), C.ptr(loss_part), C.ptr(dlogits),
+           _2d(dlogits) if dlogits is not None else 0, int(mean_loss), float(loss_scale), C.stream())
     return scores, img_scores, loss_part
 
 
@@ -168,8 +171,10 @@ def softmax_ce(logits, col0, ncol, labels=None, weights=None, dlogits=None, loss
     M = logits.shape[0]
     probs = torch.empty((M, ncol), dtype=torch.float32, device=logits.device)
     loss = torch.zeros((1,), dtype=torch.float32, device=logits.device) if labels is not None else None
+    scratch = torch.empty((2 * ((M + 15) // 16),), dtype=torch.float32, device=logits.device) if labels is not None else None
     C.call("drn_softmax_ce", C.ptr(logits), _2d(logits), col0, ncol, C.ptr(labels), C.ptr(weights), C.ptr(probs),
-           C.ptr(dlogits), _2d(dlogits) if dlogits is not None else 0, C.ptr(loss), M, float(loss_scale), C.stream())
+           C.ptr(dlogits), _2d(dlogits) if dlogits is not None else 0, C.ptr(loss), C.ptr(scratch), M, float(loss_scale),
+           C.stream())
     return probs, loss
 
 
@@ -200,7 +205,7 @@ def sum_small(x, scale=1.0):
 
 def sgd_step(weights, momentum_buf, grads, segs_dev, nseg, momentum, first_step, grad_scale=1.0, shadow=None):
     C.call("drn_sgd_step", C.ptr(weights), C.ptr(momentum_buf), C.ptr(grads), C.ptr(shadow),
-           C.dt(shadow.dtype) if shadow is not None else -1, C.ptr(segs_dev), nseg, float(momentum), int(first_step),
+           C.dt(shadow.dtype) if shadow is not None else 0, C.ptr(segs_dev), nseg, float(momentum), int(first_step),
            float(grad_scale), C.stream())
 
 

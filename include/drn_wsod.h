@@ -85,11 +85,12 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
 
 /* autograd of the above: dpre = grad_out * dropout_mult * (saved_out > 0); colsum[n] = sum_m dpre (bias
  * gradient, fixed summation order); saved_out == NULL means "no activation"; colscale [N] (optional)
- * multiplies grad_out per column (per-loss upstream gradients stay on the device). */
+ * multiplies grad_out per column (per-loss upstream gradients stay on the device); colpart = scratch of
+ * ceil(M/256)*N floats for the two-stage (deterministic) column sums, required with colsum. */
 int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const void* saved_out,
                      const float* mask, float drop_p,
-                     void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, int accumulate_colsum, int M,
-                     int N, int out_dtype, void* stream);
+                     void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
+                     int accumulate_colsum, int M, int N, int out_dtype, void* stream);
 
 /* ---- MIL / OICR head ------------------------------------------------------------------------- */
 
@@ -97,8 +98,8 @@ int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, c
  * WSDDNOutputs.binary_cross_entropy_loss (:317-329) + their autograd.  logits [M][ld] fp32 with the
  * cls / det heads at columns c_cls / c_det; img_off [n_img+1] row offsets.  loss = sum(loss_part). */
 int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K, const int* img_off, int n_img,
-                      const float* gt_onehot, float* scores, float* img_scores, float* loss_part, float* dlogits,
-                      long ld_d, int mean_loss, float loss_scale, void* stream);
+                      const float* gt_onehot, float* scores, float* row_softmax, float* img_scores, float* loss_part,
+                      float* dlogits, long ld_d, int mean_loss, float loss_scale, void* stream);
 
 /* OICRROIHeads.get_pgt (roi_heads_oicr.py:491-567) + ROIHeads.label_and_sample_proposals
  * (roi_heads.py:255-353; pairwise_iou structures/boxes.py:329-361; Matcher modeling/matcher.py:61-103).
@@ -110,9 +111,11 @@ int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxe
                      float* pgt_boxes, void* stream);
 
 /* OICROutputs.softmax_cross_entropy_loss (fast_rcnn.py:1087-1096,1128-1144), predict_probs (:1561-1575)
- * and the backward: loss = sum_r w_r CE_r / #{w_r > 1e-12}.  labels == NULL => probabilities only. */
+ * and the backward: loss = sum_r w_r CE_r / #{w_r > 1e-12}.  labels == NULL => probabilities only.
+ * scratch: 2*ceil(M/16) floats (two-stage deterministic reduction), required with labels. */
 int drn_softmax_ce(const float* logits, long ld, int col0, int C, const int* labels, const float* weights,
-                   float* probs, float* dlogits, long ld_d, float* loss, int M, float loss_scale, void* stream);
+                   float* probs, float* dlogits, long ld_d, float* loss, float* scratch, int M, float loss_scale,
+                   void* stream);
 
 /* OICROutputLayers.predict_probs_K, fast_rcnn.py:1577-1594. */
 int drn_mean_softmax(const float* logits, long ld, const int* col0s_dev, int n_heads, int C, float* probs, int M,
@@ -127,7 +130,8 @@ int drn_sum_small(const float* in, int n, float scale, float* out, void* stream)
 /* ---- optimizer ------------------------------------------------------------------------------- */
 
 /* torch.optim.SGD(momentum) with the per-parameter groups of detectron2/solver/build.py:93-137, applied to a
- * flat parameter arena.  segs_dev: array of {int64 offset, int64 count, float lr, float weight_decay}. */
+ * flat parameter arena.  segs_dev: array of {int64 offset, int64 count, float lr, float weight_decay}.
+ * shadow (optional, bf16, same flat layout) is refreshed in the same pass. */
 int drn_sgd_step(float* weights, float* momentum_buf, const float* grads, void* shadow, int shadow_dtype,
                  const void* segs_dev, int nseg, float momentum, int first_step, float grad_scale, void* stream);
 

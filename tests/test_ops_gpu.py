@@ -181,9 +181,11 @@ def _rois(R, n_img, H, W, seed):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C,P,scale", [(96, 7, 0.125), (6, 3, 0.125), (130, 7, 0.0625)])
-def test_roi_pool(drn, dtype, C, P, scale):
-    n_img, H, W = 2, 23, 29
+@pytest.mark.parametrize("C,P,scale,H,W", [(96, 7, 0.125, 23, 29), (6, 3, 0.125, 23, 29), (130, 7, 0.0625, 23, 29),
+                                           (128, 7, 0.0625, 14, 14), (64, 7, 0.125, 40, 37)])
+def test_roi_pool(drn, dtype, C, P, scale, H, W):
+    """C % 64 == 0 takes the LDS-staged path (boxes larger than the staging tile fall back to direct loads)."""
+    n_img = 2
     feat = _rnd((n_img, C, H, W), 11)
     rois = _rois(80, n_img, W / scale, H / scale, 12)
     obj = torch.rand(80)
