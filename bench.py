@@ -165,6 +165,7 @@ def main():
     batches = synthetic_batches(8, R, K, device, rank, pkg)
 
     def step(i):
+        model.prefetch_features(batches[(i + 1) % len(batches)])  # next batch's frozen backbone, side stream
         losses = model(batches[i % len(batches)])
         sum(losses.values()).backward()
         dp.finish()

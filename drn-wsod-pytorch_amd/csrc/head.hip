@@ -55,8 +55,9 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
   __shared__ float cs[4][64];
   const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
   const int n = blockIdx.x * 64 + tx;
-  const int mb0 = blockIdx.y * ACT_ROWS;
-  const int mb1 = min(mb0 + ACT_ROWS, p.M);
+  constexpr int ROWS = BWD ? ACT_ROWS : 64;
+  const int mb0 = blockIdx.y * ROWS;
+  const int mb1 = min(mb0 + ROWS, p.M);
   float csum = 0.f;
   const float cscale = (BWD && p.colscale && n < p.N) ? p.colscale[n] : 1.f;
   for (int mb = mb0; mb < mb1; mb += 64) {
@@ -139,97 +140,116 @@ struct WsddnParams {
   int n_img; int mean_loss; float loss_scale;
 };
 
-// one block (1024 threads) per image.  Pass 0: thread per ROW computes the row softmax once and parks it in
-// the scores buffer.  Passes 1-3: thread -> (column c = t % K, row phase t / K) for the column softmax, the
-// product, the image scores / BCE and the analytic backward (fixed-order LDS trees).
+// One block (1024 threads) per image.  A row is owned by LPR consecutive lanes (32 for K <= 32, else 64 with two
+// columns per lane), so the softmax over classes is a shuffle reduction and every global access is a
+// contiguous K-float run; a thread always sees the same column(s), so column max / sum / score sums accumulate in
+// registers over the row sweep and are combined once per sweep through LDS in a fixed order (deterministic).
+template <int LPR>
 __global__ __launch_bounds__(1024) void wsddn_kernel(WsddnParams p) {
-  __shared__ float red[1024];
-  __shared__ float colv[128], colg[128], cold[128], colm[128];
+  constexpr int RPP = 1024 / LPR;          // rows per pass
+  constexpr int CPL = LPR == 64 ? 2 : 1;   // columns per lane
+  __shared__ float red[RPP][LPR * CPL];
   const int img = blockIdx.x;
   const int r0 = p.img_off[img], r1 = p.img_off[img + 1];
-  const int K = p.K, nph = 1024 / K;
-  const int c = threadIdx.x % K, ph = threadIdx.x / K;
-  const bool act = ph < nph;
-  // 0. a[r][:] = softmax over classes of the cls logits
-  for (int r = r0 + threadIdx.x; r < r1; r += 1024) {
-    const float* row = p.logits + (long)r * p.ld + p.c_cls;
-    float rm = -FLT_MAX;
-    for (int k = 0; k < K; ++k) rm = fmaxf(rm, row[k]);
-    float rs = 0.f;
-    for (int k = 0; k < K; ++k) rs += expf(row[k] - rm);
-    for (int k = 0; k < K; ++k) p.rowsm[(long)r * K + k] = expf(row[k] - rm) / rs;
-  }
-  __syncthreads();
-  // 1. column max of det logits
-  float mx = -FLT_MAX;
-  if (act) for (int r = r0 + ph; r < r1; r += nph) mx = fmaxf(mx, p.logits[(long)r * p.ld + p.c_det + c]);
-  red[threadIdx.x] = mx;
-  __syncthreads();
-  if (threadIdx.x < K) { float m = -FLT_MAX; for (int q = 0; q < nph; ++q) m = fmaxf(m, red[q * K + threadIdx.x]); colm[threadIdx.x] = m; }
-  __syncthreads();
-  const float cmax = colm[c];
-  // 2. column sum of exp
-  float se = 0.f;
-  if (act) for (int r = r0 + ph; r < r1; r += nph) se += expf(p.logits[(long)r * p.ld + p.c_det + c] - cmax);
-  red[threadIdx.x] = se;
-  __syncthreads();
-  if (threadIdx.x < K) { float s = 0.f; for (int q = 0; q < nph; ++q) s += red[q * K + threadIdx.x]; colv[threadIdx.x] = s; }
-  __syncthreads();
-  const float csum = colv[c];
-  // 3. scores = a * b ; column sums
-  float ss = 0.f;
-  if (act)
-    for (int r = r0 + ph; r < r1; r += nph) {
-      const float a = p.rowsm[(long)r * K + c];
-      const float b = expf(p.logits[(long)r * p.ld + p.c_det + c] - cmax) / csum;
-      const float s = a * b;
-      p.scores[(long)r * K + c] = s;
-      ss += s;
+  const int K = p.K;
+  const int l = threadIdx.x % LPR, ph = threadIdx.x / LPR;
+  bool ok[CPL];
+  int col[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) { col[j] = l + j * LPR; ok[j] = col[j] < K; }
+  auto gmax = [](float v) { for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, LPR)); return v; };
+  auto gsum = [](float v) { for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR); return v; };
+  // combine the per-phase partials of my column(s): every thread reads the whole column of `red` itself
+  auto colreduce = [&](float (&v)[CPL], bool is_max) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) red[ph][col[j]] = v[j];
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      float acc = is_max ? -FLT_MAX : 0.f;
+      for (int q = 0; q < RPP; ++q) acc = is_max ? fmaxf(acc, red[q][col[j]]) : acc + red[q][col[j]];
+      v[j] = acc;
     }
-  __syncthreads();
-  red[threadIdx.x] = ss;
-  __syncthreads();
-  if (threadIdx.x < K) {
-    float s = 0.f;
-    for (int q = 0; q < nph; ++q) s += red[q * K + threadIdx.x];
-    const float sc = fminf(fmaxf(s, 1e-6f), 1.0f - 1e-6f);
-    cold[threadIdx.x] = s;  // unclamped column sum S_c, reused by the backward
-    p.img_scores[img * K + threadIdx.x] = sc;
-    const float y = p.gt_onehot[img * K + threadIdx.x];
-    // F.binary_cross_entropy: -(y*log(s) + (1-y)*log(1-s)), logs clamped at -100
-    const float l = -(y * fmaxf(logf(sc), -100.f) + (1.f - y) * fmaxf(logf(1.f - sc), -100.f));
-    colv[threadIdx.x] = l;
-    const float norm = (p.mean_loss ? 1.f / (float)(p.n_img * K) : 1.f) / (float)p.n_img;
-    // d loss / d (unclamped sum); clamp passes gradient only inside [1e-6, 1-1e-6]
-    colg[threadIdx.x] = (s >= 1e-6f && s <= 1.0f - 1e-6f) ? (-(y / sc) + (1.f - y) / (1.f - sc)) * norm * p.loss_scale : 0.f;
+  };
+  // sweep 1: a = softmax over classes (kept in rowsm); column max of the det logits
+  float cmax[CPL], csum[CPL], S[CPL], g[CPL];
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) cmax[j] = -FLT_MAX;
+#pragma unroll 2
+  for (int r = r0 + ph; r < r1; r += RPP) {
+    const float* row = p.logits + (long)r * p.ld;
+    float x[CPL], e[CPL], mx = -FLT_MAX;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      x[j] = ok[j] ? row[p.c_cls + col[j]] : -FLT_MAX;
+      if (ok[j]) cmax[j] = fmaxf(cmax[j], row[p.c_det + col[j]]);
+      mx = fmaxf(mx, x[j]);
+    }
+    mx = gmax(mx);
+    float se = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { e[j] = ok[j] ? expf(x[j] - mx) : 0.f; se += e[j]; }
+    se = gsum(se);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) if (ok[j]) p.rowsm[(long)r * K + col[j]] = e[j] / se;
   }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    float l = 0.f;
-    for (int k = 0; k < K; ++k) l += colv[k];
-    const float norm = (p.mean_loss ? 1.f / (float)(p.n_img * K) : 1.f) / (float)p.n_img;
-    p.loss_part[img] = l * norm;
+  colreduce(cmax, true);
+  // sweep 2: column sum of exp(det - cmax)
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) csum[j] = 0.f;
+#pragma unroll 2
+  for (int r = r0 + ph; r < r1; r += RPP)
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+      if (ok[j]) csum[j] += expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - cmax[j]);
+  colreduce(csum, false);
+  // sweep 3: scores = a * b; column sums
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) S[j] = 0.f;
+#pragma unroll 2
+  for (int r = r0 + ph; r < r1; r += RPP)
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+      if (ok[j]) {
+        const float b = expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - cmax[j]) / csum[j];
+        const float sc = p.rowsm[(long)r * K + col[j]] * b;
+        p.scores[(long)r * K + col[j]] = sc;
+        S[j] += sc;
+      }
+  colreduce(S, false);
+  // image scores, BCE and d loss / d S_c (clamp passes gradient only inside [1e-6, 1 - 1e-6])
+  const float norm = (p.mean_loss ? 1.f / (float)(p.n_img * K) : 1.f) / (float)p.n_img;
+  float lsum = 0.f;
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    g[j] = 0.f;
+    if (ok[j]) {
+      const float sc = fminf(fmaxf(S[j], 1e-6f), 1.0f - 1e-6f);
+      const float y = p.gt_onehot[img * K + col[j]];
+      // F.binary_cross_entropy: -(y*log(s) + (1-y)*log(1-s)), logs clamped at -100
+      lsum += -(y * fmaxf(logf(sc), -100.f) + (1.f - y) * fmaxf(logf(1.f - sc), -100.f));
+      g[j] = (S[j] >= 1e-6f && S[j] <= 1.0f - 1e-6f) ? (-(y / sc) + (1.f - y) / (1.f - sc)) * norm * p.loss_scale : 0.f;
+      if (ph == 0) p.img_scores[img * K + col[j]] = sc;
+    }
   }
+  lsum = gsum(lsum);
+  if (threadIdx.x == 0) p.loss_part[img] = lsum * norm;
   if (!p.dlogits) return;
-  // backward. s = a*b, ds = g[c] for every row.  d cls = g_c*s - a*dot with dot = sum_k g_k s_rk;
-  // d det = g_c*(s - b*S_c) with S_c the unclamped column sum.  dot is computed once per row by the row's
-  // first thread (c == 0) and parked in `red` (rows of this pass are distinct per phase).
-  for (int rb = r0; rb < r1; rb += nph) {
-    const int r = rb + ph;
-    const bool ok = act && r < r1;
-    float s = 0.f;
-    if (ok) s = p.scores[(long)r * K + c];
-    red[threadIdx.x] = ok ? colg[c] * s : 0.f;
-    __syncthreads();
-    if (ok) {
-      float dot = 0.f;
-      for (int k = 0; k < K; ++k) dot += red[ph * K + k];
-      const float b = expf(p.logits[(long)r * p.ld + p.c_det + c] - cmax) / csum;
-      const float a = p.rowsm[(long)r * K + c];
-      p.dlogits[(long)r * p.ld_d + p.c_cls + c] = colg[c] * s - a * dot;
-      p.dlogits[(long)r * p.ld_d + p.c_det + c] = colg[c] * (s - b * cold[c]);
-    }
-    __syncthreads();
+  // sweep 4: backward.  d cls = g_c*s - a*dot, dot = sum_k g_k s_rk;  d det = g_c*(s - b*S_c)
+#pragma unroll 2
+  for (int r = r0 + ph; r < r1; r += RPP) {
+    float sc[CPL], dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) { sc[j] = ok[j] ? p.scores[(long)r * K + col[j]] : 0.f; dot += g[j] * sc[j]; }
+    dot = gsum(dot);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j)
+      if (ok[j]) {
+        const float b = expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - cmax[j]) / csum[j];
+        p.dlogits[(long)r * p.ld_d + p.c_cls + col[j]] = g[j] * sc[j] - p.rowsm[(long)r * K + col[j]] * dot;
+        p.dlogits[(long)r * p.ld_d + p.c_det + col[j]] = g[j] * (sc[j] - b * S[j]);
+      }
   }
 }
 
@@ -493,7 +513,7 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
   if (M == 0 || N == 0) return DRN_OK;
   ActParams p{partials, splits, split_stride, bias, mask, seed, drop_p, nullptr, (char*)out, ld_out, (char*)outT,
               ld_outT, nullptr, nullptr, nullptr, M, N, ld_in, relu, 0};
-  dim3 grid((N + 63) / 64, (M + ACT_ROWS - 1) / ACT_ROWS), block(256);
+  dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == DRN_BF16) hipLaunchKernelGGL((act_kernel<DRN_BF16, DRN_BF16, false>), grid, block, 0, st, p);
   else if (out_dtype == DRN_F32) hipLaunchKernelGGL((act_kernel<DRN_F32, DRN_F32, false>), grid, block, 0, st, p);
@@ -532,7 +552,8 @@ int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K,
     return DRN_ERR_ARG;
   WsddnParams p{logits, ld, c_cls, c_det, K, img_off, gt_onehot, scores, row_softmax, img_scores, loss_part, dlogits, ld_d, n_img,
                 mean_loss, loss_scale};
-  hipLaunchKernelGGL(wsddn_kernel, dim3(n_img), dim3(1024), 0, (hipStream_t)stream, p);
+  if (K <= 32) hipLaunchKernelGGL(wsddn_kernel<32>, dim3(n_img), dim3(1024), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(wsddn_kernel<64>, dim3(n_img), dim3(1024), 0, (hipStream_t)stream, p);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

@@ -212,10 +212,67 @@ __global__ __launch_bounds__(256) void roi_kernel(RoiParams p) {
   // coalesced write-out: k = c*PP + bin is contiguous over this block's 64 channels
   const int nvalid = min(RP_CH, p.C - c0) * PP;
   TO* orow = (TO*)p.out + (long)m * p.ld_out + (long)c0 * PP;
-  for (int i = threadIdx.x; i < nvalid; i += 256) {
-    const int lc = i / PP, bin = i - lc * PP;
-    EO::st(orow + i, tile[lc][bin]);
-    if (MODE == 0 && p.argmax) p.argmax[(long)m * p.C * PP + (long)c0 * PP + i] = atile[lc][bin];
+  constexpr int ESO = DT_OUT == DRN_BF16 ? 2 : 4;
+  constexpr int VE = 16 / ESO;  // elements per 16-B store
+  if ((nvalid % VE) == 0 && ((((long)m * p.ld_out + (long)c0 * PP) * ESO) & 15) == 0 && (((uintptr_t)p.out) & 15) == 0) {
+    for (int v = threadIdx.x; v < nvalid / VE; v += 256) {
+      float f[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const int i = v * VE + e, lc = i / PP;
+        f[e] = tile[lc][i - lc * PP];
+      }
+      i32x4_t o;
+      if constexpr (DT_OUT == DRN_BF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (int)((uint32_t)f32_to_bf16(f[2 * e]) | ((uint32_t)f32_to_bf16(f[2 * e + 1]) << 16));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(int, f[e]);
+      }
+      *(i32x4_t*)((char*)orow + (long)v * 16) = o;
+    }
+  } else {
+    for (int i = threadIdx.x; i < nvalid; i += 256) {
+      const int lc = i / PP;
+      EO::st(orow + i, tile[lc][i - lc * PP]);
+    }
+  }
+  if (MODE == 0 && p.argmax)
+    for (int i = threadIdx.x; i < nvalid; i += 256) {
+      const int lc = i / PP;
+      p.argmax[(long)m * p.C * PP + (long)c0 * PP + i] = atile[lc][i - lc * PP];
+    }
+}
+
+// bf16 -> bf16 transpose with 16-B global accesses on both sides (the A -> A^T copy of the fc6 operand is
+// 2 x 205 MB per step): 64x64 tile, rows read as 8-element vectors, written transposed into LDS, re-read as vectors.
+__global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
+                                                             int rows, int cols, long ld_in, long ld_out) {
+  __shared__ bf16_t t[64][72];  // [c][r], row pitch 144 B keeps the 16-B reads aligned and spreads banks
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int v = threadIdx.x & 7, rr = threadIdx.x >> 3;  // 8 vectors per 64-element row, 32 rows per pass
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int r = r0 + rr + 32 * pass, c = c0 + v * 8;
+    i32x4_t x = {0, 0, 0, 0};
+    if (r < rows && c + 8 <= cols) x = *(const i32x4_t*)(in + (long)r * ld_in + c);
+    else if (r < rows)
+      for (int e = 0; e < 8; ++e)
+        if (c + e < cols) ((bf16_t*)&x)[e] = in[(long)r * ld_in + c + e];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) t[v * 8 + e][rr + 32 * pass] = ((const bf16_t*)&x)[e];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int c = c0 + rr + 32 * pass, r = r0 + v * 8;
+    if (c >= cols) continue;
+    const i32x4_t x = *(const i32x4_t*)(&t[rr + 32 * pass][v * 8]);
+    if (r + 8 <= rows) *(i32x4_t*)(out + (long)c * ld_out + r) = x;
+    else
+      for (int e = 0; e < 8; ++e)
+        if (r + e < rows) out[(long)c * ld_out + r + e] = ((const bf16_t*)&x)[e];
   }
 }
 
@@ -334,7 +391,10 @@ int drn_transpose2d(const void* in, void* out, int rows, int cols, long ld_in, l
   dim3 grid((cols + 63) / 64, (rows + 63) / 64), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define TR_LAUNCH(DI, DO) hipLaunchKernelGGL((transpose_kernel<DI, DO>), grid, block, 0, st, (const char*)in, (char*)out, rows, cols, ld_in, ld_out)
-  if (in_dtype == DRN_BF16 && out_dtype == DRN_BF16) TR_LAUNCH(DRN_BF16, DRN_BF16);
+  if (in_dtype == DRN_BF16 && out_dtype == DRN_BF16 && (ld_in % 8) == 0 && (ld_out % 8) == 0 &&
+      ((((uintptr_t)in) | ((uintptr_t)out)) & 15) == 0)
+    hipLaunchKernelGGL(transpose_bf16_kernel, grid, block, 0, st, (const bf16_t*)in, (bf16_t*)out, rows, cols, ld_in, ld_out);
+  else if (in_dtype == DRN_BF16 && out_dtype == DRN_BF16) TR_LAUNCH(DRN_BF16, DRN_BF16);
   else if (in_dtype == DRN_F32 && out_dtype == DRN_F32) TR_LAUNCH(DRN_F32, DRN_F32);
   else if (in_dtype == DRN_F32 && out_dtype == DRN_BF16) TR_LAUNCH(DRN_F32, DRN_BF16);
   else if (in_dtype == DRN_BF16 && out_dtype == DRN_F32) TR_LAUNCH(DRN_BF16, DRN_F32);

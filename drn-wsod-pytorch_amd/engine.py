@@ -205,10 +205,16 @@ class Trainer:
 
     def run_step(self):
         assert self.model.training, "[Trainer] model was changed to eval mode!"
-        while True:  # train_net.py:74-81: re-draw batches that contain an image without GT
-            data = next(self._it)
-            if all(len(x["instances"]) > 0 for x in data):
-                break
+        def draw():
+            while True:  # train_net.py:74-81: re-draw batches that contain an image without GT
+                d = next(self._it)
+                if all(len(x["instances"]) > 0 for x in d):
+                    return d
+
+        data = self._lookahead if getattr(self, "_lookahead", None) is not None else draw()
+        self._lookahead = draw()
+        if hasattr(self.model, "prefetch_features"):
+            self.model.prefetch_features(self._lookahead)  # frozen backbone of the next batch, on a side stream
         with self.storage:
             loss_dict = self.model(data)
         losses = sum(loss_dict.values())

@@ -73,6 +73,36 @@ class GeneralizedRCNNWSL(nn.Module):
         view._drn_nhwc = nhwc
         return ImageList(view, sizes, nhwc)
 
+    def prefetch_features(self, batched_inputs):
+        """Run preprocess + backbone of a FUTURE batch on a side stream.  The shipped configs freeze the whole
+        backbone (FREEZE_AT=5), so its forward has no dependency on the head update: its ~45 small, latency-bound
+        conv launches hide under the current batch's fc6/fc7 GEMMs instead of serialising in front of them."""
+        if any(p.requires_grad for p in self.backbone.parameters()):
+            return  # only legal for a frozen backbone
+        if getattr(self, "_side", None) is None:
+            self._side = torch.cuda.Stream()
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)
+        with torch.cuda.stream(self._side), torch.no_grad():
+            images = self.preprocess_image(batched_inputs)
+            features = self.backbone(images.tensor)
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._prefetched = (id(batched_inputs), images, features, ev)
+
+    def _features(self, batched_inputs):
+        pre = getattr(self, "_prefetched", None)
+        if pre is not None and pre[0] == id(batched_inputs):
+            self._prefetched = None
+            _, images, features, ev = pre
+            main = torch.cuda.current_stream()
+            main.wait_event(ev)
+            for t in list(features.values()) + [images.nhwc]:
+                t.record_stream(main)
+            return images, features
+        images = self.preprocess_image(batched_inputs)
+        return images, self.backbone(images.tensor)
+
     def _proposals(self, batched_inputs):
         assert self.load_proposals and "proposals" in batched_inputs[0], "this path uses precomputed proposals"
         return [x["proposals"].to(self.device) for x in batched_inputs]
@@ -80,10 +110,9 @@ class GeneralizedRCNNWSL(nn.Module):
     def forward(self, batched_inputs):
         if not self.training:
             return self.inference(batched_inputs)
-        images = self.preprocess_image(batched_inputs)
+        images, features = self._features(batched_inputs)
         # image-level labels are read on the host (they come from the loader there): no device round trip
         gt_instances = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
-        features = self.backbone(images.tensor)
         proposals = self._proposals(batched_inputs)
         _, detector_losses = self.roi_heads(images, features, proposals, gt_instances)
         losses = {}

@@ -312,10 +312,10 @@ class _HeadEngine:
         offs, off = [], 0
         for name, p, used in order:
             if name not in contiguous:
-                off = (off + 3) // 4 * 4
+                off = (off + 7) // 8 * 8  # 16 B in the bf16 shadow arena, 32 B in the fp32 one
             offs.append(off)
             off += p.numel()
-        total = (off + 3) // 4 * 4
+        total = (off + 7) // 8 * 8
         w = torch.zeros((total,), dtype=torch.float32, device=device)
         g = torch.zeros((total,), dtype=torch.float32, device=device)
         self.segments = []
