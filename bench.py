@@ -185,6 +185,7 @@ def main():
     t0 = time.perf_counter()
     for i in range(args.steps):
         last = step(args.warmup + i)
+    t_enq = time.perf_counter() - t0  # host time to enqueue the whole timed region (diagnostic)
     barrier()
     dt = time.perf_counter() - t0
     timing, ops.GEMM_TIMING = ops.GEMM_TIMING, None
@@ -213,7 +214,7 @@ def main():
                                       "%d proposals/img, 1 img/GPU/iter, K=20, 3 OICR refinements, frozen backbone "
                                       "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % R,
                           "global_batch": world, "proposals": R, "parallelism": "dp%d" % world},
-               "losses_last_step": loss_vals, "roofline": roof}
+               "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batches)
         print(json.dumps(out))

@@ -24,7 +24,7 @@ _SIGS = {
     "drn_bias_act_fwd": "pilppQfplpliiliip",
     "drn_bias_act_bwd": "plpppfplplppiiiip",
     "drn_cast2d": "ppiilliip",
-    "drn_wsddn_fwd_bwd": "pliiipipppppplifp",
+    "drn_wsddn_fwd_bwd": "pliiipippppppl" + "pi" + "ifp",
     "drn_oicr_targets": "plpi" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",
     "drn_softmax_ce": "pliipppplppifp",
     "drn_mean_softmax": "plpiipip",

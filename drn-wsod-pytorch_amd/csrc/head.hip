@@ -138,111 +138,155 @@ struct WsddnParams {
   float* loss_part;                // [n_img]
   float* dlogits; long ld_d;       // [M][ld_d] (same column offsets) or null
   int n_img; int mean_loss; float loss_scale;
+  float* part; int max_blocks;     // [n_img][max_blocks][3][WS_KP] per-block column partials
 };
 
-// One block (1024 threads) per image.  A row is owned by LPR consecutive lanes (32 for K <= 32, else 64 with two
-// columns per lane), so the softmax over classes is a shuffle reduction and every global access is a
-// contiguous K-float run; a thread always sees the same column(s), so column max / sum / score sums accumulate in
-// registers over the row sweep and are combined once per sweep through LDS in a fixed order (deterministic).
+// WSDDN forward + backward as three multi-block launches over row blocks of WS_ROWS rows (grid = blocks x images):
+//   A: a = softmax over classes (shuffle reduction inside the LPR lanes that own a row) -> rowsm; per-block online
+//      column-softmax partials (block max, block sum of exp relative to it)
+//   B: every block re-combines the partials of its image in a fixed order (cmax, csum), writes the scores and its
+//      partial column sums
+//   C: combine the score sums, image scores / BCE / d loss (first block of the image), analytic backward
+// Rows are owned by LPR consecutive lanes (32 for K <= 32, else 64 with two columns per lane); all reductions have
+// a fixed order, so the result does not depend on scheduling.
+constexpr int WS_ROWS = 128;
+constexpr int WS_KP = 128;  // padded column count of the partial buffers
+
 template <int LPR>
-__global__ __launch_bounds__(1024) void wsddn_kernel(WsddnParams p) {
-  constexpr int RPP = 1024 / LPR;          // rows per pass
-  constexpr int CPL = LPR == 64 ? 2 : 1;   // columns per lane
+struct WsLanes {
+  static constexpr int RPP = 256 / LPR, CPL = LPR == 64 ? 2 : 1;
+  static __device__ __forceinline__ float gmax(float v) { for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, LPR)); return v; }
+  static __device__ __forceinline__ float gsum(float v) { for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR); return v; }
+};
+
+// block-level combine of per-phase column partials (fixed order over phases)
+template <int LPR, bool IS_MAX>
+__device__ __forceinline__ void ws_colreduce(float (&v)[WsLanes<LPR>::CPL], const int (&col)[WsLanes<LPR>::CPL],
+                                             int ph, float (*red)[LPR * WsLanes<LPR>::CPL]) {
+  using L = WsLanes<LPR>;
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < L::CPL; ++j) red[ph][col[j]] = v[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < L::CPL; ++j) {
+    float acc = IS_MAX ? -FLT_MAX : 0.f;
+    for (int q = 0; q < L::RPP; ++q) acc = IS_MAX ? fmaxf(acc, red[q][col[j]]) : acc + red[q][col[j]];
+    v[j] = acc;
+  }
+}
+
+// cmax / csum of image `img` from the per-block partials, same order in every block
+template <int LPR>
+__device__ __forceinline__ void ws_combine(const WsddnParams& p, int img, int nb, const int (&col)[WsLanes<LPR>::CPL],
+                                           const bool (&ok)[WsLanes<LPR>::CPL], float (&cmax)[WsLanes<LPR>::CPL],
+                                           float (&csum)[WsLanes<LPR>::CPL]) {
+  const float* part = p.part + (long)img * p.max_blocks * 3 * WS_KP;
+#pragma unroll
+  for (int j = 0; j < WsLanes<LPR>::CPL; ++j) {
+    cmax[j] = -FLT_MAX; csum[j] = 0.f;
+    if (!ok[j]) continue;
+    for (int q = 0; q < nb; ++q) cmax[j] = fmaxf(cmax[j], part[(q * 3 + 0) * WS_KP + col[j]]);
+    for (int q = 0; q < nb; ++q)
+      csum[j] += part[(q * 3 + 1) * WS_KP + col[j]] * expf(part[(q * 3 + 0) * WS_KP + col[j]] - cmax[j]);
+  }
+}
+
+template <int LPR, int STAGE>
+__global__ __launch_bounds__(256) void wsddn_stage_kernel(WsddnParams p) {
+  using L = WsLanes<LPR>;
+  constexpr int RPP = L::RPP, CPL = L::CPL;
   __shared__ float red[RPP][LPR * CPL];
-  const int img = blockIdx.x;
+  const int img = blockIdx.y, blk = blockIdx.x;
   const int r0 = p.img_off[img], r1 = p.img_off[img + 1];
+  const int nb = (r1 - r0 + WS_ROWS - 1) / WS_ROWS;
+  if (blk >= nb) return;
+  const int rb0 = r0 + blk * WS_ROWS, rb1 = min(rb0 + WS_ROWS, r1);
   const int K = p.K;
   const int l = threadIdx.x % LPR, ph = threadIdx.x / LPR;
   bool ok[CPL];
   int col[CPL];
 #pragma unroll
   for (int j = 0; j < CPL; ++j) { col[j] = l + j * LPR; ok[j] = col[j] < K; }
-  auto gmax = [](float v) { for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, LPR)); return v; };
-  auto gsum = [](float v) { for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR); return v; };
-  // combine the per-phase partials of my column(s): every thread reads the whole column of `red` itself
-  auto colreduce = [&](float (&v)[CPL], bool is_max) {
-    __syncthreads();
+  float* part = p.part + ((long)img * p.max_blocks + blk) * 3 * WS_KP;
+  if (STAGE == 0) {
+    float bmax[CPL], bsum[CPL];
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) red[ph][col[j]] = v[j];
-    __syncthreads();
+    for (int j = 0; j < CPL; ++j) { bmax[j] = -FLT_MAX; bsum[j] = 0.f; }
+    for (int r = rb0 + ph; r < rb1; r += RPP) {
+      const float* row = p.logits + (long)r * p.ld;
+      float x[CPL], e[CPL], mx = -FLT_MAX;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      float acc = is_max ? -FLT_MAX : 0.f;
-      for (int q = 0; q < RPP; ++q) acc = is_max ? fmaxf(acc, red[q][col[j]]) : acc + red[q][col[j]];
-      v[j] = acc;
-    }
-  };
-  // sweep 1: a = softmax over classes (kept in rowsm); column max of the det logits
-  float cmax[CPL], csum[CPL], S[CPL], g[CPL];
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) cmax[j] = -FLT_MAX;
-#pragma unroll 2
-  for (int r = r0 + ph; r < r1; r += RPP) {
-    const float* row = p.logits + (long)r * p.ld;
-    float x[CPL], e[CPL], mx = -FLT_MAX;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) {
-      x[j] = ok[j] ? row[p.c_cls + col[j]] : -FLT_MAX;
-      if (ok[j]) cmax[j] = fmaxf(cmax[j], row[p.c_det + col[j]]);
-      mx = fmaxf(mx, x[j]);
-    }
-    mx = gmax(mx);
-    float se = 0.f;
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) { e[j] = ok[j] ? expf(x[j] - mx) : 0.f; se += e[j]; }
-    se = gsum(se);
-#pragma unroll
-    for (int j = 0; j < CPL; ++j) if (ok[j]) p.rowsm[(long)r * K + col[j]] = e[j] / se;
-  }
-  colreduce(cmax, true);
-  // sweep 2: column sum of exp(det - cmax)
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) csum[j] = 0.f;
-#pragma unroll 2
-  for (int r = r0 + ph; r < r1; r += RPP)
-#pragma unroll
-    for (int j = 0; j < CPL; ++j)
-      if (ok[j]) csum[j] += expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - cmax[j]);
-  colreduce(csum, false);
-  // sweep 3: scores = a * b; column sums
-#pragma unroll
-  for (int j = 0; j < CPL; ++j) S[j] = 0.f;
-#pragma unroll 2
-  for (int r = r0 + ph; r < r1; r += RPP)
-#pragma unroll
-    for (int j = 0; j < CPL; ++j)
-      if (ok[j]) {
-        const float b = expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - cmax[j]) / csum[j];
-        const float sc = p.rowsm[(long)r * K + col[j]] * b;
-        p.scores[(long)r * K + col[j]] = sc;
-        S[j] += sc;
+      for (int j = 0; j < CPL; ++j) {
+        x[j] = ok[j] ? row[p.c_cls + col[j]] : -FLT_MAX;
+        if (ok[j]) bmax[j] = fmaxf(bmax[j], row[p.c_det + col[j]]);
+        mx = fmaxf(mx, x[j]);
       }
-  colreduce(S, false);
-  // image scores, BCE and d loss / d S_c (clamp passes gradient only inside [1e-6, 1 - 1e-6])
+      mx = L::gmax(mx);
+      float se = 0.f;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) { e[j] = ok[j] ? expf(x[j] - mx) : 0.f; se += e[j]; }
+      se = L::gsum(se);
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) if (ok[j]) p.rowsm[(long)r * K + col[j]] = e[j] / se;
+    }
+    ws_colreduce<LPR, true>(bmax, col, ph, red);
+    for (int r = rb0 + ph; r < rb1; r += RPP)
+#pragma unroll
+      for (int j = 0; j < CPL; ++j)
+        if (ok[j]) bsum[j] += expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - bmax[j]);
+    ws_colreduce<LPR, false>(bsum, col, ph, red);
+    if (ph == 0)
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) if (ok[j]) { part[0 * WS_KP + col[j]] = bmax[j]; part[1 * WS_KP + col[j]] = bsum[j]; }
+    return;
+  }
+  float cmax[CPL], csum[CPL];
+  ws_combine<LPR>(p, img, nb, col, ok, cmax, csum);
+  if (STAGE == 1) {
+    float S[CPL];
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) S[j] = 0.f;
+    for (int r = rb0 + ph; r < rb1; r += RPP)
+#pragma unroll
+      for (int j = 0; j < CPL; ++j)
+        if (ok[j]) {
+          const float b = expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - cmax[j]) / csum[j];
+          const float sc = p.rowsm[(long)r * K + col[j]] * b;
+          p.scores[(long)r * K + col[j]] = sc;
+          S[j] += sc;
+        }
+    ws_colreduce<LPR, false>(S, col, ph, red);
+    if (ph == 0)
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) if (ok[j]) part[2 * WS_KP + col[j]] = S[j];
+    return;
+  }
+  // STAGE 2: image scores, BCE, d loss / d S_c (clamp passes gradient only inside [1e-6, 1 - 1e-6]), backward
+  const float* ipart = p.part + (long)img * p.max_blocks * 3 * WS_KP;
   const float norm = (p.mean_loss ? 1.f / (float)(p.n_img * K) : 1.f) / (float)p.n_img;
-  float lsum = 0.f;
+  float S[CPL], g[CPL], lsum = 0.f;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    g[j] = 0.f;
-    if (ok[j]) {
-      const float sc = fminf(fmaxf(S[j], 1e-6f), 1.0f - 1e-6f);
-      const float y = p.gt_onehot[img * K + col[j]];
-      // F.binary_cross_entropy: -(y*log(s) + (1-y)*log(1-s)), logs clamped at -100
-      lsum += -(y * fmaxf(logf(sc), -100.f) + (1.f - y) * fmaxf(logf(1.f - sc), -100.f));
-      g[j] = (S[j] >= 1e-6f && S[j] <= 1.0f - 1e-6f) ? (-(y / sc) + (1.f - y) / (1.f - sc)) * norm * p.loss_scale : 0.f;
-      if (ph == 0) p.img_scores[img * K + col[j]] = sc;
-    }
+    S[j] = 0.f; g[j] = 0.f;
+    if (!ok[j]) continue;
+    for (int q = 0; q < nb; ++q) S[j] += ipart[(q * 3 + 2) * WS_KP + col[j]];
+    const float sc = fminf(fmaxf(S[j], 1e-6f), 1.0f - 1e-6f);
+    const float y = p.gt_onehot[img * K + col[j]];
+    // F.binary_cross_entropy: -(y*log(s) + (1-y)*log(1-s)), logs clamped at -100
+    lsum += -(y * fmaxf(logf(sc), -100.f) + (1.f - y) * fmaxf(logf(1.f - sc), -100.f));
+    g[j] = (S[j] >= 1e-6f && S[j] <= 1.0f - 1e-6f) ? (-(y / sc) + (1.f - y) / (1.f - sc)) * norm * p.loss_scale : 0.f;
+    if (blk == 0 && ph == 0) p.img_scores[img * K + col[j]] = sc;
   }
-  lsum = gsum(lsum);
-  if (threadIdx.x == 0) p.loss_part[img] = lsum * norm;
+  lsum = L::gsum(lsum);
+  if (blk == 0 && threadIdx.x == 0) p.loss_part[img] = lsum * norm;
   if (!p.dlogits) return;
-  // sweep 4: backward.  d cls = g_c*s - a*dot, dot = sum_k g_k s_rk;  d det = g_c*(s - b*S_c)
-#pragma unroll 2
-  for (int r = r0 + ph; r < r1; r += RPP) {
+  // d cls = g_c*s - a*dot, dot = sum_k g_k s_rk;  d det = g_c*(s - b*S_c)
+  for (int r = rb0 + ph; r < rb1; r += RPP) {
     float sc[CPL], dot = 0.f;
 #pragma unroll
     for (int j = 0; j < CPL; ++j) { sc[j] = ok[j] ? p.scores[(long)r * K + col[j]] : 0.f; dot += g[j] * sc[j]; }
-    dot = gsum(dot);
+    dot = L::gsum(dot);
 #pragma unroll
     for (int j = 0; j < CPL; ++j)
       if (ok[j]) {
@@ -544,16 +588,28 @@ int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, c
   return DRN_OK;
 }
 
+// scratch: n_img * ceil(max_rows/128) * 3 * 128 floats (max_rows = largest proposal count of one image)
 int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K, const int* img_off, int n_img,
                       const float* gt_onehot, float* scores, float* row_softmax, float* img_scores, float* loss_part,
-                      float* dlogits, long ld_d, int mean_loss, float loss_scale, void* stream) {
-  if (!logits || !img_off || !gt_onehot || !scores || !row_softmax || !img_scores || !loss_part || K < 1 || K > 128 ||
-      n_img < 1)
+                      float* dlogits, long ld_d, float* scratch, int max_rows, int mean_loss, float loss_scale,
+                      void* stream) {
+  if (!logits || !img_off || !gt_onehot || !scores || !row_softmax || !img_scores || !loss_part || !scratch || K < 1 ||
+      K > 128 || n_img < 1 || max_rows < 1)
     return DRN_ERR_ARG;
-  WsddnParams p{logits, ld, c_cls, c_det, K, img_off, gt_onehot, scores, row_softmax, img_scores, loss_part, dlogits, ld_d, n_img,
-                mean_loss, loss_scale};
-  if (K <= 32) hipLaunchKernelGGL(wsddn_kernel<32>, dim3(n_img), dim3(1024), 0, (hipStream_t)stream, p);
-  else hipLaunchKernelGGL(wsddn_kernel<64>, dim3(n_img), dim3(1024), 0, (hipStream_t)stream, p);
+  const int nb = (max_rows + WS_ROWS - 1) / WS_ROWS;
+  WsddnParams p{logits, ld, c_cls, c_det, K, img_off, gt_onehot, scores, row_softmax, img_scores, loss_part, dlogits, ld_d,
+                n_img, mean_loss, loss_scale, scratch, nb};
+  dim3 grid(nb, n_img), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (K <= 32) {
+    hipLaunchKernelGGL((wsddn_stage_kernel<32, 0>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((wsddn_stage_kernel<32, 1>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((wsddn_stage_kernel<32, 2>), grid, block, 0, st, p);
+  } else {
+    hipLaunchKernelGGL((wsddn_stage_kernel<64, 0>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((wsddn_stage_kernel<64, 1>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((wsddn_stage_kernel<64, 2>), grid, block, 0, st, p);
+  }
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

@@ -245,6 +245,88 @@ __global__ __launch_bounds__(256) void roi_kernel(RoiParams p) {
     }
 }
 
+// ROIPool specialised for the 7x7 pooler every DRN-WSOD config uses.  One block = one ROI x 256 channels (four
+// 64-channel chunks, so the ROI geometry, the 49 bin rectangles and the window's pixel table are computed once);
+// per chunk the window pixels are staged in LDS by 16-B loads, the bin maxima come out of LDS, and the
+// [c*49 + bin] run (64*49 contiguous outputs) leaves in 16-B stores.  All divisions are by constants.
+template <int DT_IN, int DT_OUT>
+__global__ __launch_bounds__(256) void roi_pool7_kernel(RoiParams p) {
+  using EI = ElemOf<DT_IN>;
+  using TI = typename EI::type;
+  using EO = ElemOf<DT_OUT>;
+  using TO = typename EO::type;
+  constexpr int PP = 49, CHUNKS = 4;
+  constexpr int ESI = DT_IN == DRN_BF16 ? 2 : 4, ESO = DT_OUT == DRN_BF16 ? 2 : 4;
+  constexpr int VPL = RP_CH * ESI / 16, VE = 16 / ESO;
+  extern __shared__ __attribute__((aligned(16))) char stage[];  // [lds_px][64] TI
+  __shared__ float tile[RP_CH][PP + 1];
+  __shared__ int bins[PP][4];
+  __shared__ int pxoff[256];
+  const int m = blockIdx.x;
+  const int cl = threadIdx.x & 63, bg = threadIdx.x >> 6;
+  const float* roi = p.rois + 5 * (long)m;
+  const int b = (int)roi[0];
+  const float mul = p.obj ? p.obj[m] + 1.f : 1.f;
+  const TI* fb = (const TI*)p.feat + (long)b * p.H * p.W * p.C;
+  const int x1 = (int)roundf(roi[1] * p.scale), y1 = (int)roundf(roi[2] * p.scale);
+  const int x2 = (int)roundf(roi[3] * p.scale), y2 = (int)roundf(roi[4] * p.scale);
+  const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+  const float bin_h = (float)rh / 7.f, bin_w = (float)rw / 7.f;
+  const int ry0 = min(max(y1, 0), p.H), ry1 = min(max(y1 + rh, 0), p.H);
+  const int rx0 = min(max(x1, 0), p.W), rx1 = min(max(x1 + rw, 0), p.W);
+  const int rww = rx1 - rx0, npx = (ry1 - ry0) * rww;  // npx <= lds_px <= 256 guaranteed by the launcher
+  if (threadIdx.x < PP) {
+    const int ph = threadIdx.x / 7, pw = threadIdx.x - ph * 7;
+    int hs = (int)floorf((float)ph * bin_h), he = (int)ceilf((float)(ph + 1) * bin_h);
+    int ws = (int)floorf((float)pw * bin_w), we = (int)ceilf((float)(pw + 1) * bin_w);
+    bins[threadIdx.x][0] = min(max(hs + y1, 0), p.H); bins[threadIdx.x][1] = min(max(he + y1, 0), p.H);
+    bins[threadIdx.x][2] = min(max(ws + x1, 0), p.W); bins[threadIdx.x][3] = min(max(we + x1, 0), p.W);
+  }
+  if (threadIdx.x < npx) {
+    const int hh = threadIdx.x / rww;
+    pxoff[threadIdx.x] = (ry0 + hh) * p.W + rx0 + (threadIdx.x - hh * rww);
+  }
+  __syncthreads();
+  for (int ch = 0; ch < CHUNKS; ++ch) {
+    const int c0 = (blockIdx.y * CHUNKS + ch) * RP_CH;
+    if (c0 >= p.C) break;
+    for (int i = threadIdx.x; i < npx * VPL; i += 256) {
+      const int px = i / VPL, v = i - px * VPL;
+      *(i32x4_t*)(stage + (long)px * (RP_CH * ESI) + v * 16) =
+          *(const i32x4_t*)((const char*)(fb + (long)pxoff[px] * p.C + c0) + v * 16);
+    }
+    __syncthreads();
+    const TI* st = (const TI*)stage;
+    for (int bin = bg; bin < PP; bin += 4) {
+      const int hs = bins[bin][0], he = bins[bin][1], ws = bins[bin][2], we = bins[bin][3];
+      float best = (he <= hs || we <= ws) ? 0.f : -FLT_MAX;
+      for (int h = hs; h < he; ++h)
+        for (int w = ws; w < we; ++w) best = fmaxf(best, EI::ld(st + ((h - ry0) * rww + (w - rx0)) * RP_CH + cl));
+      tile[cl][bin] = best * mul;
+    }
+    __syncthreads();
+    char* orow = (char*)((TO*)p.out + (long)m * p.ld_out + (long)c0 * PP);
+    for (int v = threadIdx.x; v < RP_CH * PP / VE; v += 256) {
+      float f[VE];
+#pragma unroll
+      for (int e = 0; e < VE; ++e) {
+        const int i = v * VE + e, lc = i / PP;
+        f[e] = tile[lc][i - lc * PP];
+      }
+      i32x4_t o;
+      if constexpr (DT_OUT == DRN_BF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (int)((uint32_t)f32_to_bf16(f[2 * e]) | ((uint32_t)f32_to_bf16(f[2 * e + 1]) << 16));
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = __builtin_bit_cast(int, f[e]);
+      }
+      *(i32x4_t*)(orow + (long)v * 16) = o;
+    }
+    __syncthreads();
+  }
+}
+
 // bf16 -> bf16 transpose with 16-B global accesses on both sides (the A -> A^T copy of the fc6 operand is
 // 2 x 205 MB per step): 64x64 tile, rows read as 8-element vectors, written transposed into LDS, re-read as vectors.
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
@@ -372,6 +454,17 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
     if ((size_t)px * RP_CH * es > 32 * 1024) px = 32 * 1024 / (RP_CH * es);
     p.lds_px = px;
     smem = (size_t)px * RP_CH * es;
+  }
+  // fast path: 7x7 ROIPool, no argmax wanted, whole map fits the staging tile, channels in full 64-wide chunks,
+  // 16-B aligned output rows
+  const int eso = drn_esize(out_dtype);
+  if (mode == 0 && P == 7 && !argmax && C % RP_CH == 0 && H * W <= p.lds_px && p.lds_px > 0 && H * W <= 256 &&
+      ((ld_out * eso) % 16) == 0 && (((uintptr_t)out) & 15) == 0 && (in_dtype == out_dtype)) {
+    dim3 g7(M, (C / RP_CH + 3) / 4);
+    if (in_dtype == DRN_BF16) hipLaunchKernelGGL((roi_pool7_kernel<DRN_BF16, DRN_BF16>), g7, block, smem, st, p);
+    else hipLaunchKernelGGL((roi_pool7_kernel<DRN_F32, DRN_F32>), g7, block, smem, st, p);
+    DRN_CHECK_LAUNCH();
+    return DRN_OK;
   }
 #define RP_LAUNCH(DI, DO, MD) hipLaunchKernelGGL((roi_kernel<DI, DO, MD>), grid, block, smem, st, p)
   if (in_dtype == DRN_BF16 && out_dtype == DRN_BF16) { if (mode == 0) RP_LAUNCH(DRN_BF16, DRN_BF16, 0); else RP_LAUNCH(DRN_BF16, DRN_BF16, 1); }

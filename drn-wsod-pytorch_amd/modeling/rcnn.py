@@ -88,13 +88,16 @@ class GeneralizedRCNNWSL(nn.Module):
             features = self.backbone(images.tensor)
             ev = torch.cuda.Event()
             ev.record(self._side)
-        self._prefetched = (id(batched_inputs), images, features, ev)
+        if not hasattr(self, "_prefetch_cache"):
+            self._prefetch_cache = {}
+        if len(self._prefetch_cache) >= 2:
+            self._prefetch_cache.pop(next(iter(self._prefetch_cache)))
+        self._prefetch_cache[id(batched_inputs)] = (images, features, ev)
 
     def _features(self, batched_inputs):
-        pre = getattr(self, "_prefetched", None)
-        if pre is not None and pre[0] == id(batched_inputs):
-            self._prefetched = None
-            _, images, features, ev = pre
+        pre = getattr(self, "_prefetch_cache", {}).pop(id(batched_inputs), None)
+        if pre is not None:
+            images, features, ev = pre
             main = torch.cuda.current_stream()
             main.wait_event(ev)
             for t in list(features.values()) + [images.nhwc]:

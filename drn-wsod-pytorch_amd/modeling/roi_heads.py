@@ -460,7 +460,8 @@ class _HeadEngine:
         # ---- losses (fused with their dlogits) ----
         dl = w["dlogits"]
         scores, img_scores, loss_part = ops.wsddn_fwd_bwd(w["logits"], col["cls"], col["det"], K, img_off, n_img,
-                                                         gt["onehot"], dlogits=dl, mean_loss=h.box_predictor.mean_loss)
+                                                         gt["onehot"], dlogits=dl, mean_loss=h.box_predictor.mean_loss,
+                                                         max_rows=gt["max_rows"])
         for m in [h.box_predictor] + list(h.box_refinery[: h.refine_K]):
             assert m.loss_weight.get("loss_cls", 1.0) == 1.0, "loss_cls weight != 1 is not used by any config"
         loss_names = ["loss_cls"]
@@ -680,7 +681,7 @@ class OICRROIHeads(ROIHeads):
             off = torch.tensor([0] + list(torch.tensor(nper).cumsum(0).tolist()), dtype=torch.int32)
             gt = dict(onehot=oh.to(dev, non_blocking=True), classes=gcl.to(dev, non_blocking=True),
                       count=torch.tensor([len(g) for g in ints], dtype=torch.int32).to(dev, non_blocking=True),
-                      props=rois[:, 1:].contiguous())
+                      props=rois[:, 1:].contiguous(), max_rows=max(nper))
             losses, state = self._engine.forward(nhwc, rois, obj, True, off.to(dev, non_blocking=True), n_img, gt)
             self.pred_class_img_logits = state["aux"]["img_scores"]
             self._last_state = state

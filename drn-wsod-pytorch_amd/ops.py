@@ -134,16 +134,20 @@ def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=Non
            int(accumulate_colsum), M, N, C.dt(ref.dtype), C.stream())
 
 
-def wsddn_fwd_bwd(logits, c_cls, c_det, K, img_off, n_img, gt_onehot, dlogits=None, mean_loss=True, loss_scale=1.0):
+def wsddn_fwd_bwd(logits, c_cls, c_det, K, img_off, n_img, gt_onehot, dlogits=None, mean_loss=True, loss_scale=1.0,
+                  max_rows=None):
     M = logits.shape[0]
+    max_rows = max_rows or M
     dev = logits.device
     scores = torch.empty((M, K), dtype=torch.float32, device=dev)
     img_scores = torch.empty((n_img, K), dtype=torch.float32, device=dev)
     loss_part = torch.empty((n_img,), dtype=torch.float32, device=dev)
     rowsm = torch.empty((M, K), dtype=torch.float32, device=dev)
+    scratch = torch.empty((n_img * ((max_rows + 127) // 128) * 384,), dtype=torch.float32, device=dev)
     C.call("drn_wsddn_fwd_bwd", C.ptr(logits), _2d(logits), c_cls, c_det, K, C.ptr(img_off), n_img, C.ptr(gt_onehot),
            C.ptr(scores), C.ptr(rowsm), C.ptr(img_scores), C.ptr(loss_part), C.ptr(dlogits),
-           _2d(dlogits) if dlogits is not None else 0, int(mean_loss), float(loss_scale), C.stream())
+           _2d(dlogits) if dlogits is not None else 0, C.ptr(scratch), int(max_rows), int(mean_loss), float(loss_scale),
+           C.stream())
     return scores, img_scores, loss_part
 
 

@@ -197,6 +197,8 @@ def test_roi_pool(drn, dtype, C, P, scale, H, W):
     assert torch.equal(out[:, :k].float().cpu(), ref)  # bit-exact: max + one fp32 multiply + rounding
     assert (out[:, k:] == 0).all()
     assert torch.equal(arg.cpu(), rarg.reshape(80, -1))
+    out2 = drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale)  # no argmax: 7x7 fast path when it applies
+    assert torch.equal(out2, out)
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
@@ -281,7 +283,8 @@ def test_wsddn_fwd_bwd(drn, K, M_per):
     loss = O.wsddn_loss(sc, M_per, oh, True)
     loss.backward()
     dl = torch.zeros((sum(M_per), ld), device=DEV)
-    scores, img_scores, lp = drn.wsddn_fwd_bwd(logits.to(DEV), 0, K, K, off.to(DEV), n_img, oh.to(DEV), dlogits=dl)
+    scores, img_scores, lp = drn.wsddn_fwd_bwd(logits.to(DEV), 0, K, K, off.to(DEV), n_img, oh.to(DEV), dlogits=dl,
+                                               max_rows=max(M_per))
     assert torch.allclose(scores.cpu(), sc.detach(), rtol=1e-5, atol=1e-9)
     assert torch.allclose(img_scores.cpu(), O.predict_probs_img(sc.detach(), M_per), rtol=1e-5)
     assert abs(float(lp.sum()) - float(loss.detach())) <= 1e-5 * abs(float(loss.detach()))
