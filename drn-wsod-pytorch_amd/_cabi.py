@@ -21,7 +21,8 @@ _SIGS = {
     "drn_roi_pool_nhwc": "ppppp" + "iiiiii" + "f" + "l" + "iiiiip",
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliilip",
-    "drn_bias_act_fwd": "pilppQfplpliiliip",
+    "drn_bias_act_fwd": "pilppQpfplpliiliip",
+    "drn_counter_add": "pQp",
     "drn_bias_act_bwd": "plpppfplplppiiiip",
     "drn_cast2d": "ppiilliip",
     "drn_wsddn_fwd_bwd": "pliiipippppppl" + "pi" + "ifp",

@@ -32,6 +32,7 @@ struct ActParams {
   const float* bias;   // fwd: [N] or null
   const float* mask;   // explicit dropout multipliers [M][N] or null
   unsigned long long seed; float drop_p;  // used when mask == null and drop_p > 0
+  const unsigned long long* seed_dev;     // optional device counter added to `seed` (hipGraph-safe)
   const char* saved;   // bwd: forward output [M][ld_out] (post relu+dropout) or null (no activation)
   char* out; long ld_out;     // [M][ld_out] in out_dtype
   char* outT; long ld_outT;   // [N][ld_outT] in out_dtype or null
@@ -60,6 +61,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
   const int mb1 = min(mb0 + ROWS, p.M);
   float csum = 0.f;
   const float cscale = (BWD && p.colscale && n < p.N) ? p.colscale[n] : 1.f;
+  const unsigned long long seed = p.seed + ((!BWD && p.seed_dev) ? p.seed_dev[0] : 0ULL);
   for (int mb = mb0; mb < mb1; mb += 64) {
 #pragma unroll 4
     for (int i = ty; i < 64; i += 4) {
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
           if (p.bias) v += p.bias[n];
           if (p.relu) v = fmaxf(v, 0.f);
           if (p.mask) v *= p.mask[(long)m * p.N + n];
-          else if (p.drop_p > 0.f) v *= drop_mult(p.seed, (uint64_t)m * p.N + n, p.drop_p);
+          else if (p.drop_p > 0.f) v *= drop_mult(seed, (uint64_t)m * p.N + n, p.drop_p);
         } else {
           v = p.in[(long)m * p.ld_in + n] * cscale;
           if (p.saved) {
@@ -551,11 +553,11 @@ __global__ void sum_small_kernel(const float* in, int n, float scale, float* out
 extern "C" {
 
 int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const float* bias, const float* mask,
-                     unsigned long long seed, float drop_p, void* out, long ld_out, void* outT, long ld_outT, int M,
-                     int N, long ld_in, int relu, int out_dtype, void* stream) {
+                     unsigned long long seed, const unsigned long long* seed_dev, float drop_p, void* out, long ld_out,
+                     void* outT, long ld_outT, int M, int N, long ld_in, int relu, int out_dtype, void* stream) {
   if (!partials || M < 0 || N < 0 || splits < 1 || (!out && !outT)) return DRN_ERR_ARG;
   if (M == 0 || N == 0) return DRN_OK;
-  ActParams p{partials, splits, split_stride, bias, mask, seed, drop_p, nullptr, (char*)out, ld_out, (char*)outT,
+  ActParams p{partials, splits, split_stride, bias, mask, seed, drop_p, seed_dev, nullptr, (char*)out, ld_out, (char*)outT,
               ld_outT, nullptr, nullptr, nullptr, M, N, ld_in, relu, 0};
   dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
   hipStream_t st = (hipStream_t)stream;
@@ -573,7 +575,7 @@ int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, c
   if (!grad_out || M < 0 || N < 0) return DRN_ERR_ARG;
   if (colsum && !colpart) return DRN_ERR_ARG;  // colpart: ceil(M/256)*N floats of scratch
   if (M == 0 || N == 0) return DRN_OK;
-  ActParams p{grad_out, 1, 0, nullptr, mask, 0ULL, drop_p, (const char*)saved_out, (char*)dpre, ld_out, (char*)dpreT,
+  ActParams p{grad_out, 1, 0, nullptr, mask, 0ULL, drop_p, nullptr, (const char*)saved_out, (char*)dpre, ld_out, (char*)dpreT,
               ld_outT, colsum, colscale, colpart, M, N, ld_in, 1, accumulate_colsum};
   const int nparts = (M + ACT_ROWS - 1) / ACT_ROWS;
   dim3 grid((N + 63) / 64, nparts), block(256);
@@ -687,6 +689,21 @@ int drn_sgd_step(float* weights, float* momentum_buf, const float* grads, void* 
   else
     hipLaunchKernelGGL(sgd_kernel<false>, grid, block, 0, st, weights, momentum_buf, grads, (bf16_t*)nullptr,
                        (const SgdSeg*)segs_dev, nseg, momentum, first_step, grad_scale);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+__global__ void counter_add_kernel(unsigned long long* c, unsigned long long inc) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) c[0] += inc;
+}
+
+}  // extern "C"  (kernel above needs C++ linkage)
+extern "C" {
+
+// device-side counter (dropout seed) advanced inside the stream / graph: no host involvement per step
+int drn_counter_add(unsigned long long* counter, unsigned long long inc, void* stream) {
+  if (!counter) return DRN_ERR_ARG;
+  hipLaunchKernelGGL(counter_add_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, counter, inc);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

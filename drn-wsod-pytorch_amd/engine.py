@@ -56,7 +56,11 @@ class FusedSGD:
             arr = np.zeros(len(groups), dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
             for i, g in enumerate(groups):
                 arr[i] = (g["off"], g["cnt"], g["lr"], g["weight_decay"])
-            self._segs_dev = torch.from_numpy(arr.view(np.uint8).copy()).to(self.engine.arena_w.device)
+            host = torch.from_numpy(arr.view(np.uint8).copy())
+            if self._segs_dev is None:
+                self._segs_dev = host.to(self.engine.arena_w.device)
+            else:
+                self._segs_dev.copy_(host)  # in place: a captured hipGraph keeps reading this table
             self._segs_key, self._nseg = key, len(groups)
         return self._segs_dev, self._nseg
 
@@ -238,3 +242,120 @@ class Trainer:
             tot = float(sum(v.detach() for v in self.last_losses.values()))
             if not math.isfinite(tot):
                 raise FloatingPointError("Loss became infinite or NaN at iteration={}!".format(self.iter))
+
+
+class GraphedTrainStep:
+    """One full training step (preprocess + backbone of the NEXT image on a side stream, ROI heads forward, losses,
+    backward, fused SGD) captured once into a hipGraph and replayed: a step is ~130 kernel launches of 2-600 us, so
+    the eager Python host needs ~2.4 ms to enqueue what the GPU executes in ~2.6 ms; replay costs ~15 us.
+
+    Static shapes only (fixed image size, proposals per image and images per GPU — the benchmark's case and the
+    common fixed-R training case); anything else runs the eager path.  Single process: with N > 1 the gradient
+    exchange stays eager (DataParallel), so this class is used when world == 1.
+
+    Pipeline skew: the graph reads `image` = the NEXT batch's image (its backbone runs on the side stream and lands
+    in `feat_next`) while the heads consume `feat_cur` with the CURRENT batch's proposals/labels; the last node copies
+    feat_next -> feat_cur.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5)."""
+
+    def __init__(self, model, optimizer, example_batch):
+        from .structures import Boxes  # noqa: F401
+
+        assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
+        self.model, self.opt = model, optimizer
+        self.heads = model.roi_heads
+        self.engine = self.heads._engine
+        dev = model.device
+        K = self.heads.num_classes
+        self.nper = [len(x["proposals"]) for x in example_batch]
+        n_img, M = len(example_batch), sum(self.nper)
+        self.n_img, self.K = n_img, K
+        self.image = [x["image"].to(dev).float().clone() for x in example_batch]
+        self.rois = torch.zeros((M, 5), dtype=torch.float32, device=dev)
+        self.obj = torch.zeros((M,), dtype=torch.float32, device=dev)
+        off = [0]
+        for n in self.nper:
+            off.append(off[-1] + n)
+        self.gt = dict(onehot=torch.zeros((n_img, K), device=dev), classes=torch.zeros((n_img, K), dtype=torch.int32, device=dev),
+                       count=torch.zeros((n_img,), dtype=torch.int32, device=dev), props=None, max_rows=max(self.nper))
+        self.img_off = torch.tensor(off, dtype=torch.int32, device=dev)
+        for i in range(n_img):
+            self.rois[off[i]: off[i + 1], 0] = float(i)
+        self.graph = None
+        self.losses = None
+        self._side = torch.cuda.Stream()
+        self._primed = False
+
+    # ---- host side of one step: stage inputs into the static buffers (tiny async copies) -----------------------
+    def _stage_heads_inputs(self, batch):
+        off = 0
+        ints = []
+        for i, x in enumerate(batch):
+            n = self.nper[i]
+            assert len(x["proposals"]) == n, "graphed step: proposals per image must stay fixed"
+            self.rois[off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
+            self.obj[off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
+            ints.append(torch.unique(x["instances"].gt_classes.cpu(), sorted=True))
+            off += n
+        oh = torch.zeros((self.n_img, self.K))
+        cl = torch.zeros((self.n_img, self.K), dtype=torch.int32)
+        for i, g in enumerate(ints):
+            oh[i, g] = 1
+            cl[i, : len(g)] = g.to(torch.int32)
+        self.gt["onehot"].copy_(oh, non_blocking=True)
+        self.gt["classes"].copy_(cl, non_blocking=True)
+        self.gt["count"].copy_(torch.tensor([len(g) for g in ints], dtype=torch.int32), non_blocking=True)
+
+    def _stage_image(self, batch):
+        for buf, x in zip(self.image, batch):
+            buf.copy_(x["image"], non_blocking=True)
+
+    def _backbone(self):
+        m = self.model
+        dtype_feat = None
+        imgs = m.preprocess_image([{"image": im} for im in self.image])
+        feats = m.backbone(imgs.tensor)
+        f = feats[self.heads.box_in_features[0]].permute(0, 2, 3, 1)
+        assert f.is_contiguous()
+        return f
+
+    def _body(self):
+        """the step as it is captured"""
+        cur = torch.cuda.current_stream()
+        self._side.wait_stream(cur)
+        with torch.cuda.stream(self._side), torch.no_grad():
+            self.feat_next.copy_(self._backbone())
+        self.gt["props"] = self.rois[:, 1:].contiguous()
+        losses, _ = self.engine.forward(self.feat_cur, self.rois, self.obj, True, self.img_off, self.n_img, self.gt)
+        sum(losses.values()).backward()
+        self.opt.step(1.0)
+        cur.wait_stream(self._side)
+        self.feat_cur.copy_(self.feat_next)
+        return losses
+
+    def prime(self, first_batch):
+        """eager warm-up: computes the first batch's features, runs one eager step (so the captured SGD is not the
+        momentum-initialising first step and every workspace exists), then captures."""
+        self._stage_image(first_batch)
+        with torch.no_grad():
+            f = self._backbone()
+        self.feat_cur = f.clone()
+        self.feat_next = torch.empty_like(f)
+        self._stage_heads_inputs(first_batch)
+        self.opt.zero_grad()
+        self.heads.train()
+        self._body()           # eager step 0 (image buffer still holds batch 0: feat_next == feat_cur afterwards)
+        self.opt.zero_grad()
+        torch.cuda.synchronize()
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.losses = self._body()
+        self._primed = True
+
+    def step(self, batch, next_batch):
+        """run the step for `batch`; `next_batch`'s image is fed to the side-stream backbone of the same replay"""
+        if not self._primed:
+            self.prime(batch)
+        self._stage_heads_inputs(batch)
+        self._stage_image(next_batch)
+        self.graph.replay()
+        return self.losses

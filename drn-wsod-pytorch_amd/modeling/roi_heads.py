@@ -419,10 +419,10 @@ class _HeadEngine:
         nslab = K * ops.esize(dtype) // 128
         return max(1, min(1024 // max(tiles, 1), max(1, nslab // 8), 16))
 
-    def _linear_fwd(self, A, Wt, M, N, K, bias, relu, out, outT, mask, seed, drop_p):
+    def _linear_fwd(self, A, Wt, M, N, K, bias, relu, out, outT, mask, seed, drop_p, seed_dev=None):
         s = self._splits(M, N, K, A.dtype)
         part = ops.gemm_nt(A, Wt, M, N, K, splits=s)
-        ops.bias_act_fwd(part, M, N, bias, relu, mask, seed, drop_p, out=out, outT=outT)
+        ops.bias_act_fwd(part, M, N, bias, relu, mask, seed, drop_p, out=out, outT=outT, seed_dev=seed_dev)
 
     # ---- forward -------------------------------------------------------------------------------------
     def forward(self, feat_nhwc, rois, objectness, training, img_off=None, n_img=1, gt=None):
@@ -442,16 +442,21 @@ class _HeadEngine:
         ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=w["A"], **h.box_pooler.kernel_args())
         drop_p = h.box_head.dropout_p if training else 0.0
         masks = h.box_head.dropout_masks if training else None
-        seed = 0
+        seed, seed_dev = 0, None
         if training and masks is None and drop_p > 0:
-            self._drop_iter += 1
-            seed = (torch.initial_seed() + 7919 * self._drop_iter) & 0xFFFFFFFFFFFF
+            # counter-based masks keyed by (torch seed, device-side step counter, layer): the counter lives on the
+            # device and is advanced on the stream, so a replayed hipGraph draws fresh masks every step
+            if getattr(self, "seed_dev", None) is None or self.seed_dev.device != dev:
+                self.seed_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
+            seed, seed_dev = torch.initial_seed() & 0xFFFFFFFFFFFF, self.seed_dev
         if training:
             ops.transpose2d(w["A"], M, K1, out=w["AT"])
         self._linear_fwd(w["A"], sh["W1v"], M, D1, kp(K1), fc1.bias.data, True, w["H1"], w["H1T"] if training else None,
-                         masks[0] if masks else None, seed, drop_p)
+                         masks[0] if masks else None, seed, drop_p, seed_dev)
         self._linear_fwd(w["H1"], sh["W2"], M, D2, kp(D1), fc2.bias.data, True, w["H2"], w["H2T"] if training else None,
-                         masks[1] if masks else None, seed + 1, drop_p)
+                         masks[1] if masks else None, seed + 0x9E3779B1, drop_p, seed_dev)
+        if seed_dev is not None:
+            ops.counter_add(seed_dev, 2654435761)
         bo, _ = self._seg[self.cols[0][0] + ".bias"]
         self._linear_fwd(w["H2"], sh["Wh"], M, NH, kp(D2), self.arena_w[bo: bo + NH], False, w["logits"], None, None, 0, 0.0)
         col = {n: c for n, _, c, _ in self.cols}

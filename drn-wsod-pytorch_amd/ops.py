@@ -112,11 +112,16 @@ def cast2d(inp, rows, cols, out):
     return out
 
 
-def bias_act_fwd(partials, M, N, bias=None, relu=True, mask=None, seed=0, drop_p=0.0, out=None, outT=None):
+def counter_add(counter, inc=1):
+    C.call("drn_counter_add", C.ptr(counter), int(inc), C.stream())
+
+
+def bias_act_fwd(partials, M, N, bias=None, relu=True, mask=None, seed=0, drop_p=0.0, out=None, outT=None, seed_dev=None):
     splits = partials.shape[0] if partials.dim() == 3 else 1
     sstride = partials.stride(0) if partials.dim() == 3 else 0
     ref = out if out is not None else outT
-    C.call("drn_bias_act_fwd", C.ptr(partials), splits, sstride, C.ptr(bias), C.ptr(mask), int(seed), float(drop_p),
+    C.call("drn_bias_act_fwd", C.ptr(partials), splits, sstride, C.ptr(bias), C.ptr(mask), int(seed), C.ptr(seed_dev),
+           float(drop_p),
            C.ptr(out), _2d(out) if out is not None else 0, C.ptr(outT), _2d(outT) if outT is not None else 0, M, N,
            partials.stride(-2), int(relu), C.dt(ref.dtype), C.stream())
 

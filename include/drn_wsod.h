@@ -77,11 +77,14 @@ int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, lon
                 int splits, long c_split_stride, int accumulate, void* stream);
 
 /* relu_(fc(x)) + F.dropout(p), box_head.py:88-90: sums split-K partials, adds bias, ReLU, dropout
- * (explicit multiplier mask [M][N] if given, else counter-based mask from seed when drop_p > 0);
+ * (explicit multiplier mask [M][N] if given, else counter-based mask from seed (+ *seed_dev) when drop_p > 0);
  * writes out [M][ld_out] and/or its transpose outT [N][ld_outT]. */
 int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const float* bias, const float* mask,
-                     unsigned long long seed, float drop_p, void* out, long ld_out, void* outT, long ld_outT, int M,
-                     int N, long ld_in, int relu, int out_dtype, void* stream);
+                     unsigned long long seed, const unsigned long long* seed_dev, float drop_p, void* out, long ld_out,
+                     void* outT, long ld_outT, int M, int N, long ld_in, int relu, int out_dtype, void* stream);
+
+/* *counter += inc on the stream (the dropout seed lives on the device so a replayed hipGraph draws fresh masks). */
+int drn_counter_add(unsigned long long* counter, unsigned long long inc, void* stream);
 
 /* autograd of the above: dpre = grad_out * dropout_mult * (saved_out > 0); colsum[n] = sum_m dpre (bias
  * gradient, fixed summation order); saved_out == NULL means "no activation"; colscale [N] (optional)

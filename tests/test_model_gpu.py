@@ -181,3 +181,44 @@ def test_grad_accumulation_iter_size():
     (sum(model(batch).values()) * 0.5).backward()
     assert torch.allclose(model.roi_heads.box_head.fc1.weight.grad, 1.5 * g1, rtol=1e-4, atol=1e-7)
     assert torch.allclose(model.roi_heads.box_refinery_0.cls_score.bias.grad, 1.5 * b1, rtol=1e-4, atol=1e-7)
+
+
+def test_hipgraph_step_equals_eager():
+    """GraphedTrainStep (whole step captured into a hipGraph, next image's backbone forked onto a side stream) must
+    reproduce the eager trainer step for step: same losses over 4 steps on alternating batches."""
+    from drn_wsod_pytorch_amd.engine import GraphedTrainStep, build_optimizer
+
+    name = "model_r50c4_tiny"
+    d = G.load(name)
+    ocfg = G.MODEL_CASES[name]
+    base = G.batch_from(d)
+    # two different batches with identical shapes (graphs need static shapes): swap / perturb the fixture's images
+    b0 = G.drn_inputs([base[0]])
+    alt = dict(base[0])
+    alt["image"] = (255.0 - base[0]["image"]).contiguous()
+    alt["objectness_logits"] = base[0]["objectness_logits"].flip(0).contiguous()
+    b1 = G.drn_inputs([alt])
+    seq = [b0, b1, b0, b1, b0]
+    results = []
+    for graphed in (False, True):
+        cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, "fp32")
+        model.roi_heads.box_head.dropout_p = 0.0
+        model.train()
+        opt = build_optimizer(cfg, model)
+        out = []
+        if graphed:
+            stepper = GraphedTrainStep(model, opt, seq[0])
+            for i in range(4):
+                losses = stepper.step(seq[i], seq[i + 1])
+                out.append({k: float(v.detach()) for k, v in losses.items()})
+        else:
+            for i in range(4):
+                opt.zero_grad()
+                losses = model(seq[i])
+                sum(losses.values()).backward()
+                opt.step()
+                out.append({k: float(v.detach()) for k, v in losses.items()})
+        results.append(out)
+    for e, g in zip(*results):
+        for k in e:
+            assert abs(e[k] - g[k]) <= 1e-5 * max(abs(e[k]), 1e-3), (k, e[k], g[k])
