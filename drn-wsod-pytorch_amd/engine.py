@@ -332,29 +332,31 @@ class GraphedTrainStep:
         self.feat_cur.copy_(self.feat_next)
         return losses
 
-    def prime(self, first_batch):
-        """eager warm-up: computes the first batch's features, runs one eager step (so the captured SGD is not the
-        momentum-initialising first step and every workspace exists), then captures."""
+    def prime(self, first_batch, next_batch):
+        """Step 0, eagerly (so every workspace exists and the captured SGD is not the momentum-initialising first
+        step), then the capture.  Returns step 0's losses."""
         self._stage_image(first_batch)
         with torch.no_grad():
             f = self._backbone()
         self.feat_cur = f.clone()
         self.feat_next = torch.empty_like(f)
+        self._stage_image(next_batch)
         self._stage_heads_inputs(first_batch)
         self.opt.zero_grad()
         self.heads.train()
-        self._body()           # eager step 0 (image buffer still holds batch 0: feat_next == feat_cur afterwards)
+        first = {k: v.detach().clone() for k, v in self._body().items()}
         self.opt.zero_grad()
         torch.cuda.synchronize()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.losses = self._body()
         self._primed = True
+        return first
 
     def step(self, batch, next_batch):
         """run the step for `batch`; `next_batch`'s image is fed to the side-stream backbone of the same replay"""
         if not self._primed:
-            self.prime(batch)
+            return self.prime(batch, next_batch)
         self._stage_heads_inputs(batch)
         self._stage_image(next_batch)
         self.graph.replay()
