@@ -211,6 +211,114 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// 256x256 tile, 8 waves (2 x 4, 128x64 per wave = 4x2 MFMA 32x32 tiles), LDS-DMA staging.
+//   * global -> LDS by `buffer_load_dwordx4 ... lds` (no staging VGPRs, hardware bounds check keeps the free zero
+//     fill of ragged edges).  An LDS-DMA wave-instruction writes base + lane*16, i.e. 8 rows x 128 B, so the LDS
+//     image is row-major and the XOR swizzle is applied to the per-lane SOURCE k-slot (same involution on the
+//     ds_read side): the 8 lanes of a row still read one whole 128-B line.
+//   * 2 LDS stages of 64 KB; the next slab's 8 loads per thread are issued before the current slab is consumed and
+//     stay in flight across the barrier: counted `s_waitcnt vmcnt(8)` + raw s_barrier (a __syncthreads() would
+//     drain them).
+//   * operands are swapped in the MFMA (D^T = B.A^T) so a lane holds 4 consecutive output columns per register
+//     quad: the epilogue issues 16-B stores (4x fewer store instructions; the fc6 dW output is 411 MB).
+template <int DT>
+__global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = DT == DRN_BF16 ? 2 : 4;
+  constexpr int BM = 256, BN = 256, MI = 4, NJ = 2;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+  const int bm = tm * BM, bn = tn * BN;
+  const int split = blockIdx.y;
+  const int nslab = p.K * ES / 128;
+  const int s0 = split * p.k_slabs_per_split;
+  const int s1 = s0 + p.k_slabs_per_split < nslab ? s0 + p.k_slabs_per_split : nslab;
+  const RowLoader la = make_row_loader(p.A, bm, p.M, BM, p.lda * ES);
+  const RowLoader lb = make_row_loader(p.B, bn, p.N, BN, p.ldb * ES);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  // per-thread source offsets of its 4 A-chunks and 4 B-chunks (row = i*64 + tid/8, k-slot pre-swizzled)
+  unsigned voa[4], vob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned row = i * 64 + (tid >> 3), ks = (tid & 7) ^ ((row >> 1) & 7);
+    voa[i] = row * la.ld_bytes + ks * 16;
+    vob[i] = row * lb.ld_bytes + ks * 16;
+  }
+  auto issue = [&](char* stage, int slab) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      char* dst = stage + (i * 64 + wave * 8) * 128;  // wave-uniform LDS base of this 1-KB piece
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(la.rsrc, (__attribute__((address_space(3))) void*)dst, 16, voa[i], slab * 128, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(lb.rsrc, (__attribute__((address_space(3))) void*)(dst + A_BYTES), 16, vob[i], slab * 128, 0, 0);
+    }
+  };
+  f32x16_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  if (s0 < s1) {
+    issue(smem, s0);
+    for (int s = s0; s < s1; ++s) {
+      char* cur = smem + ((s - s0) & 1) * STAGE;
+      char* nxt = smem + (((s - s0) & 1) ^ 1) * STAGE;
+      if (s + 1 < s1) {
+        issue(nxt, s + 1);
+        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+      } else {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        i32x4_t fa[MI], fb[NJ];
+        const int slot = ks * 2 + (lane >> 5);
+#pragma unroll
+        for (int i = 0; i < MI; ++i) fa[i] = *(const i32x4_t*)(cur + swz(wm * 128 + i * 32 + (lane & 31), slot));
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) fb[j] = *(const i32x4_t*)(cur + A_BYTES + swz(wn * 64 + j * 32 + (lane & 31), slot));
+#pragma unroll
+        for (int i = 0; i < MI; ++i)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[i][j], fb[j], fa[i]);  // swapped: D^T[n][m]
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
+  }
+  // D^T layout: lane -> m (A row) = lane&31, register r -> n = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  float* C = p.C + (long)split * p.c_split_stride;
+  const bool vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0;
+#pragma unroll
+  for (int i = 0; i < MI; ++i) {
+    const int m = bm + wm * 128 + i * 32 + (lane & 31);
+    if (m >= p.M) continue;
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = bn + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+        float* dst = C + (long)m * p.ldc + n;
+        f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+        if (vec_ok && n + 4 <= p.N) {
+          if (p.accumulate) { const f32x4_t o = *(const f32x4_t*)dst; v += o; }
+          *(f32x4_t*)dst = v;
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (n + e < p.N) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
+        }
+      }
+  }
+}
+
 template <int DT, int BM, int BN>
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -288,6 +396,22 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
+template <int DT>
+int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
+  const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
+  constexpr int smem = 2 * 512 * 128;
+  auto k = gemm_nt256_kernel<DT>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DRN_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(512), smem, st, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
 template <int DT, int BM, int BN>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
@@ -307,7 +431,16 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
+static int g_force_tile = 0;  // 0 = heuristic; 64 / 128 / 256 pin the tile (tuning + tests)
+
 extern "C" {
+
+// tuning/test hook: pin the GEMM tile (0 restores the heuristic). Returns the previous value.
+int drn_gemm_set_tile(int tile) {
+  const int old = g_force_tile;
+  if (tile == 0 || tile == 64 || tile == 128 || tile == 256) g_force_tile = tile;
+  return old;
+}
 
 // C[split][M,N] (fp32) = A[M,K] * B[N,K]^T over this split's K range.  See include/drn_wsod.h.
 int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
@@ -324,7 +457,13 @@ int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, lon
   GemmParams p{(const char*)A, (const char*)B, C, M, N, K, lda, ldb, ldc, (nslab + splits - 1) / splits,
                c_split_stride, accumulate};
   hipStream_t st = (hipStream_t)stream;
-  const bool small = (long)((M + 127) / 128) * ((N + 127) / 128) * splits < 128;
+  // 256x256 LDS-DMA kernel when it can put >= ~3/4 of the 256 CUs to work (1 workgroup of 128 KB LDS per CU);
+  // otherwise the 128x128 / 64x64 register-staged kernels (more, smaller workgroups)
+  const long wg256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
+  const int force = g_force_tile;
+  if ((force == 256 || (force == 0 && wg256 >= 192)) && (((uintptr_t)C) & 3) == 0)
+    return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16>(p, splits, st) : launch_gemm256<DRN_F32>(p, splits, st);
+  const bool small = force == 64 || (force == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) * splits < 128);
   if (dtype == DRN_BF16) return small ? launch_gemm<DRN_BF16, 64, 64>(p, splits, st) : launch_gemm<DRN_BF16, 128, 128>(p, splits, st);
   return small ? launch_gemm<DRN_F32, 64, 64>(p, splits, st) : launch_gemm<DRN_F32, 128, 128>(p, splits, st);
 }

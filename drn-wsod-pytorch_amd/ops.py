@@ -27,6 +27,11 @@ def _2d(t):
     return t.stride(0)
 
 
+def gemm_set_tile(tile):
+    """pin the GEMM tile (64/128/256; 0 = heuristic); returns the previous setting"""
+    return C.lib().drn_gemm_set_tile(int(tile))
+
+
 def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
     """C[s,M,N] (fp32) = A[M,:K] @ B[N,:K]^T.  A, B: 2-D row-major device tensors of the compute dtype
     whose leading dimension may exceed K (zero padded up to kpad)."""

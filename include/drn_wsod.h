@@ -76,6 +76,9 @@ int drn_cast2d(const void* in, void* out, int rows, int cols, long ld_in, long l
 int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
                 int splits, long c_split_stride, int accumulate, void* stream);
 
+/* tuning / test hook: pin the GEMM tile to 64, 128 or 256 (0 = heuristic); returns the previous setting. */
+int drn_gemm_set_tile(int tile);
+
 /* relu_(fc(x)) + F.dropout(p), box_head.py:88-90: sums split-K partials, adds bias, ReLU, dropout
  * (explicit multiplier mask [M][N] if given, else counter-based mask from seed (+ *seed_dev) when drop_p > 0);
  * writes out [M][ld_out] and/or its transpose outT [N][ld_outT]. */

@@ -70,6 +70,35 @@ def test_gemm_nt(drn, dtype, shape):
     assert torch.allclose(Cacc[0].cpu().double(), C0.cpu().double() + ref, rtol=1e-4, atol=1e-3)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("shape", [(300, 517, 256), (256, 256, 64), (2000, 600, 1024), (513, 259, 192)])
+def test_gemm_nt_tile256(drn, dtype, shape):
+    """the 256x256 LDS-DMA kernel, pinned: ragged M/N edges (hardware bounds check), split-K, accumulate"""
+    M, N, K = shape
+    A, B = _rnd((M, K), 4), _rnd((N, K), 5)
+    Ad, Bd = _padded(A, dtype, drn), _padded(B, dtype, drn)
+    Kp = Ad.shape[1]
+    ref = _q(A, dtype).double() @ _q(B, dtype).double().t()
+    mag = _q(A, dtype).abs().double() @ _q(B, dtype).abs().double().t()
+    tol = 4 * 2.0 ** -24 * math.sqrt(K) * mag + 1e-6
+    prev = drn.gemm_set_tile(256)
+    try:
+        for splits in (1, 2):
+            got = drn.gemm_nt(Ad, Bd, M, N, Kp, splits=splits).sum(0).cpu().double()
+            assert ((got - ref).abs() <= tol).all(), float(((got - ref).abs() / (mag + 1e-9)).max())
+        C0 = _rnd((M, N), 6).to(DEV)
+        Cacc = C0.clone().unsqueeze(0)
+        drn.gemm_nt(Ad, Bd, M, N, Kp, out=Cacc, accumulate=True)
+        assert torch.allclose(Cacc[0].cpu().double(), C0.cpu().double() + ref, rtol=1e-4, atol=1e-3)
+        # A = I against an asymmetric B: catches a transposed / mis-mapped C write of the swapped-operand epilogue
+        n = 256
+        Bm = (torch.arange(n * n, dtype=torch.float32).reshape(n, n) % 251)
+        Cd = drn.gemm_nt(torch.eye(n).to(DEV), Bm.to(DEV), n, n, n)
+        assert torch.equal(Cd[0].cpu(), Bm.t().contiguous())
+    finally:
+        drn.gemm_set_tile(prev)
+
+
 def test_gemm_asymmetric_identity(drn):
     """A = I with an ASYMMETRIC B catches a transposed C write (cdna guide rule 16)."""
     n = 128

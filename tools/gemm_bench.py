@@ -33,6 +33,19 @@ def bench(name, M, N, K, dtype, splits, iters=10):
 
 if __name__ == "__main__":
     bf, f32 = torch.bfloat16, torch.float32
+    for tile in (128, 256):
+        ops.gemm_set_tile(tile)
+        print("---- tile", tile)
+        for s in (2, 4, 8):
+            bench("fc6 fwd", 2000, 2048, 50176, bf, s)
+        bench("fc6 dW", 2048, 50176, 2048, bf, 1)
+        bench("fc7 fwd", 2000, 4096, 2048, bf, 2)
+        bench("fc7 dW", 4096, 2048, 2048, bf, 1)
+        bench("square 4096", 4096, 4096, 4096, bf, 1)
+        bench("square 8192", 8192, 8192, 8192, bf, 1)
+        bench("fc6 fwd f32", 2000, 2048, 50176, f32, 4, iters=3)
+    ops.gemm_set_tile(0)
+    print("---- heuristic")
     for s in (1, 2, 4, 8):
         bench("fc6 fwd", 2000, 2048, 50176, bf, s)
     bench("fc6 dW", 2048, 50176, 2048, bf, 1)
