@@ -228,7 +228,8 @@ def main():
             ms = sum(t for t, _ in fwd) / len(fwd)
             achieved = fwd[0][1] / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None, "kernel": "gemm_nt_kernel<bf16,128,128> (fc6 fwd)",
+                    "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "kernel": "gemm_nt256_kernel<bf16> (fc6 fwd: [%d x %d] . [%d x %d]^T, split-K 4)" % (R, K1, D1, K1),
                     "avg_launch_ms": ms, "launches_timed": len(fwd),
                     "timed_in": "eager warm-up steps of this run (HIP events on the launch stream)" if use_graph
                     else "the timed region (HIP events on the launch stream)"}
