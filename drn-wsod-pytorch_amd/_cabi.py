@@ -30,6 +30,7 @@ _SIGS = {
     "drn_oicr_targets": "plpi" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",
     "drn_softmax_ce": "pliipppplppifp",
     "drn_mean_softmax": "plpiipip",
+    "drn_box_reg_loss": "pliippppplppifp",
     "drn_apply_deltas": "plppiipfp",
     "drn_sum_small": "pifpp",
     "drn_sgd_step": "ppppipififp",

@@ -449,6 +449,71 @@ __global__ __launch_bounds__(256) void ce_grad_kernel(CeParams p, const float* p
   }
 }
 
+// OICROutputs.box_reg_loss (fast_rcnn.py:1146-1211): foreground rows only, class-specific columns 4c..4c+3,
+// target = Box2BoxTransform.get_deltas(proposal, matched pseudo-GT box) (box_regression.py:38-71), smooth-L1 with
+// beta = 0 (= L1), summed and divided by the number of proposals.  Two launches like the CE pair: per-block partial
+// sums, then a fixed-order combine + the gradient sign(pred - target)/M in the class columns (zeros elsewhere).
+struct BoxRegParams {
+  const float* logits; long ld; int col0; int K;   // deltas of this head: columns col0 .. col0 + 4K
+  const int* labels; const float* props; const float* gt_boxes;
+  float* dlogits; long ld_d; float* loss; int M; float wx, wy, ww, wh, loss_scale;
+};
+
+__device__ __forceinline__ void box_target(const float* s, const float* t, float wx, float wy, float ww, float wh,
+                                           float (&d)[4]) {
+  const float sw = s[2] - s[0], sh = s[3] - s[1];
+  const float sx = s[0] + 0.5f * sw, sy = s[1] + 0.5f * sh;
+  const float tw = t[2] - t[0], th = t[3] - t[1];
+  const float tx = t[0] + 0.5f * tw, ty = t[1] + 0.5f * th;
+  d[0] = wx * (tx - sx) / sw; d[1] = wy * (ty - sy) / sh;
+  d[2] = ww * logf(tw / sw); d[3] = wh * logf(th / sh);
+}
+
+__global__ __launch_bounds__(256) void boxreg_rows_kernel(BoxRegParams p, float* partial) {
+  __shared__ float sh[256];
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  float l = 0.f;
+  if (r < p.M) {
+    const int lab = p.labels[r];
+    if (lab >= 0 && lab < p.K) {
+      float d[4];
+      box_target(p.props + 4 * (long)r, p.gt_boxes + 4 * (long)r, p.wx, p.wy, p.ww, p.wh, d);
+      const float* pr = p.logits + (long)r * p.ld + p.col0 + 4 * lab;
+      for (int e = 0; e < 4; ++e) l += fabsf(pr[e] - d[e]);
+    }
+  }
+  sh[threadIdx.x] = l;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if (threadIdx.x < o) sh[threadIdx.x] += sh[threadIdx.x + o];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) partial[blockIdx.x] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void boxreg_grad_kernel(BoxRegParams p, const float* partial, int nparts) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    float l = 0.f;
+    for (int q = 0; q < nparts; ++q) l += partial[q];
+    p.loss[0] = l / (float)p.M;
+  }
+  if (!p.dlogits) return;
+  const int r = blockIdx.x * 256 + threadIdx.x;
+  if (r >= p.M) return;
+  float* dr = p.dlogits + (long)r * p.ld_d + p.col0;
+  for (int c = 0; c < 4 * p.K; ++c) dr[c] = 0.f;
+  const int lab = p.labels[r];
+  if (lab >= 0 && lab < p.K) {
+    float d[4];
+    box_target(p.props + 4 * (long)r, p.gt_boxes + 4 * (long)r, p.wx, p.wy, p.ww, p.wh, d);
+    const float* pr = p.logits + (long)r * p.ld + p.col0 + 4 * lab;
+    for (int e = 0; e < 4; ++e) {
+      const float diff = pr[e] - d[e];
+      dr[4 * lab + e] = (diff > 0.f ? 1.f : (diff < 0.f ? -1.f : 0.f)) / (float)p.M * p.loss_scale;
+    }
+  }
+}
+
 // mean over n_heads of row softmaxes (fast_rcnn.py:1577-1594)
 __global__ void mean_softmax_kernel(const float* logits, long ld, const int* col0s, int n_heads, int C, float* probs,
                                     int M) {
@@ -650,6 +715,22 @@ int drn_softmax_ce(const float* logits, long ld, int col0, int C, const int* lab
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ce_rows_kernel, dim3(nb), dim3(256), 0, st, p, scratch);
   if (labels) hipLaunchKernelGGL(ce_grad_kernel, dim3(nb), dim3(256), 0, st, p, (const float*)scratch, nb);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// scratch: ceil(M/256) floats
+int drn_box_reg_loss(const float* logits, long ld, int col0, int K, const int* labels, const float* props,
+                     const float* gt_boxes, const float* weights4_host, float* dlogits, long ld_d, float* loss,
+                     float* scratch, int M, float loss_scale, void* stream) {
+  if (!logits || !labels || !props || !gt_boxes || !weights4_host || !loss || !scratch || K < 1 || M < 1)
+    return DRN_ERR_ARG;
+  BoxRegParams p{logits, ld, col0, K, labels, props, gt_boxes, dlogits, ld_d, loss, M, weights4_host[0],
+                 weights4_host[1], weights4_host[2], weights4_host[3], loss_scale};
+  const int nb = (M + 255) / 256;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(boxreg_rows_kernel, dim3(nb), dim3(256), 0, st, p, scratch);
+  hipLaunchKernelGGL(boxreg_grad_kernel, dim3(nb), dim3(256), 0, st, p, (const float*)scratch, nb);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

@@ -476,9 +476,6 @@ class _HeadEngine:
         aux = dict(scores=scores, img_scores=img_scores, targets=[])
         thr = h.proposal_matcher.thresholds[1:-1]
         for k in range(h.refine_K):
-            if h.refine_reg[k]:
-                raise DrnError("WSL.REFINE_REG training (box-regression refinement loss) is not built yet; "
-                               "the BASELINE configs do not use it")
             tg = ops.oicr_targets(prev_scores, prev_boxes, gt["props"], img_off, n_img, gt["classes"], gt["count"],
                                   img_scores, K, thr, h.proposal_matcher.labels)
             probs, loss = ops.softmax_ce(w["logits"], col["r%d" % k], K + 1, tg["labels"], tg["weights"], dlogits=dl)
@@ -487,7 +484,16 @@ class _HeadEngine:
             head_cols.append(("r%d" % k, len(loss_list) - 1))
             aux["targets"].append(tg)
             prev_scores = probs
-            prev_boxes = ops.apply_deltas(None, gt["props"], K, h.box_refinery[k].box2box_transform.weights)
+            bw = h.box_refinery[k].box2box_transform.weights
+            if h.refine_reg[k]:  # fast_rcnn.py:1146-1211 + :1227-1240: loss_box_reg_r{k}
+                lreg = ops.box_reg_loss(w["logits"], col["b%d" % k], K, tg["labels"], gt["props"], tg["gt_boxes"], bw,
+                                        dlogits=dl)
+                loss_names.append("loss_box_reg_r%d" % k)
+                loss_list.append(lreg.view(()))
+                head_cols.append(("b%d" % k, len(loss_list) - 1))
+                prev_boxes = ops.apply_deltas(w["logits"], gt["props"], K, bw, col0=col["b%d" % k])
+            else:
+                prev_boxes = ops.apply_deltas(None, gt["props"], K, bw)
         state = dict(w=w, M=M, dtype=dtype, loss_list=loss_list, head_cols=head_cols, masks=masks, drop_p=drop_p,
                      aux=aux)
         outs = _TrainFn.apply(self.anchor, self, state)
@@ -508,8 +514,10 @@ class _HeadEngine:
         # per-loss upstream gradients -> per-column scale of dlogits (stays on the device)
         g = [torch.zeros((), device=dev) if x is None else x.float().reshape(()) for x in gouts]
         width = {n: c for n, _, _, c in self.cols}
-        colscale = torch.cat([g[li].expand(width[n]) for n, li in st["head_cols"]] +
-                             [torch.zeros(NH - sum(width[n] for n, _ in st["head_cols"]), device=dev)]).contiguous()
+        start = {n: o for n, _, o, _ in self.cols}
+        trained = dict(st["head_cols"])
+        colscale = torch.cat([(g[trained[n]] if n in trained else torch.zeros((), device=dev)).expand(width[n])
+                              for n in sorted(width, key=lambda n: start[n])]).contiguous()
         acc = self._grads_valid and fc1.weight.grad is not None
         bo, _ = self._seg[self.cols[0][0] + ".bias"]
         wo, _ = self._seg[self.cols[0][0] + ".weight"]

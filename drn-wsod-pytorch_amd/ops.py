@@ -192,6 +192,17 @@ def softmax_ce(logits, col0, ncol, labels=None, weights=None, dlogits=None, loss
     return probs, loss
 
 
+def box_reg_loss(logits, col0, K, labels, props, gt_boxes, weights=(10.0, 10.0, 5.0, 5.0), dlogits=None, loss_scale=1.0):
+    M = logits.shape[0]
+    loss = torch.zeros((1,), dtype=torch.float32, device=logits.device)
+    scratch = torch.empty(((M + 255) // 256,), dtype=torch.float32, device=logits.device)
+    w = C.host_floats(weights)
+    C.call("drn_box_reg_loss", C.ptr(logits), _2d(logits), col0, K, C.ptr(labels), C.ptr(props), C.ptr(gt_boxes),
+           ctypes.cast(w, ctypes.c_void_p), C.ptr(dlogits), _2d(dlogits) if dlogits is not None else 0, C.ptr(loss),
+           C.ptr(scratch), M, float(loss_scale), C.stream())
+    return loss
+
+
 def mean_softmax(logits, col0s, ncol):
     M = logits.shape[0]
     probs = torch.empty((M, ncol), dtype=torch.float32, device=logits.device)

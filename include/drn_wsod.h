@@ -125,6 +125,13 @@ int drn_softmax_ce(const float* logits, long ld, int col0, int C, const int* lab
                    float* probs, float* dlogits, long ld_d, float* loss, float* scratch, int M, float loss_scale,
                    void* stream);
 
+/* OICROutputs.box_reg_loss, fast_rcnn.py:1146-1211 (WSL.REFINE_REG heads) with Box2BoxTransform.get_deltas,
+ * detectron2/modeling/box_regression.py:38-71, smooth-L1 beta = 0: loss = sum_fg |pred - target| / M, and its
+ * gradient written to dlogits columns col0 .. col0+4K.  scratch: ceil(M/256) floats. */
+int drn_box_reg_loss(const float* logits, long ld, int col0, int K, const int* labels, const float* props,
+                     const float* gt_boxes, const float* weights4_host, float* dlogits, long ld_d, float* loss,
+                     float* scratch, int M, float loss_scale, void* stream);
+
 /* OICROutputLayers.predict_probs_K, fast_rcnn.py:1577-1594. */
 int drn_mean_softmax(const float* logits, long ld, const int* col0s_dev, int n_heads, int C, float* probs, int M,
                      void* stream);

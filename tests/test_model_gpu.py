@@ -14,7 +14,7 @@ from __graft_entry__ import load_package
 pytestmark = pytest.mark.gpu
 O = G.O
 load_package()  # registers the hyphen-named package directory as drn_wsod_pytorch_amd
-FROZEN_CASES = [n for n in sorted(G.MODEL_CASES) if G.FREEZE_AT.get(n, 5) == 5 and "reg" not in n]
+FROZEN_CASES = [n for n in sorted(G.MODEL_CASES) if G.FREEZE_AT.get(n, 5) == 5]
 
 
 def _relerr(a, b, floor=1e-6):
