@@ -105,7 +105,10 @@ def test_backbone_features_and_inference_fp32(name):
     res, all_scores, all_boxes = model.inference(G.drn_inputs(batch, False), do_postprocess=False)
     for i in range(len(batch)):
         assert _relerr(all_scores[i][0].cpu().numpy(), ref_scores[i].numpy()) < 1e-4
-        assert torch.equal(all_boxes[i][0].cpu(), ref_boxes[i])  # zero-delta decode: bit-exact
+        if any(ocfg.refine_reg):  # real deltas go through exp(): GEMM + expf rounding, not bit-exact
+            assert torch.allclose(all_boxes[i][0].cpu(), ref_boxes[i], rtol=1e-4, atol=1e-3)
+        else:
+            assert torch.equal(all_boxes[i][0].cpu(), ref_boxes[i])  # zero-delta decode: bit-exact
         rb, rs, rc, rr = ref[i]
         # detections: identical classes / order wherever the oracle's score gaps exceed the fp32 noise
         n = min(len(rs), len(res[i]))
