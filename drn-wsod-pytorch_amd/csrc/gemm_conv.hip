@@ -222,7 +222,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 //     drain them).
 //   * operands are swapped in the MFMA (D^T = B.A^T) so a lane holds 4 consecutive output columns per register
 //     quad: the epilogue issues 16-B stores (4x fewer store instructions; the fc6 dW output is 411 MB).
-template <int DT>
+template <int DT, bool PIPE>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
@@ -264,33 +264,69 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  auto load_frags = [&](const char* buf, int ks, i32x4_t (&fa)[MI], i32x4_t (&fb)[NJ]) {
+    const int slot = ks * 2 + (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[i] = *(const i32x4_t*)(buf + swz(wm * 128 + i * 32 + (lane & 31), slot));
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) fb[j] = *(const i32x4_t*)(buf + A_BYTES + swz(wn * 64 + j * 32 + (lane & 31), slot));
+  };
+  auto mma_all = [&](const i32x4_t (&fa)[MI], const i32x4_t (&fb)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[i][j], fb[j], fa[i]);  // swapped: D^T[n][m]
+  };
   if (s0 < s1) {
-    issue(smem, s0);
-    for (int s = s0; s < s1; ++s) {
-      char* cur = smem + ((s - s0) & 1) * STAGE;
-      char* nxt = smem + (((s - s0) & 1) ^ 1) * STAGE;
-      if (s + 1 < s1) {
-        issue(nxt, s + 1);
-        asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-      } else {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      }
+    if constexpr (PIPE) {
+      // Software-pipelined schedule: fragments of k-step k+1 are read while the MFMAs of k-step k run (two register
+      // sets), and ONE barrier per slab - placed after the slab's last fragment read and before its last MFMA block -
+      // serves both as "slab s+1 has landed" and "everybody is done reading slab s"; the DMA of slab s+2 is issued
+      // right behind it and has a whole slab of MFMAs to land.
+      i32x4_t fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
+      issue(smem, s0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        i32x4_t fa[MI], fb[NJ];
-        const int slot = ks * 2 + (lane >> 5);
-#pragma unroll
-        for (int i = 0; i < MI; ++i) fa[i] = *(const i32x4_t*)(cur + swz(wm * 128 + i * 32 + (lane & 31), slot));
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) fb[j] = *(const i32x4_t*)(cur + A_BYTES + swz(wn * 64 + j * 32 + (lane & 31), slot));
-#pragma unroll
-        for (int i = 0; i < MI; ++i)
-#pragma unroll
-          for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[i][j], fb[j], fa[i]);  // swapped: D^T[n][m]
+      if (s0 + 1 < s1) issue(smem + STAGE, s0 + 1);
+      load_frags(smem, 0, fa0, fb0);
+      for (int s = s0; s < s1; ++s) {
+        char* cur = smem + ((s - s0) & 1) * STAGE;
+        char* nxt = smem + (((s - s0) & 1) ^ 1) * STAGE;
+        load_frags(cur, 1, fa1, fb1);
+        mma_all(fa0, fb0);
+        load_frags(cur, 2, fa0, fb0);
+        mma_all(fa1, fb1);
+        load_frags(cur, 3, fa1, fb1);
+        mma_all(fa0, fb0);
+        if (s + 1 < s1) {
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          if (s + 2 < s1) issue(cur, s + 2);
+          load_frags(nxt, 0, fa0, fb0);
+        }
+        mma_all(fa1, fb1);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
+    } else {
+      issue(smem, s0);
+      for (int s = s0; s < s1; ++s) {
+        char* cur = smem + ((s - s0) & 1) * STAGE;
+        char* nxt = smem + (((s - s0) & 1) ^ 1) * STAGE;
+        if (s + 1 < s1) {
+          issue(nxt, s + 1);
+          asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        } else {
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          i32x4_t fa[MI], fb[NJ];
+          load_frags(cur, ks, fa, fb);
+          mma_all(fa, fb);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
   }
   // D^T layout: lane -> m (A row) = lane&31, register r -> n = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -396,11 +432,11 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
-template <int DT>
+template <int DT, bool PIPE>
 int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256_kernel<DT>;
+  auto k = gemm_nt256_kernel<DT, PIPE>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -438,7 +474,7 @@ extern "C" {
 // tuning/test hook: pin the GEMM tile (0 restores the heuristic). Returns the previous value.
 int drn_gemm_set_tile(int tile) {
   const int old = g_force_tile;
-  if (tile == 0 || tile == 64 || tile == 128 || tile == 256) g_force_tile = tile;
+  if (tile == 0 || tile == 64 || tile == 128 || tile == 255 || tile == 256) g_force_tile = tile;
   return old;
 }
 
@@ -461,8 +497,10 @@ int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, lon
   // otherwise the 128x128 / 64x64 register-staged kernels (more, smaller workgroups)
   const long wg256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   const int force = g_force_tile;
+  if (force == 255)  // the non-pipelined 256 kernel (kept for A/B comparison)
+    return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, false>(p, splits, st) : launch_gemm256<DRN_F32, false>(p, splits, st);
   if ((force == 256 || (force == 0 && wg256 >= 192)) && (((uintptr_t)C) & 3) == 0)
-    return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16>(p, splits, st) : launch_gemm256<DRN_F32>(p, splits, st);
+    return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true>(p, splits, st) : launch_gemm256<DRN_F32, true>(p, splits, st);
   const bool small = force == 64 || (force == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) * splits < 128);
   if (dtype == DRN_BF16) return small ? launch_gemm<DRN_BF16, 64, 64>(p, splits, st) : launch_gemm<DRN_BF16, 128, 128>(p, splits, st);
   return small ? launch_gemm<DRN_F32, 64, 64>(p, splits, st) : launch_gemm<DRN_F32, 128, 128>(p, splits, st);

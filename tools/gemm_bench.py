@@ -33,7 +33,7 @@ def bench(name, M, N, K, dtype, splits, iters=10):
 
 if __name__ == "__main__":
     bf, f32 = torch.bfloat16, torch.float32
-    for tile in (128, 256):
+    for tile in (255, 256):
         ops.gemm_set_tile(tile)
         print("---- tile", tile)
         for s in (2, 4, 8):
