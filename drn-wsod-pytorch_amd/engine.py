@@ -245,21 +245,21 @@ class Trainer:
 
 
 class GraphedTrainStep:
-    """One full training step (preprocess + backbone of the NEXT image on a side stream, ROI heads forward, losses,
-    backward, fused SGD) captured once into a hipGraph and replayed: a step is ~130 kernel launches of 2-600 us, so
-    the eager Python host needs ~2.4 ms to enqueue what the GPU executes in ~2.6 ms; replay costs ~15 us.
+    """One full training step captured into hipGraphs and replayed: a step is ~130 kernel launches of 2-600 us, so the
+    eager Python host needs ~2.4 ms to enqueue what the GPU executes in ~2.6 ms; a replay costs ~15 us of host time.
 
-    Static shapes only (fixed image size, proposals per image and images per GPU — the benchmark's case and the
-    common fixed-R training case); anything else runs the eager path.  Single process: with N > 1 the gradient
-    exchange stays eager (DataParallel), so this class is used when world == 1.
+    What one replay contains (two streams, forked and joined inside the capture):
+      side stream : preprocess + frozen backbone + ROIPool(+objectness) + A^T copy of the NEXT batch -> buffer set 1-p
+      main stream : heads forward on buffer set p (fc6 GEMM first), losses, explicit backward, fused SGD
+    so the latency-bound backbone and the HBM-bound pooling never sit in front of the fc6 GEMM.  The two buffer sets
+    (pooled features A / A^T, rois, objectness, labels) alternate, hence two graphs (p = 0, 1) replayed in turn - no
+    copies.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5).
 
-    Pipeline skew: the graph reads `image` = the NEXT batch's image (its backbone runs on the side stream and lands
-    in `feat_next`) while the heads consume `feat_cur` with the CURRENT batch's proposals/labels; the last node copies
-    feat_next -> feat_cur.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5)."""
+    Static shapes only (fixed image size, proposals per image, images per GPU: the benchmark's case and the common
+    fixed-R training case); anything else runs the eager path.  Single process: with N > 1 the gradient exchange
+    stays eager (DataParallel), so this class is used when world == 1."""
 
     def __init__(self, model, optimizer, example_batch):
-        from .structures import Boxes  # noqa: F401
-
         assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
         self.model, self.opt = model, optimizer
         self.heads = model.roi_heads
@@ -268,32 +268,37 @@ class GraphedTrainStep:
         K = self.heads.num_classes
         self.nper = [len(x["proposals"]) for x in example_batch]
         n_img, M = len(example_batch), sum(self.nper)
-        self.n_img, self.K = n_img, K
+        self.n_img, self.K, self.M = n_img, K, M
         self.image = [x["image"].to(dev).float().clone() for x in example_batch]
-        self.rois = torch.zeros((M, 5), dtype=torch.float32, device=dev)
-        self.obj = torch.zeros((M,), dtype=torch.float32, device=dev)
         off = [0]
         for n in self.nper:
             off.append(off[-1] + n)
-        self.gt = dict(onehot=torch.zeros((n_img, K), device=dev), classes=torch.zeros((n_img, K), dtype=torch.int32, device=dev),
-                       count=torch.zeros((n_img,), dtype=torch.int32, device=dev), props=None, max_rows=max(self.nper))
         self.img_off = torch.tensor(off, dtype=torch.int32, device=dev)
-        for i in range(n_img):
-            self.rois[off[i]: off[i + 1], 0] = float(i)
-        self.graph = None
-        self.losses = None
+        self.sets = []
+        for _ in range(2):
+            rois = torch.zeros((M, 5), dtype=torch.float32, device=dev)
+            for i in range(n_img):
+                rois[off[i]: off[i + 1], 0] = float(i)
+            self.sets.append(dict(rois=rois, obj=torch.zeros((M,), dtype=torch.float32, device=dev),
+                                  gt=dict(onehot=torch.zeros((n_img, K), device=dev),
+                                          classes=torch.zeros((n_img, K), dtype=torch.int32, device=dev),
+                                          count=torch.zeros((n_img,), dtype=torch.int32, device=dev), props=None,
+                                          max_rows=max(self.nper)), pooled=None))
+        self.graphs = [None, None]
+        self.losses = [None, None]
         self._side = torch.cuda.Stream()
         self._primed = False
+        self.parity = 0
 
-    # ---- host side of one step: stage inputs into the static buffers (tiny async copies) -----------------------
-    def _stage_heads_inputs(self, batch):
-        off = 0
-        ints = []
+    # ---- host side of one step: stage a batch into buffer set `k` (tiny async copies) -----------------------
+    def _stage(self, batch, k):
+        st = self.sets[k]
+        off, ints = 0, []
         for i, x in enumerate(batch):
             n = self.nper[i]
             assert len(x["proposals"]) == n, "graphed step: proposals per image must stay fixed"
-            self.rois[off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
-            self.obj[off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
+            st["rois"][off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
+            st["obj"][off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
             ints.append(torch.unique(x["instances"].gt_classes.cpu(), sorted=True))
             off += n
         oh = torch.zeros((self.n_img, self.K))
@@ -301,63 +306,62 @@ class GraphedTrainStep:
         for i, g in enumerate(ints):
             oh[i, g] = 1
             cl[i, : len(g)] = g.to(torch.int32)
-        self.gt["onehot"].copy_(oh, non_blocking=True)
-        self.gt["classes"].copy_(cl, non_blocking=True)
-        self.gt["count"].copy_(torch.tensor([len(g) for g in ints], dtype=torch.int32), non_blocking=True)
-
-    def _stage_image(self, batch):
+        st["gt"]["onehot"].copy_(oh, non_blocking=True)
+        st["gt"]["classes"].copy_(cl, non_blocking=True)
+        st["gt"]["count"].copy_(torch.tensor([len(g) for g in ints], dtype=torch.int32), non_blocking=True)
         for buf, x in zip(self.image, batch):
             buf.copy_(x["image"], non_blocking=True)
 
-    def _backbone(self):
+    def _backbone_and_pool(self, k):
+        """image buffers -> features -> pooled fc6 operand of buffer set k (runs on the current stream)"""
         m = self.model
-        dtype_feat = None
         imgs = m.preprocess_image([{"image": im} for im in self.image])
         feats = m.backbone(imgs.tensor)
         f = feats[self.heads.box_in_features[0]].permute(0, 2, 3, 1)
-        assert f.is_contiguous()
-        return f
+        st = self.sets[k]
+        st["pooled"] = self.engine.pool(f, st["rois"], st["obj"], True, slot=k)
 
-    def _body(self):
-        """the step as it is captured"""
+    def _body(self, p):
+        """the step as it is captured: heads on set p (main stream) || backbone+pool of the next batch into set 1-p"""
         cur = torch.cuda.current_stream()
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side), torch.no_grad():
-            self.feat_next.copy_(self._backbone())
-        self.gt["props"] = self.rois[:, 1:].contiguous()
-        losses, _ = self.engine.forward(self.feat_cur, self.rois, self.obj, True, self.img_off, self.n_img, self.gt)
+            self._backbone_and_pool(1 - p)
+        st = self.sets[p]
+        st["gt"]["props"] = st["rois"][:, 1:].contiguous()
+        losses, _ = self.engine.forward(None, st["rois"], st["obj"], True, self.img_off, self.n_img, st["gt"],
+                                        pooled=st["pooled"])
         sum(losses.values()).backward()
         self.opt.step(1.0)
         cur.wait_stream(self._side)
-        self.feat_cur.copy_(self.feat_next)
         return losses
 
     def prime(self, first_batch, next_batch):
         """Step 0, eagerly (so every workspace exists and the captured SGD is not the momentum-initialising first
-        step), then the capture.  Returns step 0's losses."""
-        self._stage_image(first_batch)
-        with torch.no_grad():
-            f = self._backbone()
-        self.feat_cur = f.clone()
-        self.feat_next = torch.empty_like(f)
-        self._stage_image(next_batch)
-        self._stage_heads_inputs(first_batch)
-        self.opt.zero_grad()
+        step), then the two captures.  Returns step 0's losses."""
         self.heads.train()
-        first = {k: v.detach().clone() for k, v in self._body().items()}
+        self._stage(first_batch, 0)
+        with torch.no_grad():
+            self._backbone_and_pool(0)
+        self._stage(next_batch, 1)
+        self.opt.zero_grad()
+        first = {k: v.detach().clone() for k, v in self._body(0).items()}
         self.opt.zero_grad()
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.losses = self._body()
-        self._primed = True
+        for p in (1, 0):  # capture order is irrelevant (capturing does not execute)
+            self.graphs[p] = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graphs[p]):
+                self.losses[p] = self._body(p)
+        self._primed, self.parity = True, 1
         return first
 
     def step(self, batch, next_batch):
-        """run the step for `batch`; `next_batch`'s image is fed to the side-stream backbone of the same replay"""
+        """run the step for `batch` (which must be the batch passed as `next_batch` to the previous call); the side
+        stream of the same replay prepares `next_batch`"""
         if not self._primed:
             return self.prime(batch, next_batch)
-        self._stage_heads_inputs(batch)
-        self._stage_image(next_batch)
-        self.graph.replay()
-        return self.losses
+        p = self.parity
+        self._stage(next_batch, 1 - p)
+        self.graphs[p].replay()
+        self.parity ^= 1
+        return self.losses[p]

@@ -86,25 +86,29 @@ class GeneralizedRCNNWSL(nn.Module):
         with torch.cuda.stream(self._side), torch.no_grad():
             images = self.preprocess_image(batched_inputs)
             features = self.backbone(images.tensor)
+            pooled = None
+            if self.training and hasattr(self.roi_heads, "prefetch_pooled") and "proposals" in batched_inputs[0]:
+                # ROIPool + the A^T copy of the next batch leave the critical path too
+                pooled = self.roi_heads.prefetch_pooled(features, self._proposals(batched_inputs))
             ev = torch.cuda.Event()
             ev.record(self._side)
         if not hasattr(self, "_prefetch_cache"):
             self._prefetch_cache = {}
         if len(self._prefetch_cache) >= 2:
             self._prefetch_cache.pop(next(iter(self._prefetch_cache)))
-        self._prefetch_cache[id(batched_inputs)] = (images, features, ev)
+        self._prefetch_cache[id(batched_inputs)] = (images, features, ev, pooled)
 
     def _features(self, batched_inputs):
         pre = getattr(self, "_prefetch_cache", {}).pop(id(batched_inputs), None)
         if pre is not None:
-            images, features, ev = pre
+            images, features, ev, pooled = pre
             main = torch.cuda.current_stream()
             main.wait_event(ev)
             for t in list(features.values()) + [images.nhwc]:
                 t.record_stream(main)
-            return images, features
+            return images, features, pooled
         images = self.preprocess_image(batched_inputs)
-        return images, self.backbone(images.tensor)
+        return images, self.backbone(images.tensor), None
 
     def _proposals(self, batched_inputs):
         assert self.load_proposals and "proposals" in batched_inputs[0], "this path uses precomputed proposals"
@@ -113,11 +117,14 @@ class GeneralizedRCNNWSL(nn.Module):
     def forward(self, batched_inputs):
         if not self.training:
             return self.inference(batched_inputs)
-        images, features = self._features(batched_inputs)
+        images, features, pooled = self._features(batched_inputs)
         # image-level labels are read on the host (they come from the loader there): no device round trip
         gt_instances = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
         proposals = self._proposals(batched_inputs)
-        _, detector_losses = self.roi_heads(images, features, proposals, gt_instances)
+        if pooled is not None:
+            _, detector_losses = self.roi_heads(images, features, proposals, gt_instances, prefetched=pooled)
+        else:
+            _, detector_losses = self.roi_heads(images, features, proposals, gt_instances)
         losses = {}
         losses.update(detector_losses)
         return losses

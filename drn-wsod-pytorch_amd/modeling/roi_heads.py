@@ -403,15 +403,39 @@ class _HeadEngine:
         kp = lambda k: ops.kpad(k, dtype)
         z = lambda r, c, dt=dtype: torch.zeros((r, c), dtype=dt, device=dev)
         NHp = kp(self.NH)
-        w = dict(A=z(M, kp(K1)), H1=z(M, kp(D1)), H2=z(M, kp(D2)), logits=z(M, NHp, torch.float32))
+        w = dict(H1=z(M, kp(D1)), H2=z(M, kp(D2)), logits=z(M, NHp, torch.float32))
         if training:
             Mp = kp(M)
-            w.update(AT=z(K1, Mp), H1T=z(D1, Mp), H2T=z(D2, Mp), dlogits=z(M, NHp, torch.float32), dS=z(M, NHp),
+            w.update(H1T=z(D1, Mp), H2T=z(D2, Mp), dlogits=z(M, NHp, torch.float32), dS=z(M, NHp),
                      dST=z(self.NH, Mp), dH2=z(M, D2, torch.float32), dP2=z(M, kp(D2)), dP2T=z(D2, Mp),
                      dH1=z(M, D1, torch.float32), dP1T=z(D1, Mp),
                      colpart=z((M + 255) // 256, max(D1, D2, self.NH), torch.float32))
         self._ws[key] = w
         return w
+
+    def pool(self, feat_nhwc, rois, objectness, training, slot=None):
+        """ROIPool/ROIAlign fused with the objectness scaling -> fc6 operand A [M, C*P*P] (+ A^T for the dW GEMM when
+        training), into one of two rotating buffer sets so that the NEXT batch can be pooled on a side stream while the
+        current batch's forward/backward still reads its own set."""
+        h = self.h
+        dev, dtype = feat_nhwc.device, feat_nhwc.dtype
+        self.ensure(dev)
+        M = rois.shape[0]
+        K1 = h.box_head.fc1.weight.shape[1]
+        key = (M, dtype, training)
+        if getattr(self, "_pool_key", None) != key:
+            z = lambda r_, c_: torch.zeros((r_, c_), dtype=dtype, device=dev)
+            self._pool_sets = [dict(A=z(M, ops.kpad(K1, dtype)), AT=z(K1, ops.kpad(M, dtype)) if training else None)
+                               for _ in range(2)]
+            self._pool_key, self._pool_next = key, 0
+        if slot is None:
+            slot = self._pool_next
+            self._pool_next ^= 1
+        s = self._pool_sets[slot]
+        ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=s["A"], **h.box_pooler.kernel_args())
+        if training:
+            ops.transpose2d(s["A"], M, K1, out=s["AT"])
+        return s
 
     @staticmethod
     def _splits(M, N, K, dtype):
@@ -425,21 +449,22 @@ class _HeadEngine:
         ops.bias_act_fwd(part, M, N, bias, relu, mask, seed, drop_p, out=out, outT=outT, seed_dev=seed_dev)
 
     # ---- forward -------------------------------------------------------------------------------------
-    def forward(self, feat_nhwc, rois, objectness, training, img_off=None, n_img=1, gt=None):
+    def forward(self, feat_nhwc, rois, objectness, training, img_off=None, n_img=1, gt=None, pooled=None):
         h = self.h
-        dev = feat_nhwc.device
+        if pooled is None:
+            pooled = self.pool(feat_nhwc, rois, objectness, training)
+        dev, dtype = pooled["A"].device, pooled["A"].dtype
         self.ensure(dev)
-        dtype = feat_nhwc.dtype
         self.refresh_shadows(dtype)
         M = rois.shape[0]
-        w = self.ws(M, dtype, training)
+        w = dict(self.ws(M, dtype, training))
+        w["A"], w["AT"] = pooled["A"], pooled["AT"]
         sh = self.sh
         fc1, fc2 = h.box_head.fc1, h.box_head.fc2
         D1, K1 = fc1.weight.shape
         D2 = fc2.weight.shape[0]
         K, NH = h.num_classes, self.NH
         kp = lambda k: ops.kpad(k, dtype)
-        ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=w["A"], **h.box_pooler.kernel_args())
         drop_p = h.box_head.dropout_p if training else 0.0
         masks = h.box_head.dropout_masks if training else None
         seed, seed_dev = 0, None
@@ -449,8 +474,6 @@ class _HeadEngine:
             if getattr(self, "seed_dev", None) is None or self.seed_dev.device != dev:
                 self.seed_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
             seed, seed_dev = torch.initial_seed() & 0xFFFFFFFFFFFF, self.seed_dev
-        if training:
-            ops.transpose2d(w["A"], M, K1, out=w["AT"])
         self._linear_fwd(w["A"], sh["W1v"], M, D1, kp(K1), fc1.bias.data, True, w["H1"], w["H1T"] if training else None,
                          masks[0] if masks else None, seed, drop_p, seed_dev)
         self._linear_fwd(w["H1"], sh["W2"], M, D2, kp(D1), fc2.bias.data, True, w["H2"], w["H2T"] if training else None,
@@ -662,9 +685,15 @@ class OICRROIHeads(ROIHeads):
         obj = torch.cat([p.objectness_logits for p in proposals], dim=0).float().contiguous()
         return nhwc, rois, obj
 
-    def forward(self, images, features, proposals, targets=None):
+    def prefetch_pooled(self, features, proposals):
+        """pool a FUTURE batch's proposals (on whatever stream is current) into the engine's spare buffer set"""
+        nhwc, rois, obj = self._gather_inputs(features, proposals)
+        return dict(rois=rois, obj=obj, pooled=self._engine.pool(nhwc, rois, obj, self.training))
+
+    def forward(self, images, features, proposals, targets=None, prefetched=None):
         """roi_heads_oicr.py:248-291."""
         self.images = images
+        self._prefetched = prefetched
         if self.training:
             assert targets
             losses = self._forward_box(features, proposals, targets)
@@ -679,8 +708,14 @@ class OICRROIHeads(ROIHeads):
 
     def _forward_box(self, features, proposals, targets):
         """roi_heads_oicr.py:320-421."""
-        nhwc, rois, obj = self._gather_inputs(features, proposals)
-        dev = nhwc.device
+        pre = getattr(self, "_prefetched", None)
+        self._prefetched = None
+        if pre is not None:
+            nhwc, rois, obj, pooled = None, pre["rois"], pre["obj"], pre["pooled"]
+        else:
+            nhwc, rois, obj = self._gather_inputs(features, proposals)
+            pooled = None
+        dev = rois.device
         nper = [len(p) for p in proposals]
         n_img = len(proposals)
         K = self.num_classes
@@ -695,7 +730,8 @@ class OICRROIHeads(ROIHeads):
             gt = dict(onehot=oh.to(dev, non_blocking=True), classes=gcl.to(dev, non_blocking=True),
                       count=torch.tensor([len(g) for g in ints], dtype=torch.int32).to(dev, non_blocking=True),
                       props=rois[:, 1:].contiguous(), max_rows=max(nper))
-            losses, state = self._engine.forward(nhwc, rois, obj, True, off.to(dev, non_blocking=True), n_img, gt)
+            losses, state = self._engine.forward(nhwc, rois, obj, True, off.to(dev, non_blocking=True), n_img, gt,
+                                                 pooled=pooled)
             self.pred_class_img_logits = state["aux"]["img_scores"]
             self._last_state = state
             if has_event_storage():  # kept as device scalars: no sync (the reference syncs 3x here)
@@ -705,7 +741,7 @@ class OICRROIHeads(ROIHeads):
                 st.put_scalar("proposals/objectness_logits+1 max", o1.max())
                 st.put_scalar("proposals/objectness_logits+1 min", o1.min())
             return losses
-        w, col = self._engine.forward(nhwc, rois, obj, False)
+        w, col = self._engine.forward(nhwc, rois, obj, False, pooled=pooled)
         heads = [k for k in range(self.refine_K)]
         props = rois[:, 1:].contiguous()
         if self.refine_K == 0:
