@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
+    ap.add_argument("--no-pipelined-sgd", action="store_true", help="plain optimizer.step() after backward")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -161,6 +162,8 @@ def main():
     opt = build_optimizer(cfg, model)
     dp = DataParallel(model)
     dp.broadcast_parameters(0)
+    if not args.no_pipelined_sgd:
+        opt.enable_pipelined(dp)  # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
     batches = synthetic_batches(8, R, K, device, rank, pkg)
 

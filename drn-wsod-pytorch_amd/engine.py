@@ -64,6 +64,78 @@ class FusedSGD:
             self._segs_key, self._nseg = key, len(groups)
         return self._segs_dev, self._nseg
 
+    # ---- pipelined mode: the update of a gradient bucket starts as soon as the bucket is final ----------------
+    def enable_pipelined(self, dp=None, slab_rows=None):
+        """ITER_SIZE == 1 only.  The explicit backward finishes gradients in a known order: first every small tensor
+        (predictors, fc7, fc6 bias), then fc6.weight in row slabs.  In pipelined mode each bucket is (all-reduced when
+        N > 1 and then) updated by the SGD kernel on a second stream the moment its dW GEMM is queued, so the HBM-bound
+        optimizer pass hides under the MFMA-bound remaining dW GEMMs; `step()` then only joins the streams.
+        Same arithmetic as the plain step (the kernel, the per-group lr/wd and the 1/W scale are identical)."""
+        e = self.engine
+        d1 = self.model.roi_heads.box_head.fc1.weight.shape[0]
+        world = dp.world if dp is not None else 1
+        if slab_rows is None:
+            # 256-row tile granularity of the dW GEMM; 5/8 + 3/8 keeps its tile-round count, 4 equal slabs feed the
+            # interconnect earlier when gradients must cross GPUs
+            t = (d1 + 255) // 256
+            slab_rows = [min(d1, ((5 * t + 7) // 8) * 256)] if world == 1 else [min(d1, ((i + 1) * t // 4) * 256) for i in range(3)]
+            slab_rows = sorted(set(r for r in slab_rows if 0 < r < d1)) + [d1]
+        self._slab_ends = slab_rows
+        e.fc1_slab_ends = slab_rows
+        e.grad_ready_hook = self._on_grad_ready
+        self._dp, self._pipelined = dp, True
+        self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        self._bucket_segs = {}
+
+    def _bucket_table(self, what):
+        groups = [g for g in self.param_groups if g["used"]]
+        key = (what, tuple((g["lr"], g["weight_decay"]) for g in groups))
+        hit = self._bucket_segs.get(what)
+        if hit is not None and hit[0] == key:
+            return hit[1], hit[2]
+        rows = []
+        for g in groups:
+            if what == "small" and g["name"] != "fc1.weight":
+                rows.append((g["off"], g["cnt"], g["lr"], g["weight_decay"]))
+            elif what != "small" and g["name"] == "fc1.weight":
+                _, r0, r1 = what
+                k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
+                rows.append((g["off"] + r0 * k1, (r1 - r0) * k1, g["lr"], g["weight_decay"]))
+        arr = np.zeros(len(rows), dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+        for i, r in enumerate(rows):
+            arr[i] = r
+        host = torch.from_numpy(arr.view(np.uint8).copy())
+        if hit is not None:
+            hit[1].copy_(host)  # in place: captured graphs keep reading this table
+            dev = hit[1]
+        else:
+            dev = host.to(self.engine.arena_w.device)
+        self._bucket_segs[what] = (key, dev, len(rows))
+        return dev, len(rows)
+
+    def _on_grad_ready(self, what):
+        e = self.engine
+        if self._mom is None:
+            self._mom = torch.zeros_like(e.arena_w)
+        segs, nseg = self._bucket_table(what)
+        world = self._dp.world if self._dp is not None else 1
+        cur = torch.cuda.current_stream()
+        ev = torch.cuda.Event()
+        ev.record(cur)
+        self._opt_stream.wait_event(ev)
+        with torch.cuda.stream(self._opt_stream):
+            if world > 1:
+                if what == "small":
+                    o_fc1, _ = e._seg["fc1.weight"]
+                    dist.all_reduce(e.arena_g[:o_fc1], group=self._dp.group)
+                else:
+                    _, r0, r1 = what
+                    o, _ = e._seg["fc1.weight"]
+                    k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
+                    dist.all_reduce(e.arena_g[o + r0 * k1: o + r1 * k1], group=self._dp.group)
+            ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
+                         shadow=e.arena_s)
+
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
             for p in g["params"]:
@@ -74,6 +146,12 @@ class FusedSGD:
         e = self.engine
         if not e._grads_valid:
             raise DrnError("optimizer.step() before any backward()")
+        if getattr(self, "_pipelined", False):
+            # every bucket was already updated on the optimizer stream during backward(): join it
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self._steps += 1
+            e.mark_dirty(shadow_fresh=e.arena_s is not None)
+            return
         if self._mom is None:
             self._mom = torch.zeros_like(e.arena_w)
         segs, nseg = self._segs()
@@ -245,21 +323,21 @@ class Trainer:
 
 
 class GraphedTrainStep:
-    """One full training step captured into hipGraphs and replayed: a step is ~130 kernel launches of 2-600 us, so the
-    eager Python host needs ~2.4 ms to enqueue what the GPU executes in ~2.6 ms; a replay costs ~15 us of host time.
+    """One full training step (preprocess + backbone of the NEXT image on a side stream, ROI heads forward, losses,
+    backward, fused SGD) captured once into a hipGraph and replayed: a step is ~130 kernel launches of 2-600 us, so
+    the eager Python host needs ~2.4 ms to enqueue what the GPU executes in ~2.6 ms; replay costs ~15 us.
 
-    What one replay contains (two streams, forked and joined inside the capture):
-      side stream : preprocess + frozen backbone + ROIPool(+objectness) + A^T copy of the NEXT batch -> buffer set 1-p
-      main stream : heads forward on buffer set p (fc6 GEMM first), losses, explicit backward, fused SGD
-    so the latency-bound backbone and the HBM-bound pooling never sit in front of the fc6 GEMM.  The two buffer sets
-    (pooled features A / A^T, rois, objectness, labels) alternate, hence two graphs (p = 0, 1) replayed in turn - no
-    copies.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5).
+    Static shapes only (fixed image size, proposals per image and images per GPU — the benchmark's case and the
+    common fixed-R training case); anything else runs the eager path.  Single process: with N > 1 the gradient
+    exchange stays eager (DataParallel), so this class is used when world == 1.
 
-    Static shapes only (fixed image size, proposals per image, images per GPU: the benchmark's case and the common
-    fixed-R training case); anything else runs the eager path.  Single process: with N > 1 the gradient exchange
-    stays eager (DataParallel), so this class is used when world == 1."""
+    Pipeline skew: the graph reads `image` = the NEXT batch's image (its backbone runs on the side stream and lands
+    in `feat_next`) while the heads consume `feat_cur` with the CURRENT batch's proposals/labels; the last node copies
+    feat_next -> feat_cur.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5)."""
 
     def __init__(self, model, optimizer, example_batch):
+        from .structures import Boxes  # noqa: F401
+
         assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
         self.model, self.opt = model, optimizer
         self.heads = model.roi_heads
@@ -268,37 +346,32 @@ class GraphedTrainStep:
         K = self.heads.num_classes
         self.nper = [len(x["proposals"]) for x in example_batch]
         n_img, M = len(example_batch), sum(self.nper)
-        self.n_img, self.K, self.M = n_img, K, M
+        self.n_img, self.K = n_img, K
         self.image = [x["image"].to(dev).float().clone() for x in example_batch]
+        self.rois = torch.zeros((M, 5), dtype=torch.float32, device=dev)
+        self.obj = torch.zeros((M,), dtype=torch.float32, device=dev)
         off = [0]
         for n in self.nper:
             off.append(off[-1] + n)
+        self.gt = dict(onehot=torch.zeros((n_img, K), device=dev), classes=torch.zeros((n_img, K), dtype=torch.int32, device=dev),
+                       count=torch.zeros((n_img,), dtype=torch.int32, device=dev), props=None, max_rows=max(self.nper))
         self.img_off = torch.tensor(off, dtype=torch.int32, device=dev)
-        self.sets = []
-        for _ in range(2):
-            rois = torch.zeros((M, 5), dtype=torch.float32, device=dev)
-            for i in range(n_img):
-                rois[off[i]: off[i + 1], 0] = float(i)
-            self.sets.append(dict(rois=rois, obj=torch.zeros((M,), dtype=torch.float32, device=dev),
-                                  gt=dict(onehot=torch.zeros((n_img, K), device=dev),
-                                          classes=torch.zeros((n_img, K), dtype=torch.int32, device=dev),
-                                          count=torch.zeros((n_img,), dtype=torch.int32, device=dev), props=None,
-                                          max_rows=max(self.nper)), pooled=None))
-        self.graphs = [None, None]
-        self.losses = [None, None]
+        for i in range(n_img):
+            self.rois[off[i]: off[i + 1], 0] = float(i)
+        self.graph = None
+        self.losses = None
         self._side = torch.cuda.Stream()
         self._primed = False
-        self.parity = 0
 
-    # ---- host side of one step: stage a batch into buffer set `k` (tiny async copies) -----------------------
-    def _stage(self, batch, k):
-        st = self.sets[k]
-        off, ints = 0, []
+    # ---- host side of one step: stage inputs into the static buffers (tiny async copies) -----------------------
+    def _stage_heads_inputs(self, batch):
+        off = 0
+        ints = []
         for i, x in enumerate(batch):
             n = self.nper[i]
             assert len(x["proposals"]) == n, "graphed step: proposals per image must stay fixed"
-            st["rois"][off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
-            st["obj"][off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
+            self.rois[off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
+            self.obj[off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
             ints.append(torch.unique(x["instances"].gt_classes.cpu(), sorted=True))
             off += n
         oh = torch.zeros((self.n_img, self.K))
@@ -306,62 +379,63 @@ class GraphedTrainStep:
         for i, g in enumerate(ints):
             oh[i, g] = 1
             cl[i, : len(g)] = g.to(torch.int32)
-        st["gt"]["onehot"].copy_(oh, non_blocking=True)
-        st["gt"]["classes"].copy_(cl, non_blocking=True)
-        st["gt"]["count"].copy_(torch.tensor([len(g) for g in ints], dtype=torch.int32), non_blocking=True)
+        self.gt["onehot"].copy_(oh, non_blocking=True)
+        self.gt["classes"].copy_(cl, non_blocking=True)
+        self.gt["count"].copy_(torch.tensor([len(g) for g in ints], dtype=torch.int32), non_blocking=True)
+
+    def _stage_image(self, batch):
         for buf, x in zip(self.image, batch):
             buf.copy_(x["image"], non_blocking=True)
 
-    def _backbone_and_pool(self, k):
-        """image buffers -> features -> pooled fc6 operand of buffer set k (runs on the current stream)"""
+    def _backbone(self):
         m = self.model
+        dtype_feat = None
         imgs = m.preprocess_image([{"image": im} for im in self.image])
         feats = m.backbone(imgs.tensor)
         f = feats[self.heads.box_in_features[0]].permute(0, 2, 3, 1)
-        st = self.sets[k]
-        st["pooled"] = self.engine.pool(f, st["rois"], st["obj"], True, slot=k)
+        assert f.is_contiguous()
+        return f
 
-    def _body(self, p):
-        """the step as it is captured: heads on set p (main stream) || backbone+pool of the next batch into set 1-p"""
+    def _body(self):
+        """the step as it is captured"""
         cur = torch.cuda.current_stream()
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side), torch.no_grad():
-            self._backbone_and_pool(1 - p)
-        st = self.sets[p]
-        st["gt"]["props"] = st["rois"][:, 1:].contiguous()
-        losses, _ = self.engine.forward(None, st["rois"], st["obj"], True, self.img_off, self.n_img, st["gt"],
-                                        pooled=st["pooled"])
+            self.feat_next.copy_(self._backbone())
+        self.gt["props"] = self.rois[:, 1:].contiguous()
+        losses, _ = self.engine.forward(self.feat_cur, self.rois, self.obj, True, self.img_off, self.n_img, self.gt)
         sum(losses.values()).backward()
         self.opt.step(1.0)
         cur.wait_stream(self._side)
+        self.feat_cur.copy_(self.feat_next)
         return losses
 
     def prime(self, first_batch, next_batch):
         """Step 0, eagerly (so every workspace exists and the captured SGD is not the momentum-initialising first
-        step), then the two captures.  Returns step 0's losses."""
-        self.heads.train()
-        self._stage(first_batch, 0)
+        step), then the capture.  Returns step 0's losses."""
+        self._stage_image(first_batch)
         with torch.no_grad():
-            self._backbone_and_pool(0)
-        self._stage(next_batch, 1)
+            f = self._backbone()
+        self.feat_cur = f.clone()
+        self.feat_next = torch.empty_like(f)
+        self._stage_image(next_batch)
+        self._stage_heads_inputs(first_batch)
         self.opt.zero_grad()
-        first = {k: v.detach().clone() for k, v in self._body(0).items()}
+        self.heads.train()
+        first = {k: v.detach().clone() for k, v in self._body().items()}
         self.opt.zero_grad()
         torch.cuda.synchronize()
-        for p in (1, 0):  # capture order is irrelevant (capturing does not execute)
-            self.graphs[p] = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graphs[p]):
-                self.losses[p] = self._body(p)
-        self._primed, self.parity = True, 1
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.losses = self._body()
+        self._primed = True
         return first
 
     def step(self, batch, next_batch):
-        """run the step for `batch` (which must be the batch passed as `next_batch` to the previous call); the side
-        stream of the same replay prepares `next_batch`"""
+        """run the step for `batch`; `next_batch`'s image is fed to the side-stream backbone of the same replay"""
         if not self._primed:
             return self.prime(batch, next_batch)
-        p = self.parity
-        self._stage(next_batch, 1 - p)
-        self.graphs[p].replay()
-        self.parity ^= 1
-        return self.losses[p]
+        self._stage_heads_inputs(batch)
+        self._stage_image(next_batch)
+        self.graph.replay()
+        return self.losses

@@ -562,16 +562,20 @@ class _HeadEngine:
         hook = getattr(self, "grad_ready_hook", None)
         if hook is not None:
             hook("small")  # everything except fc1.weight is final: the DP engine starts reducing it now
-        nslab = getattr(self, "fc1_grad_slabs", 1)
+        ends = getattr(self, "fc1_slab_ends", None)
+        if ends is None:
+            nslab = getattr(self, "fc1_grad_slabs", 1)
+            rows = (D1 + nslab - 1) // nslab
+            ends = [min(D1, (s + 1) * rows) for s in range(nslab)]
         gw = self._gview("fc1.weight", (D1, K1))
-        rows = (D1 + nslab - 1) // nslab
-        for s in range(nslab):
-            r0, r1 = s * rows, min(D1, (s + 1) * rows)
+        r0 = 0
+        for r1 in ends:
             if r0 >= r1:
-                break
+                continue
             ops.gemm_nt(w["dP1T"][r0:r1], w["AT"], r1 - r0, K1, Mp, out=gw[r0:r1].unsqueeze(0), accumulate=acc)
             if hook is not None:
                 hook(("fc1", r0, r1))
+            r0 = r1
         self._grads_valid = True
         for name, p, o, n, used in self.segments:
             if used and p.grad is None:

@@ -225,3 +225,29 @@ def test_hipgraph_step_equals_eager():
     for e, g in zip(*results):
         for k in e:
             assert abs(e[k] - g[k]) <= 1e-5 * max(abs(e[k]), 1e-3), (k, e[k], g[k])
+
+
+def test_pipelined_sgd_equals_plain():
+    """FusedSGD.enable_pipelined (per-bucket update on a second stream during backward) == plain step()."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    name = "model_r50c4_tiny"
+    d = G.load(name)
+    ocfg = G.MODEL_CASES[name]
+    batch = G.drn_inputs(G.batch_from(d))
+    params = []
+    for pipelined in (False, True):
+        cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, "fp32")
+        model.roi_heads.box_head.dropout_p = 0.0
+        model.train()
+        opt = build_optimizer(cfg, model)
+        if pipelined:
+            opt.enable_pipelined(None, slab_rows=[16, 48])
+        for _ in range(3):
+            opt.zero_grad()
+            sum(model(batch).values()).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        params.append({n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad})
+    for n in params[0]:
+        assert torch.equal(params[0][n], params[1][n]), n
