@@ -365,6 +365,9 @@ class GraphedTrainStep:
 
     # ---- host side of one step: stage inputs into the static buffers (tiny async copies) -----------------------
     def _stage_heads_inputs(self, batch):
+        """Proposals are device tensors (async D2D copies).  The image-level labels are built on the host: they go
+        through a ring of PINNED staging buffers so the H2D copies are truly asynchronous - a pageable source would
+        block the host until the previous replay has drained and leave the GPU idle between replays."""
         off = 0
         ints = []
         for i, x in enumerate(batch):
@@ -374,14 +377,26 @@ class GraphedTrainStep:
             self.obj[off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
             ints.append(torch.unique(x["instances"].gt_classes.cpu(), sorted=True))
             off += n
-        oh = torch.zeros((self.n_img, self.K))
-        cl = torch.zeros((self.n_img, self.K), dtype=torch.int32)
+        if not hasattr(self, "_ring"):
+            mk = lambda shape, dt: torch.zeros(shape, dtype=dt).pin_memory()
+            self._ring = [dict(oh=mk((self.n_img, self.K), torch.float32), cl=mk((self.n_img, self.K), torch.int32),
+                               cnt=mk((self.n_img,), torch.int32), ev=None) for _ in range(8)]
+            self._ring_i = 0
+        slot = self._ring[self._ring_i]
+        self._ring_i = (self._ring_i + 1) % len(self._ring)
+        if slot["ev"] is not None:
+            slot["ev"].synchronize()  # only blocks when the host is a full ring ahead of the GPU
+        slot["oh"].zero_()
+        slot["cl"].zero_()
         for i, g in enumerate(ints):
-            oh[i, g] = 1
-            cl[i, : len(g)] = g.to(torch.int32)
-        self.gt["onehot"].copy_(oh, non_blocking=True)
-        self.gt["classes"].copy_(cl, non_blocking=True)
-        self.gt["count"].copy_(torch.tensor([len(g) for g in ints], dtype=torch.int32), non_blocking=True)
+            slot["oh"][i, g] = 1
+            slot["cl"][i, : len(g)] = g.to(torch.int32)
+            slot["cnt"][i] = len(g)
+        self.gt["onehot"].copy_(slot["oh"], non_blocking=True)
+        self.gt["classes"].copy_(slot["cl"], non_blocking=True)
+        self.gt["count"].copy_(slot["cnt"], non_blocking=True)
+        slot["ev"] = torch.cuda.Event()
+        slot["ev"].record()
 
     def _stage_image(self, batch):
         for buf, x in zip(self.image, batch):
