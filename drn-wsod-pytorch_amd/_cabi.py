@@ -24,10 +24,10 @@ _SIGS = {
     "drn_gemm_set_tile": "i",
     "drn_bias_act_fwd": "pilppQpfplpliiliip",
     "drn_counter_add": "pQp",
-    "drn_bias_act_bwd": "plpppfplplppiiiip",
+    "drn_bias_act_bwd": "plppppfplplppiiiip",
     "drn_cast2d": "ppiilliip",
     "drn_wsddn_fwd_bwd": "pliiipippppppl" + "pi" + "ifp",
-    "drn_oicr_targets": "plpi" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",
+    "drn_oicr_targets": "plpii" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",
     "drn_softmax_ce": "pliipppplppifp",
     "drn_mean_softmax": "plpiipip",
     "drn_box_reg_loss": "pliippppplppifp",

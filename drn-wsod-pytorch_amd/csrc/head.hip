@@ -37,7 +37,8 @@ struct ActParams {
   char* out; long ld_out;     // [M][ld_out] in out_dtype
   char* outT; long ld_outT;   // [N][ld_outT] in out_dtype or null
   float* colsum;       // bwd: [N] column sums (bias gradient) or null
-  const float* colscale;  // bwd: [N] per-column multiplier of grad_out (per-loss upstream grads) or null
+  const float* colscale;  // bwd: per-column multiplier of grad_out (per-loss upstream grads) or null
+  const int* colidx;      // bwd: [N] index into colscale per column (-1 = 0.0), or null (colscale is [N])
   float* colpart;      // bwd: [ceil(M/ACT_ROWS)][N] scratch for the two-stage column sums
   int M, N; long ld_in; int relu; int accumulate_colsum;
 };
@@ -60,7 +61,11 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
   const int mb0 = blockIdx.y * ROWS;
   const int mb1 = min(mb0 + ROWS, p.M);
   float csum = 0.f;
-  const float cscale = (BWD && p.colscale && n < p.N) ? p.colscale[n] : 1.f;
+  float cscale = 1.f;
+  if (BWD && p.colscale && n < p.N) {
+    const int ci = p.colidx ? p.colidx[n] : n;
+    cscale = ci >= 0 ? p.colscale[ci] : 0.f;
+  }
   const unsigned long long seed = p.seed + ((!BWD && p.seed_dev) ? p.seed_dev[0] : 0ULL);
   for (int mb = mb0; mb < mb1; mb += 64) {
 #pragma unroll 4
@@ -302,6 +307,7 @@ __global__ __launch_bounds__(256) void wsddn_stage_kernel(WsddnParams p) {
 struct TargetParams {
   const float* prev_scores; long ld_s;  // [M][ld_s], class columns 0..K-1 (bg column, if any, ignored)
   const float* prev_boxes; int box_cols;  // [M][box_cols], box_cols = 4 or 4K
+  int zero_delta_decode;               // 1: pgt box = apply_deltas(0, prev_boxes[idx]) (box_cols must be 4)
   const float* props;                  // [M][4]
   const int* img_off;                  // [n_img+1]
   const int* gt_classes; const int* gt_count; int gmax;  // [n_img][gmax], [n_img]
@@ -341,7 +347,17 @@ __global__ __launch_bounds__(1024) void oicr_targets_kernel(TargetParams p) {
       for (int q = 1; q < 16; ++q) if (sv[q] > best || (sv[q] == best && si[q] < bi)) { best = sv[q]; bi = si[q]; }
       if (bi == 0x7fffffff) bi = r0;
       const float* bx = p.prev_boxes + (long)bi * p.box_cols + (p.box_cols == 4 ? 0 : 4 * cls);
-      for (int e = 0; e < 4; ++e) { gbox[g][e] = bx[e]; p.pgt_boxes[((long)img * p.gmax + g) * 4 + e] = bx[e]; }
+      float bb[4] = {bx[0], bx[1], bx[2], bx[3]};
+      if (p.zero_delta_decode) {
+        // Box2BoxTransform.apply_deltas with all-zero deltas (box_regression.py:73-110), op for op: what a
+        // non-regressing refinement head hands to the next stage (equal to the proposal up to 1 ulp)
+        const float w = bb[2] - bb[0], h = bb[3] - bb[1];
+        const float cx = bb[0] + 0.5f * w, cy = bb[1] + 0.5f * h;
+        const float pcx = 0.f * w + cx, pcy = 0.f * h + cy;
+        const float pw = expf(0.f) * w, ph = expf(0.f) * h;
+        bb[0] = pcx - 0.5f * pw; bb[1] = pcy - 0.5f * ph; bb[2] = pcx + 0.5f * pw; bb[3] = pcy + 0.5f * ph;
+      }
+      for (int e = 0; e < 4; ++e) { gbox[g][e] = bb[e]; p.pgt_boxes[((long)img * p.gmax + g) * 4 + e] = bb[e]; }
       gw[g] = p.img_scores[img * p.K + cls];
       gcls[g] = cls;
       p.pgt_idx[img * p.gmax + g] = bi - r0;
@@ -623,7 +639,7 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
   if (!partials || M < 0 || N < 0 || splits < 1 || (!out && !outT)) return DRN_ERR_ARG;
   if (M == 0 || N == 0) return DRN_OK;
   ActParams p{partials, splits, split_stride, bias, mask, seed, drop_p, seed_dev, nullptr, (char*)out, ld_out, (char*)outT,
-              ld_outT, nullptr, nullptr, nullptr, M, N, ld_in, relu, 0};
+              ld_outT, nullptr, nullptr, nullptr, nullptr, M, N, ld_in, relu, 0};
   dim3 grid((N + 63) / 64, (M + 63) / 64), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (out_dtype == DRN_BF16) hipLaunchKernelGGL((act_kernel<DRN_BF16, DRN_BF16, false>), grid, block, 0, st, p);
@@ -633,7 +649,7 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
   return DRN_OK;
 }
 
-int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const void* saved_out,
+int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const int* colidx, const void* saved_out,
                      const float* mask, float drop_p,
                      void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
                      int accumulate_colsum, int M, int N, int out_dtype, void* stream) {
@@ -641,7 +657,7 @@ int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, c
   if (colsum && !colpart) return DRN_ERR_ARG;  // colpart: ceil(M/256)*N floats of scratch
   if (M == 0 || N == 0) return DRN_OK;
   ActParams p{grad_out, 1, 0, nullptr, mask, 0ULL, drop_p, nullptr, (const char*)saved_out, (char*)dpre, ld_out, (char*)dpreT,
-              ld_outT, colsum, colscale, colpart, M, N, ld_in, 1, accumulate_colsum};
+              ld_outT, colsum, colscale, colidx, colpart, M, N, ld_in, 1, accumulate_colsum};
   const int nparts = (M + ACT_ROWS - 1) / ACT_ROWS;
   dim3 grid((N + 63) / 64, nparts), block(256);
   hipStream_t st = (hipStream_t)stream;
@@ -681,7 +697,8 @@ int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K,
   return DRN_OK;
 }
 
-int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxes, int box_cols, const float* props,
+int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxes, int box_cols, int zero_delta_decode,
+                     const float* props,
                      const int* img_off, int n_img, const int* gt_classes, const int* gt_count, int gmax,
                      const float* img_scores, int K, const float* thresholds, const int* thr_labels, int nthr,
                      int* labels, float* weights, int* matched, float* gt_boxes, int* pgt_idx, float* pgt_boxes,
@@ -690,8 +707,10 @@ int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxe
       !weights || !matched || !gt_boxes || !pgt_idx || !pgt_boxes)
     return DRN_ERR_ARG;
   if (gmax < 1 || gmax > 128 || nthr < 1 || nthr > 3 || (box_cols != 4 && box_cols != 4 * K)) return DRN_ERR_ARG;
+  if (zero_delta_decode && box_cols != 4) return DRN_ERR_ARG;
   TargetParams p;
   p.prev_scores = prev_scores; p.ld_s = ld_s; p.prev_boxes = prev_boxes; p.box_cols = box_cols; p.props = props;
+  p.zero_delta_decode = zero_delta_decode;
   p.img_off = img_off; p.gt_classes = gt_classes; p.gt_count = gt_count; p.gmax = gmax; p.img_scores = img_scores;
   p.K = K; p.nthr = nthr;
   for (int i = 0; i < 3; ++i) p.thr[i] = i < nthr ? thresholds[i] : 0.f;

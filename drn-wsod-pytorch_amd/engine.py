@@ -323,21 +323,22 @@ class Trainer:
 
 
 class GraphedTrainStep:
-    """One full training step (preprocess + backbone of the NEXT image on a side stream, ROI heads forward, losses,
-    backward, fused SGD) captured once into a hipGraph and replayed: a step is ~130 kernel launches of 2-600 us, so
-    the eager Python host needs ~2.4 ms to enqueue what the GPU executes in ~2.6 ms; replay costs ~15 us.
+    """One full training step captured once into a hipGraph and replayed: a step is ~110 kernel launches of 2-450 us,
+    so the eager Python host needs ~2.4 ms to enqueue what the GPU executes in ~2.5 ms; a replay costs ~15 us.
 
-    Static shapes only (fixed image size, proposals per image and images per GPU — the benchmark's case and the
-    common fixed-R training case); anything else runs the eager path.  Single process: with N > 1 the gradient
-    exchange stays eager (DataParallel), so this class is used when world == 1.
+    What one replay contains (three streams, forked and joined inside the capture):
+      main      : heads forward (fc6 GEMM first, on the pooled operand prepared by the PREVIOUS replay), losses,
+                  explicit backward ... last dW GEMM, then ROIPool(+objectness) + A^T of the NEXT batch
+      side      : preprocess + frozen backbone of the NEXT batch's image (latency-bound convs under the GEMMs)
+      optimizer : per-bucket SGD under the remaining dW GEMMs and under the next batch's pooling (FusedSGD pipelined)
+    The next batch's pooling is queued behind this step's last reader of A^T (the fc6 dW GEMM), so one buffer set
+    and one graph suffice.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5).
 
-    Pipeline skew: the graph reads `image` = the NEXT batch's image (its backbone runs on the side stream and lands
-    in `feat_next`) while the heads consume `feat_cur` with the CURRENT batch's proposals/labels; the last node copies
-    feat_next -> feat_cur.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5)."""
+    Static shapes only (fixed image size, proposals per image, images per GPU: the benchmark's case and the common
+    fixed-R training case); anything else runs the eager path.  Single process: with N > 1 the gradient exchange
+    stays eager (DataParallel), so this class is used when world == 1."""
 
     def __init__(self, model, optimizer, example_batch):
-        from .structures import Boxes  # noqa: F401
-
         assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
         self.model, self.opt = model, optimizer
         self.heads = model.roi_heads
@@ -348,35 +349,31 @@ class GraphedTrainStep:
         n_img, M = len(example_batch), sum(self.nper)
         self.n_img, self.K = n_img, K
         self.image = [x["image"].to(dev).float().clone() for x in example_batch]
-        self.rois = torch.zeros((M, 5), dtype=torch.float32, device=dev)
-        self.obj = torch.zeros((M,), dtype=torch.float32, device=dev)
         off = [0]
         for n in self.nper:
             off.append(off[-1] + n)
+        mk = lambda: torch.zeros((M, 5), dtype=torch.float32, device=dev)
+        self.rois, self.rois_next = mk(), mk()
+        for t in (self.rois, self.rois_next):
+            for i in range(n_img):
+                t[off[i]: off[i + 1], 0] = float(i)
+        self.obj = torch.zeros((M,), dtype=torch.float32, device=dev)
+        self.obj_next = torch.zeros((M,), dtype=torch.float32, device=dev)
+        self.props = torch.zeros((M, 4), dtype=torch.float32, device=dev)
         self.gt = dict(onehot=torch.zeros((n_img, K), device=dev), classes=torch.zeros((n_img, K), dtype=torch.int32, device=dev),
-                       count=torch.zeros((n_img,), dtype=torch.int32, device=dev), props=None, max_rows=max(self.nper))
+                       count=torch.zeros((n_img,), dtype=torch.int32, device=dev), props=self.props, max_rows=max(self.nper))
         self.img_off = torch.tensor(off, dtype=torch.int32, device=dev)
-        for i in range(n_img):
-            self.rois[off[i]: off[i + 1], 0] = float(i)
         self.graph = None
         self.losses = None
         self._side = torch.cuda.Stream()
         self._primed = False
 
     # ---- host side of one step: stage inputs into the static buffers (tiny async copies) -----------------------
-    def _stage_heads_inputs(self, batch):
-        """Proposals are device tensors (async D2D copies).  The image-level labels are built on the host: they go
-        through a ring of PINNED staging buffers so the H2D copies are truly asynchronous - a pageable source would
-        block the host until the previous replay has drained and leave the GPU idle between replays."""
-        off = 0
-        ints = []
-        for i, x in enumerate(batch):
-            n = self.nper[i]
-            assert len(x["proposals"]) == n, "graphed step: proposals per image must stay fixed"
-            self.rois[off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
-            self.obj[off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
-            ints.append(torch.unique(x["instances"].gt_classes.cpu(), sorted=True))
-            off += n
+    def _stage_labels(self, batch):
+        """Image-level labels of the CURRENT batch.  They are built on the host and go through a ring of PINNED
+        staging buffers so the H2D copies are truly asynchronous - a pageable source would block the host until the
+        previous replay has drained and leave the GPU idle between replays."""
+        ints = [torch.unique(x["instances"].gt_classes.cpu(), sorted=True) for x in batch]
         if not hasattr(self, "_ring"):
             mk = lambda shape, dt: torch.zeros(shape, dtype=dt).pin_memory()
             self._ring = [dict(oh=mk((self.n_img, self.K), torch.float32), cl=mk((self.n_img, self.K), torch.int32),
@@ -398,18 +395,31 @@ class GraphedTrainStep:
         slot["ev"] = torch.cuda.Event()
         slot["ev"].record()
 
-    def _stage_image(self, batch):
-        for buf, x in zip(self.image, batch):
-            buf.copy_(x["image"], non_blocking=True)
+    def _stage_next(self, batch):
+        """image + proposals of the NEXT batch (device tensors: async D2D copies)"""
+        off = 0
+        for i, x in enumerate(batch):
+            n = self.nper[i]
+            assert len(x["proposals"]) == n, "graphed step: proposals per image must stay fixed"
+            self.rois_next[off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
+            self.obj_next[off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
+            self.image[i].copy_(x["image"], non_blocking=True)
+            off += n
 
     def _backbone(self):
         m = self.model
-        dtype_feat = None
         imgs = m.preprocess_image([{"image": im} for im in self.image])
         feats = m.backbone(imgs.tensor)
         f = feats[self.heads.box_in_features[0]].permute(0, 2, 3, 1)
         assert f.is_contiguous()
         return f
+
+    def _pool_next(self):
+        """pooled fc6 operand (A, A^T) of the staged next batch + hand its proposals over to the heads"""
+        self.pooled = self.engine.pool(self.feat_next, self.rois_next, self.obj_next, True, slot=0)
+        self.rois.copy_(self.rois_next)
+        self.obj.copy_(self.obj_next)
+        self.props.copy_(self.rois_next[:, 1:])
 
     def _body(self):
         """the step as it is captured"""
@@ -417,26 +427,26 @@ class GraphedTrainStep:
         self._side.wait_stream(cur)
         with torch.cuda.stream(self._side), torch.no_grad():
             self.feat_next.copy_(self._backbone())
-        self.gt["props"] = self.rois[:, 1:].contiguous()
-        losses, _ = self.engine.forward(self.feat_cur, self.rois, self.obj, True, self.img_off, self.n_img, self.gt)
+        losses, _ = self.engine.forward(None, self.rois, self.obj, True, self.img_off, self.n_img, self.gt,
+                                        pooled=self.pooled)
         sum(losses.values()).backward()
-        self.opt.step(1.0)
         cur.wait_stream(self._side)
-        self.feat_cur.copy_(self.feat_next)
+        with torch.no_grad():
+            self._pool_next()  # behind the last dW GEMM on this stream; overlaps the SGD tail on the optimizer stream
+        self.opt.step(1.0)
         return losses
 
     def prime(self, first_batch, next_batch):
         """Step 0, eagerly (so every workspace exists and the captured SGD is not the momentum-initialising first
         step), then the capture.  Returns step 0's losses."""
-        self._stage_image(first_batch)
-        with torch.no_grad():
-            f = self._backbone()
-        self.feat_cur = f.clone()
-        self.feat_next = torch.empty_like(f)
-        self._stage_image(next_batch)
-        self._stage_heads_inputs(first_batch)
-        self.opt.zero_grad()
         self.heads.train()
+        self._stage_next(first_batch)
+        with torch.no_grad():
+            self.feat_next = self._backbone().clone()
+            self._pool_next()
+        self._stage_labels(first_batch)
+        self._stage_next(next_batch)
+        self.opt.zero_grad()
         first = {k: v.detach().clone() for k, v in self._body().items()}
         self.opt.zero_grad()
         torch.cuda.synchronize()
@@ -447,10 +457,11 @@ class GraphedTrainStep:
         return first
 
     def step(self, batch, next_batch):
-        """run the step for `batch`; `next_batch`'s image is fed to the side-stream backbone of the same replay"""
+        """run the step for `batch` (which must be the batch passed as `next_batch` to the previous call); the same
+        replay prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM)"""
         if not self._primed:
             return self.prime(batch, next_batch)
-        self._stage_heads_inputs(batch)
-        self._stage_image(next_batch)
+        self._stage_labels(batch)
+        self._stage_next(next_batch)
         self.graph.replay()
         return self.losses

@@ -253,7 +253,7 @@ class _TrainFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, anchor, engine, state):
         ctx.engine, ctx.state = engine, state
-        return tuple(l.clone() for l in state["loss_list"])
+        return tuple(state["loss_list"])
 
     @staticmethod
     def backward(ctx, *gouts):
@@ -493,14 +493,14 @@ class _HeadEngine:
         for m in [h.box_predictor] + list(h.box_refinery[: h.refine_K]):
             assert m.loss_weight.get("loss_cls", 1.0) == 1.0, "loss_cls weight != 1 is not used by any config"
         loss_names = ["loss_cls"]
-        loss_list = [ops.sum_small(loss_part).view(())]
+        loss_list = [(loss_part if n_img == 1 else ops.sum_small(loss_part)).view(())]
         head_cols = [("cls", 0), ("det", 0)]
-        prev_scores, prev_boxes = scores, gt["props"]
+        prev_scores, prev_boxes, prev_zero = scores, gt["props"], False
         aux = dict(scores=scores, img_scores=img_scores, targets=[])
         thr = h.proposal_matcher.thresholds[1:-1]
         for k in range(h.refine_K):
             tg = ops.oicr_targets(prev_scores, prev_boxes, gt["props"], img_off, n_img, gt["classes"], gt["count"],
-                                  img_scores, K, thr, h.proposal_matcher.labels)
+                                  img_scores, K, thr, h.proposal_matcher.labels, zero_delta_decode=prev_zero)
             probs, loss = ops.softmax_ce(w["logits"], col["r%d" % k], K + 1, tg["labels"], tg["weights"], dlogits=dl)
             loss_names.append("loss_cls_r%d" % k)
             loss_list.append(loss.view(()))
@@ -514,9 +514,11 @@ class _HeadEngine:
                 loss_names.append("loss_box_reg_r%d" % k)
                 loss_list.append(lreg.view(()))
                 head_cols.append(("b%d" % k, len(loss_list) - 1))
-                prev_boxes = ops.apply_deltas(w["logits"], gt["props"], K, bw, col0=col["b%d" % k])
+                prev_boxes, prev_zero = ops.apply_deltas(w["logits"], gt["props"], K, bw, col0=col["b%d" % k]), False
             else:
-                prev_boxes = ops.apply_deltas(None, gt["props"], K, bw)
+                # a non-regressing head passes apply_deltas(0, proposals) on: only the G mined boxes are ever read,
+                # so the decode happens inside the next targets kernel instead of materialising [M, 4K] boxes
+                prev_boxes, prev_zero = gt["props"], True
         state = dict(w=w, M=M, dtype=dtype, loss_list=loss_list, head_cols=head_cols, masks=masks, drop_p=drop_p,
                      aux=aux)
         outs = _TrainFn.apply(self.anchor, self, state)
@@ -536,16 +538,21 @@ class _HeadEngine:
         dev = self.arena_w.device
         # per-loss upstream gradients -> per-column scale of dlogits (stays on the device)
         g = [torch.zeros((), device=dev) if x is None else x.float().reshape(()) for x in gouts]
-        width = {n: c for n, _, _, c in self.cols}
-        start = {n: o for n, _, o, _ in self.cols}
-        trained = dict(st["head_cols"])
-        colscale = torch.cat([(g[trained[n]] if n in trained else torch.zeros((), device=dev)).expand(width[n])
-                              for n in sorted(width, key=lambda n: start[n])]).contiguous()
+        colscale = torch.stack(g)  # one entry per loss; columns find theirs through the static index table
+        key = tuple(st["head_cols"])
+        if getattr(self, "_colidx_key", None) != key:
+            trained = dict(st["head_cols"])
+            idx = torch.full((NH,), -1, dtype=torch.int32)
+            for n, _, o, c in self.cols:
+                if n in trained:
+                    idx[o: o + c] = trained[n]
+            self._colidx, self._colidx_key = idx.to(dev), key
+        colidx = self._colidx
         acc = self._grads_valid and fc1.weight.grad is not None
         bo, _ = self._seg[self.cols[0][0] + ".bias"]
         wo, _ = self._seg[self.cols[0][0] + ".weight"]
         # heads: dS, dS^T, bias grads
-        ops.bias_act_bwd(w["dlogits"], M, NH, colscale=colscale, dpre=w["dS"], dpreT=w["dST"],
+        ops.bias_act_bwd(w["dlogits"], M, NH, colscale=colscale, colidx=colidx, dpre=w["dS"], dpreT=w["dST"],
                          colsum=self.arena_g[bo: bo + NH], accumulate_colsum=acc, colpart=w["colpart"])
         ops.gemm_nt(w["dST"], w["H2T"], NH, D2, Mp, out=self.arena_g[wo: wo + NH * D2].view(1, NH, D2), accumulate=acc)
         ops.gemm_nt(w["dS"], sh["WhT"], M, D2, kp(NH), out=w["dH2"].view(1, M, D2))

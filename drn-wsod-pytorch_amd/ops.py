@@ -132,14 +132,15 @@ def bias_act_fwd(partials, M, N, bias=None, relu=True, mask=None, seed=0, drop_p
 
 
 def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=None, dpre=None, dpreT=None, colsum=None,
-                 accumulate_colsum=False, colpart=None):
+                 accumulate_colsum=False, colpart=None, colidx=None):
     ref = dpre if dpre is not None else dpreT
     if saved is not None and dpre is not None:
         assert _2d(saved) == _2d(dpre)
     ld_out = _2d(dpre) if dpre is not None else (_2d(saved) if saved is not None else 0)
     if colsum is not None and colpart is None:
         colpart = torch.empty(((M + 255) // 256, N), dtype=torch.float32, device=grad_out.device)
-    C.call("drn_bias_act_bwd", C.ptr(grad_out), _2d(grad_out), C.ptr(colscale), C.ptr(saved), C.ptr(mask), float(drop_p),
+    C.call("drn_bias_act_bwd", C.ptr(grad_out), _2d(grad_out), C.ptr(colscale), C.ptr(colidx), C.ptr(saved), C.ptr(mask),
+           float(drop_p),
            C.ptr(dpre), ld_out, C.ptr(dpreT), _2d(dpreT) if dpreT is not None else 0, C.ptr(colsum), C.ptr(colpart),
            int(accumulate_colsum), M, N, C.dt(ref.dtype), C.stream())
 
@@ -162,7 +163,7 @@ def wsddn_fwd_bwd(logits, c_cls, c_det, K, img_off, n_img, gt_onehot, dlogits=No
 
 
 def oicr_targets(prev_scores, prev_boxes, props, img_off, n_img, gt_classes, gt_count, img_scores, K,
-                 thresholds=(0.5,), labels=(0, 1)):
+                 thresholds=(0.5,), labels=(0, 1), zero_delta_decode=False):
     M = props.shape[0]
     dev = props.device
     gmax = gt_classes.shape[1]
@@ -170,10 +171,11 @@ def oicr_targets(prev_scores, prev_boxes, props, img_off, n_img, gt_classes, gt_
                weights=torch.empty((M,), dtype=torch.float32, device=dev),
                matched=torch.empty((M,), dtype=torch.int32, device=dev),
                gt_boxes=torch.empty((M, 4), dtype=torch.float32, device=dev),
-               pgt_idx=torch.zeros((n_img, gmax), dtype=torch.int32, device=dev),
-               pgt_boxes=torch.zeros((n_img, gmax, 4), dtype=torch.float32, device=dev))
+               pgt_idx=torch.empty((n_img, gmax), dtype=torch.int32, device=dev),
+               pgt_boxes=torch.empty((n_img, gmax, 4), dtype=torch.float32, device=dev))
     th, lb = C.host_floats(thresholds), C.host_ints(labels)
-    C.call("drn_oicr_targets", C.ptr(prev_scores), _2d(prev_scores), C.ptr(prev_boxes), prev_boxes.shape[1], C.ptr(props),
+    C.call("drn_oicr_targets", C.ptr(prev_scores), _2d(prev_scores), C.ptr(prev_boxes), prev_boxes.shape[1],
+           int(zero_delta_decode), C.ptr(props),
            C.ptr(img_off), n_img, C.ptr(gt_classes), C.ptr(gt_count), gmax, C.ptr(img_scores), K,
            ctypes.cast(th, ctypes.c_void_p), ctypes.cast(lb, ctypes.c_void_p), len(thresholds), C.ptr(out["labels"]),
            C.ptr(out["weights"]), C.ptr(out["matched"]), C.ptr(out["gt_boxes"]), C.ptr(out["pgt_idx"]),
@@ -184,7 +186,7 @@ def oicr_targets(prev_scores, prev_boxes, props, img_off, n_img, gt_classes, gt_
 def softmax_ce(logits, col0, ncol, labels=None, weights=None, dlogits=None, loss_scale=1.0):
     M = logits.shape[0]
     probs = torch.empty((M, ncol), dtype=torch.float32, device=logits.device)
-    loss = torch.zeros((1,), dtype=torch.float32, device=logits.device) if labels is not None else None
+    loss = torch.empty((1,), dtype=torch.float32, device=logits.device) if labels is not None else None
     scratch = torch.empty((2 * ((M + 15) // 16),), dtype=torch.float32, device=logits.device) if labels is not None else None
     C.call("drn_softmax_ce", C.ptr(logits), _2d(logits), col0, ncol, C.ptr(labels), C.ptr(weights), C.ptr(probs),
            C.ptr(dlogits), _2d(dlogits) if dlogits is not None else 0, C.ptr(loss), C.ptr(scratch), M, float(loss_scale),

@@ -91,9 +91,10 @@ int drn_counter_add(unsigned long long* counter, unsigned long long inc, void* s
 
 /* autograd of the above: dpre = grad_out * dropout_mult * (saved_out > 0); colsum[n] = sum_m dpre (bias
  * gradient, fixed summation order); saved_out == NULL means "no activation"; colscale [N] (optional)
- * multiplies grad_out per column (per-loss upstream gradients stay on the device); colpart = scratch of
+ * multiplies grad_out per column (per-loss upstream gradients stay on the device): column n uses
+ * colscale[colidx ? colidx[n] : n] (index -1 = 0); colpart = scratch of
  * ceil(M/256)*N floats for the two-stage (deterministic) column sums, required with colsum. */
-int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const void* saved_out,
+int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const int* colidx, const void* saved_out,
                      const float* mask, float drop_p,
                      void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
                      int accumulate_colsum, int M, int N, int out_dtype, void* stream);
@@ -111,8 +112,10 @@ int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K,
 
 /* OICRROIHeads.get_pgt (roi_heads_oicr.py:491-567) + ROIHeads.label_and_sample_proposals
  * (roi_heads.py:255-353; pairwise_iou structures/boxes.py:329-361; Matcher modeling/matcher.py:61-103).
- * prev_boxes [M][box_cols] with box_cols = 4 (Boxes path) or 4K (class-specific decoded boxes). */
-int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxes, int box_cols, const float* props,
+ * prev_boxes [M][box_cols] with box_cols = 4 (Boxes path) or 4K (class-specific decoded boxes);
+ * zero_delta_decode = 1 applies apply_deltas(0, .) to the selected box (what a non-regressing head passes on). */
+int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxes, int box_cols, int zero_delta_decode,
+                     const float* props,
                      const int* img_off, int n_img, const int* gt_classes, const int* gt_count, int gmax,
                      const float* img_scores, int K, const float* thresholds_host, const int* thr_labels_host,
                      int nthr, int* labels, float* weights, int* matched, float* gt_boxes, int* pgt_idx,
