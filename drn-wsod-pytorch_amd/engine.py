@@ -363,7 +363,6 @@ class GraphedTrainStep:
         self.gt = dict(onehot=torch.zeros((n_img, K), device=dev), classes=torch.zeros((n_img, K), dtype=torch.int32, device=dev),
                        count=torch.zeros((n_img,), dtype=torch.int32, device=dev), props=self.props, max_rows=max(self.nper))
         self.img_off = torch.tensor(off, dtype=torch.int32, device=dev)
-        self.graph = None
         self.losses = None
         self._side = torch.cuda.Stream()
         self._primed = False
@@ -421,38 +420,43 @@ class GraphedTrainStep:
         self.obj.copy_(self.obj_next)
         self.props.copy_(self.rois_next[:, 1:])
 
-    def _body(self):
-        """the step as it is captured"""
-        cur = torch.cuda.current_stream()
-        start = torch.cuda.Event()
-        start.record(cur)
-
-        def fork_backbone():
-            # Called right after the fc6 GEMM has been queued.  The HIP runtime submits a replayed graph's nodes in
-            # creation order at ~9 us per node: capturing the 49 backbone nodes first keeps the fc6 GEMM from being
-            # submitted for ~0.4 ms, capturing them last starts the (latency-bound, ~1.2 ms when co-running) backbone
-            # chain too late for the end-of-step pooling.  Here the 0.4 ms fc6 GEMM covers their submission.  The
-            # branch hangs off the event recorded at the start of the step, so it depends on nothing the heads do.
-            self._side.wait_event(start)
-            with torch.cuda.stream(self._side), torch.no_grad():
-                self.feat_next.copy_(self._backbone())
-
-        self.engine.after_fc6_hook = fork_backbone
-        try:
-            losses, _ = self.engine.forward(None, self.rois, self.obj, True, self.img_off, self.n_img, self.gt,
-                                            pooled=self.pooled)
-        finally:
-            self.engine.after_fc6_hook = None
-        sum(losses.values()).backward()
-        cur.wait_stream(self._side)
+    # ---- the three captured pieces ---------------------------------------------------------------------------
+    def _bb_body(self):
         with torch.no_grad():
-            self._pool_next()  # behind the last dW GEMM on this stream; overlaps the SGD tail on the optimizer stream
-        self.opt.step(1.0)
+            self.feat_next.copy_(self._backbone())
+
+    def _main_body(self):
+        losses, _ = self.engine.forward(None, self.rois, self.obj, True, self.img_off, self.n_img, self.gt,
+                                        pooled=self.pooled)
+        sum(losses.values()).backward()  # pipelined SGD buckets fork onto the optimizer stream in here
+        self.opt.step(1.0)               # joins the optimizer stream
+        return losses
+
+    def _pool_body(self):
+        with torch.no_grad():
+            self._pool_next()
+
+    def _run(self, eager):
+        """One step = three pieces on two torch streams, ordered by events exactly like eager multi-stream code.  (A
+        single graph with the backbone as an internal branch was measured first: the HIP graph executor starts that
+        branch late whatever the capture order, so the 49 latency-bound conv nodes ended up on the critical path.)
+          side : backbone graph of the NEXT image     - may start once the previous step's pooling has read feat_next
+          main : heads / losses / backward / SGD graph - reads the operand pooled by the previous step
+          main : pooling graph of the NEXT batch       - behind this step's last reader of A^T, after the backbone"""
+        main = torch.cuda.current_stream()
+        self._side.wait_stream(main)  # staged image is in place; previous pooling has consumed feat_next
+        with torch.cuda.stream(self._side):
+            self._bb_body() if eager else self.g_bb.replay()
+            done = torch.cuda.Event()
+            done.record(self._side)
+        losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
+        main.wait_event(done)
+        self._pool_body() if eager else self.g_pool.replay()
         return losses
 
     def prime(self, first_batch, next_batch):
         """Step 0, eagerly (so every workspace exists and the captured SGD is not the momentum-initialising first
-        step), then the capture.  Returns step 0's losses."""
+        step), then the captures.  Returns step 0's losses."""
         self.heads.train()
         self._stage_next(first_batch)
         with torch.no_grad():
@@ -461,21 +465,24 @@ class GraphedTrainStep:
         self._stage_labels(first_batch)
         self._stage_next(next_batch)
         self.opt.zero_grad()
-        first = {k: v.detach().clone() for k, v in self._body().items()}
+        first = {k: v.detach().clone() for k, v in self._run(eager=True).items()}
         self.opt.zero_grad()
         torch.cuda.synchronize()
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.losses = self._body()
+        self.g_bb, self.g_main, self.g_pool = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g_bb):
+            self._bb_body()
+        with torch.cuda.graph(self.g_main):
+            self.losses = self._main_body()
+        with torch.cuda.graph(self.g_pool):
+            self._pool_body()
         self._primed = True
         return first
 
     def step(self, batch, next_batch):
         """run the step for `batch` (which must be the batch passed as `next_batch` to the previous call); the same
-        replay prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM)"""
+        step prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM)"""
         if not self._primed:
             return self.prime(batch, next_batch)
         self._stage_labels(batch)
         self._stage_next(next_batch)
-        self.graph.replay()
-        return self.losses
+        return self._run(eager=False)
