@@ -44,9 +44,9 @@ struct ActParams {
 };
 
 // 64 columns x ROWS_PER_BLOCK rows per block (64x64 tiles through LDS for the transposed copy).
-// bwd: per-block partial column sums go to colpart[blockIdx.y][N]; colsum_reduce_kernel adds them in a
+// bwd: per-block partial column sums go to colpart[blockIdx.y][N] (ceil(M/64) partials); colsum_reduce_kernel adds them in a
 // fixed order (deterministic bias gradients, no float atomics).
-constexpr int ACT_ROWS = 256;
+constexpr int ACT_ROWS = 64;
 
 template <int DT_OUT, int DT_SAVED, bool BWD>
 __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
@@ -654,7 +654,7 @@ int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, c
                      void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
                      int accumulate_colsum, int M, int N, int out_dtype, void* stream) {
   if (!grad_out || M < 0 || N < 0) return DRN_ERR_ARG;
-  if (colsum && !colpart) return DRN_ERR_ARG;  // colpart: ceil(M/256)*N floats of scratch
+  if (colsum && !colpart) return DRN_ERR_ARG;  // colpart: ceil(M/64)*N floats of scratch
   if (M == 0 || N == 0) return DRN_OK;
   ActParams p{grad_out, 1, 0, nullptr, mask, 0ULL, drop_p, nullptr, (const char*)saved_out, (char*)dpre, ld_out, (char*)dpreT,
               ld_outT, colsum, colscale, colidx, colpart, M, N, ld_in, 1, accumulate_colsum};

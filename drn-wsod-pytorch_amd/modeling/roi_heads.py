@@ -409,7 +409,7 @@ class _HeadEngine:
             w.update(H1T=z(D1, Mp), H2T=z(D2, Mp), dlogits=z(M, NHp, torch.float32), dS=z(M, NHp),
                      dST=z(self.NH, Mp), dH2=z(M, D2, torch.float32), dP2=z(M, kp(D2)), dP2T=z(D2, Mp),
                      dH1=z(M, D1, torch.float32), dP1T=z(D1, Mp),
-                     colpart=z((M + 255) // 256, max(D1, D2, self.NH), torch.float32))
+                     colpart=z((M + 63) // 64, max(D1, D2, self.NH), torch.float32))
         self._ws[key] = w
         return w
 

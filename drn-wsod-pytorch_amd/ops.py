@@ -138,7 +138,7 @@ def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=Non
         assert _2d(saved) == _2d(dpre)
     ld_out = _2d(dpre) if dpre is not None else (_2d(saved) if saved is not None else 0)
     if colsum is not None and colpart is None:
-        colpart = torch.empty(((M + 255) // 256, N), dtype=torch.float32, device=grad_out.device)
+        colpart = torch.empty(((M + 63) // 64, N), dtype=torch.float32, device=grad_out.device)
     C.call("drn_bias_act_bwd", C.ptr(grad_out), _2d(grad_out), C.ptr(colscale), C.ptr(colidx), C.ptr(saved), C.ptr(mask),
            float(drop_p),
            C.ptr(dpre), ld_out, C.ptr(dpreT), _2d(dpreT) if dpreT is not None else 0, C.ptr(colsum), C.ptr(colpart),

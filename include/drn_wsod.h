@@ -93,7 +93,7 @@ int drn_counter_add(unsigned long long* counter, unsigned long long inc, void* s
  * gradient, fixed summation order); saved_out == NULL means "no activation"; colscale [N] (optional)
  * multiplies grad_out per column (per-loss upstream gradients stay on the device): column n uses
  * colscale[colidx ? colidx[n] : n] (index -1 = 0); colpart = scratch of
- * ceil(M/256)*N floats for the two-stage (deterministic) column sums, required with colsum. */
+ * ceil(M/64)*N floats for the two-stage (deterministic) column sums, required with colsum. */
 int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const int* colidx, const void* saved_out,
                      const float* mask, float drop_p,
                      void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
