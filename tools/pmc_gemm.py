@@ -1,0 +1,23 @@
+"""Launch the roofline kernel (fc6 forward GEMM of BASELINE configs[1]) a few times on its own, for the PMC passes:
+  rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out1 -- python tools/pmc_gemm.py
+  rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out2 -- python tools/pmc_gemm.py
+(separate passes: FETCH_SIZE needs 3 TCC slots, WRITE_SIZE 2 - MI355X_MICROARCH.md, rocprofv3 PMC slots)."""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from __graft_entry__ import load_package
+
+load_package()
+ops = importlib.import_module("drn_wsod_pytorch_amd.ops")
+M, N, K, S = 2000, 2048, 50176, 4
+A = (torch.randn((M, K), device="cuda") * 0.5).to(torch.bfloat16)
+B = (torch.randn((N, K), device="cuda") * 0.05).to(torch.bfloat16)
+out = torch.empty((S, M, N), dtype=torch.float32, device="cuda")
+for _ in range(6):
+    ops.gemm_nt(A, B, M, N, K, out=out, splits=S)
+torch.cuda.synchronize()
+print("done")
