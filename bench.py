@@ -125,6 +125,19 @@ def cpu_baseline(batches, n_steps=2):
                       "1 warm-up step; oracle/wsod_oracle.py on torch-CPU + oracle/roi_ops.c" % n_steps}
 
 
+def pmc_traffic(shape):
+    """HBM bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
+    WRITE_SIZE run separately on tools/pmc_gemm.py, corrected as profiles/r1_04_pmc_fc6_gemm.json records). PMC
+    counters cannot be collected from inside this process, so the value is the recorded measurement for exactly this
+    kernel and shape, or None when the shape differs."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_04_pmc_fc6_gemm.json")
+    try:
+        rec = json.load(open(path))
+    except OSError:
+        return None
+    return rec["traffic_bytes_per_launch"] if tuple(rec["shape"]) == tuple(shape) else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -231,7 +244,7 @@ def main():
             ms = sum(t for t, _ in fwd) / len(fwd)
             achieved = fwd[0][1] / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": None,
+                    "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic((R, D1, K1)),
                     "kernel": "gemm_nt256_kernel<bf16> (fc6 fwd: [%d x %d] . [%d x %d]^T, split-K 4)" % (R, K1, D1, K1),
                     "avg_launch_ms": ms, "launches_timed": len(fwd),
                     "timed_in": "eager warm-up steps of this run (HIP events on the launch stream)" if use_graph

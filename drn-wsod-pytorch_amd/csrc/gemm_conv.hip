@@ -175,10 +175,14 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
   constexpr int MI = BM / 64, NJ = BN / 64;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  // (tile, split) are linearised together before the XCD remap: one XCD then owns a contiguous
+  // run of tiles of ONE K-split (a 4 x tiles_n patch), so its L2 fetches each operand panel once.
+  const int tiles = tiles_m * tiles_n;
+  const int logical = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, tiles * gridDim.y);
+  const int split = logical / tiles;
   int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+  tile_coords(logical - split * tiles, tiles_m, tiles_n, tm, tn);
   const int bm = tm * BM, bn = tn * BN;
-  const int split = blockIdx.y;
   const int nslab = p.K * ES / 128;
   const int s0 = split * p.k_slabs_per_split;
   const int s1 = s0 + p.k_slabs_per_split < nslab ? s0 + p.k_slabs_per_split : nslab;
@@ -229,10 +233,14 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   constexpr int BM = 256, BN = 256, MI = 4, NJ = 2;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
   const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  // (tile, split) are linearised together before the XCD remap: one XCD then owns a contiguous
+  // run of tiles of ONE K-split (a 4 x tiles_n patch), so its L2 fetches each operand panel once.
+  const int tiles = tiles_m * tiles_n;
+  const int logical = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, tiles * gridDim.y);
+  const int split = logical / tiles;
   int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+  tile_coords(logical - split * tiles, tiles_m, tiles_n, tm, tn);
   const int bm = tm * BM, bn = tn * BN;
-  const int split = blockIdx.y;
   const int nslab = p.K * ES / 128;
   const int s0 = split * p.k_slabs_per_split;
   const int s1 = s0 + p.k_slabs_per_split < nslab ? s0 + p.k_slabs_per_split : nslab;
