@@ -18,7 +18,7 @@ _SIGS = {
     "drn_preprocess_nhwc": "piiipiiippip",
     "drn_conv2d_nhwc": "pppppp" + "iiiiiiiiii" + "lll" + "iip",
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
-    "drn_roi_pool_nhwc": "ppppp" + "iiiiii" + "f" + "l" + "iiiiip",
+    "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliilip",
     "drn_gemm_set_tile": "i",

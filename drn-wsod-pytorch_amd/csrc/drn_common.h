@@ -26,12 +26,9 @@ typedef unsigned short bf16_t;  // storage type
 __device__ __forceinline__ float bf16_to_f32(bf16_t v) {
   return __builtin_bit_cast(float, (uint32_t)v << 16);
 }
-// round-to-nearest-even, NaN preserved (same as torch's float->bfloat16)
+// round-to-nearest-even, NaN preserved (same as torch's float->bfloat16): gfx950's v_cvt_pk_bf16_f32
 __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
-  uint32_t u = __builtin_bit_cast(uint32_t, f);
-  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-  u += 0x7fffu + ((u >> 16) & 1u);
-  return (bf16_t)(u >> 16);
+  return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
 template <int DT> struct ElemOf;

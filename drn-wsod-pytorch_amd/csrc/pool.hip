@@ -92,6 +92,8 @@ struct RoiParams {
   long ld_out;
   int sampling_ratio, aligned;
   int lds_px;  // pixels of staging LDS available per block (0 = direct path only)
+  char* out_t;   // optional transposed copy [C*P*P][ld_out_t] (column = roi), or null
+  long ld_out_t;
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -327,6 +329,150 @@ __global__ __launch_bounds__(256) void roi_pool7_kernel(RoiParams p) {
   }
 }
 
+// 7x7 ROIPool, whole-map variant: when a CH-channel slice of one image's feature map fits in LDS (C4/DC5 maps of
+// VOC-sized images: 14x14 .. 28x28 pixels) a block stages that slice ONCE and pools ROI_GROUP = 8 consecutive ROIs
+// out of it - no per-ROI trip to L2, two barriers per block instead of three per (ROI, chunk).  The [8][CH*49] result
+// tile leaves LDS twice: as the 8 row runs of A (16-B stores, k = c*49 + bin) and, when out_t is given, as CH*49
+// 16-B column runs of A^T (8 ROIs wide), which replaces the separate 2 x 205 MB transpose pass of the fc6 operand.
+// Block ids are XCD-remapped chunk-major, so the 8 blocks that complete one 128-B line of A^T share an XCD's L2.
+// two packed bf16 -> two packed int16 with the same ordering (and back: the map is an involution); lets window
+// maxima run as v_pk_max_i16 on whole 32-bit words.  -0 orders below +0, NaNs order as large magnitudes.
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ int bf16x2_order(int x) {
+  const s16x2_t v = __builtin_bit_cast(s16x2_t, x);
+  const s16x2_t m = (v >> (short)15) & (short)0x7fff;
+  return __builtin_bit_cast(int, (s16x2_t)(v ^ m));
+}
+__device__ __forceinline__ int pk_max_i16(int a, int b) {
+  return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b)));
+}
+
+constexpr int ROI_GROUP = 8;
+template <int DT, int CH>
+__global__ __launch_bounds__(256) void roi_pool7_map_kernel(RoiParams p) {
+  using E = ElemOf<DT>;
+  using T = typename E::type;
+  constexpr int PP = 49, ES = DT == DRN_BF16 ? 2 : 4;
+  constexpr int RUN = CH * PP;       // outputs per ROI in this chunk
+  constexpr int VPL = CH * ES / 16;  // 16-B vectors per pixel
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = p.H * p.W;
+  char* map = smem;                                          // [HW][CH]
+  T* tile = (T*)(smem + (((long)HW * CH * ES + 15) & ~15L));  // [ROI_GROUP][RUN]
+  __shared__ int hb[ROI_GROUP][7][2], wb[ROI_GROUP][7][2], bidx[ROI_GROUP];
+  __shared__ float mulv[ROI_GROUP];
+  const int ngroups = (p.M + ROI_GROUP - 1) / ROI_GROUP;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int chunk = logical / ngroups, group = logical - chunk * ngroups;
+  const int c0 = chunk * CH, m0 = group * ROI_GROUP;
+  const int nr = min(ROI_GROUP, p.M - m0);
+  const int tid = threadIdx.x;
+  if (tid < ROI_GROUP * 7) {
+    const int r = tid / 7, i = tid - r * 7;
+    if (r < nr) {
+      const float* roi = p.rois + 5 * (long)(m0 + r);
+      const int x1 = (int)roundf(roi[1] * p.scale), y1 = (int)roundf(roi[2] * p.scale);
+      const int x2 = (int)roundf(roi[3] * p.scale), y2 = (int)roundf(roi[4] * p.scale);
+      const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+      const float bin_h = (float)rh / 7.f, bin_w = (float)rw / 7.f;
+      hb[r][i][0] = min(max((int)floorf((float)i * bin_h) + y1, 0), p.H);
+      hb[r][i][1] = min(max((int)ceilf((float)(i + 1) * bin_h) + y1, 0), p.H);
+      wb[r][i][0] = min(max((int)floorf((float)i * bin_w) + x1, 0), p.W);
+      wb[r][i][1] = min(max((int)ceilf((float)(i + 1) * bin_w) + x1, 0), p.W);
+      if (i == 0) {
+        bidx[r] = (int)roi[0];
+        mulv[r] = p.obj ? p.obj[m0 + r] + 1.f : 1.f;
+      }
+    }
+  }
+  __syncthreads();
+  const int r = tid >> 5, lane = tid & 31;
+  for (int r0 = 0; r0 < nr;) {  // one pass per run of ROIs on the same image (one pass unless a group straddles images)
+    const int b = bidx[r0];
+    int r1 = r0 + 1;
+    while (r1 < nr && bidx[r1] == b) ++r1;
+    const char* fb = p.feat + ((long)b * HW * p.C + c0) * ES;
+    for (int i = tid; i < HW * VPL; i += 256) {
+      const int px = i / VPL, v = i - px * VPL;
+      i32x4_t x = *(const i32x4_t*)(fb + (long)px * p.C * ES + v * 16);
+      if constexpr (DT == DRN_BF16) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
+      }
+      *(i32x4_t*)(map + (long)i * 16) = x;
+    }
+    __syncthreads();
+    if (r >= r0 && r < r1) {
+      const float mul = mulv[r];
+      T* trow = tile + (long)r * RUN;
+      if constexpr (DT == DRN_BF16) {
+        // lane = (channel octet, bin subset): one 16-B LDS read feeds four packed int16 maxima (8 channels)
+        constexpr int NOCT = CH / 8, NSUB = 32 / NOCT;
+        const int oct = lane % NOCT, bs = lane / NOCT;
+        for (int bin = bs; bin < PP; bin += NSUB) {
+          const int ph = bin / 7, pw = bin - ph * 7;
+          const int hs = hb[r][ph][0], he = hb[r][ph][1], ws = wb[r][pw][0], we = wb[r][pw][1];
+          const int lo = (int)0x80008000u;
+          i32x4_t acc = {lo, lo, lo, lo};
+          for (int h = hs; h < he; ++h) {
+            const char* row = map + ((long)(h * p.W) * CH + oct * 8) * 2;
+            for (int w = ws; w < we; ++w) {
+              const i32x4_t x = *(const i32x4_t*)(row + (long)w * CH * 2);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[e] = pk_max_i16(acc[e], x[e]);
+            }
+          }
+          const bool empty = he <= hs || we <= ws;
+          bf16_t* dst = trow + (oct * 8) * PP + bin;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t y = (uint32_t)bf16x2_order(acc[e]);
+            const float f0 = empty ? 0.f : __builtin_bit_cast(float, y << 16);
+            const float f1 = empty ? 0.f : __builtin_bit_cast(float, y & 0xffff0000u);
+            dst[(2 * e) * PP] = f32_to_bf16(f0 * mul);
+            dst[(2 * e + 1) * PP] = f32_to_bf16(f1 * mul);
+          }
+        }
+      } else {
+        for (int u = lane; u < CH * PP; u += 32) {
+          const int bin = u / CH, cu = u - bin * CH;
+          const int ph = bin / 7, pw = bin - ph * 7;
+          const int hs = hb[r][ph][0], he = hb[r][ph][1], ws = wb[r][pw][0], we = wb[r][pw][1];
+          float b0 = (he <= hs || we <= ws) ? 0.f : -FLT_MAX;
+          for (int h = hs; h < he; ++h)
+            for (int w = ws; w < we; ++w) b0 = fmaxf(b0, *(const float*)(map + ((long)(h * p.W + w) * CH + cu) * 4));
+          trow[cu * PP + bin] = b0 * mul;
+        }
+      }
+    }
+    __syncthreads();
+    r0 = r1;
+  }
+  // A rows: nr contiguous runs of RUN elements
+  constexpr int VROW = RUN * ES / 16;
+  for (int v = tid; v < nr * VROW; v += 256) {
+    const int rr = v / VROW, q = v - rr * VROW;
+    *(i32x4_t*)(p.out + ((long)(m0 + rr) * p.ld_out + (long)c0 * PP) * ES + (long)q * 16) =
+        *(const i32x4_t*)((const char*)tile + ((long)rr * RUN * ES + (long)q * 16));
+  }
+  if (p.out_t) {
+    T* ot = (T*)p.out_t + (long)c0 * PP * p.ld_out_t + m0;
+    if (nr == ROI_GROUP) {  // launcher guarantees 16-B alignment of every 8-ROI run
+      for (int idx = tid; idx < RUN; idx += 256) {
+        T vals[ROI_GROUP];
+#pragma unroll
+        for (int rr = 0; rr < ROI_GROUP; ++rr) vals[rr] = tile[(long)rr * RUN + idx];
+        i32x4_t* dst = (i32x4_t*)(ot + (long)idx * p.ld_out_t);
+#pragma unroll
+        for (int q = 0; q < ROI_GROUP * ES / 16; ++q) dst[q] = ((const i32x4_t*)vals)[q];
+      }
+    } else {
+      for (int idx = tid; idx < RUN; idx += 256)
+        for (int rr = 0; rr < nr; ++rr) ot[(long)idx * p.ld_out_t + rr] = tile[(long)rr * RUN + idx];
+    }
+  }
+}
+
 // bf16 -> bf16 transpose with 16-B global accesses on both sides (the A -> A^T copy of the fc6 operand is
 // 2 x 205 MB per step): 64x64 tile, rows read as 8-element vectors, written transposed into LDS, re-read as vectors.
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
@@ -397,6 +543,20 @@ inline int grid_for(long total, int block) {
 
 }  // namespace
 
+extern "C" int drn_transpose2d(const void* in, void* out, int rows, int cols, long ld_in, long ld_out, int in_dtype,
+                               int out_dtype, void* stream);
+
+template <int DT, int CH>
+static bool launch_roi_map(const RoiParams& p, hipStream_t st) {
+  const int es = DT == DRN_BF16 ? 2 : 4;
+  if (p.C % CH) return false;
+  const size_t smem = (((size_t)p.H * p.W * CH * es + 15) & ~(size_t)15) + (size_t)ROI_GROUP * CH * 49 * es;
+  if (smem > 80 * 1024) return false;  // keep >= 2 blocks per CU
+  const int ngroups = (p.M + ROI_GROUP - 1) / ROI_GROUP;
+  hipLaunchKernelGGL((roi_pool7_map_kernel<DT, CH>), dim3((p.C / CH) * ngroups), dim3(256), smem, st, p);
+  return true;
+}
+
 extern "C" {
 
 int drn_preprocess_nhwc(const float* img_chw, int C, int H, int W, void* out_nhwc, int Hp, int Wp, int Cp,
@@ -436,16 +596,39 @@ int drn_maxpool2x2_nhwc(const void* x, void* y, int Nb, int H, int W, int C, int
 }
 
 // mode 0 = RoIPool, 1 = ROIAlign. in_dtype = feature dtype, out_dtype = pooled dtype.
-int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectness, void* out, int32_t* argmax, int N,
-                      int H, int W, int C, int P, int M, float spatial_scale, long ld_out, int mode,
-                      int sampling_ratio, int aligned, int in_dtype, int out_dtype, void* stream) {
+int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
+                      int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
+                      long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
+                      void* stream) {
   if (!feat || !rois || !out || P < 1 || P * P > RP_MAXBIN || M < 0 || (mode != 0 && mode != 1)) return DRN_ERR_ARG;
-  if (ld_out < (long)C * P * P) return DRN_ERR_ARG;
+  if (ld_out < (long)C * P * P || (out_t && ld_out_t < M)) return DRN_ERR_ARG;
   if (M == 0) return DRN_OK;
   RoiParams p{(const char*)feat, rois, objectness, (char*)out, argmax, N, H, W, C, P, M, spatial_scale, ld_out,
-              sampling_ratio, aligned, 0};
+              sampling_ratio, aligned, 0, (char*)out_t, ld_out_t};
   dim3 grid(M, (C + RP_CH - 1) / RP_CH), block(256);
   hipStream_t st = (hipStream_t)stream;
+  {
+    // whole-map path (see roi_pool7_map_kernel): 7x7 ROIPool, same in/out dtype, no argmax, 16-B aligned runs
+    const int es = drn_esize(out_dtype);
+    const bool al = ((ld_out * es) % 16) == 0 && (((uintptr_t)out) & 15) == 0 && (((uintptr_t)feat) & 15) == 0 &&
+                    (!out_t || (((ld_out_t * es) % 16) == 0 && (((uintptr_t)out_t) & 15) == 0));
+    if (mode == 0 && P == 7 && !argmax && in_dtype == out_dtype && al) {
+      bool done = false;
+      if (in_dtype == DRN_BF16) done = launch_roi_map<DRN_BF16, 64>(p, st) || launch_roi_map<DRN_BF16, 32>(p, st);
+      else if (in_dtype == DRN_F32) done = launch_roi_map<DRN_F32, 32>(p, st) || launch_roi_map<DRN_F32, 16>(p, st);
+      if (done) {
+        DRN_CHECK_LAUNCH();
+        return DRN_OK;
+      }
+    }
+  }
+  if (out_t) {  // general shapes: pool into `out`, then the transpose pass
+    p.out_t = nullptr;
+    int rc = drn_roi_pool_nhwc(feat, rois, objectness, out, nullptr, argmax, N, H, W, C, P, M, spatial_scale, ld_out, 0,
+                               mode, sampling_ratio, aligned, in_dtype, out_dtype, stream);
+    if (rc != DRN_OK) return rc;
+    return drn_transpose2d(out, out_t, M, C * P * P, ld_out, ld_out_t, out_dtype, out_dtype, stream);
+  }
   // ROIPool on a full 64-channel chunk stages the box window in LDS: up to 256 pixels (25 KB bf16 / 64 KB f32... capped)
   size_t smem = 0;
   if (mode == 0 && C % RP_CH == 0) {

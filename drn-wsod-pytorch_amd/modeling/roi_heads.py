@@ -432,9 +432,7 @@ class _HeadEngine:
             slot = self._pool_next
             self._pool_next ^= 1
         s = self._pool_sets[slot]
-        ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=s["A"], **h.box_pooler.kernel_args())
-        if training:
-            ops.transpose2d(s["A"], M, K1, out=s["AT"])
+        ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=s["A"], out_t=s["AT"], **h.box_pooler.kernel_args())
         return s
 
     @staticmethod

@@ -89,16 +89,20 @@ def preprocess_nhwc(images, mean, std, dtype, cpad):
 
 
 def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, aligned=False, out=None, out_dtype=None,
-                  want_argmax=False):
-    """feat [N,H,W,C]; rois [M,5] f32; -> out [M, ld] (first C*P*P columns valid, k = c*P*P + bin)."""
+                  want_argmax=False, out_t=None):
+    """feat [N,H,W,C]; rois [M,5] f32; -> out [M, ld] (first C*P*P columns valid, k = c*P*P + bin); out_t (optional,
+    [C*P*P, ld_t]) receives the transposed copy in the same call."""
     n, h, w, c = feat.shape
     m = rois.shape[0]
     out_dtype = out_dtype or feat.dtype
     if out is None:
         out = torch.zeros((m, kpad(c * P * P, out_dtype)), dtype=out_dtype, device=feat.device)
     arg = torch.empty((m, c * P * P), dtype=torch.int32, device=feat.device) if want_argmax else None
-    C.call("drn_roi_pool_nhwc", C.ptr(feat), C.ptr(rois), C.ptr(objectness), C.ptr(out), C.ptr(arg), n, h, w, c, P, m,
-           float(scale), _2d(out), mode, sampling_ratio, int(aligned), C.dt(feat.dtype), C.dt(out.dtype), C.stream())
+    if out_t is not None:
+        assert out_t.dtype == out.dtype
+    C.call("drn_roi_pool_nhwc", C.ptr(feat), C.ptr(rois), C.ptr(objectness), C.ptr(out), C.ptr(out_t), C.ptr(arg), n, h,
+           w, c, P, m, float(scale), _2d(out), _2d(out_t) if out_t is not None else 0, mode, sampling_ratio,
+           int(aligned), C.dt(feat.dtype), C.dt(out.dtype), C.stream())
     return (out, arg) if want_argmax else out
 
 

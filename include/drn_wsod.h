@@ -55,10 +55,13 @@ int drn_maxpool2x2_nhwc(const void* x, void* y, int Nb, int H, int W, int C, int
  * mode 1 = ROIAlign (detectron2/layers/csrc/ROIAlign/ROIAlign.h:54-128 roi_align_forward),
  * fused with `box_features * (objectness_logits + 1)` (roi_heads_oicr.py:342-343) when objectness != NULL.
  * feat NHWC; rois [M][5] = (batch_idx, x0, y0, x1, y1); out [M][ld_out] with column
- * c*P*P + ph*P + pw (the NCHW flatten order of box_head.py:85-86); argmax [M][C*P*P] or NULL. */
-int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectness, void* out, int32_t* argmax, int N,
-                      int H, int W, int C, int P, int M, float spatial_scale, long ld_out, int mode,
-                      int sampling_ratio, int aligned, int in_dtype, int out_dtype, void* stream);
+ * c*P*P + ph*P + pw (the NCHW flatten order of box_head.py:85-86); argmax [M][C*P*P] or NULL.
+ * out_t (optional, same dtype as out): the transposed copy [C*P*P][ld_out_t] (column = roi) that the fc6 dW GEMM
+ * consumes as its K-major operand; written by the same launch when the feature map fits in LDS. */
+int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
+                      int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
+                      long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
+                      void* stream);
 
 /* out[c][r] = cast(in[r][c]) — builds the K-major operands of the dW GEMMs. */
 int drn_transpose2d(const void* in, void* out, int rows, int cols, long ld_in, long ld_out, int in_dtype,

@@ -210,24 +210,34 @@ def _rois(R, n_img, H, W, seed):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("C,P,scale,H,W", [(96, 7, 0.125, 23, 29), (6, 3, 0.125, 23, 29), (130, 7, 0.0625, 23, 29),
-                                           (128, 7, 0.0625, 14, 14), (64, 7, 0.125, 40, 37)])
-def test_roi_pool(drn, dtype, C, P, scale, H, W):
-    """C % 64 == 0 takes the LDS-staged path (boxes larger than the staging tile fall back to direct loads)."""
+@pytest.mark.parametrize("C,P,scale,H,W,R", [(96, 7, 0.125, 23, 29, 80), (6, 3, 0.125, 23, 29, 80),
+                                             (130, 7, 0.0625, 23, 29, 80), (128, 7, 0.0625, 14, 14, 83),
+                                             (64, 7, 0.125, 40, 37, 80), (64, 7, 0.125, 28, 28, 45),
+                                             (16, 7, 0.125, 28, 28, 19)])
+def test_roi_pool(drn, dtype, C, P, scale, H, W, R):
+    """7x7 pooling of maps that fit in LDS takes the whole-map kernel (ROI groups straddling images, ragged last
+    group); C % 64 == 0 otherwise takes the window-staged path; everything else the direct path.  The fused transposed
+    output must equal the row-major one whichever kernel produced it."""
     n_img = 2
     feat = _rnd((n_img, C, H, W), 11)
-    rois = _rois(80, n_img, W / scale, H / scale, 12)
-    obj = torch.rand(80)
+    rois = _rois(R, n_img, W / scale, H / scale, 12)
+    obj = torch.rand(R)
     ref, rarg = O.roi_pool_forward(_q(feat, dtype), rois, P, scale)
-    ref = _q(ref * (obj + 1).view(-1, 1, 1, 1), dtype).reshape(80, -1)
+    ref = _q(ref * (obj + 1).view(-1, 1, 1, 1), dtype).reshape(R, -1)
     fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
     out, arg = drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale, want_argmax=True)
     k = C * P * P
     assert torch.equal(out[:, :k].float().cpu(), ref)  # bit-exact: max + one fp32 multiply + rounding
     assert (out[:, k:] == 0).all()
-    assert torch.equal(arg.cpu(), rarg.reshape(80, -1))
-    out2 = drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale)  # no argmax: 7x7 fast path when it applies
+    assert torch.equal(arg.cpu(), rarg.reshape(R, -1))
+    out2 = drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale)  # no argmax: fast paths when they apply
     assert torch.equal(out2, out)
+    out3 = torch.zeros_like(out)
+    out_t = torch.zeros((k, drn.kpad(R, dtype)), dtype=dtype, device=DEV)
+    drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale, out=out3, out_t=out_t)
+    assert torch.equal(out3, out)
+    assert torch.equal(out_t[:, :R], out[:, :k].t())
+    assert (out_t[:, R:] == 0).all()
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
