@@ -147,6 +147,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
     ap.add_argument("--no-pipelined-sgd", action="store_true", help="plain optimizer.step() after backward")
+    ap.add_argument("--fused-sgd", action="store_true",
+                    help="N=1 only: fc6 dW GEMM with the SGD update as its epilogue (drn_gemm_nt_sgd; measured "
+                         "neutral: its HBM-heavy epilogues run in lock-step across CUs, see DESIGN.md)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -177,6 +180,8 @@ def main():
     dp.broadcast_parameters(0)
     if not args.no_pipelined_sgd:
         opt.enable_pipelined(dp)  # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
+        if world == 1 and args.fused_sgd:
+            opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
     batches = synthetic_batches(8, R, K, device, rank, pkg)
 

@@ -21,6 +21,7 @@ _SIGS = {
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliilip",
+    "drn_gemm_nt_sgd": "ppiiilli" + "ppplp" + "fifp",
     "drn_gemm_set_tile": "i",
     "drn_bias_act_fwd": "pilppQpfplpliiliip",
     "drn_counter_add": "pQp",

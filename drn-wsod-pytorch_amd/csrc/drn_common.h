@@ -31,6 +31,9 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
+// one row of the optimizer's segment table (device memory, refreshed in place when the LR schedule moves)
+struct SgdSeg { long off; long cnt; float lr; float wd; };
+
 template <int DT> struct ElemOf;
 template <> struct ElemOf<DRN_F32> {
   using type = float;

@@ -28,6 +28,13 @@ struct GemmParams {
   int k_slabs_per_split;
   long c_split_stride;  // elements
   int accumulate;
+  // fused-optimizer epilogue (gemm_nt256_kernel<.., SGD=true>): C is never stored, the tile updates W in place
+  float* sgd_w;
+  float* sgd_mom;
+  bf16_t* sgd_shadow;  // bf16 compute copy of W (same layout) or null
+  const SgdSeg* sgd_seg;  // lr / wd of this tensor, read on the device (a replayed hipGraph follows the schedule)
+  float sgd_momentum, sgd_grad_scale;
+  int sgd_first_step;
 };
 
 struct ConvParams {
@@ -226,7 +233,11 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 //     drain them).
 //   * operands are swapped in the MFMA (D^T = B.A^T) so a lane holds 4 consecutive output columns per register
 //     quad: the epilogue issues 16-B stores (4x fewer store instructions; the fc6 dW output is 411 MB).
-template <int DT, bool PIPE>
+//   * SGD = true: the fc6 weight-gradient GEMM with the optimizer step as its epilogue.  The gradient tile stays in
+//     the accumulators and W / momentum / the bf16 shadow are updated in place (same arithmetic and order as
+//     sgd_kernel in head.hip), so the 411 MB gradient is neither written nor re-read and the HBM-bound optimizer
+//     pass over the largest tensor disappears as a separate launch.  Single-GPU, no-accumulation steps only.
+template <int DT, bool PIPE, bool SGD = false>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
@@ -338,6 +349,55 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     }
   }
   // D^T layout: lane -> m (A row) = lane&31, register r -> n = (r&3) + 8*(r>>2) + 4*(lane>>5)
+  if constexpr (SGD) {
+#pragma clang fp contract(off)
+    const float lr = p.sgd_seg->lr, wd = p.sgd_seg->wd;
+    const float momentum = p.sgd_momentum, gs = p.sgd_grad_scale;
+    const bool first = p.sgd_first_step != 0;
+#pragma unroll
+    for (int i = 0; i < MI; ++i) {
+      const int m = bm + wm * 128 + i * 32 + (lane & 31);
+      if (m >= p.M) continue;
+      const long row = (long)m * p.ldc;
+      f32x4_t pw[NJ][4], mm[NJ][4];
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = bn + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+          pw[j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          mm[j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+          if (n < p.N) {  // N % 4 == 0 (launcher): a 4-column group is inside or outside as a whole
+            pw[j][q] = *(const f32x4_t*)(p.sgd_w + row + n);
+            if (!first) mm[j][q] = *(const f32x4_t*)(p.sgd_mom + row + n);
+          }
+        }
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int n = bn + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+          if (n >= p.N) continue;
+          f32x4_t nb, nw;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float d = acc[i][j][4 * q + e] * gs;
+            if (wd != 0.f) d = d + wd * pw[j][q][e];
+            nb[e] = first ? d : momentum * mm[j][q][e] + d;
+            nw[e] = pw[j][q][e] - lr * nb[e];
+          }
+          *(f32x4_t*)(p.sgd_mom + row + n) = nb;
+          *(f32x4_t*)(p.sgd_w + row + n) = nw;
+          if (p.sgd_shadow) {
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(nw[0]) | ((uint32_t)f32_to_bf16(nw[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(nw[2]) | ((uint32_t)f32_to_bf16(nw[3]) << 16);
+            *(uint2*)(p.sgd_shadow + row + n) = o;
+          }
+        }
+    }
+    return;
+  }
   float* C = p.C + (long)split * p.c_split_stride;
   const bool vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0;
 #pragma unroll
@@ -440,11 +500,11 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
-template <int DT, bool PIPE>
+template <int DT, bool PIPE, bool SGD = false>
 int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256_kernel<DT, PIPE>;
+  auto k = gemm_nt256_kernel<DT, PIPE, SGD>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -512,6 +572,23 @@ int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, lon
   const bool small = force == 64 || (force == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) * splits < 128);
   if (dtype == DRN_BF16) return small ? launch_gemm<DRN_BF16, 64, 64>(p, splits, st) : launch_gemm<DRN_BF16, 128, 128>(p, splits, st);
   return small ? launch_gemm<DRN_F32, 64, 64>(p, splits, st) : launch_gemm<DRN_F32, 128, 128>(p, splits, st);
+}
+
+// W[M,N] <- SGD(W, momentum_buf, G = A[M,K] * B[N,K]^T) with G kept in registers.  See include/drn_wsod.h.
+int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda, long ldb, int dtype, float* weights,
+                    float* momentum_buf, void* shadow, long ld_w, const void* seg_dev, float momentum, int first_step,
+                    float grad_scale, void* stream) {
+  if (!A || !B || !weights || !momentum_buf || !seg_dev || M < 0 || N < 0 || K < 0) return DRN_ERR_ARG;
+  if (M == 0 || N == 0) return DRN_OK;
+  if (dtype != DRN_F32 && dtype != DRN_BF16) return DRN_ERR_ARG;
+  const int es = drn_esize(dtype);
+  if ((K * es) % 128 != 0 || (lda * es) % 16 != 0 || (ldb * es) % 16 != 0 || lda < K || ldb < K) return DRN_ERR_ARG;
+  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)weights | (uintptr_t)momentum_buf) & 15) return DRN_ERR_ARG;
+  if ((N & 3) || (ld_w & 3) || ld_w < N || (((uintptr_t)shadow) & 7)) return DRN_ERR_ARG;
+  GemmParams p{(const char*)A, (const char*)B, nullptr, M, N, K, lda, ldb, ld_w, K * es / 128, 0, 0,
+               weights, momentum_buf, (bf16_t*)shadow, (const SgdSeg*)seg_dev, momentum, grad_scale, first_step};
+  hipStream_t st = (hipStream_t)stream;
+  return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true, true>(p, 1, st) : launch_gemm256<DRN_F32, true, true>(p, 1, st);
 }
 
 // NHWC conv + per-channel affine (folded FrozenBN or bias) + optional residual + optional ReLU.

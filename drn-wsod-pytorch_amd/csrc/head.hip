@@ -567,8 +567,6 @@ __global__ void apply_deltas_kernel(const float* deltas, long ld_d, const float*
   o[0] = pcx - 0.5f * pw; o[1] = pcy - 0.5f * ph; o[2] = pcx + 0.5f * pw; o[3] = pcy + 0.5f * ph;
 }
 
-struct SgdSeg { long off; long cnt; float lr; float wd; };
-
 // p -= lr * (buf = mom*buf + (g + wd*p)); first step: buf = g + wd*p.  One launch over the flat parameter
 // arena (blockIdx.y walks the segments, float4 lanes when the segment offset is 16-B aligned); the bf16
 // compute shadow (same flat layout) is refreshed in the same pass, so the weights are read once per step.

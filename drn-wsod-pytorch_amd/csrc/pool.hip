@@ -614,7 +614,7 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
                     (!out_t || (((ld_out_t * es) % 16) == 0 && (((uintptr_t)out_t) & 15) == 0));
     if (mode == 0 && P == 7 && !argmax && in_dtype == out_dtype && al) {
       bool done = false;
-      if (in_dtype == DRN_BF16) done = launch_roi_map<DRN_BF16, 64>(p, st) || launch_roi_map<DRN_BF16, 32>(p, st);
+      if (in_dtype == DRN_BF16) done = launch_roi_map<DRN_BF16, 32>(p, st) || launch_roi_map<DRN_BF16, 64>(p, st);
       else if (in_dtype == DRN_F32) done = launch_roi_map<DRN_F32, 32>(p, st) || launch_roi_map<DRN_F32, 16>(p, st);
       if (done) {
         DRN_CHECK_LAUNCH();

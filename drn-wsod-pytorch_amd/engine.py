@@ -93,6 +93,27 @@ class FusedSGD:
         self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._bucket_segs = {}
 
+    def enable_fused_fc1(self):
+        """Single process, ITER_SIZE == 1, on top of the pipelined mode: the fc6 weight gradient (the largest tensor by
+        far: D1 x C*49) is consumed by the optimizer inside the dW GEMM's epilogue (drn_gemm_nt_sgd), so it is never
+        written to or read back from HBM and its share of the optimizer pass needs no launch of its own.  Same
+        arithmetic as the SGD kernel; `fc1.weight.grad` is not materialised in this mode."""
+        if not getattr(self, "_pipelined", False):
+            raise DrnError("enable_pipelined() first")
+        if self._dp is not None and self._dp.world > 1:
+            raise DrnError("fused fc6 dW+SGD is a single-process mode: with N > 1 the gradient must be all-reduced")
+        self.engine.fc1_fused_update = self._fused_fc1
+
+    def _fused_fc1(self, dPT, AT, D1, K1, Mp):
+        e = self.engine
+        if self._mom is None:
+            self._mom = torch.zeros_like(e.arena_w)
+        segs, _ = self._bucket_table(("fc1", 0, D1))
+        o, n = e._seg["fc1.weight"]
+        view = lambda t: t[o: o + n].view(D1, K1)
+        ops.gemm_nt_sgd(dPT, AT, D1, K1, Mp, view(e.arena_w), view(self._mom),
+                        view(e.arena_s) if e.arena_s is not None else None, segs, self.momentum, self._steps == 0, 1.0)
+
     def _bucket_table(self, what):
         groups = [g for g in self.param_groups if g["used"]]
         key = (what, tuple((g["lr"], g["weight_decay"]) for g in groups))

@@ -575,18 +575,25 @@ class _HeadEngine:
             nslab = getattr(self, "fc1_grad_slabs", 1)
             rows = (D1 + nslab - 1) // nslab
             ends = [min(D1, (s + 1) * rows) for s in range(nslab)]
-        gw = self._gview("fc1.weight", (D1, K1))
-        r0 = 0
-        for r1 in ends:
-            if r0 >= r1:
-                continue
-            ops.gemm_nt(w["dP1T"][r0:r1], w["AT"], r1 - r0, K1, Mp, out=gw[r0:r1].unsqueeze(0), accumulate=acc)
-            if hook is not None:
-                hook(("fc1", r0, r1))
-            r0 = r1
+        fused = getattr(self, "fc1_fused_update", None)
+        if fused is not None and not acc:
+            # the optimizer consumes this gradient inside the GEMM epilogue: fc1.weight.grad is never materialised
+            fused(w["dP1T"], w["AT"], D1, K1, Mp)
+        else:
+            if fused is not None:
+                raise DrnError("fused fc6 dW+SGD step cannot be combined with gradient accumulation")
+            gw = self._gview("fc1.weight", (D1, K1))
+            r0 = 0
+            for r1 in ends:
+                if r0 >= r1:
+                    continue
+                ops.gemm_nt(w["dP1T"][r0:r1], w["AT"], r1 - r0, K1, Mp, out=gw[r0:r1].unsqueeze(0), accumulate=acc)
+                if hook is not None:
+                    hook(("fc1", r0, r1))
+                r0 = r1
         self._grads_valid = True
         for name, p, o, n, used in self.segments:
-            if used and p.grad is None:
+            if used and p.grad is None and not (fused is not None and name == "fc1.weight"):
                 p.grad = self.arena_g[o: o + n].view(p.shape)
 
 

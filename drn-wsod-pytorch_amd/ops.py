@@ -53,6 +53,22 @@ def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
     return out
 
 
+def gemm_nt_sgd(A, B, M, N, K, weights, mom, shadow, seg_dev, momentum, first_step, grad_scale=1.0):
+    """weights[M,N] <- SGD step with the gradient A[M,:K] @ B[N,:K]^T, which is never materialised."""
+    assert A.dtype == B.dtype and weights.dtype == torch.float32 and mom.dtype == torch.float32
+    assert weights.is_contiguous() and mom.is_contiguous() and weights.shape == (M, N) and mom.shape == (M, N)
+    if shadow is not None:
+        assert shadow.dtype == torch.bfloat16 and shadow.is_contiguous() and shadow.shape == (M, N)
+    if GEMM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    C.call("drn_gemm_nt_sgd", C.ptr(A), C.ptr(B), M, N, K, _2d(A), _2d(B), C.dt(A.dtype), C.ptr(weights), C.ptr(mom),
+           C.ptr(shadow), N, C.ptr(seg_dev), float(momentum), int(bool(first_step)), float(grad_scale), C.stream())
+    if GEMM_TIMING is not None:
+        e1.record()
+        GEMM_TIMING.append((e0, e1, 2.0 * M * N * K, ("sgd", M, N, K)))
+
+
 def conv2d_nhwc(x, w_packed, cout, kh, kw, stride=1, pad=0, dil=1, scale=None, bias=None, residual=None, relu=False):
     """x [N,H,W,Cin] NHWC contiguous; w_packed [Cout, ldw]; returns y [N,Ho,Wo,Cout]."""
     assert x.is_contiguous() and x.dim() == 4

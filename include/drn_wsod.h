@@ -79,6 +79,17 @@ int drn_cast2d(const void* in, void* out, int rows, int cols, long ld_in, long l
 int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
                 int splits, long c_split_stride, int accumulate, void* stream);
 
+/* The weight-gradient contraction of a Linear layer with the optimizer step as its epilogue
+ * (torch.autograd's dW = dY^T X of F.linear followed by torch.optim.SGD.step on that tensor,
+ * detectron2/solver/build.py:93-137 builds the optimizer; plain_train_net/train_loop.py:232-236 calls it):
+ *   G = A[M][K] * B[N][K]^T;  d = G*grad_scale + wd*W;  buf = first_step ? d : momentum*buf + d;  W -= lr*buf
+ * with G kept in registers (never stored), W/buf fp32 [M][ld_w] updated in place, `shadow` (optional) the bf16
+ * compute copy of W refreshed in the same pass.  lr/wd are read on the device from seg_dev (one drn_sgd_step
+ * table row).  Valid only when nothing else contributes to this gradient (one process, no accumulation). */
+int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda, long ldb, int dtype, float* weights,
+                    float* momentum_buf, void* shadow, long ld_w, const void* seg_dev, float momentum, int first_step,
+                    float grad_scale, void* stream);
+
 /* tuning / test hook: pin the GEMM tile to 64, 128 or 256 (0 = heuristic); returns the previous setting. */
 int drn_gemm_set_tile(int tile);
 

@@ -436,6 +436,37 @@ def test_sgd_step(drn):
         assert torch.equal(shadow.float().cpu(), ref.to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,wd", [(300, 520, 200, 1e-4), (512, 1024, 2000, 0.0), (77, 36, 64, 5e-4)])
+def test_gemm_nt_sgd_equals_gemm_then_sgd(drn, dtype, M, N, K, wd):
+    """dW GEMM with the optimizer step as its epilogue == drn_gemm_nt(256 tile) followed by drn_sgd_step, bit for
+    bit (weights, momentum, bf16 shadow), over a first step and two momentum steps; ragged M/N edges included."""
+    rs = np.random.RandomState(5)
+    Kp = drn.kpad(K, dtype)
+    w0 = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).to(DEV)
+    seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+    seg[0] = (0, M * N, 0.01, wd)
+    seg_dev = torch.from_numpy(seg.view(np.uint8)).to(DEV)
+    wa, ma = w0.clone(), torch.zeros_like(w0)
+    wb, mb = w0.clone(), torch.zeros_like(w0)
+    sa = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    sb = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    old = drn.gemm_set_tile(256)
+    try:
+        for step in range(3):
+            A = torch.zeros((M, Kp), dtype=dtype, device=DEV)
+            B = torch.zeros((N, Kp), dtype=dtype, device=DEV)
+            A[:, :K] = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(DEV).to(dtype)
+            B[:, :K] = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)).to(DEV).to(dtype)
+            g = drn.gemm_nt(A, B, M, N, Kp)[0].contiguous()
+            drn.sgd_step(wa.view(-1), ma.view(-1), g.view(-1), seg_dev, 1, 0.9, step == 0, shadow=sa.view(-1))
+            drn.gemm_nt_sgd(A, B, M, N, Kp, wb, mb, sb, seg_dev, 0.9, step == 0)
+            assert torch.equal(wa, wb) and torch.equal(ma, mb) and torch.equal(sa, sb), step
+    finally:
+        drn.gemm_set_tile(old)
+    assert not torch.equal(wa, w0)
+
+
 # ------------------------------------------------------------------------------------------- inference tail
 def test_detect_golden_indices(drn):
     d = G.load("ops")
