@@ -150,6 +150,11 @@ def main():
     ap.add_argument("--fused-sgd", action="store_true",
                     help="N=1 only: fc6 dW GEMM with the SGD update as its epilogue (drn_gemm_nt_sgd; measured "
                          "neutral: its HBM-heavy epilogues run in lock-step across CUs, see DESIGN.md)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="run the N>1 code path (RCCL process group, split-tail graph, per-bucket all-reduce) even with "
+                         "one rank: exercises the exchange machinery on a single-GPU box")
+    ap.add_argument("--comm-dtype", choices=["bf16", "fp32"], default=None,
+                    help="dtype of the fc6 gradient buckets on the wire (default: bf16, the compute dtype)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -160,8 +165,9 @@ def main():
 
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
-    if world > 1:
+    if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
     pkg = load_package()
@@ -176,10 +182,11 @@ def main():
     init_weights(model, seed=0)
     model.train()
     opt = build_optimizer(cfg, model)
-    dp = DataParallel(model)
+    dp = DataParallel(model, force_exchange=args.force_exchange)
     dp.broadcast_parameters(0)
     if not args.no_pipelined_sgd:
-        opt.enable_pipelined(dp)  # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
+        # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
+        opt.enable_pipelined(dp, comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype])
         if world == 1 and args.fused_sgd:
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
@@ -199,7 +206,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    use_graph = world == 1 and not args.no_graph
+    # N > 1: the graphed step keeps the gradient exchange out of the capture (split tail); it needs the pipelined
+    # optimizer, whose hooks issue the collectives
+    use_graph = not args.no_graph and (not dp.exchange or not args.no_pipelined_sgd)
     # HIP events around every GEMM launch (on the launching stream) during eager steps: the dominant kernel's
     # average launch duration for the roofline object.  A replayed hipGraph cannot be bracketed per kernel, so with
     # --graph these come from the eager warm-up steps of this same run (same buffers, same shapes).
@@ -213,7 +222,7 @@ def main():
         from drn_wsod_pytorch_amd.engine import GraphedTrainStep
 
         ops.GEMM_TIMING = None
-        stepper = GraphedTrainStep(model, opt, batches[0])
+        stepper = GraphedTrainStep(model, opt, batches[0], split_tail=dp.exchange)
         for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
             last = stepper.step(batches[i % len(batches)], batches[(i + 1) % len(batches)])
         barrier()
@@ -261,12 +270,24 @@ def main():
                                       "%d proposals/img, 1 img/GPU/iter, K=20, 3 OICR refinements, frozen backbone "
                                       "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % R,
                           "global_batch": world, "proposals": R, "parallelism": "dp%d" % world},
-               "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph), "roofline": roof}
+               "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph),
+               "grad_exchange": None if not dp.exchange else {
+                   "collective": "RCCL all-reduce per bucket (small tensors fp32, fc6 dW row slabs)",
+                   "fc6_bucket_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
+                   "slab_ends": getattr(opt, "_slab_ends", None)},
+               "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batches)
-        print(json.dumps(out))
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
+    if rank == 0:
+        # RCCL prints its version banner through C stdio, which is flushed at exit when stdout is a pipe: flush it now
+        # so that the JSON line is the LAST line of this process's output
+        import ctypes
+
+        sys.stdout.flush()
+        ctypes.CDLL(None).fflush(None)
+        print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

@@ -20,7 +20,7 @@ _SIGS = {
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
     "drn_transpose2d": "ppiilliip",
-    "drn_gemm_nt": "pppiiillliilip",
+    "drn_gemm_nt": "pppiiillliiilip",
     "drn_gemm_nt_sgd": "ppiiilli" + "ppplp" + "fifp",
     "drn_gemm_set_tile": "i",
     "drn_bias_act_fwd": "pilppQpfplpliiliip",
@@ -34,7 +34,7 @@ _SIGS = {
     "drn_box_reg_loss": "pliippppplppifp",
     "drn_apply_deltas": "plppiipfp",
     "drn_sum_small": "pifpp",
-    "drn_sgd_step": "ppppipififp",
+    "drn_sgd_step": "pppilpipififp",
     "drn_detect_topk": "ppiii" + "ffff" + "i" + "pl" + "i" + "ppp",
     "drn_detect_gather": "plippippppp",
 }

@@ -35,6 +35,7 @@ struct GemmParams {
   const SgdSeg* sgd_seg;  // lr / wd of this tensor, read on the device (a replayed hipGraph follows the schedule)
   float sgd_momentum, sgd_grad_scale;
   int sgd_first_step;
+  int c_bf16;  // C holds bf16 (gradient buckets that cross xGMI in bf16); splits == 1, no accumulate
 };
 
 struct ConvParams {
@@ -215,8 +216,12 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
       for (int r = 0; r < 16; ++r) {
         const int m = bm + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < p.M && n < p.N) {
-          float* dst = C + (long)m * p.ldc + n;
-          *dst = p.accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
+          if (p.c_bf16) {
+            ((bf16_t*)p.C)[(long)m * p.ldc + n] = f32_to_bf16(acc[i][j][r]);
+          } else {
+            float* dst = C + (long)m * p.ldc + n;
+            *dst = p.accumulate ? *dst + acc[i][j][r] : acc[i][j][r];
+          }
         }
       }
     }
@@ -411,7 +416,19 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
         const int n = bn + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
         float* dst = C + (long)m * p.ldc + n;
         f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
-        if (vec_ok && n + 4 <= p.N) {
+        if (p.c_bf16) {
+          bf16_t* d16 = (bf16_t*)p.C + (long)m * p.ldc + n;
+          if (vec_ok && n + 4 <= p.N) {
+            uint2 o;
+            o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+            o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+            *(uint2*)d16 = o;
+          } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+              if (n + e < p.N) d16[e] = f32_to_bf16(v[e]);
+          }
+        } else if (vec_ok && n + 4 <= p.N) {
           if (p.accumulate) { const f32x4_t o = *(const f32x4_t*)dst; v += o; }
           *(f32x4_t*)dst = v;
         } else {
@@ -547,8 +564,8 @@ int drn_gemm_set_tile(int tile) {
 }
 
 // C[split][M,N] (fp32) = A[M,K] * B[N,K]^T over this split's K range.  See include/drn_wsod.h.
-int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
-                int splits, long c_split_stride, int accumulate, void* stream) {
+int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
+                int c_dtype, int splits, long c_split_stride, int accumulate, void* stream) {
   if (!A || !B || !C || M < 0 || N < 0 || K < 0) return DRN_ERR_ARG;
   if (M == 0 || N == 0) return DRN_OK;
   const int es = drn_esize(dtype);
@@ -557,9 +574,12 @@ int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, lon
   if (((uintptr_t)A | (uintptr_t)B) & 15) return DRN_ERR_ARG;
   if (splits < 1) return DRN_ERR_ARG;
   if (splits > 1 && accumulate) return DRN_ERR_ARG;
+  if (c_dtype != DRN_F32 && c_dtype != DRN_BF16) return DRN_ERR_ARG;
+  if (c_dtype == DRN_BF16 && (splits != 1 || accumulate)) return DRN_ERR_ARG;
   const int nslab = K * es / 128;
-  GemmParams p{(const char*)A, (const char*)B, C, M, N, K, lda, ldb, ldc, (nslab + splits - 1) / splits,
+  GemmParams p{(const char*)A, (const char*)B, (float*)C, M, N, K, lda, ldb, ldc, (nslab + splits - 1) / splits,
                c_split_stride, accumulate};
+  p.c_bf16 = c_dtype == DRN_BF16;
   hipStream_t st = (hipStream_t)stream;
   // 256x256 LDS-DMA kernel when it can put >= ~3/4 of the 256 CUs to work (1 workgroup of 128 KB LDS per CU);
   // otherwise the 128x128 / 64x64 register-staged kernels (more, smaller workgroups)

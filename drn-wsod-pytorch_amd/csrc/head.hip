@@ -570,20 +570,30 @@ __global__ void apply_deltas_kernel(const float* deltas, long ld_d, const float*
 // p -= lr * (buf = mom*buf + (g + wd*p)); first step: buf = g + wd*p.  One launch over the flat parameter
 // arena (blockIdx.y walks the segments, float4 lanes when the segment offset is 16-B aligned); the bf16
 // compute shadow (same flat layout) is refreshed in the same pass, so the weights are read once per step.
-template <bool SHADOW>
+template <bool SHADOW, int GDT>
 __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* __restrict__ mom,
-                                                  const float* __restrict__ g, bf16_t* __restrict__ shadow,
+                                                  const void* __restrict__ gv, long goff, bf16_t* __restrict__ shadow,
                                                   const SgdSeg* segs, int nseg, float momentum, int first_step,
                                                   float grad_scale) {
+  using GT = typename ElemOf<GDT>::type;
+  const GT* g = (const GT*)gv - goff;  // arena element j <-> g[j]
   for (int s = blockIdx.y; s < nseg; s += gridDim.y) {
     const SgdSeg sg = segs[s];
     const long tid = blockIdx.x * (long)blockDim.x + threadIdx.x, nthr = (long)gridDim.x * blockDim.x;
     long done = 0;
-    if ((sg.off & 3) == 0) {
+    if ((sg.off & 3) == 0 && ((sg.off - goff) & 3) == 0) {
       const long nvec = sg.cnt >> 2;
       for (long i = tid; i < nvec; i += nthr) {
         const long j = sg.off + 4 * i;
-        const f32x4_t pw = *(const f32x4_t*)(w + j), gg = *(const f32x4_t*)(g + j);
+        const f32x4_t pw = *(const f32x4_t*)(w + j);
+        f32x4_t gg;
+        if constexpr (GDT == DRN_BF16) {
+          const uint2 x = *(const uint2*)(g + j);
+          gg = f32x4_t{__builtin_bit_cast(float, x.x << 16), __builtin_bit_cast(float, x.x & 0xffff0000u),
+                       __builtin_bit_cast(float, x.y << 16), __builtin_bit_cast(float, x.y & 0xffff0000u)};
+        } else {
+          gg = *(const f32x4_t*)(g + j);
+        }
         f32x4_t mm = {0.f, 0.f, 0.f, 0.f};
         if (!first_step) mm = *(const f32x4_t*)(mom + j);
         f32x4_t nb, nw;
@@ -608,7 +618,7 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* 
     for (long i = done + tid; i < sg.cnt; i += nthr) {
       const long j = sg.off + i;
       const float pw = w[j];
-      float d = g[j] * grad_scale;
+      float d = ElemOf<GDT>::ld(g + j) * grad_scale;
       if (sg.wd != 0.f) d = d + sg.wd * pw;
       const float b = first_step ? d : momentum * mom[j] + d;
       mom[j] = b;
@@ -775,18 +785,20 @@ int drn_apply_deltas(const float* deltas, long ld_d, const float* boxes, float* 
 
 // segs_dev: device array of {int64 off, int64 cnt, float lr, float wd} (24 bytes each).  shadow (optional):
 // bf16 array with the arena's flat layout, refreshed in the same pass.
-int drn_sgd_step(float* weights, float* momentum_buf, const float* grads, void* shadow, int shadow_dtype,
-                 const void* segs_dev, int nseg, float momentum, int first_step, float grad_scale, void* stream) {
+int drn_sgd_step(float* weights, float* momentum_buf, const void* grads, int grad_dtype, long grad_off, void* shadow,
+                 int shadow_dtype, const void* segs_dev, int nseg, float momentum, int first_step, float grad_scale,
+                 void* stream) {
   if (!weights || !momentum_buf || !grads || !segs_dev || nseg < 1) return DRN_ERR_ARG;
   if (shadow && shadow_dtype != DRN_BF16) return DRN_ERR_ARG;
+  if (grad_dtype != DRN_F32 && grad_dtype != DRN_BF16) return DRN_ERR_ARG;
   dim3 grid(1024, nseg < 32 ? nseg : 32), block(256);
   hipStream_t st = (hipStream_t)stream;
-  if (shadow)
-    hipLaunchKernelGGL(sgd_kernel<true>, grid, block, 0, st, weights, momentum_buf, grads, (bf16_t*)shadow,
-                       (const SgdSeg*)segs_dev, nseg, momentum, first_step, grad_scale);
-  else
-    hipLaunchKernelGGL(sgd_kernel<false>, grid, block, 0, st, weights, momentum_buf, grads, (bf16_t*)nullptr,
-                       (const SgdSeg*)segs_dev, nseg, momentum, first_step, grad_scale);
+#define SGD_LAUNCH(SH, GD)                                                                                       \
+  hipLaunchKernelGGL((sgd_kernel<SH, GD>), grid, block, 0, st, weights, momentum_buf, grads, grad_off,           \
+                     (bf16_t*)shadow, (const SgdSeg*)segs_dev, nseg, momentum, first_step, grad_scale)
+  if (shadow) { if (grad_dtype == DRN_BF16) SGD_LAUNCH(true, DRN_BF16); else SGD_LAUNCH(true, DRN_F32); }
+  else { if (grad_dtype == DRN_BF16) SGD_LAUNCH(false, DRN_BF16); else SGD_LAUNCH(false, DRN_F32); }
+#undef SGD_LAUNCH
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

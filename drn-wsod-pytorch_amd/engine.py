@@ -65,12 +65,16 @@ class FusedSGD:
         return self._segs_dev, self._nseg
 
     # ---- pipelined mode: the update of a gradient bucket starts as soon as the bucket is final ----------------
-    def enable_pipelined(self, dp=None, slab_rows=None):
+    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None):
         """ITER_SIZE == 1 only.  The explicit backward finishes gradients in a known order: first every small tensor
         (predictors, fc7, fc6 bias), then fc6.weight in row slabs.  In pipelined mode each bucket is (all-reduced when
         N > 1 and then) updated by the SGD kernel on a second stream the moment its dW GEMM is queued, so the HBM-bound
         optimizer pass hides under the MFMA-bound remaining dW GEMMs; `step()` then only joins the streams.
-        Same arithmetic as the plain step (the kernel, the per-group lr/wd and the 1/W scale are identical)."""
+        Same arithmetic as the plain step (the kernel, the per-group lr/wd and the 1/W scale are identical).
+        comm_dtype (N > 1): dtype of the fc6 weight-gradient buckets on the wire.  torch.bfloat16 = the dW GEMM writes
+        bf16 straight into an exchange buffer (half the xGMI bytes, the dominant cost of the 8-GPU step: 411 MB fp32 per
+        step for R50-C4) and the SGD kernel reads it; default = bf16 in the bf16 compute mode, fp32 (the reference's
+        DDP arithmetic) in the fp32 parity mode.  The small tensors always travel in fp32."""
         e = self.engine
         d1 = self.model.roi_heads.box_head.fc1.weight.shape[0]
         world = dp.world if dp is not None else 1
@@ -92,6 +96,17 @@ class FusedSGD:
         self._dp, self._pipelined = dp, True
         self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._bucket_segs = {}
+        self._exchange = dp is not None and dp.exchange
+        if comm_dtype is None:
+            from . import get_precision
+
+            comm_dtype = torch.bfloat16 if (self._exchange and get_precision() == "bf16") else torch.float32
+        self._comm_dtype = comm_dtype
+        e.fc1_grad_bucket = None
+        if self._comm_dtype == torch.bfloat16:
+            k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
+            e.ensure(next(self.model.roi_heads.parameters()).device)
+            e.fc1_grad_bucket = torch.zeros((d1, k1), dtype=torch.bfloat16, device=e.arena_w.device)
 
     def enable_fused_fc1(self):
         """Single process, ITER_SIZE == 1, on top of the pipelined mode: the fc6 weight gradient (the largest tensor by
@@ -150,8 +165,9 @@ class FusedSGD:
         ev = torch.cuda.Event()
         ev.record(cur)
         self._opt_stream.wait_event(ev)
+        bucket = e.fc1_grad_bucket if what != "small" else None
         with torch.cuda.stream(self._opt_stream):
-            if world > 1:
+            if self._exchange:
                 if what == "small":
                     o_fc1, _ = e._seg["fc1.weight"]
                     dist.all_reduce(e.arena_g[:o_fc1], group=self._dp.group)
@@ -159,9 +175,14 @@ class FusedSGD:
                     _, r0, r1 = what
                     o, _ = e._seg["fc1.weight"]
                     k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
-                    dist.all_reduce(e.arena_g[o + r0 * k1: o + r1 * k1], group=self._dp.group)
-            ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
-                         shadow=e.arena_s)
+                    dist.all_reduce(bucket[r0:r1] if bucket is not None else e.arena_g[o + r0 * k1: o + r1 * k1],
+                                    group=self._dp.group)
+            if bucket is not None:
+                ops.sgd_step(e.arena_w, self._mom, bucket, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
+                             shadow=e.arena_s, grad_off=e._seg["fc1.weight"][0])
+            else:
+                ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
+                             shadow=e.arena_s)
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
@@ -248,11 +269,13 @@ class DataParallel:
     Buckets follow the order gradients become final in the explicit backward: [all small tensors] then the fc6
     weight gradient in `slabs` row slabs, each launched on a side stream as soon as its dW GEMM has been queued."""
 
-    def __init__(self, model, process_group=None, slabs=4, backend_stream=True):
+    def __init__(self, model, process_group=None, slabs=4, backend_stream=True, force_exchange=False):
         self.model = model
         self.engine = model.roi_heads._engine
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_available() and dist.is_initialized() else 1
+        # force_exchange: run the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box)
+        self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
         self.engine.fc1_grad_slabs = slabs if self.world > 1 else 1
         self.engine.grad_ready_hook = self._on_ready if self.world > 1 else None
         self._use_stream = backend_stream and torch.cuda.is_available()
@@ -362,10 +385,15 @@ class GraphedTrainStep:
     and one graph suffice.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5).
 
     Static shapes only (fixed image size, proposals per image, images per GPU: the benchmark's case and the common
-    fixed-R training case); anything else runs the eager path.  Single process: with N > 1 the gradient exchange
-    stays eager (DataParallel), so this class is used when world == 1."""
+    fixed-R training case); anything else runs the eager path.
 
-    def __init__(self, model, optimizer, example_batch):
+    N > 1 (`split_tail`): the captured heads graph stops in front of the fc6 weight-gradient GEMMs.  That tail - the
+    announcement of the small gradients, the dW row-slab GEMMs and, from the optimizer's hooks, one RCCL all-reduce +
+    SGD launch per bucket on the optimizer stream - is issued eagerly after the replay (~10 launches), so no
+    collective is ever captured into a hipGraph, while the next image's backbone graph and pooling graph run under
+    the exchange.  The optimizer stream is joined at the start of the next step."""
+
+    def __init__(self, model, optimizer, example_batch, split_tail=False):
         assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
         self.model, self.opt = model, optimizer
         self.heads = model.roi_heads
@@ -393,6 +421,8 @@ class GraphedTrainStep:
         self.losses = None
         self._side = torch.cuda.Stream()
         self._primed = False
+        self.split_tail = bool(split_tail)
+        self.engine.defer_fc1_tail = self.split_tail
 
     # ---- host side of one step: stage inputs into the static buffers (tiny async copies) -----------------------
     def _stage_labels(self, batch):
@@ -456,7 +486,8 @@ class GraphedTrainStep:
         losses, _ = self.engine.forward(None, self.rois, self.obj, True, self.img_off, self.n_img, self.gt,
                                         pooled=self.pooled)
         sum(losses.values()).backward()  # pipelined SGD buckets fork onto the optimizer stream in here
-        self.opt.step(1.0)               # joins the optimizer stream
+        if not self.split_tail:
+            self.opt.step(1.0)           # joins the optimizer stream
         return losses
 
     def _pool_body(self):
@@ -475,12 +506,16 @@ class GraphedTrainStep:
         # submit the heads graph FIRST: submitting a graph costs the host ~9 us per node, and the backbone graph has
         # 49 nodes - issued first it would leave the main stream idle for ~0.45 ms in front of the fc6 GEMM
         losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
+        if self.split_tail:
+            self.engine.run_fc1_tail()  # eager: dW slabs on this stream, all-reduce + SGD per bucket on the optimizer stream
         with torch.cuda.stream(self._side):
             self._bb_body() if eager else self.g_bb.replay()
             done = torch.cuda.Event()
             done.record(self._side)
         main.wait_event(done)
         self._pool_body() if eager else self.g_pool.replay()
+        if self.split_tail:
+            self.opt.step(1.0)  # join the optimizer stream: the exchange ran under the backbone + pooling above
         return losses
 
     def prime(self, first_batch, next_batch):

@@ -549,7 +549,7 @@ class _HeadEngine:
                     idx[o: o + c] = trained[n]
             self._colidx, self._colidx_key = idx.to(dev), key
         colidx = self._colidx
-        acc = self._grads_valid and fc1.weight.grad is not None
+        acc = self._grads_valid and fc2.weight.grad is not None  # fc1.weight.grad is not materialised in bucket modes
         bo, _ = self._seg[self.cols[0][0] + ".bias"]
         wo, _ = self._seg[self.cols[0][0] + ".weight"]
         # heads: dS, dS^T, bias grads
@@ -567,6 +567,16 @@ class _HeadEngine:
         ops.bias_act_bwd(w["dH1"], M, D1, saved=w["H1"], mask=st["masks"][0] if st["masks"] else None,
                          drop_p=st["drop_p"], dpreT=w["dP1T"], colsum=self._gview("fc1.bias"), accumulate_colsum=acc,
                          colpart=w["colpart"])
+        self._tail = (w["dP1T"], w["AT"], D1, K1, Mp, acc)
+        if not getattr(self, "defer_fc1_tail", False):
+            self.run_fc1_tail()
+
+    def run_fc1_tail(self):
+        """Last piece of the explicit backward: announce the small gradients, then the fc6 weight gradient in row
+        slabs (each announced as soon as its GEMM is queued).  Normally called by backward() itself; the multi-GPU
+        graphed step sets `defer_fc1_tail` and calls it eagerly after replaying the captured part, so the RCCL calls
+        issued from the hooks are ordinary stream work and never part of a hipGraph."""
+        dP1T, AT, D1, K1, Mp, acc = self._tail
         hook = getattr(self, "grad_ready_hook", None)
         if hook is not None:
             hook("small")  # everything except fc1.weight is final: the DP engine starts reducing it now
@@ -576,24 +586,26 @@ class _HeadEngine:
             rows = (D1 + nslab - 1) // nslab
             ends = [min(D1, (s + 1) * rows) for s in range(nslab)]
         fused = getattr(self, "fc1_fused_update", None)
+        bucket = getattr(self, "fc1_grad_bucket", None)  # [D1, K1] exchange buffer (bf16 or fp32) instead of the arena
         if fused is not None and not acc:
             # the optimizer consumes this gradient inside the GEMM epilogue: fc1.weight.grad is never materialised
-            fused(w["dP1T"], w["AT"], D1, K1, Mp)
+            fused(dP1T, AT, D1, K1, Mp)
         else:
-            if fused is not None:
-                raise DrnError("fused fc6 dW+SGD step cannot be combined with gradient accumulation")
-            gw = self._gview("fc1.weight", (D1, K1))
+            if fused is not None or (bucket is not None and acc):
+                raise DrnError("fused / bucketed fc6 gradient cannot be combined with gradient accumulation")
+            gw = bucket if bucket is not None else self._gview("fc1.weight", (D1, K1))
             r0 = 0
             for r1 in ends:
                 if r0 >= r1:
                     continue
-                ops.gemm_nt(w["dP1T"][r0:r1], w["AT"], r1 - r0, K1, Mp, out=gw[r0:r1].unsqueeze(0), accumulate=acc)
+                ops.gemm_nt(dP1T[r0:r1], AT, r1 - r0, K1, Mp, out=gw[r0:r1].unsqueeze(0), accumulate=acc)
                 if hook is not None:
                     hook(("fc1", r0, r1))
                 r0 = r1
         self._grads_valid = True
+        skip = fused is not None or bucket is not None
         for name, p, o, n, used in self.segments:
-            if used and p.grad is None and not (fused is not None and name == "fc1.weight"):
+            if used and p.grad is None and not (skip and name == "fc1.weight"):
                 p.grad = self.arena_g[o: o + n].view(p.shape)
 
 

@@ -39,14 +39,15 @@ def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
     assert A.dtype == B.dtype
     if out is None:
         out = torch.empty((splits, M, N), dtype=torch.float32, device=A.device)
+    assert out.dtype == torch.float32 or (out.dtype == torch.bfloat16 and splits == 1 and not accumulate)
     ldc = out.stride(-2)
     sstride = out.stride(0) if out.dim() == 3 else 0
     assert out.dim() == 3 or splits == 1
     if GEMM_TIMING is not None:  # bench.py: HIP events on the launching stream around this launch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    C.call("drn_gemm_nt", C.ptr(A), C.ptr(B), C.ptr(out), M, N, K, lda, ldb, ldc, C.dt(A.dtype), splits, sstride,
-           int(accumulate), C.stream())
+    C.call("drn_gemm_nt", C.ptr(A), C.ptr(B), C.ptr(out), M, N, K, lda, ldb, ldc, C.dt(A.dtype), C.dt(out.dtype), splits,
+           sstride, int(accumulate), C.stream())
     if GEMM_TIMING is not None:
         e1.record()
         GEMM_TIMING.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
@@ -250,10 +251,13 @@ def sum_small(x, scale=1.0):
     return out
 
 
-def sgd_step(weights, momentum_buf, grads, segs_dev, nseg, momentum, first_step, grad_scale=1.0, shadow=None):
-    C.call("drn_sgd_step", C.ptr(weights), C.ptr(momentum_buf), C.ptr(grads), C.ptr(shadow),
-           C.dt(shadow.dtype) if shadow is not None else 0, C.ptr(segs_dev), nseg, float(momentum), int(first_step),
-           float(grad_scale), C.stream())
+def sgd_step(weights, momentum_buf, grads, segs_dev, nseg, momentum, first_step, grad_scale=1.0, shadow=None,
+             grad_off=0):
+    """grads: the fp32 gradient arena, or (grad_off > 0) a bucket buffer - fp32 or bf16 - whose element 0 is arena
+    element grad_off."""
+    C.call("drn_sgd_step", C.ptr(weights), C.ptr(momentum_buf), C.ptr(grads), C.dt(grads.dtype), int(grad_off),
+           C.ptr(shadow), C.dt(shadow.dtype) if shadow is not None else 0, C.ptr(segs_dev), nseg, float(momentum),
+           int(first_step), float(grad_scale), C.stream())
 
 
 def detect_topk(boxes, scores, image_shape, score_thresh, nms_thresh, topk):

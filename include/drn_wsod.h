@@ -75,9 +75,11 @@ int drn_cast2d(const void* in, void* out, int rows, int cols, long ld_in, long l
 
 /* nn.Linear / F.linear and its autograd (fc6/fc7 of box_head.py:82-91, predictors of
  * fast_rcnn.py:453-461,1316-1327).  C[s][M][N] (fp32) = A[M][K] * B[N][K]^T over K-split s.
- * K*esize must be a multiple of 128 bytes (callers zero-pad K), lda/ldb multiples of 16 bytes. */
-int drn_gemm_nt(const void* A, const void* B, float* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
-                int splits, long c_split_stride, int accumulate, void* stream);
+ * K*esize must be a multiple of 128 bytes (callers zero-pad K), lda/ldb multiples of 16 bytes.
+ * c_dtype: DRN_F32, or DRN_BF16 (splits == 1, no accumulate) for weight-gradient buckets that are exchanged
+ * between GPUs in bf16. */
+int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
+                int c_dtype, int splits, long c_split_stride, int accumulate, void* stream);
 
 /* The weight-gradient contraction of a Linear layer with the optimizer step as its epilogue
  * (torch.autograd's dW = dY^T X of F.linear followed by torch.optim.SGD.step on that tensor,
@@ -163,9 +165,12 @@ int drn_sum_small(const float* in, int n, float scale, float* out, void* stream)
 
 /* torch.optim.SGD(momentum) with the per-parameter groups of detectron2/solver/build.py:93-137, applied to a
  * flat parameter arena.  segs_dev: array of {int64 offset, int64 count, float lr, float weight_decay}.
- * shadow (optional, bf16, same flat layout) is refreshed in the same pass. */
-int drn_sgd_step(float* weights, float* momentum_buf, const float* grads, void* shadow, int shadow_dtype,
-                 const void* segs_dev, int nseg, float momentum, int first_step, float grad_scale, void* stream);
+ * shadow (optional, bf16, same flat layout) is refreshed in the same pass.  grads: fp32, or bf16 (gradient buckets
+ * that were all-reduced in bf16); arena element j reads grads[j - grad_off], so a bucket buffer that only covers
+ * one tensor can be passed with that tensor's arena offset. */
+int drn_sgd_step(float* weights, float* momentum_buf, const void* grads, int grad_dtype, long grad_off, void* shadow,
+                 int shadow_dtype, const void* segs_dev, int nseg, float momentum, int first_step, float grad_scale,
+                 void* stream);
 
 /* ---- inference tail -------------------------------------------------------------------------- */
 

@@ -227,6 +227,74 @@ def test_hipgraph_step_equals_eager():
             assert abs(e[k] - g[k]) <= 1e-5 * max(abs(e[k]), 1e-3), (k, e[k], g[k])
 
 
+@pytest.mark.parametrize("comm", ["fp32", "bf16"])
+def test_split_tail_exchange_step_equals_eager(comm):
+    """The N>1 step on one GPU: a 1-rank RCCL group with the exchange forced on, GraphedTrainStep(split_tail=True)
+    (captured heads graph + eager fc6-dW / all-reduce / SGD tail on the optimizer stream).  With fp32 buckets it must
+    reproduce the plain eager trainer exactly (weights bit for bit after 4 steps); with bf16 fc6 buckets the
+    gradient is rounded once to bf16 before the update, so weights agree to bf16 resolution of one lr-scaled step."""
+    import socket
+
+    import torch.distributed as dist
+    from drn_wsod_pytorch_amd.engine import DataParallel, GraphedTrainStep, build_optimizer
+
+    name = "model_r50c4_tiny"
+    d = G.load(name)
+    ocfg = G.MODEL_CASES[name]
+    base = G.batch_from(d)
+    b0 = G.drn_inputs([base[0]])
+    alt = dict(base[0])
+    alt["image"] = (255.0 - base[0]["image"]).contiguous()
+    alt["objectness_logits"] = base[0]["objectness_logits"].flip(0).contiguous()
+    b1 = G.drn_inputs([alt])
+    seq = [b0, b1, b0, b1, b0]
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    dist.init_process_group("nccl", rank=0, world_size=1, init_method="tcp://127.0.0.1:%d" % port)
+    try:
+        res = []
+        for mode in ("eager", "split"):
+            cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, "fp32")
+            model.roi_heads.box_head.dropout_p = 0.0
+            model.train()
+            opt = build_optimizer(cfg, model)
+            out = []
+            if mode == "split":
+                dp = DataParallel(model, force_exchange=True)
+                assert dp.exchange and dp.world == 1
+                dp.broadcast_parameters(0)
+                opt.enable_pipelined(dp, slab_rows=[16, 48],
+                                     comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32)
+                assert (model.roi_heads._engine.fc1_grad_bucket is not None) == (comm == "bf16")
+                stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True)
+                for i in range(4):
+                    losses = stepper.step(seq[i], seq[i + 1])
+                    out.append({k: float(v.detach()) for k, v in losses.items()})
+            else:
+                for i in range(4):
+                    opt.zero_grad()
+                    losses = model(seq[i])
+                    sum(losses.values()).backward()
+                    opt.step()
+                    out.append({k: float(v.detach()) for k, v in losses.items()})
+            torch.cuda.synchronize()
+            res.append((out, {n: p.detach().clone() for n, p in model.named_parameters() if p.requires_grad}))
+    finally:
+        dist.destroy_process_group()
+    (le, pe), (ls, ps) = res
+    for e, g in zip(le, ls):
+        for k in e:
+            tol = 1e-5 if comm == "fp32" else 2e-3
+            assert abs(e[k] - g[k]) <= tol * max(abs(e[k]), 1e-3), (k, e[k], g[k])
+    for n in pe:
+        if comm == "fp32":
+            assert torch.equal(pe[n], ps[n]), n
+        else:
+            assert torch.allclose(pe[n], ps[n], rtol=0, atol=2e-4), (n, float((pe[n] - ps[n]).abs().max()))
+
+
 def test_pipelined_sgd_equals_plain():
     """FusedSGD.enable_pipelined (per-bucket update on a second stream during backward) == plain step(), and so is
     enable_fused_fc1 (optimizer step inside the fc6 dW GEMM epilogue)."""

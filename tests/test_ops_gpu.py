@@ -436,6 +436,44 @@ def test_sgd_step(drn):
         assert torch.equal(shadow.float().cpu(), ref.to(torch.bfloat16).float())
 
 
+@pytest.mark.parametrize("tile", [64, 128, 256])
+def test_gemm_nt_bf16_output(drn, tile):
+    """c_dtype = bf16 (gradient buckets exchanged in bf16): same accumulators, rounded once (RNE) on the way out"""
+    rs = np.random.RandomState(8)
+    M, N, K = 300, 520, 256
+    A = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    B = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    old = drn.gemm_set_tile(tile)
+    try:
+        ref = drn.gemm_nt(A, B, M, N, K)[0]
+        out = torch.full((1, M, N), 7.0, dtype=torch.bfloat16, device=DEV)
+        drn.gemm_nt(A, B, M, N, K, out=out)
+    finally:
+        drn.gemm_set_tile(old)
+    assert torch.equal(out[0], ref.to(torch.bfloat16))
+
+
+def test_sgd_step_bf16_bucket(drn):
+    """bf16 gradient bucket covering one tensor of the arena (grad_off) == fp32 step on the same (rounded) gradient"""
+    rs = np.random.RandomState(9)
+    n0, n1 = 1000, 4096 + 3
+    w = torch.from_numpy(rs.standard_normal(n0 + n1).astype(np.float32)).to(DEV)
+    seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+    seg[0] = (n0, n1, 0.01, 5e-4)
+    seg_dev = torch.from_numpy(seg.view(np.uint8)).to(DEV)
+    wa, wb = w.clone(), w.clone()
+    ma, mb = torch.zeros_like(w), torch.zeros_like(w)
+    sa, sb = torch.zeros_like(w, dtype=torch.bfloat16), torch.zeros_like(w, dtype=torch.bfloat16)
+    for step in range(3):
+        g16 = torch.from_numpy(rs.standard_normal(n1).astype(np.float32)).to(DEV).to(torch.bfloat16)
+        g32 = torch.zeros_like(w)
+        g32[n0:] = g16.float()
+        drn.sgd_step(wa, ma, g32, seg_dev, 1, 0.9, step == 0, 0.5, shadow=sa)
+        drn.sgd_step(wb, mb, g16, seg_dev, 1, 0.9, step == 0, 0.5, shadow=sb, grad_off=n0)
+        assert torch.equal(wa, wb) and torch.equal(ma, mb) and torch.equal(sa, sb)
+    assert torch.equal(wa[:n0], w[:n0]) and not torch.equal(wa[n0:], w[n0:])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,wd", [(300, 520, 200, 1e-4), (512, 1024, 2000, 0.0), (77, 36, 64, 5e-4)])
 def test_gemm_nt_sgd_equals_gemm_then_sgd(drn, dtype, M, N, K, wd):
