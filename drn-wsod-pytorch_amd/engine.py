@@ -96,11 +96,11 @@ class FusedSGD:
         self._dp, self._pipelined = dp, True
         self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._bucket_segs = {}
-        self._exchange = dp is not None and dp.exchange
+        self._exchange_on = dp is not None and dp.exchange
         if comm_dtype is None:
             from . import get_precision
 
-            comm_dtype = torch.bfloat16 if (self._exchange and get_precision() == "bf16") else torch.float32
+            comm_dtype = torch.bfloat16 if (self._exchange_on and get_precision() == "bf16") else torch.float32
         self._comm_dtype = comm_dtype
         e.fc1_grad_bucket = None
         if self._comm_dtype == torch.bfloat16:
@@ -155,6 +155,23 @@ class FusedSGD:
         self._bucket_segs[what] = (key, dev, len(rows))
         return dev, len(rows)
 
+    def _exchange(self, what):
+        """sum one gradient bucket over the ranks (in place; on the current stream).  Returns the fc6 exchange buffer
+        when this bucket lives there instead of the fp32 arena."""
+        e = self.engine
+        bucket = e.fc1_grad_bucket if what != "small" else None
+        if self._exchange_on:
+            if what == "small":
+                o_fc1, _ = e._seg["fc1.weight"]
+                dist.all_reduce(e.arena_g[:o_fc1], group=self._dp.group)  # arena order: everything else precedes fc1.weight
+            else:
+                _, r0, r1 = what
+                o, _ = e._seg["fc1.weight"]
+                k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
+                dist.all_reduce(bucket[r0:r1] if bucket is not None else e.arena_g[o + r0 * k1: o + r1 * k1],
+                                group=self._dp.group)
+        return bucket
+
     def _on_grad_ready(self, what):
         e = self.engine
         if self._mom is None:
@@ -165,18 +182,8 @@ class FusedSGD:
         ev = torch.cuda.Event()
         ev.record(cur)
         self._opt_stream.wait_event(ev)
-        bucket = e.fc1_grad_bucket if what != "small" else None
         with torch.cuda.stream(self._opt_stream):
-            if self._exchange:
-                if what == "small":
-                    o_fc1, _ = e._seg["fc1.weight"]
-                    dist.all_reduce(e.arena_g[:o_fc1], group=self._dp.group)
-                else:
-                    _, r0, r1 = what
-                    o, _ = e._seg["fc1.weight"]
-                    k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
-                    dist.all_reduce(bucket[r0:r1] if bucket is not None else e.arena_g[o + r0 * k1: o + r1 * k1],
-                                    group=self._dp.group)
+            bucket = self._exchange(what)
             if bucket is not None:
                 ops.sgd_step(e.arena_w, self._mom, bucket, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
                              shadow=e.arena_s, grad_off=e._seg["fc1.weight"][0])

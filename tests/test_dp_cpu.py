@@ -63,6 +63,24 @@ def _worker(rank, world, port, q):
             if not used:  # unused bbox_pred: never reduced
                 assert torch.equal(e.arena_g[o: o + c], base[o: o + c] * (rank + 1)), name
         assert used_end <= o_fc1 + c_fc1
+        # the pipelined optimizer's own exchange (what the N>1 bench step uses): small bucket in fp32 from the arena,
+        # fc6 row slabs from the bf16 exchange buffer the dW GEMM writes into
+        from drn_wsod_pytorch_amd.engine import build_optimizer
+
+        opt = build_optimizer(G.drn_cfg(G.MODEL_CASES["model_r50c4_tiny"], "cpu"), model)
+        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.bfloat16)
+        assert opt._slab_ends == [16, 40, d1] and e.fc1_grad_bucket.dtype == torch.bfloat16
+        e.arena_g.copy_(base * (rank + 1))
+        vals = (torch.arange(d1 * k1, dtype=torch.float32).view(d1, k1) % 61) * 0.25  # exactly representable in bf16
+        e.fc1_grad_bucket.copy_((vals * (rank + 1)).to(torch.bfloat16))
+        assert opt._exchange("small") is None
+        r0 = 0
+        for r1 in opt._slab_ends:
+            assert opt._exchange(("fc1", r0, r1)) is e.fc1_grad_bucket
+            r0 = r1
+        assert torch.allclose(e.arena_g[:o_fc1], exp[:o_fc1])
+        assert torch.equal(e.arena_g[o_fc1: o_fc1 + c_fc1], base[o_fc1: o_fc1 + c_fc1] * (rank + 1))  # arena fc6 slot unused
+        assert torch.equal(e.fc1_grad_bucket.float(), vals * 3.0)
         q.put((rank, "ok"))
     except Exception as ex:  # noqa: BLE001
         q.put((rank, "FAIL: %r" % (ex,)))
