@@ -158,8 +158,12 @@ def main():
     ap.add_argument("--force-exchange", action="store_true",
                     help="run the N>1 code path (RCCL process group, split-tail graph, per-bucket all-reduce) even with "
                          "one rank: exercises the exchange machinery on a single-GPU box")
+    ap.add_argument("--tail", choices=["auto", "graph", "eager"], default="auto",
+                    help="fc6 dW + optimizer tail of the graphed step: inside the captured graph, or issued eagerly "
+                         "behind it (default, measured +1.3%%; always eager when gradients are exchanged)")
     ap.add_argument("--comm-dtype", choices=["bf16", "fp32"], default=None,
-                    help="dtype of the fc6 gradient buckets on the wire (default: bf16, the compute dtype)")
+                    help="dtype of the fc6 weight-gradient buckets (HBM and xGMI); default bf16 = the compute dtype, the "
+                         "rounding torch.autocast(bf16) applies to a Linear's weight gradient")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -227,7 +231,8 @@ def main():
         from drn_wsod_pytorch_amd.engine import GraphedTrainStep
 
         ops.GEMM_TIMING = None
-        stepper = GraphedTrainStep(model, opt, batches[0], split_tail=dp.exchange)
+        split = dp.exchange or (args.tail != "graph" and not args.no_pipelined_sgd)
+        stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split)
         for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
             last = stepper.step(batches[i % len(batches)], batches[(i + 1) % len(batches)])
         barrier()
@@ -276,9 +281,9 @@ def main():
                                       "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % R,
                           "global_batch": world, "proposals": R, "parallelism": "dp%d" % world},
                "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph),
+               "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
                "grad_exchange": None if not dp.exchange else {
-                   "collective": "RCCL all-reduce per bucket (small tensors fp32, fc6 dW row slabs)",
-                   "fc6_bucket_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
+                   "collective": "RCCL all-reduce per bucket (small tensors fp32, fc6 dW row slabs in fc6_grad_dtype)",
                    "slab_ends": getattr(opt, "_slab_ends", None)},
                "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

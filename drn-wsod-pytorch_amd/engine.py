@@ -71,10 +71,12 @@ class FusedSGD:
         N > 1 and then) updated by the SGD kernel on a second stream the moment its dW GEMM is queued, so the HBM-bound
         optimizer pass hides under the MFMA-bound remaining dW GEMMs; `step()` then only joins the streams.
         Same arithmetic as the plain step (the kernel, the per-group lr/wd and the 1/W scale are identical).
-        comm_dtype (N > 1): dtype of the fc6 weight-gradient buckets on the wire.  torch.bfloat16 = the dW GEMM writes
-        bf16 straight into an exchange buffer (half the xGMI bytes, the dominant cost of the 8-GPU step: 411 MB fp32 per
-        step for R50-C4) and the SGD kernel reads it; default = bf16 in the bf16 compute mode, fp32 (the reference's
-        DDP arithmetic) in the fp32 parity mode.  The small tensors always travel in fp32."""
+        comm_dtype: dtype of the fc6 weight-gradient buckets.  torch.bfloat16 = the dW GEMM rounds its fp32 accumulators
+        once and writes bf16 straight into a bucket buffer that RCCL sums (N > 1) and the SGD kernel reads: half the
+        xGMI bytes (the dominant cost of the 8-GPU step: 411 MB fp32 per step for R50-C4) and 0.4 GB less HBM traffic
+        per step on every GPU.  Default = bf16 in the bf16 compute mode - the same rounding torch.autocast(bf16) applies
+        to a Linear's weight gradient; master weights and momentum stay fp32 - and fp32 (the reference's DDP
+        arithmetic) in the fp32 parity mode.  The small tensors always stay fp32."""
         e = self.engine
         d1 = self.model.roi_heads.box_head.fc1.weight.shape[0]
         world = dp.world if dp is not None else 1
@@ -100,7 +102,7 @@ class FusedSGD:
         if comm_dtype is None:
             from . import get_precision
 
-            comm_dtype = torch.bfloat16 if (self._exchange_on and get_precision() == "bf16") else torch.float32
+            comm_dtype = torch.bfloat16 if get_precision() == "bf16" else torch.float32
         self._comm_dtype = comm_dtype
         e.fc1_grad_bucket = None
         if self._comm_dtype == torch.bfloat16:
@@ -190,6 +192,9 @@ class FusedSGD:
             else:
                 ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
                              shadow=e.arena_s)
+            if what == "small" and hasattr(e, "sh"):
+                e.refresh_transposes()  # fc7 / predictor weights are final for this step: rebuild their K-major twins here
+                e._transposes_fresh = True
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
@@ -490,9 +495,10 @@ class GraphedTrainStep:
             self.feat_next.copy_(self._backbone())
 
     def _main_body(self):
-        losses, _ = self.engine.forward(None, self.rois, self.obj, True, self.img_off, self.n_img, self.gt,
-                                        pooled=self.pooled)
-        sum(losses.values()).backward()  # pipelined SGD buckets fork onto the optimizer stream in here
+        losses, st = self.engine.forward(None, self.rois, self.obj, True, self.img_off, self.n_img, self.gt,
+                                         pooled=self.pooled)
+        # = sum(losses.values()).backward() without autograd's scalar adds / ones / stack launches
+        self.engine.backward(st, None)   # pipelined SGD buckets fork onto the optimizer stream in here
         if not self.split_tail:
             self.opt.step(1.0)           # joins the optimizer stream
         return losses

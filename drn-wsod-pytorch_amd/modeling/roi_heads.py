@@ -352,6 +352,17 @@ class _HeadEngine:
         self._dirty = True
         self._shadow_from_sgd = shadow_fresh
 
+    def refresh_transposes(self):
+        """K-major twins of fc7 / predictor weights for the dX GEMMs.  The pipelined optimizer calls this on its own
+        stream right behind the small-tensor SGD bucket (under the fc6 dW GEMMs) and sets `_transposes_fresh`, which
+        takes the two launches off the front of the next forward."""
+        h, sh = self.h, self.sh
+        fc1, fc2 = h.box_head.fc1, h.box_head.fc2
+        D1, D2, NH = fc1.weight.shape[0], fc2.weight.shape[0], self.NH
+        o, _ = self._seg[self.cols[0][0] + ".weight"]
+        ops.transpose2d(fc2.weight.data, D2, D1, out=sh["W2T"])
+        ops.transpose2d(self.arena_w[o: o + NH * D2].view(NH, D2), NH, D2, out=sh["WhT"])
+
     # ---- compute-dtype shadows of the weights -----------------------------------------------------
     def refresh_shadows(self, dtype):
         key = (dtype,) + tuple(p._version for _, p, _, _, u in self.segments if u)
@@ -385,8 +396,9 @@ class _HeadEngine:
             if sh[nm + "_own"] or (dtype == torch.bfloat16 and not self._shadow_from_sgd):
                 ops.cast2d(src, rows, cols_, sh[nm])
         sh["W1v"] = sh["W1"]
-        ops.transpose2d(fc2.weight.data, D2, D1, out=sh["W2T"])
-        ops.transpose2d(wh, NH, D2, out=sh["WhT"])
+        if not getattr(self, "_transposes_fresh", False):
+            self.refresh_transposes()
+        self._transposes_fresh = False
         self._shadow_key, self._dirty, self._shadow_from_sgd = key, False, False
 
     # ---- workspaces ---------------------------------------------------------------------------------
@@ -538,8 +550,14 @@ class _HeadEngine:
         Mp = kp(M)
         dev = self.arena_w.device
         # per-loss upstream gradients -> per-column scale of dlogits (stays on the device)
-        g = [torch.zeros((), device=dev) if x is None else x.float().reshape(()) for x in gouts]
-        colscale = torch.stack(g)  # one entry per loss; columns find theirs through the static index table
+        if gouts is None:  # d(sum of losses): every loss has upstream gradient 1 (GraphedTrainStep calls this directly)
+            nl = len(st["loss_list"])
+            if getattr(self, "_unit_scale", None) is None or self._unit_scale.numel() != nl or self._unit_scale.device != dev:
+                self._unit_scale = torch.ones((nl,), dtype=torch.float32, device=dev)
+            colscale = self._unit_scale
+        else:
+            g = [torch.zeros((), device=dev) if x is None else x.float().reshape(()) for x in gouts]
+            colscale = torch.stack(g)  # one entry per loss; columns find theirs through the static index table
         key = tuple(st["head_cols"])
         if getattr(self, "_colidx_key", None) != key:
             trained = dict(st["head_cols"])
