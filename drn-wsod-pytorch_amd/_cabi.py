@@ -29,6 +29,7 @@ _SIGS = {
     "drn_cast2d": "ppiilliip",
     "drn_wsddn_fwd_bwd": "pliiipippppppl" + "pi" + "ifp",
     "drn_oicr_targets": "plpii" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",
+    "drn_oicr_refine_chain": "plpiipl" + "ppipp" + "ip" + "ppi" + "ppppppp" + "plpp" + "ifp",
     "drn_softmax_ce": "pliipppplppifp",
     "drn_mean_softmax": "plpiipip",
     "drn_box_reg_loss": "pliippppplppifp",

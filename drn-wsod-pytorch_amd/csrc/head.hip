@@ -320,7 +320,10 @@ struct TargetParams {
   int* pgt_idx; float* pgt_boxes;      // [n_img][gmax], [n_img][gmax][4]
 };
 
-__global__ __launch_bounds__(1024) void oicr_targets_kernel(TargetParams p) {
+constexpr int MAX_CHAIN_HEADS = 8;
+struct TargetMulti { TargetParams h[MAX_CHAIN_HEADS]; };
+
+__device__ __forceinline__ void oicr_targets_body(const TargetParams& p) {
   __shared__ float sv[16];
   __shared__ int si[16];
   __shared__ float gbox[128][4];
@@ -397,6 +400,11 @@ __global__ __launch_bounds__(1024) void oicr_targets_kernel(TargetParams p) {
   }
 }
 
+__global__ __launch_bounds__(1024) void oicr_targets_kernel(TargetParams p) { oicr_targets_body(p); }
+// all refinement heads at once (blockIdx.y = head): head k mines its pseudo ground truth from the probabilities of head
+// k-1, which only need the logits of the ONE predictor GEMM - no dependency between the heads' launches
+__global__ __launch_bounds__(1024) void oicr_targets_multi_kernel(TargetMulti mp) { oicr_targets_body(mp.h[blockIdx.y]); }
+
 struct CeParams {
   const float* logits; long ld; int col0; int C;  // C = K+1 columns starting at col0
   const int* labels; const float* weights;         // [M] (null => inference: probs only)
@@ -411,7 +419,9 @@ struct CeParams {
 // (every block gets the same total), writes the loss and the gradient of the logits.
 constexpr int CE_ROWS = 16;
 
-__global__ __launch_bounds__(256) void ce_rows_kernel(CeParams p, float* partial) {
+struct CeMulti { CeParams h[MAX_CHAIN_HEADS]; float* partial[MAX_CHAIN_HEADS]; };
+
+__device__ __forceinline__ void ce_rows_body(const CeParams& p, float* partial) {
   __shared__ float sl[4], sv[4];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float lsum = 0.f, vsum = 0.f;
@@ -441,8 +451,10 @@ __global__ __launch_bounds__(256) void ce_rows_kernel(CeParams p, float* partial
     partial[2 * blockIdx.x + 1] = ((sv[0] + sv[1]) + sv[2]) + sv[3];
   }
 }
+__global__ __launch_bounds__(256) void ce_rows_kernel(CeParams p, float* partial) { ce_rows_body(p, partial); }
+__global__ __launch_bounds__(256) void ce_rows_multi_kernel(CeMulti mp) { ce_rows_body(mp.h[blockIdx.y], mp.partial[blockIdx.y]); }
 
-__global__ __launch_bounds__(256) void ce_grad_kernel(CeParams p, const float* partial, int nparts) {
+__device__ __forceinline__ void ce_grad_body(const CeParams& p, const float* partial, int nparts) {
   __shared__ float sh[2][256];
   float l = 0.f, v = 0.f;
   for (int q = threadIdx.x; q < nparts; q += 256) { l += partial[2 * q]; v += partial[2 * q + 1]; }
@@ -465,6 +477,10 @@ __global__ __launch_bounds__(256) void ce_grad_kernel(CeParams p, const float* p
     for (int c = lane; c < p.C; c += 64)
       p.dlogits[(long)r * p.ld_d + p.col0 + c] = f * (p.probs[(long)r * p.C + c] - (c == lab ? 1.f : 0.f));
   }
+}
+__global__ __launch_bounds__(256) void ce_grad_kernel(CeParams p, const float* partial, int nparts) { ce_grad_body(p, partial, nparts); }
+__global__ __launch_bounds__(256) void ce_grad_multi_kernel(CeMulti mp, int nparts) {
+  ce_grad_body(mp.h[blockIdx.y], mp.partial[blockIdx.y], nparts);
 }
 
 // OICROutputs.box_reg_loss (fast_rcnn.py:1146-1211): foreground rows only, class-specific columns 4c..4c+3,
@@ -739,6 +755,51 @@ int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxe
   p.labels = labels; p.weights = weights; p.matched = matched; p.gt_boxes = gt_boxes; p.pgt_idx = pgt_idx;
   p.pgt_boxes = pgt_boxes;
   hipLaunchKernelGGL(oicr_targets_kernel, dim3(n_img), dim3(1024), 0, (hipStream_t)stream, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// All n_heads refinement branches in four launches (softmax of every head, pseudo-GT mining + labelling of every head,
+// CE partials, CE combine + gradient) instead of three per head.  Per-head outputs are [n_heads] x the single-head
+// shape, contiguous.  Non-regressing heads only (pgt boxes = decoded zero deltas of the proposals for heads >= 1).
+int drn_oicr_refine_chain(const float* logits, long ld, const int* col0s_host, int n_heads, int K, const float* scores0,
+                          long ld_s0, const float* props, const int* img_off, int n_img, const int* gt_classes,
+                          const int* gt_count, int gmax, const float* img_scores, const float* thresholds,
+                          const int* thr_labels, int nthr, float* probs, int* labels, float* weights, int* matched,
+                          float* gt_boxes, int* pgt_idx, float* pgt_boxes, float* dlogits, long ld_d, float* losses,
+                          float* scratch, int M, float loss_scale, void* stream) {
+  if (!logits || !col0s_host || !scores0 || !props || !img_off || !gt_classes || !gt_count || !img_scores || !probs ||
+      !labels || !weights || !matched || !gt_boxes || !pgt_idx || !pgt_boxes || !losses || !scratch)
+    return DRN_ERR_ARG;
+  if (n_heads < 1 || n_heads > MAX_CHAIN_HEADS || K < 1 || K + 1 > 128 || gmax < 1 || gmax > 128 || nthr < 1 || nthr > 3)
+    return DRN_ERR_ARG;
+  if (M <= 0 || n_img < 1) return M == 0 ? DRN_OK : DRN_ERR_ARG;
+  const int C = K + 1, nb = (M + CE_ROWS - 1) / CE_ROWS;
+  TargetMulti tm;
+  CeMulti probs_only, ce;
+  for (int k = 0; k < n_heads; ++k) {
+    float* pk = probs + (long)k * M * C;
+    TargetParams& t = tm.h[k];
+    t.prev_scores = k == 0 ? scores0 : probs + (long)(k - 1) * M * C;
+    t.ld_s = k == 0 ? ld_s0 : C;
+    t.prev_boxes = props; t.box_cols = 4; t.zero_delta_decode = k > 0; t.props = props;
+    t.img_off = img_off; t.gt_classes = gt_classes; t.gt_count = gt_count; t.gmax = gmax; t.img_scores = img_scores;
+    t.K = K; t.nthr = nthr;
+    for (int i = 0; i < 3; ++i) t.thr[i] = i < nthr ? thresholds[i] : 0.f;
+    for (int i = 0; i < 4; ++i) t.lab[i] = i <= nthr ? thr_labels[i] : 0;
+    t.labels = labels + (long)k * M; t.weights = weights + (long)k * M; t.matched = matched + (long)k * M;
+    t.gt_boxes = gt_boxes + (long)k * M * 4; t.pgt_idx = pgt_idx + (long)k * n_img * gmax;
+    t.pgt_boxes = pgt_boxes + (long)k * n_img * gmax * 4;
+    probs_only.h[k] = CeParams{logits, ld, col0s_host[k], C, nullptr, nullptr, pk, nullptr, 0, nullptr, M, loss_scale};
+    probs_only.partial[k] = nullptr;
+    ce.h[k] = CeParams{logits, ld, col0s_host[k], C, t.labels, t.weights, pk, dlogits, ld_d, losses + k, M, loss_scale};
+    ce.partial[k] = scratch + (long)k * 2 * nb;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ce_rows_multi_kernel, dim3(nb, n_heads), dim3(256), 0, st, probs_only);
+  hipLaunchKernelGGL(oicr_targets_multi_kernel, dim3(n_img, n_heads), dim3(1024), 0, st, tm);
+  hipLaunchKernelGGL(ce_rows_multi_kernel, dim3(nb, n_heads), dim3(256), 0, st, ce);
+  hipLaunchKernelGGL(ce_grad_multi_kernel, dim3(nb, n_heads), dim3(256), 0, st, ce, nb);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

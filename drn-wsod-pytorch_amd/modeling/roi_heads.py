@@ -511,10 +511,20 @@ class _HeadEngine:
         prev_scores, prev_boxes, prev_zero = scores, gt["props"], False
         aux = dict(scores=scores, img_scores=img_scores, targets=[])
         thr = h.proposal_matcher.thresholds[1:-1]
+        chain = None
+        if h.refine_K > 0 and not any(h.refine_reg[: h.refine_K]):
+            # no branch regresses boxes: every branch's targets depend only on the previous branch's softmax of logits
+            # that already exist, so the whole cascade is four launches (drn_oicr_refine_chain)
+            chain = ops.oicr_refine_chain(w["logits"], [col["r%d" % k] for k in range(h.refine_K)], K, scores,
+                                          gt["props"], img_off, n_img, gt["classes"], gt["count"], img_scores, thr,
+                                          h.proposal_matcher.labels, dlogits=dl)
         for k in range(h.refine_K):
-            tg = ops.oicr_targets(prev_scores, prev_boxes, gt["props"], img_off, n_img, gt["classes"], gt["count"],
-                                  img_scores, K, thr, h.proposal_matcher.labels, zero_delta_decode=prev_zero)
-            probs, loss = ops.softmax_ce(w["logits"], col["r%d" % k], K + 1, tg["labels"], tg["weights"], dlogits=dl)
+            if chain is not None:
+                tg, probs, loss = chain[k]
+            else:
+                tg = ops.oicr_targets(prev_scores, prev_boxes, gt["props"], img_off, n_img, gt["classes"], gt["count"],
+                                      img_scores, K, thr, h.proposal_matcher.labels, zero_delta_decode=prev_zero)
+                probs, loss = ops.softmax_ce(w["logits"], col["r%d" % k], K + 1, tg["labels"], tg["weights"], dlogits=dl)
             loss_names.append("loss_cls_r%d" % k)
             loss_list.append(loss.view(()))
             head_cols.append(("r%d" % k, len(loss_list) - 1))

@@ -204,6 +204,31 @@ def oicr_targets(prev_scores, prev_boxes, props, img_off, n_img, gt_classes, gt_
     return out
 
 
+def oicr_refine_chain(logits, col0s, K, scores0, props, img_off, n_img, gt_classes, gt_count, img_scores,
+                      thresholds=(0.5,), labels=(0, 1), dlogits=None, loss_scale=1.0):
+    """All (non-regressing) refinement branches at once; returns per-head (targets dict, probs, loss) views."""
+    M, dev, nh = props.shape[0], props.device, len(col0s)
+    gmax = gt_classes.shape[1]
+    nb = (M + 15) // 16
+    e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+    probs = e((nh, M, K + 1), torch.float32)
+    out = dict(labels=e((nh, M), torch.int32), weights=e((nh, M), torch.float32), matched=e((nh, M), torch.int32),
+               gt_boxes=e((nh, M, 4), torch.float32), pgt_idx=e((nh, n_img, gmax), torch.int32),
+               pgt_boxes=e((nh, n_img, gmax, 4), torch.float32))
+    losses = e((nh,), torch.float32)
+    scratch = e((nh * 2 * nb,), torch.float32)
+    th, lb, c0 = C.host_floats(thresholds), C.host_ints(labels), C.host_ints(col0s)
+    vp = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    C.call("drn_oicr_refine_chain", C.ptr(logits), _2d(logits), vp(c0), nh, K, C.ptr(scores0), _2d(scores0),
+           C.ptr(props), C.ptr(img_off), n_img, C.ptr(gt_classes), C.ptr(gt_count), gmax, C.ptr(img_scores),
+           vp(th), vp(lb), len(thresholds),
+           C.ptr(probs), C.ptr(out["labels"]), C.ptr(out["weights"]), C.ptr(out["matched"]), C.ptr(out["gt_boxes"]),
+           C.ptr(out["pgt_idx"]), C.ptr(out["pgt_boxes"]),
+           C.ptr(dlogits), _2d(dlogits) if dlogits is not None else 0, C.ptr(losses), C.ptr(scratch), M,
+           float(loss_scale), C.stream())
+    return [({k: v[i] for k, v in out.items()}, probs[i], losses[i: i + 1]) for i in range(nh)]
+
+
 def softmax_ce(logits, col0, ncol, labels=None, weights=None, dlogits=None, loss_scale=1.0):
     M = logits.shape[0]
     probs = torch.empty((M, ncol), dtype=torch.float32, device=logits.device)

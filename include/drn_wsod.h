@@ -137,6 +137,18 @@ int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxe
                      int nthr, int* labels, float* weights, int* matched, float* gt_boxes, int* pgt_idx,
                      float* pgt_boxes, void* stream);
 
+/* The whole refinement cascade of OICRROIHeads._forward_box (roi_heads_oicr.py:372-395: for each branch k,
+ * get_pgt on the previous branch's scores -> label_and_sample_proposals -> OICROutputs.losses) for n_heads
+ * NON-regressing branches in four launches: = drn_softmax_ce(probs only) / drn_oicr_targets / drn_softmax_ce per head,
+ * bit for bit.  scores0 [M][ld_s0] = the WSDDN scores feeding branch 0.  Per-head outputs are [n_heads] x the
+ * single-head arrays, contiguous; scratch: n_heads * 2*ceil(M/16) floats; col0s_host: host array [n_heads]. */
+int drn_oicr_refine_chain(const float* logits, long ld, const int* col0s_host, int n_heads, int K, const float* scores0,
+                          long ld_s0, const float* props, const int* img_off, int n_img, const int* gt_classes,
+                          const int* gt_count, int gmax, const float* img_scores, const float* thresholds,
+                          const int* thr_labels, int nthr, float* probs, int* labels, float* weights, int* matched,
+                          float* gt_boxes, int* pgt_idx, float* pgt_boxes, float* dlogits, long ld_d, float* losses,
+                          float* scratch, int M, float loss_scale, void* stream);
+
 /* OICROutputs.softmax_cross_entropy_loss (fast_rcnn.py:1087-1096,1128-1144), predict_probs (:1561-1575)
  * and the backward: loss = sum_r w_r CE_r / #{w_r > 1e-12}.  labels == NULL => probabilities only.
  * scratch: 2*ceil(M/16) floats (two-stage deterministic reduction), required with labels. */

@@ -375,6 +375,48 @@ def test_oicr_targets(drn, K, M_per, with_bg):
         assert out["pgt_idx"][i, : len(idx)].cpu().tolist() == idx.tolist()
 
 
+@pytest.mark.parametrize("K,M_per,nh", [(20, [2000], 3), (6, [90, 77], 2), (80, [1500, 500], 4)])
+def test_oicr_refine_chain_equals_per_head_sequence(drn, K, M_per, nh):
+    """drn_oicr_refine_chain (all branches in four launches) == targets -> softmax-CE per branch, bit for bit: labels,
+    matches, weights, mined boxes, probabilities, losses and the gradient of the logits"""
+    M, n_img = sum(M_per), len(M_per)
+    rs = np.random.RandomState(77)
+    C_ = K + 1
+    ld = 2 * K + nh * C_ + 5
+    col0s = [2 * K + k * C_ for k in range(nh)]
+    logits = torch.from_numpy(rs.standard_normal((M, ld)).astype(np.float32) * 3).to(DEV)
+    scores0 = torch.from_numpy(rs.rand(M, K).astype(np.float32)).to(DEV)
+    props = _boxes(M, 33).to(DEV)
+    img_scores = torch.from_numpy(rs.rand(n_img, K).astype(np.float32)).to(DEV)
+    gmax = 4
+    gcl = torch.zeros((n_img, gmax), dtype=torch.int32)
+    gcn = torch.zeros((n_img,), dtype=torch.int32)
+    for i in range(n_img):
+        g = torch.unique(torch.from_numpy(rs.randint(0, K, 3)))
+        gcl[i, : len(g)] = g.int()
+        gcn[i] = len(g)
+    gcl, gcn = gcl.to(DEV), gcn.to(DEV)
+    off = torch.tensor([0] + list(np.cumsum(M_per)), dtype=torch.int32, device=DEV)
+    dl_a = torch.zeros((M, ld), device=DEV)
+    dl_b = torch.zeros((M, ld), device=DEV)
+    chain = drn.oicr_refine_chain(logits, col0s, K, scores0, props, off, n_img, gcl, gcn, img_scores, dlogits=dl_a)
+    prev, zero = scores0, False
+    for k in range(nh):
+        tg = drn.oicr_targets(prev, props, props, off, n_img, gcl, gcn, img_scores, K, zero_delta_decode=zero)
+        probs, loss = drn.softmax_ce(logits, col0s[k], C_, tg["labels"], tg["weights"], dlogits=dl_b)
+        ctg, cprobs, closs = chain[k]
+        for key in ("labels", "weights", "matched", "gt_boxes"):
+            assert torch.equal(ctg[key], tg[key]), (k, key)
+        for i in range(n_img):  # only the first G_i mined entries per image are defined
+            g = int(gcn[i])
+            assert torch.equal(ctg["pgt_idx"][i, :g], tg["pgt_idx"][i, :g]), (k, i)
+            assert torch.equal(ctg["pgt_boxes"][i, :g], tg["pgt_boxes"][i, :g]), (k, i)
+        assert torch.equal(cprobs, probs) and torch.equal(closs, loss), k
+        prev, zero = probs, True
+    assert torch.equal(dl_a, dl_b)
+    assert float(dl_a.abs().max()) > 0
+
+
 @pytest.mark.parametrize("K,M", [(20, 2000), (5, 77), (80, 4000)])
 def test_softmax_ce(drn, K, M):
     rs = np.random.RandomState(41)
