@@ -427,8 +427,12 @@ class GraphedTrainStep:
         self.obj = torch.zeros((M,), dtype=torch.float32, device=dev)
         self.obj_next = torch.zeros((M,), dtype=torch.float32, device=dev)
         self.props = torch.zeros((M, 4), dtype=torch.float32, device=dev)
-        self.gt = dict(onehot=torch.zeros((n_img, K), device=dev), classes=torch.zeros((n_img, K), dtype=torch.int32, device=dev),
-                       count=torch.zeros((n_img,), dtype=torch.int32, device=dev), props=self.props, max_rows=max(self.nper))
+        # image-level labels live in ONE device block (one H2D copy per step): [onehot f32 | classes i32 | count i32]
+        self._gt_block = torch.zeros((2 * n_img * K + n_img,), dtype=torch.int32, device=dev)
+        nk = n_img * K
+        self.gt = dict(onehot=self._gt_block[:nk].view(torch.float32).view(n_img, K),
+                       classes=self._gt_block[nk: 2 * nk].view(n_img, K), count=self._gt_block[2 * nk:],
+                       props=self.props, max_rows=max(self.nper))
         self.img_off = torch.tensor(off, dtype=torch.int32, device=dev)
         self.losses = None
         self._side = torch.cuda.Stream()
@@ -442,24 +446,23 @@ class GraphedTrainStep:
         staging buffers so the H2D copies are truly asynchronous - a pageable source would block the host until the
         previous replay has drained and leave the GPU idle between replays."""
         ints = [torch.unique(x["instances"].gt_classes.cpu(), sorted=True) for x in batch]
+        nk = self.n_img * self.K
         if not hasattr(self, "_ring"):
-            mk = lambda shape, dt: torch.zeros(shape, dtype=dt).pin_memory()
-            self._ring = [dict(oh=mk((self.n_img, self.K), torch.float32), cl=mk((self.n_img, self.K), torch.int32),
-                               cnt=mk((self.n_img,), torch.int32), ev=None) for _ in range(8)]
+            self._ring = [dict(buf=torch.zeros_like(self._gt_block, device="cpu").pin_memory(), ev=None) for _ in range(8)]
             self._ring_i = 0
         slot = self._ring[self._ring_i]
         self._ring_i = (self._ring_i + 1) % len(self._ring)
         if slot["ev"] is not None:
             slot["ev"].synchronize()  # only blocks when the host is a full ring ahead of the GPU
-        slot["oh"].zero_()
-        slot["cl"].zero_()
+        buf = slot["buf"]
+        buf.zero_()
+        oh = buf[:nk].view(torch.float32).view(self.n_img, self.K)
+        cl = buf[nk: 2 * nk].view(self.n_img, self.K)
         for i, g in enumerate(ints):
-            slot["oh"][i, g] = 1
-            slot["cl"][i, : len(g)] = g.to(torch.int32)
-            slot["cnt"][i] = len(g)
-        self.gt["onehot"].copy_(slot["oh"], non_blocking=True)
-        self.gt["classes"].copy_(slot["cl"], non_blocking=True)
-        self.gt["count"].copy_(slot["cnt"], non_blocking=True)
+            oh[i, g] = 1
+            cl[i, : len(g)] = g.to(torch.int32)
+            buf[2 * nk + i] = len(g)
+        self._gt_block.copy_(buf, non_blocking=True)
         slot["ev"] = torch.cuda.Event()
         slot["ev"].record()
 
@@ -485,8 +488,7 @@ class GraphedTrainStep:
     def _pool_next(self):
         """pooled fc6 operand (A, A^T) of the staged next batch + hand its proposals over to the heads"""
         self.pooled = self.engine.pool(self.feat_next, self.rois_next, self.obj_next, True, slot=0)
-        self.rois.copy_(self.rois_next)
-        self.obj.copy_(self.obj_next)
+        # the heads only need the pooled operand and the proposal boxes (pseudo-GT mining / IoU labelling) of a batch
         self.props.copy_(self.rois_next[:, 1:])
 
     # ---- the three captured pieces ---------------------------------------------------------------------------
