@@ -82,11 +82,12 @@ class FusedSGD:
         world = dp.world if dp is not None else 1
         if slab_rows is None:
             # 256-row tile granularity of the dW GEMM.  Single GPU: two equal slabs (measured: 3+ forked buckets make the
-            # HIP graph executor schedule the branches badly, 395 -> 310 img/s).  N > 1: 4 equal slabs feed the
-            # interconnect earlier
+            # HIP graph executor schedule the branches badly, 395 -> 310 img/s).  N > 1: two slabs at 5/8 of the rows -
+            # with 196 column tiles per row-tile the launches are 980 and 588 tiles = 3.83 and 2.3 rounds of the 256
+            # CUs (7 rounds, like one launch; four equal slabs would be 8), and the first fc6 bucket is final about
+            # when the all-reduce of the small tensors in front of it has drained
             t = (d1 + 255) // 256
-            slab_rows = ([min(d1, ((t + 1) // 2) * 256)] if world == 1
-                         else [min(d1, ((i + 1) * t // 4) * 256) for i in range(3)])
+            slab_rows = [min(d1, ((t + 1) // 2) * 256)] if world == 1 else [min(d1, ((5 * t + 7) // 8) * 256)]
             slab_rows = sorted(set(r for r in slab_rows if 0 < r < d1)) + [d1]
         import os
         if os.environ.get("DRN_SGD_SLAB_TILEROWS"):  # tuning hook, e.g. "5" or "5,7"
@@ -98,6 +99,11 @@ class FusedSGD:
         self._dp, self._pipelined = dp, True
         self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._bucket_segs = {}
+        # with an exchange the optimizer stream carries only the link-bound all-reduces (one event per bucket); the
+        # HBM-bound SGD launches are issued by step() on the caller's stream, each behind its bucket's event, so the
+        # update of bucket i runs under the all-reduce of bucket i+1 without a fifth stream (HIP multiplexes streams
+        # onto 4 hardware queues by default; a fifth aliased the main stream's queue and cost 20 %)
+        self._deferred = []
         self._exchange_on = dp is not None and dp.exchange
         if comm_dtype is None:
             from . import get_precision
@@ -186,15 +192,25 @@ class FusedSGD:
         self._opt_stream.wait_event(ev)
         with torch.cuda.stream(self._opt_stream):
             bucket = self._exchange(what)
-            if bucket is not None:
-                ops.sgd_step(e.arena_w, self._mom, bucket, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
-                             shadow=e.arena_s, grad_off=e._seg["fc1.weight"][0])
-            else:
-                ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
-                             shadow=e.arena_s)
-            if what == "small" and hasattr(e, "sh"):
-                e.refresh_transposes()  # fc7 / predictor weights are final for this step: rebuild their K-major twins here
-                e._transposes_fresh = True
+            if self._exchange_on:
+                evc = torch.cuda.Event()
+                evc.record(self._opt_stream)
+                self._deferred.append((what, bucket, segs, nseg, evc))
+                return
+            self._update(what, bucket, segs, nseg)
+
+    def _update(self, what, bucket, segs, nseg):
+        e = self.engine
+        world = self._dp.world if self._dp is not None else 1
+        if bucket is not None:
+            ops.sgd_step(e.arena_w, self._mom, bucket, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
+                         shadow=e.arena_s, grad_off=e._seg["fc1.weight"][0])
+        else:
+            ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
+                         shadow=e.arena_s)
+        if what == "small" and hasattr(e, "sh"):
+            e.refresh_transposes()  # fc7 / predictor weights are final for this step: rebuild their K-major twins here
+            e._transposes_fresh = True
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
@@ -207,8 +223,16 @@ class FusedSGD:
         if not e._grads_valid:
             raise DrnError("optimizer.step() before any backward()")
         if getattr(self, "_pipelined", False):
-            # every bucket was already updated on the optimizer stream during backward(): join it
-            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            cur = torch.cuda.current_stream()
+            if self._deferred:
+                # exchanged buckets: update each one here as soon as its all-reduce (optimizer stream) has finished
+                for what, bucket, segs, nseg, evc in self._deferred:
+                    cur.wait_event(evc)
+                    self._update(what, bucket, segs, nseg)
+                self._deferred = []
+            else:
+                # every bucket was already updated on the optimizer stream during backward(): join it
+                cur.wait_stream(self._opt_stream)
             self._steps += 1
             e.mark_dirty(shadow_fresh=e.arena_s is not None)
             return
