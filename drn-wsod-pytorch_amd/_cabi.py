@@ -19,6 +19,7 @@ _SIGS = {
     "drn_conv2d_nhwc": "pppppp" + "iiiiiiiiii" + "lll" + "iip",
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
+    "drn_roi_pool_backward_nhwc": "ppppp" + "iiiiii" + "f" + "l" + "iiiip",
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliiilip",
     "drn_gemm_nt_sgd": "ppiiilli" + "ppplp" + "fifp",

@@ -247,6 +247,81 @@ __global__ __launch_bounds__(256) void roi_kernel(RoiParams p) {
     }
 }
 
+// Backward of RoIPool (MODE 0: scatter to the saved arg-max) / ROIAlign (MODE 1: bilinear scatter,
+// ROIAlign_cuda.cu:141-250 semantics), fused with the objectness scaling of the forward.  One block = one ROI x 64
+// channels like roi_kernel: the [64 x P*P] slice of grad_out is read coalesced into LDS, then lane = channel scatters
+// with fp32 atomics into the NHWC gradient map - neighbouring lanes hit neighbouring addresses.  Like the
+// reference's CUDA kernels the accumulation order is not fixed (only used when the backbone trains).
+struct RoiBwdParams {
+  const char* grad_out;  // [M][ld], k = c*P*P + bin
+  const float* rois; const float* obj; const int32_t* argmax;
+  float* dfeat;          // [N][H][W][C] fp32, zeroed by the launcher
+  int N, H, W, C, P, M; float scale; long ld; int sampling_ratio, aligned;
+};
+
+template <int DT, int MODE>
+__global__ __launch_bounds__(256) void roi_bwd_kernel(RoiBwdParams p) {
+  using E = ElemOf<DT>;
+  using T = typename E::type;
+  __shared__ float tile[RP_CH][RP_MAXBIN + 1];
+  __shared__ int atile[RP_CH][RP_MAXBIN + 1];
+  const int m = blockIdx.x, c0 = blockIdx.y * RP_CH;
+  const int cl = threadIdx.x & 63, bg = threadIdx.x >> 6;
+  const int c = c0 + cl;
+  const float* roi = p.rois + 5 * (long)m;
+  const int b = (int)roi[0];
+  const int PP = p.P * p.P;
+  const float mul = p.obj ? p.obj[m] + 1.f : 1.f;
+  const int nvalid = min(RP_CH, p.C - c0) * PP;
+  const T* grow = (const T*)p.grad_out + (long)m * p.ld + (long)c0 * PP;
+  for (int i = threadIdx.x; i < nvalid; i += 256) {
+    const int lc = i / PP;
+    tile[lc][i - lc * PP] = E::ld(grow + i) * mul;
+    if (MODE == 0) atile[lc][i - lc * PP] = p.argmax[(long)m * p.C * PP + (long)c0 * PP + i];
+  }
+  __syncthreads();
+  if (c >= p.C) return;
+  float* gb = p.dfeat + (long)b * p.H * p.W * p.C + c;
+  if (MODE == 0) {
+    for (int bin = bg; bin < PP; bin += 4) {
+      const int a = atile[cl][bin];
+      if (a >= 0) atomicAdd(gb + (long)a * p.C, tile[cl][bin]);
+    }
+  } else {
+    const float off = p.aligned ? 0.5f : 0.f;
+    const float sw = roi[1] * p.scale - off, sh = roi[2] * p.scale - off;
+    const float ew = roi[3] * p.scale - off, eh = roi[4] * p.scale - off;
+    float rw = ew - sw, rh = eh - sh;
+    if (!p.aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+    const float bin_h = rh / (float)p.P, bin_w = rw / (float)p.P;
+    const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(rh / p.P);
+    const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(rw / p.P);
+    const float count = (float)(gh * gw);
+    for (int bin = bg; bin < PP; bin += 4) {
+      const int ph = bin / p.P, pw = bin - ph * p.P;
+      const float g = tile[cl][bin];
+      for (int iy = 0; iy < gh; ++iy) {
+        const float yy = sh + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float xx = sw + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
+          float x = xx, y = yy;
+          if (y < -1.0f || y > p.H || x < -1.0f || x > p.W) continue;
+          if (y <= 0) y = 0;
+          if (x <= 0) x = 0;
+          int yl = (int)y, xl = (int)x, yh, xh;
+          if (yl >= p.H - 1) { yh = yl = p.H - 1; y = (float)yl; } else yh = yl + 1;
+          if (xl >= p.W - 1) { xh = xl = p.W - 1; x = (float)xl; } else xh = xl + 1;
+          const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+          atomicAdd(gb + ((long)yl * p.W + xl) * p.C, g * (hy * hx) / count);
+          atomicAdd(gb + ((long)yl * p.W + xh) * p.C, g * (hy * lx) / count);
+          atomicAdd(gb + ((long)yh * p.W + xl) * p.C, g * (ly * hx) / count);
+          atomicAdd(gb + ((long)yh * p.W + xh) * p.C, g * (ly * lx) / count);
+        }
+      }
+    }
+  }
+}
+
 // ROIPool specialised for the 7x7 pooler every DRN-WSOD config uses.  One block = one ROI x 256 channels (four
 // 64-channel chunks, so the ROI geometry, the 49 bin rectangles and the window's pixel table are computed once);
 // per chunk the window pixels are staged in LDS by 16-B loads, the bin maxima come out of LDS, and the
@@ -656,6 +731,28 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
   else if (in_dtype == DRN_BF16 && out_dtype == DRN_F32) { if (mode == 0) RP_LAUNCH(DRN_BF16, DRN_F32, 0); else RP_LAUNCH(DRN_BF16, DRN_F32, 1); }
   else return DRN_ERR_ARG;
 #undef RP_LAUNCH
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// d(feat) of drn_roi_pool_nhwc: grad_out [M][ld_g] (k = c*P*P + bin, fp32 or bf16) -> dfeat [N][H][W][C] fp32 (zeroed
+// here).  mode 0 needs the arg-max the forward returned; `objectness` as in the forward (fused scaling).
+int drn_roi_pool_backward_nhwc(const void* grad_out, const float* rois, const float* objectness, const int32_t* argmax,
+                               float* dfeat, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_g,
+                               int mode, int sampling_ratio, int aligned, int grad_dtype, void* stream) {
+  if (!grad_out || !rois || !dfeat || P < 1 || P * P > RP_MAXBIN || M < 0 || (mode != 0 && mode != 1)) return DRN_ERR_ARG;
+  if ((mode == 0 && !argmax) || ld_g < (long)C * P * P || N < 1 || H < 1 || W < 1 || C < 1) return DRN_ERR_ARG;
+  if (grad_dtype != DRN_F32 && grad_dtype != DRN_BF16) return DRN_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (hipMemsetAsync(dfeat, 0, sizeof(float) * (size_t)N * H * W * C, st) != hipSuccess) return DRN_ERR_LAUNCH;
+  if (M == 0) return DRN_OK;
+  RoiBwdParams p{(const char*)grad_out, rois, objectness, argmax, dfeat, N, H, W, C, P, M, spatial_scale, ld_g,
+                 sampling_ratio, aligned};
+  dim3 grid(M, (C + RP_CH - 1) / RP_CH), block(256);
+#define RB_LAUNCH(DT, MD) hipLaunchKernelGGL((roi_bwd_kernel<DT, MD>), grid, block, 0, st, p)
+  if (grad_dtype == DRN_BF16) { if (mode == 0) RB_LAUNCH(DRN_BF16, 0); else RB_LAUNCH(DRN_BF16, 1); }
+  else { if (mode == 0) RB_LAUNCH(DRN_F32, 0); else RB_LAUNCH(DRN_F32, 1); }
+#undef RB_LAUNCH
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

@@ -199,6 +199,34 @@ class Linear(nn.Linear):
         return out
 
 
+class _ROIOp(torch.autograd.Function):
+    """detectron2/layers/roi_align.py:22-59 (`_ROIAlign`) and torchvision's RoIPool function: forward through
+    drn_roi_pool_nhwc, backward w.r.t. the feature map through drn_roi_pool_backward_nhwc (rois get no gradient)."""
+
+    @staticmethod
+    def forward(ctx, input, rois, p, scale, mode, sampling_ratio, aligned):
+        x = to_nhwc(input, input.dtype if input.dtype in (torch.float32, torch.bfloat16) else torch.float32)
+        rois = rois.float().contiguous()
+        need = input.requires_grad
+        res = ops.roi_pool_nhwc(x, rois, None, p, scale, mode=mode, sampling_ratio=sampling_ratio, aligned=aligned,
+                                want_argmax=(need and mode == 0))
+        out, arg = res if (need and mode == 0) else (res, None)
+        ctx.args = (tuple(x.shape), p, scale, mode, sampling_ratio, aligned, input.dtype)
+        ctx.save_for_backward(rois, arg)
+        c = input.shape[1]
+        return out[:, : c * p * p].reshape(rois.shape[0], c, p, p)
+
+    @staticmethod
+    def backward(ctx, grad):
+        rois, arg = ctx.saved_tensors
+        shape, p, scale, mode, sampling_ratio, aligned, dtype = ctx.args
+        g = grad.reshape(grad.shape[0], -1)
+        g = (g if g.dtype in (torch.float32, torch.bfloat16) else g.float()).contiguous()
+        d = ops.roi_pool_backward_nhwc(g, rois, None, shape, p, scale, mode=mode, sampling_ratio=sampling_ratio,
+                                       aligned=aligned, argmax=arg)
+        return d.permute(0, 3, 1, 2).to(dtype), None, None, None, None, None, None
+
+
 class ROIAlign(nn.Module):
     """detectron2/layers/roi_align.py:63-117."""
 
@@ -211,12 +239,8 @@ class ROIAlign(nn.Module):
 
     def forward(self, input, rois):
         assert rois.dim() == 2 and rois.size(1) == 5
-        p = self.output_size[0]
-        x = to_nhwc(input, input.dtype if input.dtype in (torch.float32, torch.bfloat16) else torch.float32)
-        out = ops.roi_pool_nhwc(x, rois.float().contiguous(), None, p, self.spatial_scale, mode=1,
-                                sampling_ratio=self.sampling_ratio, aligned=self.aligned)
-        c = input.shape[1]
-        return out[:, : c * p * p].reshape(rois.shape[0], c, p, p)
+        assert rois.dim() == 2 and rois.size(1) == 5
+        return _ROIOp.apply(input, rois, self.output_size[0], self.spatial_scale, 1, self.sampling_ratio, self.aligned)
 
     def __repr__(self):
         return "ROIAlign(output_size={}, spatial_scale={}, sampling_ratio={}, aligned={})".format(
@@ -232,11 +256,7 @@ class RoIPool(nn.Module):
         self.spatial_scale = spatial_scale
 
     def forward(self, input, rois):
-        p = self.output_size[0]
-        x = to_nhwc(input, input.dtype if input.dtype in (torch.float32, torch.bfloat16) else torch.float32)
-        out = ops.roi_pool_nhwc(x, rois.float().contiguous(), None, p, self.spatial_scale, mode=0)
-        c = input.shape[1]
-        return out[:, : c * p * p].reshape(rois.shape[0], c, p, p)
+        return _ROIOp.apply(input, rois, self.output_size[0], self.spatial_scale, 0, 0, False)
 
     def __repr__(self):
         return "RoIPool(output_size={}, spatial_scale={})".format(self.output_size, self.spatial_scale)

@@ -123,6 +123,18 @@ def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, al
     return (out, arg) if want_argmax else out
 
 
+def roi_pool_backward_nhwc(grad_out, rois, objectness, feat_shape, P, scale, mode=0, sampling_ratio=0, aligned=False,
+                           argmax=None):
+    """grad_out [M, >= C*P*P] -> d(feat) [N,H,W,C] fp32 (see drn_roi_pool_backward_nhwc)."""
+    n, h, w, c = feat_shape
+    m = rois.shape[0]
+    dfeat = torch.empty((n, h, w, c), dtype=torch.float32, device=grad_out.device)
+    C.call("drn_roi_pool_backward_nhwc", C.ptr(grad_out), C.ptr(rois), C.ptr(objectness), C.ptr(argmax), C.ptr(dfeat),
+           n, h, w, c, P, m, float(scale), _2d(grad_out), mode, sampling_ratio, int(aligned), C.dt(grad_out.dtype),
+           C.stream())
+    return dfeat
+
+
 def transpose2d(inp, rows, cols, out=None, out_dtype=None):
     out_dtype = out_dtype or inp.dtype
     if out is None:

@@ -63,6 +63,14 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
                       long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
                       void* stream);
 
+/* Backward of the above w.r.t. the feature map: torchvision RoIPool's backward (scatter to the arg-max the forward
+ * returned) and roi_align_backward (detectron2/layers/csrc/ROIAlign/ROIAlign.h:93-128, ROIAlign_cuda.cu:141-250),
+ * with the forward's objectness scaling applied to grad_out.  grad_out [M][ld_g] (column c*P*P + bin, fp32 or bf16);
+ * dfeat [N][H][W][C] fp32 is zeroed and accumulated with fp32 atomics like the reference's CUDA kernels. */
+int drn_roi_pool_backward_nhwc(const void* grad_out, const float* rois, const float* objectness, const int32_t* argmax,
+                               float* dfeat, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_g,
+                               int mode, int sampling_ratio, int aligned, int grad_dtype, void* stream);
+
 /* out[c][r] = cast(in[r][c]) — builds the K-major operands of the dW GEMMs. */
 int drn_transpose2d(const void* in, void* out, int rows, int cols, long ld_in, long ld_out, int in_dtype,
                     int out_dtype, void* stream);

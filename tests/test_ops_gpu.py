@@ -547,6 +547,67 @@ def test_gemm_nt_sgd_equals_gemm_then_sgd(drn, dtype, M, N, K, wd):
     assert not torch.equal(wa, w0)
 
 
+# ------------------------------------------------------------------------------------------- ROI backward
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("C,H,W,R", [(70, 19, 23, 60), (128, 14, 14, 200)])
+def test_roi_pool_backward(drn, dtype, C, H, W, R):
+    """RoIPool backward (scatter to the forward's arg-max) fused with the objectness scaling, vs the oracle's
+    sequential scatter-add; atomics change the fp32 summation order only"""
+    n_img, P, scale = 2, 7, 0.125
+    feat = _rnd((n_img, C, H, W), 21)
+    rois = _rois(R, n_img, W / scale, H / scale, 22)
+    obj = torch.rand(R)
+    fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    out, arg = drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale, want_argmax=True)
+    g = _q(_rnd((R, C, P, P), 23), dtype)
+    ref = O.roi_pool_backward(g * (obj + 1).view(-1, 1, 1, 1), rois, arg.cpu().reshape(R, C, P, P), (n_img, C, H, W))
+    gd = torch.zeros_like(out)
+    gd[:, : C * P * P] = g.reshape(R, -1).to(DEV).to(dtype)
+    d = drn.roi_pool_backward_nhwc(gd, rois.to(DEV), obj.to(DEV), (n_img, H, W, C), P, scale, argmax=arg)
+    got = d.permute(0, 3, 1, 2).cpu()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    assert float(ref.abs().max()) > 0
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("aligned,sr", [(False, 0), (True, 0), (True, 2)])
+def test_roi_align_backward(drn, dtype, aligned, sr):
+    """roi_align_backward vs the oracle (pinned to the reference's ROIAlign_cpu.cpp by tests/test_oracle_golden.py)"""
+    n_img, C, H, W, P, scale, R = 2, 70, 19, 23, 7, 0.125, 50
+    rois = _rois(R, n_img, W / scale, H / scale, 24)
+    if aligned:
+        rois = rois[2:]  # aligned=True asserts non-negative ROI size on CPU; row 0/1 are degenerate on purpose
+    R = rois.shape[0]
+    g = _q(_rnd((R, C, P, P), 25), dtype)
+    ref = O.roi_align_backward(g, rois, (n_img, C, H, W), P, scale, sr, aligned)
+    gd = torch.zeros((R, drn.kpad(C * P * P, dtype)), dtype=dtype, device=DEV)
+    gd[:, : C * P * P] = g.reshape(R, -1).to(DEV).to(dtype)
+    d = drn.roi_pool_backward_nhwc(gd, rois.to(DEV), None, (n_img, H, W, C), P, scale, mode=1, sampling_ratio=sr,
+                                   aligned=aligned)
+    got = d.permute(0, 3, 1, 2).cpu()
+    assert float((got - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+def test_roi_layers_autograd(drn):
+    """detectron2.layers.ROIAlign / RoIPool as autograd ops (roi_align.py:22-59): input gradients through the HIP
+    backward equal the oracle's autograd functions"""
+    from drn_wsod_pytorch_amd.layers import ROIAlign, RoIPool
+
+    n_img, C, H, W, P, scale, R = 2, 24, 17, 21, 7, 0.125, 40
+    feat = _rnd((n_img, C, H, W), 26)
+    rois = _rois(R, n_img, W / scale, H / scale, 27)[2:]
+    up = _rnd((rois.shape[0], C, P, P), 28)
+    for mod, fn in ((ROIAlign((P, P), scale, 0, True), lambda x: O._RoIAlignFn.apply(x, rois, P, scale, 0, True)),
+                    (RoIPool((P, P), scale), lambda x: O._RoIPoolFn.apply(x, rois, P, scale))):
+        xr = feat.clone().requires_grad_(True)
+        (fn(xr) * up).sum().backward()
+        xd = feat.clone().to(DEV).requires_grad_(True)
+        out = mod(xd, rois.to(DEV))
+        (out * up.to(DEV)).sum().backward()
+        assert xd.grad.shape == xr.grad.shape
+        assert float((xd.grad.cpu() - xr.grad).abs().max()) <= 2e-5 * float(xr.grad.abs().max()), type(mod).__name__
+
+
 # ------------------------------------------------------------------------------------------- inference tail
 def test_detect_golden_indices(drn):
     d = G.load("ops")
