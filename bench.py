@@ -233,8 +233,14 @@ def main():
         ops.GEMM_TIMING = None
         split = dp.exchange or (args.tail != "graph" and not args.no_pipelined_sgd)
         stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split)
-        for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
-            last = stepper.step(batches[i % len(batches)], batches[(i + 1) % len(batches)])
+        try:
+            for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
+                last = stepper.step(batches[i % len(batches)], batches[(i + 1) % len(batches)])
+        except Exception as ex:  # noqa: BLE001 - a failed capture must not cost the measurement: run the eager step
+            print("[bench] hipGraph capture failed (%r); falling back to the eager step" % (ex,), file=sys.stderr)
+            use_graph = False
+            model.roi_heads._engine.defer_fc1_tail = False
+    if use_graph:
         barrier()
         t0 = time.perf_counter()
         for i in range(args.steps):

@@ -572,11 +572,13 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         torch.cuda.synchronize()
         self.g_bb, self.g_main, self.g_pool = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.g_bb):
+        # thread_local: with N > 1 the RCCL watchdog thread polls its events while we capture; only this thread's calls
+        # belong to the capture
+        with torch.cuda.graph(self.g_bb, capture_error_mode="thread_local"):
             self._bb_body()
-        with torch.cuda.graph(self.g_main):
+        with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.losses = self._main_body()
-        with torch.cuda.graph(self.g_pool):
+        with torch.cuda.graph(self.g_pool, capture_error_mode="thread_local"):
             self._pool_body()
         self._primed = True
         return first
