@@ -19,6 +19,9 @@ _SIGS = {
     "drn_conv2d_nhwc": "pppppp" + "iiiiiiiiii" + "lll" + "iip",
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
+    "drn_im2col_t": "pp" + "iiiiiiiiii" + "lip",
+    "drn_maxpool2x2_bwd_nhwc": "pppiiiiiip",
+    "drn_add": "ppplip",
     "drn_roi_pool_backward_nhwc": "ppppp" + "iiiiii" + "f" + "l" + "iiiip",
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliiilip",
@@ -26,7 +29,7 @@ _SIGS = {
     "drn_gemm_set_tile": "i",
     "drn_bias_act_fwd": "pilppQpfplpliiliip",
     "drn_counter_add": "pQp",
-    "drn_bias_act_bwd": "plppppfplplppiiiip",
+    "drn_bias_act_bwd": "pilppppfplplppiiiip",
     "drn_cast2d": "ppiilliip",
     "drn_wsddn_fwd_bwd": "pliiipippppppl" + "pi" + "ifp",
     "drn_oicr_targets": "plpii" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",

@@ -42,6 +42,7 @@ struct ActParams {
   float* colpart;      // bwd: [ceil(M/ACT_ROWS)][N] scratch for the two-stage column sums
   int M, N; long ld_in; int relu; int accumulate_colsum;
   int rows_fwd;  // fwd: rows per block (64, or 16 for skinny outputs without a transposed copy)
+  int in_bf16;   // bwd: grad_out holds bf16 (gradients flowing through the conv trunk in the bf16 mode)
 };
 
 // 64 columns x ROWS_PER_BLOCK rows per block (64x64 tiles through LDS for the transposed copy).
@@ -82,7 +83,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
           if (p.mask) v *= p.mask[(long)m * p.N + n];
           else if (p.drop_p > 0.f) v *= drop_mult(seed, (uint64_t)m * p.N + n, p.drop_p);
         } else {
-          v = p.in[(long)m * p.ld_in + n] * cscale;
+          v = (p.in_bf16 ? bf16_to_f32(((const bf16_t*)p.in)[(long)m * p.ld_in + n]) : p.in[(long)m * p.ld_in + n]) * cscale;
           if (p.saved) {
             const float o = ES::ld((const typename ES::type*)p.saved + (long)m * p.ld_out + n);
             float mult = o > 0.f ? 1.f : 0.f;
@@ -673,7 +674,7 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
   if (!partials || M < 0 || N < 0 || splits < 1 || (!out && !outT)) return DRN_ERR_ARG;
   if (M == 0 || N == 0) return DRN_OK;
   ActParams p{partials, splits, split_stride, bias, mask, seed, drop_p, seed_dev, nullptr, (char*)out, ld_out, (char*)outT,
-              ld_outT, nullptr, nullptr, nullptr, nullptr, M, N, ld_in, relu, 0, 64};
+              ld_outT, nullptr, nullptr, nullptr, nullptr, M, N, ld_in, relu, 0, 64, 0};
   // skinny outputs (the 103 predictor columns): 64-row blocks would give only ~64 blocks, each walking
   // 16 rows x splits partials per thread; 16-row blocks fill the chip (no transposed copy in that case)
   if (!outT && (long)((N + 63) / 64) * ((M + 63) / 64) < 256) p.rows_fwd = 16;
@@ -686,15 +687,16 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
   return DRN_OK;
 }
 
-int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const int* colidx, const void* saved_out,
-                     const float* mask, float drop_p,
+int drn_bias_act_bwd(const void* grad_out, int grad_dtype, long ld_in, const float* colscale, const int* colidx,
+                     const void* saved_out, const float* mask, float drop_p,
                      void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
                      int accumulate_colsum, int M, int N, int out_dtype, void* stream) {
-  if (!grad_out || M < 0 || N < 0) return DRN_ERR_ARG;
+  if (!grad_out || M < 0 || N < 0 || (grad_dtype != DRN_F32 && grad_dtype != DRN_BF16)) return DRN_ERR_ARG;
   if (colsum && !colpart) return DRN_ERR_ARG;  // colpart: ceil(M/64)*N floats of scratch
   if (M == 0 || N == 0) return DRN_OK;
-  ActParams p{grad_out, 1, 0, nullptr, mask, 0ULL, drop_p, nullptr, (const char*)saved_out, (char*)dpre, ld_out, (char*)dpreT,
-              ld_outT, colsum, colscale, colidx, colpart, M, N, ld_in, 1, accumulate_colsum, 64};
+  ActParams p{(const float*)grad_out, 1, 0, nullptr, mask, 0ULL, drop_p, nullptr, (const char*)saved_out, (char*)dpre, ld_out,
+              (char*)dpreT, ld_outT, colsum, colscale, colidx, colpart, M, N, ld_in, 1, accumulate_colsum, 64,
+              grad_dtype == DRN_BF16};
   const int nparts = (M + ACT_ROWS - 1) / ACT_ROWS;
   dim3 grid((N + 63) / 64, nparts), block(256);
   hipStream_t st = (hipStream_t)stream;

@@ -322,6 +322,87 @@ __global__ __launch_bounds__(256) void roi_bwd_kernel(RoiBwdParams p) {
   }
 }
 
+// ---- backward of the conv trunk (only when MODEL.BACKBONE.FREEZE_AT < 5) -------------------------------------
+// Transposed im2col: out[(ci*KH + kh)*KW + kw][p] = x[n, ho*s + kh*d - pad, wo*s + kw*d - pad, ci] (0 outside),
+// p = (n*Ho + ho)*Wo + wo.  It is the K-major B operand of the weight-gradient GEMM  dW[co][ci,kh,kw] = g^T . out^T,
+// whose row order makes dW come out in the [Cout, Cin, KH, KW] state_dict layout.  64 pixels x 64 channels per block
+// for one tap: channel-contiguous reads, pixel-contiguous writes through an LDS tile.
+template <int DT>
+__global__ __launch_bounds__(256) void im2col_t_kernel(const char* __restrict__ x, char* __restrict__ out, int Nb, int H,
+                                                       int W, int Cin, int ldc, int KH, int KW, int stride, int pad,
+                                                       int dil, int Ho, int Wo, long ld_out) {
+  using E = ElemOf<DT>;
+  using T = typename E::type;
+  __shared__ T t[64][66];
+  const int tap = blockIdx.z, kh = tap / KW, kw = tap - kh * KW;
+  const int p0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+  const int P = Nb * Ho * Wo;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int p = p0 + i, c = c0 + tx;
+    T v = (T)0;
+    if (p < P && c < Cin) {
+      const int wo = p % Wo, ho = (p / Wo) % Ho, n = p / (Wo * Ho);
+      const int hi = ho * stride + kh * dil - pad, wi = wo * stride + kw * dil - pad;
+      if (hi >= 0 && hi < H && wi >= 0 && wi < W) v = ((const T*)x)[((long)(n * H + hi) * W + wi) * ldc + c];
+    }
+    t[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, p = p0 + tx;
+    if (c < Cin && p < P) ((T*)out)[((long)(c * KH + kh) * KW + kw) * ld_out + p] = t[tx][i];
+  }
+}
+
+// d(x) of MaxPool2d(2, stride s, padding 0): every input pixel gathers from the (at most 4) windows that contain it
+// and takes a window's gradient iff it is that window's first maximum in scan order (torch: `val > maxval`) -
+// deterministic, no atomics even for the overlapping stride-1 windows of the dilated configs.
+template <int DT>
+__global__ void maxpool2x2_bwd_kernel(const char* __restrict__ x, const char* __restrict__ dy, char* __restrict__ dx,
+                                      int Nb, int H, int W, int C, int Ho, int Wo, int stride) {
+  using E = ElemOf<DT>;
+  using T = typename E::type;
+  const long total = (long)Nb * H * W * C;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int c = i % C;
+    long r = i / C;
+    const int w = r % W; r /= W;
+    const int h = r % H;
+    const int n = r / H;
+    float acc = 0.f;
+    for (int dh = 0; dh < 2; ++dh) {
+      const int hs = h - dh;  // window start row if this pixel is row dh of the window
+      if (hs < 0 || hs % stride) continue;
+      const int ho = hs / stride;
+      if (ho >= Ho) continue;
+      for (int dw = 0; dw < 2; ++dw) {
+        const int ws = w - dw;
+        if (ws < 0 || ws % stride) continue;
+        const int wo = ws / stride;
+        if (wo >= Wo) continue;
+        const T* base = (const T*)x + ((long)(n * H + hs) * W + ws) * C + c;
+        float best = E::ld(base);
+        int arg = 0;
+        const float v1 = E::ld(base + C), v2 = E::ld(base + (long)W * C), v3 = E::ld(base + (long)W * C + C);
+        if (v1 > best) { best = v1; arg = 1; }
+        if (v2 > best) { best = v2; arg = 2; }
+        if (v3 > best) { best = v3; arg = 3; }
+        if (arg == dh * 2 + dw) acc += E::ld((const T*)dy + ((long)(n * Ho + ho) * Wo + wo) * C + c);
+      }
+    }
+    E::st((T*)dx + i, acc);
+  }
+}
+
+template <int DT>
+__global__ void add_kernel(const char* __restrict__ a, const char* __restrict__ b, char* __restrict__ out, long n) {
+  using E = ElemOf<DT>;
+  using T = typename E::type;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+    E::st((T*)out + i, E::ld((const T*)a + i) + E::ld((const T*)b + i));
+}
+
 // ROIPool specialised for the 7x7 pooler every DRN-WSOD config uses.  One block = one ROI x 256 channels (four
 // 64-channel chunks, so the ROI geometry, the 49 bin rectangles and the window's pixel table are computed once);
 // per chunk the window pixels are staged in LDS by 16-B loads, the bin maxima come out of LDS, and the
@@ -664,6 +745,57 @@ int drn_maxpool2x2_nhwc(const void* x, void* y, int Nb, int H, int W, int C, int
   else if (dtype == DRN_F32)
     hipLaunchKernelGGL(maxpool2x2_kernel<DRN_F32>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const char*)x,
                        (char*)y, Nb, H, W, C, Ho, Wo, stride);
+  else
+    return DRN_ERR_ARG;
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_im2col_t(const void* x, void* out, int Nb, int H, int W, int Cin, int ldc, int KH, int KW, int stride, int pad,
+                 int dil, long ld_out, int dtype, void* stream) {
+  if (!x || !out || Nb < 1 || Cin < 1 || ldc < Cin || KH < 1 || KW < 1 || stride < 1 || dil < 1) return DRN_ERR_ARG;
+  const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1, Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  if (Ho < 1 || Wo < 1 || ld_out < (long)Nb * Ho * Wo) return DRN_ERR_ARG;
+  dim3 grid((Nb * Ho * Wo + 63) / 64, (Cin + 63) / 64, KH * KW), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DRN_BF16)
+    hipLaunchKernelGGL(im2col_t_kernel<DRN_BF16>, grid, block, 0, st, (const char*)x, (char*)out, Nb, H, W, Cin, ldc, KH,
+                       KW, stride, pad, dil, Ho, Wo, ld_out);
+  else if (dtype == DRN_F32)
+    hipLaunchKernelGGL(im2col_t_kernel<DRN_F32>, grid, block, 0, st, (const char*)x, (char*)out, Nb, H, W, Cin, ldc, KH,
+                       KW, stride, pad, dil, Ho, Wo, ld_out);
+  else
+    return DRN_ERR_ARG;
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int Nb, int H, int W, int C, int stride, int dtype,
+                            void* stream) {
+  if (!x || !dy || !dx || (stride != 1 && stride != 2) || H < 2 || W < 2) return DRN_ERR_ARG;
+  const int Ho = (H - 2) / stride + 1, Wo = (W - 2) / stride + 1;
+  const long total = (long)Nb * H * W * C;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DRN_BF16)
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel<DRN_BF16>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const char*)x,
+                       (const char*)dy, (char*)dx, Nb, H, W, C, Ho, Wo, stride);
+  else if (dtype == DRN_F32)
+    hipLaunchKernelGGL(maxpool2x2_bwd_kernel<DRN_F32>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const char*)x,
+                       (const char*)dy, (char*)dx, Nb, H, W, C, Ho, Wo, stride);
+  else
+    return DRN_ERR_ARG;
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_add(const void* a, const void* b, void* out, long n, int dtype, void* stream) {
+  if (!a || !b || !out || n < 0) return DRN_ERR_ARG;
+  if (n == 0) return DRN_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == DRN_BF16)
+    hipLaunchKernelGGL(add_kernel<DRN_BF16>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const char*)a, (const char*)b, (char*)out, n);
+  else if (dtype == DRN_F32)
+    hipLaunchKernelGGL(add_kernel<DRN_F32>, dim3(grid_for(n, 256)), dim3(256), 0, st, (const char*)a, (const char*)b, (char*)out, n);
   else
     return DRN_ERR_ARG;
   DRN_CHECK_LAUNCH();

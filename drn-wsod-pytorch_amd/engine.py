@@ -30,10 +30,6 @@ class FusedSGD:
             raise DrnError("nesterov SGD is not used by any DRN-WSOD config")
         self.model = model
         self.engine = model.roi_heads._engine
-        extra = [n for n, p in model.named_parameters() if p.requires_grad and not n.startswith("roi_heads.")]
-        if extra:
-            raise DrnError("trainable backbone parameters (%s ...): conv backward is not built yet; use "
-                           "MODEL.BACKBONE.FREEZE_AT=5 as every shipped config does" % extra[0])
         self.momentum = momentum
         wdb = weight_decay if weight_decay_bias is None else weight_decay_bias
         self.engine.ensure(next(model.roi_heads.parameters()).device)
@@ -48,9 +44,62 @@ class FusedSGD:
         self._segs_key = None
         self._segs_dev = None
         self._steps = 0
+        # MODEL.BACKBONE.FREEZE_AT < 5: trainable trunk parameters get a flat arena of their own (weights, gradients,
+        # momentum; nn.Parameters and their .grad are views in the state_dict layout, which is also the layout the
+        # weight-gradient GEMMs write)
+        self._bb = None
+        extra = [(n, p) for n, p in model.named_parameters() if p.requires_grad and not n.startswith("roi_heads.")]
+        if extra:
+            dev = extra[0][1].device
+            tot = sum((p.numel() + 7) // 8 * 8 for _, p in extra)
+            bw = torch.zeros((tot,), dtype=torch.float32, device=dev)
+            bg = torch.zeros_like(bw)
+            off, groups = 0, []
+            for n, p in extra:
+                cnt = p.numel()
+                bw[off: off + cnt].copy_(p.data.reshape(-1))
+                p.data = bw[off: off + cnt].view(p.shape)
+                p.grad = bg[off: off + cnt].view(p.shape)
+                is_bias = n.endswith(".bias")
+                groups.append({"params": [p], "name": n, "off": off, "cnt": cnt, "used": True, "bb": True,
+                               "lr": base_lr * (bias_lr_factor if is_bias else 1.0),
+                               "initial_lr": base_lr * (bias_lr_factor if is_bias else 1.0),
+                               "weight_decay": wdb if is_bias else weight_decay, "momentum": momentum})
+                off += (cnt + 7) // 8 * 8
+            self._bb = dict(w=bw, g=bg, mom=None, groups=groups, segs_key=None, segs_dev=None)
+            self.param_groups += groups
+            model._bb_grad_arena = bg  # the data-parallel engine sums this buffer
+            for m in model.backbone.modules():
+                if hasattr(m, "invalidate_packs"):
+                    m.invalidate_packs()
+
+    def _segs_bb(self):
+        bb = self._bb
+        key = tuple((g["lr"], g["weight_decay"]) for g in bb["groups"])
+        if key != bb["segs_key"]:
+            arr = np.zeros(len(bb["groups"]), dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+            for i, g in enumerate(bb["groups"]):
+                arr[i] = (g["off"], g["cnt"], g["lr"], g["weight_decay"])
+            host = torch.from_numpy(arr.view(np.uint8).copy())
+            if bb["segs_dev"] is None:
+                bb["segs_dev"] = host.to(bb["w"].device)
+            else:
+                bb["segs_dev"].copy_(host)
+            bb["segs_key"] = key
+        return bb["segs_dev"], len(bb["groups"])
+
+    def _step_bb(self, grad_scale):
+        bb = self._bb
+        if bb["mom"] is None:
+            bb["mom"] = torch.zeros_like(bb["w"])
+        segs, nseg = self._segs_bb()
+        ops.sgd_step(bb["w"], bb["mom"], bb["g"], segs, nseg, self.momentum, self._steps == 0, grad_scale)
+        for m in self.model.backbone.modules():
+            if hasattr(m, "invalidate_packs"):
+                m.invalidate_packs()  # updated in place: the packed compute copies of the conv weights are stale
 
     def _segs(self):
-        groups = [g for g in self.param_groups if g["used"]]
+        groups = [g for g in self.param_groups if g["used"] and not g.get("bb")]
         key = tuple((g["lr"], g["weight_decay"]) for g in groups)
         if key != self._segs_key:
             arr = np.zeros(len(groups), dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
@@ -77,6 +126,8 @@ class FusedSGD:
         per step on every GPU.  Default = bf16 in the bf16 compute mode - the same rounding torch.autocast(bf16) applies
         to a Linear's weight gradient; master weights and momentum stay fp32 - and fp32 (the reference's DDP
         arithmetic) in the fp32 parity mode.  The small tensors always stay fp32."""
+        if self._bb is not None:
+            raise DrnError("the pipelined optimizer mode assumes a frozen backbone (FREEZE_AT=5); use the plain step()")
         e = self.engine
         d1 = self.model.roi_heads.box_head.fc1.weight.shape[0]
         world = dp.world if dp is not None else 1
@@ -214,6 +265,8 @@ class FusedSGD:
 
     def zero_grad(self, set_to_none=True):
         for g in self.param_groups:
+            if g.get("bb"):
+                continue  # trunk gradients stay views of their arena; the next backward overwrites them
             for p in g["params"]:
                 p.grad = None
         self.engine._grads_valid = False
@@ -241,6 +294,8 @@ class FusedSGD:
         segs, nseg = self._segs()
         ops.sgd_step(e.arena_w, self._mom, e.arena_g, segs, nseg, self.momentum, self._steps == 0, grad_scale,
                      shadow=e.arena_s)
+        if self._bb is not None:
+            self._step_bb(grad_scale)
         self._steps += 1
         e.mark_dirty(shadow_fresh=e.arena_s is not None)
 
@@ -338,7 +393,11 @@ class DataParallel:
 
     def _on_ready(self, what):
         e = self.engine
-        if what == "small":
+        if what == "backbone":  # trainable trunk (FREEZE_AT < 5): its flat gradient arena, once its backward is done
+            bg = getattr(self.model, "_bb_grad_arena", None)
+            if bg is not None:
+                self._reduce(bg)
+        elif what == "small":
             o_fc1, _ = e._seg["fc1.weight"]
             self._reduce(e.arena_g[:o_fc1])  # arena order: heads, fc2, fc1.bias come before fc1.weight
         else:

@@ -160,10 +160,67 @@ class Conv2d(nn.Conv2d):
                 self._pack_key = key
         return self._pack
 
-    def run_nhwc(self, x, residual=None, relu=False):
-        if torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
-            raise DrnError("conv dgrad/wgrad are not built yet: run the backbone frozen (MODEL.BACKBONE.FREEZE_AT=5, "
-                           "as every shipped projects/WSL config does) — see DESIGN.md 'out of scope this round'")
+    def packed_dgrad(self, dtype):
+        """weights of the data-gradient pass, which for a stride-1 conv is itself a conv over the output gradient with
+        the taps flipped and the channel roles swapped: wd[ci][(kh'*KW + kw')*Cout + co] = w[co, ci, KH-1-kh', KW-1-kw'],
+        padding dil*(K-1) - pad.  Rows beyond Cin (the channel padding of x) are zero."""
+        key = (dtype, self.weight.device, self.weight.data_ptr(), self.weight._version, getattr(self, "_pack_gen", 0))
+        if key != getattr(self, "_packd_key", None):
+            with torch.no_grad():
+                cout, cin, kh, kw = self.weight.shape
+                assert self.stride[0] == 1, "dgrad is only needed for the stride-1 convs of the trunk"
+                w = self.weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).reshape(cin, kh * kw * cout)
+                wd = torch.zeros((self.cin_pad(dtype), ops.kpad(kh * kw * cout, dtype)), dtype=dtype, device=w.device)
+                wd[:cin, : kh * kw * cout] = w.to(dtype)
+                self._packd, self._packd_key = wd, key
+        return self._packd
+
+    def invalidate_packs(self):
+        """the optimizer updated the weights in place (no _version bump): drop the packed compute copies"""
+        self._pack_key = None
+        self._pack_gen = getattr(self, "_pack_gen", 0) + 1
+
+    def backward_nhwc(self, x, y, dy, relu, need_dx, residual, accumulate):
+        """Explicit backward of run_nhwc (torch.autograd of F.conv2d + FrozenBatchNorm2d + relu_ + residual add):
+        x [N,H,W,Cin_pad] input, y [N,Ho,Wo,Cout] output (saved for the ReLU mask), dy gradient of y (compute dtype or
+        fp32).  Weight / bias gradients are written (or accumulated) into self.weight.grad / self.bias.grad, which the
+        optimizer keeps as views of its fp32 gradient arena in the state_dict layout.
+        Returns (dx or None, gradient of the residual input or None)."""
+        dtype = x.dtype
+        n, ho, wo, cout = y.shape
+        P = n * ho * wo
+        k, cin = self.kernel_size[0], self.in_channels
+        _, scale, _ = self.packed(dtype)
+        dy2 = dy.reshape(P, cout)
+        saved = y.reshape(P, cout) if relu else None
+        d_res = None
+        if residual:
+            d_res = torch.empty((P, cout), dtype=dtype, device=x.device)
+            ops.bias_act_bwd(dy2, P, cout, saved=saved, dpre=d_res)
+        key = (P, cout, dtype)
+        if getattr(self, "_bw_key", None) != key:  # g^T keeps zero padding columns: allocate once per shape
+            self._bw_gT = torch.zeros((cout, ops.kpad(P, dtype)), dtype=dtype, device=x.device)
+            self._bw_key = key
+        g = torch.empty((P, cout), dtype=dtype, device=x.device)
+        want_w = self.weight.requires_grad
+        bgrad = self.bias.grad if (self.bias is not None and self.bias.requires_grad) else None
+        ops.bias_act_bwd(dy2, P, cout, saved=saved, colscale=scale, dpre=g, dpreT=self._bw_gT if want_w else None,
+                         colsum=bgrad, accumulate_colsum=accumulate)
+        if want_w:
+            col = ops.im2col_t(x, cin, k, k, self.stride[0], self.padding[0], self.dilation[0])
+            gw = self.weight.grad.view(1, cout, cin * k * k)
+            ops.gemm_nt(self._bw_gT, col, cout, cin * k * k, ops.kpad(P, dtype), out=gw, accumulate=accumulate)
+        dx = None
+        if need_dx:
+            wd = self.packed_dgrad(dtype)
+            dx = ops.conv2d_nhwc(g.view(n, ho, wo, cout), wd, self.cin_pad(dtype), k, k, 1,
+                                 self.dilation[0] * (k - 1) - self.padding[0], self.dilation[0])
+        return dx, (d_res.view(n, ho, wo, cout) if d_res is not None else None)
+
+    def run_nhwc(self, x, residual=None, relu=False, explicit_backward=False):
+        if not explicit_backward and torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
+            raise DrnError("a stand-alone Conv2d has no autograd on this path: trainable convs run inside the backbone, "
+                           "whose blocks keep what their explicit backward needs (backbone.backward_nhwc)")
         wp, scale, bias = self.packed(x.dtype)
         assert x.shape[-1] == self.cin_pad(x.dtype), (x.shape, self.in_channels)
         return ops.conv2d_nhwc(x, wp, self.out_channels, self.kernel_size[0], self.kernel_size[1], self.stride[0],

@@ -19,6 +19,14 @@ __all__ = ["Backbone", "BasicStem", "BasicBlock", "BottleneckBlock", "ResNet", "
            "build_ws_resnet_backbone", "build_vgg_backbone", "build_backbone"]
 
 
+def _as(t, dtype):
+    """gradient tensors travel through the trunk in the compute dtype (contiguous NHWC)"""
+    t = t if t.dtype == dtype else ops.cast2d(t.reshape(-1, t.shape[-1]), t.numel() // t.shape[-1], t.shape[-1],
+                                               torch.empty(t.shape, dtype=dtype, device=t.device).view(-1, t.shape[-1])
+                                               ).view(t.shape)
+    return t.contiguous()
+
+
 def c2_msra_fill(module):
     """fvcore.nn.weight_init.c2_msra_fill."""
     nn.init.kaiming_normal_(module.weight, mode="fan_out", nonlinearity="relu")
@@ -60,11 +68,22 @@ class BasicStem(CNNBlockBase):
             c2_msra_fill(l)
         self.pool = nn.MaxPool2d(kernel_size=2, stride=2, padding=0)
 
-    def forward_nhwc(self, x):
-        x = self.conv1.run_nhwc(x, relu=True)
-        x = self.conv2.run_nhwc(x, relu=True)
-        x = self.conv3.run_nhwc(x, relu=True)
-        return ops.maxpool2x2_nhwc(x, 2)
+    def forward_nhwc(self, x, save=False):
+        o1 = self.conv1.run_nhwc(x, relu=True, explicit_backward=save)
+        o2 = self.conv2.run_nhwc(o1, relu=True, explicit_backward=save)
+        o3 = self.conv3.run_nhwc(o2, relu=True, explicit_backward=save)
+        self._sv = (x, o1, o2, o3) if save else None
+        return ops.maxpool2x2_nhwc(o3, 2)
+
+    def backward_nhwc(self, dy, need_dx, accumulate):
+        """explicit backward of forward_nhwc(save=True); the image needs no gradient, so conv1 has no dgrad"""
+        x, o1, o2, o3 = self._sv
+        d = ops.maxpool2x2_bwd_nhwc(o3, _as(dy, o3.dtype), 2)
+        d, _ = self.conv3.backward_nhwc(o2, o3, d, True, True, False, accumulate)
+        d, _ = self.conv2.backward_nhwc(o1, o2, d, True, True, False, accumulate)
+        self.conv1.backward_nhwc(x, o1, d, True, False, False, accumulate)
+        self._sv = None
+        return None
 
     def forward(self, x):
         return from_nhwc(self.forward_nhwc(to_nhwc(x, compute_dtype(), 8 if compute_dtype() == torch.bfloat16 else 4)))
@@ -90,13 +109,28 @@ class BasicBlock(CNNBlockBase):
         if self.has_pool:
             self.pool = nn.MaxPool2d(kernel_size=2, stride=self.pool_stride, padding=0)
 
-    def forward_nhwc(self, x):
-        out = self.conv1.run_nhwc(x, relu=True)
-        sc = self.shortcut.run_nhwc(x) if self.shortcut is not None else x
-        out = self.conv2.run_nhwc(out, residual=sc, relu=True)  # out += shortcut; relu_
+    def forward_nhwc(self, x, save=False):
+        o1 = self.conv1.run_nhwc(x, relu=True, explicit_backward=save)
+        sc = self.shortcut.run_nhwc(x, explicit_backward=save) if self.shortcut is not None else x
+        out = self.conv2.run_nhwc(o1, residual=sc, relu=True, explicit_backward=save)  # out += shortcut; relu_
+        self._sv = (x, o1, sc, out) if save else None
         if self.has_pool:
             out = ops.maxpool2x2_nhwc(out, self.pool_stride)
         return out
+
+    def backward_nhwc(self, dy, need_dx, accumulate):
+        x, o1, sc, out = self._sv
+        d = _as(dy, out.dtype)
+        if self.has_pool:
+            d = ops.maxpool2x2_bwd_nhwc(out, d, self.pool_stride)
+        d1, d_sc = self.conv2.backward_nhwc(o1, out, d, True, True, True, accumulate)
+        dx, _ = self.conv1.backward_nhwc(x, o1, d1, True, need_dx, False, accumulate)
+        if self.shortcut is not None:
+            dxs, _ = self.shortcut.backward_nhwc(x, sc, d_sc, False, need_dx, False, accumulate)
+        else:
+            dxs = d_sc
+        self._sv = None
+        return ops.add(dx, dxs) if need_dx else None
 
     def forward(self, x):
         return from_nhwc(self.forward_nhwc(to_nhwc(x)))
@@ -127,14 +161,32 @@ class BottleneckBlock(CNNBlockBase):
         if self.has_pool:
             self.pool = nn.MaxPool2d(kernel_size=2, stride=self.pool_stride, padding=0)
 
-    def forward_nhwc(self, x):
-        out = self.conv1.run_nhwc(x, relu=True)
-        out = self.conv2.run_nhwc(out, relu=True)
-        sc = self.shortcut.run_nhwc(x) if self.shortcut is not None else x
-        out = self.conv3.run_nhwc(out, residual=sc, relu=True)
+    def forward_nhwc(self, x, save=False):
+        o1 = self.conv1.run_nhwc(x, relu=True, explicit_backward=save)
+        o2 = self.conv2.run_nhwc(o1, relu=True, explicit_backward=save)
+        sc = self.shortcut.run_nhwc(x, explicit_backward=save) if self.shortcut is not None else x
+        out = self.conv3.run_nhwc(o2, residual=sc, relu=True, explicit_backward=save)
+        self._sv = (x, o1, o2, sc, out) if save else None
         if self.has_pool:
             out = ops.maxpool2x2_nhwc(out, self.pool_stride)
         return out
+
+    def backward_nhwc(self, dy, need_dx, accumulate):
+        """torch.autograd of resnet_ws.py:217-237: pool -> relu(conv3 + shortcut) -> conv2 -> conv1, with the gradient
+        of the block input = conv1 path + shortcut path"""
+        x, o1, o2, sc, out = self._sv
+        d = _as(dy, out.dtype)
+        if self.has_pool:
+            d = ops.maxpool2x2_bwd_nhwc(out, d, self.pool_stride)
+        d2, d_sc = self.conv3.backward_nhwc(o2, out, d, True, True, True, accumulate)
+        d1, _ = self.conv2.backward_nhwc(o1, o2, d2, True, True, False, accumulate)
+        dx, _ = self.conv1.backward_nhwc(x, o1, d1, True, need_dx, False, accumulate)
+        if self.shortcut is not None:
+            dxs, _ = self.shortcut.backward_nhwc(x, sc, d_sc, False, need_dx, False, accumulate)
+        else:
+            dxs = d_sc
+        self._sv = None
+        return ops.add(dx, dxs) if need_dx else None
 
     def forward(self, x):
         return from_nhwc(self.forward_nhwc(to_nhwc(x)))
@@ -168,16 +220,34 @@ class ResNet(Backbone):
     def forward(self, x):
         assert x.dim() == 4, "ResNet takes an input of shape (N, C, H, W). Got {} instead!".format(x.shape)
         outputs = {}
-        with torch.no_grad() if not any(p.requires_grad for p in self.parameters()) else torch.enable_grad():
-            y = self.stem.forward_nhwc(self._input_nhwc(x))
+        # trainable blocks (MODEL.BACKBONE.FREEZE_AT < 5) keep their activations for backward_nhwc(); the gradient
+        # stops at the first trainable block, so everything in front of it runs as pure inference
+        save = self.training and torch.is_grad_enabled()
+        units = [self.stem] + [b for stage, _ in self.stages_and_names for b in stage]
+        first = next((i for i, u in enumerate(units) if any(p.requires_grad for p in u.parameters())), None)
+        self._bw_units = units[first:] if (save and first is not None) else None
+        assert len(self._out_features) == 1 or self._bw_units is None, "trainable trunk: one output feature (as configured)"
+        with torch.no_grad():
+            i = 0
+            y = self.stem.forward_nhwc(self._input_nhwc(x), save=self._bw_units is not None and first == 0)
             if "stem" in self._out_features:
                 outputs["stem"] = from_nhwc(y)
             for stage, name in self.stages_and_names:
                 for block in stage:
-                    y = block.forward_nhwc(y)
+                    i += 1
+                    y = block.forward_nhwc(y, save=self._bw_units is not None and i >= first)
                 if name in self._out_features:
                     outputs[name] = from_nhwc(y)
         return outputs
+
+    def backward_nhwc(self, dfeat, accumulate=False):
+        """dfeat: gradient of the (single) output feature, NHWC; walks the trainable units in reverse"""
+        units = self._bw_units
+        assert units is not None, "backward_nhwc() needs a training-mode forward with trainable parameters"
+        d = dfeat
+        for j in range(len(units) - 1, -1, -1):
+            d = units[j].backward_nhwc(d, need_dx=j > 0, accumulate=accumulate)
+        self._bw_units = None
 
     def freeze(self, freeze_at=0):
         if freeze_at >= 1:
@@ -270,12 +340,26 @@ class PlainBlock(nn.Module):
         FrozenBatchNorm2d.convert_frozen_batchnorm(self)
         return self
 
-    def forward_nhwc(self, x):
+    def forward_nhwc(self, x, save=False):
+        acts = [x]
         for i in range(self.num_conv):
-            x = getattr(self, "conv%d" % (i + 1)).run_nhwc(x, relu=True)
+            x = getattr(self, "conv%d" % (i + 1)).run_nhwc(x, relu=True, explicit_backward=save)
+            acts.append(x)
+        self._sv = acts if save else None
         if self.has_pool:
             x = ops.maxpool2x2_nhwc(x, self.pool_stride)
         return x
+
+    def backward_nhwc(self, dy, need_dx, accumulate):
+        acts = self._sv
+        d = _as(dy, acts[-1].dtype)
+        if self.has_pool:
+            d = ops.maxpool2x2_bwd_nhwc(acts[-1], d, self.pool_stride)
+        for i in range(self.num_conv - 1, -1, -1):
+            d, _ = getattr(self, "conv%d" % (i + 1)).backward_nhwc(acts[i], acts[i + 1], d, True, need_dx or i > 0, False,
+                                                                   accumulate)
+        self._sv = None
+        return d
 
     def forward(self, x):
         return from_nhwc(self.forward_nhwc(to_nhwc(x, compute_dtype(), 8 if compute_dtype() == torch.bfloat16 else 4)))
@@ -308,14 +392,22 @@ class VGG16(Backbone):
 
     def forward(self, x):
         outputs = {}
-        with torch.no_grad() if not any(p.requires_grad for p in self.parameters()) else torch.enable_grad():
+        save = self.training and torch.is_grad_enabled()
+        units = [b for stage, _ in self.stages_and_names for b in stage]
+        first = next((i for i, u in enumerate(units) if any(p.requires_grad for p in u.parameters())), None)
+        self._bw_units = units[first:] if (save and first is not None) else None
+        with torch.no_grad():
             y = self._input_nhwc(x)
+            i = -1
             for stage, name in self.stages_and_names:
                 for block in stage:
-                    y = block.forward_nhwc(y)
+                    i += 1
+                    y = block.forward_nhwc(y, save=self._bw_units is not None and i >= first)
                 if name in self._out_features:
                     outputs[name] = from_nhwc(y)
         return outputs
+
+    backward_nhwc = ResNet.backward_nhwc
 
 
 @BACKBONE_REGISTRY.register()

@@ -110,6 +110,9 @@ class GeneralizedRCNNWSL(nn.Module):
         images = self.preprocess_image(batched_inputs)
         return images, self.backbone(images.tensor), None
 
+    def _backbone_backward(self, dfeat_nhwc, accumulate):
+        self.backbone.backward_nhwc(dfeat_nhwc, accumulate)
+
     def _proposals(self, batched_inputs):
         assert self.load_proposals and "proposals" in batched_inputs[0], "this path uses precomputed proposals"
         return [x["proposals"].to(self.device) for x in batched_inputs]
@@ -118,6 +121,11 @@ class GeneralizedRCNNWSL(nn.Module):
         if not self.training:
             return self.inference(batched_inputs)
         images, features, pooled = self._features(batched_inputs)
+        eng = getattr(self.roi_heads, "_engine", None)
+        if eng is not None:
+            # MODEL.BACKBONE.FREEZE_AT < 5: the heads' explicit backward hands the feature-map gradient to the trunk's
+            eng.feature_grad_hook = (self._backbone_backward if any(p.requires_grad for p in self.backbone.parameters())
+                                     else None)
         # image-level labels are read on the host (they come from the loader there): no device round trip
         gt_instances = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
         proposals = self._proposals(batched_inputs)

@@ -425,7 +425,7 @@ class _HeadEngine:
         self._ws[key] = w
         return w
 
-    def pool(self, feat_nhwc, rois, objectness, training, slot=None):
+    def pool(self, feat_nhwc, rois, objectness, training, slot=None, want_argmax=False):
         """ROIPool/ROIAlign fused with the objectness scaling -> fc6 operand A [M, C*P*P] (+ A^T for the dW GEMM when
         training), into one of two rotating buffer sets so that the NEXT batch can be pooled on a side stream while the
         current batch's forward/backward still reads its own set."""
@@ -444,7 +444,10 @@ class _HeadEngine:
             slot = self._pool_next
             self._pool_next ^= 1
         s = self._pool_sets[slot]
-        ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=s["A"], out_t=s["AT"], **h.box_pooler.kernel_args())
+        ka = h.box_pooler.kernel_args()
+        res = ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=s["A"], out_t=s["AT"],
+                                want_argmax=want_argmax and ka["mode"] == 0, **ka)
+        s["argmax"] = res[1] if (want_argmax and ka["mode"] == 0) else None
         return s
 
     @staticmethod
@@ -461,8 +464,11 @@ class _HeadEngine:
     # ---- forward -------------------------------------------------------------------------------------
     def forward(self, feat_nhwc, rois, objectness, training, img_off=None, n_img=1, gt=None, pooled=None):
         h = self.h
+        fg_hook = getattr(self, "feature_grad_hook", None) if training else None
         if pooled is None:
-            pooled = self.pool(feat_nhwc, rois, objectness, training)
+            pooled = self.pool(feat_nhwc, rois, objectness, training, want_argmax=fg_hook is not None)
+        elif fg_hook is not None:
+            raise DrnError("a trainable backbone cannot use a prefetched pooled operand")
         dev, dtype = pooled["A"].device, pooled["A"].dtype
         self.ensure(dev)
         self.refresh_shadows(dtype)
@@ -544,6 +550,9 @@ class _HeadEngine:
                 prev_boxes, prev_zero = gt["props"], True
         state = dict(w=w, M=M, dtype=dtype, loss_list=loss_list, head_cols=head_cols, masks=masks, drop_p=drop_p,
                      aux=aux)
+        if fg_hook is not None:  # what the gradient of the feature map needs (trainable backbone)
+            state["fg"] = dict(hook=fg_hook, rois=rois, obj=objectness, feat_shape=tuple(feat_nhwc.shape),
+                               argmax=pooled.get("argmax"))
         outs = _TrainFn.apply(self.anchor, self, state)
         return dict(zip(loss_names, outs)), state
 
@@ -592,12 +601,38 @@ class _HeadEngine:
         ops.gemm_nt(w["dP2T"], w["H1T"], D2, D1, Mp, out=self._gview("fc2.weight", (1, D2, D1)), accumulate=acc)
         ops.gemm_nt(w["dP2"], sh["W2T"], M, D1, kp(D2), out=w["dH1"].view(1, M, D1))
         # fc6 (the backbone is frozen: no dX)
+        fg = st.get("fg")
+        if fg is not None and ("dP1" not in w or w["dP1"].shape != w["H1"].shape):
+            w["dP1"] = torch.zeros_like(w["H1"])
         ops.bias_act_bwd(w["dH1"], M, D1, saved=w["H1"], mask=st["masks"][0] if st["masks"] else None,
-                         drop_p=st["drop_p"], dpreT=w["dP1T"], colsum=self._gview("fc1.bias"), accumulate_colsum=acc,
-                         colpart=w["colpart"])
+                         drop_p=st["drop_p"], dpre=w["dP1"] if fg is not None else None, dpreT=w["dP1T"],
+                         colsum=self._gview("fc1.bias"), accumulate_colsum=acc, colpart=w["colpart"])
         self._tail = (w["dP1T"], w["AT"], D1, K1, Mp, acc)
         if not getattr(self, "defer_fc1_tail", False):
             self.run_fc1_tail()
+        if fg is not None:
+            self._feature_backward(w, fg, M, D1, K1, dtype, acc)
+
+    def _feature_backward(self, w, fg, M, D1, K1, dtype, acc):
+        """MODEL.BACKBONE.FREEZE_AT < 5: fc6 dX = dP1 . W1 (NT GEMM on a K-major copy of W1), RoIPool / ROIAlign backward
+        (with the objectness scaling) -> gradient of the feature map, handed to the backbone's explicit backward."""
+        h = self.h
+        kp = lambda k: ops.kpad(k, dtype)
+        fc1 = h.box_head.fc1
+        if getattr(self, "_w1t_key", None) != (dtype, K1, D1):
+            self._w1t = torch.zeros((K1, kp(D1)), dtype=dtype, device=self.arena_w.device)
+            self._dA = torch.zeros((1, M, kp(K1)), dtype=dtype, device=self.arena_w.device)
+            self._w1t_key = (dtype, K1, D1)
+        if self._dA.shape[1] != M:
+            self._dA = torch.zeros((1, M, kp(K1)), dtype=dtype, device=self.arena_w.device)
+        ops.transpose2d(fc1.weight.data, D1, K1, out=self._w1t)
+        ops.gemm_nt(w["dP1"], self._w1t, M, K1, kp(D1), out=self._dA[:, :, :K1])
+        ka = h.box_pooler.kernel_args()
+        dfeat = ops.roi_pool_backward_nhwc(self._dA[0], fg["rois"], fg["obj"], fg["feat_shape"], argmax=fg["argmax"], **ka)
+        fg["hook"](dfeat, acc)
+        hook = getattr(self, "grad_ready_hook", None)
+        if hook is not None:
+            hook("backbone")
 
     def run_fc1_tail(self):
         """Last piece of the explicit backward: announce the small gradients, then the fc6 weight gradient in row

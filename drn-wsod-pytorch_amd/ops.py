@@ -123,6 +123,34 @@ def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, al
     return (out, arg) if want_argmax else out
 
 
+def im2col_t(x, cin, kh, kw, stride, pad, dil, out=None):
+    """x [N,H,W,Cpad] NHWC -> [cin*kh*kw, kpad(N*Ho*Wo)] (row (ci*kh + i)*kw + j), zero padded columns."""
+    n, h, w, cp = x.shape
+    ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    if out is None:
+        out = torch.zeros((cin * kh * kw, kpad(n * ho * wo, x.dtype)), dtype=x.dtype, device=x.device)
+    C.call("drn_im2col_t", C.ptr(x), C.ptr(out), n, h, w, cin, cp, kh, kw, stride, pad, dil, _2d(out), C.dt(x.dtype),
+           C.stream())
+    return out
+
+
+def maxpool2x2_bwd_nhwc(x, dy, stride):
+    n, h, w, c = x.shape
+    assert dy.dtype == x.dtype and dy.is_contiguous() and x.is_contiguous()
+    dx = torch.empty_like(x)
+    C.call("drn_maxpool2x2_bwd_nhwc", C.ptr(x), C.ptr(dy), C.ptr(dx), n, h, w, c, stride, C.dt(x.dtype), C.stream())
+    return dx
+
+
+def add(a, b, out=None):
+    assert a.dtype == b.dtype and a.numel() == b.numel() and a.is_contiguous() and b.is_contiguous()
+    if out is None:
+        out = torch.empty_like(a)
+    C.call("drn_add", C.ptr(a), C.ptr(b), C.ptr(out), a.numel(), C.dt(a.dtype), C.stream())
+    return out
+
+
 def roi_pool_backward_nhwc(grad_out, rois, objectness, feat_shape, P, scale, mode=0, sampling_ratio=0, aligned=False,
                            argmax=None):
     """grad_out [M, >= C*P*P] -> d(feat) [N,H,W,C] fp32 (see drn_roi_pool_backward_nhwc)."""
@@ -172,8 +200,8 @@ def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=Non
     ld_out = _2d(dpre) if dpre is not None else (_2d(saved) if saved is not None else 0)
     if colsum is not None and colpart is None:
         colpart = torch.empty(((M + 63) // 64, N), dtype=torch.float32, device=grad_out.device)
-    C.call("drn_bias_act_bwd", C.ptr(grad_out), _2d(grad_out), C.ptr(colscale), C.ptr(colidx), C.ptr(saved), C.ptr(mask),
-           float(drop_p),
+    C.call("drn_bias_act_bwd", C.ptr(grad_out), C.dt(grad_out.dtype), _2d(grad_out), C.ptr(colscale), C.ptr(colidx),
+           C.ptr(saved), C.ptr(mask), float(drop_p),
            C.ptr(dpre), ld_out, C.ptr(dpreT), _2d(dpreT) if dpreT is not None else 0, C.ptr(colsum), C.ptr(colpart),
            int(accumulate_colsum), M, N, C.dt(ref.dtype), C.stream())
 

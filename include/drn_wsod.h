@@ -48,6 +48,23 @@ int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, c
 /* nn.MaxPool2d(kernel_size=2, stride=s, padding=0), resnet_ws.py:214-215,403; vgg.py:99-100. */
 int drn_maxpool2x2_nhwc(const void* x, void* y, int Nb, int H, int W, int C, int stride, int dtype, void* stream);
 
+/* ---- backward of the conv trunk (MODEL.BACKBONE.FREEZE_AT < 5; torch.autograd of F.conv2d / max_pool2d) ---- *
+ * conv dgrad runs drn_conv2d_nhwc on the flipped/transposed packed weights (every trained conv has stride 1,
+ * resnet_ws.py:148-150), the FrozenBN-affine/ReLU backward runs drn_bias_act_bwd, and the weight gradient is
+ * drn_gemm_nt(g^T, im2col_t): */
+
+/* out[(ci*KH + kh)*KW + kw][p] = x[n, ho*s + kh*d - pad, wo*s + kw*d - pad, ci]  (x NHWC with channel stride ldc,
+ * p = (n*Ho + ho)*Wo + wo, zeros outside the image; columns beyond p are left untouched). */
+int drn_im2col_t(const void* x, void* out, int Nb, int H, int W, int Cin, int ldc, int KH, int KW, int stride, int pad,
+                 int dil, long ld_out, int dtype, void* stream);
+
+/* d(x) of nn.MaxPool2d(2, stride, 0): gradient goes to each window's first maximum (torch semantics). */
+int drn_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int Nb, int H, int W, int C, int stride, int dtype,
+                            void* stream);
+
+/* out = a + b (gradient fan-in of a residual block). */
+int drn_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);
+
 /* ---- region pooling -------------------------------------------------------------------------- */
 
 /* ROIPooler.forward single-level path, detectron2/modeling/poolers.py:191-226:
@@ -118,8 +135,8 @@ int drn_counter_add(unsigned long long* counter, unsigned long long inc, void* s
  * multiplies grad_out per column (per-loss upstream gradients stay on the device): column n uses
  * colscale[colidx ? colidx[n] : n] (index -1 = 0); colpart = scratch of
  * ceil(M/64)*N floats for the two-stage (deterministic) column sums, required with colsum. */
-int drn_bias_act_bwd(const float* grad_out, long ld_in, const float* colscale, const int* colidx, const void* saved_out,
-                     const float* mask, float drop_p,
+int drn_bias_act_bwd(const void* grad_out, int grad_dtype, long ld_in, const float* colscale, const int* colidx,
+                     const void* saved_out, const float* mask, float drop_p,
                      void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
                      int accumulate_colsum, int M, int N, int out_dtype, void* stream);
 

@@ -63,6 +63,12 @@ def _worker(rank, world, port, q):
             if not used:  # unused bbox_pred: never reduced
                 assert torch.equal(e.arena_g[o: o + c], base[o: o + c] * (rank + 1)), name
         assert used_end <= o_fc1 + c_fc1
+        # trainable trunk (FREEZE_AT < 5): its flat gradient arena is one more bucket, announced after its backward
+        model._bb_grad_arena = torch.arange(37, dtype=torch.float32) * (rank + 1)
+        e.grad_ready_hook("backbone")
+        dp.finish()
+        assert torch.equal(model._bb_grad_arena, torch.arange(37, dtype=torch.float32) * 3.0)
+        del model._bb_grad_arena
         # the pipelined optimizer's own exchange (what the N>1 bench step uses): small bucket in fp32 from the arena,
         # fc6 row slabs from the bf16 exchange buffer the dW GEMM writes into
         from drn_wsod_pytorch_amd.engine import build_optimizer

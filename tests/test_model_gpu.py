@@ -145,18 +145,102 @@ def test_roialign_pooler_model_fp32():
         assert abs(float(v.detach()) - float(ref[k])) <= 1e-4 * max(abs(float(ref[k])), 1e-3), (k, float(v.detach()), float(ref[k]))
 
 
-def test_unfrozen_backbone_fails_loudly():
+UNFROZEN = [("model_r50c4_tiny", 2), ("model_r50c4_tiny", 3), ("model_r50c4_align_tiny", 3), ("model_r50dc5_tiny", 3),
+            ("model_r18dc5_tiny", 1), ("model_vgg16_small", 2), ("model_r50c4_tiny", 0), ("model_vgg16_small", 0)]
+
+
+@pytest.mark.parametrize("name,freeze_at", UNFROZEN)
+def test_unfrozen_backbone_train_step_fp32(name, freeze_at):
+    """MODEL.BACKBONE.FREEZE_AT < 5: fc6 dX, RoIPool / ROIAlign backward, max-pool backward, conv dgrad / wgrad and
+    the FrozenBN-affine / ReLU / residual backward of the trunk vs the oracle's autograd on the same seeded weights:
+    losses <= 1e-4, every trainable gradient (trunk and heads), and the SGD update of the trunk."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    ocfg = G.MODEL_CASES[name]
+    d = G.load(name)
+    seed = int(d["seed"])
+    batch = G.batch_from(d)
+    ocfg.dropout = 0.0
+    p = O.seeded_params(O.param_shapes(ocfg), seed)
+    before = {n: t.clone() for n, t in p.items()}
+    opt_o = O.SGDState(ocfg)
+    ref_losses, ref_grads = O.train_step(p, batch, ocfg, opt_o, freeze_at=freeze_at)
+    trunk = [n for n in ref_grads if n.startswith("backbone.")]
+    assert trunk, "case must train part of the trunk"
+
+    cfg, model = G.drn_model(ocfg, seed, "cuda", freeze_at, "fp32")
+    model.roi_heads.box_head.dropout_p = 0.0
+    model.train()
+    opt = build_optimizer(cfg, model)
+    got_names = sorted(n for n, q in model.named_parameters() if q.requires_grad and n.startswith("backbone."))
+    assert got_names == sorted(trunk)
+    opt.zero_grad()
+    losses = model(G.drn_inputs(batch))
+    sum(losses.values()).backward()
+    for k, v in losses.items():
+        assert abs(float(v.detach()) - ref_losses[k]) <= 1e-4 * max(abs(ref_losses[k]), 1e-3), (k, float(v.detach()), ref_losses[k])
+    sd = dict(model.named_parameters())
+    # VGG trained from conv1: in this fixture ONE pre-activation of plain2.0.conv1 (of 131072) lies within 1e-5 of zero
+    # and lands on different sides of the ReLU in the two fp32 summation orders (measured: the only mask mismatch in
+    # the whole trunk).  That moves one pixel's contribution in plain2.0.conv1 and everything below it, which a
+    # max-norm comparison sees at the 1e-2 level; those tensors get the relaxed bound, all others the tight one.
+    # Every conv / pool backward call inside this very backward was checked against CPU autograd on its own inputs
+    # (<= 2e-6 relative).
+    def loose(n):
+        return (name, freeze_at) == ("model_vgg16_small", 0) and (".plain1." in n or ".plain2.0.conv1." in n)
+
+    for n in trunk:
+        g, rg = sd[n].grad.detach().cpu().numpy().astype(np.float64), ref_grads[n].numpy().astype(np.float64)
+        assert g.shape == rg.shape, n
+        if np.abs(rg).max() < 1e-7:
+            assert np.abs(g).max() < 1e-5, n
+        else:
+            assert _relerr(g, rg) < (5e-2 if loose(n) else 2e-3), (n, _relerr(g, rg))
+            l2 = float(np.linalg.norm(g - rg) / np.linalg.norm(rg))
+            assert l2 < (2e-2 if loose(n) else 3e-3), (n, l2)
+    for n in ("roi_heads.box_head.fc2.weight", "roi_heads.box_refinery_0.cls_score.weight"):
+        assert _relerr(sd[n].grad.detach().cpu().numpy(), ref_grads[n].numpy()) < 2e-3, n
+    opt.step()
+    torch.cuda.synchronize()
+    for n in trunk:
+        delta, ref_delta = (sd[n].detach().cpu() - before[n]).numpy(), (p[n] - before[n]).numpy()
+        if np.abs(ref_delta).max() > 1e-9:
+            assert _relerr(delta, ref_delta) < (5e-2 if loose(n) else 2e-3), n
+    # second step on the updated weights: packed conv copies must have been refreshed
+    ref2, _ = O.train_step(p, batch, ocfg, opt_o, freeze_at=freeze_at)
+    opt.zero_grad()
+    losses2 = model(G.drn_inputs(batch))
+    sum(losses2.values()).backward()
+    opt.step()
+    for k, v in losses2.items():
+        assert abs(float(v.detach()) - ref2[k]) <= 2e-2 * max(abs(ref2[k]), 1e-3), (k, float(v.detach()), ref2[k])
+    ocfg.dropout = 0.5
+
+
+def test_unfrozen_backbone_bf16_and_pipelined_guard():
+    """bf16 mode trains the trunk too (finite gradients, loss close to fp32); the pipelined optimizer refuses it"""
     from drn_wsod_pytorch_amd._cabi import DrnError
     from drn_wsod_pytorch_amd.engine import build_optimizer
 
-    name = "model_r50c4_align_tiny"
-    ocfg = G.MODEL_CASES[name]
-    cfg, model = G.drn_model(ocfg, 1, "cuda", 3, "fp32")
-    with pytest.raises(DrnError):
-        build_optimizer(cfg, model)
+    name = "model_r50c4_tiny"
+    ocfg, d = G.MODEL_CASES[name], G.load(name)
+    cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 2, "bf16")
+    model.roi_heads.box_head.dropout_p = 0.0
     model.train()
+    opt = build_optimizer(cfg, model)
     with pytest.raises(DrnError):
-        model(G.drn_inputs(G.batch_from(G.load(name))))
+        opt.enable_pipelined(None)
+    opt.zero_grad()
+    losses = model(G.drn_inputs(G.batch_from(d)))
+    sum(losses.values()).backward()
+    for k, v in losses.items():
+        ref = float(d["step0_%s" % k])
+        assert abs(float(v.detach()) - ref) <= 3e-2 * max(abs(ref), 1e-2), (k, float(v.detach()), ref)
+    for n, q in model.named_parameters():
+        if q.requires_grad and q.grad is not None:
+            assert torch.isfinite(q.grad).all(), n
+    opt.step()
+    load_package().set_precision("fp32")
 
 
 @pytest.mark.parametrize("name", ["model_r50c4_tiny", "model_vgg16_small"])

@@ -547,6 +547,74 @@ def test_gemm_nt_sgd_equals_gemm_then_sgd(drn, dtype, M, N, K, wd):
     assert not torch.equal(wa, w0)
 
 
+# ------------------------------------------------------------------------------------------- conv trunk backward
+def _relerr(a, b, floor=1e-6):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("cin,cout,k,stride,pad,dil,H,W", [(16, 24, 3, 1, 1, 1, 13, 17), (8, 16, 1, 1, 0, 1, 9, 11),
+                                                           (16, 16, 3, 1, 2, 2, 14, 14), (3, 8, 3, 2, 1, 1, 20, 22),
+                                                           (128, 128, 3, 1, 1, 1, 32, 32), (64, 128, 3, 1, 1, 1, 32, 32),
+                                                           (64, 64, 3, 1, 1, 1, 64, 64)])
+def test_conv_backward(drn, dtype, cin, cout, k, stride, pad, dil, H, W):
+    """Conv2d.backward_nhwc (mask/affine backward -> wgrad GEMM on the transposed im2col -> dgrad conv on flipped
+    weights) vs torch autograd of conv2d * scale + bias -> relu on the CPU"""
+    from drn_wsod_pytorch_amd import set_precision
+    from drn_wsod_pytorch_amd.layers import Conv2d, FrozenBatchNorm2d
+
+    set_precision("bf16" if dtype == torch.bfloat16 else "fp32")
+    rs = np.random.RandomState(3)
+    n = 2
+    conv = Conv2d(cin, cout, kernel_size=k, stride=stride, padding=pad, dilation=dil, bias=False,
+                  norm=FrozenBatchNorm2d(cout)).to(DEV)
+    with torch.no_grad():
+        conv.weight.copy_(torch.from_numpy(rs.standard_normal(conv.weight.shape).astype(np.float32) * 0.2))
+        conv.norm.weight.copy_(torch.from_numpy(rs.rand(cout).astype(np.float32) + 0.5))
+        conv.norm.bias.copy_(torch.from_numpy(rs.standard_normal(cout).astype(np.float32) * 0.1))
+    conv.weight.grad = torch.zeros_like(conv.weight)
+    x = _q(_rnd((n, cin, H, W), 4), dtype)
+    cp = conv.cin_pad(dtype)
+    xd = torch.zeros((n, H, W, cp), dtype=dtype, device=DEV)
+    xd[..., :cin] = x.permute(0, 2, 3, 1).to(DEV).to(dtype)
+    y = conv.run_nhwc(xd, relu=True, explicit_backward=True)
+    dy = _q(_rnd(tuple(y.permute(0, 3, 1, 2).shape), 5), dtype)
+    need_dx = stride == 1
+    dx, _ = conv.backward_nhwc(xd, y, dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype), True, need_dx, False, False)
+    # reference
+    xr = x.clone().requires_grad_(True)
+    wr = _q(conv.weight.detach().cpu(), dtype).requires_grad_(True)
+    scale, bias = conv.norm.folded()
+    yr = torch.relu(torch.nn.functional.conv2d(xr, wr, None, stride, pad, dil) * scale.cpu().view(1, -1, 1, 1)
+                    + bias.cpu().view(1, -1, 1, 1))
+    yr.backward(dy)
+    tol = 2e-2 if dtype == torch.bfloat16 else 2e-4
+    # the ReLU mask comes from the (rounded) forward output: compare only where the reference is not at the kink
+    assert _relerr(conv.weight.grad.cpu().numpy(), wr.grad.numpy()) < tol
+    if need_dx:
+        assert _relerr(dx[..., :cin].float().cpu().permute(0, 3, 1, 2).numpy(), xr.grad.numpy()) < tol
+        assert (dx[..., cin:] == 0).all()
+    set_precision("fp32")
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("stride", [1, 2])
+def test_maxpool_backward(drn, dtype, stride):
+    n, C, H, W = 2, 24, 11, 14
+    x = _q(_rnd((n, C, H, W), 6), dtype)
+    x[0, :, 2, 3] = x[0, :, 2, 4]  # tie inside a window: the first maximum takes the gradient
+    xr = x.clone().requires_grad_(True)
+    yr = torch.nn.functional.max_pool2d(xr, 2, stride)
+    dy = _q(_rnd(tuple(yr.shape), 7), dtype)
+    yr.backward(dy)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    dx = drn.maxpool2x2_bwd_nhwc(xd, dy.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype), stride)
+    ref = _q(xr.grad, dtype) if stride == 2 else xr.grad
+    tol = 1e-2 if (dtype == torch.bfloat16 and stride == 1) else 1e-6
+    assert _relerr(dx.float().cpu().permute(0, 3, 1, 2).numpy(), ref.numpy()) <= tol
+
+
 # ------------------------------------------------------------------------------------------- ROI backward
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("C,H,W,R", [(70, 19, 23, 60), (128, 14, 14, 200)])
