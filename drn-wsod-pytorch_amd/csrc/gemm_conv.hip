@@ -95,14 +95,19 @@ __device__ __forceinline__ RowLoader make_row_loader(const char* base, long row0
   return l;
 }
 
-// im2col-on-the-fly operand of an NHWC convolution: row = output pixel, k = (kh, kw, ci).
+// im2col-on-the-fly operand of an NHWC convolution: row = output pixel, k = (kh, kw, ci).  Branch-free: every lane
+// issues a bounds-checked buffer load, and lanes that fall into the zero padding, beyond the last tap or beyond M
+// use an offset past the descriptor's range, for which the hardware returns zeros.  (Conditional global loads made
+// the compiler drain each one before leaving its branch, so a slab cost a full memory latency whatever the prefetch
+// depth: 0.85 us per slab on the res4 3x3 convs.)
 template <int DT, int ROWS>
 struct ConvLoader {
   static constexpr int ES = DT == DRN_BF16 ? 2 : 4;
-  const char* x;
+  static constexpr unsigned OOB = 0xFFFFFFF0u;
+  __amdgpu_buffer_rsrc_t rsrc;  // whole input tensor (launcher guarantees < 4 GB - 16)
   int H, W, Cin, KW, dil, ntaps;
   int hi0[ROWS / 32], wi0[ROWS / 32];
-  long nbase[ROWS / 32];  // byte offset of image n, or -1 for rows beyond M
+  unsigned nbase[ROWS / 32];  // byte offset of image n, or OOB for rows beyond M
   template <int R>
   __device__ __forceinline__ void load(i32x4_t (&r)[R / 32], int slab, int tid) const {
     static_assert(R == ROWS, "tile rows");
@@ -113,55 +118,71 @@ struct ConvLoader {
 #pragma unroll
     for (int p = 0; p < ROWS / 32; ++p) {
       const int hi = hi0[p] + kh * dil, wi = wi0[p] + kw * dil;
-      i32x4_t v = {0, 0, 0, 0};
-      if (nbase[p] >= 0 && tap < ntaps && hi >= 0 && hi < H && wi >= 0 && wi < W)
-        v = *(const i32x4_t*)(x + nbase[p] + ((long)(hi * W + wi) * Cin + ci) * ES);
-      r[p] = v;
+      const bool ok = nbase[p] != OOB && tap < ntaps && hi >= 0 && hi < H && wi >= 0 && wi < W;
+      const unsigned off = ok ? nbase[p] + (unsigned)(((hi * W + wi) * Cin + ci) * ES) : OOB;
+      r[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     }
   }
 };
 
+// Register-staged mainloop of the 64x64 / 128x128 kernels (GEMM and conv share it).  These tiles do little MFMA work
+// per K-slab (one to four MFMAs per wave and k-step), so a slab's cost is the latency of its global loads unless they
+// are issued far ahead: the staging registers form a statically indexed ring of DEPTH slabs - while slab i is
+// multiplied out of LDS, slab i+DEPTH is being fetched and slab i+1 (fetched DEPTH-1 iterations ago) moves from its
+// registers into the other LDS stage.  LDS stays at two stages (32 / 64 KB), so a conv block still fits next to a
+// 128-KB GEMM block on a CU.
 template <int DT, int BM, int BN, class ALoader, class BLoader>
 __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char* smem, const ALoader& la,
                                          const BLoader& lb, int s0, int s1) {
   constexpr int MI = BM / 64, NJ = BN / 64;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  constexpr int DEPTH = BM <= 64 ? 4 : 3;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  i32x4_t ra[BM / 32], rb[BN / 32];
-  if (s0 >= s1) return;
-  la.template load<BM>(ra, s0, tid);
-  lb.template load<BN>(rb, s0, tid);
-  lds_store_tile<BM>(smem, ra, tid);
-  lds_store_tile<BN>(smem + A_BYTES, rb, tid);
+  i32x4_t ra[DEPTH][BM / 32], rb[DEPTH][BN / 32];
+  const int n = s1 - s0;
+  if (n <= 0) return;
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < n) {
+      la.template load<BM>(ra[d], s0 + d, tid);
+      lb.template load<BN>(rb[d], s0 + d, tid);
+    }
+  lds_store_tile<BM>(smem, ra[0], tid);
+  lds_store_tile<BN>(smem + A_BYTES, rb[0], tid);
   __syncthreads();
-  for (int s = s0; s < s1; ++s) {
-    char* cur = smem + ((s - s0) & 1) * STAGE;
-    char* nxt = smem + (((s - s0) & 1) ^ 1) * STAGE;
-    const bool more = s + 1 < s1;
-    if (more) {
-      la.template load<BM>(ra, s + 1, tid);
-      lb.template load<BN>(rb, s + 1, tid);
+  for (int base = 0; base < n; base += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int i = base + d;
+      if (i < n) {
+        char* cur = smem + (i & 1) * STAGE;
+        char* nxt = smem + ((i & 1) ^ 1) * STAGE;
+        if (i + DEPTH < n) {  // ring slot d held slab i, which already sits in LDS
+          la.template load<BM>(ra[d], s0 + i + DEPTH, tid);
+          lb.template load<BN>(rb[d], s0 + i + DEPTH, tid);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          i32x4_t fa[MI], fb[NJ];
+          const int slot = ks * 2 + (lane >> 5);
+#pragma unroll
+          for (int ii = 0; ii < MI; ++ii) fa[ii] = *(const i32x4_t*)(cur + swz(wm * (BM / 2) + ii * 32 + (lane & 31), slot));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            fb[j] = *(const i32x4_t*)(cur + A_BYTES + swz(wn * (BN / 2) + j * 32 + (lane & 31), slot));
+#pragma unroll
+          for (int ii = 0; ii < MI; ++ii)
+#pragma unroll
+            for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[ii][j], fa[ii], fb[j]);
+        }
+        if (i + 1 < n) {
+          lds_store_tile<BM>(nxt, ra[(d + 1) % DEPTH], tid);
+          lds_store_tile<BN>(nxt + A_BYTES, rb[(d + 1) % DEPTH], tid);
+        }
+        __syncthreads();
+      }
     }
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      i32x4_t fa[MI], fb[NJ];
-      const int slot = ks * 2 + (lane >> 5);
-#pragma unroll
-      for (int i = 0; i < MI; ++i) fa[i] = *(const i32x4_t*)(cur + swz(wm * (BM / 2) + i * 32 + (lane & 31), slot));
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-        fb[j] = *(const i32x4_t*)(cur + A_BYTES + swz(wn * (BN / 2) + j * 32 + (lane & 31), slot));
-#pragma unroll
-      for (int i = 0; i < MI; ++i)
-#pragma unroll
-        for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[i][j], fa[i], fb[j]);
-    }
-    if (more) {
-      lds_store_tile<BM>(nxt, ra, tid);
-      lds_store_tile<BN>(nxt + A_BYTES, rb, tid);
-    }
-    __syncthreads();
   }
 }
 
@@ -453,7 +474,8 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
   tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
   const int bm = tm * BM, bn = tn * BN;
   ConvLoader<DT, BM> la;
-  la.x = p.X; la.H = p.H; la.W = p.W; la.Cin = p.Cin; la.KW = p.KW; la.dil = p.dil; la.ntaps = p.KH * p.KW;
+  la.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((long)p.Nb * p.H * p.W * p.Cin * ES), 0x00020000);
+  la.H = p.H; la.W = p.W; la.Cin = p.Cin; la.KW = p.KW; la.dil = p.dil; la.ntaps = p.KH * p.KW;
   const int r0 = threadIdx.x >> 3;
 #pragma unroll
   for (int q = 0; q < BM / 32; ++q) {
@@ -463,9 +485,9 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
       const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
       la.hi0[q] = ho * p.stride - p.pad;
       la.wi0[q] = wo * p.stride - p.pad;
-      la.nbase[q] = (long)n * p.H * p.W * p.Cin * ES;
+      la.nbase[q] = (unsigned)((long)n * p.H * p.W * p.Cin * ES);
     } else {
-      la.hi0[q] = 0; la.wi0[q] = 0; la.nbase[q] = -1;
+      la.hi0[q] = 0; la.wi0[q] = 0; la.nbase[q] = ConvLoader<DT, BM>::OOB;
     }
   }
   const RowLoader lb = make_row_loader(p.Wt, bn, p.Cout, BN, p.ldw * ES);
@@ -622,6 +644,7 @@ int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, c
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wo = (W + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   if (Ho <= 0 || Wo <= 0 || Nb <= 0) return DRN_ERR_ARG;
+  if ((long)Nb * H * W * Cin * es >= 0xFFFFFFF0L) return DRN_ERR_ARG;  // one buffer descriptor spans the input
   const int Ktot = KH * KW * Cin;
   if (ldw * es < ((Ktot * es + 127) / 128) * 128) return DRN_ERR_ARG;  // weight rows zero-padded to 128-B slabs
   ConvParams p{(const char*)x, (const char*)w, (char*)y, scale, bias, (const char*)residual, Nb, H, W, Cin, Ho, Wo,
