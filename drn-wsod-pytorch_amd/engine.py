@@ -140,10 +140,6 @@ class FusedSGD:
             t = (d1 + 255) // 256
             slab_rows = [min(d1, ((t + 1) // 2) * 256)] if world == 1 else [min(d1, ((5 * t + 7) // 8) * 256)]
             slab_rows = sorted(set(r for r in slab_rows if 0 < r < d1)) + [d1]
-        import os
-        if os.environ.get("DRN_SGD_SLAB_TILEROWS"):  # tuning hook, e.g. "5" or "5,7"
-            slab_rows = sorted(set(min(d1, int(x) * 256) for x in os.environ["DRN_SGD_SLAB_TILEROWS"].split(","))) + [d1]
-            slab_rows = sorted(set(slab_rows))
         self._slab_ends = slab_rows
         e.fc1_slab_ends = slab_rows
         e.grad_ready_hook = self._on_grad_ready
@@ -468,16 +464,18 @@ class Trainer:
 
 
 class GraphedTrainStep:
-    """One full training step captured once into a hipGraph and replayed: a step is ~110 kernel launches of 2-450 us,
-    so the eager Python host needs ~2.4 ms to enqueue what the GPU executes in ~2.5 ms; a replay costs ~15 us.
+    """One training step as three hipGraphs captured once and replayed: a step is ~100 kernel launches of 2-450 us, so
+    the eager Python host needs ~2.4 ms to enqueue what the GPU executes in ~2.1 ms; a replay costs the host ~9 us per
+    node and nothing else.
 
-    What one replay contains (three streams, forked and joined inside the capture):
-      main      : heads forward (fc6 GEMM first, on the pooled operand prepared by the PREVIOUS replay), losses,
-                  explicit backward ... last dW GEMM, then ROIPool(+objectness) + A^T of the NEXT batch
-      side      : preprocess + frozen backbone of the NEXT batch's image (latency-bound convs under the GEMMs)
-      optimizer : per-bucket SGD under the remaining dW GEMMs and under the next batch's pooling (FusedSGD pipelined)
-    The next batch's pooling is queued behind this step's last reader of A^T (the fc6 dW GEMM), so one buffer set
-    and one graph suffice.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5).
+      g_main (main stream) : heads forward (fc6 GEMM first, on the pooled operand prepared by the PREVIOUS step), MIL /
+                             OICR losses, explicit backward up to the fc6 weight gradient
+      tail   (eager)       : fc6 dW row-slab GEMMs on the main stream; per bucket, (all-reduce +) SGD on the optimizer
+                             stream (`split_tail`, the default of bench.py; with split_tail=False the tail is part of
+                             g_main - measured 1.3 % slower, the executor schedules forked branches late)
+      g_bb   (side stream) : preprocess + frozen backbone of the NEXT batch's image (latency-bound convs under the GEMMs)
+      g_pool (main stream) : ROIPool(+objectness) -> A and A^T of the next batch, behind this step's last reader of A^T
+    One buffer set suffices.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5).
 
     Static shapes only (fixed image size, proposals per image, images per GPU: the benchmark's case and the common
     fixed-R training case); anything else runs the eager path.

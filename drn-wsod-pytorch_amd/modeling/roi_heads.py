@@ -492,9 +492,6 @@ class _HeadEngine:
             seed, seed_dev = torch.initial_seed() & 0xFFFFFFFFFFFF, self.seed_dev
         self._linear_fwd(w["A"], sh["W1v"], M, D1, kp(K1), fc1.bias.data, True, w["H1"], w["H1T"] if training else None,
                          masks[0] if masks else None, seed, drop_p, seed_dev)
-        hook = getattr(self, "after_fc6_hook", None)
-        if hook is not None:
-            hook()  # the fc6 GEMM (the longest kernel of the step) is queued: a good moment to fork side work
         self._linear_fwd(w["H1"], sh["W2"], M, D2, kp(D1), fc2.bias.data, True, w["H2"], w["H2T"] if training else None,
                          masks[1] if masks else None, seed + 0x9E3779B1, drop_p, seed_dev)
         if seed_dev is not None:
