@@ -130,6 +130,60 @@ def cpu_baseline(batches, n_steps=10, threads=32):
                       "host) + oracle/roi_ops.c" % (n_steps, threads)}
 
 
+def hbm_rooflines(model, batch, R, device, ops):
+    """The two dominant HBM-bound kernels of the step, timed on their own with HIP events (5 launches each, scratch
+    buffers of the workload's sizes, after the timed region): achieved = ALGORITHMIC bytes / launch duration against
+    the 8 TB/s HBM3E peak (MI355X_MICROARCH.md).
+      roi_pool7_map_kernel: writes A and A^T (2 x R x C*49 x 2 B), reads the 14x14xC map + R boxes
+      sgd_kernel (fc6 half): per parameter reads w, momentum (fp32) + gradient (bf16), writes w, momentum (fp32) +
+                             bf16 shadow = 20 B"""
+    import numpy as np
+
+    out = []
+    heads = model.roi_heads
+    eng = heads._engine
+
+    def timed(fn, n=5):
+        fn()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(n):
+            fn()
+        b.record()
+        torch.cuda.synchronize()
+        return a.elapsed_time(b) / n * 1e-3
+
+    with torch.no_grad():
+        images = model.preprocess_image(batch)
+        feats = model.backbone(images.tensor)
+        nhwc, rois, obj = heads._gather_inputs(feats, [x["proposals"] for x in batch])
+        C = nhwc.shape[-1]
+        K1 = C * 49
+        A = torch.zeros((R, ops.kpad(K1, nhwc.dtype)), dtype=nhwc.dtype, device=device)
+        AT = torch.zeros((K1, ops.kpad(R, nhwc.dtype)), dtype=nhwc.dtype, device=device)
+        ka = heads.box_pooler.kernel_args()
+        t = timed(lambda: ops.roi_pool_nhwc(nhwc, rois, obj, out=A, out_t=AT, **ka))
+        es = 2 if nhwc.dtype == torch.bfloat16 else 4
+        nbytes = 2 * R * K1 * es + nhwc.numel() * es + rois.numel() * 4
+        out.append({"kernel": "roi_pool7_map_kernel (ROIPool + objectness scale -> A and A^T)", "bound": "hbm",
+                    "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
+                    "bytes_per_launch": nbytes, "avg_launch_ms": t * 1e3})
+        D1 = heads.box_head.fc1.weight.shape[0]
+        n = (D1 // 2) * K1
+        w = torch.zeros((n,), device=device)
+        m = torch.zeros_like(w)
+        g = torch.zeros((n,), dtype=torch.bfloat16, device=device)
+        sh = torch.zeros((n,), dtype=torch.bfloat16, device=device)
+        seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+        seg[0] = (0, n, 0.01, 5e-4)
+        seg_dev = torch.from_numpy(seg.view(np.uint8)).to(device)
+        t = timed(lambda: ops.sgd_step(w, m, g, seg_dev, 1, 0.9, False, shadow=sh))
+        out.append({"kernel": "sgd_kernel<shadow, bf16 grad> (one fc6 row slab: %d parameters)" % n, "bound": "hbm",
+                    "achieved": 20.0 * n / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": 20.0 * n / t / 1e9 / 8000.0,
+                    "bytes_per_launch": 20 * n, "avg_launch_ms": t * 1e3})
+    return out
+
+
 def pmc_traffic(shape):
     """HBM bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
     WRITE_SIZE run separately on tools/pmc_gemm.py, corrected as profiles/r1_04_pmc_fc6_gemm.json records). PMC
@@ -292,6 +346,11 @@ def main():
                    "collective": "RCCL all-reduce per bucket (small tensors fp32, fc6 dW row slabs in fc6_grad_dtype)",
                    "slab_ends": getattr(opt, "_slab_ends", None)},
                "roofline": roof}
+        if world == 1 and not dp.exchange:
+            try:
+                out["roofline_hbm"] = hbm_rooflines(model, batches[0], R, device, ops)
+            except Exception as ex:  # noqa: BLE001 - supporting evidence only, never at the cost of the main line
+                out["roofline_hbm"] = "unavailable: %r" % (ex,)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batches)
     if dist.is_initialized():
