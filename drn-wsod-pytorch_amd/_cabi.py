@@ -19,6 +19,7 @@ _SIGS = {
     "drn_conv2d_nhwc": "pppppp" + "iiiiiiiiii" + "lll" + "iip",
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
+    "drn_tta_accumulate": "ppppllfffiip",
     "drn_im2col_t": "pp" + "iiiiiiiiii" + "lip",
     "drn_maxpool2x2_bwd_nhwc": "pppiiiiiip",
     "drn_add": "ppplip",

@@ -219,6 +219,36 @@ inline Ws carve(void* workspace, long bytes, int cap) {
 
 }  // namespace
 
+// ---- test-time augmentation (wsl/modeling/test_time_augmentation_avg.py:269-294) --------------------------------
+// One augmentation's predictions folded into the running averages on the device: every predicted box is mapped back
+// to the original image - HFlipTransform.inverse (x -> W' - x) then ResizeTransform.inverse (x * sx, y * sy) applied
+// to its four corners, then their bounding box, in float32 exactly like the numpy code the reference runs on the
+// host - and added to acc_boxes; the scores are added to acc_scores.  The last augmentation divides by n_aug (torch.mean).
+// The reference moves every augmentation's [R, 4K] boxes to the host and back for this.
+__global__ void tta_accumulate_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                      float* __restrict__ acc_boxes, float* __restrict__ acc_scores, long nbox, long nscore,
+                                      float sx, float sy, float flip_w, int first, int n_final) {
+  const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+  if (i < nbox) {
+    const float* b = boxes + 4 * i;
+    float x0 = b[0], y0 = b[1], x1 = b[2], y1 = b[3];
+    if (flip_w >= 0.f) { x0 = flip_w - x0; x1 = flip_w - x1; }
+    x0 = x0 * sx; x1 = x1 * sx; y0 = y0 * sy; y1 = y1 * sy;
+    const float o[4] = {fminf(x0, x1), fminf(y0, y1), fmaxf(x0, x1), fmaxf(y0, y1)};
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float v = first ? o[e] : acc_boxes[4 * i + e] + o[e];
+      if (n_final > 0) v = v / (float)n_final;
+      acc_boxes[4 * i + e] = v;
+    }
+  }
+  if (i < nscore) {
+    float v = first ? scores[i] : acc_scores[i] + scores[i];
+    if (n_final > 0) v = v / (float)n_final;
+    acc_scores[i] = v;
+  }
+}
+
 extern "C" {
 
 // bytes of scratch drn_detect_topk needs for up to `cap` candidates (cap = R*K is always enough)
@@ -261,6 +291,17 @@ int drn_detect_gather(const void* workspace, long workspace_bytes, int cap, cons
   Ws k = carve((void*)workspace, workspace_bytes, cap);
   hipLaunchKernelGGL(gather_kernel, dim3((topk + 63) / 64), dim3(64), 0, (hipStream_t)stream, k.c_box, k.c_score,
                      k.c_row, k.c_cls, keep_ids, n_keep, out_boxes, out_scores, out_classes, out_rows);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+int drn_tta_accumulate(const float* boxes, const float* scores, float* acc_boxes, float* acc_scores, long n_boxes,
+                       long n_scores, float sx, float sy, float flip_w, int first, int n_final, void* stream) {
+  if (!boxes || !scores || !acc_boxes || !acc_scores || n_boxes < 0 || n_scores < 0) return DRN_ERR_ARG;
+  const long n = n_boxes > n_scores ? n_boxes : n_scores;
+  if (n == 0) return DRN_OK;
+  hipLaunchKernelGGL(tta_accumulate_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, boxes,
+                     scores, acc_boxes, acc_scores, n_boxes, n_scores, sx, sy, flip_w, first, n_final);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

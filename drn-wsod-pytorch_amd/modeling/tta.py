@@ -1,0 +1,168 @@
+"""Test-time augmentation of the WSL detector, behind the reference's names:
+`DatasetMapperTTAAVG` and `GeneralizedRCNNWithTTAAVG` (projects/WSL/wsl/modeling/test_time_augmentation_avg.py:68-137,
+:139-321) with the transforms they drive - ResizeShortestEdge (detectron2/data/transforms/augmentation_impl.py:155-175),
+ResizeTransform (detectron2/data/transforms/transform.py:83-134), fvcore's HFlipTransform.
+
+Split of work: the mapper (image resize through PIL for uint8 images exactly like the reference, flip, proposal boxes
+scaled / flipped / clipped / filtered / top-k) is host-side data preparation, as in the reference.  Everything after it
+stays on the GPU: one `model.inference` per augmentation, `drn_tta_accumulate` maps each augmentation's [R, 4K]
+predictions back to the original image and folds them into the running box / score averages (the reference copies
+them to the host and back for this), and `drn_detect_topk` runs the final score-threshold / NMS / top-k."""
+import copy
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+from torch import nn
+
+from .. import ops
+from .._cabi import DrnError
+from ..structures import Boxes, Instances
+
+__all__ = ["DatasetMapperTTAAVG", "GeneralizedRCNNWithTTAAVG", "resize_shortest_edge_shape"]
+
+
+def resize_shortest_edge_shape(h, w, size, max_size):
+    """ResizeShortestEdge.get_transform, augmentation_impl.py:164-174"""
+    scale = size * 1.0 / min(h, w)
+    if h < w:
+        newh, neww = size, scale * w
+    else:
+        newh, neww = scale * h, size
+    if max(newh, neww) > max_size:
+        scale = max_size * 1.0 / max(newh, neww)
+        newh = newh * scale
+        neww = neww * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def _resize_image(img_hwc, new_h, new_w):
+    """ResizeTransform.apply_image, transform.py:101-122"""
+    if img_hwc.dtype == np.uint8:
+        try:
+            from PIL import Image
+        except ImportError as e:  # the reference has the same dependency for uint8 images
+            raise DrnError("PIL is needed to resize uint8 images like the reference does") from e
+        return np.asarray(Image.fromarray(img_hwc).resize((new_w, new_h), Image.BILINEAR))
+    t = torch.from_numpy(np.ascontiguousarray(img_hwc)).permute(2, 0, 1)[None]
+    t = F.interpolate(t, (new_h, new_w), mode="bilinear", align_corners=False)
+    return t[0].permute(1, 2, 0).numpy()
+
+
+def _apply_box(boxes, sx, sy, flip_w):
+    """Transform.apply_box through [ResizeTransform, HFlipTransform?]: corners in float32, then their bounding box"""
+    b = np.asarray(boxes, dtype=np.float32).reshape(-1, 4)
+    idx = np.array([(0, 1), (2, 1), (0, 3), (2, 3)]).flatten()
+    c = b[:, idx].reshape(-1, 2).copy()
+    c[:, 0] = c[:, 0] * sx
+    c[:, 1] = c[:, 1] * sy
+    if flip_w is not None:
+        c[:, 0] = flip_w - c[:, 0]
+    c = c.reshape(-1, 4, 2)
+    return np.concatenate((c.min(axis=1), c.max(axis=1)), axis=1)
+
+
+class DatasetMapperTTAAVG:
+    """test_time_augmentation_avg.py:68-137: dataset dict -> list of augmented dataset dicts (len(min_sizes) x
+    (2 if flip else 1)); each carries "tta" = (sx, sy, flip_w) of the INVERSE box transform instead of a TransformList."""
+
+    def __init__(self, cfg):
+        self.min_sizes = cfg.TEST.AUG.MIN_SIZES
+        self.max_size = cfg.TEST.AUG.MAX_SIZE
+        self.flip = cfg.TEST.AUG.FLIP
+        self.image_format = cfg.INPUT.FORMAT
+        self.proposal_topk = cfg.DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST if cfg.MODEL.LOAD_PROPOSALS else None
+
+    def __call__(self, dataset_dict):
+        img = dataset_dict["image"].detach().cpu().permute(1, 2, 0).numpy()
+        h, w = img.shape[:2]
+        if (dataset_dict["height"], dataset_dict["width"]) != (h, w):
+            raise DrnError("TTA on an already resized input (pre_tfm of the reference) is off this path")
+        ret = []
+        for size in self.min_sizes:
+            nh, nw = resize_shortest_edge_shape(h, w, size, self.max_size)
+            rimg = _resize_image(np.copy(img), nh, nw)
+            for flipped in ([False, True] if self.flip else [False]):
+                im = np.flip(rimg, axis=1) if flipped else rimg
+                dic = {k: v for k, v in dataset_dict.items() if k not in ("image", "proposals")}
+                dic["image"] = torch.from_numpy(np.ascontiguousarray(im.transpose(2, 0, 1)))
+                dic["tta"] = (w * 1.0 / nw, h * 1.0 / nh, float(nw) if flipped else -1.0)
+                if self.proposal_topk is not None:
+                    # transform_proposals (:27-65)
+                    prop = dataset_dict["proposals"]
+                    boxes = _apply_box(prop.proposal_boxes.tensor.detach().cpu().numpy(), nw * 1.0 / w, nh * 1.0 / h,
+                                       nw if flipped else None)
+                    boxes = Boxes(torch.from_numpy(boxes))
+                    logits = prop.objectness_logits.detach().cpu()
+                    boxes.clip((nh, nw))
+                    keep = boxes.nonempty(threshold=0)
+                    boxes, logits = boxes[keep], logits[keep]
+                    p = Instances((nh, nw))
+                    p.proposal_boxes = boxes[: self.proposal_topk]
+                    p.objectness_logits = logits[: self.proposal_topk]
+                    dic["proposals"] = p
+                ret.append(dic)
+        return ret
+
+
+class GeneralizedRCNNWithTTAAVG(nn.Module):
+    """test_time_augmentation_avg.py:139-321 (box branch; masks / keypoints are off the WSL path)."""
+
+    def __init__(self, cfg, model, tta_mapper=None, batch_size=1):
+        super().__init__()
+        from .rcnn import GeneralizedRCNNWSL
+
+        model = getattr(model, "module", model)
+        assert isinstance(model, GeneralizedRCNNWSL), \
+            "TTA is only supported on GeneralizedRCNNWSL. Got a model of type {}".format(type(model))
+        self.cfg = cfg.clone()
+        assert not self.cfg.MODEL.KEYPOINT_ON, "TTA for keypoint is not supported yet"
+        if self.cfg.MODEL.MASK_ON:
+            raise DrnError("mask heads are off the DRN-WSOD path")
+        if batch_size != 1:
+            raise DrnError("augmented images have different sizes and the averages need one prediction set per "
+                           "augmentation: batch_size must stay 1 (the reference's default)")
+        self.model = model
+        self.tta_mapper = tta_mapper if tta_mapper is not None else DatasetMapperTTAAVG(cfg)
+        self.batch_size = batch_size
+
+    def __call__(self, batched_inputs):
+        out = []
+        for x in batched_inputs:
+            if "image" not in x:
+                raise DrnError("reading images from file_name is the data loader's job (off this path)")
+            ret = copy.copy(x)
+            if "height" not in ret and "width" not in ret:
+                ret["height"], ret["width"] = x["image"].shape[1], x["image"].shape[2]
+            out.append(self._inference_one_image(ret))
+        return out
+
+    def _get_augmented_boxes(self, augmented_inputs):
+        """:269-294, on the device: running means of the back-transformed boxes and of the scores"""
+        acc_b = acc_s = None
+        n = len(augmented_inputs)
+        for i, inp in enumerate(augmented_inputs):
+            sx, sy, flip_w = inp["tta"]
+            _, scores, boxes = self.model.inference([{k: v for k, v in inp.items() if k != "tta"}], do_postprocess=False)
+            b, s = boxes[0][0].contiguous(), scores[0][0].contiguous()
+            if acc_b is None:
+                acc_b, acc_s = torch.empty_like(b), torch.empty_like(s)
+            elif acc_b.shape != b.shape:
+                raise DrnError("augmentations kept different numbers of proposals (%s vs %s): the averages are "
+                               "undefined (the reference fails in torch.cat here)" % (tuple(acc_b.shape), tuple(b.shape)))
+            ops.tta_accumulate(b, s, acc_b, acc_s, np.float32(sx), np.float32(sy), flip_w, i == 0, n if i == n - 1 else 0)
+        return acc_b, acc_s
+
+    def _inference_one_image(self, input):
+        orig_shape = (input["height"], input["width"])
+        with torch.no_grad():
+            augmented_inputs = self.tta_mapper(input)
+            all_boxes, all_scores = self._get_augmented_boxes(augmented_inputs)
+            # _merge_detections (:296-309) = fast_rcnn_inference_single_image on the averages
+            ob, os_, oc, _ = ops.detect_topk(all_boxes, all_scores, orig_shape, self.cfg.MODEL.ROI_HEADS.SCORE_THRESH_TEST,
+                                             self.cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST, self.cfg.TEST.DETECTIONS_PER_IMAGE)
+        r = Instances(orig_shape)
+        r.pred_boxes = Boxes(ob)
+        r.scores = os_
+        r.pred_classes = oc
+        return {"instances": r}

@@ -348,3 +348,11 @@ def detect_topk(boxes, scores, image_shape, score_thresh, nms_thresh, topk):
            C.ptr(orow), C.stream())
     n = int(nk.item())
     return ob[:n], os_[:n], oc[:n].long(), orow[:n].long()
+
+
+def tta_accumulate(boxes, scores, acc_boxes, acc_scores, sx, sy, flip_w, first, n_final):
+    """fold one augmentation's [R, 4K] boxes / [R, K+1] scores into the running TTA averages (see the header)"""
+    assert boxes.is_contiguous() and scores.is_contiguous() and boxes.dtype == torch.float32 and scores.dtype == torch.float32
+    assert acc_boxes.shape == boxes.shape and acc_scores.shape == scores.shape
+    C.call("drn_tta_accumulate", C.ptr(boxes), C.ptr(scores), C.ptr(acc_boxes), C.ptr(acc_scores), boxes.numel() // 4,
+           scores.numel(), float(sx), float(sy), float(flip_w), int(first), int(n_final), C.stream())

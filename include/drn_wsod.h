@@ -219,6 +219,17 @@ int drn_detect_topk(const float* boxes, const float* scores, int R, int K, int n
 int drn_detect_gather(const void* workspace, long workspace_bytes, int cap, const int* keep_ids, const int* n_keep,
                       int topk, float* out_boxes, float* out_scores, int* out_classes, int* out_rows, void* stream);
 
+/* ---- test-time augmentation ------------------------------------------- */
+
+/* GeneralizedRCNNWithTTAAVG._get_augmented_boxes (projects/WSL/wsl/modeling/test_time_augmentation_avg.py:269-294):
+ * fold one augmentation's predictions into the running averages.  boxes [n_boxes][4] (the [R, 4K] prediction viewed
+ * as boxes, in the augmented image's coordinates) are mapped back through HFlipTransform.inverse (flip_w = width of
+ * the augmented image, < 0 = not flipped) and ResizeTransform.inverse (sx = w / new_w, sy = h / new_h, float32 like
+ * the reference's numpy code) and added to acc_boxes; scores [n_scores] are added to acc_scores.  first = 1 starts the
+ * sums, n_final = number of augmentations on the last call (the means are written then), 0 otherwise. */
+int drn_tta_accumulate(const float* boxes, const float* scores, float* acc_boxes, float* acc_scores, long n_boxes,
+                       long n_scores, float sx, float sy, float flip_w, int first, int n_final, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

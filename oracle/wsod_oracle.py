@@ -795,3 +795,105 @@ def synthetic_batch(n_images, R, cfg: OracleCfg, seed=1234, H=224, W=224):
         cls = torch.randperm(cfg.num_classes, generator=g)[:G].to(torch.int64)
         batch.append({"image": img, "proposal_boxes": boxes, "objectness_logits": obj, "gt_classes": cls})
     return batch
+
+
+# --------------------------------------------------------------------------------------------
+# Test-time augmentation.  Restates projects/WSL/wsl/modeling/test_time_augmentation_avg.py
+# (DatasetMapperTTAAVG :68-137, transform_proposals :27-65, GeneralizedRCNNWithTTAAVG :139-321) together with the
+# transforms it drives: ResizeShortestEdge.get_transform (detectron2/data/transforms/augmentation_impl.py:155-175),
+# ResizeTransform (detectron2/data/transforms/transform.py:83-134) and fvcore's HFlipTransform / Transform.apply_box
+# (fvcore is external and absent: its published semantics are restated).  Pinned by tests/golden/tta_r50c4_tiny.npz,
+# produced by the reference's own GeneralizedRCNNWithTTAAVG.
+# --------------------------------------------------------------------------------------------
+def tta_resize_shape(h, w, size, max_size):
+    """augmentation_impl.py:164-174"""
+    scale = size * 1.0 / min(h, w)
+    if h < w:
+        newh, neww = size, scale * w
+    else:
+        newh, neww = scale * h, size
+    if max(newh, neww) > max_size:
+        scale = max_size * 1.0 / max(newh, neww)
+        newh = newh * scale
+        neww = neww * scale
+    return int(newh + 0.5), int(neww + 0.5)
+
+
+def tta_resize_image(img_hwc, new_h, new_w):
+    """transform.py:101-122: PIL bilinear for uint8, F.interpolate(bilinear, align_corners=False) otherwise"""
+    import numpy as np
+
+    if img_hwc.dtype == np.uint8:
+        from PIL import Image
+
+        return np.asarray(Image.fromarray(img_hwc).resize((new_w, new_h), Image.BILINEAR))
+    t = torch.from_numpy(np.ascontiguousarray(img_hwc)).permute(2, 0, 1)[None]
+    t = F.interpolate(t, (new_h, new_w), mode="bilinear", align_corners=False)
+    return t[0].permute(1, 2, 0).numpy()
+
+
+def tta_apply_box(boxes, steps):
+    """Transform.apply_box through a TransformList: the 4 corners go through every transform's apply_coords (float32
+    array x python float, i.e. float32 arithmetic), the result is their axis-aligned bounding box.
+    steps: ("scale", sx, sy) = ResizeTransform.apply_coords (transform.py:124-127), ("hflip", W) = HFlipTransform."""
+    import numpy as np
+
+    b = np.asarray(boxes, dtype=np.float32).reshape(-1, 4)
+    idx = np.array([(0, 1), (2, 1), (0, 3), (2, 3)]).flatten()
+    c = b[:, idx].reshape(-1, 2).copy()
+    for st in steps:
+        if st[0] == "scale":
+            c[:, 0] = c[:, 0] * st[1]
+            c[:, 1] = c[:, 1] * st[2]
+        elif st[0] == "hflip":
+            c[:, 0] = st[1] - c[:, 0]
+        else:
+            raise ValueError(st)
+    c = c.reshape(-1, 4, 2)
+    return np.concatenate((c.min(axis=1), c.max(axis=1)), axis=1)
+
+
+def tta_augment(image_chw, proposal_boxes, objectness, min_sizes, max_size, flip, topk):
+    """DatasetMapperTTAAVG.__call__ + transform_proposals: one dict per (size[, flip]) with the resized (flipped)
+    image [3,h,w], the transformed / clipped / non-empty / top-k proposals, and the forward and inverse box steps."""
+    import numpy as np
+
+    img = image_chw.permute(1, 2, 0).numpy()
+    h, w = img.shape[:2]
+    out = []
+    for size in min_sizes:
+        nh, nw = tta_resize_shape(h, w, size, max_size)
+        rimg = tta_resize_image(np.copy(img), nh, nw)
+        fwd = [("scale", nw * 1.0 / w, nh * 1.0 / h)]
+        inv = [("scale", w * 1.0 / nw, h * 1.0 / nh)]
+        variants = [(rimg, fwd, inv)]
+        if flip:
+            variants.append((np.flip(rimg, axis=1), fwd + [("hflip", nw)], [("hflip", nw)] + inv))
+        for im, f, iv in variants:
+            bx = torch.from_numpy(tta_apply_box(proposal_boxes.numpy(), f))
+            bx[:, 0].clamp_(min=0, max=nw)
+            bx[:, 1].clamp_(min=0, max=nh)
+            bx[:, 2].clamp_(min=0, max=nw)
+            bx[:, 3].clamp_(min=0, max=nh)
+            keep = ((bx[:, 2] - bx[:, 0]) > 0) & ((bx[:, 3] - bx[:, 1]) > 0)
+            out.append({"image": torch.from_numpy(np.ascontiguousarray(im.transpose(2, 0, 1))),
+                        "proposal_boxes": bx[keep][:topk], "objectness_logits": objectness[keep][:topk], "inverse": iv})
+    return out
+
+
+def tta_inference(p, image_chw, proposal_boxes, objectness, orig_hw, cfg: OracleCfg, min_sizes, max_size, flip=True,
+                  topk=1000, return_aux=False):
+    """GeneralizedRCNNWithTTAAVG._inference_one_image (box branch): per-augmentation inference, boxes mapped back to the
+    original image and averaged, scores averaged, then fast_rcnn_inference_single_image on the averages."""
+    augs = tta_augment(image_chw, proposal_boxes, objectness, min_sizes, max_size, flip, topk)
+    all_boxes, all_scores = [], []
+    for a in augs:
+        _, scores, boxes = model_inference(p, [a], cfg)
+        nb = boxes[0]
+        back = tta_apply_box(nb.reshape(-1, 4).numpy(), a["inverse"])
+        all_boxes.append(torch.from_numpy(back).reshape(1, *nb.shape))
+        all_scores.append(scores[0][None])
+    avg_boxes = torch.mean(torch.cat(all_boxes, dim=0), dim=0)
+    avg_scores = torch.mean(torch.cat(all_scores, dim=0), dim=0)
+    det = fast_rcnn_inference_single_image(avg_boxes, avg_scores, orig_hw, cfg.score_thresh, cfg.nms_thresh, cfg.topk)
+    return (det, augs, avg_boxes, avg_scores) if return_aux else det

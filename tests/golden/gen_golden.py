@@ -367,10 +367,53 @@ TINY_R50 = ["MODEL.RESNETS.STEM_OUT_CHANNELS", "8", "MODEL.RESNETS.RES2_OUT_CHAN
 C4 = ["MODEL.RESNETS.OUT_FEATURES", "['res4']", "MODEL.ROI_HEADS.IN_FEATURES", "['res4']",
       "MODEL.RESNETS.RES5_DILATION", "1"]
 
+def case_tta(name, yaml_rel, opts, seed, R, H, W, min_sizes, max_size, topk):
+    """GeneralizedRCNNWithTTAAVG (projects/WSL/wsl/modeling/test_time_augmentation_avg.py:139-321) on one uint8 image:
+    the reference's own mapper (ResizeShortestEdge via PIL + horizontal flip, transformed/clipped/top-k proposals), one
+    inference per augmentation, boxes mapped back and averaged, scores averaged, final NMS / top-k."""
+    from wsl.modeling.test_time_augmentation_avg import DatasetMapperTTAAVG, GeneralizedRCNNWithTTAAVG
+
+    o = list(opts) + ["TEST.AUG.ENABLED", "True", "TEST.AUG.MIN_SIZES", str(tuple(min_sizes)), "TEST.AUG.MAX_SIZE",
+                      str(max_size), "TEST.AUG.FLIP", "True", "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST", str(topk)]
+    cfg, model = rh.build_reference_model(yaml_rel, o)
+    fill_reference(model, seed)
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    b = make_inputs(1, R, K, H, W, seed + 17)[0]
+    img8 = b["image"].astype(np.uint8)
+    d = {"seed": np.int64(seed), "image_u8": img8, "proposal_boxes": b["proposal_boxes"],
+         "objectness_logits": b["objectness_logits"], "min_sizes": np.array(min_sizes), "max_size": np.int64(max_size),
+         "topk": np.int64(topk)}
+    prop = Instances((H, W))
+    prop.proposal_boxes = Boxes(torch.from_numpy(b["proposal_boxes"]))
+    prop.objectness_logits = torch.from_numpy(b["objectness_logits"])
+    inp = {"image": torch.from_numpy(img8), "proposals": prop, "height": H, "width": W}
+    model.eval()
+    tta = GeneralizedRCNNWithTTAAVG(cfg, model)
+    with torch.no_grad(), EventStorage():
+        aug, tfms = tta._get_augmented_inputs(dict(inp))
+        d["n_aug"] = np.int64(len(aug))
+        for i, a in enumerate(aug):
+            d["aug%d_image" % i] = a["image"].numpy().copy()
+            d["aug%d_boxes" % i] = a["proposals"].proposal_boxes.tensor.numpy().copy()
+            d["aug%d_obj" % i] = a["proposals"].objectness_logits.numpy().copy()
+        all_boxes, all_scores, _ = tta._get_augmented_boxes(aug, tfms)
+        d["avg_boxes"] = all_boxes.numpy().copy()
+        d["avg_scores"] = all_scores.numpy().copy()
+        out = tta([dict(inp)])[0]["instances"]
+    d["det_boxes"] = out.pred_boxes.tensor.numpy().copy()
+    d["det_scores"] = out.scores.numpy().copy()
+    d["det_classes"] = out.pred_classes.numpy().copy()
+    d["cfg_opts"] = np.array([yaml_rel] + list(o))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", "n_aug", len(aug), "dets", len(out),
+          [tuple(a["image"].shape) for a in aug])
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "heads", "r50dc5", "r50c4", "r50c4_align", "r18", "vgg", "r50c4_drop", "r50c4_reg"]
+    which = sys.argv[1:] or ["ops", "heads", "r50dc5", "r50c4", "r50c4_align", "r18", "vgg", "r50c4_drop", "r50c4_reg", "tta"]
     if "ops" in which:
         case_ops("ops", 11)
     if "heads" in which:
@@ -394,6 +437,9 @@ if __name__ == "__main__":
     if "r50c4_drop" in which:
         case_full_model("model_r50c4_dropmask_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 36,
                         1, 40, 96, 96, dropmask=True)
+    if "tta" in which:
+        case_tta("tta_r50c4_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 38, 48, 60, 84,
+                 (48, 72), 96, 40)
     if "r50c4_reg" in which:
         case_full_model("model_r50c4_reg_tiny", "PascalVOC-Detection/reg/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 37,
                         1, 40, 96, 96)

@@ -54,8 +54,17 @@ class _StubModule(types.ModuleType):
         return cls
 
 
+# real reference modules that live under an auto-stubbed package (TTA golden: the reference's own resize / flip
+# transforms and its GeneralizedRCNNWithTTAAVG are imported for real; their parents stay stubs)
+REAL_UNDER_STUB = ("detectron2.data.transforms", "wsl.modeling.test_time_augmentation_avg")
+REAL_PATHS = {"detectron2.data": os.path.join(REF, "detectron2", "data")}
+
+
 class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
     def find_spec(self, fullname, path=None, target=None):
+        for s in REAL_UNDER_STUB:
+            if fullname == s or fullname.startswith(s + "."):
+                return None
         for s in AUTO_STUB:
             if fullname == s or fullname.startswith(s + "."):
                 return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
@@ -63,7 +72,7 @@ class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):
 
     def create_module(self, spec):
         m = _StubModule(spec.name)
-        m.__path__ = []
+        m.__path__ = [REAL_PATHS[spec.name]] if spec.name in REAL_PATHS else []
         if spec.name == "cv2":
             m.__version__ = "2.0.0"
         return m

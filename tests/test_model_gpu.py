@@ -472,3 +472,65 @@ def test_full_size_train_step_matches_oracle_fp32(case):
             (ref_new - before[n]).reshape(-1)[::4099 if new.numel() > 10 ** 7 else 1]
         assert _relerr(delta.numpy(), ref_delta.numpy()) < 2e-3, n
     load_package().set_precision("fp32")
+
+
+def test_tta_matches_reference_golden():
+    """GeneralizedRCNNWithTTAAVG (2 scales x flip) vs the golden produced by the reference's own class: the mapper's
+    augmented images / proposals bit for bit, the device-side back-transformed box and score averages
+    (drn_tta_accumulate), and the final detections (classes exact, scores / boxes within fp32 tolerance)."""
+    from drn_wsod_pytorch_amd.modeling import GeneralizedRCNNWithTTAAVG
+    from drn_wsod_pytorch_amd.structures import Boxes, Instances
+
+    d = G.load("tta_r50c4_tiny")
+    ocfg = G.MODEL_CASES["model_r50c4_tiny"]
+    cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, "fp32")
+    cfg.merge_from_list(["TEST.AUG.ENABLED", "True", "TEST.AUG.MIN_SIZES", str(tuple(int(x) for x in d["min_sizes"])),
+                         "TEST.AUG.MAX_SIZE", str(int(d["max_size"])), "TEST.AUG.FLIP", "True",
+                         "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST", str(int(d["topk"]))])
+    model.eval()
+    img = torch.from_numpy(d["image_u8"])
+    H, W = img.shape[1:]
+    prop = Instances((H, W))
+    prop.proposal_boxes = Boxes(torch.from_numpy(d["proposal_boxes"]))
+    prop.objectness_logits = torch.from_numpy(d["objectness_logits"])
+    inp = {"image": img, "proposals": prop, "height": H, "width": W}
+    tta = GeneralizedRCNNWithTTAAVG(cfg, model)
+    augs = tta.tta_mapper(inp)
+    assert len(augs) == int(d["n_aug"])
+    for i, a in enumerate(augs):
+        assert np.array_equal(a["image"].numpy(), d["aug%d_image" % i]), i
+        assert np.array_equal(a["proposals"].proposal_boxes.tensor.numpy(), d["aug%d_boxes" % i]), i
+        assert np.array_equal(a["proposals"].objectness_logits.numpy(), d["aug%d_obj" % i]), i
+    with torch.no_grad():
+        avg_b, avg_s = tta._get_augmented_boxes(augs)
+    assert np.allclose(avg_s.cpu().numpy(), d["avg_scores"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(avg_b.cpu().numpy(), d["avg_boxes"], rtol=1e-5, atol=1e-3)
+    out = tta([inp])[0]["instances"]
+    assert np.array_equal(out.pred_classes.cpu().numpy(), d["det_classes"])
+    assert np.allclose(out.scores.cpu().numpy(), d["det_scores"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(out.pred_boxes.tensor.cpu().numpy(), d["det_boxes"], rtol=1e-5, atol=1e-3)
+    load_package().set_precision("fp32")
+
+
+def test_tta_accumulate_matches_host_transform():
+    """drn_tta_accumulate vs the oracle's float32 numpy restatement of TransformList.inverse().apply_box + mean:
+    bit-exact for the back-transformed boxes of one augmentation, and for the sequential mean of four"""
+    from drn_wsod_pytorch_amd import ops
+
+    rs = np.random.RandomState(9)
+    R, K = 333, 7
+    params = [(1.25, 0.8, -1.0), (1.25, 0.8, 67.0), (0.875, 0.8695652, -1.0), (0.875, 0.8695652, 96.0)]
+    boxes = [torch.from_numpy((rs.rand(R, 4 * K) * 90).astype(np.float32)) for _ in params]
+    scores = [torch.from_numpy(rs.rand(R, K + 1).astype(np.float32)) for _ in params]
+    acc_b = torch.empty((R, 4 * K), device="cuda")
+    acc_s = torch.empty((R, K + 1), device="cuda")
+    refs = []
+    for i, ((sx, sy, fw), b, s) in enumerate(zip(params, boxes, scores)):
+        ops.tta_accumulate(b.cuda(), s.cuda(), acc_b, acc_s, sx, sy, fw, i == 0, len(params) if i == len(params) - 1 else 0)
+        steps = ([("hflip", int(fw))] if fw >= 0 else []) + [("scale", sx, sy)]
+        refs.append(torch.from_numpy(O.tta_apply_box(b.reshape(-1, 4).numpy(), steps)).reshape(R, 4 * K))
+        if i == 0:
+            assert torch.equal(acc_b.cpu(), refs[0])
+    ref_b = torch.mean(torch.stack(refs), dim=0)
+    ref_s = torch.mean(torch.stack(scores), dim=0)
+    assert torch.allclose(acc_b.cpu(), ref_b, rtol=0, atol=1e-5) and torch.allclose(acc_s.cpu(), ref_s, rtol=0, atol=1e-7)

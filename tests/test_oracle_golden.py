@@ -337,3 +337,27 @@ def test_appendix_d_known_answer():
                                                    p["roi_heads.box_predictor.cls.bias"]])
     _close(g[0], [0.072416, 0.048081, -0.012642, 0], rtol=1e-4, atol=1e-6)
     _close(g[1], [0.017981, 0.274978, -0.292959], rtol=1e-4, atol=1e-6)
+
+
+def test_tta_golden():
+    """oracle.tta_* vs the reference's own GeneralizedRCNNWithTTAAVG (tests/golden/gen_golden.py `tta`): augmented
+    images (PIL resize + flip) and proposals bit for bit, averaged boxes / scores, final detections."""
+    d = G.load("tta_r50c4_tiny")
+    ocfg = G.MODEL_CASES["model_r50c4_tiny"]
+    p = O.seeded_params(O.param_shapes(ocfg), int(d["seed"]))
+    img = torch.from_numpy(d["image_u8"])
+    boxes, obj = torch.from_numpy(d["proposal_boxes"]), torch.from_numpy(d["objectness_logits"])
+    det, augs, avg_boxes, avg_scores = O.tta_inference(p, img, boxes, obj, tuple(img.shape[1:]), ocfg,
+                                                       [int(x) for x in d["min_sizes"]], int(d["max_size"]), True,
+                                                       int(d["topk"]), return_aux=True)
+    assert len(augs) == int(d["n_aug"])
+    for i, a in enumerate(augs):
+        assert np.array_equal(a["image"].numpy(), d["aug%d_image" % i]), i
+        assert np.array_equal(a["proposal_boxes"].numpy(), d["aug%d_boxes" % i]), i
+        assert np.array_equal(a["objectness_logits"].numpy(), d["aug%d_obj" % i]), i
+    assert np.allclose(avg_scores.numpy(), d["avg_scores"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(avg_boxes.numpy(), d["avg_boxes"], rtol=1e-6, atol=1e-4)
+    b, s, c, _ = det
+    assert np.array_equal(c.numpy(), d["det_classes"])
+    assert np.allclose(s.numpy(), d["det_scores"], rtol=1e-5, atol=1e-7)
+    assert np.allclose(b.numpy(), d["det_boxes"], rtol=1e-6, atol=1e-4)

@@ -126,3 +126,31 @@ def test_instances_boxes_api(pkg):
     with pytest.raises(AssertionError):
         i.bad = torch.zeros(3)
     assert len(Instances.cat([i, i])) == 4
+
+
+def test_tta_mapper_matches_reference_golden():
+    """DatasetMapperTTAAVG (host-side data preparation of the TTA path) vs the reference's own mapper: augmented
+    images (PIL resize + flip) and transformed / clipped / top-k proposals bit for bit"""
+    import numpy as np
+    import torch
+
+    import golden_util as G
+    from drn_wsod_pytorch_amd.modeling import DatasetMapperTTAAVG
+    from drn_wsod_pytorch_amd.structures import Boxes, Instances
+
+    d = G.load("tta_r50c4_tiny")
+    cfg = G.drn_cfg(G.MODEL_CASES["model_r50c4_tiny"], "cpu")
+    cfg.merge_from_list(["TEST.AUG.MIN_SIZES", str(tuple(int(x) for x in d["min_sizes"])), "TEST.AUG.MAX_SIZE",
+                         str(int(d["max_size"])), "TEST.AUG.FLIP", "True", "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST",
+                         str(int(d["topk"]))])
+    img = torch.from_numpy(d["image_u8"])
+    H, W = img.shape[1:]
+    prop = Instances((H, W))
+    prop.proposal_boxes = Boxes(torch.from_numpy(d["proposal_boxes"]))
+    prop.objectness_logits = torch.from_numpy(d["objectness_logits"])
+    augs = DatasetMapperTTAAVG(cfg)({"image": img, "proposals": prop, "height": H, "width": W})
+    assert len(augs) == int(d["n_aug"])
+    for i, a in enumerate(augs):
+        assert np.array_equal(a["image"].numpy(), d["aug%d_image" % i]), i
+        assert np.array_equal(a["proposals"].proposal_boxes.tensor.numpy(), d["aug%d_boxes" % i]), i
+        assert np.array_equal(a["proposals"].objectness_logits.numpy(), d["aug%d_obj" % i]), i
