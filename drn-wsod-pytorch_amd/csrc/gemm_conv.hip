@@ -334,23 +334,62 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
       __builtin_amdgcn_s_barrier();
       if (s0 + 1 < s1) issue(smem + STAGE, s0 + 1);
       load_frags(smem, 0, fa0, fb0);
-      for (int s = s0; s < s1; ++s) {
+      // each group below = 6 fragment reads for the NEXT k-step + 8 MFMAs of the current one; the scheduling groups
+      // interleave them one read per MFMA so a wave's matrix instructions never queue behind its own LDS reads
+      // (+5 % on the fc6 shapes).  The last slab is peeled so the steady-state body is one branch-free block, which
+      // lets the 4th group also take the next slab's DMA issue (8 buffer_load..lds) under its MFMAs.
+#define DRN_INTERLEAVE()                                                     \
+  _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        \
+  }                                                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, 2, 0)
+      int s = s0;
+      for (; s + 1 < s1; ++s) {
         char* cur = smem + ((s - s0) & 1) * STAGE;
         char* nxt = smem + (((s - s0) & 1) ^ 1) * STAGE;
         load_frags(cur, 1, fa1, fb1);
         mma_all(fa0, fb0);
+        DRN_INTERLEAVE();
         load_frags(cur, 2, fa0, fb0);
         mma_all(fa1, fb1);
+        DRN_INTERLEAVE();
         load_frags(cur, 3, fa1, fb1);
         mma_all(fa0, fb0);
-        if (s + 1 < s1) {
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-          __builtin_amdgcn_s_barrier();
-          if (s + 2 < s1) issue(cur, s + 2);
-          load_frags(nxt, 0, fa0, fb0);
-        }
+        DRN_INTERLEAVE();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        // slab s+2 into the stage everybody just finished reading; past the end the last slab is fetched again into
+        // a stage nobody will read (keeps this block branch-free)
+        issue(cur, s + 2 < s1 ? s + 2 : s1 - 1);
+        load_frags(nxt, 0, fa0, fb0);
         mma_all(fa1, fb1);
+#pragma unroll
+        for (int q_ = 0; q_ < 6; ++q_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
       }
+      {  // last slab of this split: nothing left to fetch
+        char* cur = smem + ((s - s0) & 1) * STAGE;
+        load_frags(cur, 1, fa1, fb1);
+        mma_all(fa0, fb0);
+        DRN_INTERLEAVE();
+        load_frags(cur, 2, fa0, fb0);
+        mma_all(fa1, fb1);
+        DRN_INTERLEAVE();
+        load_frags(cur, 3, fa1, fb1);
+        mma_all(fa0, fb0);
+        DRN_INTERLEAVE();
+        mma_all(fa1, fb1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before LDS is reused
+      }
+#undef DRN_INTERLEAVE
     } else {
       issue(smem, s0);
       for (int s = s0; s < s1; ++s) {
