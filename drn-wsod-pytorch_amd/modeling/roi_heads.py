@@ -307,15 +307,17 @@ class _HeadEngine:
                 order += [("u%d.weight" % k, h.box_refinery[k].bbox_pred.weight, False),
                           ("u%d.bias" % k, h.box_refinery[k].bbox_pred.bias, False)]
         # the concatenated head weights / biases must stay contiguous (they are ONE GEMM operand); every other
-        # segment starts on a 16-byte boundary so the SGD kernel runs float4 lanes over it
+        # segment starts on a 64-element boundary = one 128-byte line of the bf16 shadow arena (256 B of the fp32 one):
+        # the GEMMs fetch operands in 128-byte K-slabs per row, and a row that starts mid-line makes every slab straddle
+        # two lines (measured on the fc6 forward GEMM: 392 us with a 16-byte aligned W1 vs 340 us line-aligned)
         contiguous = {n + ".weight" for n, _, _, _ in cols[1:]} | {n + ".bias" for n, _, _, _ in cols[1:]}
         offs, off = [], 0
         for name, p, used in order:
             if name not in contiguous:
-                off = (off + 7) // 8 * 8  # 16 B in the bf16 shadow arena, 32 B in the fp32 one
+                off = (off + 63) // 64 * 64
             offs.append(off)
             off += p.numel()
-        total = (off + 7) // 8 * 8
+        total = (off + 63) // 64 * 64
         w = torch.zeros((total,), dtype=torch.float32, device=device)
         g = torch.zeros((total,), dtype=torch.float32, device=device)
         self.segments = []
