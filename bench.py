@@ -233,6 +233,7 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
+    torch.manual_seed(1234 + rank)  # detectron2/engine/defaults.py:147: SEED + rank (per-rank dropout streams)
     pkg = load_package()
     pkg._cabi.lib()  # fail loudly if the HIP library is missing
     pkg.set_precision("bf16")
