@@ -13,10 +13,10 @@ from __graft_entry__ import load_package
 
 load_package()
 ops = importlib.import_module("drn_wsod_pytorch_amd.ops")
-M, N, K, S = 2000, 2048, 50176, 4
+M, N, K, S = [int(x) for x in os.environ.get("PMC_SHAPE", "2000,2048,50176,4").split(",")]  # default: fc6 forward
 A = (torch.randn((M, K), device="cuda") * 0.5).to(torch.bfloat16)
 B = (torch.randn((N, K), device="cuda") * 0.05).to(torch.bfloat16)
-out = torch.empty((S, M, N), dtype=torch.float32, device="cuda")
+out = torch.empty((S, M, N), dtype=torch.bfloat16 if os.environ.get("PMC_BF16_OUT") else torch.float32, device="cuda")
 for _ in range(6):
     ops.gemm_nt(A, B, M, N, K, out=out, splits=S)
 torch.cuda.synchronize()
