@@ -703,13 +703,19 @@ extern "C" int drn_transpose2d(const void* in, void* out, int rows, int cols, lo
                                int out_dtype, void* stream);
 
 template <int DT, int CH>
-static bool launch_roi_map(const RoiParams& p, hipStream_t st) {
+static bool launch_roi_map(const RoiParams& p, hipStream_t st, size_t lds_budget) {
   const int es = DT == DRN_BF16 ? 2 : 4;
   if (p.C % CH) return false;
   const size_t smem = (((size_t)p.H * p.W * CH * es + 15) & ~(size_t)15) + (size_t)ROI_GROUP * CH * 49 * es;
-  if (smem > 80 * 1024) return false;  // keep >= 2 blocks per CU
+  if (smem > lds_budget) return false;
   const int ngroups = (p.M + ROI_GROUP - 1) / ROI_GROUP;
-  hipLaunchKernelGGL((roi_pool7_map_kernel<DT, CH>), dim3((p.C / CH) * ngroups), dim3(256), smem, st, p);
+  auto k = roi_pool7_map_kernel<DT, CH>;
+  static bool attr = false;
+  if (!attr && smem > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return false;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3((p.C / CH) * ngroups), dim3(256), smem, st, p);
   return true;
 }
 
@@ -821,8 +827,20 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
                     (!out_t || (((ld_out_t * es) % 16) == 0 && (((uintptr_t)out_t) & 15) == 0));
     if (mode == 0 && P == 7 && !argmax && in_dtype == out_dtype && al) {
       bool done = false;
-      if (in_dtype == DRN_BF16) done = launch_roi_map<DRN_BF16, 32>(p, st) || launch_roi_map<DRN_BF16, 64>(p, st);
-      else if (in_dtype == DRN_F32) done = launch_roi_map<DRN_F32, 32>(p, st) || launch_roi_map<DRN_F32, 16>(p, st);
+      // channel slice per block: 32 wide when two blocks fit a CU (the 14x14 .. 28x28 training maps), else the widest
+      // slice whose map fits at all - the 43x58 .. 75x100 maps of test-time scales need 16 or 8 channels and most of
+      // a CU's LDS (one block per CU), which still beats the per-ROI window kernels by 3-4x there
+      const size_t two = 80 * 1024, one = 156 * 1024;
+      if (in_dtype == DRN_BF16)
+        done = launch_roi_map<DRN_BF16, 32>(p, st, two) || launch_roi_map<DRN_BF16, 64>(p, st, two) ||
+               launch_roi_map<DRN_BF16, 16>(p, st, two) || launch_roi_map<DRN_BF16, 8>(p, st, two) ||
+               launch_roi_map<DRN_BF16, 32>(p, st, one) || launch_roi_map<DRN_BF16, 16>(p, st, one) ||
+               launch_roi_map<DRN_BF16, 8>(p, st, one);
+      else if (in_dtype == DRN_F32)
+        done = launch_roi_map<DRN_F32, 32>(p, st, two) || launch_roi_map<DRN_F32, 16>(p, st, two) ||
+               launch_roi_map<DRN_F32, 8>(p, st, two) || launch_roi_map<DRN_F32, 4>(p, st, two) ||
+               launch_roi_map<DRN_F32, 16>(p, st, one) || launch_roi_map<DRN_F32, 8>(p, st, one) ||
+               launch_roi_map<DRN_F32, 4>(p, st, one);
       if (done) {
         DRN_CHECK_LAUNCH();
         return DRN_OK;

@@ -213,7 +213,8 @@ def _rois(R, n_img, H, W, seed):
 @pytest.mark.parametrize("C,P,scale,H,W,R", [(96, 7, 0.125, 23, 29, 80), (6, 3, 0.125, 23, 29, 80),
                                              (130, 7, 0.0625, 23, 29, 80), (128, 7, 0.0625, 14, 14, 83),
                                              (64, 7, 0.125, 40, 37, 80), (64, 7, 0.125, 28, 28, 45),
-                                             (16, 7, 0.125, 28, 28, 19)])
+                                             (16, 7, 0.125, 28, 28, 19), (64, 7, 0.0625, 43, 58, 37),
+                                             (24, 7, 0.0625, 75, 100, 21)])
 def test_roi_pool(drn, dtype, C, P, scale, H, W, R):
     """7x7 pooling of maps that fit in LDS takes the whole-map kernel (ROI groups straddling images, ragged last
     group); C % 64 == 0 otherwise takes the window-staged path; everything else the direct path.  The fused transposed
