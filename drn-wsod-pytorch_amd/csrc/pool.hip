@@ -94,6 +94,7 @@ struct RoiParams {
   int lds_px;  // pixels of staging LDS available per block (0 = direct path only)
   char* out_t;   // optional transposed copy [C*P*P][ld_out_t] (column = roi), or null
   long ld_out_t;
+  int gpw;       // whole-map kernel: consecutive 8-ROI groups handled by one block (per staged map slice)
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -518,11 +519,21 @@ __global__ __launch_bounds__(256) void roi_pool7_map_kernel(RoiParams p) {
   __shared__ int hb[ROI_GROUP][7][2], wb[ROI_GROUP][7][2], bidx[ROI_GROUP];
   __shared__ float mulv[ROI_GROUP];
   const int ngroups = (p.M + ROI_GROUP - 1) / ROI_GROUP;
+  const int nblk = (ngroups + p.gpw - 1) / p.gpw;  // blocks per channel chunk
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int chunk = logical / ngroups, group = logical - chunk * ngroups;
-  const int c0 = chunk * CH, m0 = group * ROI_GROUP;
-  const int nr = min(ROI_GROUP, p.M - m0);
+  const int chunk = logical / nblk, gblk = logical - chunk * nblk;
+  const int c0 = chunk * CH;
   const int tid = threadIdx.x;
+  const int r = tid >> 5, lane = tid & 31;
+  int staged = -1;  // image whose map slice currently sits in LDS
+  // several ROI groups per block share one staged map slice: for the large maps of test-time scales the slice is far
+  // bigger than a group's output, and re-staging it per group was the whole cost
+  for (int gi = 0; gi < p.gpw; ++gi) {
+  const int group = gblk * p.gpw + gi;
+  if (group >= ngroups) break;
+  const int m0 = group * ROI_GROUP;
+  const int nr = min(ROI_GROUP, p.M - m0);
+  __syncthreads();  // the previous group's tile / bounds are no longer read
   if (tid < ROI_GROUP * 7) {
     const int r = tid / 7, i = tid - r * 7;
     if (r < nr) {
@@ -547,17 +558,20 @@ __global__ __launch_bounds__(256) void roi_pool7_map_kernel(RoiParams p) {
     const int b = bidx[r0];
     int r1 = r0 + 1;
     while (r1 < nr && bidx[r1] == b) ++r1;
-    const char* fb = p.feat + ((long)b * HW * p.C + c0) * ES;
-    for (int i = tid; i < HW * VPL; i += 256) {
-      const int px = i / VPL, v = i - px * VPL;
-      i32x4_t x = *(const i32x4_t*)(fb + (long)px * p.C * ES + v * 16);
-      if constexpr (DT == DRN_BF16) {
+    if (b != staged) {  // uniform over the block
+      const char* fb = p.feat + ((long)b * HW * p.C + c0) * ES;
+      for (int i = tid; i < HW * VPL; i += 256) {
+        const int px = i / VPL, v = i - px * VPL;
+        i32x4_t x = *(const i32x4_t*)(fb + (long)px * p.C * ES + v * 16);
+        if constexpr (DT == DRN_BF16) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
+          for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
+        }
+        *(i32x4_t*)(map + (long)i * 16) = x;
       }
-      *(i32x4_t*)(map + (long)i * 16) = x;
+      staged = b;
+      __syncthreads();
     }
-    __syncthreads();
     if (r >= r0 && r < r1) {
       const float mul = mulv[r];
       T* trow = tile + (long)r * RUN;
@@ -627,6 +641,7 @@ __global__ __launch_bounds__(256) void roi_pool7_map_kernel(RoiParams p) {
         for (int rr = 0; rr < nr; ++rr) ot[(long)idx * p.ld_out_t + rr] = tile[(long)rr * RUN + idx];
     }
   }
+  }  // ROI groups of this block
 }
 
 // bf16 -> bf16 transpose with 16-B global accesses on both sides (the A -> A^T copy of the fc6 operand is
@@ -709,13 +724,20 @@ static bool launch_roi_map(const RoiParams& p, hipStream_t st, size_t lds_budget
   const size_t smem = (((size_t)p.H * p.W * CH * es + 15) & ~(size_t)15) + (size_t)ROI_GROUP * CH * 49 * es;
   if (smem > lds_budget) return false;
   const int ngroups = (p.M + ROI_GROUP - 1) / ROI_GROUP;
+  // groups per block: keep the bytes staged per block (H*W pixels) below the bytes it writes (8 ROIs x 49 bins x 2
+  // copies per group) - 1 for the 14x14 training map, up to 10 for a 75x100 map
+  RoiParams q = p;
+  q.gpw = (p.H * p.W + 783) / 784;
+  if (q.gpw > 16) q.gpw = 16;
+  if (q.gpw < 1) q.gpw = 1;
+  const int nblk = (ngroups + q.gpw - 1) / q.gpw;
   auto k = roi_pool7_map_kernel<DT, CH>;
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess) return false;
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3((p.C / CH) * ngroups), dim3(256), smem, st, p);
+  hipLaunchKernelGGL(k, dim3((p.C / CH) * nblk), dim3(256), smem, st, q);
   return true;
 }
 
