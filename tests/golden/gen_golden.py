@@ -410,10 +410,79 @@ def case_tta(name, yaml_rel, opts, seed, R, H, W, min_sizes, max_size, topk):
           [tuple(a["image"].shape) for a in aug])
 
 
+def c2_style_name(model_key):
+    """inverse of the naming the released WSL checkpoints use (projects/WSL/tools/convert_resnet_ws_c2.py output, i.e.
+    Caffe2 blob names with the stem renamed to stem_convN and fc6/fc7 to fc1/fc2); None for keys such files lack"""
+    k = model_key
+    if k.startswith("backbone."):
+        k = k[len("backbone."):]
+    elif k.startswith("roi_heads.box_head."):
+        k = k[len("roi_heads.box_head."):]
+    else:
+        return None
+    parts = k.split(".")
+    leaf = {"weight": "w", "bias": "b"}[parts[-1]] if parts[-2] != "norm" else \
+        {"weight": "bn_s", "bias": "bn_b", "running_mean": "bn_rm", "running_var": "bn_riv"}[parts[-1]]
+    body = parts[:-1] if parts[-2] != "norm" else parts[:-2]
+    body = [{"conv1": "branch2a", "conv2": "branch2b", "conv3": "branch2c", "shortcut": "branch1"}.get(x, x)
+            if body[0].startswith("res") else x for x in body]
+    if body[0] == "stem":
+        body = ["stem_" + body[1]]
+    return "_".join(body + [leaf])
+
+
+def case_checkpoint(name, yaml_rel, opts):
+    """detectron2/checkpoint/c2_model_loading.py: convert_c2_detectron_names + align_and_update_state_dicts run on a
+    synthetic WSL-style Caffe2 checkpoint (every tensor filled with its own index) for the tiny R50-C4 model, plus
+    decoys: a *_momentum blob, an unrelated blob, a shape mismatch, and a d2-format (no conversion) pass."""
+    import importlib.util
+
+    cfg, model = rh.build_reference_model(yaml_rel, opts)
+    spec = importlib.util.spec_from_file_location("ref_c2_model_loading",
+                                                  os.path.join(rh.REF, "detectron2", "checkpoint", "c2_model_loading.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    sd = model.state_dict()
+    ckpt, ckeys, cshapes = {}, [], []
+    for i, (k, t) in enumerate(sd.items()):
+        c = c2_style_name(k)
+        if c is None:
+            continue
+        shape = tuple(t.shape)
+        if k.endswith("res3.1.conv2.weight"):
+            shape = shape[:-1] + (shape[-1] + 1,)  # shape mismatch: must be skipped with a warning
+        ckpt[c] = torch.full(shape, float(len(ckeys) + 1))
+        ckeys.append(c)
+        cshapes.append(np.array(shape))
+    for extra, shape in (("res2_0_branch2a_w_momentum", (3,)), ("pred_w", (7, 5)), ("conv5_mask_w", (2, 2))):
+        ckpt[extra] = torch.full(shape, float(len(ckeys) + 1))
+        ckeys.append(extra)
+        cshapes.append(np.array(shape))
+    d = {"ckpt_keys": np.array(ckeys), "model_keys": np.array(list(sd.keys()))}
+    for i, sh in enumerate(cshapes):
+        d["ckpt_shape%d" % i] = sh
+    for tag, c2 in (("c2", True), ("d2", False)):
+        msd = {k: torch.zeros_like(v) for k, v in sd.items()}
+        src = {k: v for k, v in ckpt.items() if not k.endswith("_momentum")} if c2 else \
+            {k.replace("backbone.", ""): torch.full(tuple(v.shape), float(j + 1)) for j, (k, v) in enumerate(sd.items())
+             if k.startswith("backbone.")}
+        if not c2:
+            d["d2_keys"] = np.array(list(src.keys()))
+        mod.align_and_update_state_dicts(msd, src, c2_conversion=c2)
+        # every loaded tensor is constant = 1-based index of its source key
+        d["map_" + tag] = np.array([int(v.reshape(-1)[0].item()) for v in msd.values()], dtype=np.int64)
+    new_w, new_to_orig = mod.convert_c2_detectron_names({k: v for k, v in ckpt.items() if not k.endswith("_momentum")})
+    d["renamed"] = np.array(sorted(new_w.keys()))
+    d["renamed_orig"] = np.array([new_to_orig[k] for k in sorted(new_w.keys())])
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, "loaded c2:", int((d["map_c2"] > 0).sum()), "of", len(sd), " d2:", int((d["map_d2"] > 0).sum()))
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "heads", "r50dc5", "r50c4", "r50c4_align", "r18", "vgg", "r50c4_drop", "r50c4_reg", "tta"]
+    which = sys.argv[1:] or ["ops", "heads", "r50dc5", "r50c4", "r50c4_align", "r18", "vgg", "r50c4_drop", "r50c4_reg", "tta", "ckpt"]
     if "ops" in which:
         case_ops("ops", 11)
     if "heads" in which:
@@ -437,6 +506,8 @@ if __name__ == "__main__":
     if "r50c4_drop" in which:
         case_full_model("model_r50c4_dropmask_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 36,
                         1, 40, 96, 96, dropmask=True)
+    if "ckpt" in which:
+        case_checkpoint("ckpt_r50c4_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4)
     if "tta" in which:
         case_tta("tta_r50c4_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 38, 48, 60, 84,
                  (48, 72), 96, 40)

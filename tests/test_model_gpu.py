@@ -534,3 +534,32 @@ def test_tta_accumulate_matches_host_transform():
     ref_b = torch.mean(torch.stack(refs), dim=0)
     ref_s = torch.mean(torch.stack(scores), dim=0)
     assert torch.allclose(acc_b.cpu(), ref_b, rtol=0, atol=1e-5) and torch.allclose(acc_s.cpu(), ref_s, rtol=0, atol=1e-7)
+
+
+def test_checkpoint_load_into_live_cuda_model(tmp_path):
+    """DetectionCheckpointer.load into a model that has already run (packed conv weights cached, head parameters living
+    in the flat arena with bf16 shadows): the next inference must equal a model built directly on those weights."""
+    from drn_wsod_pytorch_amd.checkpoint import DetectionCheckpointer
+
+    name = "model_r50c4_tiny"
+    d = G.load(name)
+    ocfg = G.MODEL_CASES[name]
+    batch = G.drn_inputs(G.batch_from(d), with_gt=False)
+    _, src = G.drn_model(ocfg, 123, "cuda", 5, "bf16")
+    src.eval()
+    with torch.no_grad():
+        ref, ref_scores, _ = src.inference(batch, do_postprocess=False)
+    DetectionCheckpointer(src, str(tmp_path)).save("w")
+    _, model = G.drn_model(ocfg, 7, "cuda", 5, "bf16")
+    model.eval()
+    with torch.no_grad():
+        _, s0, _ = model.inference(batch, do_postprocess=False)  # caches packs / shadows of the OLD weights
+    assert not torch.equal(s0[0], ref_scores[0])
+    missing, unexpected = DetectionCheckpointer(model, str(tmp_path)).resume_or_load("", resume=True) or ([], [])
+    with torch.no_grad():
+        got, got_scores, _ = model.inference(batch, do_postprocess=False)
+    for a, b in zip(got_scores, ref_scores):
+        assert torch.equal(a, b)
+    for a, b in zip(got, ref):
+        assert torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.scores, b.scores)
+    load_package().set_precision("fp32")

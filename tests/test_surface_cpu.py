@@ -154,3 +154,66 @@ def test_tta_mapper_matches_reference_golden():
         assert np.array_equal(a["image"].numpy(), d["aug%d_image" % i]), i
         assert np.array_equal(a["proposals"].proposal_boxes.tensor.numpy(), d["aug%d_boxes" % i]), i
         assert np.array_equal(a["proposals"].objectness_logits.numpy(), d["aug%d_obj" % i]), i
+
+
+def test_checkpoint_alignment_matches_reference_golden(tmp_path):
+    """checkpoint.py vs the reference's own convert_c2_detectron_names / align_and_update_state_dicts on the synthetic
+    WSL-style Caffe2 checkpoint of tests/golden/gen_golden.py `ckpt`: identical renaming and identical
+    model-key <- blob assignment (Caffe2 mode incl. the skipped shape mismatch and the ignored decoys; plain mode),
+    then the file-level paths: Caffe2 .pkl, Detectron2-zoo .pkl, .pth save / resume."""
+    import pickle
+
+    import numpy as np
+    import torch
+
+    import golden_util as G
+    from __graft_entry__ import load_package
+
+    load_package()
+    from drn_wsod_pytorch_amd import checkpoint as C
+    from drn_wsod_pytorch_amd.modeling import build_model
+
+    d = G.load("ckpt_r50c4_tiny")
+    model = build_model(G.drn_cfg(G.MODEL_CASES["model_r50c4_tiny"], "cpu"))
+    sd = model.state_dict()
+    assert list(sd.keys()) == list(d["model_keys"])
+    keys = [str(k) for k in d["ckpt_keys"]]
+    ckpt = {k: torch.full(tuple(int(x) for x in d["ckpt_shape%d" % i]), float(i + 1)) for i, k in enumerate(keys)}
+    blobs = {k: v for k, v in ckpt.items() if not k.endswith("_momentum")}
+    new_w, back = C.convert_c2_detectron_names(blobs)
+    assert sorted(new_w) == [str(x) for x in d["renamed"]]
+    assert [back[k] for k in sorted(new_w)] == [str(x) for x in d["renamed_orig"]]
+    msd = {k: torch.zeros_like(v) for k, v in sd.items()}
+    C.align_and_update_state_dicts(msd, blobs, c2_conversion=True)
+    assert [int(v.reshape(-1)[0]) for v in msd.values()] == d["map_c2"].tolist()
+    src = {k[len("backbone."):]: torch.full(tuple(v.shape), float(j + 1)) for j, (k, v) in enumerate(sd.items())
+           if k.startswith("backbone.")}  # same construction as the generator: value = 1-based index among ALL model keys
+    assert list(src.keys()) == [str(x) for x in d["d2_keys"]]
+    msd = {k: torch.zeros_like(v) for k, v in sd.items()}
+    C.align_and_update_state_dicts(msd, src, c2_conversion=False)
+    assert [int(v.reshape(-1)[0]) for v in msd.values()] == d["map_d2"].tolist()
+    # file level: Caffe2-style pkl (numpy blobs + a momentum blob) -> model
+    f = tmp_path / "wsl_c2.pkl"
+    with open(f, "wb") as fh:
+        pickle.dump({"blobs": {k: v.numpy() for k, v in ckpt.items()}}, fh)
+    ck = C.DetectionCheckpointer(model, str(tmp_path))
+    ck.load(str(f))
+    got = model.state_dict()
+    for mk, idx in zip(sd.keys(), d["map_c2"].tolist()):
+        if idx > 0:
+            assert float(got[mk].reshape(-1)[0]) == float(idx), mk
+    # .pth round trip + resume
+    ck.save("model_0000001", iteration=1)
+    model2 = build_model(G.drn_cfg(G.MODEL_CASES["model_r50c4_tiny"], "cpu"))
+    extra = C.DetectionCheckpointer(model2, str(tmp_path)).resume_or_load("", resume=True)
+    assert extra["iteration"] == 1
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, model2.state_dict()[k]), k
+    # Detectron2-zoo pkl: exact names, no heuristics
+    f2 = tmp_path / "zoo.pkl"
+    with open(f2, "wb") as fh:
+        pickle.dump({"model": {k: v.numpy() for k, v in model.state_dict().items()}, "__author__": "test"}, fh)
+    model3 = build_model(G.drn_cfg(G.MODEL_CASES["model_r50c4_tiny"], "cpu"))
+    C.DetectionCheckpointer(model3).load(str(f2))
+    for k, v in model.state_dict().items():
+        assert torch.equal(v, model3.state_dict()[k]), k
