@@ -691,8 +691,13 @@ int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, c
   hipStream_t st = (hipStream_t)stream;
   const long Mtot = (long)Nb * Ho * Wo;
   const bool small = ((Mtot + 127) / 128) * ((Cout + 127) / 128) < 128;
-  if (dtype == DRN_BF16) return small ? launch_conv<DRN_BF16, 64, 64>(p, st) : launch_conv<DRN_BF16, 128, 128>(p, st);
-  return small ? launch_conv<DRN_F32, 64, 64>(p, st) : launch_conv<DRN_F32, 128, 128>(p, st);
+  // narrow outputs (the 64-channel stem / res2 layers at real image sizes): a 128x128 tile would run half empty
+  const bool narrow = !small && Cout <= 64;
+  if (dtype == DRN_BF16)
+    return small ? launch_conv<DRN_BF16, 64, 64>(p, st)
+                 : narrow ? launch_conv<DRN_BF16, 128, 64>(p, st) : launch_conv<DRN_BF16, 128, 128>(p, st);
+  return small ? launch_conv<DRN_F32, 64, 64>(p, st)
+               : narrow ? launch_conv<DRN_F32, 128, 64>(p, st) : launch_conv<DRN_F32, 128, 128>(p, st);
 }
 
 }  // extern "C"

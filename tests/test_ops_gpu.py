@@ -146,6 +146,9 @@ CONV_CASES = [
     (1, 33, 31, 3, 8, 3, 2, 1, 1, False, True),
     (1, 56, 56, 64, 256, 1, 1, 0, 1, True, False),
     (3, 9, 11, 8, 136, 3, 1, 1, 1, False, False),
+    (1, 131, 160, 16, 64, 3, 1, 1, 1, False, True),   # large M, narrow output: the 128x64 tile
+    (1, 131, 160, 16, 48, 1, 1, 0, 1, True, True),    # same with a ragged Cout and a residual
+    (1, 150, 150, 32, 192, 3, 1, 1, 1, False, True),  # large M, 128x128 tile with a ragged second column tile
 ]
 
 

@@ -18,6 +18,13 @@ model = build_model(cfg)
 bench.init_weights(model, seed=0)
 model.eval()
 batches = bench.synthetic_batches(2, 2000, 20, "cuda", 0, pkg)
+HW = os.environ.get("BB_HW")
+if HW:  # e.g. BB_HW=800,1216: a realistic training / test-time scale instead of the 224x224 benchmark image
+    H, W = [int(x) for x in HW.split(",")]
+    for b in batches:
+        b[0]["image"] = torch.randint(0, 256, (3, H, W)).float().cuda()
+    # R50-C4 trunk: 7.90 GFLOP at 224x224, linear in the pixel count
+    print("trunk FLOPs at %dx%d: %.1f GF" % (H, W, 7.90 * H * W / (224 * 224)))
 
 
 def fwd():
@@ -46,4 +53,7 @@ for _ in range(20):
     g.replay()
 b.record()
 torch.cuda.synchronize()
-print("graph  : %.1f us per trunk forward" % (a.elapsed_time(b) / 20 * 1e3))
+t = a.elapsed_time(b) / 20 * 1e3
+print("graph  : %.1f us per trunk forward" % t)
+if HW:
+    print("        = %.1f TFLOP/s" % (7.90 * H * W / (224 * 224) / t * 1e3))
