@@ -197,6 +197,18 @@ def pmc_traffic(shape):
     return rec["traffic_bytes_per_launch"] if tuple(rec["shape"]) == tuple(shape) else None
 
 
+def pmc_mfma_util(shape):
+    """SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8) of the roofline kernel from the committed PMC pass
+    (profiles/r1_08_pmc_mfma_fc6_gemm.json): MFMA pipe utilisation at the clock the chip sustains under that kernel
+    (1.72 GHz), which is why it is higher than `frac` (relative to the 2.4 GHz peak)."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_08_pmc_mfma_fc6_gemm.json")
+    try:
+        rec = json.load(open(path))
+    except OSError:
+        return None
+    return rec["mfma_util"] if tuple(rec["shape"]) == tuple(shape) else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -330,6 +342,7 @@ def main():
             achieved = fwd[0][1] / (ms * 1e-3) / 1e12
             roof = {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic((R, D1, K1)),
+                    "mfma_util_pmc": pmc_mfma_util((R, D1, K1)),
                     "kernel": "gemm_nt256_kernel<bf16> (fc6 fwd: [%d x %d] . [%d x %d]^T, split-K 4)" % (R, K1, D1, K1),
                     "avg_launch_ms": ms, "launches_timed": len(fwd),
                     "timed_in": "eager warm-up steps of this run (HIP events on the launch stream)" if use_graph
