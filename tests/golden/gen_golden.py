@@ -410,6 +410,66 @@ def case_tta(name, yaml_rel, opts, seed, R, H, W, min_sizes, max_size, topk):
           [tuple(a["image"].shape) for a in aug])
 
 
+def case_data(name, yaml_rel, opts, seed):
+    """The data path either side of the model: load_proposals_into_dataset
+    (detectron2/data/build.py:102-153) on a Detectron1-keyed proposal pickle, then the reference DatasetMapper
+    (detectron2/data/dataset_mapper.py + detection_utils.py: read_image, ResizeShortestEdge / RandomFlip /
+    RandomBrightness / RandomSaturation of this fork's build_augmentation, transform_instance_annotations,
+    transform_proposals with unique_boxes) in train mode under a fixed numpy seed and in test mode."""
+    import pickle
+    import tempfile
+
+    from PIL import Image
+
+    import detectron2.data.build as B
+    import detectron2.data.dataset_mapper as DM
+
+    o = list(opts) + ["INPUT.MIN_SIZE_TRAIN", "(48, 64, 80)", "INPUT.MAX_SIZE_TRAIN", "120", "INPUT.MIN_SIZE_TEST", "64",
+                      "INPUT.MAX_SIZE_TEST", "100", "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TRAIN", "30",
+                      "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST", "25"]
+    cfg, _ = rh.build_reference_model(yaml_rel, o)
+    rs = np.random.RandomState(seed)
+    H, W, R = 60, 84, 40
+    rgb = rs.randint(0, 256, size=(H, W, 3)).astype(np.uint8)
+    tmp = tempfile.mkdtemp()
+    fn = os.path.join(tmp, "000123.png")
+    Image.fromarray(rgb).save(fn)
+    x0, y0 = rs.rand(R) * (W - 20), rs.rand(R) * (H - 20)
+    boxes = np.stack([x0, y0, x0 + 4 + rs.rand(R) * (W - x0 - 4), y0 + 4 + rs.rand(R) * (H - y0 - 4)], 1).astype(np.float32)
+    boxes[7] = boxes[3]          # exact duplicate -> unique_boxes
+    boxes[11] = boxes[5] + 0.2   # duplicate after rounding
+    boxes[13, 2] = boxes[13, 0]  # empty box
+    scores = rs.rand(R).astype(np.float32)
+    other = np.zeros((3, 4), dtype=np.float32)
+    pf = os.path.join(tmp, "props.pkl")
+    with open(pf, "wb") as f:  # Detectron1 key names + an image that is not in the dataset
+        pickle.dump({"indexes": [7, 123], "boxes": [other, boxes], "scores": [np.zeros(3, np.float32), scores]}, f)
+    annos = [{"bbox": [10.0, 8.0, 50.0, 40.0], "bbox_mode": 0, "category_id": 3},
+             {"bbox": [30.5, 20.25, 80.0, 58.0], "bbox_mode": 0, "category_id": 1},
+             {"bbox": [5.0, 5.0, 20.0, 20.0], "bbox_mode": 0, "category_id": 2, "iscrowd": 1}]
+    rec = {"file_name": fn, "height": H, "width": W, "image_id": 123, "annotations": annos}
+    d = {"rgb": rgb, "boxes": boxes, "scores": scores, "seed": np.int64(seed)}
+    recs = B.load_proposals_into_dataset([dict(rec)], pf)
+    d["loaded_boxes"] = recs[0]["proposal_boxes"]
+    d["loaded_logits"] = recs[0]["proposal_objectness_logits"]
+    for tag, is_train, nrep in (("train", True, 4), ("test", False, 1)):
+        mapper = DM.DatasetMapper(cfg, is_train)
+        np.random.seed(seed)
+        for rep in range(nrep):
+            out = mapper(recs[0])
+            k = "%s%d_" % (tag, rep)
+            d[k + "image"] = out["image"].numpy()
+            d[k + "prop_boxes"] = out["proposals"].proposal_boxes.tensor.numpy()
+            d[k + "prop_logits"] = out["proposals"].objectness_logits.numpy()
+            if is_train:
+                d[k + "gt_boxes"] = out["instances"].gt_boxes.tensor.numpy()
+                d[k + "gt_classes"] = out["instances"].gt_classes.numpy()
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", [tuple(d["train%d_image" % i].shape) for i in range(4)],
+          len(d["train0_prop_boxes"]), len(d["test0_prop_boxes"]))
+
+
 def c2_style_name(model_key):
     """inverse of the naming the released WSL checkpoints use (projects/WSL/tools/convert_resnet_ws_c2.py output, i.e.
     Caffe2 blob names with the stem renamed to stem_convN and fc6/fc7 to fc1/fc2); None for keys such files lack"""
@@ -482,7 +542,7 @@ def case_checkpoint(name, yaml_rel, opts):
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "heads", "r50dc5", "r50c4", "r50c4_align", "r18", "vgg", "r50c4_drop", "r50c4_reg", "tta", "ckpt"]
+    which = sys.argv[1:] or ["ops", "heads", "r50dc5", "r50c4", "r50c4_align", "r18", "vgg", "r50c4_drop", "r50c4_reg", "tta", "ckpt", "data"]
     if "ops" in which:
         case_ops("ops", 11)
     if "heads" in which:
@@ -506,6 +566,8 @@ if __name__ == "__main__":
     if "r50c4_drop" in which:
         case_full_model("model_r50c4_dropmask_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 36,
                         1, 40, 96, 96, dropmask=True)
+    if "data" in which:
+        case_data("data_mapper", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 41)
     if "ckpt" in which:
         case_checkpoint("ckpt_r50c4_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4)
     if "tta" in which:

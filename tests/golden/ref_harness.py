@@ -26,6 +26,13 @@ AUTO_STUB = (
 )
 
 
+# real reference modules that live under an auto-stubbed package (TTA golden: the reference's own resize / flip
+# transforms and its GeneralizedRCNNWithTTAAVG are imported for real; their parents stay stubs)
+REAL_UNDER_STUB = ("detectron2.data.transforms", "wsl.modeling.test_time_augmentation_avg", "detectron2.data.build",
+                   "detectron2.data.detection_utils", "detectron2.data.dataset_mapper")
+REAL_PATHS = {"detectron2.data": os.path.join(REF, "detectron2", "data")}
+
+
 class _Dummy:
     def __init__(self, *a, **k):
         pass
@@ -49,15 +56,16 @@ class _StubModule(types.ModuleType):
     def __getattr__(self, name):
         if name.startswith("__") and name.endswith("__"):
             raise AttributeError(name)
+        full = self.__name__ + "." + name
+        if full in REAL_UNDER_STUB:  # `from . import transforms`: hand out the real sub-module, not a dummy class
+            import importlib
+
+            mod = importlib.import_module(full)
+            setattr(self, name, mod)
+            return mod
         cls = type(name, (), {"__init__": lambda self, *a, **k: None, "__call__": lambda self, *a, **k: None})
         setattr(self, name, cls)
         return cls
-
-
-# real reference modules that live under an auto-stubbed package (TTA golden: the reference's own resize / flip
-# transforms and its GeneralizedRCNNWithTTAAVG are imported for real; their parents stay stubs)
-REAL_UNDER_STUB = ("detectron2.data.transforms", "wsl.modeling.test_time_augmentation_avg")
-REAL_PATHS = {"detectron2.data": os.path.join(REF, "detectron2", "data")}
 
 
 class _Finder(importlib.abc.MetaPathFinder, importlib.abc.Loader):

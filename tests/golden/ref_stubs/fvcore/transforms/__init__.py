@@ -1,2 +1,2 @@
 from .transform import *  # noqa: F401,F403
-from .transform import HFlipTransform, NoOpTransform, Transform, TransformList  # noqa: F401
+from .transform import BlendTransform, CropTransform, HFlipTransform, NoOpTransform, Transform, TransformList  # noqa: F401

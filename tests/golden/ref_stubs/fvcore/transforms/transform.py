@@ -106,9 +106,49 @@ class NoOpTransform(Transform):
         raise AttributeError(name)
 
 
+class BlendTransform(Transform):
+    """fvcore: img' = src_weight * src_image + dst_weight * img; uint8 inputs are computed in float32, clipped to
+    [0, 255] and cast back; coordinates are untouched"""
+
+    def __init__(self, src_image, src_weight, dst_weight):
+        super().__init__()
+        self._set_attributes(locals())
+
+    def apply_image(self, img, interp=None):
+        if img.dtype == np.uint8:
+            img = img.astype(np.float32)
+            img = self.src_weight * self.src_image + self.dst_weight * img
+            return np.clip(img, 0, 255).astype(np.uint8)
+        return self.src_weight * self.src_image + self.dst_weight * img
+
+    def apply_coords(self, coords):
+        return coords
+
+    def inverse(self):
+        return NoOpTransform()
+
+
+class CropTransform(Transform):
+    """fvcore: crop the window [y0, y0+h) x [x0, x0+w); coordinates shift by (-x0, -y0)"""
+
+    def __init__(self, x0, y0, w, h, orig_w=None, orig_h=None):
+        super().__init__()
+        self._set_attributes(locals())
+
+    def apply_image(self, img):
+        if len(img.shape) <= 3:
+            return img[self.y0: self.y0 + self.h, self.x0: self.x0 + self.w]
+        return img[..., self.y0: self.y0 + self.h, self.x0: self.x0 + self.w, :]
+
+    def apply_coords(self, coords):
+        coords[:, 0] -= self.x0
+        coords[:, 1] -= self.y0
+        return coords
+
+
 class _T(Transform):
     def __init__(self, *a, **k):
         pass
 
 
-VFlipTransform = BlendTransform = CropTransform = GridSampleTransform = ScaleTransform = _T
+VFlipTransform = GridSampleTransform = ScaleTransform = _T

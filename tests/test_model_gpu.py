@@ -563,3 +563,42 @@ def test_checkpoint_load_into_live_cuda_model(tmp_path):
     for a, b in zip(got, ref):
         assert torch.equal(a.pred_classes, b.pred_classes) and torch.equal(a.scores, b.scores)
     load_package().set_precision("fp32")
+
+
+def test_dataset_mapper_output_trains(tmp_path):
+    """the data path's output is the model's input: a record goes through load_proposals_into_dataset + DatasetMapper
+    (train mode: crop / resize / flip / colour) straight into a train step on the GPU, and through the test-mode
+    mapper into inference"""
+    import pickle
+
+    from drn_wsod_pytorch_amd import data as D
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    d = G.load("data_mapper")
+    ocfg = G.MODEL_CASES["model_r50c4_tiny"]
+    cfg, model = G.drn_model(ocfg, 5, "cuda", 5, "bf16")
+    cfg.merge_from_list(["INPUT.MIN_SIZE_TRAIN", "(48, 64, 80)", "INPUT.MAX_SIZE_TRAIN", "120", "INPUT.MIN_SIZE_TEST", "64",
+                         "INPUT.MAX_SIZE_TEST", "100", "INPUT.CROP.ENABLED", "True",
+                         "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TRAIN", "30", "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST", "25"])
+    pf = str(tmp_path / "props.pkl")
+    with open(pf, "wb") as f:
+        pickle.dump({"ids": [123], "boxes": [d["boxes"]], "objectness_logits": [d["scores"]]}, f)
+    H, W = d["rgb"].shape[:2]
+    rec = {"image_array": d["rgb"][:, :, ::-1].copy(), "height": H, "width": W, "image_id": 123,
+           "annotations": [{"bbox": [10.0, 8.0, 50.0, 40.0], "bbox_mode": 0, "category_id": 3},
+                           {"bbox": [30.5, 20.25, 80.0, 58.0], "bbox_mode": 0, "category_id": 1}]}
+    recs = D.load_proposals_into_dataset([rec], pf)
+    np.random.seed(3)
+    batch = [D.DatasetMapper(cfg, True)(recs[0]) for _ in range(2)]
+    assert batch[0]["image"].dtype == torch.uint8
+    model.train()
+    opt = build_optimizer(cfg, model)
+    opt.zero_grad()
+    losses = model(batch)
+    sum(losses.values()).backward()
+    opt.step()
+    assert all(torch.isfinite(v).all() for v in losses.values()) and set(losses) >= {"loss_cls", "loss_cls_r0"}
+    model.eval()
+    out = model([D.DatasetMapper(cfg, False)(recs[0])])
+    assert len(out) == 1 and len(out[0]["instances"]) <= cfg.TEST.DETECTIONS_PER_IMAGE
+    load_package().set_precision("fp32")

@@ -217,3 +217,53 @@ def test_checkpoint_alignment_matches_reference_golden(tmp_path):
     C.DetectionCheckpointer(model3).load(str(f2))
     for k, v in model.state_dict().items():
         assert torch.equal(v, model3.state_dict()[k]), k
+
+
+def test_data_path_matches_reference_golden(tmp_path):
+    """data.py vs the reference's own load_proposals_into_dataset + DatasetMapper (tests/golden/gen_golden.py `data`):
+    proposal file with Detectron1 key names, then four TRAIN draws under the same numpy seed (random crop, multi-scale
+    resize through PIL, flip, brightness / saturation blends, box annotations, proposals transformed / clipped /
+    de-duplicated / top-k) and one TEST pass - images, boxes, logits and classes bit for bit."""
+    import pickle
+
+    import numpy as np
+    from PIL import Image
+
+    import golden_util as G
+    from __graft_entry__ import load_package
+
+    load_package()
+    from drn_wsod_pytorch_amd import data as D
+
+    d = G.load("data_mapper")
+    cfg = G.drn_cfg(G.MODEL_CASES["model_r50c4_tiny"], "cpu")
+    cfg.merge_from_list(["INPUT.MIN_SIZE_TRAIN", "(48, 64, 80)", "INPUT.MAX_SIZE_TRAIN", "120", "INPUT.MIN_SIZE_TEST", "64",
+                         "INPUT.MAX_SIZE_TEST", "100", "INPUT.CROP.ENABLED", "True",
+                         "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TRAIN", "30", "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST", "25"])
+    rgb = d["rgb"]
+    H, W = rgb.shape[:2]
+    fn = str(tmp_path / "000123.png")
+    Image.fromarray(rgb).save(fn)
+    pf = str(tmp_path / "props.pkl")
+    with open(pf, "wb") as f:
+        pickle.dump({"indexes": [7, 123], "boxes": [np.zeros((3, 4), np.float32), d["boxes"]],
+                     "scores": [np.zeros(3, np.float32), d["scores"]]}, f)
+    annos = [{"bbox": [10.0, 8.0, 50.0, 40.0], "bbox_mode": 0, "category_id": 3},
+             {"bbox": [30.5, 20.25, 80.0, 58.0], "bbox_mode": 0, "category_id": 1},
+             {"bbox": [5.0, 5.0, 20.0, 20.0], "bbox_mode": 0, "category_id": 2, "iscrowd": 1}]
+    rec = {"file_name": fn, "height": H, "width": W, "image_id": 123, "annotations": annos}
+    recs = D.load_proposals_into_dataset([dict(rec)], pf)
+    assert np.array_equal(recs[0]["proposal_boxes"], d["loaded_boxes"])
+    assert np.array_equal(recs[0]["proposal_objectness_logits"], d["loaded_logits"])
+    for tag, is_train, nrep in (("train", True, 4), ("test", False, 1)):
+        mapper = D.DatasetMapper(cfg, is_train)
+        np.random.seed(int(d["seed"]))
+        for rep in range(nrep):
+            out = mapper(recs[0])
+            k = "%s%d_" % (tag, rep)
+            assert np.array_equal(out["image"].numpy(), d[k + "image"]), k
+            assert np.array_equal(out["proposals"].proposal_boxes.tensor.numpy(), d[k + "prop_boxes"]), k
+            assert np.array_equal(out["proposals"].objectness_logits.numpy(), d[k + "prop_logits"]), k
+            if is_train:
+                assert np.array_equal(out["instances"].gt_boxes.tensor.numpy(), d[k + "gt_boxes"]), k
+                assert np.array_equal(out["instances"].gt_classes.numpy(), d[k + "gt_classes"]), k
