@@ -470,6 +470,58 @@ def case_data(name, yaml_rel, opts, seed):
           len(d["train0_prop_boxes"]), len(d["test0_prop_boxes"]))
 
 
+sys.path.insert(0, os.path.join(HERE, ".."))
+from golden_util import voc_fixture  # noqa: E402  (shared with the tests)
+
+
+def case_voc_eval(name, seed):
+    """detectron2/evaluation/pascal_voc_evaluation.py: the text lines of PascalVOCDetectionEvaluator.process, then
+    voc_eval / voc_eval_corloc per class and IoU threshold, then the aggregation of evaluate()"""
+    import tempfile
+
+    import detectron2.evaluation.pascal_voc_evaluation as V
+
+    classes, annos, dets = voc_fixture(seed)
+    tmp = tempfile.mkdtemp()
+    os.makedirs(os.path.join(tmp, "Annotations"))
+    for iid, objs in annos.items():
+        body = "".join("<object><name>%s</name><pose>Unspecified</pose><truncated>0</truncated><difficult>%d</difficult>"
+                       "<bndbox><xmin>%d</xmin><ymin>%d</ymin><xmax>%d</xmax><ymax>%d</ymax></bndbox></object>"
+                       % (n, df, b[0], b[1], b[2], b[3]) for n, df, b in objs)
+        with open(os.path.join(tmp, "Annotations", iid + ".xml"), "w") as f:
+            f.write("<annotation><filename>%s.jpg</filename>%s</annotation>" % (iid, body))
+    with open(os.path.join(tmp, "test.txt"), "w") as f:
+        f.write("\n".join(annos.keys()) + "\n")
+    lines = {c: [] for c in range(len(classes))}
+    for c, iid, score, box in dets:  # PascalVOCDetectionEvaluator.process (:52-66)
+        xmin, ymin, xmax, ymax = np.array(box, dtype=np.float32)
+        xmin += 1
+        ymin += 1
+        lines[c].append(f"{iid} {score:.3f} {xmin:.1f} {ymin:.1f} {xmax:.1f} {ymax:.1f}")
+    d = {"seed": np.int64(seed)}
+    for year07 in (True, False):
+        aps, cls_ = {}, {}
+        for ci, cname in enumerate(classes):
+            with open(os.path.join(tmp, cname + ".txt"), "w") as f:
+                f.write("\n".join(lines[ci] or [""]))
+            for thr in range(50, 100, 5):
+                rec, prec, ap = V.voc_eval(os.path.join(tmp, "{}.txt"), os.path.join(tmp, "Annotations", "{}.xml"),
+                                           os.path.join(tmp, "test.txt"), cname, ovthresh=thr / 100.0,
+                                           use_07_metric=year07)
+                aps.setdefault(thr, []).append(ap * 100)
+                cl = V.voc_eval_corloc(os.path.join(tmp, "{}.txt"), os.path.join(tmp, "Annotations", "{}.xml"),
+                                       os.path.join(tmp, "test.txt"), cname, ovthresh=thr / 100.0, use_07_metric=year07)
+                cls_.setdefault(thr, []).append(cl * 100)
+                if thr == 50:
+                    d["rec_%d_%s" % (year07, cname)], d["prec_%d_%s" % (year07, cname)] = rec, prec
+        tag = "y07" if year07 else "y12"
+        d["ap_" + tag] = np.array([aps[t] for t in range(50, 100, 5)])
+        d["corloc_" + tag] = np.array([cls_[t] for t in range(50, 100, 5)])
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, "AP50 (07):", d["ap_y07"][0], "CorLoc50:", d["corloc_y07"][0])
+
+
 def c2_style_name(model_key):
     """inverse of the naming the released WSL checkpoints use (projects/WSL/tools/convert_resnet_ws_c2.py output, i.e.
     Caffe2 blob names with the stem renamed to stem_convN and fc6/fc7 to fc1/fc2); None for keys such files lack"""
@@ -542,7 +594,7 @@ def case_checkpoint(name, yaml_rel, opts):
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
-    which = sys.argv[1:] or ["ops", "heads", "r50dc5", "r50c4", "r50c4_align", "r18", "vgg", "r50c4_drop", "r50c4_reg", "tta", "ckpt", "data"]
+    which = sys.argv[1:] or ["ops", "heads", "r50dc5", "r50c4", "r50c4_align", "r18", "vgg", "r50c4_drop", "r50c4_reg", "tta", "ckpt", "data", "voc"]
     if "ops" in which:
         case_ops("ops", 11)
     if "heads" in which:
@@ -566,6 +618,8 @@ if __name__ == "__main__":
     if "r50c4_drop" in which:
         case_full_model("model_r50c4_dropmask_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 36,
                         1, 40, 96, 96, dropmask=True)
+    if "voc" in which:
+        case_voc_eval("voc_eval", 51)
     if "data" in which:
         case_data("data_mapper", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 41)
     if "ckpt" in which:

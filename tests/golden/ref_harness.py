@@ -29,8 +29,10 @@ AUTO_STUB = (
 # real reference modules that live under an auto-stubbed package (TTA golden: the reference's own resize / flip
 # transforms and its GeneralizedRCNNWithTTAAVG are imported for real; their parents stay stubs)
 REAL_UNDER_STUB = ("detectron2.data.transforms", "wsl.modeling.test_time_augmentation_avg", "detectron2.data.build",
-                   "detectron2.data.detection_utils", "detectron2.data.dataset_mapper")
-REAL_PATHS = {"detectron2.data": os.path.join(REF, "detectron2", "data")}
+                   "detectron2.data.detection_utils", "detectron2.data.dataset_mapper",
+                   "detectron2.evaluation.pascal_voc_evaluation")
+REAL_PATHS = {"detectron2.data": os.path.join(REF, "detectron2", "data"),
+              "detectron2.evaluation": os.path.join(REF, "detectron2", "evaluation")}
 
 
 class _Dummy:

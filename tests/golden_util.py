@@ -127,3 +127,26 @@ def drn_inputs(batch, with_gt=True):
             d["instances"] = inst
         out.append(d)
     return out
+
+
+def voc_fixture(seed, n_img=7, classes=("cat", "dog", "bus")):
+    """synthetic VOC-style ground truth + detections shared by the generator and the tests (deterministic)"""
+    rs = np.random.RandomState(seed)
+    annos, dets = {}, []
+    for i in range(n_img):
+        iid = "%06d" % (i + 1)
+        objs = []
+        for _ in range(rs.randint(0, 4)):
+            x0, y0 = rs.randint(1, 200), rs.randint(1, 150)
+            objs.append((classes[rs.randint(len(classes))], int(rs.rand() < 0.25),
+                         [int(x0), int(y0), int(x0 + rs.randint(20, 120)), int(y0 + rs.randint(20, 100))]))
+        annos[iid] = objs
+        for name, diff, bb in objs:  # detections near the objects (some good, some shifted, some duplicated)
+            for _ in range(rs.randint(0, 3)):
+                j = rs.randn(4) * rs.choice([2.0, 25.0])
+                dets.append((classes.index(name) if rs.rand() < 0.85 else rs.randint(len(classes)), iid,
+                             float(rs.rand()), [bb[0] - 1 + j[0], bb[1] - 1 + j[1], bb[2] + j[2], bb[3] + j[3]]))
+        for _ in range(rs.randint(0, 3)):  # pure false positives
+            x0, y0 = rs.rand() * 200, rs.rand() * 150
+            dets.append((rs.randint(len(classes)), iid, float(rs.rand()), [x0, y0, x0 + 50, y0 + 40]))
+    return list(classes), annos, dets

@@ -602,3 +602,36 @@ def test_dataset_mapper_output_trains(tmp_path):
     out = model([D.DatasetMapper(cfg, False)(recs[0])])
     assert len(out) == 1 and len(out[0]["instances"]) <= cfg.TEST.DETECTIONS_PER_IMAGE
     load_package().set_precision("fp32")
+
+
+def test_tta_outputs_feed_voc_evaluator():
+    """detector (with TTA) -> PascalVOCDetectionEvaluator: CUDA Instances go straight into process(); evaluate() returns
+    the reference's result layout (bbox AP/AP50/AP75 + CorLoc)"""
+    from drn_wsod_pytorch_amd.evaluation import PascalVOCDetectionEvaluator
+    from drn_wsod_pytorch_amd.modeling import GeneralizedRCNNWithTTAAVG
+    from drn_wsod_pytorch_amd.structures import Boxes, Instances
+
+    d = G.load("tta_r50c4_tiny")
+    ocfg = G.MODEL_CASES["model_r50c4_tiny"]
+    cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, "fp32")
+    cfg.merge_from_list(["TEST.AUG.MIN_SIZES", "(48, 72)", "TEST.AUG.MAX_SIZE", "96", "TEST.AUG.FLIP", "True",
+                         "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST", "40"])
+    model.eval()
+    img = torch.from_numpy(d["image_u8"])
+    H, W = img.shape[1:]
+    prop = Instances((H, W))
+    prop.proposal_boxes = Boxes(torch.from_numpy(d["proposal_boxes"]))
+    prop.objectness_logits = torch.from_numpy(d["objectness_logits"])
+    inp = {"image": img, "proposals": prop, "height": H, "width": W, "image_id": "000001"}
+    out = GeneralizedRCNNWithTTAAVG(cfg, model)([inp])
+    names = ["c%d" % i for i in range(ocfg.num_classes)]
+    top = out[0]["instances"]
+    k = int(top.pred_classes[0])
+    gt_box = [int(v) for v in (top.pred_boxes.tensor[0].cpu() + torch.tensor([1.0, 1.0, 0.0, 0.0])).round().tolist()]
+    ev = PascalVOCDetectionEvaluator(names, annotations={"000001": [(names[k], 0, gt_box)]}, year=2007)
+    ev.process([inp], out)
+    res = ev.evaluate()
+    assert set(res["bbox"]) == {"AP", "AP50", "AP75"} and set(res["bbox CorLoc"]) == {"CL", "CL50", "CL75"}
+    assert res["per_class"]["CL50"][names[k]] == 100.0  # the top detection of that class is the annotated object
+    assert res["per_class"]["AP50"][names[k]] > 0
+    load_package().set_precision("fp32")

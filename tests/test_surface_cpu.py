@@ -267,3 +267,53 @@ def test_data_path_matches_reference_golden(tmp_path):
             if is_train:
                 assert np.array_equal(out["instances"].gt_boxes.tensor.numpy(), d[k + "gt_boxes"]), k
                 assert np.array_equal(out["instances"].gt_classes.numpy(), d[k + "gt_classes"]), k
+
+
+def test_voc_evaluation_matches_reference_golden():
+    """evaluation.py vs the reference's voc_eval / voc_eval_corloc on the shared synthetic VOC fixture: recall and
+    precision curves, AP (VOC07 11-point and area) and CorLoc for every class and IoU threshold, and the evaluator's
+    aggregated dict through process() / evaluate()"""
+    import numpy as np
+    import torch
+
+    import golden_util as G
+    from __graft_entry__ import load_package
+
+    load_package()
+    from drn_wsod_pytorch_amd import evaluation as E
+    from drn_wsod_pytorch_amd.structures import Boxes, Instances
+
+    d = G.load("voc_eval")
+    classes, annos, dets = G.voc_fixture(int(d["seed"]))
+    lines = {c: [] for c in range(len(classes))}
+    for c, iid, score, box in dets:
+        lines[c].append(E.format_prediction(iid, score, np.array(box, dtype=np.float32)))
+    for year07, tag in ((True, "y07"), (False, "y12")):
+        for ci, name in enumerate(classes):
+            for ti, thr in enumerate(range(50, 100, 5)):
+                ln = lines[ci] or [""]
+                if lines[ci]:
+                    rec, prec, ap = E.voc_eval(lines[ci], annos, name, thr / 100.0, year07)
+                    assert abs(ap * 100 - d["ap_" + tag][ti, ci]) < 1e-9, (tag, name, thr)
+                    if thr == 50:
+                        assert np.array_equal(rec, d["rec_%d_%s" % (year07, name)])
+                        assert np.array_equal(prec, d["prec_%d_%s" % (year07, name)])
+                    cl = E.voc_eval_corloc(lines[ci], annos, name, thr / 100.0, year07)
+                    assert abs(cl * 100 - d["corloc_" + tag][ti, ci]) < 1e-9, (tag, name, thr)
+    # the evaluator object: same numbers through Instances
+    ev = E.PascalVOCDetectionEvaluator(classes, annotations=annos, year=2007)
+    by_img = {}
+    for c, iid, score, box in dets:
+        by_img.setdefault(iid, []).append((c, score, box))
+    for iid, items in by_img.items():
+        inst = Instances((300, 300))
+        inst.pred_boxes = Boxes(torch.tensor([b for _, _, b in items], dtype=torch.float32))
+        inst.scores = torch.tensor([s for _, s, _ in items], dtype=torch.float64)
+        inst.pred_classes = torch.tensor([c for c, _, _ in items])
+        ev.process([{"image_id": iid}], [{"instances": inst}])
+    res = ev.evaluate()
+    has = [ci for ci in range(len(classes)) if lines[ci]]
+    ap50 = [d["ap_y07"][0, ci] if ci in has else 0.0 for ci in range(len(classes))]
+    assert abs(res["bbox"]["AP50"] - np.mean(ap50)) < 1e-9
+    cl50 = [d["corloc_y07"][0, ci] for ci in range(len(classes))]
+    assert abs(res["bbox CorLoc"]["CL50"] - np.mean(cl50)) < 1e-9
