@@ -370,10 +370,22 @@ class DataParallel:
         self._pending = []
 
     def broadcast_parameters(self, src=0):
-        if self.world > 1:
-            self.engine.ensure(next(self.model.roi_heads.parameters()).device)
-            dist.broadcast(self.engine.arena_w, src, group=self.group)
-            self.engine.mark_dirty()
+        """DistributedDataParallel's construction-time sync (detectron2/engine/defaults.py:279-282): every parameter AND
+        buffer of the module comes from rank `src` - the head arena in one piece, then the trunk's weights and FrozenBN
+        statistics (they never change afterwards when frozen, but the ranks must start from the same ones)."""
+        if not self.exchange:
+            return
+        self.engine.ensure(next(self.model.roi_heads.parameters()).device)
+        dist.broadcast(self.engine.arena_w, src, group=self.group)
+        lo = self.engine.arena_w.data_ptr()
+        hi = lo + self.engine.arena_w.numel() * 4
+        with torch.no_grad():
+            for t in list(self.model.parameters()) + list(self.model.buffers()):
+                if lo <= t.data_ptr() < hi:
+                    continue  # lives in the arena: already done
+                dist.broadcast(t.data, src, group=self.group)
+                t.data.add_(0)  # in-place touch: bumps the version counter the packed conv copies are keyed on
+        self.engine.mark_dirty()
 
     def _reduce(self, t):
         if self._use_stream and t.is_cuda:
