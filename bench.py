@@ -227,6 +227,10 @@ def main():
     ap.add_argument("--tail", choices=["auto", "graph", "eager"], default="auto",
                     help="fc6 dW + optimizer tail of the graphed step: inside the captured graph, or issued eagerly "
                          "behind it (default, measured +1.3%%; always eager when gradients are exchanged)")
+    ap.add_argument("--backend", choices=["nccl", "gloo"], default="nccl",
+                    help='torch.distributed backend ("nccl" = RCCL); gloo + --single-device runs N ranks on ONE GPU to '
+                         "exercise the N>1 flow of this script where only one GPU is available (not a measurement)")
+    ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (with --backend gloo)")
     ap.add_argument("--comm-dtype", choices=["bf16", "fp32"], default=None,
                     help="dtype of the fc6 weight-gradient buckets (HBM and xGMI); default bf16 = the compute dtype, the "
                          "rounding torch.autocast(bf16) applies to a Linear's weight gradient")
@@ -238,12 +242,14 @@ def main():
     assert world == args.gpus, "launch with --nproc-per-node equal to --gpus (WORLD_SIZE=%d, --gpus=%d)" % (world, args.gpus)
     import torch.distributed as dist
 
+    if args.single_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     if world > 1 or args.force_exchange:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
+        dist.init_process_group(args.backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
     torch.manual_seed(1234 + rank)  # detectron2/engine/defaults.py:147: SEED + rank (per-rank dropout streams)
     pkg = load_package()
