@@ -69,8 +69,9 @@ def _worker(rank, world, port, q):
         dp.finish()
         assert torch.equal(model._bb_grad_arena, torch.arange(37, dtype=torch.float32) * 3.0)
         del model._bb_grad_arena
-        # the pipelined optimizer's own exchange (what the N>1 bench step uses): small bucket in fp32 from the arena,
-        # fc6 row slabs from the bf16 exchange buffer the dW GEMM writes into
+        # the pipelined optimizer's own exchange (what the N>1 bench step uses): in bf16 mode the small bucket is cast
+        # into a bf16 wire buffer (the fp32 arena keeps the local gradient), the fc6 row slabs come from the bf16
+        # exchange buffer the dW GEMM writes into
         from drn_wsod_pytorch_amd.engine import build_optimizer
 
         opt = build_optimizer(G.drn_cfg(G.MODEL_CASES["model_r50c4_tiny"], "cpu"), model)
@@ -79,14 +80,20 @@ def _worker(rank, world, port, q):
         e.arena_g.copy_(base * (rank + 1))
         vals = (torch.arange(d1 * k1, dtype=torch.float32).view(d1, k1) % 61) * 0.25  # exactly representable in bf16
         e.fc1_grad_bucket.copy_((vals * (rank + 1)).to(torch.bfloat16))
-        assert opt._exchange("small") is None
+        small = opt._exchange("small")
+        assert small is opt._small_bucket and small.dtype == torch.bfloat16 and small.numel() == o_fc1
         r0 = 0
         for r1 in opt._slab_ends:
             assert opt._exchange(("fc1", r0, r1)) is e.fc1_grad_bucket
             r0 = r1
-        assert torch.allclose(e.arena_g[:o_fc1], exp[:o_fc1])
+        assert torch.allclose(small.float(), exp[:o_fc1], rtol=2.0 ** -7, atol=0)  # two bf16 roundings + a bf16 sum
+        assert torch.equal(e.arena_g[:o_fc1], base[:o_fc1] * (rank + 1))  # local fp32 gradient untouched
         assert torch.equal(e.arena_g[o_fc1: o_fc1 + c_fc1], base[o_fc1: o_fc1 + c_fc1] * (rank + 1))  # arena fc6 slot unused
         assert torch.equal(e.fc1_grad_bucket.float(), vals * 3.0)
+        # fp32 wire: the small bucket is reduced in place in the arena
+        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.float32)
+        assert opt._exchange("small") is None
+        assert torch.allclose(e.arena_g[:o_fc1], exp[:o_fc1])
         q.put((rank, "ok"))
     except Exception as ex:  # noqa: BLE001
         q.put((rank, "FAIL: %r" % (ex,)))

