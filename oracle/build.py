@@ -6,6 +6,8 @@
                    together with oracle/ref_binding.cpp (a 20-line pybind shim of ours) into
                    oracle/_ref/d2_roialign_ref*.so.  Outputs only go to oracle/_ref/ (git-ignored,
                    NOT gpurun-ignored, so the built .so travels to the GPU box).
+`build_ref_pcl()`  same for projects/WSL/wsl/layers/csrc/pcl_loss/pcl_loss_cpu.cpp + oracle/ref_pcl_binding.cpp
+                   -> oracle/_ref/wsl_pcl_ref.so (the reference's PCL loss, which it always runs on the CPU).
 """
 import os
 import subprocess
@@ -17,6 +19,10 @@ REF_DIR = os.path.join(HERE, "_ref")
 ORACLE_SO = os.path.join(BUILD_DIR, "liboracle_roi.so")
 REF_SRC = "/root/reference/detectron2/layers/csrc/ROIAlign/ROIAlign_cpu.cpp"
 REF_INC = "/root/reference/detectron2/layers/csrc"
+
+
+PCL_SRC = "/root/reference/projects/WSL/wsl/layers/csrc/pcl_loss/pcl_loss_cpu.cpp"
+PCL_INC = "/root/reference/projects/WSL/wsl/layers/csrc"
 
 
 def _newer(src, dst):
@@ -43,6 +49,23 @@ def ref_so_path():
     return None
 
 
+def _compile_torch_ext(name, src, shim, inc_dir, out):
+    import torch
+    from torch.utils import cpp_extension as ce
+    import sysconfig
+
+    inc = ce.include_paths() + [sysconfig.get_paths()["include"], inc_dir]
+    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
+    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-w", "-DTORCH_EXTENSION_NAME=" + name,
+           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
+    for i in inc:
+        cmd += ["-I", i]
+    cmd += [src, shim, "-o", out, "-L", libdir, "-Wl,-rpath," + libdir,
+            "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"]
+    subprocess.check_call(cmd)
+    return out
+
+
 def build_ref(force=False):
     """Compile the reference ROIAlign CPU source in place -> oracle/_ref/. Returns path or None."""
     if not os.path.exists(REF_SRC):
@@ -52,23 +75,22 @@ def build_ref(force=False):
     if existing and not force and not _newer(shim, existing):
         return existing
     os.makedirs(REF_DIR, exist_ok=True)
-    import torch
-    from torch.utils import cpp_extension as ce
-    import sysconfig
+    return _compile_torch_ext("d2_roialign_ref", REF_SRC, shim, REF_INC, os.path.join(REF_DIR, "d2_roialign_ref.so"))
 
-    out = os.path.join(REF_DIR, "d2_roialign_ref.so")
-    inc = ce.include_paths() + [sysconfig.get_paths()["include"], REF_INC]
-    libdir = os.path.join(os.path.dirname(torch.__file__), "lib")
-    cmd = ["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DTORCH_EXTENSION_NAME=d2_roialign_ref",
-           "-DTORCH_API_INCLUDE_EXTENSION_H", "-D_GLIBCXX_USE_CXX11_ABI=%d" % int(torch._C._GLIBCXX_USE_CXX11_ABI)]
-    for i in inc:
-        cmd += ["-I", i]
-    cmd += [REF_SRC, shim, "-o", out, "-L", libdir, "-Wl,-rpath," + libdir,
-            "-ltorch", "-ltorch_cpu", "-lc10", "-ltorch_python"]
-    subprocess.check_call(cmd)
-    return out
+
+def build_ref_pcl(force=False):
+    """Compile the reference PCL loss (CPU) in place -> oracle/_ref/wsl_pcl_ref.so. Returns path or None."""
+    out = os.path.join(REF_DIR, "wsl_pcl_ref.so")
+    if not os.path.exists(PCL_SRC):
+        return out if os.path.exists(out) else None
+    shim = os.path.join(HERE, "ref_pcl_binding.cpp")
+    if os.path.exists(out) and not force and not _newer(shim, out):
+        return out
+    os.makedirs(REF_DIR, exist_ok=True)
+    return _compile_torch_ext("wsl_pcl_ref", PCL_SRC, shim, PCL_INC, out)
 
 
 if __name__ == "__main__":
     print(build_oracle(force="--force" in sys.argv))
     print(build_ref(force="--force" in sys.argv))
+    print(build_ref_pcl(force="--force" in sys.argv))

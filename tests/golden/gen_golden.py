@@ -185,6 +185,105 @@ def case_full_model(name, yaml_rel, opts, seed, n_img, R, H, W, dropmask=False, 
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: v for k, v in d.items() if k.startswith("step")})
 
 
+def case_pcl_unit(name, seed, n_try=40):
+    """PCL targets and loss, op level: the reference's own PCL() (third_party/pcl.py, with the scikit-learn installed
+    here) and its pcl_loss_cpu.cpp (compiled in place).  Two steps of PCL() are not functions of their inputs
+    (oracle/pcl_oracle.py header: sklearn's seeded k-means, numpy's unstable argsort on ties); cases where the
+    reference's draw differs from the restated definition are counted and dropped, the rest are the golden."""
+    import sklearn
+    from oracle import pcl_oracle as PO
+    from wsl.modeling.roi_heads.third_party import pcl as ref_pcl
+    import wsl._C as wsl_c
+
+    rs = np.random.RandomState(seed)
+    d = {"sklearn": np.array(sklearn.__version__), "numpy": np.array(np.__version__)}
+    kept = n_km_diff = n_other_diff = 0
+    for t in range(n_try):
+        R = int(rs.choice([24, 60, 150, 400]))
+        K = int(rs.choice([4, 20]))
+        W, H = 200.0, 160.0
+        # clustered boxes (jittered copies of a few seeds) so that the IoU graph has real cliques
+        nseed = max(3, R // 12)
+        sx0 = rs.rand(nseed) * (W - 60)
+        sy0 = rs.rand(nseed) * (H - 60)
+        sw = 30 + rs.rand(nseed) * (W - sx0 - 30)
+        sh = 30 + rs.rand(nseed) * (H - sy0 - 30)
+        pick = rs.randint(0, nseed, size=R)
+        jit = rs.randn(R, 4) * 6.0
+        x0 = np.clip(sx0[pick] + jit[:, 0], 0, W - 21)
+        y0 = np.clip(sy0[pick] + jit[:, 1], 0, H - 21)
+        x1 = np.clip(sx0[pick] + sw[pick] + jit[:, 2], x0 + 20, W)
+        y1 = np.clip(sy0[pick] + sh[pick] + jit[:, 3], y0 + 20, H)
+        boxes = np.stack([x0, y0, x1, y1], 1).astype(np.float32)
+        G = int(rs.randint(1, 4))
+        im_labels = np.zeros((1, K), dtype=np.float32)
+        im_labels[0, rs.permutation(K)[:G]] = 1
+        first = (t % 2 == 0)
+        if first:  # WSDDN-shaped scores [R, K]: softmax over classes x softmax over proposals
+            a = torch.from_numpy(rs.randn(R, K).astype(np.float32) * 2.0)
+            b = torch.from_numpy(rs.randn(R, K).astype(np.float32) * 3.0)
+            last = (torch.softmax(a, 1) * torch.softmax(b, 0)).numpy()
+        else:  # a previous refinement's softmax [R, K+1]
+            last = torch.softmax(torch.from_numpy(rs.randn(R, K + 1).astype(np.float32) * 3.0), 1).numpy()
+        logits = rs.randn(R, K + 1).astype(np.float32) * 2.0
+        probs = torch.softmax(torch.from_numpy(logits), 1)
+        ref = ref_pcl.PCL(boxes.copy(), torch.from_numpy(last.copy()), im_labels.copy(), probs.clone())
+        mine = PO.pcl_targets(boxes, last, im_labels[0], probs.numpy())
+        def same_as_ref(m):
+            return (np.array_equal(ref["labels"][0], m["labels"].astype(np.float32)) and
+                    np.array_equal(ref["gt_assignment"][0], m["gt_assignment"].astype(np.float32)) and
+                    np.array_equal(ref["pc_labels"][0], m["pc_labels"].astype(np.float32)) and
+                    np.array_equal(ref["pc_count"][0], m["pc_count"].astype(np.float32)) and
+                    np.array_equal(ref["cls_loss_weights"][0], m["cls_loss_weights"]))
+
+        if not same_as_ref(mine):
+            # classify the difference by substituting the two non-functional steps with what THIS machine's numpy and
+            # scikit-learn do: with both substituted the restatement must reproduce the reference on every case
+            keep_pick, keep_km = PO._argmax_last, PO.kmeans_top_threshold
+            try:
+                PO._argmax_last = lambda x: int(np.asarray(x, dtype=np.float32).argsort()[::-1][0])
+                tie_only = same_as_ref(PO.pcl_targets(boxes, last, im_labels[0], probs.numpy()))
+                PO.kmeans_top_threshold = lambda v: v[ref_pcl._get_top_ranking_propoals(
+                    np.asarray(v).reshape(-1, 1).copy())].min()
+                both = same_as_ref(PO.pcl_targets(boxes, last, im_labels[0], probs.numpy()))
+            finally:
+                PO._argmax_last, PO.kmeans_top_threshold = keep_pick, keep_km
+            assert both, "restatement differs from the reference beyond k-means draws / tie order (case %d)" % t
+            if tie_only:
+                n_other_diff += 1
+            else:
+                n_km_diff += 1
+            continue
+        # loss + gradient from the reference's C++
+        tt = {k: torch.from_numpy(v) for k, v in ref.items()}
+        out = torch.zeros(1, K + 1)
+        pp = probs.clone()
+        wsl_c.pcl_loss_forward(pp, tt["labels"], tt["cls_loss_weights"], tt["pc_labels"], tt["pc_probs"],
+                               tt["img_cls_loss_weights"], tt["im_labels_real"], out)
+        loss = out.sum() / R  # pcl_loss.py:51
+        gin = torch.zeros(R, K + 1)
+        wsl_c.pcl_loss_backward(pp, tt["labels"], tt["cls_loss_weights"], tt["gt_assignment"], tt["pc_labels"],
+                                tt["pc_probs"], tt["pc_count"], tt["img_cls_loss_weights"], tt["im_labels_real"],
+                                torch.ones(()), gin)
+        gin /= R  # pcl_loss.py:89
+        pre = "c%d_" % kept
+        d[pre + "boxes"], d[pre + "last"], d[pre + "im_labels"], d[pre + "logits"] = boxes, last, im_labels[0], logits
+        for k in ("labels", "cls_loss_weights", "gt_assignment", "pc_labels", "pc_probs", "pc_count",
+                  "img_cls_loss_weights"):
+            d[pre + k] = ref[k][0]
+        d[pre + "loss"] = np.float32(loss.item())
+        d[pre + "dprobs"] = gin.numpy()
+        kept += 1
+    d["n_cases"] = np.int64(kept)
+    d["n_tried"] = np.int64(n_try)
+    d["n_kmeans_draw_differs"] = np.int64(n_km_diff)
+    d["n_tie_order_differs"] = np.int64(n_other_diff)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB; kept", kept, "of", n_try, "| sklearn draw differs:",
+          n_km_diff, "| other (tie order):", n_other_diff)
+
+
 def case_heads_detail(name, seed, K=4, R=40, n_img=2):
     """OICRROIHeads through explicit kwargs (every class is @configurable): op-level intermediates —
     WSDDN scores, pgt indices incl. a forced TIE, labels, per-refinement losses, grads wrt logits."""
@@ -618,6 +717,8 @@ if __name__ == "__main__":
     if "r50c4_drop" in which:
         case_full_model("model_r50c4_dropmask_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 36,
                         1, 40, 96, 96, dropmask=True)
+    if "pcl" in which:
+        case_pcl_unit("pcl_unit", 61)
     if "voc" in which:
         case_voc_eval("voc_eval", 51)
     if "data" in which:

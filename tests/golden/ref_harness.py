@@ -127,6 +127,14 @@ def install():
     import detectron2
 
     detectron2._C = refmod
+    # wsl._C stays an auto-stub except for the PCL loss: the reference's pcl_loss_cpu.cpp compiled in place
+    spec = importlib.util.spec_from_file_location("wsl_pcl_ref", ob.build_ref_pcl())
+    pclmod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(pclmod)
+    import wsl._C as wsl_c
+
+    wsl_c.pcl_loss_forward = pclmod.pcl_loss_forward
+    wsl_c.pcl_loss_backward = pclmod.pcl_loss_backward
     import wsl.modeling  # noqa: F401
     import wsl.modeling.meta_arch  # noqa: F401
 

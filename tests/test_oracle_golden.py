@@ -361,3 +361,74 @@ def test_tta_golden():
     assert np.array_equal(c.numpy(), d["det_classes"])
     assert np.allclose(s.numpy(), d["det_scores"], rtol=1e-5, atol=1e-7)
     assert np.allclose(b.numpy(), d["det_boxes"], rtol=1e-6, atol=1e-4)
+
+
+def test_pcl_targets_and_loss_golden():
+    """PCL: oracle/pcl_oracle.py against the reference's own PCL() (third_party/pcl.py) and its
+    pcl_loss_cpu.cpp, on the golden cases where the reference's scikit-learn draw and numpy tie order coincide with
+    the restated definitions (the generator counts the others; see the oracle's header)."""
+    from oracle import pcl_oracle as PO
+
+    d = G.load("pcl_unit")
+    n = int(d["n_cases"])
+    assert n >= 20 and n + int(d["n_kmeans_draw_differs"]) + int(d["n_tie_order_differs"]) == int(d["n_tried"])
+    for i in range(n):
+        g = lambda k: d["c%d_%s" % (i, k)]
+        loss, dl, probs, t = PO.pcl_refine_loss(g("logits"), g("boxes"), g("last"), g("im_labels"))
+        # integer / index outputs: bit-exact
+        assert np.array_equal(t["labels"].astype(np.float32), g("labels")), i
+        assert np.array_equal(t["gt_assignment"].astype(np.float32), g("gt_assignment")), i
+        assert np.array_equal(t["pc_labels"].astype(np.float32), g("pc_labels")), i
+        assert np.array_equal(t["pc_count"].astype(np.float32), g("pc_count")), i
+        assert np.array_equal(t["cls_loss_weights"], g("cls_loss_weights")), i  # gathered values: exact
+        np.testing.assert_allclose(t["pc_probs"], g("pc_probs"), rtol=1e-6)
+        np.testing.assert_allclose(t["img_cls_loss_weights"], g("img_cls_loss_weights"), rtol=1e-6)
+        assert abs(float(loss) - float(g("loss"))) <= 1e-5 * max(1.0, abs(float(g("loss")))), i
+        gp = PO.pcl_loss_backward(probs, t, g("im_labels"))
+        np.testing.assert_allclose(gp, g("dprobs"), rtol=1e-5, atol=1e-9)
+
+
+def test_pcl_kmeans_exact_optimum_bruteforce():
+    """the k-means restatement is the global optimum: brute force over all cut pairs on small inputs, incl. duplicates,
+    fewer distinct values than clusters, n < 3"""
+    from oracle import pcl_oracle as PO
+
+    rs = np.random.RandomState(5)
+    for n in (1, 2, 3, 4, 7, 12, 30):
+        for rep in range(6):
+            v = (rs.rand(n) ** 3).astype(np.float32)
+            if rep % 3 == 1:
+                v = np.round(v * 4) / 4  # many duplicates
+            if rep % 3 == 2:
+                v[:] = v[0]
+            thr = PO.kmeans_top_threshold(v)
+            s = np.sort(v).astype(np.float64)
+            cuts = [c for c in range(1, n) if s[c - 1] < s[c]]
+            k = min(3, n, len(cuts) + 1)
+
+            def sse(a, b):
+                return ((s[a:b] - s[a:b].mean()) ** 2).sum()
+
+            if k == 1:
+                assert thr == s[0]
+                continue
+            best = None
+            if k == 2:
+                for c in cuts:
+                    e = sse(0, c) + sse(c, n)
+                    if best is None or e < best[0] - 1e-15:
+                        best = (e, c)
+            else:
+                for i, c1 in enumerate(cuts):
+                    for c2 in cuts[i + 1:]:
+                        e = sse(0, c1) + sse(c1, c2) + sse(c2, n)
+                        if best is None or e < best[0] - 1e-15:
+                            best = (e, c2)
+            top = int((v >= thr).sum())
+            # same objective value (cut positions may differ only on exact ties of the objective)
+            c_my = n - top
+            if k == 2:
+                e_my = sse(0, c_my) + sse(c_my, n)
+            else:
+                e_my = min(sse(0, c1) + sse(c1, c_my) + sse(c_my, n) for c1 in cuts if c1 < c_my)
+            assert e_my <= best[0] + 1e-12, (n, rep)
