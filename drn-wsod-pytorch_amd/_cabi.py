@@ -20,6 +20,8 @@ _SIGS = {
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
     "drn_tta_accumulate": "ppppllfffiip",
+    "drn_pcl_adjacency": "pifpp",
+    "drn_pcl_refine": "pipiipipppip" + "ppppppppppi" + "ppp",
     "drn_im2col_t": "pp" + "iiiiiiiiii" + "lip",
     "drn_maxpool2x2_bwd_nhwc": "pppiiiiiip",
     "drn_add": "ppplip",

@@ -356,3 +356,41 @@ def tta_accumulate(boxes, scores, acc_boxes, acc_scores, sx, sy, flip_w, first, 
     assert acc_boxes.shape == boxes.shape and acc_scores.shape == scores.shape
     C.call("drn_tta_accumulate", C.ptr(boxes), C.ptr(scores), C.ptr(acc_boxes), C.ptr(acc_scores), boxes.numel() // 4,
            scores.numel(), float(sx), float(sy), float(flip_w), int(first), int(n_final), C.stream())
+
+
+def pcl_adjacency(boxes, iou_thr=0.4):
+    """[R, ceil(R/32)] uint32 bit matrix of IoU(boxes, boxes) > iou_thr (third_party/pcl.py:78-87)"""
+    R = boxes.shape[0]
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous()
+    adj = torch.empty((R, (R + 31) // 32), dtype=torch.int32, device=boxes.device)
+    C.call("drn_pcl_adjacency", C.ptr(boxes), R, float(iou_thr), C.ptr(adj), C.stream())
+    return adj
+
+
+def pcl_refine(logits, col0s, K, wsddn_scores, boxes, adj, onehot, dlogits):
+    """PCL targets + loss + d loss / d logits of every refinement branch of ONE image (see include/drn_wsod.h).
+    Returns a list of per-branch dicts (targets, clusters, probs, loss view)."""
+    R, dev, nb = boxes.shape[0], boxes.device, len(col0s)
+    pmax = min(640, 5 * K)
+    e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+    probs = e((nb, R, K + 1), torch.float32)
+    row = dict(labels=e((nb, R), torch.int32), cls_loss_weights=e((nb, R), torch.float32),
+               gt_assignment=e((nb, R), torch.int32))
+    pc = dict(pc_labels=e((nb, pmax), torch.int32), pc_probs=e((nb, pmax), torch.float32),
+              pc_count=e((nb, pmax), torch.int32), img_cls_loss_weights=e((nb, pmax), torch.float32),
+              pc_rows=e((nb, pmax), torch.int32), pc_scores=e((nb, pmax), torch.float32))
+    n_pc = e((nb,), torch.int32)
+    losses = e((nb,), torch.float32)
+    c0 = C.host_ints(col0s)
+    C.call("drn_pcl_refine", C.ptr(logits), _2d(logits), ctypes.cast(c0, ctypes.c_void_p), nb, K, C.ptr(wsddn_scores),
+           _2d(wsddn_scores), C.ptr(boxes), C.ptr(adj), C.ptr(onehot), R, C.ptr(probs),
+           C.ptr(row["labels"]), C.ptr(row["cls_loss_weights"]), C.ptr(row["gt_assignment"]), C.ptr(pc["pc_labels"]),
+           C.ptr(pc["pc_probs"]), C.ptr(pc["pc_count"]), C.ptr(pc["img_cls_loss_weights"]), C.ptr(pc["pc_rows"]),
+           C.ptr(pc["pc_scores"]), C.ptr(n_pc), pmax, C.ptr(losses), C.ptr(dlogits), C.stream())
+    out = []
+    for b in range(nb):
+        d = {k: v[b] for k, v in row.items()}
+        d.update({k: v[b] for k, v in pc.items()})
+        d.update(n_pc=n_pc[b: b + 1], probs=probs[b], loss=losses[b: b + 1])
+        out.append(d)
+    return out

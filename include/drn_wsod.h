@@ -230,6 +230,32 @@ int drn_detect_gather(const void* workspace, long workspace_bytes, int cap, cons
 int drn_tta_accumulate(const float* boxes, const float* scores, float* acc_boxes, float* acc_scores, long n_boxes,
                        long n_scores, float sx, float sy, float flip_w, int first, int n_final, void* stream);
 
+/* ---- PCL refinement (PCLROIHeads) ------------------------------------------------------------------
+ * The reference computes these on the HOST: the targets in numpy + scikit-learn after a device->host copy of the scores
+ * (projects/WSL/wsl/modeling/roi_heads/third_party/pcl.py:26-200, called from fast_rcnn.py:1725-1745), the loss in C++ on
+ * the CPU (projects/WSL/wsl/layers/csrc/pcl_loss/pcl_loss.h:52-131 always dispatches to pcl_loss_cpu.cpp:8-117).  One
+ * image per call (the reference asserts a batch of one, pcl.py:94,149); R <= 4096, K <= 128.
+ *
+ * drn_pcl_adjacency: `_build_graph` (pcl.py:78-87): bit r2 of word adj[r1][r2/32] = IoU(box r1, box r2) > iou_thr
+ * (pairwise_iou, detectron2/structures/boxes.py:329-361).  adj: [R, ceil(R/32)] uint32.  Shared by every branch. */
+int drn_pcl_adjacency(const float* boxes, int R, float iou_thr, uint32_t* adj, void* stream);
+
+/* drn_pcl_refine: every refinement branch b < n_branch in one call.  logits [R, ld] fp32 holds branch b's K+1 columns
+ * at cols[b] (host array; column 0 of a branch = background, class c at 1 + c - the PCL convention).  Branch 0 clusters
+ * on wsddn_scores [R, ld_ws] (class c at column c), branch b > 0 on the softmax of branch b-1 (roi_heads_pcl.py:321-334).
+ * onehot [K]: image-level labels.  Writes: probs [n_branch, R, K+1] (row softmax, fast_rcnn.py:1561-1575);
+ * labels / cls_w / assign [n_branch, R] (pcl.py:166-181; assign = -1 for background rows); the proposal clusters
+ * pc_labels / pc_probs / pc_count / img_w / pc_rows (row of the centre box) / pc_scores [n_branch, pmax] with their
+ * number in n_pc [n_branch] (pmax >= 5 * labelled classes, <= 640); losses [n_branch] = pcl_loss forward summed over
+ * classes / R (pcl_loss.py:51); dlogits [R, ld] at the same columns = d loss / d logits (pcl_loss_cpu.cpp:60-115 through
+ * the softmax).  k-means and equal-degree ties follow the fixed definitions of oracle/pcl_oracle.py (the reference's
+ * scikit-learn draw / numpy sort order are not functions of the inputs). */
+int drn_pcl_refine(const float* logits, int ld, const int* cols, int n_branch, int K, const float* wsddn_scores,
+                   int ld_ws, const float* boxes, const uint32_t* adj, const float* onehot, int R, float* probs,
+                   int* labels, float* cls_w, int* assign, int* pc_labels, float* pc_probs, int* pc_count,
+                   float* img_w, int* pc_rows, float* pc_scores, int* n_pc, int pmax, float* losses, float* dlogits,
+                   void* stream);
+
 #ifdef __cplusplus
 }
 #endif
