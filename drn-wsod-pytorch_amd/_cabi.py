@@ -38,7 +38,7 @@ _SIGS = {
     "drn_oicr_targets": "plpii" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",
     "drn_oicr_refine_chain": "plpiipl" + "ppipp" + "ip" + "ppi" + "ppppppp" + "plpp" + "ifp",
     "drn_softmax_ce": "pliipppplppifp",
-    "drn_mean_softmax": "plpiipip",
+    "drn_mean_softmax": "plpiipiip",
     "drn_box_reg_loss": "pliippppplppifp",
     "drn_apply_deltas": "plppiipfp",
     "drn_sum_small": "pifpp",

@@ -550,8 +550,10 @@ __global__ __launch_bounds__(256) void boxreg_grad_kernel(BoxRegParams p, const 
 }
 
 // mean over n_heads of row softmaxes (fast_rcnn.py:1577-1594)
+// bg_first: the heads keep the background in column 0 (PCL); the output is rotated so that it is the last column
+// (OICROutputLayers.inference pcl_bg, fast_rcnn.py:1463-1465)
 __global__ void mean_softmax_kernel(const float* logits, long ld, const int* col0s, int n_heads, int C, float* probs,
-                                    int M) {
+                                    int M, int bg_first) {
   const int r = blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= M) return;
   for (int c = 0; c < C; ++c) probs[(long)r * C + c] = 0.f;
@@ -561,7 +563,10 @@ __global__ void mean_softmax_kernel(const float* logits, long ld, const int* col
     for (int c = 0; c < C; ++c) mx = fmaxf(mx, row[c]);
     float se = 0.f;
     for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
-    for (int c = 0; c < C; ++c) probs[(long)r * C + c] += expf(row[c] - mx) / se;
+    for (int c = 0; c < C; ++c) {
+      const int oc = bg_first ? (c == 0 ? C - 1 : c - 1) : c;
+      probs[(long)r * C + oc] += expf(row[c] - mx) / se;
+    }
   }
   for (int c = 0; c < C; ++c) probs[(long)r * C + c] = probs[(long)r * C + c] / (float)n_heads;
 }
@@ -839,11 +844,11 @@ int drn_box_reg_loss(const float* logits, long ld, int col0, int K, const int* l
 }
 
 int drn_mean_softmax(const float* logits, long ld, const int* col0s_dev, int n_heads, int C, float* probs, int M,
-                     void* stream) {
+                     int bg_first, void* stream) {
   if (!logits || !col0s_dev || !probs || n_heads < 1) return DRN_ERR_ARG;
   if (M == 0) return DRN_OK;
   hipLaunchKernelGGL(mean_softmax_kernel, dim3((M + 255) / 256), dim3(256), 0, (hipStream_t)stream, logits, ld,
-                     col0s_dev, n_heads, C, probs, M);
+                     col0s_dev, n_heads, C, probs, M, bg_first);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

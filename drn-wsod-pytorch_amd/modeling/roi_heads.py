@@ -517,13 +517,29 @@ class _HeadEngine:
         aux = dict(scores=scores, img_scores=img_scores, targets=[])
         thr = h.proposal_matcher.thresholds[1:-1]
         chain = None
-        if h.refine_K > 0 and not any(h.refine_reg[: h.refine_K]):
+        pcl = getattr(h, "refine_mode", "oicr") == "pcl"
+        if pcl and h.refine_K > 0:
+            # PCLROIHeads (roi_heads_pcl.py:311-334): every branch's targets come from the previous branch's
+            # probabilities through proposal clustering; targets, loss and dlogits of all branches in three launches
+            if n_img != 1:
+                raise DrnError("PCL clusters the proposals of ONE image per step (third_party/pcl.py:94 asserts it)")
+            if any(h.refine_reg[: h.refine_K]):
+                raise DrnError("PCL with box regression branches is not on the built path (no reference config uses it)")
+            adj = ops.pcl_adjacency(gt["props"], 0.4)
+            res = ops.pcl_refine(w["logits"], [col["r%d" % k] for k in range(h.refine_K)], K, scores, gt["props"], adj,
+                                 gt["onehot"].view(-1), dl)
+            for k in range(h.refine_K):
+                loss_names.append("loss_cls_r%d" % k)
+                loss_list.append(res[k]["loss"].view(()))
+                head_cols.append(("r%d" % k, len(loss_list) - 1))
+                aux["targets"].append(res[k])
+        elif h.refine_K > 0 and not any(h.refine_reg[: h.refine_K]):
             # no branch regresses boxes: every branch's targets depend only on the previous branch's softmax of logits
             # that already exist, so the whole cascade is four launches (drn_oicr_refine_chain)
             chain = ops.oicr_refine_chain(w["logits"], [col["r%d" % k] for k in range(h.refine_K)], K, scores,
                                           gt["props"], img_off, n_img, gt["classes"], gt["count"], img_scores, thr,
                                           h.proposal_matcher.labels, dlogits=dl)
-        for k in range(h.refine_K):
+        for k in range(0 if pcl else h.refine_K):
             if chain is not None:
                 tg, probs, loss = chain[k]
             else:
@@ -844,7 +860,8 @@ class OICRROIHeads(ROIHeads):
             probs, _ = ops.softmax_ce(w["logits"], col["r%d" % heads[-1]], K + 1)
             boxes = ops.apply_deltas(w["logits"], props, K, last.box2box_transform.weights, col0=col["b%d" % heads[-1]])
         else:
-            probs = ops.mean_softmax(w["logits"], [col["r%d" % k] for k in heads], K + 1)
+            probs = ops.mean_softmax(w["logits"], [col["r%d" % k] for k in heads], K + 1,
+                                     bg_first=getattr(self, "refine_mode", "oicr") == "pcl")
             boxes = ops.apply_deltas(None, props, K, last.box2box_transform.weights)
         results, all_scores, all_boxes = [], [], []
         for p, s, b in zip(proposals, probs.split(nper), boxes.split(nper)):
@@ -858,6 +875,17 @@ class OICRROIHeads(ROIHeads):
             all_scores.append(s.unsqueeze(0))
             all_boxes.append(b.unsqueeze(0))
         return results, all_scores, all_boxes
+
+
+@ROI_HEADS_REGISTRY.register()
+class PCLROIHeads(OICRROIHeads):
+    """roi_heads_pcl.py:28-349: the same trunk, neck, MIL head and K+1-way refinement branches as OICR; the branches
+    are trained with the proposal-cluster loss (fast_rcnn.py:1725-1745) instead of the pseudo-GT cross entropy, keep
+    the background in column 0, and are averaged with `pcl_bg` at test time (roi_heads_pcl.py:341-349).  The reference
+    runs the clustering in numpy / scikit-learn and the loss in C++ on the host; here both stay on the device
+    (csrc/pcl.hip)."""
+
+    refine_mode = "pcl"
 
 
 @ROI_HEADS_REGISTRY.register()

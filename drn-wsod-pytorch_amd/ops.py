@@ -291,11 +291,12 @@ def box_reg_loss(logits, col0, K, labels, props, gt_boxes, weights=(10.0, 10.0, 
     return loss
 
 
-def mean_softmax(logits, col0s, ncol):
+def mean_softmax(logits, col0s, ncol, bg_first=False):
     M = logits.shape[0]
     probs = torch.empty((M, ncol), dtype=torch.float32, device=logits.device)
     cd = torch.tensor(list(col0s), dtype=torch.int32, device=logits.device)
-    C.call("drn_mean_softmax", C.ptr(logits), _2d(logits), C.ptr(cd), len(col0s), ncol, C.ptr(probs), M, C.stream())
+    C.call("drn_mean_softmax", C.ptr(logits), _2d(logits), C.ptr(cd), len(col0s), ncol, C.ptr(probs), M, int(bg_first),
+           C.stream())
     return probs
 
 

@@ -188,9 +188,10 @@ int drn_box_reg_loss(const float* logits, long ld, int col0, int K, const int* l
                      const float* gt_boxes, const float* weights4_host, float* dlogits, long ld_d, float* loss,
                      float* scratch, int M, float loss_scale, void* stream);
 
-/* OICROutputLayers.predict_probs_K, fast_rcnn.py:1577-1594. */
+/* OICROutputLayers.predict_probs_K, fast_rcnn.py:1577-1594.  bg_first = 1: the heads keep the background in their
+ * column 0 (PCL) and the output is rotated so that it is the last column (`pcl_bg`, fast_rcnn.py:1463-1465). */
 int drn_mean_softmax(const float* logits, long ld, const int* col0s_dev, int n_heads, int C, float* probs, int M,
-                     void* stream);
+                     int bg_first, void* stream);
 
 /* Box2BoxTransform.apply_deltas, detectron2/modeling/box_regression.py:73-110 (deltas NULL = zeros). */
 int drn_apply_deltas(const float* deltas, long ld_d, const float* boxes, float* out, int M, int K,

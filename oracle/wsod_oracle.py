@@ -270,6 +270,7 @@ class OracleCfg:
     bias_lr_factor: float = 2.0
     weight_decay_bias: float = 0.0
     width_per_group: int = 64  # MODEL.RESNETS.WIDTH_PER_GROUP (bottleneck width of res2)
+    heads: str = "oicr"  # MODEL.ROI_HEADS.NAME: "oicr" (OICRROIHeads) | "pcl" (PCLROIHeads, oracle/pcl_oracle.py)
 
     @property
     def blocks(self):
@@ -515,6 +516,20 @@ def roi_heads_train(p, feat, prop_boxes, objectness, gt_classes_list, cfg: Oracl
     props_cat = torch.cat(prop_boxes, dim=0)
     aux = {"pooled": pooled, "fc7": x, "scores": scores, "img_scores": img_scores, "pgt": [], "labels": [],
            "weights": [], "logits": []}
+    if cfg.heads == "pcl":
+        # roi_heads_pcl.py:311-334: branch k clusters on branch k-1's probabilities (one image per step)
+        assert len(prop_boxes) == 1, "PCL asserts a batch of one image (third_party/pcl.py:94)"
+        last = scores.detach().numpy()
+        aux["pcl"] = []
+        for k in range(cfg.refine_num):
+            pre = "roi_heads.box_refinery_%d." % k
+            logits = F.linear(x, p[pre + "cls_score.weight"], p[pre + "cls_score.bias"])
+            loss, tg, probs = _PclLossFn.apply(logits, prop_boxes[0].numpy(), last, gt_oh[0].numpy())
+            losses["loss_cls_r%d" % k] = loss
+            aux["logits"].append(logits)
+            aux["pcl"].append(tg)
+            last = probs
+        return (losses, aux) if return_aux else losses
     for k in range(cfg.refine_num):
         pgt = get_pgt(prev_boxes, prev_scores, gt_ints, img_scores, K)
         gcs, ws, gbs = [], [], []
@@ -541,6 +556,24 @@ def roi_heads_train(p, feat, prop_boxes, objectness, gt_classes_list, cfg: Oracl
         aux["weights"].append(weights)
         aux["logits"].append(logits)
     return (losses, aux) if return_aux else losses
+
+
+class _PclLossFn(torch.autograd.Function):
+    """wsl/layers/pcl_loss.py:10-93 around fast_rcnn.py:1725-1745 (targets are constants; the gradient reaches the
+    logits through the softmax of predict_probs)"""
+
+    @staticmethod
+    def forward(ctx, logits, boxes, last, im_labels):
+        from . import pcl_oracle as PO
+
+        loss, dl, probs, t = PO.pcl_refine_loss(logits.detach().numpy(), boxes, last, im_labels)
+        ctx.save_for_backward(torch.from_numpy(dl))
+        return torch.tensor(float(loss), dtype=torch.float32), t, probs
+
+    @staticmethod
+    def backward(ctx, g, _t, _p):
+        (dl,) = ctx.saved_tensors
+        return dl * g, None, None, None
 
 
 def fast_rcnn_inference_single_image(boxes, scores, image_shape, score_thresh, nms_thresh, topk):
@@ -589,6 +622,8 @@ def roi_heads_inference(p, feat, prop_boxes, objectness, image_sizes, cfg: Oracl
             probs = pk if probs is None else probs + pk
             # deltas of non-reg heads are zeros (fast_rcnn.py:1377-1386); the mean stays zero
         probs = probs / cfg.refine_num
+        if cfg.heads == "pcl":  # pcl_bg, fast_rcnn.py:1463-1465: the branches keep the background in column 0
+            probs = torch.cat((probs[:, 1:], probs[:, :1]), dim=1)
     boxes = apply_deltas(deltas, props_cat, cfg.bbox_weights)
     res = []
     for b, s, sz in zip(boxes.split(nper), probs.split(nper), image_sizes):

@@ -728,6 +728,56 @@ if __name__ == "__main__":
     if "tta" in which:
         case_tta("tta_r50c4_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 38, 48, 60, 84,
                  (48, 72), 96, 40)
+    if "pclmodel" in which:
+        # the reference's _PCLLoss moves its output with .cuda(device_id) (wsl/layers/pcl_loss.py:51,91): without a
+        # GPU in this container that call is made the identity for this case (environment shim, like PIL.Image.LINEAR)
+        torch.Tensor.cuda = lambda self, *a, **k: self
+        # The reference's scikit-learn draw / numpy tie order are not functions of the inputs (oracle/pcl_oracle.py
+        # header), and in a model this small (top clusters of ~5 boxes) equal degrees are the rule.  So the golden also
+        # records the DECISIONS the reference took - per k-means call the top-cluster threshold, per greedy iteration
+        # the picked node - obtained by running the oracle with this machine's scikit-learn / numpy in those two places
+        # and checking that it then reproduces the reference's two training steps.  tests/test_oracle_golden.py replays
+        # the recorded decisions, which pins everything else of the PCL model flow to the reference on any machine.
+        import golden_util as GU
+        from oracle import pcl_oracle as PO
+        from wsl.modeling.roi_heads.third_party import pcl as ref_pcl
+
+        seed = 39
+        case_full_model("model_pcl_r50c4_tiny", "PascalVOC-Detection/pcl_WSR_50_DC5_1x.yaml", TINY_R50 + C4, seed, 1, 60,
+                        128, 96)
+        ocfg = GU.MODEL_CASES["model_pcl_r50c4_tiny"]
+        ocfg.dropout = 0.0
+        dd = GU.load("model_pcl_r50c4_tiny")
+        km_log, pick_log = [], []
+
+        def km_hook(v):
+            v = np.asarray(v)
+            t = v[ref_pcl._get_top_ranking_propoals(v.reshape(-1, 1).copy())].min()
+            km_log.append(np.float32(t))
+            return t
+
+        def pick_hook(x):
+            i = int(np.asarray(x, dtype=np.float32).argsort()[::-1][0])
+            pick_log.append(i)
+            return i
+
+        keep = PO.kmeans_top_threshold, PO._argmax_last
+        PO.kmeans_top_threshold, PO._argmax_last = km_hook, pick_hook
+        try:
+            pp = O.seeded_params(O.param_shapes(ocfg), seed)
+            opt = O.SGDState(ocfg)
+            for step in range(2):
+                ls, _ = O.train_step(pp, GU.batch_from(dd), ocfg, opt, None, 5)
+                for k, v in ls.items():
+                    ref_v = float(dd["step%d_%s" % (step, k)])
+                    assert abs(float(v) - ref_v) <= 1e-4 * max(1.0, abs(ref_v)), (step, k, float(v), ref_v)
+        finally:
+            PO.kmeans_top_threshold, PO._argmax_last = keep
+        dd["pcl_km_log"] = np.array(km_log, dtype=np.float32)
+        dd["pcl_pick_log"] = np.array(pick_log, dtype=np.int64)
+        np.savez_compressed(os.path.join(HERE, "model_pcl_r50c4_tiny.npz"), **dd)
+        print("PCL model golden: oracle with the reference's recorded decisions reproduces both steps;",
+              len(km_log), "k-means calls,", len(pick_log), "picks")
     if "r50c4_reg" in which:
         case_full_model("model_r50c4_reg_tiny", "PascalVOC-Detection/reg/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 37,
                         1, 40, 96, 96)

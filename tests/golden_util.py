@@ -27,6 +27,7 @@ MODEL_CASES = {
     "model_r50c4_dropmask_tiny": O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1, **TINY),
     "model_r50c4_reg_tiny": O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1, refine_num=4,
                                         refine_reg=(False, False, False, True), **TINY),
+    "model_pcl_r50c4_tiny": O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1, heads="pcl", **TINY),
 }
 FREEZE_AT = {"model_r50c4_align_tiny": 3}
 
@@ -72,7 +73,7 @@ def drn_cfg(ocfg, device="cuda", freeze_at=5):
     L = ["MODEL.META_ARCHITECTURE", "GeneralizedRCNNWSL", "MODEL.DEVICE", device, "MODEL.LOAD_PROPOSALS", "True",
          "MODEL.PIXEL_MEAN", str(list(ocfg.pixel_mean)), "MODEL.BACKBONE.FREEZE_AT", str(freeze_at),
          "MODEL.BACKBONE.NAME", "build_vgg_backbone" if vgg else "build_ws_resnet_backbone",
-         "MODEL.ROI_HEADS.NAME", "OICRROIHeads", "MODEL.ROI_HEADS.NUM_CLASSES", str(ocfg.num_classes),
+         "MODEL.ROI_HEADS.NAME", "PCLROIHeads" if ocfg.heads == "pcl" else "OICRROIHeads", "MODEL.ROI_HEADS.NUM_CLASSES", str(ocfg.num_classes),
          "MODEL.ROI_HEADS.IN_FEATURES", str([feat]), "MODEL.ROI_HEADS.SCORE_THRESH_TEST", "0.00001",
          "MODEL.ROI_HEADS.NMS_THRESH_TEST", "0.3", "MODEL.ROI_HEADS.PROPOSAL_APPEND_GT", "False",
          "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", "4096", "MODEL.ROI_HEADS.POSITIVE_FRACTION", "1.0",

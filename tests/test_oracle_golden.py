@@ -264,6 +264,24 @@ def test_heads_detail(reg):
             assert "bbox_pred" in n  # unused parameters (F10)
 
 
+def _replay_pcl_decisions(d):
+    """PCL model golden: the reference's k-means draw and equal-degree picks are not functions of the inputs; the
+    generator recorded the decisions it took (tests/golden/gen_golden.py `pclmodel`).  Replaying them in the two places
+    of oracle/pcl_oracle.py that restate those steps pins everything else of the PCL flow (cascade wiring, clusters,
+    loss, gradient, SGD) to the reference.  Returns the undo function."""
+    from oracle import pcl_oracle as PO
+
+    km, picks = iter(d["pcl_km_log"].tolist()), iter(d["pcl_pick_log"].tolist())
+    keep = PO.kmeans_top_threshold, PO._argmax_last
+    PO.kmeans_top_threshold = lambda v: np.float32(next(km))
+    PO._argmax_last = lambda x: int(next(picks))
+
+    def undo():
+        PO.kmeans_top_threshold, PO._argmax_last = keep
+
+    return undo
+
+
 # ------------------------------------------------------------------ whole model, 2 SGD steps
 @pytest.mark.parametrize("name", sorted(G.MODEL_CASES))
 def test_full_model_two_steps(name):
@@ -280,8 +298,15 @@ def test_full_model_two_steps(name):
     on = set(O.trainable_names(p, cfg, fz))
     assert {n for n in tn if not ("bbox_pred" in n and n not in on)} == on
     opt = O.SGDState(cfg)
+    undo = _replay_pcl_decisions(d) if cfg.heads == "pcl" else (lambda: None)
     for step in range(2):
-        losses, grads = O.train_step(p, batch, cfg, opt, masks, fz)
+        try:
+            losses, grads = O.train_step(p, batch, cfg, opt, masks, fz)
+        except Exception:
+            undo()
+            raise
+        if step == 1:
+            undo()
         for k, v in losses.items():
             _close(v, float(d["step%d_%s" % (step, k)]), rtol=1e-4)
         if step == 0:
