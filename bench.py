@@ -216,6 +216,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--heads", choices=["oicr", "pcl"], default="oicr",
+                    help="oicr = the BASELINE workload; pcl = PCLROIHeads on the same trunk (SURVEY 8f rank 4; a side "
+                         "measurement, not the headline metric)")
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
     ap.add_argument("--no-pipelined-sgd", action="store_true", help="plain optimizer.step() after backward")
     ap.add_argument("--fused-sgd", action="store_true",
@@ -260,6 +263,8 @@ def main():
     from drn_wsod_pytorch_amd.modeling import build_model
 
     cfg = build_cfg(pkg, device)
+    if args.heads == "pcl":
+        cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "PCLROIHeads"])
     model = build_model(cfg)
     init_weights(model, seed=0)
     model.train()
@@ -357,8 +362,8 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "DRN-WSOD ResNet50-WS C4 (res4 out, stride 16), VOC07-shaped synthetic 224x224, "
-                                      "%d proposals/img, 1 img/GPU/iter, K=20, 3 OICR refinements, frozen backbone "
-                                      "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % R,
+                                      "%d proposals/img, 1 img/GPU/iter, K=20, 3 %s refinements, frozen backbone "
+                                      "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % (R, args.heads.upper()),
                           "global_batch": world, "proposals": R, "parallelism": "dp%d" % world},
                "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph),
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),

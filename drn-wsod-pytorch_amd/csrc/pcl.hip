@@ -26,6 +26,8 @@ constexpr int PCL_W = PCL_MAXR / 32;    // words of a row mask
 constexpr int PCL_T = 1024;             // threads of the one workgroup that walks one refinement branch
 constexpr int PCL_CHUNK = 64;           // blocked prefix sum (oracle/pcl_oracle.py SCAN_CHUNK)
 constexpr int PCL_MAXP = 640;           // centres kept in LDS for the assignment phase (5 per labelled class)
+constexpr int PCL_NINV = 3584;          // reciprocals kept in LDS for the k-means search (larger distances divide)
+constexpr int PCL_ROWBUF_WORDS = (16384 + 32768 + 8192) / 4;  // adjacency rows of the top cluster staged in LDS
 
 __device__ __forceinline__ float iou_xyxy(const float* a, const float* b) {
   const float a1 = (a[2] - a[0]) * (a[3] - a[1]);
@@ -93,6 +95,7 @@ struct PclRefineParams {
 struct PclShared {  // fixed-size part of the LDS image (the big arrays follow, carved from dynamic LDS)
   uint32_t alive[PCL_W], member[PCL_W], live[PCL_W], inds[PCL_W];
   int nz[PCL_W];
+  int wpre[PCL_W];  // rows set in the mask words before word w (of `alive` while gathering, of `member` afterwards)
   int nnz, cnt;
   unsigned long long red_u[16];
   double red_d[16];
@@ -141,6 +144,14 @@ __device__ __forceinline__ void block_best_cut(double& g, int& i, int& j, PclSha
 }
 
 __device__ __forceinline__ bool bit(const uint32_t* m, int r) { return (m[r >> 5] >> (r & 31)) & 1u; }
+// 1.0 / d, correctly rounded either way (the table holds the same IEEE quotients)
+__device__ __forceinline__ double recip(const double* inv, int d) { return d <= PCL_NINV ? inv[d - 1] : 1.0 / (double)d; }
+
+#ifdef PCL_PROFILE  // phase clocks (s_memtime) of branch 0, written over the tail of pc_scores: tools/pcl_bench.py reads them
+#define PCL_TICK(k) { const long long now_ = clock64(); prof_[k] += now_ - last_; last_ = now_; }
+#else
+#define PCL_TICK(k)
+#endif
 
 __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
   extern __shared__ __align__(16) unsigned char lds_raw[];
@@ -149,12 +160,20 @@ __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
   // k-means phase                                   | graph phase            | assignment phase
   float* sv = reinterpret_cast<float*>(big);         // sorted values [4096]  | centre boxes [PMAXP][4] + scores + labels
   double* P1 = reinterpret_cast<double*>(big + 16384);          // prefix [4097] -> Pc[j] | keep_row / keep_score
-  double* T2 = reinterpret_cast<double*>(big + 16384 + 32776);  // term2 by cut [4096]    | deg [4096] int | w, assign
-  double* INV = reinterpret_cast<double*>(big + 16384 + 32776 + 32768);  // 1/m [4096]
-  unsigned short* CP = reinterpret_cast<unsigned short*>(big + 16384 + 32776 + 65536);  // cut positions [4096]
-  int* deg = reinterpret_cast<int*>(T2);
-  unsigned short* keep_row = reinterpret_cast<unsigned short*>(P1);
-  float* keep_score = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(P1) + 8192);
+  double* T2 = reinterpret_cast<double*>(big + 16384 + 32776);  // chunk totals -> G0[j]  | deg [4096] int | w, assign
+  double* B2 = reinterpret_cast<double*>(big + 16384 + 32776 + 32768);  // best 2-cluster gain of the prefix below cut j
+  unsigned short* CP = reinterpret_cast<unsigned short*>(big + 16384 + 32776 + 65536);   // cut positions [4096]
+  unsigned short* OPT = reinterpret_cast<unsigned short*>(big + 16384 + 32776 + 65536 + 8192);  // best lower cut of j
+  double* INV = reinterpret_cast<double*>(big + 16384 + 32776 + 65536 + 16384);  // 1/d for d <= PCL_NINV (what LDS has left)
+  // graph phase (the k-means arrays are dead by then)
+  float* rval = sv;                                    // clipped score of every row [4096]
+  unsigned short* keep_row = reinterpret_cast<unsigned short*>(P1);                                        // [4096]
+  float* keep_score = reinterpret_cast<float*>(reinterpret_cast<unsigned char*>(P1) + 8192);                // [4096]
+  unsigned short* rslot = reinterpret_cast<unsigned short*>(reinterpret_cast<unsigned char*>(P1) + 24576);  // row -> slot
+  int* deg = reinterpret_cast<int*>(T2);               // degree of every member, by slot [4096]
+  uint32_t* rowbuf = reinterpret_cast<uint32_t*>(reinterpret_cast<unsigned char*>(T2) + 16384);  // staged member rows:
+                                                       // upper half of T2 + B2 + CP = 56 KB
+  unsigned short* mlist = OPT;                         // members, ascending rows [4096]
 
   const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int R = p.R, K = p.K, K1 = p.K1, W32 = p.W32;
@@ -173,9 +192,13 @@ __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
   const float EPS9 = 1e-9f;  // pcl.py:33-37 (the upper clip 1 - 1e-9 rounds to 1.0f and never fires)
 
   if (tid < PCL_W) S.alive[tid] = tid < W32 ? (tid == W32 - 1 && (R & 31) ? (1u << (R & 31)) - 1u : 0xFFFFFFFFu) : 0u;
-  for (int m = tid; m < PCL_MAXR; m += PCL_T) INV[m] = 1.0 / (double)(m + 1);
   __syncthreads();
 
+#ifdef PCL_PROFILE
+  long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, last_ = clock64();
+#endif
+  for (int d = tid; d < PCL_NINV; d += PCL_T) INV[d] = 1.0 / (double)(d + 1);
+  __syncthreads();
   int P = 0;  // centres so far (uniform)
   for (int c = 0; c < K; ++c) {
     if (p.onehot[c] != 1.f) continue;
@@ -185,14 +208,16 @@ __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
     if (n == 0 || P + 5 > p.PMAX) continue;
     int npad = 64;
     while (npad < n) npad <<= 1;
+    if (tid < PCL_W) {
+      int acc = 0;
+      for (int w = 0; w < tid; ++w) acc += __popc(S.alive[w]);
+      S.wpre[tid] = acc;
+    }
+    __syncthreads();
     for (int q = 0; q < PCL_MAXR / PCL_T; ++q) {
       const int r = q * PCL_T + tid;
-      const bool a = r < R && bit(S.alive, r);
-      // position = alive rows before r
-      int pos = 0;
-      if (a) {
-        for (int w = 0; w < (r >> 5); ++w) pos += __popc(S.alive[w]);
-        pos += __popc(S.alive[r >> 5] & ((1u << (r & 31)) - 1u));
+      if (r < R && bit(S.alive, r)) {
+        const int pos = S.wpre[r >> 5] + __popc(S.alive[r >> 5] & ((1u << (r & 31)) - 1u));
         sv[pos] = fmaxf(last[(long)r * ldl + c], EPS9);
       }
     }
@@ -208,8 +233,13 @@ __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
             if ((va > vb) == up) { sv[i] = vb; sv[x] = va; }
           }
         }
-        __syncthreads();
+        // element i lives with thread i % 1024: partners at distance < 64 stay inside one wave, whose LDS accesses are
+        // issued in program order - a workgroup barrier is only needed next to a pass that crosses waves
+        const int nj = j > 1 ? (j >> 1) : k;  // distance of the next pass (first pass of the next stage: k)
+        if (j >= 64 || nj >= 64) __syncthreads();
+        else __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
       }
+    PCL_TICK(0)
     // ---- blocked prefix sums in float64 (sequential in chunks of 64, sequential over chunk totals)
     const int nch = (n + PCL_CHUNK - 1) / PCL_CHUNK;
     if (tid < nch) {
@@ -255,131 +285,254 @@ __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
       }
       __syncthreads();
     }
+    PCL_TICK(1)
     const int kk = min(3, min(n, ncut + 1));
     float thr = sv[0];
     if (kk >= 2) {
-      // by cut index j: Pc[j] = P[cut], T2[j] = gain(cut, n); P1 is re-read before being overwritten
-      double pn = P1[n];
-      double pc_[PCL_MAXR / PCL_T], t2_[PCL_MAXR / PCL_T];
+      // by cut index j: Pc[j] = P[cut j] (in P1), G0[j] = gain(0, cut j) (in T2); gain(cut j, n) is recomputed where used.
+      // 1/m is an IEEE division wherever it appears (the oracle's 1.0 / m)
+      const double pn = P1[n];
+      double pc_[PCL_MAXR / PCL_T];
       for (int q = 0; q < PCL_MAXR / PCL_T; ++q) {
         const int j = q * PCL_T + tid;
-        if (j < ncut) {
-          const int cpos = CP[j];
-          const double d2 = pn - P1[cpos];
-          pc_[q] = P1[cpos];
-          t2_[q] = d2 * d2 * INV[n - cpos - 1];
-        }
+        if (j < ncut) pc_[q] = P1[CP[j]];
       }
       __syncthreads();
       for (int q = 0; q < PCL_MAXR / PCL_T; ++q) {
         const int j = q * PCL_T + tid;
-        if (j < ncut) { P1[j] = pc_[q]; T2[j] = t2_[q]; }
+        if (j < ncut) { P1[j] = pc_[q]; T2[j] = pc_[q] * pc_[q] * (1.0 / (double)CP[j]); }
       }
       __syncthreads();
       double bg = -1.0;
       int bi = 0x7fffffff, bj = 0x7fffffff;
       if (kk == 2) {
         for (int j = tid; j < ncut; j += PCL_T) {
-          const double d = P1[j];
-          const double g = d * d * INV[CP[j] - 1] + T2[j];
+          const double d2 = pn - P1[j];
+          const double g = T2[j] + d2 * d2 * (1.0 / (double)(n - CP[j]));
           if (g > bg) { bg = g; bi = j; bj = j; }
         }
       } else {
-        for (int i = tid; i < ncut - 1; i += PCL_T) {
-          const int c1 = CP[i];
-          const double p1 = P1[i];
-          const double g0 = p1 * p1 * INV[c1 - 1];
-          for (int j = i + 1; j < ncut; ++j) {
-            const double d1 = P1[j] - p1;
-            const double g = (g0 + d1 * d1 * INV[CP[j] - c1 - 1]) + T2[j];
-            if (g > bg) { bg = g; bi = i; bj = j; }
+        // best lower cut of every upper cut j = 1..m by divide and conquer over the cut indices (the leftmost best lower
+        // cut is non-decreasing in j: concave Monge cost): level h solves the odd multiples of h, bracketed by the
+        // solved neighbours j-h and j+h; one wave per midpoint, lanes stride its candidates.  O(n log n) evaluations
+        // instead of all pairs (which kept one CU busy for 0.28 ms per class at n = 2000).
+        const int m = ncut - 1;
+        int span = 1;
+        while (span <= m) span <<= 1;
+        for (int h = span >> 1; h >= 1; h >>= 1) {
+          const int nmid = h <= m ? (m - h) / (2 * h) + 1 : 0;  // midpoints j = h (2q + 1) <= m
+          // few midpoints with long candidate ranges: one wave each; many midpoints with short ranges: one thread each
+          // (a midpoint whose range is long anyway goes to a small work list that the waves share afterwards)
+          const bool per_thread = nmid >= 64;
+          if (per_thread) {
+            if (tid == 0) S.nnz = 0;
+            __syncthreads();
+            for (int q = tid; q < nmid; q += PCL_T) {
+              const int j = h * (2 * q + 1);
+              const int lo = (j - h >= 1) ? (int)OPT[j - h] : 0;
+              int hi = (j + h <= m) ? (int)OPT[j + h] : j - 1;
+              hi = max(min(hi, j - 1), lo);
+              int slot = -1;
+              if (hi - lo >= 48) slot = atomicAdd(&S.nnz, 1);
+              if (slot >= 0 && slot < PCL_W) { S.nz[slot] = j; continue; }
+              const double pj = P1[j];
+              const int cj = CP[j];
+              double bf = -1.0;
+              int bx = lo;
+              for (int i = lo; i <= hi; ++i) {
+                const double d1 = pj - P1[i];
+                const double f = T2[i] + d1 * d1 * recip(INV, cj - (int)CP[i]);
+                if (f > bf) { bf = f; bx = i; }
+              }
+              OPT[j] = (unsigned short)bx;
+              B2[j] = bf;
+            }
+            __syncthreads();
           }
+          const int nwave_items = per_thread ? min(S.nnz, PCL_W) : nmid;
+          for (int q = wave; q < nwave_items; q += PCL_T / 64) {
+            const int j = per_thread ? S.nz[q] : h * (2 * q + 1);
+            const int lo = (j - h >= 1) ? (int)OPT[j - h] : 0;
+            int hi = (j + h <= m) ? (int)OPT[j + h] : j - 1;
+            hi = max(min(hi, j - 1), lo);
+            const double pj = P1[j];
+            const int cj = CP[j];
+            double bf = -1.0;
+            int bx = 0x7fffffff;
+            for (int i = lo + lane; i <= hi; i += 64) {
+              const double d1 = pj - P1[i];
+              const double f = T2[i] + d1 * d1 * recip(INV, cj - (int)CP[i]);
+              if (f > bf) { bf = f; bx = i; }
+            }
+            for (int o = 32; o > 0; o >>= 1) {
+              const double of = __shfl_xor(bf, o, 64);
+              const int ox = __shfl_xor(bx, o, 64);
+              if (of > bf || (of == bf && ox < bx)) { bf = of; bx = ox; }
+            }
+            if (lane == 0) { OPT[j] = (unsigned short)bx; B2[j] = bf; }
+          }
+          __syncthreads();
+        }
+        for (int j = 1 + tid; j <= m; j += PCL_T) {
+          const double d2 = pn - P1[j];
+          const double g = B2[j] + d2 * d2 * (1.0 / (double)(n - CP[j]));
+          if (g > bg) { bg = g; bi = j; bj = j; }
         }
       }
       block_best_cut(bg, bi, bj, S);
       thr = sv[CP[bj]];
     }
     __syncthreads();
-    // ---- members of the top cluster; degrees inside it
+    PCL_TICK(2)
+    // ---- members of the top cluster (row masks + a compact ascending list), their clipped scores by row, their
+    // degrees inside the cluster; the members' adjacency rows are staged in LDS when they fit
     for (int q = 0; q < PCL_MAXR / PCL_T; ++q) {
       const int r = q * PCL_T + tid;
-      const bool mb = r < R && bit(S.alive, r) && fmaxf(last[(long)r * ldl + c], EPS9) >= thr;
+      const float v = r < R ? fmaxf(last[(long)r * ldl + c], EPS9) : 0.f;
+      const bool mb = r < R && bit(S.alive, r) && v >= thr;
       const unsigned long long m = __ballot(mb);
       if (lane == 0) { S.member[(r >> 5)] = (uint32_t)m; S.member[(r >> 5) + 1] = (uint32_t)(m >> 32); }
+      rval[r] = v;
     }
     __syncthreads();
-    if (tid < PCL_W) S.live[tid] = S.member[tid];
+    if (tid < PCL_W) {
+      S.live[tid] = S.member[tid];
+      int acc = 0;
+      for (int w = 0; w < tid; ++w) acc += __popc(S.member[w]);
+      S.wpre[tid] = acc;
+    }
     int count = 0;
     for (int w = 0; w < W32; ++w) count += __popc(S.member[w]);
+    const int nmem = count;
+    const bool staged = nmem * W32 <= PCL_ROWBUF_WORDS;
+    __syncthreads();
     for (int q = 0; q < PCL_MAXR / PCL_T; ++q) {
       const int r = q * PCL_T + tid;
-      int d = 0;
       if (r < R && bit(S.member, r)) {
-        const uint32_t* row = p.adj + (long)r * W32;
-        for (int w = 0; w < W32; ++w) d += __popc(row[w] & S.member[w]);
+        const int x = S.wpre[r >> 5] + __popc(S.member[r >> 5] & ((1u << (r & 31)) - 1u));
+        mlist[x] = (unsigned short)r;
+        rslot[r] = (unsigned short)x;
+        deg[x] = 0;
       }
-      deg[r] = d;
     }
     __syncthreads();
-    // ---- greedy graph centres (pcl.py:103-117)
-    int nkeep = 0;
-    while (true) {
-      unsigned long long key = 0;
-      for (int q = 0; q < PCL_MAXR / PCL_T; ++q) {
-        const int r = q * PCL_T + tid;
-        if (r < R && bit(S.member, r)) {
-          const unsigned long long k2 = (((unsigned long long)deg[r] << 12) | (unsigned)r) + 1ull;
+    // one (member, word) pair per thread and step: independent coalesced loads; integer LDS adds are order-free
+    for (int idx = tid; idx < nmem * W32; idx += PCL_T) {
+      const int x = idx / W32, w = idx - x * W32;
+      const uint32_t v = p.adj[(long)mlist[x] * W32 + w];
+      if (staged) rowbuf[idx] = v;
+      const int d = __popc(v & S.member[w]);
+      if (d) atomicAdd(&deg[x], d);
+    }
+    __syncthreads();
+    PCL_TICK(3)
+    // ---- greedy graph centres (pcl.py:103-117) on ONE wave, no workgroup barriers: lane l owns the rows of mask words
+    // l and l+64, so zeroing / decrementing degrees never crosses lanes.  Removing the set `inds` lowers the degree of
+    // a live row r by |{j in inds : adj(r,j)}| = sum over j of adj[j][r] (IoU is symmetric): one row read per removed
+    // node and a walk over its set bits, instead of every live row gathering over the removed set.
+    if (wave == 0) {
+      int nk = 0;
+      while (true) {
+        uint32_t key = 0;
+        for (int x = lane; x < nmem; x += 64) {
+          const uint32_t k2 = (((uint32_t)deg[x] << 12) | (uint32_t)x) + 1u;
           key = k2 > key ? k2 : key;
         }
-      }
-      key = block_max_u64(key, S);
-      const int t = (int)((key - 1ull) & 4095ull);
-      const bool tlive = bit(S.live, t);
-      if (tid < PCL_W) S.inds[tid] = (tlive && tid < W32) ? (p.adj[(long)t * W32 + tid] & S.live[tid]) : 0u;
-      __syncthreads();
-      if (wave == 0) {
-        int cnt = 0, base = 0;
+        for (int o = 32; o > 0; o >>= 1) { const uint32_t t2 = __shfl_xor(key, o, 64); key = t2 > key ? t2 : key; }
+        const int tslot = (int)((key - 1u) & 4095u);
+        const int t = mlist[tslot];
+        const bool tlive = bit(S.live, t);
+        const uint32_t* trow = staged ? rowbuf + tslot * W32 : p.adj + (long)t * W32;
+        int cnt = 0;
+        uint32_t iw[PCL_W / 64], lv[PCL_W / 64];
+        uint32_t sk = 0;
         for (int h = 0; h < PCL_W / 64; ++h) {
-          const uint32_t v = S.inds[h * 64 + lane];
-          cnt += __popc(v);
-          const unsigned long long m = __ballot(v != 0u);
-          if (v != 0u) S.nz[base + __popcll(m & ((1ull << lane) - 1ull))] = h * 64 + lane;
-          base += __popcll(m);
-        }
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
-        if (lane == 0) { S.cnt = cnt; S.nnz = base; }
-      }
-      __syncthreads();
-      const int cnt = S.cnt, nnz = S.nnz;
-      unsigned long long sk = 0;
-      for (int q = 0; q < PCL_MAXR / PCL_T; ++q) {
-        const int r = q * PCL_T + tid;
-        if (r < R && bit(S.inds, r)) {
-          const unsigned long long v = __float_as_uint(fmaxf(last[(long)r * ldl + c], EPS9));
-          sk = v > sk ? v : sk;
-        }
-      }
-      sk = block_max_u64(sk, S);
-      if (tid < PCL_W) S.live[tid] &= ~S.inds[tid];
-      __syncthreads();
-      for (int q = 0; q < PCL_MAXR / PCL_T; ++q) {
-        const int r = q * PCL_T + tid;
-        if (r < R && bit(S.member, r)) {
-          if (!bit(S.live, r)) deg[r] = 0;
-          else if (nnz) {
-            const uint32_t* row = p.adj + (long)r * W32;
-            int d = 0;
-            for (int z = 0; z < nnz; ++z) d += __popc(row[S.nz[z]] & S.inds[S.nz[z]]);
-            deg[r] -= d;
+          const int w = h * 64 + lane;
+          lv[h] = S.live[w];
+          iw[h] = (tlive && w < W32) ? (trow[w] & lv[h]) : 0u;
+          cnt += __popc(iw[h]);
+          lv[h] &= ~iw[h];
+          S.live[w] = lv[h];  // this lane is the only reader / writer of its two words inside the loop
+          uint32_t bits = iw[h];
+          while (bits) {
+            const int r = w * 32 + __ffs(bits) - 1;
+            bits &= bits - 1u;
+            const uint32_t v = __float_as_uint(rval[r]);
+            sk = v > sk ? v : sk;
+            deg[rslot[r]] = 0;
           }
         }
+        for (int o = 32; o > 0; o >>= 1) {
+          cnt += __shfl_xor(cnt, o, 64);
+          const uint32_t t2 = __shfl_xor(sk, o, 64);
+          sk = t2 > sk ? t2 : sk;
+        }
+        // the removed nodes j, listed in S.nz (128 per pass; more than one pass only for cliques above 128), then their
+        // adjacency rows fetched eight at a time so that the row reads of one pass share their latency
+        if (cnt) {
+          int mine = 0;
+          for (int h = 0; h < PCL_W / 64; ++h) mine += __popc(iw[h]);
+          int incl = mine;
+          for (int o = 1; o < 64; o <<= 1) {
+            const int up = __shfl_up(incl, o, 64);
+            if (lane >= o) incl += up;
+          }
+          const int base = incl - mine;
+          for (int pass = 0; pass * PCL_W < cnt; ++pass) {
+            int gi = base;
+            for (int h = 0; h < PCL_W / 64; ++h) {
+              uint32_t bits = iw[h];
+              while (bits) {
+                const int j = (h * 64 + lane) * 32 + __ffs(bits) - 1;
+                bits &= bits - 1u;
+                if (gi / PCL_W == pass) S.nz[gi % PCL_W] = j;
+                ++gi;
+              }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+            const int nlist = min(cnt - pass * PCL_W, PCL_W);
+            for (int g0 = 0; g0 < nlist; g0 += 8) {
+              uint32_t jw[8][PCL_W / 64];
+#pragma unroll
+              for (int u = 0; u < 8; ++u) {
+                const int j = S.nz[min(g0 + u, nlist - 1)];
+                const uint32_t* jrow = staged ? rowbuf + (int)rslot[j] * W32 : p.adj + (long)j * W32;
+#pragma unroll
+                for (int g = 0; g < PCL_W / 64; ++g) {
+                  const int w = g * 64 + lane;
+                  jw[u][g] = (g0 + u < nlist && w < W32) ? jrow[w] : 0u;
+                }
+              }
+#pragma unroll
+              for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int g = 0; g < PCL_W / 64; ++g) {
+                  uint32_t bits = jw[u][g] & lv[g];
+                  while (bits) {
+                    const int r = (g * 64 + lane) * 32 + __ffs(bits) - 1;
+                    bits &= bits - 1u;
+                    atomicSub(&deg[rslot[r]], 1);
+                  }
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+          }
+        }
+        if (lane == 0) { keep_row[nk] = (unsigned short)t; keep_score[nk] = cnt ? __uint_as_float(sk) : 0.f; }
+        ++nk;
+        count -= cnt;
+        __threadfence_block();
+        if (count <= 5 || cnt == 0) break;
       }
-      if (tid == 0) { keep_row[nkeep] = (unsigned short)t; keep_score[nkeep] = cnt ? __uint_as_float((uint32_t)sk) : 0.f; }
-      ++nkeep;
-      count -= cnt;
-      __syncthreads();
-      if (count <= 5 || cnt == 0) break;
+      if (lane == 0) { S.nnz = nk; S.cnt = count; }
     }
+    __syncthreads();
+    const int nkeep = S.nnz;
+    count = S.cnt;
+    PCL_TICK(4)
+#ifdef PCL_PROFILE
+    prof_[8] += nkeep; prof_[9] += count;
+#endif
     // ---- the min(nkeep, 5) best-scoring centres, descending, ties: later entry first (pcl.py:123-125)
     const int take = min(nkeep, 5);
     for (int s = 0; s < take; ++s) {
@@ -405,6 +558,7 @@ __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
     }
     P += take;
     __syncthreads();
+    PCL_TICK(5)
   }
 
   // ---- proposal clusters (pcl.py:143-200)
@@ -415,6 +569,7 @@ __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
   int* cl = reinterpret_cast<int*>(cs + PCL_MAXP);  // [PCL_MAXP]   (4096 floats of sv hold 640*6 = 3840)
   float* roww = reinterpret_cast<float*>(T2);       // [4096] loss weight of each row
   short* rowa = reinterpret_cast<short*>(reinterpret_cast<unsigned char*>(T2) + 16384);  // [4096] assignment
+  float* rowp = reinterpret_cast<float*>(B2);       // [4096] clipped probability of the assigned centre's class
   for (int i = tid; i < P; i += PCL_T) {
     const int row = o_rows[i];
     for (int e = 0; e < 4; ++e) cb[4 * i + e] = p.boxes[4 * (long)row + e];
@@ -443,15 +598,15 @@ __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
     }
     o_labels[r] = lab; o_w[r] = w; o_assign[r] = as;
     roww[r] = w; rowa[r] = (short)as;
+    rowp[r] = as >= 0 ? fmaxf(pnew[(long)r * K1 + lab], EPS9) : 0.f;
   }
   __syncthreads();
   // per centre: sum of weights, member count, mean clipped probability of its class (one wave per centre)
   for (int i = wave; i < P; i += PCL_T / 64) {
     double sw = 0.0, sp = 0.0;
     int n = 0;
-    const int lbl = cl[i];
     for (int r = lane; r < R; r += 64)
-      if (rowa[r] == i) { sw += (double)roww[r]; sp += (double)fmaxf(pnew[(long)r * K1 + lbl], EPS9); ++n; }
+      if (rowa[r] == i) { sw += (double)roww[r]; sp += (double)rowp[r]; ++n; }
     for (int o = 32; o > 0; o >>= 1) { sw += __shfl_xor(sw, o, 64); sp += __shfl_xor(sp, o, 64); n += __shfl_xor(n, o, 64); }
     if (lane == 0) {
       o_iw[i] = (float)sw;
@@ -464,32 +619,57 @@ __global__ __launch_bounds__(PCL_T) void pcl_refine_kernel(PclRefineParams p) {
   }
   if (tid == 0) p.n_pc[b] = P;
   __syncthreads();
+  PCL_TICK(6)
   // ---- loss (pcl_loss_cpu.cpp:8-58) and d loss / d logits through the softmax (pcl_loss_cpu.cpp:60-115)
   const int col0 = p.cols[b];
+  float* rowg = rowp;          // d loss / d prob of the row's own column (the only non-zero entry of its row) / R
+  float* rowgp = rowp + 4096;  // rowg * prob of that column
   for (int q = 0; q < PCL_MAXR / PCL_T; ++q) {
     const int r = q * PCL_T + tid;
     if (r >= R) continue;
-    const float* pr = pnew + (long)r * K1;
     const int as = rowa[r];
-    int lab = 0;
-    float g = 0.f;
+    const int lab = as < 0 ? 0 : cl[as];
+    const float pl = pnew[(long)r * K1 + lab];
+    float g;
     if (as < 0) {
-      const float p0 = pr[0];
-      lsum -= (double)roww[r] * (double)logf(fmaxf(p0, 1e-6f));
-      g = -roww[r] / fmaxf(p0, 1e-5f);
+      lsum -= (double)roww[r] * (double)logf(fmaxf(pl, 1e-6f));
+      g = -roww[r] / fmaxf(pl, 1e-5f);
     } else {
-      lab = cl[as];
       g = p.onehot[lab - 1] != 0.f ? -cs[as] / fmaxf(cb[4 * as + 1] * cb[4 * as], 1e-5f) : 0.f;
     }
     g = g * invR;
-    const float gp = g * pr[lab];
-    float* dl = p.dlogits + (long)r * p.ld + col0;
-    for (int j = 0; j < K1; ++j) dl[j] = pr[j] * ((j == lab ? g : 0.f) - gp);
+    rowg[r] = g;
+    rowgp[r] = g * pl;
+    rowa[r] = (short)lab;
+  }
+  __syncthreads();
+  // softmax backward of the one-hot row gradient, flattened over (row, column): coalesced, 8 loads in flight per thread
+  const int total = R * K1;
+  for (int base = tid; base < total; base += PCL_T * 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * PCL_T;
+      v[u] = idx < total ? pnew[idx] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int idx = base + u * PCL_T;
+      if (idx < total) {
+        const int r = idx / K1, j = idx - r * K1;
+        p.dlogits[(long)r * p.ld + col0 + j] = v[u] * ((j == (int)rowa[r] ? rowg[r] : 0.f) - rowgp[r]);
+      }
+    }
   }
   for (int i = tid; i < P; i += PCL_T)
     if (p.onehot[cl[i] - 1] != 0.f) lsum -= (double)cs[i] * (double)logf(fmaxf(cb[4 * i], 1e-6f));
   const double tot = block_sum_f64(lsum, S);
   if (tid == 0) p.losses[b] = (float)(tot / (double)R);
+  PCL_TICK(7)
+#ifdef PCL_PROFILE
+  if (tid == 0 && b == p.NB - 1)
+    for (int k = 0; k < 10; ++k) o_sc[p.PMAX - 10 + k] = (float)prof_[k];
+#endif
 }
 
 }  // namespace
@@ -526,7 +706,7 @@ int drn_pcl_refine(const float* logits, int ld, const int* cols, int n_branch, i
   for (int b = 0; b < n_branch; ++b) { sp.cols[b] = cols[b]; rp.cols[b] = cols[b]; }
   pcl_softmax_kernel<<<dim3((R + 255) / 256, n_branch), 256, 0, stream>>>(sp);
   DRN_CHECK_LAUNCH();
-  const size_t lds = ((sizeof(PclShared) + 15) & ~size_t(15)) + 16384 + 32776 + 32768 + 32768 + 8192;
+  const size_t lds = ((sizeof(PclShared) + 15) & ~size_t(15)) + 16384 + 32776 + 32768 + 32768 + 8192 + 8192 + PCL_NINV * 8;
   static bool attr_set = false;
   if (!attr_set) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(pcl_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -413,6 +413,29 @@ def test_pcl_targets_and_loss_golden():
         np.testing.assert_allclose(gp, g("dprobs"), rtol=1e-5, atol=1e-9)
 
 
+def test_pcl_kmeans_divide_and_conquer_equals_all_pairs():
+    """the O(n log n) search of kmeans_top_threshold returns the cut the all-pairs search returns (skewed MIL-like
+    scores, softmax-like scores, duplicates, sizes up to 2000)"""
+    from oracle import pcl_oracle as PO
+
+    rs = np.random.RandomState(11)
+    for n in (3, 4, 5, 9, 33, 64, 65, 200, 777, 2000):
+        for rep in range(4 if n < 1000 else 2):
+            if rep == 0:
+                v = rs.rand(n) ** 6
+            elif rep == 1:
+                a = torch.softmax(torch.from_numpy(rs.randn(n, 5) * 3), 1)[:, 0].numpy()
+                b = torch.softmax(torch.from_numpy(rs.randn(n) * 3), 0).numpy()
+                v = a * b
+            elif rep == 2:
+                v = np.round(rs.rand(n) ** 2 * 16) / 16
+            else:
+                v = np.exp(rs.randn(n) * 3) * 1e-4
+            v = np.maximum(v.astype(np.float32), np.float32(1e-9))
+            t_all, _ = PO.kmeans_top_threshold_all_pairs(v)
+            assert PO.kmeans_top_threshold(v) == t_all, (n, rep)
+
+
 def test_pcl_kmeans_exact_optimum_bruteforce():
     """the k-means restatement is the global optimum: brute force over all cut pairs on small inputs, incl. duplicates,
     fewer distinct values than clusters, n < 3"""

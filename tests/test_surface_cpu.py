@@ -51,7 +51,8 @@ def test_full_size_r50_c4_shapes(pkg):
                                             ("wsr101", "PascalVOC-Detection/oicr_WSR_101_DC5_1x.yaml"),
                                             ("vgg16", "PascalVOC-Detection/oicr_V_16_DC5_1x.yaml"),
                                             ("wsr50", "COCO-Detection/oicr_WSR_50_DC5_1x.yaml"),
-                                            ("wsr50", "PascalVOC-Detection/reg/oicr_WSR_50_DC5_1x.yaml")])
+                                            ("wsr50", "PascalVOC-Detection/reg/oicr_WSR_50_DC5_1x.yaml"),
+                                            ("wsr50", "PascalVOC-Detection/pcl_WSR_50_DC5_1x.yaml")])
 def test_unmodified_reference_yaml_loads(pkg, arch, yaml_rel):
     from drn_wsod_pytorch_amd.config import add_wsl_config, get_cfg
     from drn_wsod_pytorch_amd.modeling import build_model
@@ -63,14 +64,15 @@ def test_unmodified_reference_yaml_loads(pkg, arch, yaml_rel):
     add_wsl_config(cfg)
     cfg.merge_from_file(path)
     cfg.merge_from_list(["MODEL.DEVICE", "cpu"])
-    assert cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNNWSL" and cfg.MODEL.ROI_HEADS.NAME == "OICRROIHeads"
+    assert cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNNWSL"
+    assert cfg.MODEL.ROI_HEADS.NAME == ("PCLROIHeads" if "pcl_" in yaml_rel else "OICRROIHeads")
     assert cfg.MODEL.BACKBONE.FREEZE_AT == 5 and cfg.SOLVER.BIAS_LR_FACTOR == 2.0 and cfg.SOLVER.WEIGHT_DECAY_BIAS == 0.0
     assert tuple(cfg.SOLVER.STEPS) == (35000, 50000) or "COCO" in yaml_rel
     if "COCO" not in yaml_rel and "reg/" not in yaml_rel:
         K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
         feat = "plain5" if arch == "vgg16" else "res5"
         ocfg = O.OracleCfg(arch=arch, out_feature=feat, res5_dilation=2, num_classes=K,
-                           dan_dim=tuple(cfg.MODEL.ROI_BOX_HEAD.DAN_DIM), res2_out=cfg.MODEL.RESNETS.RES2_OUT_CHANNELS,
+                           heads="pcl" if "pcl_" in yaml_rel else "oicr", dan_dim=tuple(cfg.MODEL.ROI_BOX_HEAD.DAN_DIM), res2_out=cfg.MODEL.RESNETS.RES2_OUT_CHANNELS,
                            pixel_mean=tuple(cfg.MODEL.PIXEL_MEAN), base_lr=cfg.SOLVER.BASE_LR)
         ref = G.drn_cfg(ocfg, "cpu")
         for key in ("MODEL.ROI_HEADS", "MODEL.ROI_BOX_HEAD", "MODEL.BACKBONE", "WSL"):
@@ -106,9 +108,13 @@ def test_off_path_fails_loudly(pkg):
 
     ocfg = G.MODEL_CASES["model_r50c4_tiny"]
     cfg = G.drn_cfg(ocfg, "cpu")
-    cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "PCLROIHeads"])
+    cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "CSCROIHeads"])  # sibling head that is not built
     with pytest.raises(KeyError):
         build_model(cfg)
+    cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "PCLROIHeads"])  # built: same module tree as OICR
+    m = build_model(cfg)
+    assert type(m.roi_heads).__name__ == "PCLROIHeads" and m.roi_heads.refine_mode == "pcl"
+    assert set(m.state_dict()) == set(_build(ocfg).state_dict())
     model = _build(ocfg)
     model.train()
     batch = G.drn_inputs(G.batch_from(G.load("model_r50c4_tiny")))
