@@ -794,6 +794,12 @@ class OICRROIHeads(ROIHeads):
         obj = torch.cat([p.objectness_logits for p in proposals], dim=0).float().contiguous()
         return nhwc, rois, obj
 
+    def _zero_onehot(self, n_img, K, dev):
+        z = getattr(self, "_zero_oh", None)
+        if z is None or z.shape != (n_img, K) or z.device != dev:
+            z = self._zero_oh = torch.zeros((n_img, K), dtype=torch.float32, device=dev)
+        return z
+
     def prefetch_pooled(self, features, proposals):
         """pool a FUTURE batch's proposals (on whatever stream is current) into the engine's spare buffer set"""
         nhwc, rois, obj = self._gather_inputs(features, proposals)
@@ -853,10 +859,17 @@ class OICRROIHeads(ROIHeads):
         w, col = self._engine.forward(nhwc, rois, obj, False, pooled=pooled)
         heads = [k for k in range(self.refine_K)]
         props = rois[:, 1:].contiguous()
+        last = self.box_refinery[-1] if self.refine_K else self.box_predictor
         if self.refine_K == 0:
-            raise DrnError("WSDDN-only inference is not built yet")
-        last = self.box_refinery[-1]
-        if self.refine_reg[-1]:
+            # WSDDNROIHeads (roi_heads_wsddn.py:305-309 -> WSDDNOutputLayers.inference, fast_rcnn.py:587-608): the MIL
+            # scores with a zero background column, zero deltas
+            off = torch.tensor([0] + list(torch.tensor(nper).cumsum(0).tolist()), dtype=torch.int32).to(dev)
+            zeros = self._zero_onehot(n_img, K, dev)
+            sc, _, _ = ops.wsddn_fwd_bwd(w["logits"], col["cls"], col["det"], K, off, n_img, zeros, max_rows=max(nper))
+            probs = torch.zeros((sc.shape[0], K + 1), dtype=torch.float32, device=dev)
+            probs[:, :K].copy_(sc)
+            boxes = ops.apply_deltas(None, props, K, last.box2box_transform.weights)
+        elif self.refine_reg[-1]:
             probs, _ = ops.softmax_ce(w["logits"], col["r%d" % heads[-1]], K + 1)
             boxes = ops.apply_deltas(w["logits"], props, K, last.box2box_transform.weights, col0=col["b%d" % heads[-1]])
         else:
@@ -890,7 +903,8 @@ class PCLROIHeads(OICRROIHeads):
 
 @ROI_HEADS_REGISTRY.register()
 class WSDDNROIHeads(OICRROIHeads):
-    """roi_heads_wsddn.py: the OICR heads without refinement branches (training only on this path)."""
+    """roi_heads_wsddn.py: the MIL head alone (no refinement branches); inference scores are the MIL scores
+    (WSDDNOutputLayers.inference, fast_rcnn.py:587-608)."""
 
     _refine_from_cfg = False
 

@@ -270,7 +270,8 @@ class OracleCfg:
     bias_lr_factor: float = 2.0
     weight_decay_bias: float = 0.0
     width_per_group: int = 64  # MODEL.RESNETS.WIDTH_PER_GROUP (bottleneck width of res2)
-    heads: str = "oicr"  # MODEL.ROI_HEADS.NAME: "oicr" (OICRROIHeads) | "pcl" (PCLROIHeads, oracle/pcl_oracle.py)
+    heads: str = "oicr"  # MODEL.ROI_HEADS.NAME: "oicr" (OICRROIHeads) | "pcl" (PCLROIHeads, oracle/pcl_oracle.py) |
+                         # "wsddn" (WSDDNROIHeads: refine_num = 0)
 
     @property
     def blocks(self):
@@ -609,7 +610,13 @@ def roi_heads_inference(p, feat, prop_boxes, objectness, image_sizes, cfg: Oracl
     obn = torch.cat([o + 1 for o in objectness], dim=0)
     x = dan_forward(p, pooled * obn.view(-1, 1, 1, 1), cfg, False)
     props_cat = torch.cat(prop_boxes, dim=0)
-    if cfg.refine_reg[-1]:
+    if cfg.refine_num == 0:
+        # WSDDNROIHeads (roi_heads_wsddn.py:305-309): WSDDNOutputLayers.inference, fast_rcnn.py:587-608 - the MIL scores
+        # themselves with a zero background column (predict_probs :668-687), zero deltas (predict_boxes :645-666)
+        scores = wsddn_scores(p, x, nper)
+        probs = torch.cat((scores, torch.zeros(scores.shape[0], 1)), dim=1)
+        deltas = torch.zeros(x.shape[0], 4 * K)
+    elif cfg.refine_reg[-1]:
         pre = "roi_heads.box_refinery_%d." % (cfg.refine_num - 1)
         probs = F.softmax(F.linear(x, p[pre + "cls_score.weight"], p[pre + "cls_score.bias"]), dim=-1)
         deltas = F.linear(x, p[pre + "bbox_pred.weight"], p[pre + "bbox_pred.bias"])

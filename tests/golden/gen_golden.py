@@ -728,6 +728,9 @@ if __name__ == "__main__":
     if "tta" in which:
         case_tta("tta_r50c4_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 38, 48, 60, 84,
                  (48, 72), 96, 40)
+    if "wsddn" in which:
+        case_full_model("model_wsddn_r50c4_tiny", "PascalVOC-Detection/wsddn_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 40, 2,
+                        48, 128, 96)
     if "pclmodel" in which:
         # the reference's _PCLLoss moves its output with .cuda(device_id) (wsl/layers/pcl_loss.py:51,91): without a
         # GPU in this container that call is made the identity for this case (environment shim, like PIL.Image.LINEAR)

@@ -27,6 +27,8 @@ MODEL_CASES = {
     "model_r50c4_dropmask_tiny": O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1, **TINY),
     "model_r50c4_reg_tiny": O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1, refine_num=4,
                                         refine_reg=(False, False, False, True), **TINY),
+    "model_wsddn_r50c4_tiny": O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1, heads="wsddn", refine_num=0,
+                                          refine_reg=(), score_thresh=1e-9, nms_thresh=0.5, mean_loss=False, **TINY),
     "model_pcl_r50c4_tiny": O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1, heads="pcl", **TINY),
 }
 FREEZE_AT = {"model_r50c4_align_tiny": 3}
@@ -73,14 +75,14 @@ def drn_cfg(ocfg, device="cuda", freeze_at=5):
     L = ["MODEL.META_ARCHITECTURE", "GeneralizedRCNNWSL", "MODEL.DEVICE", device, "MODEL.LOAD_PROPOSALS", "True",
          "MODEL.PIXEL_MEAN", str(list(ocfg.pixel_mean)), "MODEL.BACKBONE.FREEZE_AT", str(freeze_at),
          "MODEL.BACKBONE.NAME", "build_vgg_backbone" if vgg else "build_ws_resnet_backbone",
-         "MODEL.ROI_HEADS.NAME", "PCLROIHeads" if ocfg.heads == "pcl" else "OICRROIHeads", "MODEL.ROI_HEADS.NUM_CLASSES", str(ocfg.num_classes),
-         "MODEL.ROI_HEADS.IN_FEATURES", str([feat]), "MODEL.ROI_HEADS.SCORE_THRESH_TEST", "0.00001",
-         "MODEL.ROI_HEADS.NMS_THRESH_TEST", "0.3", "MODEL.ROI_HEADS.PROPOSAL_APPEND_GT", "False",
+         "MODEL.ROI_HEADS.NAME", {"pcl": "PCLROIHeads", "wsddn": "WSDDNROIHeads"}.get(ocfg.heads, "OICRROIHeads"), "MODEL.ROI_HEADS.NUM_CLASSES", str(ocfg.num_classes),
+         "MODEL.ROI_HEADS.IN_FEATURES", str([feat]), "MODEL.ROI_HEADS.SCORE_THRESH_TEST", repr(ocfg.score_thresh),
+         "MODEL.ROI_HEADS.NMS_THRESH_TEST", repr(ocfg.nms_thresh), "MODEL.ROI_HEADS.PROPOSAL_APPEND_GT", "False",
          "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", "4096", "MODEL.ROI_HEADS.POSITIVE_FRACTION", "1.0",
          "MODEL.ROI_BOX_HEAD.NAME", "DiscriminativeAdaptionNeck", "MODEL.ROI_BOX_HEAD.POOLER_TYPE", ocfg.pooler_type,
          "MODEL.ROI_BOX_HEAD.POOLER_RESOLUTION", str(ocfg.pooler_res), "MODEL.ROI_BOX_HEAD.NUM_CONV", "0",
          "MODEL.ROI_BOX_HEAD.NUM_FC", "2", "MODEL.ROI_BOX_HEAD.DAN_DIM", str(list(ocfg.dan_dim)),
-         "WSL.REFINE_NUM", str(ocfg.refine_num), "WSL.REFINE_REG", str(list(ocfg.refine_reg)),
+         "WSL.MEAN_LOSS", str(bool(ocfg.mean_loss)), "WSL.REFINE_NUM", str(ocfg.refine_num), "WSL.REFINE_REG", str(list(ocfg.refine_reg)),
          "SOLVER.BASE_LR", str(ocfg.base_lr), "SOLVER.WEIGHT_DECAY", "0.0005", "SOLVER.BIAS_LR_FACTOR", "2.0",
          "SOLVER.WEIGHT_DECAY_BIAS", "0.0", "SOLVER.WARMUP_ITERS", "0", "SOLVER.STEPS", "(35000, 50000)",
          "SOLVER.MAX_ITER", "50000", "SOLVER.IMS_PER_BATCH", "4"]

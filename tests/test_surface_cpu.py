@@ -52,7 +52,8 @@ def test_full_size_r50_c4_shapes(pkg):
                                             ("vgg16", "PascalVOC-Detection/oicr_V_16_DC5_1x.yaml"),
                                             ("wsr50", "COCO-Detection/oicr_WSR_50_DC5_1x.yaml"),
                                             ("wsr50", "PascalVOC-Detection/reg/oicr_WSR_50_DC5_1x.yaml"),
-                                            ("wsr50", "PascalVOC-Detection/pcl_WSR_50_DC5_1x.yaml")])
+                                            ("wsr50", "PascalVOC-Detection/pcl_WSR_50_DC5_1x.yaml"),
+                                            ("wsr50", "PascalVOC-Detection/wsddn_WSR_50_DC5_1x.yaml")])
 def test_unmodified_reference_yaml_loads(pkg, arch, yaml_rel):
     from drn_wsod_pytorch_amd.config import add_wsl_config, get_cfg
     from drn_wsod_pytorch_amd.modeling import build_model
@@ -65,9 +66,15 @@ def test_unmodified_reference_yaml_loads(pkg, arch, yaml_rel):
     cfg.merge_from_file(path)
     cfg.merge_from_list(["MODEL.DEVICE", "cpu"])
     assert cfg.MODEL.META_ARCHITECTURE == "GeneralizedRCNNWSL"
-    assert cfg.MODEL.ROI_HEADS.NAME == ("PCLROIHeads" if "pcl_" in yaml_rel else "OICRROIHeads")
+    base = os.path.basename(yaml_rel)
+    assert cfg.MODEL.ROI_HEADS.NAME == {"pcl": "PCLROIHeads", "wsddn": "WSDDNROIHeads"}.get(base.split("_")[0], "OICRROIHeads")
     assert cfg.MODEL.BACKBONE.FREEZE_AT == 5 and cfg.SOLVER.BIAS_LR_FACTOR == 2.0 and cfg.SOLVER.WEIGHT_DECAY_BIAS == 0.0
-    assert tuple(cfg.SOLVER.STEPS) == (35000, 50000) or "COCO" in yaml_rel
+    assert tuple(cfg.SOLVER.STEPS) == (35000, 50000) or "COCO" in yaml_rel or base.startswith("wsddn")
+    if base.startswith("wsddn"):
+        assert cfg.WSL.MEAN_LOSS is False and cfg.WSL.ITER_SIZE == 32 and cfg.MODEL.ROI_HEADS.NMS_THRESH_TEST == 0.5
+        m = build_model(cfg)
+        assert type(m.roi_heads).__name__ == "WSDDNROIHeads" and not any("box_refinery" in k for k in m.state_dict())
+        return
     if "COCO" not in yaml_rel and "reg/" not in yaml_rel:
         K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
         feat = "plain5" if arch == "vgg16" else "res5"
