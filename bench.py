@@ -79,30 +79,33 @@ def init_weights(model, seed):
         t.copy_(v.to(t.device))
 
 
-def synthetic_batches(n_batches, R, K, device, rank, pkg):
+def synthetic_batches(n_batches, R, K, device, rank, pkg, ims=1):
     """SURVEY §8(d): image uint8-valued f32 [3,224,224]; proposals x0,y0 ~ U[0,184), w,h ~ U[20, 224-x0|y0];
     objectness ~ U[0,1) sorted descending; 1..3 distinct GT classes; seed = 1234 + 1000*rank + iter."""
     from drn_wsod_pytorch_amd.structures import Boxes, Instances
 
     out = []
     for it in range(n_batches):
-        g = torch.Generator().manual_seed(1234 + 1000 * rank + it)
-        img = torch.randint(0, 256, (3, 224, 224), generator=g).float()
-        x0, y0 = torch.rand(R, generator=g) * 184, torch.rand(R, generator=g) * 184
-        bw = 20 + torch.rand(R, generator=g) * (224 - x0 - 20)
-        bh = 20 + torch.rand(R, generator=g) * (224 - y0 - 20)
-        boxes = torch.stack([x0, y0, (x0 + bw).clamp(max=224), (y0 + bh).clamp(max=224)], 1)
-        obj = torch.sort(torch.rand(R, generator=g), descending=True).values
-        G = int(torch.randint(1, 4, (1,), generator=g))
-        cls = torch.randperm(K, generator=g)[:G].to(torch.int64)
-        prop = Instances((224, 224))
-        prop.proposal_boxes = Boxes(boxes.to(device))
-        prop.objectness_logits = obj.to(device)
-        inst = Instances((224, 224))
-        inst.gt_boxes = Boxes(boxes[:G].clone())
-        inst.gt_classes = cls  # image-level labels stay on the host (that is where the loader produces them)
-        out.append([{"image": img.to(device), "proposals": prop, "instances": inst, "height": 224, "width": 224,
-                     "_cpu": {"image": img, "proposal_boxes": boxes, "objectness_logits": obj, "gt_classes": cls}}])
+        batch = []
+        for im in range(ims):
+            g = torch.Generator().manual_seed(1234 + 1000 * rank + it + 100000 * im)
+            img = torch.randint(0, 256, (3, 224, 224), generator=g).float()
+            x0, y0 = torch.rand(R, generator=g) * 184, torch.rand(R, generator=g) * 184
+            bw = 20 + torch.rand(R, generator=g) * (224 - x0 - 20)
+            bh = 20 + torch.rand(R, generator=g) * (224 - y0 - 20)
+            boxes = torch.stack([x0, y0, (x0 + bw).clamp(max=224), (y0 + bh).clamp(max=224)], 1)
+            obj = torch.sort(torch.rand(R, generator=g), descending=True).values
+            G = int(torch.randint(1, 4, (1,), generator=g))
+            cls = torch.randperm(K, generator=g)[:G].to(torch.int64)
+            prop = Instances((224, 224))
+            prop.proposal_boxes = Boxes(boxes.to(device))
+            prop.objectness_logits = obj.to(device)
+            inst = Instances((224, 224))
+            inst.gt_boxes = Boxes(boxes[:G].clone())
+            inst.gt_classes = cls  # image-level labels stay on the host (that is where the loader produces them)
+            batch.append({"image": img.to(device), "proposals": prop, "instances": inst, "height": 224, "width": 224,
+                          "_cpu": {"image": img, "proposal_boxes": boxes, "objectness_logits": obj, "gt_classes": cls}})
+        out.append(batch)
     return out
 
 
@@ -216,6 +219,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--ims-per-gpu", type=int, default=1,
+                    help="images per GPU per iteration; 1 = the reference's operating point and the headline metric, "
+                         "larger values are the side measurement SURVEY 8(d) asks for")
     ap.add_argument("--heads", choices=["oicr", "pcl"], default="oicr",
                     help="oicr = the BASELINE workload; pcl = PCLROIHeads on the same trunk (SURVEY 8f rank 4; a side "
                          "measurement, not the headline metric)")
@@ -277,7 +283,7 @@ def main():
         if world == 1 and args.fused_sgd:
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
-    batches = synthetic_batches(8, R, K, device, rank, pkg)
+    batches = synthetic_batches(8, R, K, device, rank, pkg, args.ims_per_gpu)
 
     def step(i):
         losses = model(batches[i % len(batches)])
@@ -358,13 +364,13 @@ def main():
                     "avg_launch_ms": ms, "launches_timed": len(fwd),
                     "timed_in": "eager warm-up steps of this run (HIP events on the launch stream)" if use_graph
                     else "the timed region (HIP events on the launch stream)"}
-        out = {"metric": METRIC, "value": world * args.steps / dt, "unit": "images/sec", "n_gpus": world,
+        out = {"metric": METRIC, "value": world * args.ims_per_gpu * args.steps / dt, "unit": "images/sec", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
                "config": {"workload": "DRN-WSOD ResNet50-WS C4 (res4 out, stride 16), VOC07-shaped synthetic 224x224, "
-                                      "%d proposals/img, 1 img/GPU/iter, K=20, 3 %s refinements, frozen backbone "
-                                      "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % (R, args.heads.upper()),
-                          "global_batch": world, "proposals": R, "parallelism": "dp%d" % world},
+                                      "%d proposals/img, %d img/GPU/iter, K=20, 3 %s refinements, frozen backbone "
+                                      "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % (R, args.ims_per_gpu, args.heads.upper()),
+                          "global_batch": world * args.ims_per_gpu, "proposals": R, "parallelism": "dp%d" % world},
                "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph),
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
                "grad_exchange": None if not dp.exchange else {
