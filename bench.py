@@ -219,6 +219,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--slab-rows", default=None,
+                    help="comma-separated row ends of the fc6 dW slabs (experiment knob; default = the engine's choice)")
     ap.add_argument("--ims-per-gpu", type=int, default=1,
                     help="images per GPU per iteration; 1 = the reference's operating point and the headline metric, "
                          "larger values are the side measurement SURVEY 8(d) asks for")
@@ -279,7 +281,8 @@ def main():
     dp.broadcast_parameters(0)
     if not args.no_pipelined_sgd:
         # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
-        opt.enable_pipelined(dp, comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype])
+        opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
+                             comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype])
         if world == 1 and args.fused_sgd:
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
