@@ -122,6 +122,51 @@ def test_pcl_refine_cascade_vs_oracle(drn, R, K, nb, seed):
         prev = out[k]["probs"].cpu().numpy()
 
 
+@pytest.mark.parametrize("case", ["one_proposal", "constant_scores", "zero_area_boxes", "no_labels", "duplicates"])
+def test_pcl_edge_cases_vs_oracle(drn, case):
+    """degenerate inputs: a single proposal; all scores equal (one k-means cluster = every proposal); zero-area boxes
+    (no self edge in the IoU graph: the greedy loop ends on an empty clique and the centre gets score 0, its cluster
+    is empty -> NaN mean probability that fmaxf turns into eps exactly like pcl_loss_cpu.cpp); an image without labels
+    (no centres, loss 0); duplicated proposals (a later centre with an empty cluster)"""
+    from oracle import pcl_oracle as PO
+
+    rs = np.random.RandomState(9)
+    K, R = 4, 40
+    x0, y0 = rs.rand(R) * 100, rs.rand(R) * 80
+    boxes = np.stack([x0, y0, x0 + 20 + rs.rand(R) * 60, y0 + 20 + rs.rand(R) * 50], 1).astype(np.float32)
+    im = np.array([1, 0, 1, 0], dtype=np.float32)
+    last = (torch.softmax(torch.from_numpy(rs.randn(R, K).astype(np.float32) * 2), 1) *
+            torch.softmax(torch.from_numpy(rs.randn(R, K).astype(np.float32) * 3), 0)).numpy()
+    if case == "one_proposal":
+        boxes, last, R = boxes[:1], last[:1], 1
+    elif case == "constant_scores":
+        last = np.full_like(last, 0.01)
+    elif case == "zero_area_boxes":
+        boxes[:, 2] = boxes[:, 0]
+    elif case == "no_labels":
+        im = np.zeros(K, dtype=np.float32)
+    elif case == "duplicates":
+        boxes[1::2] = boxes[0::2]
+        last[1::2] = last[0::2]
+    logits = [rs.randn(R, K + 1).astype(np.float32) * 2.0 for _ in range(2)]
+    out, dl, cols, _ = _run(drn, logits, np.ascontiguousarray(last), np.ascontiguousarray(boxes), im)
+    prev = last
+    for k in range(2):
+        with np.errstate(all="ignore"):
+            loss, dlog, probs, t = PO.pcl_refine_loss(logits[k], boxes, prev, im)
+        n = int(out[k]["n_pc"].item())
+        assert n == len(t["pc_labels"]), (case, k)
+        assert np.array_equal(out[k]["labels"].cpu().numpy(), t["labels"]), (case, k)
+        assert np.array_equal(out[k]["gt_assignment"].cpu().numpy(), t["gt_assignment"]), (case, k)
+        assert np.array_equal(out[k]["pc_rows"].cpu().numpy()[:n], t["centre_rows"]), (case, k)
+        assert np.array_equal(out[k]["pc_count"].cpu().numpy()[:n], t["pc_count"]), (case, k)
+        np.testing.assert_allclose(out[k]["pc_probs"].cpu().numpy()[:n], t["pc_probs"], rtol=1e-5, equal_nan=True)
+        got = float(out[k]["loss"].item())
+        assert np.isfinite(got) and abs(got - float(loss)) <= 1e-5 * max(1.0, abs(float(loss))), (case, k, got, loss)
+        np.testing.assert_allclose(dl[:, cols[k]: cols[k] + K + 1], dlog, rtol=2e-4, atol=1e-8)
+        prev = out[k]["probs"].cpu().numpy()
+
+
 def test_pcl_limits(drn):
     from drn_wsod_pytorch_amd._cabi import DrnError
 
