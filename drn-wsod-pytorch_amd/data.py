@@ -16,6 +16,10 @@ fvcore's HFlip / Crop / Blend transforms and Transform.apply_box are external to
 semantics are restated.  Augmentations draw from np.random in the reference's order, so a seeded run reproduces the
 reference's crops / scales / flips / colour factors draw for draw (tests/golden/data_mapper.npz).
 
+  TrainingSampler, InferenceSampler  detectron2/data/samplers/distributed_sampler.py:12-56, :172-200 (the data-parallel
+                                   partition of SURVEY 8(e): rank g takes elements g, g+W, ... of ONE shared shuffled stream)
+  AspectRatioGroupedDataset,       detectron2/data/common.py:115-149, :17-73; detectron2/data/build.py:249-296, :299-354
+  MapDataset, build_batch_data_loader, build_detection_train_loader
 This is host-side preparation by design (as in the reference: loader workers); everything it emits is what
 GeneralizedRCNNWSL.forward consumes."""
 import copy
@@ -30,7 +34,9 @@ from .structures import Boxes, Instances
 
 __all__ = ["BoxMode", "DatasetMapper", "build_augmentation", "load_proposals_into_dataset", "read_image",
            "transform_proposals", "transform_instance_annotations", "annotations_to_instances", "filter_empty_instances",
-           "ResizeShortestEdge", "RandomFlip", "RandomCrop", "RandomBrightness", "RandomSaturation", "TransformList"]
+           "ResizeShortestEdge", "RandomFlip", "RandomCrop", "RandomBrightness", "RandomSaturation", "TransformList",
+           "TrainingSampler", "InferenceSampler", "AspectRatioGroupedDataset", "MapDataset", "build_batch_data_loader",
+           "build_detection_train_loader"]
 
 
 class BoxMode:
@@ -355,3 +361,156 @@ class DatasetMapper:
                      if o.get("iscrowd", 0) == 0]
             d["instances"] = filter_empty_instances(annotations_to_instances(annos, shape))
         return d
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# samplers and the batch loader (how the images are partitioned over the ranks)
+# ---------------------------------------------------------------------------------------------------------------------
+def _rank_world(rank, world_size):
+    import torch.distributed as dist
+
+    if rank is None or world_size is None:
+        if dist.is_available() and dist.is_initialized():
+            return dist.get_rank(), dist.get_world_size()
+        return 0, 1
+    return int(rank), int(world_size)
+
+
+class TrainingSampler:
+    """distributed_sampler.py:12-56: an infinite stream shuffle(range(size)) + shuffle(range(size)) + ... drawn from ONE
+    generator seeded identically on every rank; rank g yields elements g, g+W, g+2W, ... of it.  `seed=None` asks the
+    ranks to agree on one (comm.shared_random_seed: rank 0's draw broadcast to all)."""
+
+    def __init__(self, size, shuffle=True, seed=None, rank=None, world_size=None):
+        assert size > 0
+        self._size, self._shuffle = size, shuffle
+        self._rank, self._world_size = _rank_world(rank, world_size)
+        if seed is None:
+            seed = _shared_random_seed()
+        self._seed = int(seed)
+
+    def __iter__(self):
+        import itertools
+
+        yield from itertools.islice(self._infinite_indices(), self._rank, None, self._world_size)
+
+    def _infinite_indices(self):
+        g = torch.Generator()
+        g.manual_seed(self._seed)
+        while True:
+            if self._shuffle:
+                yield from torch.randperm(self._size, generator=g)
+            else:
+                yield from torch.arange(self._size)
+
+
+def _shared_random_seed():
+    """detectron2/utils/comm.py shared_random_seed: every rank draws, rank 0's value wins"""
+    import torch.distributed as dist
+
+    seed = int(np.random.randint(2 ** 31))
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        box = [seed]
+        dist.broadcast_object_list(box, src=0)
+        seed = int(box[0])
+    return seed
+
+
+class InferenceSampler:
+    """distributed_sampler.py:172-200: contiguous shards of ceil(size / W) indices; the last ranks may get fewer / none"""
+
+    def __init__(self, size, rank=None, world_size=None):
+        assert size > 0
+        self._size = size
+        self._rank, self._world_size = _rank_world(rank, world_size)
+        shard = (size - 1) // self._world_size + 1
+        self._local_indices = range(shard * self._rank, min(shard * (self._rank + 1), size))
+
+    def __iter__(self):
+        yield from self._local_indices
+
+    def __len__(self):
+        return len(self._local_indices)
+
+
+class MapDataset:
+    """detectron2/data/common.py:17-73: dataset[idx] -> map_func(dataset[idx]); when the mapper returns None (an image
+    it cannot use) another index is drawn from random.Random(42) until one maps"""
+
+    def __init__(self, dataset, map_func):
+        import random
+
+        self._dataset, self._map_func = dataset, map_func
+        self._rng = random.Random(42)
+        self._fallback_candidates = set(range(len(dataset)))
+
+    def __len__(self):
+        return len(self._dataset)
+
+    def __getitem__(self, idx):
+        retry, cur = 0, int(idx)
+        while True:
+            data = self._map_func(self._dataset[cur])
+            if data is not None:
+                self._fallback_candidates.add(cur)
+                return data
+            retry += 1
+            self._fallback_candidates.discard(cur)
+            cur = self._rng.sample(sorted(self._fallback_candidates), k=1)[0]
+            if retry >= 3 and retry % 3 == 0:
+                import logging
+
+                logging.getLogger(__name__).warning("Failed to apply `_map_func` for idx: %d, retry count: %d", idx, retry)
+
+
+class AspectRatioGroupedDataset:
+    """detectron2/data/common.py:115-149: two buckets (w > h, else); a bucket is emitted when it reaches batch_size"""
+
+    def __init__(self, dataset, batch_size):
+        self.dataset, self.batch_size = dataset, batch_size
+        self._buckets = [[] for _ in range(2)]
+
+    def __iter__(self):
+        for d in self.dataset:
+            bucket = self._buckets[0 if d["width"] > d["height"] else 1]
+            bucket.append(d)
+            if len(bucket) == self.batch_size:
+                yield bucket[:]
+                del bucket[:]
+
+
+def build_batch_data_loader(dataset, sampler, total_batch_size, *, aspect_ratio_grouping=False, num_workers=0,
+                            world_size=None):
+    """detectron2/data/build.py:249-296: per-rank batch = total_batch_size / W (must divide); with grouping the elements
+    flow one by one into AspectRatioGroupedDataset, otherwise consecutive sampler indices form a batch (incomplete
+    batches dropped).  torch's DataLoader carries the worker processes exactly as in the reference."""
+    import operator
+
+    world = _rank_world(None, None)[1] if world_size is None else int(world_size)
+    if total_batch_size <= 0 or total_batch_size % world != 0:
+        raise DrnError("Total batch size (%d) must be divisible by the number of gpus (%d)." % (total_batch_size, world))
+    batch_size = total_batch_size // world
+    if aspect_ratio_grouping:
+        loader = torch.utils.data.DataLoader(dataset, sampler=sampler, num_workers=num_workers, batch_sampler=None,
+                                             collate_fn=operator.itemgetter(0))
+        return AspectRatioGroupedDataset(loader, batch_size)
+    batch_sampler = torch.utils.data.sampler.BatchSampler(sampler, batch_size, drop_last=True)
+    return torch.utils.data.DataLoader(dataset, num_workers=num_workers, batch_sampler=batch_sampler,
+                                       collate_fn=lambda batch: batch)
+
+
+def build_detection_train_loader(cfg, dataset_dicts, mapper=None, *, rank=None, world_size=None):
+    """detectron2/data/build.py:299-354 without the dataset registry (out of scope: the caller passes the list of dataset
+    dicts, e.g. after load_proposals_into_dataset): DatasetMapper(cfg, True) by default, TrainingSampler, batches of
+    SOLVER.IMS_PER_BATCH / W images grouped by aspect ratio (DATALOADER.ASPECT_RATIO_GROUPING)."""
+    if mapper is None:
+        mapper = DatasetMapper(cfg, True)
+    dataset = MapDataset(dataset_dicts, mapper)
+    name = cfg.DATALOADER.SAMPLER_TRAIN
+    if name != "TrainingSampler":
+        raise DrnError("training sampler %r is not on the WSL path (every projects/WSL yaml uses TrainingSampler)" % name)
+    r, w = _rank_world(rank, world_size)
+    sampler = TrainingSampler(len(dataset), rank=r, world_size=w)
+    return build_batch_data_loader(dataset, sampler, cfg.SOLVER.IMS_PER_BATCH,
+                                   aspect_ratio_grouping=cfg.DATALOADER.ASPECT_RATIO_GROUPING,
+                                   num_workers=cfg.DATALOADER.NUM_WORKERS, world_size=w)

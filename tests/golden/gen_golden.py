@@ -185,6 +185,44 @@ def case_full_model(name, yaml_rel, opts, seed, n_img, R, H, W, dropmask=False, 
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: v for k, v in d.items() if k.startswith("step")})
 
 
+def case_samplers(name):
+    """the data-parallel partition: the reference's TrainingSampler / InferenceSampler per rank (this
+    container runs one process: comm.get_rank / get_world_size are pointed at the rank being recorded),
+    AspectRatioGroupedDataset batches and MapDataset's fallback draws"""
+    rh.install()
+    import importlib
+
+    ds = importlib.import_module("detectron2.data.samplers.distributed_sampler")
+    common = importlib.import_module("detectron2.data.common")
+    import itertools
+
+    d = {}
+    for tag, size, seed, world, shuffle, n in (("a", 37, 11, 4, True, 25), ("b", 5, 3, 2, False, 12), ("c", 8, 5, 1, True, 20)):
+        for r in range(world):
+            ds.comm.get_rank, ds.comm.get_world_size = (lambda r=r: r), (lambda world=world: world)
+            smp = ds.TrainingSampler(size, shuffle=shuffle, seed=seed)
+            d["train_%s_r%d" % (tag, r)] = np.array([int(x) for x in itertools.islice(iter(smp), n)], dtype=np.int64)
+        d["train_%s_cfg" % tag] = np.array([size, seed, world, int(shuffle), n], dtype=np.int64)
+    for tag, size, world in (("a", 10, 4), ("b", 3, 4), ("c", 8, 8), ("d", 1, 1), ("e", 4952, 8)):
+        for r in range(world):
+            ds.comm.get_rank, ds.comm.get_world_size = (lambda r=r: r), (lambda world=world: world)
+            smp = ds.InferenceSampler(size)
+            d["infer_%s_r%d" % (tag, r)] = np.array(list(smp), dtype=np.int64)
+        d["infer_%s_cfg" % tag] = np.array([size, world], dtype=np.int64)
+    rs = np.random.RandomState(7)
+    wh = rs.randint(100, 500, size=(23, 2))
+    wh[5] = (300, 300)
+    items = [{"width": int(w), "height": int(h), "id": i} for i, (w, h) in enumerate(wh)]
+    batches = [[x["id"] for x in b] for b in common.AspectRatioGroupedDataset(items, 3)]
+    d["group_wh"] = wh.astype(np.int64)
+    d["group_batches"] = np.array(batches, dtype=np.int64)
+    md = common.MapDataset(list(range(10)), lambda x: None if x % 3 == 0 else x * 10)
+    d["map_out"] = np.array([md[i] for i in range(10)] + [md[i] for i in range(10)], dtype=np.int64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, {k: v.tolist() for k, v in d.items() if k in ("train_a_r1", "infer_a_r3", "map_out")})
+
+
 def case_pcl_unit(name, seed, n_try=40):
     """PCL targets and loss, op level: the reference's own PCL() (third_party/pcl.py, with the scikit-learn installed
     here) and its pcl_loss_cpu.cpp (compiled in place).  Two steps of PCL() are not functions of their inputs
@@ -728,6 +766,8 @@ if __name__ == "__main__":
     if "tta" in which:
         case_tta("tta_r50c4_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 38, 48, 60, 84,
                  (48, 72), 96, 40)
+    if "samplers" in which:
+        case_samplers("samplers")
     if "wsddn" in which:
         case_full_model("model_wsddn_r50c4_tiny", "PascalVOC-Detection/wsddn_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 40, 2,
                         48, 128, 96)

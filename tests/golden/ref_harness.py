@@ -30,7 +30,7 @@ AUTO_STUB = (
 # transforms and its GeneralizedRCNNWithTTAAVG are imported for real; their parents stay stubs)
 REAL_UNDER_STUB = ("detectron2.data.transforms", "wsl.modeling.test_time_augmentation_avg", "detectron2.data.build",
                    "detectron2.data.detection_utils", "detectron2.data.dataset_mapper",
-                   "detectron2.evaluation.pascal_voc_evaluation")
+                   "detectron2.evaluation.pascal_voc_evaluation", "detectron2.data.samplers", "detectron2.data.common")
 REAL_PATHS = {"detectron2.data": os.path.join(REF, "detectron2", "data"),
               "detectron2.evaluation": os.path.join(REF, "detectron2", "evaluation")}
 

@@ -702,6 +702,18 @@ def test_dataset_mapper_output_trains(tmp_path):
     sum(losses.values()).backward()
     opt.step()
     assert all(torch.isfinite(v).all() for v in losses.values()) and set(losses) >= {"loss_cls", "loss_cls_r0"}
+    # the batch loader (TrainingSampler -> MapDataset(DatasetMapper) -> aspect-ratio buckets) yields the same kind of batch
+    many = [dict(recs[0], image_id=123 + i) for i in range(5)]
+    cfg.merge_from_list(["SOLVER.IMS_PER_BATCH", "2", "DATALOADER.NUM_WORKERS", "0"])
+    it = iter(D.build_detection_train_loader(cfg, many, rank=0, world_size=1))
+    for _ in range(2):
+        b = next(it)
+        assert len(b) == 2 and all("proposals" in x and "instances" in x for x in b)
+        opt.zero_grad()
+        losses = model(b)
+        sum(losses.values()).backward()
+        opt.step()
+        assert all(torch.isfinite(v).all() for v in losses.values())
     model.eval()
     out = model([D.DatasetMapper(cfg, False)(recs[0])])
     assert len(out) == 1 and len(out[0]["instances"]) <= cfg.TEST.DETECTIONS_PER_IMAGE

@@ -330,3 +330,53 @@ def test_voc_evaluation_matches_reference_golden():
     assert abs(res["bbox"]["AP50"] - np.mean(ap50)) < 1e-9
     cl50 = [d["corloc_y07"][0, ci] for ci in range(len(classes))]
     assert abs(res["bbox CorLoc"]["CL50"] - np.mean(cl50)) < 1e-9
+
+
+def test_samplers_and_batch_loader_match_reference_golden(pkg):
+    """SURVEY 8(e) partition: TrainingSampler (rank g takes elements g, g+W, ... of one shared shuffled stream),
+    InferenceSampler shards, AspectRatioGroupedDataset batches and MapDataset's fallback draws, index for index against
+    the reference's own classes (tests/golden/samplers.npz); then the batch loader built on them"""
+    import itertools
+
+    import numpy as np
+
+    from drn_wsod_pytorch_amd import data as D
+
+    d = G.load("samplers")
+    for tag in "abc":
+        size, seed, world, shuffle, n = (int(x) for x in d["train_%s_cfg" % tag])
+        streams = []
+        for r in range(world):
+            got = [int(x) for x in itertools.islice(iter(D.TrainingSampler(size, bool(shuffle), seed, r, world)), n)]
+            assert got == d["train_%s_r%d" % (tag, r)].tolist(), (tag, r)
+            streams.append(got)
+        # the ranks interleave back into ONE stream of whole permutations
+        merged = [streams[i % world][i // world] for i in range(world * n)]
+        assert sorted(merged[:size]) == list(range(size))
+    for tag in "abcde":
+        size, world = (int(x) for x in d["infer_%s_cfg" % tag])
+        allidx = []
+        for r in range(world):
+            s = D.InferenceSampler(size, r, world)
+            assert list(s) == d["infer_%s_r%d" % (tag, r)].tolist() and len(s) == len(d["infer_%s_r%d" % (tag, r)])
+            allidx += list(s)
+        assert allidx == list(range(size))  # every sample exactly once
+    items = [{"width": int(w), "height": int(h), "id": i} for i, (w, h) in enumerate(d["group_wh"])]
+    got = [[x["id"] for x in b] for b in D.AspectRatioGroupedDataset(items, 3)]
+    assert got == d["group_batches"].tolist()
+    md = D.MapDataset(list(range(10)), lambda x: None if x % 3 == 0 else x * 10)
+    assert [md[i] for i in range(10)] + [md[i] for i in range(10)] == d["map_out"].tolist()
+    # loader: 2 ranks, IMS_PER_BATCH 4 -> 2 images per rank and step; grouped and plain
+    ds = [{"width": 200 + 10 * (i % 3), "height": 210, "id": i} for i in range(11)]
+    for grouping in (False, True):
+        per_rank = []
+        for r in range(2):
+            loader = D.build_batch_data_loader(D.MapDataset(ds, lambda x: x), D.TrainingSampler(len(ds), True, 5, r, 2), 4,
+                                               aspect_ratio_grouping=grouping, num_workers=0, world_size=2)
+            per_rank.append([[x["id"] for x in b] for b in itertools.islice(iter(loader), 4)])
+            assert all(len(b) == 2 for b in per_rank[-1])
+        if not grouping:
+            ref = [[int(x) for x in itertools.islice(iter(D.TrainingSampler(len(ds), True, 5, r, 2)), 8)] for r in range(2)]
+            assert [sum(b, []) for b in per_rank] == ref
+    with pytest.raises(Exception):
+        D.build_batch_data_loader(ds, D.TrainingSampler(len(ds), True, 5, 0, 3), 4, world_size=3)
