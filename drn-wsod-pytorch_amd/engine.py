@@ -15,6 +15,8 @@ import bisect
 import math
 
 import numpy as np
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -612,7 +614,7 @@ class GraphedTrainStep:
         with torch.no_grad():
             self._pool_next()
 
-    def _run(self, eager):
+    def _run(self, eager, next_batch=None):
         """One step = three pieces on two torch streams, ordered by events exactly like eager multi-stream code.  (A
         single graph with the backbone as an internal branch was measured first: the HIP graph executor starts that
         branch late whatever the capture order, so the 49 latency-bound conv nodes ended up on the critical path.)
@@ -627,6 +629,10 @@ class GraphedTrainStep:
         if self.split_tail:
             self.engine.run_fc1_tail()  # eager: dW slabs on this stream, all-reduce + SGD per bucket on the optimizer stream
         with torch.cuda.stream(self._side):
+            if next_batch is not None:
+                # the next batch's image / proposals are consumed by this stream's backbone graph and by the pooling graph
+                # behind it: staging them here keeps five small copies off the front of the heads graph
+                self._stage_next(next_batch)
             self._bb_body() if eager else self.g_bb.replay()
             done = torch.cuda.Event()
             done.record(self._side)
@@ -668,5 +674,4 @@ class GraphedTrainStep:
         if not self._primed:
             return self.prime(batch, next_batch)
         self._stage_labels(batch)
-        self._stage_next(next_batch)
-        return self._run(eager=False)
+        return self._run(eager=False, next_batch=next_batch)
