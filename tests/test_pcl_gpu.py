@@ -84,7 +84,7 @@ def test_pcl_golden_cases(drn):
 
 
 @pytest.mark.parametrize("R,K,nb,seed", [(40, 5, 3, 0), (333, 20, 3, 1), (2000, 20, 3, 2), (4096, 20, 2, 3),
-                                         (31, 4, 1, 4), (5, 3, 2, 5)])
+                                         (31, 4, 1, 4), (5, 3, 2, 5), (2000, 20, 2, 106), (3000, 8, 2, 207)])
 def test_pcl_refine_cascade_vs_oracle(drn, R, K, nb, seed):
     """branch b clusters on branch b-1's softmax: the whole cascade of one image against the oracle"""
     from oracle import pcl_oracle as PO
@@ -107,6 +107,11 @@ def test_pcl_refine_cascade_vs_oracle(drn, R, K, nb, seed):
     b = torch.from_numpy(rs.randn(R, K).astype(np.float32) * 3.0)
     last = (torch.softmax(a, 1) * torch.softmax(b, 0)).numpy()
     logits = [rs.randn(R, K + 1).astype(np.float32) * 2.0 for _ in range(nb)]
+    if seed >= 200:  # heavy-tailed scores: a handful of dominant proposals, a long flat tail
+        last = (last ** 3 / (last ** 3).sum(0, keepdims=True)).astype(np.float32)
+    elif seed >= 100:  # quantised scores and logits: thousands of duplicates, few distinct cut positions
+        last = (np.round(last * 2000.0) / 2000.0).astype(np.float32)
+        logits = [np.round(l * 2.0) / 2.0 for l in logits]
     out, dl, cols, adj = _run(drn, logits, last, boxes, im)
     # adjacency bits == IoU > 0.4 of the oracle
     ref_adj = PO._iou_np(boxes, boxes) > np.float32(0.4)
