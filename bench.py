@@ -222,6 +222,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--lookahead", type=int, choices=[1, 2], default=2,
+                    help="how many batches ahead the frozen trunk runs on the side stream (2: two steps to finish)")
     ap.add_argument("--slab-rows", default=None,
                     help="comma-separated row ends of the fc6 dW slabs (experiment knob; default = the engine's choice)")
     ap.add_argument("--ims-per-gpu", type=int, default=1,
@@ -322,10 +324,11 @@ def main():
 
         ops.GEMM_TIMING = None
         split = dp.exchange or (args.tail != "graph" and not args.no_pipelined_sgd)
-        stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split)
+        stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead)
         try:
             for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
-                last = stepper.step(batches[i % len(batches)], batches[(i + 1) % len(batches)])
+                last = stepper.step(batches[i % len(batches)], batches[(i + 1) % len(batches)],
+                                    batches[(i + 2) % len(batches)])
         except Exception as ex:  # noqa: BLE001 - a failed capture must not cost the measurement: run the eager step
             print("[bench] hipGraph capture failed (%r); falling back to the eager step" % (ex,), file=sys.stderr)
             use_graph = False
@@ -335,7 +338,8 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             j = args.warmup + i
-            last = stepper.step(batches[j % len(batches)], batches[(j + 1) % len(batches)])
+            last = stepper.step(batches[j % len(batches)], batches[(j + 1) % len(batches)],
+                                batches[(j + 2) % len(batches)])
         t_enq = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0

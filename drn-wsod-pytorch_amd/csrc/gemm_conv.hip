@@ -129,14 +129,18 @@ struct ConvLoader {
 // per K-slab (one to four MFMAs per wave and k-step), so a slab's cost is the latency of its global loads unless they
 // are issued far ahead: the staging registers form a statically indexed ring of DEPTH slabs - while slab i is
 // multiplied out of LDS, slab i+DEPTH is being fetched and slab i+1 (fetched DEPTH-1 iterations ago) moves from its
-// registers into the other LDS stage.  LDS stays at two stages (32 / 64 KB), so a conv block still fits next to a
-// 128-KB GEMM block on a CU.
-template <int DT, int BM, int BN, class ALoader, class BLoader>
+// registers into the other LDS stage.
+// STAGES = 1 (the 64x64 conv): ONE 16-KB LDS stage, refilled between two barriers, and a 3-deep register ring.  Measured
+// (tools/coexist_bench.py and an LDS-size probe): a workgroup shares a CU with a 256x256 GEMM workgroup (128 KB LDS,
+// 2 x 200 VGPRs per SIMD) only with < 32 KB of LDS and <= 112 registers per wave; the two-stage version is exactly 32 KB
+// and 120 registers, so every conv launch of the frozen trunk used to wait for a GEMM workgroup to retire (a chain of ten
+// res4 convs beside the fc6 GEMM: 475 us instead of 190).
+template <int DT, int BM, int BN, class ALoader, class BLoader, int STAGES = 2>
 __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char* smem, const ALoader& la,
                                          const BLoader& lb, int s0, int s1) {
   constexpr int MI = BM / 64, NJ = BN / 64;
-  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
-  constexpr int DEPTH = BM <= 64 ? 4 : 3;
+  constexpr int A_BYTES = BM * 128, STAGE = STAGES == 2 ? (BM + BN) * 128 : 0;
+  constexpr int DEPTH = STAGES == 1 ? 3 : (BM <= 64 ? 4 : 3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   i32x4_t ra[DEPTH][BM / 32], rb[DEPTH][BN / 32];
@@ -176,6 +180,7 @@ __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char
 #pragma unroll
             for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[ii][j], fa[ii], fb[j]);
         }
+        if (STAGES == 1) __syncthreads();  // every wave is done reading the only stage
         if (i + 1 < n) {
           lds_store_tile<BM>(nxt, ra[(d + 1) % DEPTH], tid);
           lds_store_tile<BN>(nxt + A_BYTES, rb[(d + 1) % DEPTH], tid);
@@ -538,7 +543,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int nslab = (p.Ktot * ES + 127) / 128;
-  mainloop<DT, BM, BN>(acc, smem, la, lb, 0, nslab);
+  mainloop<DT, BM, BN, decltype(la), decltype(lb), (BM == 64 && BN == 64) ? 1 : 2>(acc, smem, la, lb, 0, nslab);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
 #pragma unroll
@@ -598,7 +603,7 @@ template <int DT, int BM, int BN>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
   const int tiles = ((Mtot + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
-  constexpr int smem = 2 * (BM + BN) * 128;
+  constexpr int smem = ((BM == 64 && BN == 64) ? 1 : 2) * (BM + BN) * 128;
   auto k = conv_nhwc_kernel<DT, BM, BN>;
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {

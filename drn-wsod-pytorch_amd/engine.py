@@ -501,6 +501,11 @@ class GraphedTrainStep:
       g_pool (main stream) : ROIPool(+objectness) -> A and A^T of the next batch, behind this step's last reader of A^T
     One buffer set suffices.  Legal because every shipped config freezes the whole backbone (FREEZE_AT=5).
 
+    lookahead=2 (bench.py's default): measured with HIP events, the conv chain of ONE image takes ~1.7 ms beside the
+    GEMMs (0.6 ms alone) and the main stream idled 0.26 ms per step waiting for it.  With two feature buffers / image
+    staging sets the trunk of batch t+2 runs during step t (two graphs per piece, one per slot), so the pooling graph of
+    batch t+1 never waits; `step()` then takes the batch two steps ahead as a third argument (only its images are read).
+
     Static shapes only (fixed image size, proposals per image, images per GPU: the benchmark's case and the common
     fixed-R training case); anything else runs the eager path.
 
@@ -510,8 +515,10 @@ class GraphedTrainStep:
     collective is ever captured into a hipGraph, while the next image's backbone graph and pooling graph run under
     the exchange.  The optimizer stream is joined at the start of the next step."""
 
-    def __init__(self, model, optimizer, example_batch, split_tail=False):
+    def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1):
         assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
+        assert lookahead in (1, 2)
+        self.lookahead = lookahead
         self.model, self.opt = model, optimizer
         self.heads = model.roi_heads
         self.engine = self.heads._engine
@@ -521,6 +528,12 @@ class GraphedTrainStep:
         n_img, M = len(example_batch), sum(self.nper)
         self.n_img, self.K = n_img, K
         self.image = [x["image"].to(dev).float().clone() for x in example_batch]
+        # lookahead 2: the trunk of batch t+2 runs during step t into the feature buffer batch t no longer needs, so the
+        # conv chain (0.6 ms alone, ~1.7 ms beside the GEMMs) has two steps to finish instead of one
+        self._images = [self.image] + ([[im.clone() for im in self.image]] if lookahead == 2 else [])
+        self._feats = [None, None]
+        self._bb_done = [None, None]
+        self._t = 0
         off = [0]
         for n in self.nper:
             off.append(off[-1] + n)
@@ -573,33 +586,44 @@ class GraphedTrainStep:
 
     def _stage_next(self, batch):
         """image + proposals of the NEXT batch (device tensors: async D2D copies)"""
+        self._stage_props(batch)
+        self._stage_image(batch, 0)
+
+    def _stage_props(self, batch):
         off = 0
         for i, x in enumerate(batch):
             n = self.nper[i]
             assert len(x["proposals"]) == n, "graphed step: proposals per image must stay fixed"
             self.rois_next[off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
             self.obj_next[off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
-            self.image[i].copy_(x["image"], non_blocking=True)
             off += n
 
-    def _backbone(self):
+    def _stage_image(self, batch, slot):
+        for i, x in enumerate(batch):
+            self._images[slot][i].copy_(x["image"], non_blocking=True)
+
+    def _backbone(self, slot=0):
         m = self.model
-        imgs = m.preprocess_image([{"image": im} for im in self.image])
+        imgs = m.preprocess_image([{"image": im} for im in self._images[slot]])
         feats = m.backbone(imgs.tensor)
         f = feats[self.heads.box_in_features[0]].permute(0, 2, 3, 1)
         assert f.is_contiguous()
         return f
 
-    def _pool_next(self):
+    def _pool_next(self, slot=None):
         """pooled fc6 operand (A, A^T) of the staged next batch + hand its proposals over to the heads"""
-        self.pooled = self.engine.pool(self.feat_next, self.rois_next, self.obj_next, True, slot=0)
+        feat = self.feat_next if slot is None else self._feats[slot]
+        self.pooled = self.engine.pool(feat, self.rois_next, self.obj_next, True, slot=0)
         # the heads only need the pooled operand and the proposal boxes (pseudo-GT mining / IoU labelling) of a batch
         self.props.copy_(self.rois_next[:, 1:])
 
     # ---- the three captured pieces ---------------------------------------------------------------------------
-    def _bb_body(self):
+    def _bb_body(self, slot=None):
         with torch.no_grad():
-            self.feat_next.copy_(self._backbone())
+            if slot is None:
+                self.feat_next.copy_(self._backbone())
+            else:
+                self._feats[slot].copy_(self._backbone(slot))
 
     def _main_body(self):
         losses, st = self.engine.forward(None, self.rois, self.obj, True, self.img_off, self.n_img, self.gt,
@@ -610,9 +634,69 @@ class GraphedTrainStep:
             self.opt.step(1.0)           # joins the optimizer stream
         return losses
 
-    def _pool_body(self):
+    def _pool_body(self, slot=None):
         with torch.no_grad():
-            self._pool_next()
+            self._pool_next(slot)
+
+    # ---- lookahead 2 ------------------------------------------------------------------------------------------
+    def _run2(self, eager, next_batch, next2_batch):
+        """Step t with the trunk two batches ahead.  Batch j lives in slot j % 2 (image staging set + feature buffer).
+          side : image of batch t+2 -> its slot, backbone graph of that slot (the slot's last reader, the pooling of batch t,
+                 finished with the previous call: one wait on the main stream orders it)
+          main : heads graph of batch t (+ eager tail), proposals of batch t+1, wait for the trunk of batch t+1 (launched by
+                 the PREVIOUS call), pooling graph of its slot"""
+        main = torch.cuda.current_stream()
+        t = self._t
+        s1, s2 = (t + 1) % 2, (t + 2) % 2
+        self._side.wait_stream(main)
+        losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
+        if self.split_tail:
+            self.engine.run_fc1_tail()
+        with torch.cuda.stream(self._side):
+            self._stage_image(next2_batch, s2)
+            self._bb_body(s2) if eager else self.g_bb2[s2].replay()
+            ev = torch.cuda.Event()
+            ev.record(self._side)
+        self._stage_props(next_batch)  # behind the heads graph on this stream: off the front of the fc6 GEMM
+        main.wait_event(self._bb_done[s1])
+        self._bb_done[s2] = ev
+        self._pool_body(s1) if eager else self.g_pool2[s1].replay()
+        if self.split_tail:
+            self.opt.step(1.0)
+        self._t = t + 1
+        return losses
+
+    def _prime2(self, first_batch, next_batch, next2_batch):
+        self.heads.train()
+        main = torch.cuda.current_stream()
+        with torch.no_grad():
+            self._stage_image(first_batch, 0)
+            self._feats[0] = self._backbone(0).clone()
+            self._stage_props(first_batch)
+            self._pool_next(0)
+            self._stage_image(next_batch, 1)
+            self._feats[1] = self._backbone(1).clone()
+        self._bb_done[1] = torch.cuda.Event()
+        self._bb_done[1].record(main)
+        self._stage_labels(first_batch)
+        self.opt.zero_grad()
+        self._t = 0
+        first = {k: v.detach().clone() for k, v in self._run2(True, next_batch, next2_batch).items()}
+        self.opt.zero_grad()
+        torch.cuda.synchronize()
+        self.g_main = torch.cuda.CUDAGraph()
+        self.g_bb2 = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        self.g_pool2 = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        for sl in (0, 1):
+            with torch.cuda.graph(self.g_bb2[sl], capture_error_mode="thread_local"):
+                self._bb_body(sl)
+        with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
+            self.losses = self._main_body()
+        for sl in (0, 1):
+            with torch.cuda.graph(self.g_pool2[sl], capture_error_mode="thread_local"):
+                self._pool_body(sl)
+        self._primed = True
+        return first
 
     def _run(self, eager, next_batch=None):
         """One step = three pieces on two torch streams, ordered by events exactly like eager multi-stream code.  (A
@@ -668,9 +752,17 @@ class GraphedTrainStep:
         self._primed = True
         return first
 
-    def step(self, batch, next_batch):
+    def step(self, batch, next_batch, next2_batch=None):
         """run the step for `batch` (which must be the batch passed as `next_batch` to the previous call); the same
-        step prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM)"""
+        step prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM).  With lookahead=2 the
+        caller also hands over the batch after that (`next2_batch`: only its images are read), whose backbone runs now."""
+        if self.lookahead == 2:
+            if next2_batch is None:
+                raise DrnError("GraphedTrainStep(lookahead=2).step needs the batch two steps ahead")
+            if not self._primed:
+                return self._prime2(batch, next_batch, next2_batch)
+            self._stage_labels(batch)
+            return self._run2(False, next_batch, next2_batch)
         if not self._primed:
             return self.prime(batch, next_batch)
         self._stage_labels(batch)

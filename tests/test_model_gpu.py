@@ -275,9 +275,11 @@ def test_grad_accumulation_iter_size():
     assert torch.allclose(model.roi_heads.box_refinery_0.cls_score.bias.grad, 1.5 * b1, rtol=1e-4, atol=1e-7)
 
 
-def test_hipgraph_step_equals_eager():
+@pytest.mark.parametrize("lookahead", [1, 2])
+def test_hipgraph_step_equals_eager(lookahead):
     """GraphedTrainStep (whole step captured into a hipGraph, next image's backbone forked onto a side stream) must
-    reproduce the eager trainer step for step: same losses over 4 steps on alternating batches."""
+    reproduce the eager trainer step for step: same losses over the steps on a cycle of three different batches (with
+    lookahead=2 the trunk runs two batches ahead into alternating feature buffers)."""
     from drn_wsod_pytorch_amd.engine import GraphedTrainStep, build_optimizer
 
     name = "model_r50c4_tiny"
@@ -290,7 +292,12 @@ def test_hipgraph_step_equals_eager():
     alt["image"] = (255.0 - base[0]["image"]).contiguous()
     alt["objectness_logits"] = base[0]["objectness_logits"].flip(0).contiguous()
     b1 = G.drn_inputs([alt])
-    seq = [b0, b1, b0, b1, b0]
+    alt2 = dict(base[0])
+    alt2["image"] = base[0]["image"].flip(2).contiguous()
+    alt2["proposal_boxes"] = base[0]["proposal_boxes"].flip(0).contiguous()
+    alt2["gt_classes"] = (base[0]["gt_classes"] + 1) % ocfg.num_classes
+    b2 = G.drn_inputs([alt2])
+    seq = [b0, b1, b2, b0, b1, b2, b0, b1]
     results = []
     for graphed in (False, True):
         cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, "fp32")
@@ -299,12 +306,12 @@ def test_hipgraph_step_equals_eager():
         opt = build_optimizer(cfg, model)
         out = []
         if graphed:
-            stepper = GraphedTrainStep(model, opt, seq[0])
-            for i in range(4):
-                losses = stepper.step(seq[i], seq[i + 1])
+            stepper = GraphedTrainStep(model, opt, seq[0], lookahead=lookahead)
+            for i in range(6):
+                losses = stepper.step(seq[i], seq[i + 1], seq[i + 2])
                 out.append({k: float(v.detach()) for k, v in losses.items()})
         else:
-            for i in range(4):
+            for i in range(6):
                 opt.zero_grad()
                 losses = model(seq[i])
                 sum(losses.values()).backward()
@@ -316,8 +323,8 @@ def test_hipgraph_step_equals_eager():
             assert abs(e[k] - g[k]) <= 1e-5 * max(abs(e[k]), 1e-3), (k, e[k], g[k])
 
 
-@pytest.mark.parametrize("comm", ["fp32", "bf16"])
-def test_split_tail_exchange_step_equals_eager(comm):
+@pytest.mark.parametrize("comm,lookahead", [("fp32", 1), ("bf16", 1), ("fp32", 2)])
+def test_split_tail_exchange_step_equals_eager(comm, lookahead):
     """The N>1 step on one GPU: a 1-rank RCCL group with the exchange forced on, GraphedTrainStep(split_tail=True)
     (captured heads graph + eager fc6-dW / all-reduce / SGD tail on the optimizer stream).  With fp32 buckets it must
     reproduce the plain eager trainer exactly (weights bit for bit after 4 steps); with bf16 fc6 buckets the
@@ -336,7 +343,7 @@ def test_split_tail_exchange_step_equals_eager(comm):
     alt["image"] = (255.0 - base[0]["image"]).contiguous()
     alt["objectness_logits"] = base[0]["objectness_logits"].flip(0).contiguous()
     b1 = G.drn_inputs([alt])
-    seq = [b0, b1, b0, b1, b0]
+    seq = [b0, b1, b0, b1, b0, b1]
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
@@ -357,9 +364,9 @@ def test_split_tail_exchange_step_equals_eager(comm):
                 opt.enable_pipelined(dp, slab_rows=[16, 48],
                                      comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32)
                 assert (model.roi_heads._engine.fc1_grad_bucket is not None) == (comm == "bf16")
-                stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True)
+                stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True, lookahead=lookahead)
                 for i in range(4):
-                    losses = stepper.step(seq[i], seq[i + 1])
+                    losses = stepper.step(seq[i], seq[i + 1], seq[i + 2])
                     out.append({k: float(v.detach()) for k, v in losses.items()})
             else:
                 for i in range(4):
