@@ -384,7 +384,7 @@ def main():
                "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph),
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
                "grad_exchange": None if not dp.exchange else {
-                   "collective": "RCCL all-reduce per bucket (small tensors fp32, fc6 dW row slabs in fc6_grad_dtype)",
+                   "collective": "RCCL all-reduce per bucket (small tensors and fc6 dW row slabs in fc6_grad_dtype on the wire)",
                    "slab_ends": getattr(opt, "_slab_ends", None)},
                "roofline": roof}
         if world == 1 and not dp.exchange:
