@@ -32,6 +32,7 @@ _SIGS = {
     "drn_gemm_set_tile": "i",
     "drn_bias_act_fwd": "pilppQpfplpliiliip",
     "drn_counter_add": "pQp",
+    "drn_colsum_reduce": "piipip",
     "drn_bias_act_bwd": "pilppppfplplppiiiip",
     "drn_cast2d": "ppiilliip",
     "drn_wsddn_fwd_bwd": "pliiipippppppl" + "pi" + "ifp",

@@ -110,7 +110,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
       __syncthreads();
     }
   }
-  if (BWD && p.colsum) {
+  if (BWD && p.colpart) {
     cs[ty][tx] = csum;
     __syncthreads();
     if (ty == 0 && n < p.N) p.colpart[(long)blockIdx.y * p.N + n] = ((cs[0][tx] + cs[1][tx]) + cs[2][tx]) + cs[3][tx];
@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void act_vec_kernel(ActParams p) {
       }
     }
   }
-  if (BWD && p.colsum) {
+  if (BWD && p.colpart) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) cs[ty][tx * 4 + e] = csum[e];
     __syncthreads();
@@ -826,6 +826,17 @@ int drn_bias_act_bwd(const void* grad_out, int grad_dtype, long ld_in, const flo
   if (colsum)
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, colpart, nparts, N, colsum,
                        accumulate_colsum);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// second stage of the bias-gradient column sums on its own: drn_bias_act_bwd with colsum == NULL and colpart != NULL
+// leaves ceil(M/64) x N partials, and this adds them (fixed order) into colsum - so that the optimizer stream can do it
+// right in front of the SGD pass instead of the backward's critical path
+int drn_colsum_reduce(const float* colpart, int nparts, int N, float* colsum, int accumulate, void* stream) {
+  if (!colpart || !colsum || nparts < 1 || N < 1) return DRN_ERR_ARG;
+  hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, colpart, nparts, N,
+                     colsum, accumulate);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

@@ -146,6 +146,7 @@ class FusedSGD:
         self._slab_ends = slab_rows
         e.fc1_slab_ends = slab_rows
         e.grad_ready_hook = self._on_grad_ready
+        e.defer_colsum = True
         self._dp, self._pipelined = dp, True
         self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
         self._bucket_segs = {}
@@ -250,6 +251,8 @@ class FusedSGD:
         ev.record(cur)
         self._opt_stream.wait_event(ev)
         with torch.cuda.stream(self._opt_stream):
+            if what == "small":
+                e.flush_colsums()  # bias gradients: second stage of their column sums, off the backward's critical path
             bucket = self._exchange(what)
             if self._exchange_on:
                 evc = torch.cuda.Event()

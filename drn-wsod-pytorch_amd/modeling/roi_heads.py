@@ -362,8 +362,14 @@ class _HeadEngine:
         fc1, fc2 = h.box_head.fc1, h.box_head.fc2
         D1, D2, NH = fc1.weight.shape[0], fc2.weight.shape[0], self.NH
         o, _ = self._seg[self.cols[0][0] + ".weight"]
-        ops.transpose2d(fc2.weight.data, D2, D1, out=sh["W2T"])
-        ops.transpose2d(self.arena_w[o: o + NH * D2].view(NH, D2), NH, D2, out=sh["WhT"])
+        # a shadow that is a view of the flat compute-dtype arena is refreshed by the SGD kernel itself (or by
+        # refresh_shadows just before this call): transposing IT is a bf16 -> bf16 copy with 16-B accesses (~10 us)
+        # instead of a scalar fp32 -> bf16 pass over the master weights (100 us beside the dW GEMM, on the optimizer
+        # stream's chain small SGD -> transposes -> fc6 SGD slabs that ends the step)
+        src2 = fc2.weight.data if sh.get("W2_own", True) else sh["W2"]
+        srch = self.arena_w[o: o + NH * D2].view(NH, D2) if sh.get("Wh_own", True) else sh["Wh"]
+        ops.transpose2d(src2, D2, D1, out=sh["W2T"])
+        ops.transpose2d(srch, NH, D2, out=sh["WhT"])
 
     # ---- compute-dtype shadows of the weights -----------------------------------------------------
     def refresh_shadows(self, dtype):
@@ -423,7 +429,9 @@ class _HeadEngine:
             w.update(H1T=z(D1, Mp), H2T=z(D2, Mp), dlogits=z(M, NHp, torch.float32), dS=z(M, NHp),
                      dST=z(self.NH, Mp), dH2=z(M, D2, torch.float32), dP2=z(M, kp(D2)), dP2T=z(D2, Mp),
                      dH1=z(M, D1, torch.float32), dP1T=z(D1, Mp),
-                     colpart=z((M + 63) // 64, max(D1, D2, self.NH), torch.float32))
+                     colpart=z((M + 63) // 64, max(D1, D2, self.NH), torch.float32),
+                     # one scratch per layer for the deferred mode (the three reductions then run later, together)
+                     colpart3=[z((M + 63) // 64, n_, torch.float32) for n_ in (self.NH, D2, D1)])
         self._ws[key] = w
         return w
 
@@ -604,15 +612,27 @@ class _HeadEngine:
         acc = self._grads_valid and fc2.weight.grad is not None  # fc1.weight.grad is not materialised in bucket modes
         bo, _ = self._seg[self.cols[0][0] + ".bias"]
         wo, _ = self._seg[self.cols[0][0] + ".weight"]
+        # bias gradients = column sums of the three pre-activation gradients, in two stages.  With the pipelined optimizer
+        # the second stage (three 10-us launches) leaves the critical path: the partials stay in per-layer scratch and
+        # `flush_colsums` adds them up on the optimizer stream right in front of the small-tensor SGD bucket
+        defer = getattr(self, "defer_colsum", False) and getattr(self, "grad_ready_hook", None) is not None
+        nparts = (M + 63) // 64
+        self._pending_colsum = []
+
+        def colsum_args(layer, N_, view):
+            if not defer:
+                return dict(colsum=view, accumulate_colsum=acc, colpart=w["colpart"])
+            self._pending_colsum.append((w["colpart3"][layer], nparts, N_, view, acc))
+            return dict(colsum=None, colpart=w["colpart3"][layer])
+
         # heads: dS, dS^T, bias grads
         ops.bias_act_bwd(w["dlogits"], M, NH, colscale=colscale, colidx=colidx, dpre=w["dS"], dpreT=w["dST"],
-                         colsum=self.arena_g[bo: bo + NH], accumulate_colsum=acc, colpart=w["colpart"])
+                         **colsum_args(0, NH, self.arena_g[bo: bo + NH]))
         ops.gemm_nt(w["dST"], w["H2T"], NH, D2, Mp, out=self.arena_g[wo: wo + NH * D2].view(1, NH, D2), accumulate=acc)
         ops.gemm_nt(w["dS"], sh["WhT"], M, D2, kp(NH), out=w["dH2"].view(1, M, D2))
         # fc7
         ops.bias_act_bwd(w["dH2"], M, D2, saved=w["H2"], mask=st["masks"][1] if st["masks"] else None,
-                         drop_p=st["drop_p"], dpre=w["dP2"], dpreT=w["dP2T"], colsum=self._gview("fc2.bias"),
-                         accumulate_colsum=acc, colpart=w["colpart"])
+                         drop_p=st["drop_p"], dpre=w["dP2"], dpreT=w["dP2T"], **colsum_args(1, D2, self._gview("fc2.bias")))
         ops.gemm_nt(w["dP2T"], w["H1T"], D2, D1, Mp, out=self._gview("fc2.weight", (1, D2, D1)), accumulate=acc)
         ops.gemm_nt(w["dP2"], sh["W2T"], M, D1, kp(D2), out=w["dH1"].view(1, M, D1))
         # fc6 (the backbone is frozen: no dX)
@@ -621,7 +641,7 @@ class _HeadEngine:
             w["dP1"] = torch.zeros_like(w["H1"])
         ops.bias_act_bwd(w["dH1"], M, D1, saved=w["H1"], mask=st["masks"][0] if st["masks"] else None,
                          drop_p=st["drop_p"], dpre=w["dP1"] if fg is not None else None, dpreT=w["dP1T"],
-                         colsum=self._gview("fc1.bias"), accumulate_colsum=acc, colpart=w["colpart"])
+                         **colsum_args(2, D1, self._gview("fc1.bias")))
         self._tail = (w["dP1T"], w["AT"], D1, K1, Mp, acc)
         if not getattr(self, "defer_fc1_tail", False):
             self.run_fc1_tail()
@@ -648,6 +668,13 @@ class _HeadEngine:
         hook = getattr(self, "grad_ready_hook", None)
         if hook is not None:
             hook("backbone")
+
+    def flush_colsums(self):
+        """second stage of the deferred bias-gradient column sums (current stream; see backward)"""
+        # (the list describes the LAST backward that ran in Python; a replayed hipGraph re-executes that backward's
+        # kernels into the same scratch, so the list is kept, not consumed)
+        for colpart, nparts, N_, view, acc in getattr(self, "_pending_colsum", ()):
+            ops.colsum_reduce(colpart, nparts, N_, view, acc)
 
     def run_fc1_tail(self):
         """Last piece of the explicit backward: announce the small gradients, then the fc6 weight gradient in row

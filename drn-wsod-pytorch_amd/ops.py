@@ -206,6 +206,11 @@ def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=Non
            int(accumulate_colsum), M, N, C.dt(ref.dtype), C.stream())
 
 
+def colsum_reduce(colpart, nparts, N, colsum, accumulate=False):
+    """finish the two-stage column sums that bias_act_bwd(colsum=None, colpart=...) left as per-block partials"""
+    C.call("drn_colsum_reduce", C.ptr(colpart), int(nparts), int(N), C.ptr(colsum), int(accumulate), C.stream())
+
+
 def wsddn_fwd_bwd(logits, c_cls, c_det, K, img_off, n_img, gt_onehot, dlogits=None, mean_loss=True, loss_scale=1.0,
                   max_rows=None):
     M = logits.shape[0]

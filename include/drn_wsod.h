@@ -140,6 +140,11 @@ int drn_bias_act_bwd(const void* grad_out, int grad_dtype, long ld_in, const flo
                      void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
                      int accumulate_colsum, int M, int N, int out_dtype, void* stream);
 
+/* Second stage of drn_bias_act_bwd's column sums (bias gradients) on its own: with colsum == NULL and colpart != NULL
+ * drn_bias_act_bwd only leaves the ceil(M/64) x N per-block partials; this adds them in a fixed order into colsum
+ * (accumulate != 0: += ).  Lets the optimizer stream finish the bias gradients right in front of the SGD pass. */
+int drn_colsum_reduce(const float* colpart, int nparts, int N, float* colsum, int accumulate, void* stream);
+
 /* ---- MIL / OICR head ------------------------------------------------------------------------- */
 
 /* WSDDNOutputLayers.forward (fast_rcnn.py:493-527) + predict_probs_img (:689-700) +
