@@ -222,8 +222,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--lookahead", type=int, choices=[1, 2], default=2,
-                    help="how many batches ahead the frozen trunk runs on the side stream (2: two steps to finish)")
+    ap.add_argument("--workload", choices=["r50c4", "r50dc5", "r101c4_k80"], default="r50c4",
+                    help="r50c4 = BASELINE configs[1], the headline metric; r50dc5 (configs[2]: WS-R50 dilated C5, use with "
+                         "--proposals 4000) and r101c4_k80 (configs[3]: WS-R101 C4, 80 classes) are side measurements")
+    ap.add_argument("--lookahead", type=int, choices=[1, 2, 3, 4], default=2,
+                    help="how many batches ahead the frozen trunk runs (L: L-1 conv chains in flight on L-1 side streams, "
+                         "each with L-1 steps to finish)")
     ap.add_argument("--slab-rows", default=None,
                     help="comma-separated row ends of the fc6 dW slabs (experiment knob; default = the engine's choice)")
     ap.add_argument("--ims-per-gpu", type=int, default=1,
@@ -276,6 +280,11 @@ def main():
     from drn_wsod_pytorch_amd.modeling import build_model
 
     cfg = build_cfg(pkg, device)
+    if args.workload == "r50dc5":
+        cfg.merge_from_list(["MODEL.RESNETS.OUT_FEATURES", "['res5']", "MODEL.ROI_HEADS.IN_FEATURES", "['res5']",
+                             "MODEL.RESNETS.RES5_DILATION", "2"])
+    elif args.workload == "r101c4_k80":
+        cfg.merge_from_list(["MODEL.RESNETS.DEPTH", "101", "MODEL.ROI_HEADS.NUM_CLASSES", "80"])
     if args.heads == "pcl":
         cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "PCLROIHeads"])
     model = build_model(cfg)
@@ -327,8 +336,7 @@ def main():
         stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead)
         try:
             for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
-                last = stepper.step(batches[i % len(batches)], batches[(i + 1) % len(batches)],
-                                    batches[(i + 2) % len(batches)])
+                last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(max(args.lookahead, 2) + 1)])
         except Exception as ex:  # noqa: BLE001 - a failed capture must not cost the measurement: run the eager step
             print("[bench] hipGraph capture failed (%r); falling back to the eager step" % (ex,), file=sys.stderr)
             use_graph = False
@@ -338,8 +346,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             j = args.warmup + i
-            last = stepper.step(batches[j % len(batches)], batches[(j + 1) % len(batches)],
-                                batches[(j + 2) % len(batches)])
+            last = stepper.step(*[batches[(j + q) % len(batches)] for q in range(max(args.lookahead, 2) + 1)])
         t_enq = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
@@ -377,9 +384,12 @@ def main():
         out = {"metric": METRIC, "value": world * args.ims_per_gpu * args.steps / dt, "unit": "images/sec", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-               "config": {"workload": "DRN-WSOD ResNet50-WS C4 (res4 out, stride 16), VOC07-shaped synthetic 224x224, "
-                                      "%d proposals/img, %d img/GPU/iter, K=20, 3 %s refinements, frozen backbone "
-                                      "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % (R, args.ims_per_gpu, args.heads.upper()),
+               "config": {"workload": {"r50c4": "DRN-WSOD ResNet50-WS C4 (res4 out, stride 16)",
+                                       "r50dc5": "SIDE MEASUREMENT configs[2]: DRN-WSOD ResNet50-WS dilated C5 (res5 out, stride 8)",
+                                       "r101c4_k80": "SIDE MEASUREMENT configs[3]: DRN-WSOD ResNet101-WS C4, 80 classes"}[args.workload]
+                                      + ", VOC07-shaped synthetic 224x224, "
+                                      "%d proposals/img, %d img/GPU/iter, K=%d, 3 %s refinements, frozen backbone "
+                                      "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % (R, args.ims_per_gpu, K, args.heads.upper()),
                           "global_batch": world * args.ims_per_gpu, "proposals": R, "parallelism": "dp%d" % world},
                "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph),
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),

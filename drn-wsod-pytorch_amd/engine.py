@@ -520,7 +520,7 @@ class GraphedTrainStep:
 
     def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1):
         assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
-        assert lookahead in (1, 2)
+        assert 1 <= lookahead <= 4
         self.lookahead = lookahead
         self.model, self.opt = model, optimizer
         self.heads = model.roi_heads
@@ -533,9 +533,11 @@ class GraphedTrainStep:
         self.image = [x["image"].to(dev).float().clone() for x in example_batch]
         # lookahead 2: the trunk of batch t+2 runs during step t into the feature buffer batch t no longer needs, so the
         # conv chain (0.6 ms alone, ~1.7 ms beside the GEMMs) has two steps to finish instead of one
-        self._images = [self.image] + ([[im.clone() for im in self.image]] if lookahead == 2 else [])
-        self._feats = [None, None]
-        self._bb_done = [None, None]
+        # lookahead L >= 2: L slots; with L >= 3 the chains alternate over L-1 side streams, i.e. L-1 conv chains are in
+        # flight at once and each may take L-1 steps - for trunks whose chain is longer than the step (WS-R101: ~100 launches)
+        self._images = [self.image] + [[im.clone() for im in self.image] for _ in range(lookahead - 1)]
+        self._feats = [None] * max(lookahead, 2)
+        self._bb_done = [None] * max(lookahead, 2)
         self._t = 0
         off = [0]
         for n in self.nper:
@@ -641,61 +643,68 @@ class GraphedTrainStep:
         with torch.no_grad():
             self._pool_next(slot)
 
-    # ---- lookahead 2 ------------------------------------------------------------------------------------------
-    def _run2(self, eager, next_batch, next2_batch):
-        """Step t with the trunk two batches ahead.  Batch j lives in slot j % 2 (image staging set + feature buffer).
-          side : image of batch t+2 -> its slot, backbone graph of that slot (the slot's last reader, the pooling of batch t,
-                 finished with the previous call: one wait on the main stream orders it)
-          main : heads graph of batch t (+ eager tail), proposals of batch t+1, wait for the trunk of batch t+1 (launched by
-                 the PREVIOUS call), pooling graph of its slot"""
+    # ---- lookahead L >= 2 -----------------------------------------------------------------------------------
+    def _run2(self, eager, next_batch, far_batch):
+        """Step t with the trunk L batches ahead.  Batch j lives in slot j % L (image staging set + feature buffer).
+          side : image of batch t+L -> its slot, backbone graph of that slot (the slot's last reader, the pooling of batch t,
+                 finished with the previous call: one wait on the main stream orders it); L-1 side streams take turns
+          main : heads graph of batch t (+ eager tail), proposals of batch t+1, wait for the trunk of batch t+1 (launched
+                 L-1 calls ago), pooling graph of its slot"""
         main = torch.cuda.current_stream()
+        L = self.lookahead
         t = self._t
-        s1, s2 = (t + 1) % 2, (t + 2) % 2
-        self._side.wait_stream(main)
+        s1, sL = (t + 1) % L, (t + L) % L
+        side = self._sides[t % (L - 1)]
+        side.wait_stream(main)
         losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
         if self.split_tail:
             self.engine.run_fc1_tail()
-        with torch.cuda.stream(self._side):
-            self._stage_image(next2_batch, s2)
-            self._bb_body(s2) if eager else self.g_bb2[s2].replay()
+        with torch.cuda.stream(side):
+            self._stage_image(far_batch, sL)
+            self._bb_body(sL) if eager else self.g_bb2[sL].replay()
             ev = torch.cuda.Event()
-            ev.record(self._side)
+            ev.record(side)
         self._stage_props(next_batch)  # behind the heads graph on this stream: off the front of the fc6 GEMM
         main.wait_event(self._bb_done[s1])
-        self._bb_done[s2] = ev
+        self._bb_done[sL] = ev
         self._pool_body(s1) if eager else self.g_pool2[s1].replay()
         if self.split_tail:
             self.opt.step(1.0)
         self._t = t + 1
         return losses
 
-    def _prime2(self, first_batch, next_batch, next2_batch):
+    def _prime2(self, first_batch, next_batch, upcoming):
+        """upcoming = [batch t+2, ..., batch t+L] (only their images are read)"""
         self.heads.train()
         main = torch.cuda.current_stream()
+        L = self.lookahead
+        self._sides = [self._side] + [torch.cuda.Stream() for _ in range(L - 2)]
+        ahead = [next_batch] + list(upcoming[:-1])  # batches 1 .. L-1: their trunks run here, eagerly
         with torch.no_grad():
             self._stage_image(first_batch, 0)
             self._feats[0] = self._backbone(0).clone()
             self._stage_props(first_batch)
             self._pool_next(0)
-            self._stage_image(next_batch, 1)
-            self._feats[1] = self._backbone(1).clone()
-        self._bb_done[1] = torch.cuda.Event()
-        self._bb_done[1].record(main)
+            for j, b in enumerate(ahead, start=1):
+                self._stage_image(b, j)
+                self._feats[j] = self._backbone(j).clone()
+                self._bb_done[j] = torch.cuda.Event()
+                self._bb_done[j].record(main)
         self._stage_labels(first_batch)
         self.opt.zero_grad()
         self._t = 0
-        first = {k: v.detach().clone() for k, v in self._run2(True, next_batch, next2_batch).items()}
+        first = {k: v.detach().clone() for k, v in self._run2(True, next_batch, upcoming[-1]).items()}
         self.opt.zero_grad()
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
-        self.g_bb2 = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
-        self.g_pool2 = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
-        for sl in (0, 1):
+        self.g_bb2 = [torch.cuda.CUDAGraph() for _ in range(L)]
+        self.g_pool2 = [torch.cuda.CUDAGraph() for _ in range(L)]
+        for sl in range(L):
             with torch.cuda.graph(self.g_bb2[sl], capture_error_mode="thread_local"):
                 self._bb_body(sl)
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.losses = self._main_body()
-        for sl in (0, 1):
+        for sl in range(L):
             with torch.cuda.graph(self.g_pool2[sl], capture_error_mode="thread_local"):
                 self._pool_body(sl)
         self._primed = True
@@ -755,17 +764,19 @@ class GraphedTrainStep:
         self._primed = True
         return first
 
-    def step(self, batch, next_batch, next2_batch=None):
+    def step(self, batch, next_batch, *upcoming):
         """run the step for `batch` (which must be the batch passed as `next_batch` to the previous call); the same
-        step prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM).  With lookahead=2 the
-        caller also hands over the batch after that (`next2_batch`: only its images are read), whose backbone runs now."""
-        if self.lookahead == 2:
-            if next2_batch is None:
-                raise DrnError("GraphedTrainStep(lookahead=2).step needs the batch two steps ahead")
+        step prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM).  With lookahead=L >= 2
+        the caller also hands over the L-1 batches after that (`upcoming` = batches t+2 .. t+L: only their images are
+        read); the backbone of the last one runs now."""
+        if self.lookahead >= 2:
+            if len(upcoming) != self.lookahead - 1:
+                raise DrnError("GraphedTrainStep(lookahead=%d).step needs the %d batches after next_batch"
+                               % (self.lookahead, self.lookahead - 1))
             if not self._primed:
-                return self._prime2(batch, next_batch, next2_batch)
+                return self._prime2(batch, next_batch, list(upcoming))
             self._stage_labels(batch)
-            return self._run2(False, next_batch, next2_batch)
+            return self._run2(False, next_batch, upcoming[-1])
         if not self._primed:
             return self.prime(batch, next_batch)
         self._stage_labels(batch)
