@@ -392,6 +392,7 @@ def main():
                                       "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % (R, args.ims_per_gpu, K, args.heads.upper()),
                           "global_batch": world * args.ims_per_gpu, "proposals": R, "parallelism": "dp%d" % world},
                "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph),
+               "trunk_lookahead": args.lookahead if use_graph else 1,
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
                "grad_exchange": None if not dp.exchange else {
                    "collective": "RCCL all-reduce per bucket (small tensors and fc6 dW row slabs in fc6_grad_dtype on the wire)",
