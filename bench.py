@@ -228,6 +228,10 @@ def main():
     ap.add_argument("--lookahead", type=int, choices=[1, 2, 3, 4], default=2,
                     help="how many batches ahead the frozen trunk runs (L: L-1 conv chains in flight on L-1 side streams, "
                          "each with L-1 steps to finish)")
+    ap.add_argument("--no-trunk-pairs", dest="trunk_pairs", action="store_false",
+                    help="default: ONE conv chain per TWO batches (t+2, t+3; launched on even steps) - the chain is "
+                         "latency-bound, so two images cost what one costs and the per-image chain time halves (r50c4 +2.6 %, "
+                         "r101c4_k80 +40 %); this flag goes back to one chain per batch (--lookahead)")
     ap.add_argument("--slab-rows", default=None,
                     help="comma-separated row ends of the fc6 dW slabs (experiment knob; default = the engine's choice)")
     ap.add_argument("--ims-per-gpu", type=int, default=1,
@@ -333,10 +337,11 @@ def main():
 
         ops.GEMM_TIMING = None
         split = dp.exchange or (args.tail != "graph" and not args.no_pipelined_sgd)
-        stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead)
+        stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead,
+                                   trunk_pairs=args.trunk_pairs)
         try:
             for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
-                last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(max(args.lookahead, 2) + 1)])
+                last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
         except Exception as ex:  # noqa: BLE001 - a failed capture must not cost the measurement: run the eager step
             print("[bench] hipGraph capture failed (%r); falling back to the eager step" % (ex,), file=sys.stderr)
             use_graph = False
@@ -346,7 +351,7 @@ def main():
         t0 = time.perf_counter()
         for i in range(args.steps):
             j = args.warmup + i
-            last = stepper.step(*[batches[(j + q) % len(batches)] for q in range(max(args.lookahead, 2) + 1)])
+            last = stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
         t_enq = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
@@ -392,7 +397,8 @@ def main():
                                       "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % (R, args.ims_per_gpu, K, args.heads.upper()),
                           "global_batch": world * args.ims_per_gpu, "proposals": R, "parallelism": "dp%d" % world},
                "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph),
-               "trunk_lookahead": args.lookahead if use_graph else 1,
+               "trunk_schedule": ("pairs: one conv chain per two batches, two batches ahead" if args.trunk_pairs
+                                  else "lookahead %d" % args.lookahead) if use_graph else "eager prefetch of the next batch",
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
                "grad_exchange": None if not dp.exchange else {
                    "collective": "RCCL all-reduce per bucket (small tensors and fc6 dW row slabs in fc6_grad_dtype on the wire)",

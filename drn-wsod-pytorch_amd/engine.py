@@ -518,10 +518,14 @@ class GraphedTrainStep:
     collective is ever captured into a hipGraph, while the next image's backbone graph and pooling graph run under
     the exchange.  The optimizer stream is joined at the start of the next step."""
 
-    def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1):
+    def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False):
         assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
         assert 1 <= lookahead <= 4
         self.lookahead = lookahead
+        # trunk_pairs: ONE conv chain per TWO batches (t+2 and t+3, launched on even steps): the chain is latency-bound,
+        # so two images cost what one costs and the per-image chain time halves - for trunks whose chain is as long as
+        # the step (WS-R101).  step() then takes (batch, next, t+2, t+3).
+        self.trunk_pairs = bool(trunk_pairs)
         self.model, self.opt = model, optimizer
         self.heads = model.roi_heads
         self.engine = self.heads._engine
@@ -710,6 +714,90 @@ class GraphedTrainStep:
         self._primed = True
         return first
 
+    # ---- trunk in pairs ---------------------------------------------------------------------------------------
+    def _pair_backbone(self, ps):
+        m = self.model
+        imgs = m.preprocess_image([{"image": im} for im in self._pimages[ps]])
+        f = m.backbone(imgs.tensor)[self.heads.box_in_features[0]].permute(0, 2, 3, 1)
+        assert f.is_contiguous()
+        return f
+
+    def _pair_stage(self, b_a, b_b, ps):
+        for i, x in enumerate(list(b_a) + list(b_b)):
+            self._pimages[ps][i].copy_(x["image"], non_blocking=True)
+
+    def _pair_bb_body(self, ps):
+        with torch.no_grad():
+            self._pfeats[ps].copy_(self._pair_backbone(ps))
+
+    def _pair_pool_body(self, ps, half):
+        with torch.no_grad():
+            n = self.n_img
+            self.pooled = self.engine.pool(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next, True,
+                                           slot=0)
+            self.props.copy_(self.rois_next[:, 1:])
+
+    def _run_pairs(self, eager, next_batch, b2, b3):
+        """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % 2.  Even t: the conv chain of pair t/2 + 1
+        (batches t+2, t+3) starts on the side stream - its slot was last read by the pooling of batch t-1.  Every t: the
+        pooling of batch t+1 reads its half of its pair's features (pair (t+1)/2, launched at step 2 ((t+1)/2) - 2)."""
+        main = torch.cuda.current_stream()
+        t = self._t
+        self._side.wait_stream(main)
+        losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
+        if self.split_tail:
+            self.engine.run_fc1_tail()
+        if t % 2 == 0:
+            ps = (t // 2 + 1) % 2
+            with torch.cuda.stream(self._side):
+                self._pair_stage(b2, b3, ps)
+                self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+            self._pdone[ps] = ev
+        self._stage_props(next_batch)
+        k1, h1 = ((t + 1) // 2) % 2, (t + 1) % 2
+        main.wait_event(self._pdone[k1])
+        self._pair_pool_body(k1, h1) if eager else self.g_ppool[k1][h1].replay()
+        if self.split_tail:
+            self.opt.step(1.0)
+        self._t = t + 1
+        return losses
+
+    def _prime_pairs(self, b0, b1, b2, b3):
+        self.heads.train()
+        main = torch.cuda.current_stream()
+        self._pimages = [[im.clone() for im in self.image] + [im.clone() for im in self.image] for _ in range(2)]
+        self._pfeats, self._pdone = [None, None], [None, None]
+        with torch.no_grad():
+            self._pair_stage(b0, b1, 0)
+            self._pfeats[0] = self._pair_backbone(0).clone()
+            self._pfeats[1] = torch.zeros_like(self._pfeats[0])
+            self._stage_props(b0)
+            self._pair_pool_body(0, 0)
+        self._pdone[0] = torch.cuda.Event()
+        self._pdone[0].record(main)
+        self._stage_labels(b0)
+        self.opt.zero_grad()
+        self._t = 0
+        first = {k: v.detach().clone() for k, v in self._run_pairs(True, b1, b2, b3).items()}
+        self.opt.zero_grad()
+        torch.cuda.synchronize()
+        self.g_main = torch.cuda.CUDAGraph()
+        self.g_pbb = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        self.g_ppool = [[torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()] for _ in range(2)]
+        for ps in (0, 1):
+            with torch.cuda.graph(self.g_pbb[ps], capture_error_mode="thread_local"):
+                self._pair_bb_body(ps)
+        with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
+            self.losses = self._main_body()
+        for ps in (0, 1):
+            for h in (0, 1):
+                with torch.cuda.graph(self.g_ppool[ps][h], capture_error_mode="thread_local"):
+                    self._pair_pool_body(ps, h)
+        self._primed = True
+        return first
+
     def _run(self, eager, next_batch=None):
         """One step = three pieces on two torch streams, ordered by events exactly like eager multi-stream code.  (A
         single graph with the backbone as an internal branch was measured first: the HIP graph executor starts that
@@ -768,7 +856,14 @@ class GraphedTrainStep:
         """run the step for `batch` (which must be the batch passed as `next_batch` to the previous call); the same
         step prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM).  With lookahead=L >= 2
         the caller also hands over the L-1 batches after that (`upcoming` = batches t+2 .. t+L: only their images are
-        read); the backbone of the last one runs now."""
+        read); the backbone of the last one runs now.  With trunk_pairs: step(batch, next_batch, batch t+2, batch t+3)."""
+        if self.trunk_pairs:
+            if len(upcoming) != 2:
+                raise DrnError("GraphedTrainStep(trunk_pairs=True).step needs batches t+2 and t+3")
+            if not self._primed:
+                return self._prime_pairs(batch, next_batch, upcoming[0], upcoming[1])
+            self._stage_labels(batch)
+            return self._run_pairs(False, next_batch, upcoming[0], upcoming[1])
         if self.lookahead >= 2:
             if len(upcoming) != self.lookahead - 1:
                 raise DrnError("GraphedTrainStep(lookahead=%d).step needs the %d batches after next_batch"

@@ -45,10 +45,10 @@ def _worker(rank, world, port, comm, q):
         dp.broadcast_parameters(0)
         opt.enable_pipelined(dp, slab_rows=[16, 48], comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32)
         mine = batches[rank]
-        stepper = GraphedTrainStep(model, opt, mine, split_tail=True, lookahead=2)  # bench.py's default
+        stepper = GraphedTrainStep(model, opt, mine, split_tail=True, trunk_pairs=True)  # bench.py's default schedule
         losses = []
         for _ in range(3):
-            out = stepper.step(mine, mine, mine)
+            out = stepper.step(mine, mine, mine, mine)
             losses.append({k: float(v.detach()) for k, v in out.items()})
         torch.cuda.synchronize()
         sd = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.requires_grad}  # by value

@@ -275,7 +275,7 @@ def test_grad_accumulation_iter_size():
     assert torch.allclose(model.roi_heads.box_refinery_0.cls_score.bias.grad, 1.5 * b1, rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("lookahead", [1, 2, 3])
+@pytest.mark.parametrize("lookahead", [1, 2, 3, "pairs"])
 def test_hipgraph_step_equals_eager(lookahead):
     """GraphedTrainStep (whole step captured into a hipGraph, next image's backbone forked onto a side stream) must
     reproduce the eager trainer step for step: same losses over the steps on a cycle of three different batches (with
@@ -306,9 +306,10 @@ def test_hipgraph_step_equals_eager(lookahead):
         opt = build_optimizer(cfg, model)
         out = []
         if graphed:
-            stepper = GraphedTrainStep(model, opt, seq[0], lookahead=lookahead)
+            pairs = lookahead == "pairs"  # one conv chain per two batches (t+2, t+3)
+            stepper = GraphedTrainStep(model, opt, seq[0], lookahead=1 if pairs else lookahead, trunk_pairs=pairs)
             for i in range(6):
-                losses = stepper.step(*seq[i: i + max(lookahead, 2) + 1])
+                losses = stepper.step(*seq[i: i + (4 if pairs else max(lookahead, 2) + 1)])
                 out.append({k: float(v.detach()) for k, v in losses.items()})
         else:
             for i in range(6):
@@ -323,7 +324,7 @@ def test_hipgraph_step_equals_eager(lookahead):
             assert abs(e[k] - g[k]) <= 1e-5 * max(abs(e[k]), 1e-3), (k, e[k], g[k])
 
 
-@pytest.mark.parametrize("comm,lookahead", [("fp32", 1), ("bf16", 1), ("fp32", 2)])
+@pytest.mark.parametrize("comm,lookahead", [("fp32", 1), ("bf16", 1), ("fp32", 2), ("fp32", "pairs")])
 def test_split_tail_exchange_step_equals_eager(comm, lookahead):
     """The N>1 step on one GPU: a 1-rank RCCL group with the exchange forced on, GraphedTrainStep(split_tail=True)
     (captured heads graph + eager fc6-dW / all-reduce / SGD tail on the optimizer stream).  With fp32 buckets it must
@@ -343,7 +344,7 @@ def test_split_tail_exchange_step_equals_eager(comm, lookahead):
     alt["image"] = (255.0 - base[0]["image"]).contiguous()
     alt["objectness_logits"] = base[0]["objectness_logits"].flip(0).contiguous()
     b1 = G.drn_inputs([alt])
-    seq = [b0, b1, b0, b1, b0, b1]
+    seq = [b0, b1, b0, b1, b0, b1, b0, b1]
     sk = socket.socket()
     sk.bind(("127.0.0.1", 0))
     port = sk.getsockname()[1]
@@ -364,9 +365,11 @@ def test_split_tail_exchange_step_equals_eager(comm, lookahead):
                 opt.enable_pipelined(dp, slab_rows=[16, 48],
                                      comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32)
                 assert (model.roi_heads._engine.fc1_grad_bucket is not None) == (comm == "bf16")
-                stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True, lookahead=lookahead)
+                pairs = lookahead == "pairs"
+                stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True, lookahead=1 if pairs else lookahead,
+                                           trunk_pairs=pairs)
                 for i in range(4):
-                    losses = stepper.step(seq[i], seq[i + 1], seq[i + 2])
+                    losses = stepper.step(*seq[i: i + (4 if pairs else 3)])
                     out.append({k: float(v.detach()) for k, v in losses.items()})
             else:
                 for i in range(4):
