@@ -311,14 +311,63 @@ class FusedSGD:
         e.mark_dirty(shadow_fresh=e.arena_s is not None)
 
     def state_dict(self):
-        return {"momentum_buffer": self._mom, "steps": self._steps,
+        """torch.optim.SGD's checkpoint content in this optimizer's flat form: the momentum arena of the heads, the
+        momentum arena of a trainable trunk (FREEZE_AT < 5), the step count and the per-group hyper-parameters."""
+        bb = self._bb
+        return {"momentum_buffer": None if self._mom is None else self._mom.detach().cpu(),
+                "bb_momentum_buffer": None if bb is None or bb["mom"] is None else bb["mom"].detach().cpu(),
+                "steps": self._steps,
                 "param_groups": [{k: v for k, v in g.items() if k != "params"} for g in self.param_groups]}
 
     def load_state_dict(self, sd):
-        self._mom, self._steps = sd["momentum_buffer"], sd["steps"]
-        for g, s in zip(self.param_groups, sd["param_groups"]):
-            g.update(s)
-        self._segs_key = None
+        """Resume (detectron2/engine/defaults.py:304-319 hands the optimizer to the checkpointer).  Checkpoints are read
+        with map_location='cpu': the saved momentum is COPIED into device buffers shaped like the weight arenas."""
+        e = self.engine
+        mom = sd.get("momentum_buffer")
+        if mom is None:
+            self._mom = None
+        else:
+            if mom.numel() != e.arena_w.numel():
+                raise DrnError("optimizer checkpoint does not match this model: momentum arena of %d elements, "
+                               "parameter arena of %d" % (mom.numel(), e.arena_w.numel()))
+            if self._mom is None:
+                self._mom = torch.zeros_like(e.arena_w)
+            self._mom.copy_(mom.to(torch.float32).reshape(-1))
+        bmom = sd.get("bb_momentum_buffer")
+        if self._bb is not None:
+            if bmom is None:
+                self._bb["mom"] = None
+            else:
+                if bmom.numel() != self._bb["w"].numel():
+                    raise DrnError("optimizer checkpoint does not match this model's trainable trunk")
+                if self._bb["mom"] is None:
+                    self._bb["mom"] = torch.zeros_like(self._bb["w"])
+                self._bb["mom"].copy_(bmom.to(torch.float32).reshape(-1))
+        elif bmom is not None:
+            raise DrnError("optimizer checkpoint carries trunk momentum but this model's trunk is frozen")
+        self._steps = int(sd["steps"])
+        saved = sd["param_groups"]
+        if len(saved) != len(self.param_groups):
+            raise DrnError("optimizer checkpoint has %d parameter groups, this optimizer %d"
+                           % (len(saved), len(self.param_groups)))
+        for g, s in zip(self.param_groups, saved):
+            if s.get("name") != g["name"]:
+                raise DrnError("optimizer checkpoint group %r does not match %r" % (s.get("name"), g["name"]))
+            g.update({k: v for k, v in s.items() if k in ("lr", "initial_lr", "weight_decay", "momentum")})
+        self.refresh_tables()
+
+    def refresh_tables(self):
+        """Re-evaluate every per-segment (lr, weight decay) table that already lives on the device, IN PLACE: kernels
+        captured into a hipGraph keep reading those buffers, so a replay follows scheduler.step() only if the tables
+        are rewritten before it (GraphedTrainStep.step does this)."""
+        if self._segs_dev is not None:
+            self._segs_key = None
+            self._segs()
+        for what in list(getattr(self, "_bucket_segs", {})):
+            self._bucket_table(what)
+        if self._bb is not None and self._bb["segs_dev"] is not None:
+            self._bb["segs_key"] = None
+            self._segs_bb()
 
 
 def build_optimizer(cfg, model):
@@ -357,6 +406,22 @@ class WarmupMultiStepLR:
         for g, lr in zip(self.optimizer.param_groups, self.get_lr()):
             g["lr"] = lr
 
+    def state_dict(self):
+        """torch.optim.lr_scheduler._LRScheduler.state_dict minus the optimizer (what the reference checkpoints)"""
+        return {"milestones": list(self.milestones), "gamma": self.gamma, "warmup_factor": self.warmup_factor,
+                "warmup_iters": self.warmup_iters, "warmup_method": self.warmup_method,
+                "base_lrs": list(self.base_lrs), "last_epoch": self.last_epoch}
+
+    def load_state_dict(self, sd):
+        self.milestones, self.gamma = list(sd["milestones"]), sd["gamma"]
+        self.warmup_factor, self.warmup_iters = sd["warmup_factor"], sd["warmup_iters"]
+        self.warmup_method, self.base_lrs = sd["warmup_method"], list(sd["base_lrs"])
+        self.last_epoch = sd["last_epoch"]
+        for g, lr in zip(self.optimizer.param_groups, self.get_lr()):
+            g["lr"] = lr
+        if hasattr(self.optimizer, "refresh_tables"):
+            self.optimizer.refresh_tables()
+
 
 def build_lr_scheduler(cfg, optimizer):
     assert cfg.SOLVER.LR_SCHEDULER_NAME == "WarmupMultiStepLR"
@@ -379,10 +444,19 @@ class DataParallel:
         # force_exchange: run the collectives even in a 1-rank group (exercises the RCCL path on a single-GPU box)
         self.exchange = self.world > 1 or (force_exchange and dist.is_available() and dist.is_initialized())
         self.engine.fc1_grad_slabs = slabs if self.world > 1 else 1
-        self.engine.grad_ready_hook = self._on_ready if self.world > 1 else None
+        if self.world > 1:
+            if getattr(self.engine, "grad_ready_hook", None) is not None:
+                raise DrnError("the head engine already has a gradient hook (FusedSGD.enable_pipelined ran first): build "
+                               "DataParallel before the optimizer's pipelined mode and pass it as enable_pipelined(dp)")
+            self.engine.grad_ready_hook = self._on_ready
+        # world == 1: nothing to exchange - an existing hook (the pipelined optimizer's) is left alone
         self._use_stream = backend_stream and torch.cuda.is_available()
         self._comm = None
         self._pending = []
+        # DistributedDataParallel.no_sync(): with WSL.ITER_SIZE > 1 the micro-steps accumulate LOCALLY and only the last
+        # backward of the window announces its buckets.  (The reference's DDP averages on every backward, which is
+        # idempotent; summing an already-summed buffer again is not.)  Trainer.run_step sets this per micro-step.
+        self.sync_gradients = True
 
     def broadcast_parameters(self, src=0):
         """DistributedDataParallel's construction-time sync (detectron2/engine/defaults.py:279-282): every parameter AND
@@ -399,7 +473,11 @@ class DataParallel:
                 if lo <= t.data_ptr() < hi:
                     continue  # lives in the arena: already done
                 dist.broadcast(t.data, src, group=self.group)
-                t.data.add_(0)  # in-place touch: bumps the version counter the packed conv copies are keyed on
+        # packed conv weights / folded FrozenBN affines cached before the broadcast are stale on the non-source ranks
+        # (`.data` has its own version counter, so the keys those caches use did not move): drop them explicitly
+        for m in self.model.modules():
+            if hasattr(m, "invalidate_packs"):
+                m.invalidate_packs()
         self.engine.mark_dirty()
 
     def _reduce(self, t):
@@ -416,6 +494,8 @@ class DataParallel:
 
     def _on_ready(self, what):
         e = self.engine
+        if not self.sync_gradients:
+            return  # inside an accumulation window: the gradient stays local until the window's last backward
         if what == "backbone":  # trainable trunk (FREEZE_AT < 5): its flat gradient arena, once its backward is done
             bg = getattr(self.model, "_bb_grad_arena", None)
             if bg is not None:
@@ -442,16 +522,29 @@ class DataParallel:
 class Trainer:
     """projects/WSL/tools/train_net.py:41-117 (run_step) over detectron2/engine/train_loop.py:170-289."""
 
-    def __init__(self, cfg, model, data_loader_iter, optimizer=None, scheduler=None, parallel=None):
+    def __init__(self, cfg, model, data_loader_iter, optimizer=None, scheduler=None, parallel=None, start_iter=0):
         self.cfg, self.model = cfg, model
         self._it = data_loader_iter
         self.optimizer = optimizer or build_optimizer(cfg, model)
         self.scheduler = scheduler
         self.dp = parallel or DataParallel(model)
         self.iter_size = cfg.WSL.ITER_SIZE
-        self.iter = self.start_iter = 0
-        self.storage = EventStorage(0)
+        if self.iter_size > 1 and getattr(self.optimizer, "_pipelined", False):
+            raise DrnError("the pipelined optimizer updates each bucket during backward: WSL.ITER_SIZE must be 1")
+        # resume: `start_iter` = checkpoint["iteration"] + 1 (DefaultTrainer.resume_or_load, defaults.py:304-319)
+        self.iter = self.start_iter = int(start_iter)
+        self.storage = EventStorage(self.start_iter)
         self.last_losses = None
+
+    def resume_or_load(self, checkpointer, path="", resume=True):
+        """DefaultTrainer.resume_or_load (detectron2/engine/defaults.py:304-319): load `path` or, with resume=True and a
+        last_checkpoint in the checkpointer's directory, that checkpoint including optimizer / scheduler state; training
+        continues at the iteration after the saved one."""
+        extra = checkpointer.resume_or_load(path, resume=resume) or {}
+        if resume and checkpointer.has_checkpoint():
+            self.iter = self.start_iter = int(extra.get("iteration", -1)) + 1
+            self.storage = EventStorage(self.start_iter)
+        return extra
 
     def run_step(self):
         assert self.model.training, "[Trainer] model was changed to eval mode!"
@@ -470,13 +563,17 @@ class Trainer:
         losses = sum(loss_dict.values())
         if self.iter == self.start_iter:
             self.optimizer.zero_grad()
+        last_micro = self.iter % self.iter_size == 0  # train_net.py:105: the optimizer steps on these iterations
+        self.dp.sync_gradients = last_micro           # DDP no_sync() for the other micro-steps of the window
         (losses / self.iter_size).backward()
-        if self.iter % self.iter_size == 0:
+        if last_micro:
             self.dp.finish()
             self.optimizer.step(self.dp.grad_scale)
             self.optimizer.zero_grad()
-            if self.scheduler is not None:
-                self.scheduler.step()
+        if self.scheduler is not None:
+            # hooks.LRScheduler.after_step (detectron2/engine/hooks.py:232-235) runs after EVERY iteration: SOLVER.STEPS,
+            # WARMUP_ITERS and MAX_ITER count micro-iterations also when WSL.ITER_SIZE > 1
+            self.scheduler.step()
         self.last_losses = loss_dict  # device scalars; float() them only when you need to look (no per-iter sync)
         self.iter += 1
         self.storage.step()
@@ -637,6 +734,7 @@ class GraphedTrainStep:
     def _main_body(self):
         losses, st = self.engine.forward(None, self.rois, self.obj, True, self.img_off, self.n_img, self.gt,
                                          pooled=self.pooled)
+        self.last_state = st  # static buffers: after a replay they hold that step's MIL scores / pseudo-GT / labels
         # = sum(losses.values()).backward() without autograd's scalar adds / ones / stack launches
         self.engine.backward(st, None)   # pipelined SGD buckets fork onto the optimizer stream in here
         if not self.split_tail:
@@ -857,6 +955,9 @@ class GraphedTrainStep:
         step prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM).  With lookahead=L >= 2
         the caller also hands over the L-1 batches after that (`upcoming` = batches t+2 .. t+L: only their images are
         read); the backbone of the last one runs now.  With trunk_pairs: step(batch, next_batch, batch t+2, batch t+3)."""
+        if self._primed:
+            # the captured (or eagerly issued) SGD launches read lr / weight decay from device tables: follow the schedule
+            self.opt.refresh_tables()
         if self.trunk_pairs:
             if len(upcoming) != 2:
                 raise DrnError("GraphedTrainStep(trunk_pairs=True).step needs batches t+2 and t+3")

@@ -272,6 +272,13 @@ class OracleCfg:
     width_per_group: int = 64  # MODEL.RESNETS.WIDTH_PER_GROUP (bottleneck width of res2)
     heads: str = "oicr"  # MODEL.ROI_HEADS.NAME: "oicr" (OICRROIHeads) | "pcl" (PCLROIHeads, oracle/pcl_oracle.py) |
                          # "wsddn" (WSDDNROIHeads: refine_num = 0)
+    # bf16 "fast mode" of the product (no reference counterpart: SURVEY F5 - the reference is fp32 only).  True = the
+    # same fp32 algorithm with every value the product STORES in bf16 rounded to bf16 (round-to-nearest-even) at the same
+    # point: the normalised image, every conv output after its fused epilogue, conv / fc weights as GEMM operands, the
+    # pooled fc6 operand, fc6 / fc7 activations, the pre-activation gradients fed to the dW / dX GEMMs and the fc6
+    # weight-gradient bucket.  Accumulation, biases, FrozenBN affines, logits, losses, SGD state stay fp32.  This is what
+    # the full-size bf16 parity tests compare the HIP path with (tests/test_bench_mode_gpu.py).
+    emulate_bf16: bool = False
 
     @property
     def blocks(self):
@@ -282,15 +289,50 @@ class OracleCfg:
         return {"res2": 1, "res3": 2, "res4": 3, "res5": 4}[self.out_feature]
 
 
+class _RoundFwd(torch.autograd.Function):
+    """value rounded to bf16 (RNE, as v_cvt_pk_bf16_f32 / torch do); gradient passes through (the product's backward
+    GEMMs read the rounded stored value, which is what autograd sees downstream of this node)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.to(torch.bfloat16).to(torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _RoundBwd(torch.autograd.Function):
+    """identity forward; the GRADIENT is rounded to bf16 (pre-activation gradients are stored in bf16 for the dW / dX
+    GEMMs; the fc6 weight gradient is rounded once into its bf16 bucket)"""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.to(torch.bfloat16).to(torch.float32)
+
+
+def _q(x, cfg):
+    return _RoundFwd.apply(x) if getattr(cfg, "emulate_bf16", False) else x
+
+
+def _qb(x, cfg):
+    return _RoundBwd.apply(x) if getattr(cfg, "emulate_bf16", False) else x
+
+
 def _bn(x, p, prefix, eps=1e-5):
     """detectron2/layers/batch_norm.py:45-65 (FrozenBatchNorm2d, inference branch)."""
     return F.batch_norm(x, p[prefix + ".running_mean"], p[prefix + ".running_var"], p[prefix + ".weight"],
                         p[prefix + ".bias"], training=False, eps=eps)
 
 
-def _conv_bn(x, p, prefix, stride=1, padding=0, dilation=1):
+def _conv_bn(x, p, prefix, stride=1, padding=0, dilation=1, cfg=None):
     """detectron2/layers/wrappers.py:63-99 (Conv2d: conv -> norm -> activation)."""
-    x = F.conv2d(x, p[prefix + ".weight"], p.get(prefix + ".bias"), stride=stride, padding=padding, dilation=dilation)
+    x = F.conv2d(x, _q(p[prefix + ".weight"], cfg), p.get(prefix + ".bias"), stride=stride, padding=padding,
+                 dilation=dilation)
     if prefix + ".norm.weight" in p:
         x = _bn(x, p, prefix + ".norm")
     return x
@@ -313,23 +355,24 @@ def resnet_ws_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: OracleCf
     """BasicStem resnet_ws.py:405-416; BottleneckBlock.forward :217-237; BasicBlock.forward :87-112;
     ResNet.forward :479-502."""
     s = prefix + "stem."
-    x = F.relu(_conv_bn(x, p, s + "conv1", stride=2, padding=1))
-    x = F.relu(_conv_bn(x, p, s + "conv2", padding=1))
-    x = F.relu(_conv_bn(x, p, s + "conv3", padding=1))
+    q = lambda t: _q(t, cfg)  # bf16 mode: every conv's fused epilogue (affine [+ residual] [+ ReLU]) stores bf16
+    x = q(F.relu(_conv_bn(x, p, s + "conv1", stride=2, padding=1, cfg=cfg)))
+    x = q(F.relu(_conv_bn(x, p, s + "conv2", padding=1, cfg=cfg)))
+    x = q(F.relu(_conv_bn(x, p, s + "conv3", padding=1, cfg=cfg)))
     x = F.max_pool2d(x, 2, 2)
     feats = {}
     for name, nblk, dil, pool in resnet_ws_stage_plan(cfg):
         for b in range(nblk):
             bp = "%s%s.%d." % (prefix, name, b)
             if cfg.arch == "wsr18":
-                out = F.relu(_conv_bn(x, p, bp + "conv1", padding=dil, dilation=dil))
-                out = _conv_bn(out, p, bp + "conv2", padding=dil, dilation=dil)
+                out = q(F.relu(_conv_bn(x, p, bp + "conv1", padding=dil, dilation=dil, cfg=cfg)))
+                out = _conv_bn(out, p, bp + "conv2", padding=dil, dilation=dil, cfg=cfg)
             else:
-                out = F.relu(_conv_bn(x, p, bp + "conv1"))
-                out = F.relu(_conv_bn(out, p, bp + "conv2", padding=dil, dilation=dil))
-                out = _conv_bn(out, p, bp + "conv3")
-            sc = _conv_bn(x, p, bp + "shortcut") if (bp + "shortcut.weight") in p else x
-            x = F.relu(out + sc)
+                out = q(F.relu(_conv_bn(x, p, bp + "conv1", cfg=cfg)))
+                out = q(F.relu(_conv_bn(out, p, bp + "conv2", padding=dil, dilation=dil, cfg=cfg)))
+                out = _conv_bn(out, p, bp + "conv3", cfg=cfg)
+            sc = q(_conv_bn(x, p, bp + "shortcut", cfg=cfg)) if (bp + "shortcut.weight") in p else x
+            x = q(F.relu(out + sc))
             if pool is not None and b == nblk - 1:
                 x = F.max_pool2d(x, 2, pool)
         feats[name] = x
@@ -344,7 +387,7 @@ def vgg16_forward(p, x, cfg: OracleCfg, prefix="backbone."):
     feats = {}
     for name, nconv, dil, pool in plan:
         for i in range(nconv):
-            x = F.relu(_conv_bn(x, p, "%s%s.0.conv%d" % (prefix, name, i + 1), padding=dil, dilation=dil))
+            x = _q(F.relu(_conv_bn(x, p, "%s%s.0.conv%d" % (prefix, name, i + 1), padding=dil, dilation=dil, cfg=cfg)), cfg)
         if pool is not None:
             x = F.max_pool2d(x, 2, pool)
         feats[name] = x
@@ -377,7 +420,7 @@ def preprocess_image(images: Sequence[torch.Tensor], cfg: OracleCfg):
     out = torch.zeros(len(ims), ims[0].shape[0], H, W)
     for k, im in enumerate(ims):
         out[k, :, : im.shape[1], : im.shape[2]] = im
-    return out, [(i.shape[1], i.shape[2]) for i in ims]
+    return _q(out, cfg), [(i.shape[1], i.shape[2]) for i in ims]
 
 
 # --------------------------------------------------------------------------------------------
@@ -407,21 +450,38 @@ def dan_forward(p, x, cfg, training, dropout_masks=None, prefix="roi_heads.box_h
     {0, 1/(1-p)} multiplier tensors (injected so GPU and oracle share the mask; F8)."""
     x = torch.flatten(x, start_dim=1)
     for k in (1, 2):
-        x = F.relu(F.linear(x, p[prefix + "fc%d.weight" % k], p[prefix + "fc%d.bias" % k]))
+        w = _q(p[prefix + "fc%d.weight" % k], cfg)
+        if k == 1:
+            w = _qb(w, cfg)  # the fc6 weight gradient is rounded once into its bf16 bucket (FusedSGD.enable_pipelined)
+        # bf16 mode: the pre-activation gradient is stored in bf16 for the dW / dX GEMMs, the bias gradient is its
+        # fp32 column sum (bias_act_bwd) - hence the rounding node sits between the GEMM and the bias add
+        if getattr(cfg, "emulate_bf16", False):
+            x = F.relu(_qb(F.linear(x, w), cfg) + p[prefix + "fc%d.bias" % k])
+        else:
+            x = F.relu(F.linear(x, w, p[prefix + "fc%d.bias" % k]))
         if training:
             if dropout_masks is not None:
                 x = x * dropout_masks[k - 1]
             elif cfg.dropout > 0:
                 x = F.dropout(x, p=cfg.dropout, training=True)
+        x = _q(x, cfg)  # H1 / H2 are stored in bf16 after bias + ReLU + dropout
     return x
 
 
-def wsddn_scores(p, x, num_per_image, prefix="roi_heads.box_predictor."):
+def _head_linear(x, w, b, cfg):
+    """predictor Linear; bf16 mode: bf16 weight operand, logits stay fp32, their gradient is stored in bf16 for the
+    dW / dX GEMMs while the bias gradient is its fp32 column sum"""
+    if not getattr(cfg, "emulate_bf16", False):
+        return F.linear(x, w, b)
+    return _qb(F.linear(x, _q(w, cfg)), cfg) + b
+
+
+def wsddn_scores(p, x, num_per_image, prefix="roi_heads.box_predictor.", cfg=None):
     """fast_rcnn.py:493-527 WSDDNOutputLayers.forward."""
     outs = []
     for xx in x.split(num_per_image, dim=0):
-        cls = F.linear(xx, p[prefix + "cls.weight"], p[prefix + "cls.bias"])
-        det = F.linear(xx, p[prefix + "det.weight"], p[prefix + "det.bias"])
+        cls = _head_linear(xx, p[prefix + "cls.weight"], p[prefix + "cls.bias"], cfg)
+        det = _head_linear(xx, p[prefix + "det.weight"], p[prefix + "det.bias"], cfg)
         outs.append(F.softmax(cls, dim=1) * F.softmax(det, dim=0))
     return torch.cat(outs, dim=0)
 
@@ -507,9 +567,9 @@ def roi_heads_train(p, feat, prop_boxes, objectness, gt_classes_list, cfg: Oracl
     gt_ints, gt_oh = get_image_level_gt(gt_classes_list, K)
     pooled = pool_features(feat, prop_boxes, cfg)
     obn = torch.cat([o + 1 for o in objectness], dim=0)
-    pooled = pooled * obn.view(-1, 1, 1, 1)
+    pooled = _q(pooled * obn.view(-1, 1, 1, 1), cfg)
     x = dan_forward(p, pooled, cfg, True, dropout_masks)
-    scores = wsddn_scores(p, x, nper)
+    scores = wsddn_scores(p, x, nper, cfg=cfg)
     losses = {"loss_cls": wsddn_loss(scores, nper, gt_oh, cfg.mean_loss)}
     img_scores = predict_probs_img(scores, nper).detach()
     prev_scores = list(scores.detach().split(nper, dim=0))
@@ -524,7 +584,7 @@ def roi_heads_train(p, feat, prop_boxes, objectness, gt_classes_list, cfg: Oracl
         aux["pcl"] = []
         for k in range(cfg.refine_num):
             pre = "roi_heads.box_refinery_%d." % k
-            logits = F.linear(x, p[pre + "cls_score.weight"], p[pre + "cls_score.bias"])
+            logits = _head_linear(x, p[pre + "cls_score.weight"], p[pre + "cls_score.bias"], cfg)
             loss, tg, probs = _PclLossFn.apply(logits, prop_boxes[0].numpy(), last, gt_oh[0].numpy())
             losses["loss_cls_r%d" % k] = loss
             aux["logits"].append(logits)
@@ -542,9 +602,9 @@ def roi_heads_train(p, feat, prop_boxes, objectness, gt_classes_list, cfg: Oracl
         gt_classes = torch.cat(gcs)
         weights = torch.cat(ws)
         pre = "roi_heads.box_refinery_%d." % k
-        logits = F.linear(x, p[pre + "cls_score.weight"], p[pre + "cls_score.bias"])
+        logits = _head_linear(x, p[pre + "cls_score.weight"], p[pre + "cls_score.bias"], cfg)
         if cfg.refine_reg[k]:
-            deltas = F.linear(x, p[pre + "bbox_pred.weight"], p[pre + "bbox_pred.bias"])
+            deltas = _head_linear(x, p[pre + "bbox_pred.weight"], p[pre + "bbox_pred.bias"], cfg)
         else:
             deltas = torch.zeros(logits.shape[0], 4 * K)
         losses["loss_cls_r%d" % k] = oicr_cls_loss(logits, gt_classes, weights)
@@ -619,7 +679,7 @@ def roi_heads_inference(p, feat, prop_boxes, objectness, image_sizes, cfg: Oracl
     elif cfg.refine_reg[-1]:
         pre = "roi_heads.box_refinery_%d." % (cfg.refine_num - 1)
         probs = F.softmax(F.linear(x, p[pre + "cls_score.weight"], p[pre + "cls_score.bias"]), dim=-1)
-        deltas = F.linear(x, p[pre + "bbox_pred.weight"], p[pre + "bbox_pred.bias"])
+        deltas = _head_linear(x, p[pre + "bbox_pred.weight"], p[pre + "bbox_pred.bias"], cfg)
     else:
         probs = None
         deltas = torch.zeros(x.shape[0], 4 * K)
@@ -700,21 +760,28 @@ class SGDState:
             p[n] = p[n] - lr * self.buf[n]
 
 
-def train_step(p, batch, cfg: OracleCfg, opt: SGDState, dropout_masks=None, freeze_at=5, world_grads=None):
+def train_step(p, batch, cfg: OracleCfg, opt: SGDState, dropout_masks=None, freeze_at=5, world_grads=None,
+               return_aux=False):
     """projects/WSL/tools/train_net.py:65-117 with ITER_SIZE=1: fwd, sum of losses, bwd, SGD step.
-    world_grads: optional hook(grads)->grads emulating the DDP mean all-reduce."""
+    world_grads: optional hook(grads)->grads emulating the DDP mean all-reduce.
+    return_aux: also return roi_heads_train's intermediate values (MIL scores, pseudo-GT, labels) of this step."""
     names = trainable_names(p, cfg, freeze_at)
     leaves = {n: p[n].detach().clone().requires_grad_(True) for n in names}
     q = dict(p)
     q.update(leaves)
-    losses = model_train_losses(q, batch, cfg, dropout_masks)
+    aux = None
+    if return_aux:
+        losses, aux = model_train_losses(q, batch, cfg, dropout_masks, True)
+    else:
+        losses = model_train_losses(q, batch, cfg, dropout_masks)
     total = sum(losses.values())
     gl = torch.autograd.grad(total, [leaves[n] for n in names], allow_unused=True)
     grads = {n: (g if g is not None else torch.zeros_like(p[n])) for n, g in zip(names, gl)}
     if world_grads is not None:
         grads = world_grads(grads)
     opt.step(p, grads)
-    return {k: float(v.detach()) for k, v in losses.items()}, grads
+    out = {k: float(v.detach()) for k, v in losses.items()}
+    return (out, grads, aux) if return_aux else (out, grads)
 
 
 # --------------------------------------------------------------------------------------------

@@ -69,6 +69,26 @@ def _worker(rank, world, port, q):
         dp.finish()
         assert torch.equal(model._bb_grad_arena, torch.arange(37, dtype=torch.float32) * 3.0)
         del model._bb_grad_arena
+        # WSL.ITER_SIZE > 1 (DDP no_sync): micro-steps accumulate locally, only the window's last backward exchanges.
+        # Two micro-steps per rank with gradients g1 = base*(rank+1), g2 = 2*base*(rank+1): after the window every rank
+        # must hold sum_r (g1_r + g2_r) = 9*base - what a single process accumulating all four micro-batches holds
+        def fire():
+            e.grad_ready_hook("small")
+            for s in range(e.fc1_grad_slabs):
+                r0, r1 = s * rows, min(d1, (s + 1) * rows)
+                if r0 < r1:
+                    e.grad_ready_hook(("fc1", r0, r1))
+
+        e.arena_g.copy_(base * (rank + 1))
+        dp.sync_gradients = False
+        fire()
+        dp.finish()
+        assert torch.equal(e.arena_g, base * (rank + 1)), "no exchange inside the accumulation window"
+        e.arena_g.add_(2.0 * base * (rank + 1))  # the second micro-step's GEMMs accumulate on top
+        dp.sync_gradients = True
+        fire()
+        dp.finish()
+        assert torch.allclose(e.arena_g[:o_fc1 + c_fc1], (base * 9.0)[:o_fc1 + c_fc1])
         # the pipelined optimizer's own exchange (what the N>1 bench step uses): in bf16 mode the small bucket is cast
         # into a bf16 wire buffer (the fp32 arena keeps the local gradient), the fc6 row slabs come from the bf16
         # exchange buffer the dW GEMM writes into

@@ -1,0 +1,188 @@
+"""Trainer-side behaviour on the device (engine.py):
+  * save -> resume -> continue equals uninterrupted training, optimizer momentum + LR schedule + iteration included
+    (DefaultTrainer.resume_or_load, detectron2/engine/defaults.py:304-319);
+  * a graphed step whose SGD launches are INSIDE the captured graph follows scheduler.step() between replays;
+  * two ranks with WSL.ITER_SIZE = 2 (DDP no_sync for the non-final micro-steps) equal single-process training on the
+    mean gradient (projects/WSL/tools/train_net.py:100-113 + detectron2/engine/defaults.py:279-282)."""
+import itertools
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import golden_util as G
+from __graft_entry__ import load_package
+
+pytestmark = pytest.mark.gpu
+load_package()
+NAME = "model_r50c4_tiny"
+
+
+def _three_batches():
+    d = G.load(NAME)
+    ocfg = G.MODEL_CASES[NAME]
+    base = G.batch_from(d)
+    alt = dict(base[0])
+    alt["image"] = (255.0 - base[0]["image"]).contiguous()
+    alt["objectness_logits"] = base[0]["objectness_logits"].flip(0).contiguous()
+    alt2 = dict(base[0])
+    alt2["image"] = base[0]["image"].flip(2).contiguous()
+    alt2["proposal_boxes"] = base[0]["proposal_boxes"].flip(0).contiguous()
+    alt2["gt_classes"] = (base[0]["gt_classes"] + 1) % ocfg.num_classes
+    return int(d["seed"]), ocfg, [G.drn_inputs([base[0]]), G.drn_inputs([alt]), G.drn_inputs([alt2])]
+
+
+def _model(seed, ocfg, iter_size=1):
+    cfg, model = G.drn_model(ocfg, seed, "cuda", 5, "fp32")
+    cfg.WSL.ITER_SIZE = iter_size
+    model.roi_heads.box_head.dropout_p = 0.0
+    model.train()
+    return cfg, model
+
+
+def _weights(model):
+    return {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.requires_grad}
+
+
+def test_save_resume_continue_equals_uninterrupted(tmp_path):
+    from drn_wsod_pytorch_amd.checkpoint import DetectionCheckpointer
+    from drn_wsod_pytorch_amd.engine import Trainer, WarmupMultiStepLR, build_optimizer
+
+    seed, ocfg, batches = _three_batches()
+    order = [0, 1, 2, 1, 0, 2, 2, 1, 0]
+
+    def stream(start):
+        return iter([batches[i] for i in order[start:]] + [batches[0]] * 4)
+
+    def make(start_iter=0):
+        cfg, model = _model(seed, ocfg)
+        opt = build_optimizer(cfg, model)
+        sched = WarmupMultiStepLR(opt, [3], gamma=0.5, warmup_factor=0.1, warmup_iters=2)
+        return cfg, model, opt, sched
+
+    # uninterrupted: 5 iterations
+    cfg, model, opt, sched = make()
+    tr = Trainer(cfg, model, stream(0), optimizer=opt, scheduler=sched)
+    for _ in range(5):
+        tr.run_step()
+    torch.cuda.synchronize()
+    want = _weights(model)
+    want_lr = [g["lr"] for g in opt.param_groups]
+    # interrupted after 3 iterations
+    cfg, model, opt, sched = make()
+    tr = Trainer(cfg, model, stream(0), optimizer=opt, scheduler=sched)
+    for _ in range(3):
+        tr.run_step()
+    ck = DetectionCheckpointer(model, str(tmp_path), optimizer=opt, scheduler=sched)
+    ck.save("model_0000002", iteration=tr.iter - 1)
+    del tr, model, opt, sched
+    # a fresh process would build everything anew and resume
+    cfg, model, opt, sched = make()
+    ck = DetectionCheckpointer(model, str(tmp_path), optimizer=opt, scheduler=sched)
+    tr = Trainer(cfg, model, stream(3), optimizer=opt, scheduler=sched)
+    tr.resume_or_load(ck, "", resume=True)
+    assert tr.iter == 3 and tr.start_iter == 3 and sched.last_epoch == 3 and opt._steps == 3
+    assert opt._mom.is_cuda and opt._mom.data_ptr() != 0
+    for _ in range(2):
+        tr.run_step()
+    torch.cuda.synchronize()
+    got = _weights(model)
+    assert [g["lr"] for g in opt.param_groups] == want_lr
+    for n in want:
+        assert np.array_equal(got[n], want[n]), n  # same kernels, same inputs, restored state: bit-identical
+
+
+def test_graphed_step_with_captured_sgd_follows_the_lr_schedule():
+    from drn_wsod_pytorch_amd.engine import GraphedTrainStep, WarmupMultiStepLR, build_optimizer
+
+    seed, ocfg, batches = _three_batches()
+    seq = [batches[i] for i in (0, 1, 2, 0, 1, 1, 0, 2, 1, 0)]
+    res = []
+    for graphed in (False, True):
+        cfg, model = _model(seed, ocfg)
+        opt = build_optimizer(cfg, model)
+        sched = WarmupMultiStepLR(opt, [2, 4], gamma=0.1, warmup_factor=0.01, warmup_iters=2)
+        if graphed:
+            stepper = GraphedTrainStep(model, opt, seq[0], split_tail=False)  # optimizer.step() inside the captured graph
+        for i in range(6):
+            if graphed:
+                stepper.step(seq[i], seq[i + 1])
+            else:
+                opt.zero_grad()
+                sum(model(seq[i]).values()).backward()
+                opt.step()
+            sched.step()  # warm-up then two decays: the LR differs on every one of the six steps
+        torch.cuda.synchronize()
+        res.append(_weights(model))
+    for n in res[0]:
+        a, b = res[0][n], res[1][n]
+        assert np.abs(a - b).max() <= 1e-6 * max(np.abs(a).max(), 1e-3), n
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def _worker(rank, world, port, q):
+    try:
+        os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+        torch.cuda.set_device(0)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        load_package()
+        from drn_wsod_pytorch_amd.engine import DataParallel, Trainer, build_optimizer
+
+        seed, ocfg, batches = _three_batches()
+        cfg, model = _model(seed + 10 * rank, ocfg, iter_size=2)  # ranks start different: the broadcast fixes it
+        opt = build_optimizer(cfg, model)
+        dp = DataParallel(model)
+        dp.broadcast_parameters(0)
+        mine = [batches[(rank + j) % 3] for j in range(8)]
+        tr = Trainer(cfg, model, iter(mine), optimizer=opt, parallel=dp)
+        for _ in range(5):  # optimizer steps at iterations 0, 2, 4 (train_net.py:105); windows {0}, {1,2}, {3,4}
+            tr.run_step()
+        torch.cuda.synchronize()
+        q.put((rank, "ok", _weights(model)))
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: %r\n%s" % (ex, traceback.format_exc()), None))
+    finally:
+        if dist.is_initialized():
+            dist.destroy_process_group()
+
+
+def test_two_ranks_iter_size_two_equals_mean_gradient_training():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r[1]
+    for n in res[0][2]:
+        assert np.array_equal(res[0][2][n], res[1][2][n]), n  # replicas stay identical
+    # single process on the mean gradient: per window, every rank's micro-batches at weight 1/ITER_SIZE * 1/world
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    seed, ocfg, batches = _three_batches()
+    cfg, model = _model(seed, ocfg)
+    opt = build_optimizer(cfg, model)
+    per_rank = [[batches[(rank + j) % 3] for j in range(8)] for rank in range(2)]
+    for window in ([0], [1, 2], [3, 4]):
+        opt.zero_grad()
+        for it, rank in itertools.product(window, range(2)):
+            (sum(model(per_rank[rank][it]).values()) * 0.25).backward()
+        opt.step()
+    torch.cuda.synchronize()
+    for n, p in model.named_parameters():
+        if p.requires_grad and n in res[0][2]:
+            diff = float((p.detach().cpu() - torch.from_numpy(res[0][2][n])).abs().max())
+            assert diff <= 5e-6 * max(float(p.detach().abs().max()), 1.0), (n, diff)
