@@ -10,8 +10,13 @@ synthetic input: one 224x224 image per GPU per iteration (the reference's operat
 fp32 accumulation.  One step = forward + backward + gradient all-reduce (N > 1) + fused SGD step.
 Inputs are generated once and are resident in HBM before the timed region starts.
 
-Prints ONE JSON line (rank 0) with `roofline` (dominant kernel = the fc6 MFMA GEMM, timed live with HIP events on
-its own stream) and `cpu_baseline` (the oracle — a port — timed on this box's host cores on the same workload)."""
+Prints ONE JSON line (rank 0) with
+  `roofline`          dominant kernel's launch in the step: the fc6 forward launch of gemm_nt256_kernel, issued eagerly in
+                      front of the replayed heads graph and bracketed by HIP events on its stream INSIDE the timed region
+  `roofline_launches` the same for every launch of that kernel in the step (fc6 forward + the fc6 dW row slabs)
+  `roofline_step`     the whole step: algorithmic FLOPs x steps / timed wall time against the bf16 MFMA peak
+  `roofline_hbm`      the two HBM-bound kernels (ROIPool+A^T, fused SGD on the run's live arena), timed after the region
+  `cpu_baseline`      the oracle - a port - timed on this box's host cores on the same workload."""
 import argparse
 import json
 import math
@@ -30,6 +35,17 @@ from __graft_entry__ import load_package  # noqa: E402
 
 METRIC = "images/sec training, VOC07 DRN-WSOD R50-C4 2k proposals, 1/2/4/8 GPUs"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
+
+
+CONV_GF = {"r50c4": 7.90, "r50dc5": 37.24, "r101c4_k80": 15.33}  # trunk forward GFLOP at 224x224
+
+
+def step_gflop(workload, R, K1, D1, D2, NH, ims=1):
+    """Algorithmic FLOPs of ONE training step per GPU (SURVEY 8(d), 2*M*N*K per GEMM, frozen trunk): trunk forward +
+    fc6 forward and dW + fc7 forward, dW, dX + the concatenated predictor GEMM forward, dW, dX.  R50-C4, R = 2000:
+    7.90 + 822.08 + 100.66 + 5.06 = 935.7 GF."""
+    g = lambda m, n, k: 2.0 * m * n * k / 1e9
+    return ims * (CONV_GF[workload] + 2 * g(R, D1, K1) + 3 * g(R, D2, D1) + 3 * g(R, NH, D2))
 
 
 def build_cfg(pkg, device, R50_C4=True):
@@ -136,7 +152,7 @@ def cpu_baseline(batches, n_steps=10, threads=32):
                       "host) + oracle/roi_ops.c" % (n_steps, threads)}
 
 
-def hbm_rooflines(model, batch, R, device, ops):
+def hbm_rooflines(model, batch, R, device, ops, opt=None):
     """The two dominant HBM-bound kernels of the step, timed on their own with HIP events (5 launches each, scratch
     buffers of the workload's sizes, after the timed region): achieved = ALGORITHMIC bytes / launch duration against
     the 8 TB/s HBM3E peak (MI355X_MICROARCH.md).
@@ -175,18 +191,22 @@ def hbm_rooflines(model, batch, R, device, ops):
                     "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
                     "bytes_per_launch": nbytes, "avg_launch_ms": t * 1e3})
         D1 = heads.box_head.fc1.weight.shape[0]
-        n = (D1 // 2) * K1
-        w = torch.zeros((n,), device=device)
-        m = torch.zeros_like(w)
-        g = torch.zeros((n,), dtype=torch.bfloat16, device=device)
-        sh = torch.zeros((n,), dtype=torch.bfloat16, device=device)
-        seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
-        seg[0] = (0, n, 0.01, 5e-4)
-        seg_dev = torch.from_numpy(seg.view(np.uint8)).to(device)
-        t = timed(lambda: ops.sgd_step(w, m, g, seg_dev, 1, 0.9, False, shadow=sh))
-        out.append({"kernel": "sgd_kernel<shadow, bf16 grad> (one fc6 row slab: %d parameters)" % n, "bound": "hbm",
-                    "achieved": 20.0 * n / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": 20.0 * n / t / 1e9 / 8000.0,
-                    "bytes_per_launch": 20 * n, "avg_launch_ms": t * 1e3})
+        if opt is not None and getattr(opt, "_mom", None) is not None and eng.arena_s is not None \
+                and getattr(eng, "fc1_grad_bucket", None) is not None:
+            # the LIVE buffers of the run (random weights, the momentum and the bf16 gradient bucket the last step left):
+            # zero-filled operands clock ~19 % higher (MI355X_MICROARCH.md, DVFS note).  lr = 0, wd = 0: the weights keep
+            # their values (the momentum buffer moves; the run is over)
+            o, _ = eng._seg["fc1.weight"]
+            rows = D1 // 2
+            n = rows * K1
+            seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+            seg[0] = (o, n, 0.0, 0.0)
+            seg_dev = torch.from_numpy(seg.view(np.uint8)).to(device)
+            t = timed(lambda: ops.sgd_step(eng.arena_w, opt._mom, eng.fc1_grad_bucket, seg_dev, 1, 0.9, False,
+                                           shadow=eng.arena_s, grad_off=o))
+            out.append({"kernel": "sgd_kernel<shadow, bf16 grad> (one fc6 row slab: %d parameters, live arena)" % n,
+                        "bound": "hbm", "achieved": 20.0 * n / t / 1e9, "peak": 8000.0, "unit": "GB/s",
+                        "frac": 20.0 * n / t / 1e9 / 8000.0, "bytes_per_launch": 20 * n, "avg_launch_ms": t * 1e3})
     return out
 
 
@@ -218,7 +238,7 @@ def pmc_mfma_util(shape):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -241,6 +261,11 @@ def main():
                     help="oicr = the BASELINE workload; pcl = PCLROIHeads on the same trunk (SURVEY 8f rank 4; a side "
                          "measurement, not the headline metric)")
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
+    ap.add_argument("--no-eager-fc6", action="store_true",
+                    help="keep the fc6 forward GEMM inside the captured heads graph (it is then timed on the eager warm-up "
+                         "steps only)")
+    ap.add_argument("--no-launch-timing", action="store_true",
+                    help="no HIP events around the eagerly issued GEMMs in the timed region (A/B: what the events cost)")
     ap.add_argument("--no-pipelined-sgd", action="store_true", help="plain optimizer.step() after backward")
     ap.add_argument("--fused-sgd", action="store_true",
                     help="N=1 only: fc6 dW GEMM with the SGD update as its epilogue (drn_gemm_nt_sgd; measured "
@@ -337,8 +362,10 @@ def main():
 
         ops.GEMM_TIMING = None
         split = dp.exchange or (args.tail != "graph" and not args.no_pipelined_sgd)
+        # eager_fc6: the fc6 forward GEMM is issued eagerly in front of the heads graph (the fc6 dW slabs already are,
+        # behind it), so all three launches of the dominant kernel are bracketed by HIP events INSIDE the timed region
         stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead,
-                                   trunk_pairs=args.trunk_pairs)
+                                   trunk_pairs=args.trunk_pairs, eager_fc6=not args.no_eager_fc6)
         try:
             for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
                 last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
@@ -348,13 +375,18 @@ def main():
             model.roi_heads._engine.defer_fc1_tail = False
     if use_graph:
         barrier()
+        timing = []
         t0 = time.perf_counter()
         for i in range(args.steps):
             j = args.warmup + i
+            # HIP events around the eagerly issued GEMMs on every 5th step of the timed region (every step costs 2.6 % of
+            # the step rate, measured A/B on one box: 585 vs 601 img/s; sampled: within noise)
+            ops.GEMM_TIMING = timing if (not args.no_launch_timing and i % 5 == 2) else None
             last = stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
         t_enq = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
+        ops.GEMM_TIMING = None
     else:
         ops.GEMM_TIMING = timing = []
         t0 = time.perf_counter()
@@ -372,20 +404,63 @@ def main():
     assert all(math.isfinite(v) for v in loss_vals.values()), loss_vals
 
     if rank == 0:
-        # dominant kernel: gemm_nt_kernel<bf16,128,128> at the fc6 forward shape [R x 50176] . [2048 x 50176]^T
+        # dominant kernel: gemm_nt256_kernel<bf16, PIPE> - fc6 forward [R x K1] . [D1 x K1]^T and the fc6 weight gradient
+        # [rows x R] . [K1 x R]^T in row slabs.  Every launch is bracketed by HIP events on its launch stream.
         D1, K1 = model.roi_heads.box_head.fc1.weight.shape
-        fwd = [(a.elapsed_time(b), fl) for (a, b, fl, shape) in timing if shape == (R, D1, K1)]
+        D2 = model.roi_heads.box_head.fc2.weight.shape[0]
+        NH = model.roi_heads._engine.NH
+        Rtot = R * args.ims_per_gpu
+        K1p, Mp = ops.kpad(K1, torch.bfloat16), ops.kpad(Rtot, torch.bfloat16)
+        where = ("the timed region (every 5th step): issued eagerly around the replayed heads graph, HIP events on the launch stream"
+                 if use_graph else "the timed region (HIP events on the launch stream)")
+        if use_graph and (args.no_launch_timing or args.no_eager_fc6):
+            where = "eager warm-up steps of this run (HIP events on the launch stream)"
+
+        def entry(name, shapes, flops=None):
+            """flops: ALGORITHMIC FLOPs of the launch (the K dimension of the dW GEMM is R, not its padding to 64)"""
+            sel = [(a.elapsed_time(b), fl) for (a, b, fl, shape) in timing if shape in shapes]
+            if not sel:
+                return None
+            ms = sum(t for t, _ in sel) / len(sel)
+            fl = flops if flops is not None else sum(f for _, f in sel) / len(sel)
+            ach = fl / (ms * 1e-3) / 1e12
+            return {"kernel": name, "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": ach / BF16_MFMA_PEAK_TFLOPS, "gflop_per_launch": fl / 1e9, "avg_launch_ms": ms,
+                    "launches_timed": len(sel)}
+
+        fwd = entry("gemm_nt256_kernel<bf16> fc6 forward [%d x %d] . [%d x %d]^T (split-K)" % (Rtot, K1, D1, K1),
+                    {(Rtot, D1, K1p)}, 2.0 * Rtot * D1 * K1)
         roof = None
+        launches = []
         if fwd:
-            ms = sum(t for t, _ in fwd) / len(fwd)
-            achieved = fwd[0][1] / (ms * 1e-3) / 1e12
-            roof = {"bound": "mfma", "achieved": achieved, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": achieved / BF16_MFMA_PEAK_TFLOPS, "traffic": pmc_traffic((R, D1, K1)),
-                    "mfma_util_pmc": pmc_mfma_util((R, D1, K1)),
-                    "kernel": "gemm_nt256_kernel<bf16> (fc6 fwd: [%d x %d] . [%d x %d]^T, split-K 4)" % (R, K1, D1, K1),
-                    "avg_launch_ms": ms, "launches_timed": len(fwd),
-                    "timed_in": "eager warm-up steps of this run (HIP events on the launch stream)" if use_graph
-                    else "the timed region (HIP events on the launch stream)"}
+            roof = dict(fwd)
+            roof.update({"traffic": pmc_traffic((Rtot, D1, K1)), "traffic_source": "profiles/r1_04_pmc_fc6_gemm.json: "
+                         "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/pmc_gemm.py for this kernel and "
+                         "shape - PMC counters cannot be read from inside this process",
+                         "mfma_util_pmc": pmc_mfma_util((Rtot, D1, K1)),
+                         "mfma_util_source": "profiles/r1_08_pmc_mfma_fc6_gemm.json (same method)", "timed_in": where})
+            launches.append(fwd)
+        ends = getattr(model.roi_heads._engine, "fc1_slab_ends", None) or [D1]
+        r0 = 0
+        for r1 in ends:
+            e_ = entry("gemm_nt256_kernel<bf16> fc6 dW rows %d:%d  [%d x %d] . [%d x %d]^T" % (r0, r1, r1 - r0, Rtot, K1, Rtot),
+                       {(r1 - r0, K1, Mp)}, 2.0 * (r1 - r0) * K1 * Rtot)
+            if e_:
+                launches.append(e_)
+            r0 = r1
+        fused = entry("gemm_nt256_kernel<bf16, SGD> fc6 dW + optimizer epilogue", {("sgd", D1, K1, Mp)}, 2.0 * D1 * K1 * Rtot)
+        if fused:
+            launches.append(fused)
+        gf_step = step_gflop(args.workload, R, K1, D1, D2, NH, args.ims_per_gpu)
+        step_tf = gf_step * 1e9 / (dt / args.steps) / 1e12
+        roof_step = {"bound": "mfma", "achieved": step_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": step_tf / BF16_MFMA_PEAK_TFLOPS, "gflop_per_step": gf_step,
+                     "definition": "algorithmic FLOPs of the whole step (SURVEY 8(d): trunk fwd + fc6 fwd/dW + fc7 fwd/dW/dX "
+                                   "+ predictors fwd/dW/dX) x steps / timed wall time, per GPU"}
+        if launches:
+            roof_step["dominant_kernel_ms_per_step"] = sum(l["avg_launch_ms"] for l in launches)
+            roof_step["dominant_kernel_tflops_in_step"] = (sum(l["gflop_per_launch"] for l in launches) / 1e3 /
+                                                           (roof_step["dominant_kernel_ms_per_step"] * 1e-3))
         out = {"metric": METRIC, "value": world * args.ims_per_gpu * args.steps / dt, "unit": "images/sec", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
@@ -403,10 +478,10 @@ def main():
                "grad_exchange": None if not dp.exchange else {
                    "collective": "RCCL all-reduce per bucket (small tensors and fc6 dW row slabs in fc6_grad_dtype on the wire)",
                    "slab_ends": getattr(opt, "_slab_ends", None)},
-               "roofline": roof}
+               "roofline": roof, "roofline_step": roof_step, "roofline_launches": launches}
         if world == 1 and not dp.exchange:
             try:
-                out["roofline_hbm"] = hbm_rooflines(model, batches[0], R, device, ops)
+                out["roofline_hbm"] = hbm_rooflines(model, batches[0], R, device, ops, opt)
             except Exception as ex:  # noqa: BLE001 - supporting evidence only, never at the cost of the main line
                 out["roofline_hbm"] = "unavailable: %r" % (ex,)
         if world == 1 and not args.no_cpu_baseline:

@@ -30,6 +30,7 @@ _SIGS = {
     "drn_gemm_nt": "pppiiillliiilip",
     "drn_gemm_nt_sgd": "ppiiilli" + "ppplp" + "fifp",
     "drn_gemm_set_tile": "i",
+    "drn_tune": "ii",
     "drn_bias_act_fwd": "pilppQpfplpliiliip",
     "drn_counter_add": "pQp",
     "drn_colsum_reduce": "piipip",

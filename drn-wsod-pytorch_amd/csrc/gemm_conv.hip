@@ -36,6 +36,7 @@ struct GemmParams {
   float sgd_momentum, sgd_grad_scale;
   int sgd_first_step;
   int c_bf16;  // C holds bf16 (gradient buckets that cross xGMI in bf16); splits == 1, no accumulate
+  int nsplit;  // number of K-splits (the persistent kernel's grid is 1-D: it cannot read it from gridDim.y)
 };
 
 struct ConvParams {
@@ -505,6 +506,251 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// PERSISTENT form of the 256x256 kernel (same tile, same LDS-DMA pipeline, same scheduling groups): the grid is one
+// workgroup per CU and every workgroup walks its share of the (tile, K-split) list.
+//   * A one-tile workgroup gives its CU back when it retires; with an HBM-streaming kernel (the optimizer pass) on
+//     another stream, that kernel's small, long-lived workgroups take the freed registers and the next 128-KB-LDS /
+//     400-VGPR GEMM workgroup cannot be placed there any more: the GEMM loses whole CUs ("overlap" measured as time
+//     slicing in round 1).  A persistent workgroup keeps its CU; the streaming kernel runs in what is left over
+//     (112 VGPRs per SIMD beside two 200-VGPR waves).
+//   * The first slab of the NEXT tile is issued (LDS-DMA into stage 0) before the current tile's epilogue stores, so the
+//     epilogue and the prologue latency overlap instead of costing a workgroup launch per tile.
+// Work order: workgroup (xcd = bid & 7, idx = bid >> 3) takes elements idx, idx + nwg/8, ... of its XCD's contiguous
+// chunk of the logical (tile, split) list - the same elements in the same temporal order as the one-tile grid under the
+// dispatcher's round-robin, so the L2 reuse pattern of the XCD patch mapping is unchanged.
+struct GemmWork { int bm, bn, s0, s1, split; __amdgpu_buffer_rsrc_t ra, rb; };  // one (tile, K-split) work item
+
+template <int DT, bool SGD>
+__global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = DT == DRN_BF16 ? 2 : 4;
+  constexpr int BM = 256, BN = 256, MI = 4, NJ = 2;
+  constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
+  const int tiles_m = (p.M + BM - 1) / BM, tiles_n = (p.N + BN - 1) / BN;
+  const int tiles = tiles_m * tiles_n;
+  const int total = tiles * p.nsplit;
+  const int nslab = p.K * ES / 128;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const int bid = blockIdx.x, per = gridDim.x >> 3;
+  const int xcd = bid & 7, q = total >> 3, r = total & 7;
+  const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  const int len = q + (xcd < r ? 1 : 0);
+  int j = bid >> 3;
+  if (j >= len) return;
+  const unsigned lda_b = (unsigned)(p.lda * ES), ldb_b = (unsigned)(p.ldb * ES);
+  unsigned voa[4], vob[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned row = i * 64 + (tid >> 3), ks = (tid & 7) ^ ((row >> 1) & 7);
+    voa[i] = row * lda_b + ks * 16;
+    vob[i] = row * ldb_b + ks * 16;
+  }
+  using Work = GemmWork;
+  auto setup = [&](int logical, Work& w) {
+    w.split = logical / tiles;
+    int tm, tn;
+    tile_coords(logical - w.split * tiles, tiles_m, tiles_n, tm, tn);
+    w.bm = tm * BM;
+    w.bn = tn * BN;
+    w.s0 = w.split * p.k_slabs_per_split;
+    w.s1 = w.s0 + p.k_slabs_per_split < nslab ? w.s0 + p.k_slabs_per_split : nslab;
+    w.ra = make_row_loader(p.A, w.bm, p.M, BM, p.lda * ES).rsrc;
+    w.rb = make_row_loader(p.B, w.bn, p.N, BN, p.ldb * ES).rsrc;
+  };
+  auto issue = [&](const Work& w, char* stage, int slab) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      char* dst = stage + (i * 64 + wave * 8) * 128;  // wave-uniform LDS base of this 1-KB piece
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w.ra, (__attribute__((address_space(3))) void*)dst, 16, voa[i], slab * 128, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(w.rb, (__attribute__((address_space(3))) void*)(dst + A_BYTES), 16, vob[i], slab * 128, 0, 0);
+    }
+  };
+  f32x16_t acc[MI][NJ];
+  auto load_frags = [&](const char* buf, int ks, i32x4_t (&fa)[MI], i32x4_t (&fb)[NJ]) {
+    const int slot = ks * 2 + (lane >> 5);
+#pragma unroll
+    for (int i = 0; i < MI; ++i) fa[i] = *(const i32x4_t*)(buf + swz(wm * 128 + i * 32 + (lane & 31), slot));
+#pragma unroll
+    for (int jj = 0; jj < NJ; ++jj) fb[jj] = *(const i32x4_t*)(buf + A_BYTES + swz(wn * 64 + jj * 32 + (lane & 31), slot));
+  };
+  auto mma_all = [&](const i32x4_t (&fa)[MI], const i32x4_t (&fb)[NJ]) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj) mma_step<DT>(acc[i][jj], fb[jj], fa[i]);  // swapped: D^T[n][m]
+  };
+  Work cur;
+  setup(base + j, cur);
+  if (cur.s0 < cur.s1) issue(cur, smem, cur.s0);
+  for (;;) {
+#pragma unroll
+    for (int i = 0; i < MI; ++i)
+#pragma unroll
+      for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+        for (int rr = 0; rr < 16; ++rr) acc[i][jj][rr] = 0.f;
+    const int s0 = cur.s0, s1 = cur.s1;
+    if (s0 < s1) {
+      i32x4_t fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab s0 (issued ahead of the previous tile's epilogue) has landed
+      __builtin_amdgcn_s_barrier();
+      if (s0 + 1 < s1) issue(cur, smem + STAGE, s0 + 1);
+      load_frags(smem, 0, fa0, fb0);
+#define DRN_INTERLEAVE()                                                     \
+  _Pragma("unroll") for (int q_ = 0; q_ < 6; ++q_) {                           \
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                        \
+    __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);                        \
+  }                                                                          \
+  __builtin_amdgcn_sched_group_barrier(0x008, 2, 0)
+      int s = s0;
+      for (; s + 1 < s1; ++s) {
+        char* cs = smem + ((s - s0) & 1) * STAGE;
+        char* nx = smem + (((s - s0) & 1) ^ 1) * STAGE;
+        load_frags(cs, 1, fa1, fb1);
+        mma_all(fa0, fb0);
+        DRN_INTERLEAVE();
+        load_frags(cs, 2, fa0, fb0);
+        mma_all(fa1, fb1);
+        DRN_INTERLEAVE();
+        load_frags(cs, 3, fa1, fb1);
+        mma_all(fa0, fb0);
+        DRN_INTERLEAVE();
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        issue(cur, cs, s + 2 < s1 ? s + 2 : s1 - 1);
+        load_frags(nx, 0, fa0, fb0);
+        mma_all(fa1, fb1);
+#pragma unroll
+        for (int q_ = 0; q_ < 6; ++q_) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+      }
+      {  // last slab of this (tile, split)
+        char* cs = smem + ((s - s0) & 1) * STAGE;
+        load_frags(cs, 1, fa1, fb1);
+        mma_all(fa0, fb0);
+        DRN_INTERLEAVE();
+        load_frags(cs, 2, fa0, fb0);
+        mma_all(fa1, fb1);
+        DRN_INTERLEAVE();
+        load_frags(cs, 3, fa1, fb1);
+        mma_all(fa0, fb0);
+        DRN_INTERLEAVE();
+        mma_all(fa1, fb1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before LDS is reused
+      }
+#undef DRN_INTERLEAVE
+    }
+    // ---- next work item: its first slab goes out before this tile's epilogue stores
+    j += per;
+    const bool more = j < len;
+    Work nxt;
+    if (more) {
+      setup(base + j, nxt);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();  // every wave is done reading both stages
+      if (nxt.s0 < nxt.s1) issue(nxt, smem, nxt.s0);
+    }
+    const int bm = cur.bm, bn = cur.bn;
+    // D^T layout: lane -> m (A row) = lane&31, register r -> n = (r&3) + 8*(r>>2) + 4*(lane>>5)
+    if constexpr (SGD) {
+#pragma clang fp contract(off)
+      const float lr = p.sgd_seg->lr, wd = p.sgd_seg->wd;
+      const float momentum = p.sgd_momentum, gs = p.sgd_grad_scale;
+      const bool first = p.sgd_first_step != 0;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = bm + wm * 128 + i * 32 + (lane & 31);
+        if (m >= p.M) continue;
+        const long row = (long)m * p.ldc;
+        f32x4_t pw[NJ][4], mm[NJ][4];
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int n = bn + wn * 64 + jj * 32 + 8 * qq + 4 * (lane >> 5);
+            pw[jj][qq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            mm[jj][qq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
+            if (n < p.N) {
+              pw[jj][qq] = *(const f32x4_t*)(p.sgd_w + row + n);
+              if (!first) mm[jj][qq] = *(const f32x4_t*)(p.sgd_mom + row + n);
+            }
+          }
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int n = bn + wn * 64 + jj * 32 + 8 * qq + 4 * (lane >> 5);
+            if (n >= p.N) continue;
+            f32x4_t nb, nw;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float d = acc[i][jj][4 * qq + e] * gs;
+              if (wd != 0.f) d = d + wd * pw[jj][qq][e];
+              nb[e] = first ? d : momentum * mm[jj][qq][e] + d;
+              nw[e] = pw[jj][qq][e] - lr * nb[e];
+            }
+            *(f32x4_t*)(p.sgd_mom + row + n) = nb;
+            *(f32x4_t*)(p.sgd_w + row + n) = nw;
+            if (p.sgd_shadow) {
+              uint2 o;
+              o.x = (uint32_t)f32_to_bf16(nw[0]) | ((uint32_t)f32_to_bf16(nw[1]) << 16);
+              o.y = (uint32_t)f32_to_bf16(nw[2]) | ((uint32_t)f32_to_bf16(nw[3]) << 16);
+              *(uint2*)(p.sgd_shadow + row + n) = o;
+            }
+          }
+      }
+    } else {
+      float* C = p.C + (long)cur.split * p.c_split_stride;
+      const bool vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0;
+#pragma unroll
+      for (int i = 0; i < MI; ++i) {
+        const int m = bm + wm * 128 + i * 32 + (lane & 31);
+        if (m >= p.M) continue;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+          for (int qq = 0; qq < 4; ++qq) {
+            const int n = bn + wn * 64 + jj * 32 + 8 * qq + 4 * (lane >> 5);
+            float* dst = C + (long)m * p.ldc + n;
+            f32x4_t v = {acc[i][jj][4 * qq], acc[i][jj][4 * qq + 1], acc[i][jj][4 * qq + 2], acc[i][jj][4 * qq + 3]};
+            if (p.c_bf16) {
+              bf16_t* d16 = (bf16_t*)p.C + (long)m * p.ldc + n;
+              if (vec_ok && n + 4 <= p.N) {
+                uint2 o;
+                o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                *(uint2*)d16 = o;
+              } else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                  if (n + e < p.N) d16[e] = f32_to_bf16(v[e]);
+              }
+            } else if (vec_ok && n + 4 <= p.N) {
+              if (p.accumulate) { const f32x4_t o = *(const f32x4_t*)dst; v += o; }
+              *(f32x4_t*)dst = v;
+            } else {
+#pragma unroll
+              for (int e = 0; e < 4; ++e)
+                if (n + e < p.N) dst[e] = p.accumulate ? dst[e] + v[e] : v[e];
+            }
+          }
+      }
+    }
+    if (!more) break;
+    cur = nxt;
+  }
+}
+
 template <int DT, int BM, int BN>
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -599,6 +845,41 @@ int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
+static int g_persistent = 1;  // drn_tune(DRN_TUNE_GEMM_PERSISTENT): 256x256 GEMMs with more work items than CUs loop
+
+static int cu_count() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess) n = prop.multiProcessorCount;
+    if (n <= 0) n = 256;
+  }
+  return n;
+}
+
+template <int DT, bool SGD>
+int launch_gemm256p(const GemmParams& p, int nwg, hipStream_t st) {
+  constexpr int smem = 2 * 512 * 128;
+  auto k = gemm_nt256p_kernel<DT, SGD>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DRN_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(512), smem, st, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// number of workgroups of the persistent launch, or 0 when the one-tile grid should be used
+static int persistent_grid(long total) {
+  if (!g_persistent) return 0;
+  const int nwg = (cu_count() / 8) * 8;
+  return (nwg >= 8 && total > nwg) ? nwg : 0;
+}
+
 template <int DT, int BM, int BN>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
@@ -629,6 +910,18 @@ int drn_gemm_set_tile(int tile) {
   return old;
 }
 
+// tuning knobs (A/B measurements and tests; defaults are the measured best).  Returns the previous value or -1.
+int drn_sgd_set_grid(int blocks_x);  // head.hip
+int drn_tune(int knob, int value) {
+  if (knob == 1) {  // DRN_TUNE_GEMM_PERSISTENT
+    const int old = g_persistent;
+    g_persistent = value != 0;
+    return old;
+  }
+  if (knob == 2) return drn_sgd_set_grid(value);  // DRN_TUNE_SGD_GRID
+  return -1;
+}
+
 // C[split][M,N] (fp32) = A[M,K] * B[N,K]^T over this split's K range.  See include/drn_wsod.h.
 int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
                 int c_dtype, int splits, long c_split_stride, int accumulate, void* stream) {
@@ -646,6 +939,7 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
   GemmParams p{(const char*)A, (const char*)B, (float*)C, M, N, K, lda, ldb, ldc, (nslab + splits - 1) / splits,
                c_split_stride, accumulate};
   p.c_bf16 = c_dtype == DRN_BF16;
+  p.nsplit = splits;
   hipStream_t st = (hipStream_t)stream;
   // 256x256 LDS-DMA kernel when it can put >= ~3/4 of the 256 CUs to work (1 workgroup of 128 KB LDS per CU);
   // otherwise the 128x128 / 64x64 register-staged kernels (more, smaller workgroups)
@@ -653,8 +947,11 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
   const int force = g_force_tile;
   if (force == 255)  // the non-pipelined 256 kernel (kept for A/B comparison)
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, false>(p, splits, st) : launch_gemm256<DRN_F32, false>(p, splits, st);
-  if ((force == 256 || (force == 0 && wg256 >= 192)) && (((uintptr_t)C) & 3) == 0)
+  if ((force == 256 || (force == 0 && wg256 >= 192)) && (((uintptr_t)C) & 3) == 0) {
+    if (const int nwg = persistent_grid(wg256))
+      return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, false>(p, nwg, st) : launch_gemm256p<DRN_F32, false>(p, nwg, st);
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true>(p, splits, st) : launch_gemm256<DRN_F32, true>(p, splits, st);
+  }
   const bool small = force == 64 || (force == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) * splits < 128);
   if (dtype == DRN_BF16) return small ? launch_gemm<DRN_BF16, 64, 64>(p, splits, st) : launch_gemm<DRN_BF16, 128, 128>(p, splits, st);
   return small ? launch_gemm<DRN_F32, 64, 64>(p, splits, st) : launch_gemm<DRN_F32, 128, 128>(p, splits, st);
@@ -673,7 +970,10 @@ int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda,
   if ((N & 3) || (ld_w & 3) || ld_w < N || (((uintptr_t)shadow) & 7)) return DRN_ERR_ARG;
   GemmParams p{(const char*)A, (const char*)B, nullptr, M, N, K, lda, ldb, ld_w, K * es / 128, 0, 0,
                weights, momentum_buf, (bf16_t*)shadow, (const SgdSeg*)seg_dev, momentum, grad_scale, first_step};
+  p.nsplit = 1;
   hipStream_t st = (hipStream_t)stream;
+  if (const int nwg = persistent_grid((long)((M + 255) / 256) * ((N + 255) / 256)))
+    return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, true>(p, nwg, st) : launch_gemm256p<DRN_F32, true>(p, nwg, st);
   return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true, true>(p, 1, st) : launch_gemm256<DRN_F32, true, true>(p, 1, st);
 }
 

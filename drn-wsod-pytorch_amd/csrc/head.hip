@@ -990,6 +990,15 @@ int drn_apply_deltas(const float* deltas, long ld_d, const float* boxes, float* 
   return DRN_OK;
 }
 
+// workgroups (x) of the optimizer kernel; each runs a grid-stride loop, i.e. lives for the whole launch.  At most two
+// 256-thread workgroups (34 VGPRs) fit on a CU beside a resident 256x256 GEMM workgroup - see drn_tune in gemm_conv.hip
+static int g_sgd_grid_x = 512;  // measured (tools/overlap_bench.py): 512 -> 6.5 TB/s, 1024 -> 5.8, 256 -> 5.3 on the fc6 slabs
+int drn_sgd_set_grid(int blocks_x) {
+  const int old = g_sgd_grid_x;
+  if (blocks_x >= 8 && blocks_x <= 65535) g_sgd_grid_x = blocks_x;
+  return old;
+}
+
 // segs_dev: device array of {int64 off, int64 cnt, float lr, float wd} (24 bytes each).  shadow (optional):
 // bf16 array with the arena's flat layout, refreshed in the same pass.
 int drn_sgd_step(float* weights, float* momentum_buf, const void* grads, int grad_dtype, long grad_off, void* shadow,
@@ -998,7 +1007,7 @@ int drn_sgd_step(float* weights, float* momentum_buf, const void* grads, int gra
   if (!weights || !momentum_buf || !grads || !segs_dev || nseg < 1) return DRN_ERR_ARG;
   if (shadow && shadow_dtype != DRN_BF16) return DRN_ERR_ARG;
   if (grad_dtype != DRN_F32 && grad_dtype != DRN_BF16) return DRN_ERR_ARG;
-  dim3 grid(1024, nseg < 32 ? nseg : 32), block(256);
+  dim3 grid(g_sgd_grid_x, nseg < 32 ? nseg : 32), block(256);
   hipStream_t st = (hipStream_t)stream;
 #define SGD_LAUNCH(SH, GD)                                                                                       \
   hipLaunchKernelGGL((sgd_kernel<SH, GD>), grid, block, 0, st, weights, momentum_buf, grads, grad_off,           \

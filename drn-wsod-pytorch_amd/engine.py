@@ -615,10 +615,15 @@ class GraphedTrainStep:
     collective is ever captured into a hipGraph, while the next image's backbone graph and pooling graph run under
     the exchange.  The optimizer stream is joined at the start of the next step."""
 
-    def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False):
+    def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False,
+                 eager_fc6=False):
         assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
         assert 1 <= lookahead <= 4
         self.lookahead = lookahead
+        # eager_fc6 (bench.py): the fc6 forward GEMM - first launch of the heads and the step's dominant kernel - is
+        # issued eagerly in front of the captured heads graph, like the fc6 dW tail behind it, so HIP events on the
+        # launch stream can bracket it inside the timed region (ops.GEMM_TIMING)
+        self.eager_fc6 = bool(eager_fc6)
         # trunk_pairs: ONE conv chain per TWO batches (t+2 and t+3, launched on even steps): the chain is latency-bound,
         # so two images cost what one costs and the per-image chain time halves - for trunks whose chain is as long as
         # the step (WS-R101).  step() then takes (batch, next, t+2, t+3).
@@ -731,10 +736,24 @@ class GraphedTrainStep:
             else:
                 self._feats[slot].copy_(self._backbone(slot))
 
+    @property
+    def last_state(self):
+        """intermediate values (MIL scores, image scores, pseudo-GT rows, labels) of the step that ran last"""
+        return self._captured_state if getattr(self, "_replayed", False) else self._eager_state
+
+    def _fc6_eager(self):
+        if self.eager_fc6:
+            self._fc6_part = self.engine.fc6_partials(self.pooled, self.rois.shape[0], True)
+
     def _main_body(self):
         losses, st = self.engine.forward(None, self.rois, self.obj, True, self.img_off, self.n_img, self.gt,
-                                         pooled=self.pooled)
-        self.last_state = st  # static buffers: after a replay they hold that step's MIL scores / pseudo-GT / labels
+                                         pooled=self.pooled, fc6_part=self._fc6_part if self.eager_fc6 else None)
+        # static buffers: after a replay the CAPTURED state holds that step's MIL scores / pseudo-GT / labels; the priming
+        # step ran eagerly (its state is the one built before the capture)
+        if torch.cuda.is_current_stream_capturing():
+            self._captured_state = st
+        else:
+            self._eager_state = st
         # = sum(losses.values()).backward() without autograd's scalar adds / ones / stack launches
         self.engine.backward(st, None)   # pipelined SGD buckets fork onto the optimizer stream in here
         if not self.split_tail:
@@ -758,6 +777,7 @@ class GraphedTrainStep:
         s1, sL = (t + 1) % L, (t + L) % L
         side = self._sides[t % (L - 1)]
         side.wait_stream(main)
+        self._fc6_eager()
         losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
         if self.split_tail:
             self.engine.run_fc1_tail()
@@ -842,6 +862,7 @@ class GraphedTrainStep:
         main = torch.cuda.current_stream()
         t = self._t
         self._side.wait_stream(main)
+        self._fc6_eager()
         losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
         if self.split_tail:
             self.engine.run_fc1_tail()
@@ -907,6 +928,7 @@ class GraphedTrainStep:
         self._side.wait_stream(main)  # staged image is in place; previous pooling has consumed feat_next
         # submit the heads graph FIRST: submitting a graph costs the host ~9 us per node, and the backbone graph has
         # 49 nodes - issued first it would leave the main stream idle for ~0.45 ms in front of the fc6 GEMM
+        self._fc6_eager()
         losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
         if self.split_tail:
             self.engine.run_fc1_tail()  # eager: dW slabs on this stream, all-reduce + SGD per bucket on the optimizer stream
@@ -955,6 +977,7 @@ class GraphedTrainStep:
         step prepares `next_batch` (backbone on the side stream, pooling behind the last dW GEMM).  With lookahead=L >= 2
         the caller also hands over the L-1 batches after that (`upcoming` = batches t+2 .. t+L: only their images are
         read); the backbone of the last one runs now.  With trunk_pairs: step(batch, next_batch, batch t+2, batch t+3)."""
+        self._replayed = self._primed
         if self._primed:
             # the captured (or eagerly issued) SGD launches read lr / weight decay from device tables: follow the schedule
             self.opt.refresh_tables()

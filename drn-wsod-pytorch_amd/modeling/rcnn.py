@@ -82,6 +82,13 @@ class GeneralizedRCNNWSL(nn.Module):
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream()
         main = torch.cuda.current_stream()
+        # the packed conv weights / folded FrozenBN affines are built lazily on first use: build (or re-validate) them
+        # HERE, on the caller's stream, so the side stream never creates buffers that the caller's own forward of the
+        # current batch reads concurrently (a first-iteration race when the prefetch precedes any forward)
+        dtype = compute_dtype()
+        for m in self.backbone.modules():
+            if hasattr(m, "packed"):
+                m.packed(dtype)
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side), torch.no_grad():
             images = self.preprocess_image(batched_inputs)
@@ -95,7 +102,12 @@ class GeneralizedRCNNWSL(nn.Module):
         if not hasattr(self, "_prefetch_cache"):
             self._prefetch_cache = {}
         if len(self._prefetch_cache) >= 2:
-            self._prefetch_cache.pop(next(iter(self._prefetch_cache)))
+            stale = self._prefetch_cache.pop(next(iter(self._prefetch_cache)))
+            if stale[3] is not None:
+                stale[3]["pooled"]["state"] = "free"  # never consumed: give its fc6-operand buffer set back
+        again = self._prefetch_cache.pop(id(batched_inputs), None)
+        if again is not None and again[3] is not None and again[3]["pooled"] is not (pooled or {}).get("pooled"):
+            again[3]["pooled"]["state"] = "free"
         self._prefetch_cache[id(batched_inputs)] = (images, features, ev, pooled)
 
     def _features(self, batched_inputs):

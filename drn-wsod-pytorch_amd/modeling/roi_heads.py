@@ -435,10 +435,13 @@ class _HeadEngine:
         self._ws[key] = w
         return w
 
-    def pool(self, feat_nhwc, rois, objectness, training, slot=None, want_argmax=False):
+    def pool(self, feat_nhwc, rois, objectness, training, slot=None, want_argmax=False, prefetch=False):
         """ROIPool/ROIAlign fused with the objectness scaling -> fc6 operand A [M, C*P*P] (+ A^T for the dW GEMM when
-        training), into one of two rotating buffer sets so that the NEXT batch can be pooled on a side stream while the
-        current batch's forward/backward still reads its own set."""
+        training), into one of two buffer sets so that the NEXT batch can be pooled on a side stream (prefetch=True)
+        while the current batch's forward/backward still reads its own set.  A set is 'pending' from its prefetch until
+        a forward consumes it, 'current' from then until the next forward; a new call never takes a pending set, and
+        takes the current one only when the other is pending AND the current batch's backward has been issued (the
+        trainer's order: prefetch of batch t+1 in front of forward t).  `slot` pins the set (GraphedTrainStep)."""
         h = self.h
         dev, dtype = feat_nhwc.device, feat_nhwc.dtype
         self.ensure(dev)
@@ -447,18 +450,36 @@ class _HeadEngine:
         key = (M, dtype, training)
         if getattr(self, "_pool_key", None) != key:
             z = lambda r_, c_: torch.zeros((r_, c_), dtype=dtype, device=dev)
-            self._pool_sets = [dict(A=z(M, ops.kpad(K1, dtype)), AT=z(K1, ops.kpad(M, dtype)) if training else None)
-                               for _ in range(2)]
-            self._pool_key, self._pool_next = key, 0
+            self._pool_sets = [dict(A=z(M, ops.kpad(K1, dtype)), AT=z(K1, ops.kpad(M, dtype)) if training else None,
+                                    state="free") for _ in range(2)]
+            self._pool_key = key
+            self._pool_current_done = True
         if slot is None:
-            slot = self._pool_next
-            self._pool_next ^= 1
+            free = [i for i, q in enumerate(self._pool_sets) if q["state"] == "free"]
+            cur = [i for i, q in enumerate(self._pool_sets) if q["state"] == "current"]
+            if free:
+                slot = free[0]
+            elif cur and (not training or self._pool_current_done):
+                slot = cur[0]
+            else:
+                raise DrnError("no free fc6-operand buffer set: at most one batch can be pooled ahead of the one in flight")
         s = self._pool_sets[slot]
+        if prefetch:
+            s["state"] = "pending"
+        else:
+            self._mark_current(s)
         ka = h.box_pooler.kernel_args()
         res = ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=s["A"], out_t=s["AT"],
                                 want_argmax=want_argmax and ka["mode"] == 0, **ka)
         s["argmax"] = res[1] if (want_argmax and ka["mode"] == 0) else None
         return s
+
+    def _mark_current(self, s):
+        for q in getattr(self, "_pool_sets", ()):
+            if q["state"] == "current" and q is not s:
+                q["state"] = "free"
+        s["state"] = "current"
+        self._pool_current_done = False
 
     @staticmethod
     def _splits(M, N, K, dtype):
@@ -471,14 +492,35 @@ class _HeadEngine:
         part = ops.gemm_nt(A, Wt, M, N, K, splits=s)
         ops.bias_act_fwd(part, M, N, bias, relu, mask, seed, drop_p, out=out, outT=outT, seed_dev=seed_dev)
 
+    def fc6_partials(self, pooled, M, training):
+        """The fc6 forward GEMM on its own (split-K partial sums into a static workspace).  GraphedTrainStep issues this
+        ONE launch eagerly in front of the captured heads graph, so that the step's dominant kernel can be bracketed
+        by HIP events on its stream inside the timed region (a node of a replayed hipGraph cannot); forward() then takes
+        the partials through `fc6_part`."""
+        h = self.h
+        dev, dtype = pooled["A"].device, pooled["A"].dtype
+        self.ensure(dev)
+        self.refresh_shadows(dtype)
+        D1, K1 = h.box_head.fc1.weight.shape
+        w = self.ws(M, dtype, training)
+        K1p = ops.kpad(K1, dtype)
+        s = self._splits(M, D1, K1p, dtype)
+        if w.get("part1") is None or w["part1"].shape[0] != s:
+            w["part1"] = torch.empty((s, M, D1), dtype=torch.float32, device=dev)
+        ops.gemm_nt(pooled["A"], self.sh["W1v"], M, D1, K1p, out=w["part1"], splits=s)
+        return w["part1"]
+
     # ---- forward -------------------------------------------------------------------------------------
-    def forward(self, feat_nhwc, rois, objectness, training, img_off=None, n_img=1, gt=None, pooled=None):
+    def forward(self, feat_nhwc, rois, objectness, training, img_off=None, n_img=1, gt=None, pooled=None,
+                fc6_part=None):
         h = self.h
         fg_hook = getattr(self, "feature_grad_hook", None) if training else None
         if pooled is None:
             pooled = self.pool(feat_nhwc, rois, objectness, training, want_argmax=fg_hook is not None)
         elif fg_hook is not None:
             raise DrnError("a trainable backbone cannot use a prefetched pooled operand")
+        else:
+            self._mark_current(pooled)  # a prefetched set is consumed by this forward
         dev, dtype = pooled["A"].device, pooled["A"].dtype
         self.ensure(dev)
         self.refresh_shadows(dtype)
@@ -500,8 +542,12 @@ class _HeadEngine:
             if getattr(self, "seed_dev", None) is None or self.seed_dev.device != dev:
                 self.seed_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
             seed, seed_dev = torch.initial_seed() & 0xFFFFFFFFFFFF, self.seed_dev
-        self._linear_fwd(w["A"], sh["W1v"], M, D1, kp(K1), fc1.bias.data, True, w["H1"], w["H1T"] if training else None,
-                         masks[0] if masks else None, seed, drop_p, seed_dev)
+        if fc6_part is not None:  # the GEMM was issued by fc6_partials() (eagerly, in front of a captured graph)
+            ops.bias_act_fwd(fc6_part, M, D1, fc1.bias.data, True, masks[0] if masks else None, seed, drop_p,
+                             out=w["H1"], outT=w["H1T"] if training else None, seed_dev=seed_dev)
+        else:
+            self._linear_fwd(w["A"], sh["W1v"], M, D1, kp(K1), fc1.bias.data, True, w["H1"],
+                             w["H1T"] if training else None, masks[0] if masks else None, seed, drop_p, seed_dev)
         self._linear_fwd(w["H1"], sh["W2"], M, D2, kp(D1), fc2.bias.data, True, w["H2"], w["H2T"] if training else None,
                          masks[1] if masks else None, seed + 0x9E3779B1, drop_p, seed_dev)
         if seed_dev is not None:
@@ -708,6 +754,7 @@ class _HeadEngine:
                     hook(("fc1", r0, r1))
                 r0 = r1
         self._grads_valid = True
+        self._pool_current_done = True  # the last reader of this batch's A^T has been issued
         skip = fused is not None or bucket is not None
         for name, p, o, n, used in self.segments:
             if used and p.grad is None and not (skip and name == "fc1.weight"):
@@ -830,7 +877,7 @@ class OICRROIHeads(ROIHeads):
     def prefetch_pooled(self, features, proposals):
         """pool a FUTURE batch's proposals (on whatever stream is current) into the engine's spare buffer set"""
         nhwc, rois, obj = self._gather_inputs(features, proposals)
-        return dict(rois=rois, obj=obj, pooled=self._engine.pool(nhwc, rois, obj, self.training))
+        return dict(rois=rois, obj=obj, pooled=self._engine.pool(nhwc, rois, obj, self.training, prefetch=True))
 
     def forward(self, images, features, proposals, targets=None, prefetched=None):
         """roi_heads_oicr.py:248-291."""

@@ -32,6 +32,14 @@ def gemm_set_tile(tile):
     return C.lib().drn_gemm_set_tile(int(tile))
 
 
+TUNE_GEMM_PERSISTENT, TUNE_SGD_GRID = 1, 2
+
+
+def tune(knob, value):
+    """drn_tune: set a tuning knob (A/B measurements, tests); returns the previous value"""
+    return C.lib().drn_tune(int(knob), int(value))
+
+
 def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
     """C[s,M,N] (fp32) = A[M,:K] @ B[N,:K]^T.  A, B: 2-D row-major device tensors of the compute dtype
     whose leading dimension may exceed K (zero padded up to kpad)."""

@@ -120,6 +120,14 @@ int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda,
 /* tuning / test hook: pin the GEMM tile to 64, 128 or 256 (0 = heuristic); returns the previous setting. */
 int drn_gemm_set_tile(int tile);
 
+/* tuning knobs for A/B measurements and tests (defaults = the measured best); returns the previous value, -1 for an
+ * unknown knob.  DRN_TUNE_GEMM_PERSISTENT (1): 0/1 - 256x256 GEMM launches with more (tile, K-split) work items than CUs
+ * run as ONE resident workgroup per CU that loops over its share (default 1; same arithmetic, bit-identical results).
+ * DRN_TUNE_SGD_GRID (2): workgroups (x) of the optimizer kernel (default 512). */
+#define DRN_TUNE_GEMM_PERSISTENT 1
+#define DRN_TUNE_SGD_GRID 2
+int drn_tune(int knob, int value);
+
 /* relu_(fc(x)) + F.dropout(p), box_head.py:88-90: sums split-K partials, adds bias, ReLU, dropout
  * (explicit multiplier mask [M][N] if given, else counter-based mask from seed (+ *seed_dev) when drop_p > 0);
  * writes out [M][ld_out] and/or its transpose outT [N][ld_outT]. */

@@ -99,6 +99,42 @@ def test_gemm_nt_tile256(drn, dtype, shape):
         drn.gemm_set_tile(prev)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K,splits", [(2000, 4500, 512, 2), (1030, 17000, 192, 1), (2304, 8192, 256, 1)])
+def test_gemm_persistent_equals_one_tile_grid(drn, dtype, M, N, K, splits):
+    """gemm_nt256p_kernel (one resident workgroup per CU walking the (tile, K-split) list) against the one-tile grid of
+    the same 256x256 kernel: same K order per output element, so every variant must be BIT-identical - plain fp32
+    output with split-K, accumulate, bf16 output; more work items than CUs (ragged last round) and ragged M / N edges."""
+    A, B = _rnd((M, K), 14), _rnd((N, K), 15)
+    Ad, Bd = _padded(A, dtype, drn), _padded(B, dtype, drn)
+    Kp = Ad.shape[1]
+    C0 = _rnd((M, N), 16).to(DEV)
+    prev_tile = drn.gemm_set_tile(256)
+    prev = drn.tune(drn.TUNE_GEMM_PERSISTENT, 0)
+    try:
+        res = []
+        for persistent in (0, 1):
+            drn.tune(drn.TUNE_GEMM_PERSISTENT, persistent)
+            out = [drn.gemm_nt(Ad, Bd, M, N, Kp, splits=splits).clone()]
+            acc = C0.clone().unsqueeze(0)
+            drn.gemm_nt(Ad, Bd, M, N, Kp, out=acc, accumulate=True)
+            out.append(acc)
+            o16 = torch.zeros((1, M, N), dtype=torch.bfloat16, device=DEV)
+            drn.gemm_nt(Ad, Bd, M, N, Kp, out=o16)
+            out.append(o16)
+            res.append(out)
+        torch.cuda.synchronize()
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        ref = _q(A, dtype).double() @ _q(B, dtype).double().t()
+        mag = _q(A, dtype).abs().double() @ _q(B, dtype).abs().double().t()
+        got = res[1][0].sum(0).cpu().double()
+        assert ((got - ref).abs() <= 4 * 2.0 ** -24 * math.sqrt(K) * mag + 1e-6).all()
+    finally:
+        drn.tune(drn.TUNE_GEMM_PERSISTENT, prev)
+        drn.gemm_set_tile(prev_tile)
+
+
 def test_gemm_asymmetric_identity(drn):
     """A = I with an ASYMMETRIC B catches a transposed C write (cdna guide rule 16)."""
     n = 128
@@ -521,7 +557,8 @@ def test_sgd_step_bf16_bucket(drn):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,wd", [(300, 520, 200, 1e-4), (512, 1024, 2000, 0.0), (77, 36, 64, 5e-4)])
+@pytest.mark.parametrize("M,N,K,wd", [(300, 520, 200, 1e-4), (512, 1024, 2000, 0.0), (77, 36, 64, 5e-4),
+                                      (2300, 8192, 128, 1e-4)])  # last: 288 tiles > #CUs -> the persistent kernel
 def test_gemm_nt_sgd_equals_gemm_then_sgd(drn, dtype, M, N, K, wd):
     """dW GEMM with the optimizer step as its epilogue == drn_gemm_nt(256 tile) followed by drn_sgd_step, bit for
     bit (weights, momentum, bf16 shadow), over a first step and two momentum steps; ragged M/N edges included."""
