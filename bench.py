@@ -260,6 +260,7 @@ def main():
     ap.add_argument("--heads", choices=["oicr", "pcl"], default="oicr",
                     help="oicr = the BASELINE workload; pcl = PCLROIHeads on the same trunk (SURVEY 8f rank 4; a side "
                          "measurement, not the headline metric)")
+    ap.add_argument("--tune", default="", help="comma-separated knob=value pairs for drn_tune (A/B runs), e.g. 3=4")
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
     ap.add_argument("--no-eager-fc6", action="store_true",
                     help="keep the fc6 forward GEMM inside the captured heads graph (it is then timed on the eager warm-up "
@@ -308,6 +309,8 @@ def main():
     from drn_wsod_pytorch_amd.engine import DataParallel, build_optimizer
     from drn_wsod_pytorch_amd.modeling import build_model
 
+    for kv in filter(None, args.tune.split(",")):
+        ops.tune(*[int(x) for x in kv.split("=")])
     cfg = build_cfg(pkg, device)
     if args.workload == "r50dc5":
         cfg.merge_from_list(["MODEL.RESNETS.OUT_FEATURES", "['res5']", "MODEL.ROI_HEADS.IN_FEATURES", "['res5']",

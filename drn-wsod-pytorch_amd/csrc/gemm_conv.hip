@@ -37,6 +37,7 @@ struct GemmParams {
   int sgd_first_step;
   int c_bf16;  // C holds bf16 (gradient buckets that cross xGMI in bf16); splits == 1, no accumulate
   int nsplit;  // number of K-splits (the persistent kernel's grid is 1-D: it cannot read it from gridDim.y)
+  int gm;      // tile rows per group of the XCD patch mapping (tile_coords)
 };
 
 struct ConvParams {
@@ -194,8 +195,7 @@ __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char
 
 // logical tile id -> (tm, tn), grouped so that a contiguous id range (one XCD's share) covers a
 // compact 2-D patch of tiles and re-reads its operand panels from that XCD's L2.
-__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn) {
-  constexpr int GM = 4;
+__device__ __forceinline__ void tile_coords(int id, int tiles_m, int tiles_n, int& tm, int& tn, int GM = 4) {
   const int group_sz = GM * tiles_n;
   const int g = id / group_sz, in_g = id - g * group_sz;
   const int first_m = g * GM;
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
   const int logical = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, tiles * gridDim.y);
   const int split = logical / tiles;
   int tm, tn;
-  tile_coords(logical - split * tiles, tiles_m, tiles_n, tm, tn);
+  tile_coords(logical - split * tiles, tiles_m, tiles_n, tm, tn, p.gm);
   const int bm = tm * BM, bn = tn * BN;
   const int nslab = p.K * ES / 128;
   const int s0 = split * p.k_slabs_per_split;
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   const int logical = xcd_remap(blockIdx.x + gridDim.x * blockIdx.y, tiles * gridDim.y);
   const int split = logical / tiles;
   int tm, tn;
-  tile_coords(logical - split * tiles, tiles_m, tiles_n, tm, tn);
+  tile_coords(logical - split * tiles, tiles_m, tiles_n, tm, tn, p.gm);
   const int bm = tm * BM, bn = tn * BN;
   const int nslab = p.K * ES / 128;
   const int s0 = split * p.k_slabs_per_split;
@@ -552,7 +552,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
   auto setup = [&](int logical, Work& w) {
     w.split = logical / tiles;
     int tm, tn;
-    tile_coords(logical - w.split * tiles, tiles_m, tiles_n, tm, tn);
+    tile_coords(logical - w.split * tiles, tiles_m, tiles_n, tm, tn, p.gm);
     w.bm = tm * BM;
     w.bn = tn * BN;
     w.s0 = w.split * p.k_slabs_per_split;
@@ -873,6 +873,18 @@ int launch_gemm256p(const GemmParams& p, int nwg, hipStream_t st) {
   return DRN_OK;
 }
 
+// Tile rows per group of the XCD patch mapping (tile_coords).  One XCD (32 CUs) works on 32 consecutive tiles of its
+// chunk at a time: GM rows x 32/GM columns.  4-row groups were tuned on the fc6 forward in round 1 (PMC: 1214 -> 612 MB).
+// For the fc6 dW (8 x 196 tiles) 8-row groups - every B panel streamed once per XCD instead of twice - were measured in
+// round 2 and are WORSE: FETCH_SIZE 734 MB vs 646 MB (profiles/r2_04_pmc_fc6_dw_gm8.json vs r2_03_..._gm4.json): the
+// 8-MB A operand (dP1^T) does not stay in the 4-MB L2 between rounds and is re-read 6 times per XCD (mostly from the
+// Infinity Cache - the counter sits on the fabric side of L2, so it counts those too); step rate unchanged.  4 stays.
+static int g_group_rows = 0;  // drn_tune(DRN_TUNE_GEMM_GROUP_ROWS): 0 = default (4)
+static int gemm256_group_rows(int M, int N, int splits) {
+  (void)M; (void)N; (void)splits;
+  return g_group_rows > 0 ? g_group_rows : 4;
+}
+
 // number of workgroups of the persistent launch, or 0 when the one-tile grid should be used
 static int persistent_grid(long total) {
   if (!g_persistent) return 0;
@@ -919,6 +931,11 @@ int drn_tune(int knob, int value) {
     return old;
   }
   if (knob == 2) return drn_sgd_set_grid(value);  // DRN_TUNE_SGD_GRID
+  if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
+    const int old = g_group_rows;
+    if (value >= 0 && value <= 64) g_group_rows = value;
+    return old;
+  }
   return -1;
 }
 
@@ -940,6 +957,7 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
                c_split_stride, accumulate};
   p.c_bf16 = c_dtype == DRN_BF16;
   p.nsplit = splits;
+  p.gm = 4;
   hipStream_t st = (hipStream_t)stream;
   // 256x256 LDS-DMA kernel when it can put >= ~3/4 of the 256 CUs to work (1 workgroup of 128 KB LDS per CU);
   // otherwise the 128x128 / 64x64 register-staged kernels (more, smaller workgroups)
@@ -948,6 +966,7 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
   if (force == 255)  // the non-pipelined 256 kernel (kept for A/B comparison)
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, false>(p, splits, st) : launch_gemm256<DRN_F32, false>(p, splits, st);
   if ((force == 256 || (force == 0 && wg256 >= 192)) && (((uintptr_t)C) & 3) == 0) {
+    p.gm = gemm256_group_rows(M, N, splits);
     if (const int nwg = persistent_grid(wg256))
       return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, false>(p, nwg, st) : launch_gemm256p<DRN_F32, false>(p, nwg, st);
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true>(p, splits, st) : launch_gemm256<DRN_F32, true>(p, splits, st);
@@ -971,6 +990,7 @@ int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda,
   GemmParams p{(const char*)A, (const char*)B, nullptr, M, N, K, lda, ldb, ld_w, K * es / 128, 0, 0,
                weights, momentum_buf, (bf16_t*)shadow, (const SgdSeg*)seg_dev, momentum, grad_scale, first_step};
   p.nsplit = 1;
+  p.gm = gemm256_group_rows(M, N, 1);
   hipStream_t st = (hipStream_t)stream;
   if (const int nwg = persistent_grid((long)((M + 255) / 256) * ((N + 255) / 256)))
     return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, true>(p, nwg, st) : launch_gemm256p<DRN_F32, true>(p, nwg, st);

@@ -32,7 +32,7 @@ def gemm_set_tile(tile):
     return C.lib().drn_gemm_set_tile(int(tile))
 
 
-TUNE_GEMM_PERSISTENT, TUNE_SGD_GRID = 1, 2
+TUNE_GEMM_PERSISTENT, TUNE_SGD_GRID, TUNE_GEMM_GROUP_ROWS = 1, 2, 3
 
 
 def tune(knob, value):

@@ -123,9 +123,11 @@ int drn_gemm_set_tile(int tile);
 /* tuning knobs for A/B measurements and tests (defaults = the measured best); returns the previous value, -1 for an
  * unknown knob.  DRN_TUNE_GEMM_PERSISTENT (1): 0/1 - 256x256 GEMM launches with more (tile, K-split) work items than CUs
  * run as ONE resident workgroup per CU that loops over its share (default 1; same arithmetic, bit-identical results).
- * DRN_TUNE_SGD_GRID (2): workgroups (x) of the optimizer kernel (default 512). */
+ * DRN_TUNE_SGD_GRID (2): workgroups (x) of the optimizer kernel (default 512).
+ * DRN_TUNE_GEMM_GROUP_ROWS (3): tile rows per group of the 256x256 GEMM's XCD patch mapping (0 = heuristic). */
 #define DRN_TUNE_GEMM_PERSISTENT 1
 #define DRN_TUNE_SGD_GRID 2
+#define DRN_TUNE_GEMM_GROUP_ROWS 3
 int drn_tune(int knob, int value);
 
 /* relu_(fc(x)) + F.dropout(p), box_head.py:88-90: sums split-K partials, adds bias, ReLU, dropout

@@ -20,9 +20,11 @@ f = rows(sys.argv[1], "FETCH_SIZE")[1:]
 w = rows(sys.argv[2], "WRITE_SIZE")[1:]
 fetch = sum(v for v, _ in f) / len(f) * 1024 * 2
 write = sum(v for v, _ in w) / len(w) * 1024
-M, N, K, S = 2000, 2048, 50176, 4
-alg = (M + N) * K * 2 + S * M * N * 4
-out = {"kernel": "gemm_nt256_kernel<bf16,PIPE> fc6 fwd", "shape": [M, N, K], "splits": S, "launches": len(f),
+import os
+
+M, N, K, S = [int(x) for x in os.environ.get("PMC_SHAPE", "2000,2048,50176,4").split(",")]  # default: fc6 forward
+alg = (M + N) * K * 2 + S * M * N * (2 if os.environ.get("PMC_BF16_OUT") else 4)
+out = {"kernel": os.environ.get("PMC_KERNEL", "gemm_nt256_kernel<bf16,PIPE> fc6 fwd"), "shape": [M, N, K], "splits": S, "launches": len(f),
        "fetch_bytes_per_launch": fetch, "write_bytes_per_launch": write, "traffic_bytes_per_launch": fetch + write,
        "algorithmic_bytes_per_launch": alg, "traffic_over_algorithmic": (fetch + write) / alg,
        "avg_duration_us_under_pmc": sum(d for _, d in f) / len(f) / 1e3,
