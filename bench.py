@@ -37,7 +37,7 @@ METRIC = "images/sec training, VOC07 DRN-WSOD R50-C4 2k proposals, 1/2/4/8 GPUs"
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
-CONV_GF = {"r50c4": 7.90, "r50dc5": 37.24, "r101c4_k80": 15.33}  # trunk forward GFLOP at 224x224
+CONV_GF = {"r50c4": 7.90, "r50c4_fp8": 7.90, "r50dc5": 37.24, "r101c4_k80": 15.33}  # trunk forward GFLOP at 224x224
 
 
 def step_gflop(workload, R, K1, D1, D2, NH, ims=1):
@@ -242,9 +242,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["r50c4", "r50dc5", "r101c4_k80"], default="r50c4",
+    ap.add_argument("--workload", choices=["r50c4", "r50dc5", "r101c4_k80", "r50c4_fp8"], default="r50c4",
                     help="r50c4 = BASELINE configs[1], the headline metric; r50dc5 (configs[2]: WS-R50 dilated C5, use with "
-                         "--proposals 4000) and r101c4_k80 (configs[3]: WS-R101 C4, 80 classes) are side measurements")
+                         "--proposals 4000), r101c4_k80 (configs[3]: WS-R101 C4, 80 classes) and r50c4_fp8 (configs[4]: the "
+                         "R50-C4 trunk on the fp8 MFMA conv path, calibrated on two synthetic images) are side measurements")
     ap.add_argument("--lookahead", type=int, choices=[1, 2, 3, 4], default=2,
                     help="how many batches ahead the frozen trunk runs (L: L-1 conv chains in flight on L-1 side streams, "
                          "each with L-1 steps to finish)")
@@ -333,6 +334,10 @@ def main():
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
     batches = synthetic_batches(8, R, K, device, rank, pkg, args.ims_per_gpu)
+    if args.workload == "r50c4_fp8":
+        # BASELINE configs[4]: per-tensor activation scales from two images run in bf16, per-channel fp8 weights
+        with torch.no_grad():
+            model.backbone.calibrate_fp8([model.preprocess_image(b).tensor for b in batches[:2]])
 
     def step(i):
         losses = model(batches[i % len(batches)])
@@ -466,8 +471,10 @@ def main():
                                                            (roof_step["dominant_kernel_ms_per_step"] * 1e-3))
         out = {"metric": METRIC, "value": world * args.ims_per_gpu * args.steps / dt, "unit": "images/sec", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
-               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "bf16 (trunk convs: fp8 e4m3fn MFMA)" if args.workload == "r50c4_fp8" else "bf16", "data": "synthetic",
                "config": {"workload": {"r50c4": "DRN-WSOD ResNet50-WS C4 (res4 out, stride 16)",
+                                       "r50c4_fp8": "SIDE MEASUREMENT configs[4]: DRN-WSOD ResNet50-WS C4, fp8 MFMA conv path",
                                        "r50dc5": "SIDE MEASUREMENT configs[2]: DRN-WSOD ResNet50-WS dilated C5 (res5 out, stride 8)",
                                        "r101c4_k80": "SIDE MEASUREMENT configs[3]: DRN-WSOD ResNet101-WS C4, 80 classes"}[args.workload]
                                       + ", VOC07-shaped synthetic 224x224, "

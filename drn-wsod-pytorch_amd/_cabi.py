@@ -9,7 +9,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libdrn_wsod_hip.so")
 
-F32, BF16 = 0, 1
+F32, BF16, FP8 = 0, 1, 2
 
 _T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c_float, "Q": ctypes.c_ulonglong}
 
@@ -17,6 +17,7 @@ _T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c
 _SIGS = {
     "drn_preprocess_nhwc": "piiipiiippip",
     "drn_conv2d_nhwc": "pppppp" + "iiiiiiiiii" + "lll" + "iip",
+    "drn_conv2d_nhwc_q": "pppppp" + "iiiiiiiiii" + "lll" + "iiiifp",
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
     "drn_tta_accumulate": "ppppllfffiip",
@@ -102,6 +103,8 @@ def dt(dtype):
         return F32
     if dtype == torch.bfloat16:
         return BF16
+    if dtype == torch.float8_e4m3fn:
+        return FP8
     raise DrnError("unsupported dtype %s" % dtype)
 
 

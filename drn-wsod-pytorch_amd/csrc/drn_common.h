@@ -10,6 +10,7 @@
 
 #define DRN_F32 0
 #define DRN_BF16 1
+#define DRN_FP8 2  /* OCP e4m3fn, one byte per element (gfx950's native fp8; NOT MI300X's fnuz); the conv trunk only */
 
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
@@ -31,6 +32,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   return __builtin_bit_cast(bf16_t, (__bf16)f);
 }
 
+// fp8 e4m3fn <-> f32.  v_cvt_pk_fp8_f32 rounds to nearest even; the clamp makes the conversion saturating (|x| > 448 would
+// otherwise become NaN), like the quantisers the oracle emulates (x.clamp(-448, 448).to(torch.float8_e4m3fn)).
+__device__ __forceinline__ float fp8_to_f32(uint8_t v) { return __builtin_amdgcn_cvt_f32_fp8((int)v, 0); }
+__device__ __forceinline__ uint8_t f32_to_fp8(float f) {
+  f = fminf(fmaxf(f, -448.f), 448.f);
+  return (uint8_t)(__builtin_amdgcn_cvt_pk_fp8_f32(f, 0.f, 0, false) & 0xff);
+}
+
 // one row of the optimizer's segment table (device memory, refreshed in place when the LR schedule moves)
 struct SgdSeg { long off; long cnt; float lr; float wd; };
 
@@ -46,7 +55,14 @@ template <> struct ElemOf<DRN_BF16> {
   static __device__ __forceinline__ void st(bf16_t* p, float v) { *p = f32_to_bf16(v); }
 };
 
-static inline int drn_esize(int dtype) { return dtype == DRN_BF16 ? 2 : 4; }
+template <> struct ElemOf<DRN_FP8> {
+  using type = uint8_t;
+  static __device__ __forceinline__ float ld(const uint8_t* p) { return fp8_to_f32(*p); }
+  static __device__ __forceinline__ void st(uint8_t* p, float v) { *p = f32_to_fp8(v); }
+};
+
+static inline int drn_esize(int dtype) { return dtype == DRN_FP8 ? 1 : dtype == DRN_BF16 ? 2 : 4; }
+template <int DT> struct EsOf { static constexpr int value = DT == DRN_FP8 ? 1 : DT == DRN_BF16 ? 2 : 4; };
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -50,6 +50,10 @@ struct ConvParams {
   int Nb, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, relu;
   int Ktot;  // KH*KW*Cin
   long ldw, ldy, ldres;
+  // quantised trunk (drn_conv2d_nhwc_q): the output / residual element types may differ from the input's (bf16 stem ->
+  // fp8, fp8 -> bf16 feature map), and an fp8 residual carries its own per-tensor scale (res_mult = s_out / s_res)
+  int out_dt, res_dt;
+  float res_mult;
 };
 
 template <int DT>
@@ -57,6 +61,14 @@ __device__ __forceinline__ void mma_step(f32x16_t& acc, const i32x4_t& a, const 
   if constexpr (DT == DRN_BF16) {
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a), __builtin_bit_cast(bf16x8_t, b),
                                                   acc, 0, 0, 0);
+  } else if constexpr (DT == DRN_FP8) {
+    // a 16-byte fragment holds 16 fp8 k-values: two K=16 steps of v_mfma_f32_32x32x16_fp8_fp8 (8 bytes per lane each;
+    // lanes 0-31 carry k 0-7, lanes 32-63 k 8-15 of a step).  A and B use the same byte -> k assignment, so any
+    // assignment is a permutation of the contraction index.
+    typedef long i64x2_t __attribute__((ext_vector_type(2)));
+    const i64x2_t al = __builtin_bit_cast(i64x2_t, a), bl = __builtin_bit_cast(i64x2_t, b);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(al[0], bl[0], acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_fp8_fp8(al[1], bl[1], acc, 0, 0, 0);
   } else {
     const f32x4_t af = __builtin_bit_cast(f32x4_t, a), bf = __builtin_bit_cast(f32x4_t, b);
 #pragma unroll
@@ -104,7 +116,7 @@ __device__ __forceinline__ RowLoader make_row_loader(const char* base, long row0
 // depth: 0.85 us per slab on the res4 3x3 convs.)
 template <int DT, int ROWS>
 struct ConvLoader {
-  static constexpr int ES = DT == DRN_BF16 ? 2 : 4;
+  static constexpr int ES = EsOf<DT>::value;
   static constexpr unsigned OOB = 0xFFFFFFF0u;
   __amdgpu_buffer_rsrc_t rsrc;  // whole input tensor (launcher guarantees < 4 GB - 16)
   int H, W, Cin, KW, dil, ntaps;
@@ -754,10 +766,8 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
 template <int DT, int BM, int BN>
 __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ES = DT == DRN_BF16 ? 2 : 4;
+  constexpr int ES = EsOf<DT>::value;
   constexpr int MI = BM / 64, NJ = BN / 64;
-  using E = ElemOf<DT>;
-  using T = typename E::type;
   const int Mtot = p.Nb * p.Ho * p.Wo;
   const int tiles_m = (Mtot + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
   int tm, tn;
@@ -805,9 +815,18 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
         const int m = bm + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < Mtot) {
           float v = acc[i][j][r] * sc + bi;
-          if (p.residual) v += E::ld((const T*)p.residual + (long)m * p.ldres + n);
+          if (p.residual) {
+            const long ri = (long)m * p.ldres + n;
+            const float rv = p.res_dt == DRN_BF16 ? bf16_to_f32(((const bf16_t*)p.residual)[ri])
+                             : p.res_dt == DRN_FP8 ? fp8_to_f32(((const uint8_t*)p.residual)[ri])
+                                                   : ((const float*)p.residual)[ri];
+            v += rv * p.res_mult;
+          }
           if (p.relu) v = fmaxf(v, 0.f);
-          E::st((T*)p.Y + (long)m * p.ldy + n, v);
+          const long yi = (long)m * p.ldy + n;
+          if (p.out_dt == DRN_BF16) ((bf16_t*)p.Y)[yi] = f32_to_bf16(v);
+          else if (p.out_dt == DRN_FP8) ((uint8_t*)p.Y)[yi] = f32_to_fp8(v);
+          else ((float*)p.Y)[yi] = v;
         }
       }
   }
@@ -997,12 +1016,15 @@ int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda,
   return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true, true>(p, 1, st) : launch_gemm256<DRN_F32, true, true>(p, 1, st);
 }
 
-// NHWC conv + per-channel affine (folded FrozenBN or bias) + optional residual + optional ReLU.
-int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, const float* bias,
-                    const void* residual, int Nb, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
-                    int pad, int dil, long ldw, long ldy, long ldres, int relu, int dtype, void* stream) {
+// NHWC conv + per-channel affine (folded FrozenBN or bias) + optional residual + optional ReLU; `dtype` is the element
+// type of x / w (fp32, bf16 or fp8 e4m3fn), y and the residual may be stored in another one (see include/drn_wsod.h).
+int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                      const void* residual, int Nb, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                      int pad, int dil, long ldw, long ldy, long ldres, int relu, int dtype, int out_dtype,
+                      int res_dtype, float res_mult, void* stream) {
   if (!x || !w || !y) return DRN_ERR_ARG;
-  if (dtype != DRN_F32 && dtype != DRN_BF16) return DRN_ERR_ARG;
+  auto known = [](int d) { return d == DRN_F32 || d == DRN_BF16 || d == DRN_FP8; };
+  if (!known(dtype) || !known(out_dtype) || (residual && !known(res_dtype))) return DRN_ERR_ARG;
   const int es = drn_esize(dtype);
   if ((Cin * es) % 16 != 0 || (ldw * es) % 16 != 0) return DRN_ERR_ARG;  // 16-B chunks never straddle taps
   const int Ho = (H + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
@@ -1012,7 +1034,7 @@ int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, c
   const int Ktot = KH * KW * Cin;
   if (ldw * es < ((Ktot * es + 127) / 128) * 128) return DRN_ERR_ARG;  // weight rows zero-padded to 128-B slabs
   ConvParams p{(const char*)x, (const char*)w, (char*)y, scale, bias, (const char*)residual, Nb, H, W, Cin, Ho, Wo,
-               Cout, KH, KW, stride, pad, dil, relu, Ktot, ldw, ldy, ldres};
+               Cout, KH, KW, stride, pad, dil, relu, Ktot, ldw, ldy, ldres, out_dtype, res_dtype, res_mult};
   hipStream_t st = (hipStream_t)stream;
   const long Mtot = (long)Nb * Ho * Wo;
   const bool small = ((Mtot + 127) / 128) * ((Cout + 127) / 128) < 128;
@@ -1021,8 +1043,19 @@ int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, c
   if (dtype == DRN_BF16)
     return small ? launch_conv<DRN_BF16, 64, 64>(p, st)
                  : narrow ? launch_conv<DRN_BF16, 128, 64>(p, st) : launch_conv<DRN_BF16, 128, 128>(p, st);
+  if (dtype == DRN_FP8)
+    return small ? launch_conv<DRN_FP8, 64, 64>(p, st)
+                 : narrow ? launch_conv<DRN_FP8, 128, 64>(p, st) : launch_conv<DRN_FP8, 128, 128>(p, st);
   return small ? launch_conv<DRN_F32, 64, 64>(p, st)
                : narrow ? launch_conv<DRN_F32, 128, 64>(p, st) : launch_conv<DRN_F32, 128, 128>(p, st);
+}
+
+int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                    const void* residual, int Nb, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                    int pad, int dil, long ldw, long ldy, long ldres, int relu, int dtype, void* stream) {
+  if (dtype != DRN_F32 && dtype != DRN_BF16) return DRN_ERR_ARG;
+  return drn_conv2d_nhwc_q(x, w, y, scale, bias, residual, Nb, H, W, Cin, Cout, KH, KW, stride, pad, dil, ldw, ldy, ldres,
+                           relu, dtype, dtype, dtype, 1.0f, stream);
 }
 
 }  // extern "C"

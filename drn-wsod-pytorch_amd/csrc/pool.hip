@@ -38,7 +38,7 @@ typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 template <int DT>
 __global__ void maxpool2x2_kernel(const char* __restrict__ x, char* __restrict__ y, int Nb, int H, int W, int C,
                                   int Ho, int Wo, int stride) {
-  constexpr int ES = DT == DRN_BF16 ? 2 : 4;
+  constexpr int ES = EsOf<DT>::value;
   constexpr int V = 16 / ES;
   const int cv = C / V;
   const long total = (long)Nb * Ho * Wo * cv;
@@ -51,7 +51,26 @@ __global__ void maxpool2x2_kernel(const char* __restrict__ x, char* __restrict__
     const char* p00 = x + (((long)(n * H + ho * stride) * W + wo * stride) * C + c) * ES;
     const long dw = (long)C * ES, dh = (long)W * C * ES;
     char* dst = y + (((long)(n * Ho + ho) * Wo + wo) * C + c) * ES;
-    if constexpr (DT == DRN_F32) {
+    if constexpr (DT == DRN_FP8) {
+      // the quantised trunk pools post-ReLU tensors only: non-negative e4m3 values order like their bytes
+      const u32x4_t a = *(const u32x4_t*)p00, b = *(const u32x4_t*)(p00 + dw);
+      const u32x4_t d = *(const u32x4_t*)(p00 + dh), e = *(const u32x4_t*)(p00 + dh + dw);
+      auto mx = [](unsigned ua, unsigned ub, unsigned ud, unsigned ue) -> unsigned {
+        unsigned o = 0;
+#pragma unroll
+        for (int k = 0; k < 32; k += 8) {
+          const unsigned m0 = max((ua >> k) & 0xffu, (ub >> k) & 0xffu), m1 = max((ud >> k) & 0xffu, (ue >> k) & 0xffu);
+          o |= max(m0, m1) << k;
+        }
+        return o;
+      };
+      u32x4_t o;
+      o.x = mx(a.x, b.x, d.x, e.x);
+      o.y = mx(a.y, b.y, d.y, e.y);
+      o.z = mx(a.z, b.z, d.z, e.z);
+      o.w = mx(a.w, b.w, d.w, e.w);
+      *(u32x4_t*)dst = o;
+    } else if constexpr (DT == DRN_F32) {
       const f32x4_t a = *(const f32x4_t*)p00, b = *(const f32x4_t*)(p00 + dw);
       const f32x4_t d = *(const f32x4_t*)(p00 + dh), e = *(const f32x4_t*)(p00 + dh + dw);
       f32x4_t o;
@@ -772,6 +791,9 @@ int drn_maxpool2x2_nhwc(const void* x, void* y, int Nb, int H, int W, int C, int
                        (char*)y, Nb, H, W, C, Ho, Wo, stride);
   else if (dtype == DRN_F32)
     hipLaunchKernelGGL(maxpool2x2_kernel<DRN_F32>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const char*)x,
+                       (char*)y, Nb, H, W, C, Ho, Wo, stride);
+  else if (dtype == DRN_FP8)
+    hipLaunchKernelGGL(maxpool2x2_kernel<DRN_FP8>, dim3(grid_for(total, 256)), dim3(256), 0, st, (const char*)x,
                        (char*)y, Nb, H, W, C, Ho, Wo, stride);
   else
     return DRN_ERR_ARG;

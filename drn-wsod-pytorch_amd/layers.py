@@ -129,8 +129,73 @@ class Conv2d(nn.Conv2d):
         assert self.stride[0] == self.stride[1] and self.padding[0] == self.padding[1]
 
     def cin_pad(self, dtype):
-        q = 8 if dtype == torch.bfloat16 else 4
+        q = 16 if dtype == ops.FP8 else 8 if dtype == torch.bfloat16 else 4
         return (self.in_channels + q - 1) // q * q
+
+    # ---- quantised trunk (BASELINE configs[4]: "fp8 MFMA conv path"; no reference counterpart) ------------
+    _fp8 = None          # dict(out_scale, out_dtype) once enable_fp8() ran
+    _calib_amax = None   # float while Backbone.calibrate_fp8() records this conv's output range
+
+    def enable_fp8(self, out_scale, out_dtype=None):
+        """Run this (frozen) conv on the fp8 MFMA path: weights quantised per output channel to OCP e4m3fn, the output
+        stored as fp8 with the per-tensor scale `out_scale` (y_q = fp8(y * out_scale)), or as `out_dtype` (bf16 for the
+        feature map that leaves the trunk) unscaled."""
+        if self.weight.requires_grad:
+            raise DrnError("the fp8 conv path is for the frozen trunk (MODEL.BACKBONE.FREEZE_AT = 5)")
+        out_dtype = out_dtype or ops.FP8
+        self._fp8 = dict(out_scale=float(out_scale) if out_dtype == ops.FP8 else 1.0, out_dtype=out_dtype)
+        self._packq_key = None
+
+    def disable_fp8(self):
+        self._fp8 = None
+
+    def packed_fp8(self, in_dtype, in_scale):
+        """(w, alpha, beta) of drn_conv2d_nhwc_q for an input stored as x * in_scale in `in_dtype`:
+        alpha[c] = bn_scale[c] * s_y / (s_x * s_w[c]), beta[c] = bn_bias[c] * s_y, w[c] = fp8(w[c] * s_w[c]) with
+        s_w[c] = 448 / max|w[c]| (a bf16 input - the image, whose +-150 range and 3-channel reduction fp8 would ruin -
+        keeps bf16 weights, s_w = 1)."""
+        q = self._fp8
+        key = (in_dtype, float(in_scale), q["out_scale"], q["out_dtype"], self.weight.data_ptr(), self.weight._version,
+               getattr(self, "_pack_gen", 0))
+        if key != getattr(self, "_packq_key", None):
+            with torch.no_grad():
+                cout, cin, kh, kw = self.weight.shape
+                w = self.weight.detach().float()
+                if self.norm is not None:
+                    bn_scale, bn_bias = self.norm.folded()
+                    if self.bias is not None:
+                        bn_bias = bn_bias + self.bias.detach().float() * bn_scale
+                else:
+                    bn_scale = torch.ones(cout, device=w.device)
+                    bn_bias = self.bias.detach().float() if self.bias is not None else torch.zeros(cout, device=w.device)
+                if in_dtype == ops.FP8:
+                    s_w = ops.FP8_MAX / w.abs().amax(dim=(1, 2, 3)).clamp_min(1e-12)
+                    wq = (w * s_w.view(-1, 1, 1, 1)).clamp(-ops.FP8_MAX, ops.FP8_MAX).to(ops.FP8)
+                else:
+                    s_w = torch.ones(cout, device=w.device)
+                    wq = w.to(in_dtype)
+                cp = self.cin_pad(in_dtype)
+                wp = torch.zeros((cout, kh, kw, cp), dtype=torch.float32, device=w.device)
+                wp[..., :cin] = wq.float().permute(0, 2, 3, 1)  # exact: every fp8 / bf16 value is an fp32 value
+                k = kh * kw * cp
+                packed = torch.zeros((cout, ops.kpad(k, in_dtype)), dtype=torch.float32, device=w.device)
+                packed[:, :k] = wp.reshape(cout, k)
+                packed = packed.to(in_dtype)
+                alpha = (bn_scale * q["out_scale"] / (float(in_scale) * s_w)).float().contiguous()
+                beta = (bn_bias * q["out_scale"]).float().contiguous()
+                self._packq, self._packq_key = (packed, alpha, beta, s_w), key
+        return self._packq
+
+    def _run_fp8(self, x, residual, relu):
+        q = self._fp8
+        s_x = getattr(x, "_drn_scale", 1.0)
+        wq, alpha, beta, _ = self.packed_fp8(x.dtype, s_x)
+        assert x.shape[-1] == self.cin_pad(x.dtype), (x.shape, self.in_channels)
+        res_mult = q["out_scale"] / getattr(residual, "_drn_scale", 1.0) if residual is not None else 1.0
+        y = ops.conv2d_nhwc_q(x, wq, self.out_channels, self.kernel_size[0], self.kernel_size[1], self.stride[0],
+                              self.padding[0], self.dilation[0], alpha, beta, q["out_dtype"], residual, res_mult, relu)
+        y._drn_scale = q["out_scale"]
+        return y
 
     def packed(self, dtype):
         """(w [Cout, ldw] K-major with k = (kh*KW + kw)*Cin_pad + ci, scale [Cout], bias [Cout]) cached until
@@ -221,10 +286,17 @@ class Conv2d(nn.Conv2d):
         if not explicit_backward and torch.is_grad_enabled() and (self.weight.requires_grad or x.requires_grad):
             raise DrnError("a stand-alone Conv2d has no autograd on this path: trainable convs run inside the backbone, "
                            "whose blocks keep what their explicit backward needs (backbone.backward_nhwc)")
+        if self._fp8 is not None:
+            if explicit_backward:
+                raise DrnError("the fp8 conv path has no backward: it serves the frozen trunk")
+            return self._run_fp8(x, residual, relu)
         wp, scale, bias = self.packed(x.dtype)
         assert x.shape[-1] == self.cin_pad(x.dtype), (x.shape, self.in_channels)
-        return ops.conv2d_nhwc(x, wp, self.out_channels, self.kernel_size[0], self.kernel_size[1], self.stride[0],
-                               self.padding[0], self.dilation[0], scale, bias, residual, relu)
+        y = ops.conv2d_nhwc(x, wp, self.out_channels, self.kernel_size[0], self.kernel_size[1], self.stride[0],
+                            self.padding[0], self.dilation[0], scale, bias, residual, relu)
+        if self._calib_amax is not None:  # Backbone.calibrate_fp8(): range of this conv's stored output
+            self._calib_amax = max(self._calib_amax, float(y.float().abs().max()))
+        return y
 
     def forward(self, x):
         dtype = compute_dtype()

@@ -27,6 +27,14 @@ def _as(t, dtype):
     return t.contiguous()
 
 
+def _pool(x, stride):
+    """2x2 max-pool that keeps the per-tensor quantisation scale of an fp8 activation"""
+    y = ops.maxpool2x2_nhwc(x, stride)
+    if hasattr(x, "_drn_scale"):
+        y._drn_scale = x._drn_scale
+    return y
+
+
 def c2_msra_fill(module):
     """fvcore.nn.weight_init.c2_msra_fill."""
     nn.init.kaiming_normal_(module.weight, mode="fan_out", nonlinearity="relu")
@@ -73,7 +81,7 @@ class BasicStem(CNNBlockBase):
         o2 = self.conv2.run_nhwc(o1, relu=True, explicit_backward=save)
         o3 = self.conv3.run_nhwc(o2, relu=True, explicit_backward=save)
         self._sv = (x, o1, o2, o3) if save else None
-        return ops.maxpool2x2_nhwc(o3, 2)
+        return _pool(o3, 2)
 
     def backward_nhwc(self, dy, need_dx, accumulate):
         """explicit backward of forward_nhwc(save=True); the image needs no gradient, so conv1 has no dgrad"""
@@ -115,7 +123,7 @@ class BasicBlock(CNNBlockBase):
         out = self.conv2.run_nhwc(o1, residual=sc, relu=True, explicit_backward=save)  # out += shortcut; relu_
         self._sv = (x, o1, sc, out) if save else None
         if self.has_pool:
-            out = ops.maxpool2x2_nhwc(out, self.pool_stride)
+            out = _pool(out, self.pool_stride)
         return out
 
     def backward_nhwc(self, dy, need_dx, accumulate):
@@ -168,7 +176,7 @@ class BottleneckBlock(CNNBlockBase):
         out = self.conv3.run_nhwc(o2, residual=sc, relu=True, explicit_backward=save)
         self._sv = (x, o1, o2, sc, out) if save else None
         if self.has_pool:
-            out = ops.maxpool2x2_nhwc(out, self.pool_stride)
+            out = _pool(out, self.pool_stride)
         return out
 
     def backward_nhwc(self, dy, need_dx, accumulate):
@@ -239,6 +247,47 @@ class ResNet(Backbone):
                 if name in self._out_features:
                     outputs[name] = from_nhwc(y)
         return outputs
+
+    # ---- fp8 MFMA conv path (BASELINE configs[4]) -------------------------------------------------------------------
+    def calibrate_fp8(self, images, margin=1.0):
+        """Put the (frozen) trunk on the fp8 path.  `images`: iterable of preprocessed [N,3,H,W] inputs (ImageList.tensor)
+        run ONCE in the bf16 mode to record the range of every conv's stored output; each activation tensor then gets
+        the per-tensor scale 448 / (margin * max|y|) (OCP e4m3fn: max 448), weights are quantised per output channel.
+        The image stays bf16 (so stem.conv1 runs bf16 x bf16 and only its OUTPUT is fp8) and the feature map that leaves
+        the trunk is written in bf16 by the last conv.  Returns {conv module name: output scale}."""
+        if compute_dtype() != torch.bfloat16:
+            raise RuntimeError("the fp8 conv path extends the bf16 mode: set_precision('bf16') first")
+        if any(p.requires_grad for p in self.parameters()):
+            raise RuntimeError("the fp8 conv path is for the frozen trunk (MODEL.BACKBONE.FREEZE_AT = 5)")
+        if len(self._out_features) != 1 or self._out_features[0] != self.stages_and_names[-1][1]:
+            raise RuntimeError("fp8 trunk: the single output feature must be the last built stage")
+        convs = {n: m for n, m in self.named_modules() if isinstance(m, Conv2d)}
+        self.disable_fp8()
+        for m in convs.values():
+            m._calib_amax = 0.0
+        with torch.no_grad():
+            for x in images:
+                self.forward(x)
+        last_block = self.stages_and_names[-1][0][-1]
+        final = last_block.conv3 if hasattr(last_block, "conv3") else last_block.conv2
+        scales = {}
+        for n, m in convs.items():
+            amax, m._calib_amax = m._calib_amax, None
+            if m is final:
+                m.enable_fp8(1.0, out_dtype=torch.bfloat16)
+                scales[n] = 1.0
+            else:
+                scales[n] = ops.FP8_MAX / max(amax * margin, 1e-12)
+                m.enable_fp8(scales[n])
+        self._fp8_scales = scales
+        return scales
+
+    def disable_fp8(self):
+        for m in self.modules():
+            if isinstance(m, Conv2d):
+                m.disable_fp8()
+                m._calib_amax = None
+        self._fp8_scales = None
 
     def backward_nhwc(self, dfeat, accumulate=False):
         """dfeat: gradient of the (single) output feature, NHWC; walks the trainable units in reverse"""

@@ -12,8 +12,12 @@ SCALE_CLAMP = math.log(1000.0 / 16)  # detectron2/modeling/box_regression.py:9
 GEMM_TIMING = None  # set to a list by bench.py to time GEMM launches with HIP events
 
 
+FP8 = torch.float8_e4m3fn  # OCP e4m3fn: gfx950's native fp8
+FP8_MAX = 448.0
+
+
 def esize(dtype):
-    return 2 if dtype == torch.bfloat16 else 4
+    return 1 if dtype == FP8 else 2 if dtype == torch.bfloat16 else 4
 
 
 def kpad(k, dtype):
@@ -89,6 +93,24 @@ def conv2d_nhwc(x, w_packed, cout, kh, kw, stride=1, pad=0, dil=1, scale=None, b
         assert residual.shape == y.shape and residual.is_contiguous()
     C.call("drn_conv2d_nhwc", C.ptr(x), C.ptr(w_packed), C.ptr(y), C.ptr(scale), C.ptr(bias), C.ptr(residual), n, h, w,
            cin, cout, kh, kw, stride, pad, dil, _2d(w_packed), cout, cout, int(relu), C.dt(x.dtype), C.stream())
+    return y
+
+
+def conv2d_nhwc_q(x, w_packed, cout, kh, kw, stride, pad, dil, scale, bias, out_dtype, residual=None, res_mult=1.0,
+                  relu=False):
+    """drn_conv2d_nhwc_q: x / w_packed in one element type (fp32, bf16 or fp8 e4m3fn), y stored as out_dtype, an
+    optional residual of any of the three types multiplied by res_mult before the add (see include/drn_wsod.h for how
+    the quantisation scales enter `scale`, `bias` and `res_mult`)."""
+    assert x.is_contiguous() and x.dim() == 4 and x.dtype == w_packed.dtype
+    n, h, w, cin = x.shape
+    ho = (h + 2 * pad - dil * (kh - 1) - 1) // stride + 1
+    wo = (w + 2 * pad - dil * (kw - 1) - 1) // stride + 1
+    y = torch.empty((n, ho, wo, cout), dtype=out_dtype, device=x.device)
+    if residual is not None:
+        assert residual.shape == y.shape and residual.is_contiguous()
+    C.call("drn_conv2d_nhwc_q", C.ptr(x), C.ptr(w_packed), C.ptr(y), C.ptr(scale), C.ptr(bias), C.ptr(residual), n, h, w,
+           cin, cout, kh, kw, stride, pad, dil, _2d(w_packed), cout, cout, int(relu), C.dt(x.dtype), C.dt(out_dtype),
+           C.dt(residual.dtype) if residual is not None else 0, float(res_mult), C.stream())
     return y
 
 

@@ -45,7 +45,22 @@ int drn_conv2d_nhwc(const void* x, const void* w, void* y, const float* scale, c
                     const void* residual, int Nb, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                     int pad, int dil, long ldw, long ldy, long ldres, int relu, int dtype, void* stream);
 
-/* nn.MaxPool2d(kernel_size=2, stride=s, padding=0), resnet_ws.py:214-215,403; vgg.py:99-100. */
+/* The same convolution for the QUANTISED trunk (BASELINE configs[4], "fp8 MFMA conv path"; the reference is fp32 only -
+ * SURVEY F5 - so the definition of record is the fp32 conv above with operands and activations rounded to fp8):
+ * `dtype` (DRN_F32 / DRN_BF16 / DRN_FP8 = OCP e4m3fn, one byte) is the element type of x and w - DRN_FP8 runs
+ * v_mfma_f32_32x32x16_fp8_fp8 with fp32 accumulation - while y is stored as `out_dtype` and the residual read as
+ * `res_dtype` and multiplied by `res_mult`.  Per-tensor / per-output-channel quantisation scales live in the caller's
+ * affine: with x stored as x*s_x, w[c] as w[c]*s_w[c], y as y*s_y and the residual as r*s_r the caller passes
+ * scale[c] = bn_scale[c]*s_y/(s_x*s_w[c]), bias[c] = bn_bias[c]*s_y, res_mult = s_y/s_r (s_y = 1 for a bf16/fp32 y).
+ * fp8 stores round to nearest even and saturate at +-448.  Cin*esize must be a multiple of 16 bytes. */
+#define DRN_FP8 2
+int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale, const float* bias,
+                      const void* residual, int Nb, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
+                      int pad, int dil, long ldw, long ldy, long ldres, int relu, int dtype, int out_dtype,
+                      int res_dtype, float res_mult, void* stream);
+
+/* nn.MaxPool2d(kernel_size=2, stride=s, padding=0), resnet_ws.py:214-215,403; vgg.py:99-100.  DRN_FP8: non-negative
+ * (post-ReLU) values only - they order like their bytes. */
 int drn_maxpool2x2_nhwc(const void* x, void* y, int Nb, int H, int W, int C, int stride, int dtype, void* stream);
 
 /* ---- backward of the conv trunk (MODEL.BACKBONE.FREEZE_AT < 5; torch.autograd of F.conv2d / max_pool2d) ---- *

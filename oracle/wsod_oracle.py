@@ -279,6 +279,13 @@ class OracleCfg:
     # weight-gradient bucket.  Accumulation, biases, FrozenBN affines, logits, losses, SGD state stay fp32.  This is what
     # the full-size bf16 parity tests compare the HIP path with (tests/test_bench_mode_gpu.py).
     emulate_bf16: bool = False
+    # fp8 conv trunk of the product (BASELINE configs[4]; again no reference counterpart).  {conv name relative to the
+    # backbone ("stem.conv1", "res2.0.shortcut", ...): per-tensor scale s_y of that conv's stored output}; the conv whose
+    # scale entry is 1.0 and that is named by fp8_last writes bf16.  Emulated like emulate_bf16: the fp32 algorithm with
+    # each stored activation rounded to OCP e4m3fn at scale s_y (round-to-nearest-even, saturating at 448) and each conv
+    # weight rounded per output channel at scale 448 / max|w[c]|; the image and stem.conv1's weights are bf16.
+    fp8_scales: Optional[dict] = None
+    fp8_last: str = ""
 
     @property
     def blocks(self):
@@ -319,6 +326,24 @@ def _q(x, cfg):
     return _RoundFwd.apply(x) if getattr(cfg, "emulate_bf16", False) else x
 
 
+FP8_MAX = 448.0
+
+
+def _fp8_round(t, s):
+    """value of t after being stored as fp8 e4m3fn at scale s"""
+    return (t * s).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).to(torch.float32) / s
+
+
+def _qt(t, cfg, name):
+    """stored value of the output of conv `name` (backbone-relative module name)"""
+    sc = getattr(cfg, "fp8_scales", None)
+    if not sc:
+        return _q(t, cfg)
+    if name == cfg.fp8_last:
+        return t.to(torch.bfloat16).to(torch.float32)
+    return _fp8_round(t, sc[name])
+
+
 def _qb(x, cfg):
     return _RoundBwd.apply(x) if getattr(cfg, "emulate_bf16", False) else x
 
@@ -331,8 +356,16 @@ def _bn(x, p, prefix, eps=1e-5):
 
 def _conv_bn(x, p, prefix, stride=1, padding=0, dilation=1, cfg=None):
     """detectron2/layers/wrappers.py:63-99 (Conv2d: conv -> norm -> activation)."""
-    x = F.conv2d(x, _q(p[prefix + ".weight"], cfg), p.get(prefix + ".bias"), stride=stride, padding=padding,
-                 dilation=dilation)
+    w = p[prefix + ".weight"]
+    if getattr(cfg, "fp8_scales", None):
+        if prefix.endswith("stem.conv1"):
+            w = w.to(torch.bfloat16).to(torch.float32)  # bf16 image x bf16 weights
+        else:
+            s_w = FP8_MAX / w.abs().amax(dim=(1, 2, 3), keepdim=True).clamp_min(1e-12)
+            w = (w * s_w).clamp(-FP8_MAX, FP8_MAX).to(torch.float8_e4m3fn).to(torch.float32) / s_w
+    else:
+        w = _q(w, cfg)
+    x = F.conv2d(x, w, p.get(prefix + ".bias"), stride=stride, padding=padding, dilation=dilation)
     if prefix + ".norm.weight" in p:
         x = _bn(x, p, prefix + ".norm")
     return x
@@ -355,24 +388,27 @@ def resnet_ws_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: OracleCf
     """BasicStem resnet_ws.py:405-416; BottleneckBlock.forward :217-237; BasicBlock.forward :87-112;
     ResNet.forward :479-502."""
     s = prefix + "stem."
-    q = lambda t: _q(t, cfg)  # bf16 mode: every conv's fused epilogue (affine [+ residual] [+ ReLU]) stores bf16
-    x = q(F.relu(_conv_bn(x, p, s + "conv1", stride=2, padding=1, cfg=cfg)))
-    x = q(F.relu(_conv_bn(x, p, s + "conv2", padding=1, cfg=cfg)))
-    x = q(F.relu(_conv_bn(x, p, s + "conv3", padding=1, cfg=cfg)))
+    # bf16 / fp8 emulation: every conv's fused epilogue (affine [+ residual] [+ ReLU]) stores a rounded value
+    q = lambda t, name: _qt(t, cfg, name[len(prefix):])
+    x = q(F.relu(_conv_bn(x, p, s + "conv1", stride=2, padding=1, cfg=cfg)), s + "conv1")
+    x = q(F.relu(_conv_bn(x, p, s + "conv2", padding=1, cfg=cfg)), s + "conv2")
+    x = q(F.relu(_conv_bn(x, p, s + "conv3", padding=1, cfg=cfg)), s + "conv3")
     x = F.max_pool2d(x, 2, 2)
     feats = {}
     for name, nblk, dil, pool in resnet_ws_stage_plan(cfg):
         for b in range(nblk):
             bp = "%s%s.%d." % (prefix, name, b)
             if cfg.arch == "wsr18":
-                out = q(F.relu(_conv_bn(x, p, bp + "conv1", padding=dil, dilation=dil, cfg=cfg)))
+                out = q(F.relu(_conv_bn(x, p, bp + "conv1", padding=dil, dilation=dil, cfg=cfg)), bp + "conv1")
                 out = _conv_bn(out, p, bp + "conv2", padding=dil, dilation=dil, cfg=cfg)
+                last = bp + "conv2"
             else:
-                out = q(F.relu(_conv_bn(x, p, bp + "conv1", cfg=cfg)))
-                out = q(F.relu(_conv_bn(out, p, bp + "conv2", padding=dil, dilation=dil, cfg=cfg)))
+                out = q(F.relu(_conv_bn(x, p, bp + "conv1", cfg=cfg)), bp + "conv1")
+                out = q(F.relu(_conv_bn(out, p, bp + "conv2", padding=dil, dilation=dil, cfg=cfg)), bp + "conv2")
                 out = _conv_bn(out, p, bp + "conv3", cfg=cfg)
-            sc = q(_conv_bn(x, p, bp + "shortcut", cfg=cfg)) if (bp + "shortcut.weight") in p else x
-            x = q(F.relu(out + sc))
+                last = bp + "conv3"
+            sc = q(_conv_bn(x, p, bp + "shortcut", cfg=cfg), bp + "shortcut") if (bp + "shortcut.weight") in p else x
+            x = q(F.relu(out + sc), last)
             if pool is not None and b == nblk - 1:
                 x = F.max_pool2d(x, 2, pool)
         feats[name] = x
@@ -420,6 +456,8 @@ def preprocess_image(images: Sequence[torch.Tensor], cfg: OracleCfg):
     out = torch.zeros(len(ims), ims[0].shape[0], H, W)
     for k, im in enumerate(ims):
         out[k, :, : im.shape[1], : im.shape[2]] = im
+    if getattr(cfg, "fp8_scales", None):
+        out = out.to(torch.bfloat16).to(torch.float32)  # the fp8 trunk extends the bf16 mode: bf16 image
     return _q(out, cfg), [(i.shape[1], i.shape[2]) for i in ims]
 
 
