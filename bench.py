@@ -282,6 +282,10 @@ def main():
                     help='torch.distributed backend ("nccl" = RCCL); gloo + --single-device runs N ranks on ONE GPU to '
                          "exercise the N>1 flow of this script where only one GPU is available (not a measurement)")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--exchange", choices=["sharded", "allreduce"], default=None,
+                    help="N > 1: sharded (default) = reduce-scatter of each fc6 gradient slab, SGD on the owned rows (1/N of "
+                         "the optimizer traffic), all-gather of the updated bf16 rows; allreduce = DDP's all-reduce + "
+                         "replicated update")
     ap.add_argument("--comm-dtype", choices=["bf16", "fp32"], default=None,
                     help="dtype of the fc6 weight-gradient buckets (HBM and xGMI); default bf16 = the compute dtype, the "
                          "rounding torch.autocast(bf16) applies to a Linear's weight gradient")
@@ -302,6 +306,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29517")
         dist.init_process_group(args.backend, rank=rank, world_size=world)  # "nccl" is RCCL on ROCm
 
+    rank_info = None
+    if dist.is_initialized():
+        # one line per rank on stderr + the gathered list in the JSON: a SCALE run proves that N ranks on N devices ran
+        props = torch.cuda.get_device_properties(local_rank)
+        mine = {"rank": rank, "pid": os.getpid(), "device": local_rank, "name": props.name,
+                "uuid": str(getattr(props, "uuid", "")), "backend": dist.get_backend(),
+                "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None}
+        print("[bench] rank %(rank)d pid %(pid)d cuda:%(device)d %(name)s uuid %(uuid)s backend %(backend)s rccl %(rccl)s"
+              % mine, file=sys.stderr, flush=True)
+        rank_info = [None] * world
+        dist.all_gather_object(rank_info, mine)
     torch.manual_seed(1234 + rank)  # detectron2/engine/defaults.py:147: SEED + rank (per-rank dropout streams)
     pkg = load_package()
     pkg._cabi.lib()  # fail loudly if the HIP library is missing
@@ -329,7 +344,8 @@ def main():
     if not args.no_pipelined_sgd:
         # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
-                             comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype])
+                             comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype],
+                             exchange=args.exchange)
         if world == 1 and args.fused_sgd:
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
@@ -486,8 +502,10 @@ def main():
                                   else "lookahead %d" % args.lookahead) if use_graph else "eager prefetch of the next batch",
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
                "grad_exchange": None if not dp.exchange else {
-                   "collective": "RCCL all-reduce per bucket (small tensors and fc6 dW row slabs in fc6_grad_dtype on the wire)",
-                   "slab_ends": getattr(opt, "_slab_ends", None)},
+                   "collective": ("RCCL reduce-scatter per fc6 dW row slab -> fused SGD on the owned rows -> all-gather of the "
+                                  "updated compute copy; all-reduce for the small tensors" if getattr(opt, "_sharded", False)
+                                  else "RCCL all-reduce per bucket (small tensors and fc6 dW row slabs)") + ", fc6_grad_dtype on the wire",
+                   "slab_ends": getattr(opt, "_slab_ends", None), "ranks": rank_info},
                "roofline": roof, "roofline_step": roof_step, "roofline_launches": launches}
         if world == 1 and not dp.exchange:
             try:

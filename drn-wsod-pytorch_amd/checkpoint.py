@@ -163,6 +163,11 @@ class DetectionCheckpointer:
 
     # ---- save / resume ------------------------------------------------------------------------------
     def save(self, name, **kwargs):
+        for obj in self.checkpointables.values():
+            if hasattr(obj, "sync_master"):
+                # sharded optimizer state: every rank gathers the rows the others own - a collective, so it runs on
+                # every rank, also on those that do not write the file
+                obj.sync_master()
         if not self.save_dir or not self.save_to_disk:
             return
         data = {"model": self.model.state_dict()}

@@ -116,7 +116,7 @@ class FusedSGD:
         return self._segs_dev, self._nseg
 
     # ---- pipelined mode: the update of a gradient bucket starts as soon as the bucket is final ----------------
-    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None):
+    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None, exchange=None):
         """ITER_SIZE == 1 only.  The explicit backward finishes gradients in a known order: first every small tensor
         (predictors, fc7, fc6 bias), then fc6.weight in row slabs.  In pipelined mode each bucket is (all-reduced when
         N > 1 and then) updated by the SGD kernel on a second stream the moment its dW GEMM is queued, so the HBM-bound
@@ -128,7 +128,15 @@ class FusedSGD:
         per step on every GPU.  Default = bf16 in the bf16 compute mode - the same rounding torch.autocast(bf16) applies
         to a Linear's weight gradient; master weights and momentum stay fp32 - and fp32 (the reference's DDP
         arithmetic) in the fp32 parity mode.  With an exchange the small tensors cross the wire in the same dtype (cast
-        into a wire buffer; their local fp32 gradient stays in the arena); without one they are read in fp32."""
+        into a wire buffer; their local fp32 gradient stays in the arena); without one they are read in fp32.
+        exchange (N > 1): "sharded" (default) = SURVEY 8(e)'s target - every fc6 row slab is REDUCE-SCATTERED (rank k
+        receives the sum of rows k*q .. (k+1)*q of the slab), the fused SGD kernel updates only those rows (the 2.05-GB
+        optimizer pass shrinks to 1/N per GPU; momentum is sharded the same way), and the updated compute copy of the
+        rows - the bf16 shadow, or the fp32 master in the parity mode - is ALL-GATHERED into every rank's arena under the
+        next image's trunk / pooling graphs.  Same wire bytes as an all-reduce (2 (N-1)/N of the bucket), identical
+        arithmetic (sum over ranks, 1/N in the kernel).  "allreduce" = one all-reduce per bucket and the replicated
+        update on every rank (detectron2/engine/defaults.py:279-282's DDP, restated).  The small tensors (38 MB) are
+        all-reduced and updated on every rank in both modes."""
         if self._bb is not None:
             raise DrnError("the pipelined optimizer mode assumes a frozen backbone (FREEZE_AT=5); use the plain step()")
         e = self.engine
@@ -143,6 +151,19 @@ class FusedSGD:
             t = (d1 + 255) // 256
             slab_rows = [min(d1, ((t + 1) // 2) * 256)] if world == 1 else [min(d1, ((5 * t + 7) // 8) * 256)]
             slab_rows = sorted(set(r for r in slab_rows if 0 < r < d1)) + [d1]
+        if exchange not in (None, "sharded", "allreduce"):
+            raise DrnError("exchange must be 'sharded' or 'allreduce'")
+        self._sharded = world > 1 and exchange != "allreduce"
+        if self._sharded:
+            r0 = 0
+            for r1 in slab_rows:
+                if (r1 - r0) % world:
+                    if exchange == "sharded":
+                        raise DrnError("sharded exchange: every fc6 row slab must split evenly over the %d ranks "
+                                       "(slab %d:%d)" % (world, r0, r1))
+                    self._sharded = False  # default mode: fall back to the all-reduce for shapes that do not divide
+                r0 = r1
+        self._master_stale = False
         self._slab_ends = slab_rows
         e.fc1_slab_ends = slab_rows
         e.grad_ready_hook = self._on_grad_ready
@@ -236,9 +257,57 @@ class FusedSGD:
                 _, r0, r1 = what
                 o, _ = e._seg["fc1.weight"]
                 k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
-                dist.all_reduce(bucket[r0:r1] if bucket is not None else e.arena_g[o + r0 * k1: o + r1 * k1],
-                                group=self._dp.group)
+                src = bucket[r0:r1] if bucket is not None else e.arena_g[o + r0 * k1: o + r1 * k1].view(r1 - r0, k1)
+                if self._sharded:
+                    # reduce-scatter: this rank receives the summed gradient of ITS rows of the slab
+                    q = (r1 - r0) // self._dp.world
+                    out = self._shard_bufs().setdefault(what, torch.empty((q, k1), dtype=src.dtype, device=src.device))
+                    dist.reduce_scatter_tensor(out, src, group=self._dp.group)
+                    return out
+                dist.all_reduce(src, group=self._dp.group)
         return bucket
+
+    def _shard_bufs(self):
+        if getattr(self, "_rs_out", None) is None:
+            self._rs_out = {}
+        return self._rs_out
+
+    def _own_rows(self, what):
+        """rows of slab `what` = ("fc1", r0, r1) that this rank updates in the sharded exchange"""
+        _, r0, r1 = what
+        q = (r1 - r0) // self._dp.world
+        rank = dist.get_rank(self._dp.group)
+        return r0 + rank * q, r0 + (rank + 1) * q
+
+    def _gather_rows(self, what, master_too=False):
+        """all-gather the rows every rank updated: into the compute copy the next forward reads (bf16 shadow, or the fp32
+        master when there is no shadow); master_too also gathers the fp32 master and the momentum (checkpoint time)"""
+        e = self.engine
+        _, r0, r1 = what
+        a, b = self._own_rows(what)
+        o, _ = e._seg["fc1.weight"]
+        k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
+        arenas = [e.arena_s if e.arena_s is not None else e.arena_w]
+        if master_too:
+            arenas = [t for t in (e.arena_w, self._mom) if t is not None]
+        inplace = dist.get_backend(self._dp.group) == "nccl"  # RCCL's in-place form: input = output[rank * count ...]
+        for t in arenas:
+            full, mine = t[o + r0 * k1: o + r1 * k1], t[o + a * k1: o + b * k1]
+            dist.all_gather_into_tensor(full, mine if inplace else mine.clone(), group=self._dp.group)
+
+    def sync_master(self):
+        """Sharded exchange, bf16 mode: every rank's fp32 master weights and momentum are current only for the rows it
+        updates (the forward reads the all-gathered bf16 shadow).  Before a checkpoint / state_dict() the owners' rows
+        are gathered so that every rank holds the full fp32 state again."""
+        if not getattr(self, "_sharded", False) or not self._master_stale:
+            return
+        if self._opt_stream is not None:
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+        r0 = 0
+        for r1 in self._slab_ends:
+            self._gather_rows(("fc1", r0, r1), master_too=True)
+            r0 = r1
+        self._master_stale = False
 
     def _on_grad_ready(self, what):
         e = self.engine
@@ -264,6 +333,15 @@ class FusedSGD:
     def _update(self, what, bucket, segs, nseg):
         e = self.engine
         world = self._dp.world if self._dp is not None else 1
+        if what != "small" and getattr(self, "_sharded", False) and self._exchange_on:
+            # `bucket` = this rank's reduce-scattered rows: update them alone
+            a, b = self._own_rows(what)
+            k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
+            segs, nseg = self._bucket_table(("fc1", a, b))
+            ops.sgd_step(e.arena_w, self._mom, bucket, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
+                         shadow=e.arena_s, grad_off=e._seg["fc1.weight"][0] + a * k1)
+            self._master_stale = True  # momentum (and, with a bf16 shadow, the fp32 master) of the other ranks' rows
+            return
         if bucket is not None:
             ops.sgd_step(e.arena_w, self._mom, bucket, segs, nseg, self.momentum, self._steps == 0, 1.0 / world,
                          shadow=e.arena_s, grad_off=0 if what == "small" else e._seg["fc1.weight"][0])
@@ -290,9 +368,23 @@ class FusedSGD:
             cur = torch.cuda.current_stream()
             if self._deferred:
                 # exchanged buckets: update each one here as soon as its all-reduce (optimizer stream) has finished
+                gathered = []
                 for what, bucket, segs, nseg, evc in self._deferred:
                     cur.wait_event(evc)
                     self._update(what, bucket, segs, nseg)
+                    if what != "small" and getattr(self, "_sharded", False):
+                        # the rows this rank just updated go to every other rank (optimizer stream: link-bound, beside
+                        # the next bucket's update on this stream); the next forward waits for the last gather below
+                        ev = torch.cuda.Event()
+                        ev.record(cur)
+                        self._opt_stream.wait_event(ev)
+                        with torch.cuda.stream(self._opt_stream):
+                            self._gather_rows(what)
+                            g = torch.cuda.Event()
+                            g.record(self._opt_stream)
+                        gathered.append(g)
+                for g in gathered:
+                    cur.wait_event(g)
                 self._deferred = []
             else:
                 # every bucket was already updated on the optimizer stream during backward(): join it
@@ -314,6 +406,7 @@ class FusedSGD:
         """torch.optim.SGD's checkpoint content in this optimizer's flat form: the momentum arena of the heads, the
         momentum arena of a trainable trunk (FREEZE_AT < 5), the step count and the per-group hyper-parameters."""
         bb = self._bb
+        self.sync_master()  # sharded exchange: collect the rows the other ranks own
         return {"momentum_buffer": None if self._mom is None else self._mom.detach().cpu(),
                 "bb_momentum_buffer": None if bb is None or bb["mom"] is None else bb["mom"].detach().cpu(),
                 "steps": self._steps,

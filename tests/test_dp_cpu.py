@@ -95,7 +95,7 @@ def _worker(rank, world, port, q):
         from drn_wsod_pytorch_amd.engine import build_optimizer
 
         opt = build_optimizer(G.drn_cfg(G.MODEL_CASES["model_r50c4_tiny"], "cpu"), model)
-        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.bfloat16)
+        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.bfloat16, exchange="allreduce")
         assert opt._slab_ends == [16, 40, d1] and e.fc1_grad_bucket.dtype == torch.bfloat16
         e.arena_g.copy_(base * (rank + 1))
         vals = (torch.arange(d1 * k1, dtype=torch.float32).view(d1, k1) % 61) * 0.25  # exactly representable in bf16
@@ -110,13 +110,56 @@ def _worker(rank, world, port, q):
         assert torch.equal(e.arena_g[:o_fc1], base[:o_fc1] * (rank + 1))  # local fp32 gradient untouched
         assert torch.equal(e.arena_g[o_fc1: o_fc1 + c_fc1], base[o_fc1: o_fc1 + c_fc1] * (rank + 1))  # arena fc6 slot unused
         assert torch.equal(e.fc1_grad_bucket.float(), vals * 3.0)
+        # ---- sharded exchange (SURVEY 8(e) target): reduce-scatter of each slab, owned rows, all-gather -------------
+        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.bfloat16, exchange="sharded")
+        assert opt._sharded
+        e.fc1_grad_bucket.copy_((vals * (rank + 1)).to(torch.bfloat16))
+        e.arena_s = torch.zeros_like(e.arena_w, dtype=torch.bfloat16)  # the bf16 shadow the forward reads
+        opt._mom = torch.zeros_like(e.arena_w)
+        r0 = 0
+        for r1 in opt._slab_ends:
+            what = ("fc1", r0, r1)
+            out = opt._exchange(what)
+            a, b = opt._own_rows(what)
+            nq = (r1 - r0) // 2
+            assert (a, b) == (r0 + rank * nq, r0 + (rank + 1) * nq) and out.shape == (nq, k1)
+            assert torch.equal(out.float(), vals[a:b] * 3.0), "reduce-scatter: the summed gradient of this rank's rows"
+            # stand-in for the owned-shard SGD kernel: mark the rows this rank updated, in every arena
+            e.arena_s[o_fc1 + a * k1: o_fc1 + b * k1] = float(rank + 1)
+            e.arena_w[o_fc1 + a * k1: o_fc1 + b * k1] = 10.0 * (rank + 1)
+            opt._mom[o_fc1 + a * k1: o_fc1 + b * k1] = 100.0 * (rank + 1)
+            opt._gather_rows(what)  # per step: only the compute copy travels
+            sh = e.arena_s[o_fc1 + r0 * k1: o_fc1 + r1 * k1].view(r1 - r0, k1).float()
+            assert torch.equal(sh[:nq], torch.ones(nq, k1)) and torch.equal(sh[nq:], 2.0 * torch.ones(nq, k1))
+            r0 = r1
+        opt._master_stale = True
+        opt.sync_master()  # checkpoint time: fp32 master + momentum of the other rank's rows arrive too
+        wv = e.arena_w[o_fc1: o_fc1 + c_fc1].view(d1, k1)
+        mv = opt._mom[o_fc1: o_fc1 + c_fc1].view(d1, k1)
+        r0 = 0
+        for r1 in opt._slab_ends:
+            nq = (r1 - r0) // 2
+            assert torch.equal(wv[r0: r0 + nq], torch.full((nq, k1), 10.0)) and torch.equal(wv[r0 + nq: r1], torch.full((nq, k1), 20.0))
+            assert torch.equal(mv[r0: r0 + nq], torch.full((nq, k1), 100.0)) and torch.equal(mv[r0 + nq: r1], torch.full((nq, k1), 200.0))
+            r0 = r1
+        with_odd = False
+        try:
+            opt.enable_pipelined(dp, slab_rows=[15, d1], comm_dtype=torch.float32, exchange="sharded")
+        except Exception:  # noqa: BLE001 - a slab that does not split evenly over the ranks is refused loudly
+            with_odd = True
+        assert with_odd
+        opt.enable_pipelined(dp, slab_rows=[15, d1], comm_dtype=torch.float32)  # default: falls back to the all-reduce
+        assert not opt._sharded
+        e.arena_s = None
         # fp32 wire: the small bucket is reduced in place in the arena
-        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.float32)
+        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.float32, exchange="allreduce")
         assert opt._exchange("small") is None
         assert torch.allclose(e.arena_g[:o_fc1], exp[:o_fc1])
         q.put((rank, "ok"))
     except Exception as ex:  # noqa: BLE001
-        q.put((rank, "FAIL: %r" % (ex,)))
+        import traceback
+
+        q.put((rank, "FAIL: %r\n%s" % (ex, traceback.format_exc())))
     finally:
         dist.destroy_process_group()
 

@@ -1,6 +1,7 @@
 """Two REAL ranks on one MI355X (gloo backend on CUDA tensors; RCCL refuses two ranks per device): the N>1 training
 step - GraphedTrainStep(split_tail=True): captured heads graph, eager fc6-dW slabs, per-bucket all-reduce on the
-optimizer stream, deferred per-bucket SGD - must (a) not deadlock, (b) leave both ranks with identical weights, and
+optimizer stream, deferred per-bucket SGD; with the sharded exchange: reduce-scatter per fc6 slab, update of the owned
+rows only, all-gather of the updated compute copy - must (a) not deadlock, (b) leave both ranks with identical weights, and
 (c) equal single-process training on the mean gradient of the two ranks' batches (= DDP semantics)."""
 import os
 import socket
@@ -27,7 +28,7 @@ def _batches():
     return int(d["seed"]), [G.drn_inputs([a]), G.drn_inputs([b])]
 
 
-def _worker(rank, world, port, comm, q):
+def _worker(rank, world, port, comm, exchange, q, precision="fp32"):
     try:
         os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
         torch.cuda.set_device(0)
@@ -36,22 +37,30 @@ def _worker(rank, world, port, comm, q):
         from drn_wsod_pytorch_amd.engine import DataParallel, GraphedTrainStep, build_optimizer
 
         seed, batches = _batches()
-        cfg, model = G.drn_model(G.MODEL_CASES[NAME], seed + 10 * rank, "cuda", 5, "fp32")  # ranks start different
+        cfg, model = G.drn_model(G.MODEL_CASES[NAME], seed + 10 * rank, "cuda", 5, precision)  # ranks start different
         model.roi_heads.box_head.dropout_p = 0.0
         model.train()
         opt = build_optimizer(cfg, model)
         dp = DataParallel(model)
         assert dp.world == 2 and dp.exchange
         dp.broadcast_parameters(0)
-        opt.enable_pipelined(dp, slab_rows=[16, 48], comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32)
+        opt.enable_pipelined(dp, slab_rows=[16, 48], comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32,
+                             exchange=exchange)
+        assert opt._sharded == (exchange == "sharded")
         mine = batches[rank]
         stepper = GraphedTrainStep(model, opt, mine, split_tail=True, trunk_pairs=True)  # bench.py's default schedule
         losses = []
         for _ in range(3):
             out = stepper.step(mine, mine, mine, mine)
             losses.append({k: float(v.detach()) for k, v in out.items()})
+        opt.sync_master()  # sharded exchange: the fp32 master rows the other rank owns (a collective; no-op otherwise)
         torch.cuda.synchronize()
         sd = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.requires_grad}  # by value
+        e = model.roi_heads._engine
+        if e.arena_s is not None:  # bf16 mode: the compute copy every rank reads must be the rounded master, everywhere
+            for _, _, o, n, used in e.segments:
+                if used:
+                    assert torch.equal(e.arena_s[o: o + n], e.arena_w[o: o + n].to(torch.bfloat16)), "stale shadow rows"
         q.put((rank, "ok", sd, losses))
     except Exception as ex:  # noqa: BLE001
         import traceback
@@ -62,15 +71,16 @@ def _worker(rank, world, port, comm, q):
             dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("comm", ["fp32", "bf16"])
-def test_two_rank_step_equals_mean_gradient_training(comm):
+@pytest.mark.parametrize("comm,exchange", [("fp32", "allreduce"), ("bf16", "allreduce"), ("fp32", "sharded"),
+                                           ("bf16", "sharded")])
+def test_two_rank_step_equals_mean_gradient_training(comm, exchange):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, comm, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, comm, exchange, q)) for r in range(2)]
     for p in procs:
         p.start()
     res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
@@ -108,3 +118,28 @@ def test_two_rank_step_equals_mean_gradient_training(comm):
         diff = float((p.detach().cpu() - torch.from_numpy(res[0][2][n])).abs().max())
         scale = max(float(p.detach().abs().max()), 1.0)
         assert diff <= tol * scale, (n, diff)
+
+
+def test_two_rank_sharded_exchange_bf16_mode():
+    """bf16 compute mode + sharded exchange: only the bf16 shadow rows travel every step (the fp32 master and the momentum
+    of the other rank's rows are stale until sync_master()).  After three steps and a sync: both replicas hold identical
+    fp32 weights, every shadow row equals its rounded master row on both ranks (asserted inside the workers), losses finite."""
+    import numpy as np
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, "bf16", "sharded", q, "bf16")) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted([q.get(timeout=600) for _ in procs], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+    for r in res:
+        assert r[1] == "ok", r[1]
+    for n in res[0][2]:
+        assert np.array_equal(res[0][2][n], res[1][2][n]), n
+    assert all(np.isfinite(v) for l in res[0][3] for v in l.values())
