@@ -312,7 +312,11 @@ def main():
         props = torch.cuda.get_device_properties(local_rank)
         mine = {"rank": rank, "pid": os.getpid(), "device": local_rank, "name": props.name,
                 "uuid": str(getattr(props, "uuid", "")), "backend": dist.get_backend(),
-                "rccl": ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None}
+                "rccl": None}
+        try:
+            mine["rccl"] = ".".join(str(v) for v in torch.cuda.nccl.version()) if args.backend == "nccl" else None
+        except Exception:  # noqa: BLE001 - informational only
+            pass
         print("[bench] rank %(rank)d pid %(pid)d cuda:%(device)d %(name)s uuid %(uuid)s backend %(backend)s rccl %(rccl)s"
               % mine, file=sys.stderr, flush=True)
         rank_info = [None] * world

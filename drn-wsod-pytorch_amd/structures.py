@@ -73,103 +73,109 @@ class Boxes:
 
 
 class Instances:
-    """Per-image field bag (detectron2/structures/instances.py)."""
+    """The per-image record that travels between the loader, the model and the evaluator
+    (detectron2/structures/instances.py defines the contract): an image size plus named columns that all have one
+    entry per instance - tensors, `Boxes`, lists.  Columns are reached as attributes (`inst.gt_classes = t`,
+    `inst.scores`), rows by indexing, and records of one image are merged with `Instances.cat`.
 
-    def __init__(self, image_size: Tuple[int, int], **kwargs: Any):
-        self._image_size = image_size
-        self._fields: Dict[str, Any] = {}
-        for k, v in kwargs.items():
-            self.set(k, v)
+    Stored as one ordered {name: column} table; every operation below is a map over that table."""
 
+    def __init__(self, image_size: Tuple[int, int], **columns: Any):
+        object.__setattr__(self, "_image_size", image_size)
+        object.__setattr__(self, "_fields", {})
+        for name, col in columns.items():
+            self.set(name, col)
+
+    # -- the table -------------------------------------------------------------------------------------------------
     @property
     def image_size(self):
         return self._image_size
 
-    def __setattr__(self, name, val):
-        if name.startswith("_"):
-            super().__setattr__(name, val)
-        else:
-            self.set(name, val)
-
-    def __getattr__(self, name):
-        if name == "_fields" or name not in self._fields:
-            raise AttributeError("Cannot find field '{}' in the given Instances!".format(name))
-        return self._fields[name]
-
     def set(self, name, value):
-        data_len = len(value)
-        if len(self._fields):
-            assert len(self) == data_len, "Adding a field of length {} to a Instances of length {}".format(
-                data_len, len(self))
+        n = len(value)
+        if self._fields and n != len(self):
+            raise AssertionError("Adding a field of length {} to a Instances of length {}".format(n, len(self)))
         self._fields[name] = value
+
+    def get(self, name):
+        return self._fields[name]
 
     def has(self, name):
         return name in self._fields
 
     def remove(self, name):
-        del self._fields[name]
-
-    def get(self, name):
-        return self._fields[name]
+        self._fields.pop(name)
 
     def get_fields(self):
         return self._fields
 
-    def to(self, *args, **kwargs):
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            if hasattr(v, "to"):
-                v = v.to(*args, **kwargs)
-            ret.set(k, v)
-        return ret
-
-    def __getitem__(self, item):
-        if type(item) == int:
-            if item >= len(self) or item < -len(self):
-                raise IndexError("Instances index out of range!")
-            item = slice(item, None, len(self))
-        ret = Instances(self._image_size)
-        for k, v in self._fields.items():
-            ret.set(k, v[item])
-        return ret
-
     def __len__(self):
-        for v in self._fields.values():
-            return len(v)
-        raise NotImplementedError("Empty Instances does not support __len__!")
+        if not self._fields:
+            raise NotImplementedError("Empty Instances does not support __len__!")
+        return len(next(iter(self._fields.values())))
 
     def __iter__(self):
         raise NotImplementedError("`Instances` object is not iterable!")
 
+    # -- attribute access = column access -----------------------------------------------------------------------------
+    def __setattr__(self, name, value):
+        if name[:1] == "_":
+            object.__setattr__(self, name, value)
+        else:
+            self.set(name, value)
+
+    def __getattr__(self, name):  # only reached when normal lookup fails, i.e. for column names
+        cols = self.__dict__.get("_fields")
+        if cols is None or name not in cols:
+            raise AttributeError("Cannot find field '{}' in the given Instances!".format(name))
+        return cols[name]
+
+    # -- maps over the table ------------------------------------------------------------------------------------------
+    def _mapped(self, fn):
+        out = Instances(self._image_size)
+        for name, col in self._fields.items():
+            out.set(name, fn(col))
+        return out
+
+    def to(self, *args, **kwargs):
+        return self._mapped(lambda col: col.to(*args, **kwargs) if hasattr(col, "to") else col)
+
+    def __getitem__(self, rows):
+        if isinstance(rows, int) and not isinstance(rows, bool):
+            n = len(self)
+            if not -n <= rows < n:
+                raise IndexError("Instances index out of range!")
+            rows = slice(rows, None, n)  # one row, kept as a length-1 record
+        return self._mapped(lambda col: col[rows])
+
+    @staticmethod
+    def _join(cols):
+        head = cols[0]
+        if isinstance(head, torch.Tensor):
+            return torch.cat(cols, dim=0)
+        if isinstance(head, list):
+            return list(itertools.chain.from_iterable(cols))
+        joiner = getattr(type(head), "cat", None)
+        if joiner is None:
+            raise ValueError("Unsupported type {} for concatenation".format(type(head)))
+        return joiner(cols)
+
     @staticmethod
     def cat(instance_lists):
-        assert all(isinstance(i, Instances) for i in instance_lists) and len(instance_lists) > 0
+        if not instance_lists or not all(isinstance(r, Instances) for r in instance_lists):
+            raise AssertionError("Instances.cat takes a non-empty list of Instances")
+        first = instance_lists[0]
         if len(instance_lists) == 1:
-            return instance_lists[0]
-        image_size = instance_lists[0].image_size
-        ret = Instances(image_size)
-        for k in instance_lists[0]._fields.keys():
-            values = [i.get(k) for i in instance_lists]
-            v0 = values[0]
-            if isinstance(v0, torch.Tensor):
-                values = torch.cat(values, dim=0)
-            elif isinstance(v0, list):
-                values = list(itertools.chain(*values))
-            elif hasattr(type(v0), "cat"):
-                values = type(v0).cat(values)
-            else:
-                raise ValueError("Unsupported type {} for concatenation".format(type(v0)))
-            ret.set(k, values)
-        return ret
+            return first
+        out = Instances(first.image_size)
+        for name in first._fields:
+            out.set(name, Instances._join([r.get(name) for r in instance_lists]))
+        return out
 
-    def __str__(self):
-        s = self.__class__.__name__ + "("
-        s += "num_instances={}, image_height={}, image_width={}, fields=[{}])".format(
-            len(self), self._image_size[0], self._image_size[1],
-            ", ".join("{}: {}".format(k, v) for k, v in self._fields.items()))
-        return s
-
-    __repr__ = __str__
+    def __repr__(self):
+        h, w = self._image_size
+        cols = ", ".join("{}: {}".format(k, v) for k, v in self._fields.items())
+        return "Instances(num_instances={}, image_height={}, image_width={}, fields=[{}])".format(len(self), h, w, cols)
 
 
 class ImageList:

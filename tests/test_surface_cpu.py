@@ -380,3 +380,52 @@ def test_samplers_and_batch_loader_match_reference_golden(pkg):
             assert [sum(b, []) for b in per_rank] == ref
     with pytest.raises(Exception):
         D.build_batch_data_loader(ds, D.TrainingSampler(len(ds), True, 5, 0, 3), 4, world_size=3)
+
+
+def test_alias_layer_reference_import_names(tmp_path):
+    """the reference's import lines for this path resolve to this package after aliases.install(); a model
+    builds from the reference's UNMODIFIED yaml through those names; names outside the path fail loudly."""
+    import subprocess
+    import sys
+
+    code = r'''
+import sys
+sys.path.insert(0, %r)
+from __graft_entry__ import load_package
+load_package()
+import drn_wsod_pytorch_amd.aliases as A
+names = A.install()
+from detectron2.config import get_cfg
+from detectron2.checkpoint import DetectionCheckpointer
+from detectron2.layers import Conv2d, FrozenBatchNorm2d, ROIAlign, ShapeSpec, cat
+from detectron2.structures import Boxes, Instances, ImageList
+from detectron2.modeling import build_model, META_ARCH_REGISTRY, ROI_HEADS_REGISTRY, BACKBONE_REGISTRY
+from detectron2.modeling.poolers import ROIPooler
+from detectron2.utils.events import EventStorage, get_event_storage
+from detectron2.evaluation import PascalVOCDetectionEvaluator
+import detectron2.data.detection_utils as utils
+from wsl.config import add_wsl_config
+from wsl.modeling import GeneralizedRCNNWithTTAAVG
+import detectron2, wsl
+assert detectron2.layers.Conv2d is Conv2d and wsl.config.add_wsl_config is add_wsl_config
+assert "OICRROIHeads" in ROI_HEADS_REGISTRY and "GeneralizedRCNNWSL" in META_ARCH_REGISTRY
+assert "build_ws_resnet_backbone" in BACKBONE_REGISTRY
+import os
+yaml = "/root/reference/projects/WSL/configs/PascalVOC-Detection/oicr_WSR_18_DC5_1x.yaml"
+if os.path.exists(yaml):
+    cfg = get_cfg(); add_wsl_config(cfg); cfg.merge_from_file(yaml)
+    cfg.merge_from_list(["MODEL.DEVICE", "cpu", "MODEL.WEIGHTS", ""])
+    model = build_model(cfg)
+    assert type(model).__name__ == "GeneralizedRCNNWSL" and type(model.roi_heads).__name__ == "OICRROIHeads"
+from drn_wsod_pytorch_amd._cabi import DrnError
+try:
+    from detectron2.evaluation import COCOEvaluator
+    raise SystemExit("control-plane name resolved")
+except DrnError as e:
+    assert "COCOEvaluator" in str(e)
+A.uninstall()
+assert "detectron2" not in sys.modules
+print("ALIAS_OK", len(names))
+''' % (G.ROOT,)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert "ALIAS_OK" in out.stdout, out.stdout + out.stderr
