@@ -262,6 +262,7 @@ def main():
                     help="oicr = the BASELINE workload; pcl = PCLROIHeads on the same trunk (SURVEY 8f rank 4; a side "
                          "measurement, not the headline metric)")
     ap.add_argument("--tune", default="", help="comma-separated knob=value pairs for drn_tune (A/B runs), e.g. 3=4")
+    ap.add_argument("--engine-opt", default="", help="comma-separated attr=int pairs set on the head engine (A/B runs)")
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
     ap.add_argument("--no-eager-fc6", action="store_true",
                     help="keep the fc6 forward GEMM inside the captured heads graph (it is then timed on the eager warm-up "
@@ -342,6 +343,8 @@ def main():
     model = build_model(cfg)
     init_weights(model, seed=0)
     model.train()
+    for kv in filter(None, args.engine_opt.split(",")):
+        setattr(model.roi_heads._engine, kv.split("=")[0], int(kv.split("=")[1]))
     opt = build_optimizer(cfg, model)
     dp = DataParallel(model, force_exchange=args.force_exchange)
     dp.broadcast_parameters(0)
@@ -415,6 +418,13 @@ def main():
         barrier()
         dt = time.perf_counter() - t0
         ops.GEMM_TIMING = None
+        # pure host cost of one step: six steps enqueued right after a sync (the 8-slot label ring cannot block yet)
+        th = time.perf_counter()
+        for i in range(6):
+            j = args.warmup + args.steps + i
+            last2 = stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+        host_unblocked = (time.perf_counter() - th) / 6 * 1e3
+        barrier()
     else:
         ops.GEMM_TIMING = timing = []
         t0 = time.perf_counter()
@@ -501,7 +511,8 @@ def main():
                                       "%d proposals/img, %d img/GPU/iter, K=%d, 3 %s refinements, frozen backbone "
                                       "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % (R, args.ims_per_gpu, K, args.heads.upper()),
                           "global_batch": world * args.ims_per_gpu, "proposals": R, "parallelism": "dp%d" % world},
-               "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3, "hipgraph": bool(use_graph),
+               "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
+               "host_ms_per_step_unblocked": host_unblocked if use_graph else None, "hipgraph": bool(use_graph),
                "trunk_schedule": ("pairs: one conv chain per two batches, two batches ahead" if args.trunk_pairs
                                   else "lookahead %d" % args.lookahead) if use_graph else "eager prefetch of the next batch",
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),

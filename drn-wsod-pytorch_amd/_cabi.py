@@ -36,6 +36,7 @@ _SIGS = {
     "drn_counter_add": "pQp",
     "drn_colsum_reduce": "piipip",
     "drn_bias_act_bwd": "pilppppfplplppiiiip",
+    "drn_bias_act_bwd_splits": "pililppppfplplppiiiip",
     "drn_cast2d": "ppiilliip",
     "drn_wsddn_fwd_bwd": "pliiipippppppl" + "pi" + "ifp",
     "drn_oicr_targets": "plpii" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",

@@ -84,7 +84,12 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
           if (p.mask) v *= p.mask[(long)m * p.N + n];
           else if (p.drop_p > 0.f) v *= drop_mult(seed, (uint64_t)m * p.N + n, p.drop_p);
         } else {
-          v = (p.in_bf16 ? bf16_to_f32(((const bf16_t*)p.in)[(long)m * p.ld_in + n]) : p.in[(long)m * p.ld_in + n]) * cscale;
+          if (p.in_bf16) {
+            v = bf16_to_f32(((const bf16_t*)p.in)[(long)m * p.ld_in + n]);
+          } else {
+            for (int s = 0; s < p.splits; ++s) v += p.in[(long)s * p.split_stride + (long)m * p.ld_in + n];
+          }
+          v *= cscale;
           if (p.saved) {
             const float o = ES::ld((const typename ES::type*)p.saved + (long)m * p.ld_out + n);
             float mult = o > 0.f ? 1.f : 0.f;
@@ -159,7 +164,7 @@ __global__ __launch_bounds__(256) void act_vec_kernel(ActParams p) {
           for (int e = 0; e < 4; ++e) v[e] *= drop_mult(seed, (uint64_t)m * p.N + n0 + e, p.drop_p);
         }
       } else {
-        v = *(const f32x4v*)(p.in + (long)m * p.ld_in + n0);
+        for (int s = 0; s < p.splits; ++s) v += *(const f32x4v*)(p.in + (long)s * p.split_stride + (long)m * p.ld_in + n0);
         f32x4v mk = {1.f, 1.f, 1.f, 1.f};
         if (p.mask) mk = *(const f32x4v*)(p.mask + (long)m * p.N + n0);
         uint2 sv = {0u, 0u};
@@ -806,14 +811,30 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
   return DRN_OK;
 }
 
+int drn_bias_act_bwd_splits(const void* grad_out, int grad_dtype, long ld_in, int splits, long split_stride,
+                            const float* colscale, const int* colidx, const void* saved_out, const float* mask,
+                            float drop_p, void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum,
+                            float* colpart, int accumulate_colsum, int M, int N, int out_dtype, void* stream);
+
 int drn_bias_act_bwd(const void* grad_out, int grad_dtype, long ld_in, const float* colscale, const int* colidx,
                      const void* saved_out, const float* mask, float drop_p,
                      void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
                      int accumulate_colsum, int M, int N, int out_dtype, void* stream) {
+  return drn_bias_act_bwd_splits(grad_out, grad_dtype, ld_in, 1, 0, colscale, colidx, saved_out, mask, drop_p, dpre, ld_out,
+                                 dpreT, ld_outT, colsum, colpart, accumulate_colsum, M, N, out_dtype, stream);
+}
+
+// the same with grad_out given as `splits` fp32 split-K partials (split_stride floats apart) that are summed on load, in
+// order - the dX GEMM of fc7 then runs on the 256x256 kernel with a K-split like the forward GEMMs do
+int drn_bias_act_bwd_splits(const void* grad_out, int grad_dtype, long ld_in, int splits, long split_stride,
+                            const float* colscale, const int* colidx, const void* saved_out, const float* mask,
+                            float drop_p, void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum,
+                            float* colpart, int accumulate_colsum, int M, int N, int out_dtype, void* stream) {
   if (!grad_out || M < 0 || N < 0 || (grad_dtype != DRN_F32 && grad_dtype != DRN_BF16)) return DRN_ERR_ARG;
+  if (splits < 1 || (splits > 1 && grad_dtype != DRN_F32)) return DRN_ERR_ARG;
   if (colsum && !colpart) return DRN_ERR_ARG;  // colpart: ceil(M/64)*N floats of scratch
   if (M == 0 || N == 0) return DRN_OK;
-  ActParams p{(const float*)grad_out, 1, 0, nullptr, mask, 0ULL, drop_p, nullptr, (const char*)saved_out, (char*)dpre, ld_out,
+  ActParams p{(const float*)grad_out, splits, split_stride, nullptr, mask, 0ULL, drop_p, nullptr, (const char*)saved_out, (char*)dpre, ld_out,
               (char*)dpreT, ld_outT, colsum, colscale, colidx, colpart, M, N, ld_in, 1, accumulate_colsum, 64,
               grad_dtype == DRN_BF16};
   const int nparts = (M + ACT_ROWS - 1) / ACT_ROWS;

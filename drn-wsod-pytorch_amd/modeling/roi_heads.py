@@ -428,7 +428,7 @@ class _HeadEngine:
             Mp = kp(M)
             w.update(H1T=z(D1, Mp), H2T=z(D2, Mp), dlogits=z(M, NHp, torch.float32), dS=z(M, NHp),
                      dST=z(self.NH, Mp), dH2=z(M, D2, torch.float32), dP2=z(M, kp(D2)), dP2T=z(D2, Mp),
-                     dH1=z(M, D1, torch.float32), dP1T=z(D1, Mp),
+                     dH1=torch.zeros((1, M, D1), dtype=torch.float32, device=dev), dP1T=z(D1, Mp),
                      colpart=z((M + 63) // 64, max(D1, D2, self.NH), torch.float32),
                      # one scratch per layer for the deferred mode (the three reductions then run later, together)
                      colpart3=[z((M + 63) // 64, n_, torch.float32) for n_ in (self.NH, D2, D1)])
@@ -680,7 +680,13 @@ class _HeadEngine:
         ops.bias_act_bwd(w["dH2"], M, D2, saved=w["H2"], mask=st["masks"][1] if st["masks"] else None,
                          drop_p=st["drop_p"], dpre=w["dP2"], dpreT=w["dP2T"], **colsum_args(1, D2, self._gview("fc2.bias")))
         ops.gemm_nt(w["dP2T"], w["H1T"], D2, D1, Mp, out=self._gview("fc2.weight", (1, D2, D1)), accumulate=acc)
-        ops.gemm_nt(w["dP2"], sh["W2T"], M, D1, kp(D2), out=w["dH1"].view(1, M, D1))
+        # fc7 dX: [M, D1] over K = D2 is too few 256x256 tiles for one pass (64 at R = 2000) - split K like the forward
+        # GEMMs and let the activation backward behind it sum the partials (63 -> ~45 us at the bench shape)
+        s1 = self._splits(M, D1, kp(D2), dtype) if getattr(self, "fc7_dx_split", True) else 1
+        if w["dH1"].shape[0] != s1:
+            w["dH1"] = torch.zeros((s1, M, D1), dtype=torch.float32, device=dev)
+            self._ws[(M, dtype, True)]["dH1"] = w["dH1"]
+        ops.gemm_nt(w["dP2"], sh["W2T"], M, D1, kp(D2), out=w["dH1"], splits=s1)
         # fc6 (the backbone is frozen: no dX)
         fg = st.get("fg")
         if fg is not None and ("dP1" not in w or w["dP1"].shape != w["H1"].shape):

@@ -230,6 +230,12 @@ def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=Non
     ld_out = _2d(dpre) if dpre is not None else (_2d(saved) if saved is not None else 0)
     if colsum is not None and colpart is None:
         colpart = torch.empty(((M + 63) // 64, N), dtype=torch.float32, device=grad_out.device)
+    if grad_out.dim() == 3:  # [splits, M, ld]: fp32 split-K partials of the dX GEMM, summed on load
+        C.call("drn_bias_act_bwd_splits", C.ptr(grad_out), C.dt(grad_out.dtype), grad_out.stride(-2), grad_out.shape[0],
+               grad_out.stride(0), C.ptr(colscale), C.ptr(colidx), C.ptr(saved), C.ptr(mask), float(drop_p), C.ptr(dpre),
+               ld_out, C.ptr(dpreT), _2d(dpreT) if dpreT is not None else 0, C.ptr(colsum), C.ptr(colpart),
+               int(accumulate_colsum), M, N, C.dt(ref.dtype), C.stream())
+        return
     C.call("drn_bias_act_bwd", C.ptr(grad_out), C.dt(grad_out.dtype), _2d(grad_out), C.ptr(colscale), C.ptr(colidx),
            C.ptr(saved), C.ptr(mask), float(drop_p),
            C.ptr(dpre), ld_out, C.ptr(dpreT), _2d(dpreT) if dpreT is not None else 0, C.ptr(colsum), C.ptr(colpart),

@@ -165,6 +165,13 @@ int drn_bias_act_bwd(const void* grad_out, int grad_dtype, long ld_in, const flo
                      void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum, float* colpart,
                      int accumulate_colsum, int M, int N, int out_dtype, void* stream);
 
+/* drn_bias_act_bwd with grad_out given as `splits` fp32 split-K partials, `split_stride` floats apart, summed on load in
+ * order (the dX GEMM in front of it can then use a K-split like the forward GEMMs). */
+int drn_bias_act_bwd_splits(const void* grad_out, int grad_dtype, long ld_in, int splits, long split_stride,
+                            const float* colscale, const int* colidx, const void* saved_out, const float* mask,
+                            float drop_p, void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum,
+                            float* colpart, int accumulate_colsum, int M, int N, int out_dtype, void* stream);
+
 /* Second stage of drn_bias_act_bwd's column sums (bias gradients) on its own: with colsum == NULL and colpart != NULL
  * drn_bias_act_bwd only leaves the ceil(M/64) x N per-block partials; this adds them in a fixed order into colsum
  * (accumulate != 0: += ).  Lets the optimizer stream finish the bias gradients right in front of the SGD pass. */
