@@ -708,9 +708,13 @@ class GraphedTrainStep:
     collective is ever captured into a hipGraph, while the next image's backbone graph and pooling graph run under
     the exchange.  The optimizer stream is joined at the start of the next step."""
 
+    _needs_frozen_trunk = True
+
     def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False,
                  eager_fc6=False):
-        assert not any(p.requires_grad for p in model.backbone.parameters()), "graphed step needs a frozen backbone"
+        if self._needs_frozen_trunk and any(p.requires_grad for p in model.backbone.parameters()):
+            raise DrnError("GraphedTrainStep runs the trunk of FUTURE batches on a side stream, which needs a frozen "
+                           "backbone (FREEZE_AT = 5); use GraphedFullStep for a trainable trunk")
         assert 1 <= lookahead <= 4
         self.lookahead = lookahead
         # eager_fc6 (bench.py): the fc6 forward GEMM - first launch of the heads and the step's dominant kernel - is
@@ -1093,3 +1097,70 @@ class GraphedTrainStep:
             return self.prime(batch, next_batch)
         self._stage_labels(batch)
         return self._run(eager=False, next_batch=next_batch)
+
+
+class GraphedFullStep(GraphedTrainStep):
+    """The training step of a TRAINABLE trunk (MODEL.BACKBONE.FREEZE_AT < 5) as ONE hipGraph on one stream: preprocess,
+    trunk forward with saved activations, ROIPool (with arg-max), heads, losses, the explicit backward through the
+    heads, fc6 dX, RoIPool / ROIAlign backward and every trainable trunk block (conv dgrad / wgrad straight into the
+    trunk's gradient arena), then the fused SGD step of both arenas and the re-pack of the updated conv weights at the
+    top of the next replay.  ~250 launches of 5-60 us that the eager Python host cannot enqueue as fast as the GPU runs
+    them; a replay costs one graph launch.  Nothing of a future batch can run ahead here - the trunk's weights change
+    every step - so there is no side stream and no lookahead: step(batch) stages `batch` and replays.
+    Static shapes (image size, proposals per image, images per GPU), ITER_SIZE 1, one process (with N > 1 the trunk
+    gradients are exchanged by the eager path: DataParallel's "backbone" bucket)."""
+
+    _needs_frozen_trunk = False
+
+    def __init__(self, model, optimizer, example_batch):
+        if getattr(optimizer, "_pipelined", False):
+            raise DrnError("GraphedFullStep uses the plain optimizer step (the pipelined mode assumes a frozen trunk)")
+        super().__init__(model, optimizer, example_batch, split_tail=False, lookahead=1)
+        self.g_step = None
+
+    def _stage(self, batch):
+        self._stage_labels(batch)
+        off = 0
+        for i, x in enumerate(batch):
+            n = self.nper[i]
+            assert len(x["proposals"]) == n, "graphed step: proposals per image must stay fixed"
+            self.rois[off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
+            self.obj[off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
+            off += n
+        self.props.copy_(self.rois[:, 1:])
+        self._stage_image(batch, 0)
+
+    def _full_body(self):
+        m, eng = self.model, self.engine
+        imgs = m.preprocess_image([{"image": im} for im in self._images[0]])
+        feats = m.backbone(imgs.tensor)  # training mode + trainable blocks: activations are kept for backward_nhwc()
+        f = feats[self.heads.box_in_features[0]].permute(0, 2, 3, 1)
+        assert f.is_contiguous()
+        eng.feature_grad_hook = m._backbone_backward
+        losses, st = eng.forward(f, self.rois, self.obj, True, self.img_off, self.n_img, self.gt)
+        if torch.cuda.is_current_stream_capturing():
+            self._captured_state = st
+        else:
+            self._eager_state = st
+        eng.backward(st, None)
+        self.opt.step(1.0)
+        self.opt.zero_grad()
+        return losses
+
+    def step(self, batch):
+        self.heads.train()
+        self._replayed = self.g_step is not None
+        self._stage(batch)
+        if self.g_step is None:
+            # step 0 eagerly (workspaces exist, momentum buffers initialised, packs invalidated by the update), then the
+            # capture: the captured forward starts with the re-pack of the freshly updated conv weights
+            self.opt.zero_grad()
+            first = {k: v.detach().clone() for k, v in self._full_body().items()}
+            torch.cuda.synchronize()
+            self.g_step = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.g_step, capture_error_mode="thread_local"):
+                self.losses = self._full_body()
+            return first
+        self.opt.refresh_tables()
+        self.g_step.replay()
+        return self.losses
