@@ -156,7 +156,7 @@ def hbm_rooflines(model, batch, R, device, ops, opt=None):
     """The two dominant HBM-bound kernels of the step, timed on their own with HIP events (5 launches each, scratch
     buffers of the workload's sizes, after the timed region): achieved = ALGORITHMIC bytes / launch duration against
     the 8 TB/s HBM3E peak (MI355X_MICROARCH.md).
-      roi_pool7_map_kernel: writes A and A^T (2 x R x C*49 x 2 B), reads the 14x14xC map + R boxes
+      roi_pool7_map64_kernel: writes A and A^T (2 x R x C*49 x 2 B), reads the 14x14xC map + R boxes
       sgd_kernel (fc6 half): per parameter reads w, momentum (fp32) + gradient (bf16), writes w, momentum (fp32) +
                              bf16 shadow = 20 B"""
     import numpy as np
@@ -187,7 +187,7 @@ def hbm_rooflines(model, batch, R, device, ops, opt=None):
         t = timed(lambda: ops.roi_pool_nhwc(nhwc, rois, obj, out=A, out_t=AT, **ka))
         es = 2 if nhwc.dtype == torch.bfloat16 else 4
         nbytes = 2 * R * K1 * es + nhwc.numel() * es + rois.numel() * 4
-        out.append({"kernel": "roi_pool7_map_kernel (ROIPool + objectness scale -> A and A^T)", "bound": "hbm",
+        out.append({"kernel": "roi_pool7_map64_kernel (ROIPool + objectness scale -> A and A^T)", "bound": "hbm",
                     "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
                     "bytes_per_launch": nbytes, "avg_launch_ms": t * 1e3})
         D1 = heads.box_head.fc1.weight.shape[0]

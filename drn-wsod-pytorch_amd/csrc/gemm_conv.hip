@@ -943,6 +943,7 @@ int drn_gemm_set_tile(int tile) {
 
 // tuning knobs (A/B measurements and tests; defaults are the measured best).  Returns the previous value or -1.
 int drn_sgd_set_grid(int blocks_x);  // head.hip
+int drn_roi_set_map64(int on);        // pool.hip
 int drn_tune(int knob, int value) {
   if (knob == 1) {  // DRN_TUNE_GEMM_PERSISTENT
     const int old = g_persistent;
@@ -950,6 +951,7 @@ int drn_tune(int knob, int value) {
     return old;
   }
   if (knob == 2) return drn_sgd_set_grid(value);  // DRN_TUNE_SGD_GRID
+  if (knob == 4) return drn_roi_set_map64(value);  // DRN_TUNE_ROI_MAP64
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
     const int old = g_group_rows;
     if (value >= 0 && value <= 64) g_group_rows = value;

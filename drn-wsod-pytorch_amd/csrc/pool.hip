@@ -663,6 +663,138 @@ __global__ __launch_bounds__(256) void roi_pool7_map_kernel(RoiParams p) {
   }  // ROI groups of this block
 }
 
+// 7x7 ROIPool, whole-map variant for the training operand pair (A, A^T) in bf16: a block pools 64 consecutive ROIs out
+// of an 8-channel slice of the map, so that every row of its A^T tile - 64 ROIs x 2 B - is one FULL 128-byte line
+// (the 8-ROI kernel above writes A^T as 16-byte column runs and relies on eight blocks of one XCD meeting in L2 to
+// complete a line: 0.39 of the HBM write roofline).  Work items are (ROI, bin) pairs, one 16-byte LDS read per window
+// pixel feeds the packed int16 maxima of all 8 channels; 3136 items over 256 threads - no idle lanes, which is what
+// made round 1's 64-ROI attempt slower.  The [64][8*49] tile (pitch 792 B: 8-byte aligned rows for the A runs, bank
+// spread for the transposed reads) leaves LDS as 64 runs of 784 B of A and 392 full lines of A^T.  Block ids run
+// chunk-fastest inside an XCD's contiguous range: the two partial lines at the ends of a 784-byte A run are shared with
+// the neighbouring channel chunks, which the same XCD's L2 sees right next in time.
+constexpr int ROI_G64 = 64;
+constexpr int G64_CH = 8, G64_RUN = G64_CH * 49, G64_PITCH = G64_RUN * 2 + 8, G64_THREADS = 512;
+__global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
+  constexpr int PP = 49;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = p.H * p.W;
+  char* map = smem;                                          // [HW][8 channels, order-mapped bf16]
+  char* tile = smem + (((long)HW * 16 + 15) & ~15L);         // [64][G64_PITCH]
+  __shared__ unsigned char hb[ROI_G64][7][2], wb[ROI_G64][7][2];
+  __shared__ int bidx[ROI_G64];
+  __shared__ float mulv[ROI_G64];
+  const int nchunks = p.C / G64_CH;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int group = logical / nchunks, chunk = logical - group * nchunks;
+  const int c0 = chunk * G64_CH, m0 = group * ROI_G64;
+  const int nr = min(ROI_G64, p.M - m0);
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  for (int i = tid; i < ROI_G64 * 7; i += nthr) {
+    const int r = i / 7, k = i - r * 7;
+    if (r < nr) {
+      const float* roi = p.rois + 5 * (long)(m0 + r);
+      const int x1 = (int)roundf(roi[1] * p.scale), y1 = (int)roundf(roi[2] * p.scale);
+      const int x2 = (int)roundf(roi[3] * p.scale), y2 = (int)roundf(roi[4] * p.scale);
+      const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+      const float bin_h = (float)rh / 7.f, bin_w = (float)rw / 7.f;
+      hb[r][k][0] = (unsigned char)min(max((int)floorf((float)k * bin_h) + y1, 0), p.H);
+      hb[r][k][1] = (unsigned char)min(max((int)ceilf((float)(k + 1) * bin_h) + y1, 0), p.H);
+      wb[r][k][0] = (unsigned char)min(max((int)floorf((float)k * bin_w) + x1, 0), p.W);
+      wb[r][k][1] = (unsigned char)min(max((int)ceilf((float)(k + 1) * bin_w) + x1, 0), p.W);
+      if (k == 0) {
+        bidx[r] = (int)roi[0];
+        mulv[r] = p.obj ? p.obj[m0 + r] + 1.f : 1.f;
+      }
+    }
+  }
+  __syncthreads();
+  for (int r0 = 0; r0 < nr;) {  // one pass per run of ROIs on the same image
+    const int b = bidx[r0];
+    int r1 = r0 + 1;
+    while (r1 < nr && bidx[r1] == b) ++r1;
+    const char* fb = p.feat + ((long)b * HW * p.C + c0) * 2;
+    for (int px = tid; px < HW; px += nthr) {
+      i32x4_t x = *(const i32x4_t*)(fb + (long)px * p.C * 2);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
+      *(i32x4_t*)(map + (long)px * 16) = x;
+    }
+    __syncthreads();
+    for (int it = r0 * PP + tid; it < r1 * PP; it += nthr) {
+      const int r = it / PP, bin = it - r * PP;
+      const int ph = bin / 7, pw = bin - ph * 7;
+      const int hs = hb[r][ph][0], he = hb[r][ph][1], ws = wb[r][pw][0], we = wb[r][pw][1];
+      const int lo = (int)0x80008000u;
+      i32x4_t acc = {lo, lo, lo, lo};
+      for (int h = hs; h < he; ++h) {
+        const char* row = map + (long)(h * p.W) * 16;
+        for (int w = ws; w < we; ++w) {
+          const i32x4_t x = *(const i32x4_t*)(row + w * 16);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[e] = pk_max_i16(acc[e], x[e]);
+        }
+      }
+      const bool empty = he <= hs || we <= ws;
+      const float mul = mulv[r];
+      bf16_t* dst = (bf16_t*)(tile + (long)r * G64_PITCH) + bin;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const uint32_t y = (uint32_t)bf16x2_order(acc[e]);
+        const float f0 = empty ? 0.f : __builtin_bit_cast(float, y << 16);
+        const float f1 = empty ? 0.f : __builtin_bit_cast(float, y & 0xffff0000u);
+        dst[(2 * e) * PP] = f32_to_bf16(f0 * mul);
+        dst[(2 * e + 1) * PP] = f32_to_bf16(f1 * mul);
+      }
+    }
+    __syncthreads();  // the map slice may be replaced; after the last run: the tile is complete
+    r0 = r1;
+  }
+  // A: nr runs of 784 bytes (49 x 16 B), rows of the tile are 8-byte aligned
+  typedef int i32x2_t __attribute__((ext_vector_type(2)));
+  for (int v = tid; v < nr * PP; v += nthr) {
+    const int rr = v / PP, q = v - rr * PP;
+    const char* src = tile + (long)rr * G64_PITCH + q * 16;
+    const i32x2_t a = *(const i32x2_t*)src, b2 = *(const i32x2_t*)(src + 8);
+    *(i32x4_t*)(p.out + ((long)(m0 + rr) * p.ld_out + (long)c0 * PP) * 2 + (long)q * 16) = i32x4_t{a[0], a[1], b2[0], b2[1]};
+  }
+  if (p.out_t) {
+    char* ot = p.out_t + ((long)c0 * PP * p.ld_out_t + m0) * 2;
+    if (nr == ROI_G64) {
+      for (int v = tid; v < G64_RUN * 8; v += nthr) {  // (k row, 8-ROI octet): 8 lanes write one full 128-byte line
+        const int idx = v >> 3, q = v & 7;
+        const char* src = tile + (long)(8 * q) * G64_PITCH + idx * 2;
+        uint32_t w[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          w[k] = (uint32_t)(*(const bf16_t*)(src + (long)(2 * k) * G64_PITCH)) |
+                 ((uint32_t)(*(const bf16_t*)(src + (long)(2 * k + 1) * G64_PITCH)) << 16);
+        *(i32x4_t*)(ot + (long)idx * p.ld_out_t * 2 + q * 16) = i32x4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+      }
+    } else {
+      for (int idx = tid; idx < G64_RUN; idx += nthr)
+        for (int rr = 0; rr < nr; ++rr)
+          ((bf16_t*)(ot + (long)idx * p.ld_out_t * 2))[rr] = *(const bf16_t*)(tile + (long)rr * G64_PITCH + idx * 2);
+    }
+  }
+}
+
+static int g_roi_map64 = 512;  // drn_tune(DRN_TUNE_ROI_MAP64): 0 = off, else threads per block (256 / 512 / 1024)
+
+static bool launch_roi_map64(const RoiParams& p, hipStream_t st) {
+  if (!g_roi_map64 || p.C % G64_CH || p.H > 255 || p.W > 255) return false;
+  const size_t smem = (((size_t)p.H * p.W * 16 + 15) & ~(size_t)15) + (size_t)ROI_G64 * G64_PITCH;
+  if (smem > 76 * 1024) return false;  // two blocks per CU
+  static bool attr = false;
+  if (!attr && smem > 48 * 1024) {
+    if (hipFuncSetAttribute((const void*)roi_pool7_map64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024) != hipSuccess)
+      return false;
+    attr = true;
+  }
+  const int ngroups = (p.M + ROI_G64 - 1) / ROI_G64;
+  hipLaunchKernelGGL(roi_pool7_map64_kernel, dim3((p.C / G64_CH) * ngroups), dim3(g_roi_map64), smem, st, p);
+  return true;
+}
+
 // bf16 -> bf16 transpose with 16-B global accesses on both sides (the A -> A^T copy of the fc6 operand is
 // 2 x 205 MB per step): 64x64 tile, rows read as 8-element vectors, written transposed into LDS, re-read as vectors.
 __global__ __launch_bounds__(256) void transpose_bf16_kernel(const bf16_t* __restrict__ in, bf16_t* __restrict__ out,
@@ -761,6 +893,12 @@ static bool launch_roi_map(const RoiParams& p, hipStream_t st, size_t lds_budget
 }
 
 extern "C" {
+
+int drn_roi_set_map64(int on) {
+  const int old = g_roi_map64;
+  g_roi_map64 = on == 1 ? 512 : (on == 0 || on == 256 || on == 512 || on == 1024) ? on : old;
+  return old;
+}
 
 int drn_preprocess_nhwc(const float* img_chw, int C, int H, int W, void* out_nhwc, int Hp, int Wp, int Cp,
                         const float* mean3, const float* std3, int dtype, void* stream) {
@@ -875,7 +1013,10 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
       // slice whose map fits at all - the 43x58 .. 75x100 maps of test-time scales need 16 or 8 channels and most of
       // a CU's LDS (one block per CU), which still beats the per-ROI window kernels by 3-4x there
       const size_t two = 80 * 1024, one = 156 * 1024;
-      if (in_dtype == DRN_BF16)
+      if (in_dtype == DRN_BF16 && out_t && M >= ROI_G64)  // the training operand pair: full-line A^T rows
+        done = launch_roi_map64(p, st);
+      if (done) {
+      } else if (in_dtype == DRN_BF16)
         done = launch_roi_map<DRN_BF16, 32>(p, st, two) || launch_roi_map<DRN_BF16, 64>(p, st, two) ||
                launch_roi_map<DRN_BF16, 16>(p, st, two) || launch_roi_map<DRN_BF16, 8>(p, st, two) ||
                launch_roi_map<DRN_BF16, 32>(p, st, one) || launch_roi_map<DRN_BF16, 16>(p, st, one) ||

@@ -41,3 +41,9 @@ def timeit(fn, n=20):
 print("pool A only      %7.1f us" % timeit(lambda: ops.roi_pool_nhwc(feat, rois, obj, 7, 1 / 16, out=A)))
 print("pool A + A^T     %7.1f us" % timeit(lambda: ops.roi_pool_nhwc(feat, rois, obj, 7, 1 / 16, out=A, out_t=AT)))
 print("transpose alone  %7.1f us" % timeit(lambda: ops.transpose2d(A, R, K, out=AT)))
+for on in (0, 256, 512, 1024):
+    ops.tune(ops.TUNE_ROI_MAP64, on)
+    t = timeit(lambda: ops.roi_pool_nhwc(feat, rois, obj, 7, 1 / 16, out=A, out_t=AT))
+    nbytes = 2 * R * K * 2 + feat.numel() * 2
+    print("map64=%d  pool A + A^T  %7.1f us  (%.2f TB/s of %.0f MB)" % (on, t, nbytes / t / 1e6, nbytes / 1e6))
+ops.tune(ops.TUNE_ROI_MAP64, 512)
