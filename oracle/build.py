@@ -1,6 +1,6 @@
 """ORACLE build recipe (test infrastructure, not product code).
 
-`build_oracle()`   gcc-compiles oracle/roi_ops.c -> oracle/_build/liboracle_roi.so
+`build_oracle()`   gcc-compiles oracle/roi_ops.c + oracle/csc_ops.c -> oracle/_build/liboracle_roi.so
 `build_ref()`      when /root/reference is present, compiles the reference's own
                    detectron2/layers/csrc/ROIAlign/ROIAlign_cpu.cpp *where it lies* (no copy)
                    together with oracle/ref_binding.cpp (a 20-line pybind shim of ours) into
@@ -17,6 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 BUILD_DIR = os.path.join(HERE, "_build")
 REF_DIR = os.path.join(HERE, "_ref")
 ORACLE_SO = os.path.join(BUILD_DIR, "liboracle_roi.so")
+ORACLE_SOURCES = ("roi_ops.c", "csc_ops.c")
 REF_SRC = "/root/reference/detectron2/layers/csrc/ROIAlign/ROIAlign_cpu.cpp"
 REF_INC = "/root/reference/detectron2/layers/csrc"
 
@@ -30,12 +31,12 @@ def _newer(src, dst):
 
 
 def build_oracle(force=False):
-    src = os.path.join(HERE, "roi_ops.c")
+    srcs = [os.path.join(HERE, f) for f in ORACLE_SOURCES]
     os.makedirs(BUILD_DIR, exist_ok=True)
-    if force or _newer(src, ORACLE_SO):
+    if force or any(_newer(src, ORACLE_SO) for src in srcs):
         # no -march / -ffast-math: keep plain IEEE fp32, no FMA contraction
-        cmd = ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off",
-               src, "-o", ORACLE_SO, "-lm"]
+        cmd = ["gcc", "-O2", "-std=c11", "-fPIC", "-shared", "-fopenmp", "-ffp-contract=off"] + srcs + [
+            "-o", ORACLE_SO, "-lm"]
         subprocess.check_call(cmd)
     return ORACLE_SO
 

@@ -37,11 +37,13 @@ def _lib():
         spec = importlib.util.spec_from_file_location("_oracle_build", os.path.join(_HERE, "build.py"))
         mod = importlib.util.module_from_spec(spec)
         spec.loader.exec_module(mod)
-        so = mod.ORACLE_SO if os.path.exists(mod.ORACLE_SO) and os.path.getmtime(mod.ORACLE_SO) >= os.path.getmtime(
-            os.path.join(_HERE, "roi_ops.c")) else mod.build_oracle()
+        fresh = os.path.exists(mod.ORACLE_SO) and all(
+            os.path.getmtime(mod.ORACLE_SO) >= os.path.getmtime(os.path.join(_HERE, f)) for f in mod.ORACLE_SOURCES)
+        so = mod.ORACLE_SO if fresh else mod.build_oracle()
         _LIB = ctypes.CDLL(so)
         _LIB.oracle_nms.restype = ctypes.c_int64
         _LIB.oracle_batched_nms.restype = ctypes.c_int64
+        _LIB.oracle_csc_pool_one.restype = ctypes.c_float
     return _LIB
 
 
@@ -271,7 +273,7 @@ class OracleCfg:
     weight_decay_bias: float = 0.0
     width_per_group: int = 64  # MODEL.RESNETS.WIDTH_PER_GROUP (bottleneck width of res2)
     heads: str = "oicr"  # MODEL.ROI_HEADS.NAME: "oicr" (OICRROIHeads) | "pcl" (PCLROIHeads, oracle/pcl_oracle.py) |
-                         # "wsddn" (WSDDNROIHeads: refine_num = 0)
+                         # "wsddn" (WSDDNROIHeads: refine_num = 0) | "csc" (CSCROIHeads: refine_num = 0)
     # bf16 "fast mode" of the product (no reference counterpart: SURVEY F5 - the reference is fp32 only).  True = the
     # same fp32 algorithm with every value the product STORES in bf16 rounded to bf16 (round-to-nearest-even) at the same
     # point: the normalised image, every conv output after its fused epilogue, conv / fc weights as GEMM operands, the
@@ -279,6 +281,14 @@ class OracleCfg:
     # weight-gradient bucket.  Accumulation, biases, FrozenBN affines, logits, losses, SGD state stay fp32.  This is what
     # the full-size bf16 parity tests compare the HIP path with (tests/test_bench_mode_gpu.py).
     emulate_bf16: bool = False
+    # CSCROIHeads (heads == "csc"; roi_heads_csc.py:104-118 constants, WSL.CSC_MAX_ITER).  csc_iter is the head's
+    # `self.iter` STATE (roi_heads_csc.py:106,263): roi_heads_train advances it once per training forward.
+    csc_tau: float = 0.7
+    csc_fg_threshold: float = 0.1
+    csc_context_scale: float = 1.8
+    csc_area_sqrt: bool = True
+    csc_max_iter: int = 35000
+    csc_iter: int = 0
     # fp8 conv trunk of the product (BASELINE configs[4]; again no reference counterpart).  {conv name relative to the
     # backbone ("stem.conv1", "res2.0.shortcut", ...): per-tensor scale s_y of that conv's stored output}; the conv whose
     # scale entry is 1.0 and that is named by fp8_last writes bf16.  Emulated like emulate_bf16: the fp32 algorithm with
@@ -536,6 +546,59 @@ def wsddn_loss(scores, num_per_image, gt_oh, mean_loss=True):
     return F.binary_cross_entropy(img, gt_oh, reduction="mean" if mean_loss else "sum") / gt_oh.size(0)
 
 
+# --------------------------------------------------------------------------------------------
+# CSCROIHeads (roi_heads_csc.py; op in oracle/csc_ops.c)
+# --------------------------------------------------------------------------------------------
+def csc_forward(cpgs, labels, preds, rois5, cfg: "OracleCfg"):
+    """wsl/layers/csc.py:9-47 + csrc/csc/csc_cuda.cu:352-552 (restated in csc_ops.c; the reference is CUDA-only).
+    cpgs [B,K,H,W], labels / preds [B,K], rois5 [R,5] -> W [R,K], PL, NL."""
+    cpgs, labels, preds = cpgs.contiguous().float(), labels.contiguous().float(), preds.contiguous().float()
+    rois5 = rois5.contiguous().float()
+    B, K, H, Wd = cpgs.shape
+    R = rois5.shape[0]
+    W = torch.empty((R, K), dtype=torch.float32)
+    _lib().oracle_csc_forward(_fp(cpgs), _fp(labels), _fp(preds), _fp(rois5), B, K, H, Wd, R,
+                              ctypes.c_float(cfg.csc_fg_threshold), int(cfg.csc_area_sqrt),
+                              ctypes.c_float(cfg.csc_context_scale), _fp(W))
+    return W, labels.clone(), torch.zeros_like(labels)
+
+
+def csc_cpgs(scores, image_tensor, gt_oh, cfg: "OracleCfg"):
+    """roi_heads_csc.py:423-471 _forward_cpg: per labelled class whose image score reaches tau, the gradient of the
+    summed class score w.r.t. the normalised image; |.|, max over the colour channels, divided by its maximum."""
+    K = cfg.num_classes
+    img = scores.detach().sum(dim=0, keepdim=True)
+    H, Wd = image_tensor.shape[-2:]
+    cpgs = torch.zeros((1, K, H, Wd), dtype=torch.float32)
+    for c in range(K):
+        if gt_oh[0, c] < 0.5 or img[0, c] < cfg.csc_tau:
+            continue
+        go = torch.zeros_like(scores)
+        go[:, c] = 1.0
+        (g,) = torch.autograd.grad(scores, image_tensor, grad_outputs=go, retain_graph=True)
+        g = g.detach().abs().max(dim=1)[0]
+        cpgs[0, c] = (g / g.max())[0]
+    return cpgs
+
+
+def csc_weights(scores, image_tensor, gt_oh, rois5, cfg: "OracleCfg"):
+    """roi_heads_csc.py:473-510 _forward_csc (both sides of CSC_MAX_ITER). Returns W_pos, W_neg, PL, NL, cpgs."""
+    if cfg.csc_iter > cfg.csc_max_iter:
+        return torch.ones_like(scores), torch.zeros_like(scores), gt_oh, torch.zeros_like(gt_oh), None
+    cpgs = csc_cpgs(scores, image_tensor, gt_oh, cfg)
+    W, PL, NL = csc_forward(cpgs, gt_oh, scores.detach().sum(dim=0, keepdim=True), rois5, cfg)
+    return torch.clamp(W, min=0.0).abs(), torch.clamp(W, max=0.0).abs(), PL, NL, cpgs
+
+
+def csc_losses(scores, W_pos, W_neg, PL, NL, mean_loss):
+    """fast_rcnn.py:887-931 CSCOutputs.csc_loss (loss_weight 1, empty prefix)."""
+    pos = torch.clamp((scores * W_pos).sum(dim=0, keepdim=True), min=1e-20, max=1.0 - 1e-20)
+    neg = torch.clamp((scores * W_neg).sum(dim=0, keepdim=True), min=1e-20, max=1.0 - 1e-20)
+    red = "mean" if mean_loss else "sum"
+    return {"loss_cls_pos": F.binary_cross_entropy(pos, PL, reduction=red) / PL.size(0),
+            "loss_cls_neg": F.binary_cross_entropy(neg, NL, reduction=red) / NL.size(0)}
+
+
 def get_image_level_gt(gt_classes_list, num_classes):
     """roi_heads.py:137-153."""
     ints = [torch.unique(g, sorted=True).to(torch.int64) for g in gt_classes_list]
@@ -598,8 +661,9 @@ def oicr_box_reg_loss(deltas, gt_classes, prop_boxes, gt_boxes, num_classes, cfg
 
 
 def roi_heads_train(p, feat, prop_boxes, objectness, gt_classes_list, cfg: OracleCfg, dropout_masks=None,
-                    return_aux=False):
-    """roi_heads_oicr.py:248-291 + :320-421 (training branch). Returns the loss dict."""
+                    return_aux=False, image_tensor=None):
+    """roi_heads_oicr.py:248-291 + :320-421 (training branch). Returns the loss dict.
+    heads == "csc": roi_heads_csc.py:231-266 + :301-352 (image_tensor = the normalised images, requires_grad)."""
     K = cfg.num_classes
     nper = [len(b) for b in prop_boxes]
     gt_ints, gt_oh = get_image_level_gt(gt_classes_list, K)
@@ -608,6 +672,13 @@ def roi_heads_train(p, feat, prop_boxes, objectness, gt_classes_list, cfg: Oracl
     pooled = _q(pooled * obn.view(-1, 1, 1, 1), cfg)
     x = dan_forward(p, pooled, cfg, True, dropout_masks)
     scores = wsddn_scores(p, x, nper, cfg=cfg)
+    if cfg.heads == "csc":
+        assert len(prop_boxes) == 1, "CSCROIHeads reads image_sizes[0] / gt_classes_img_oh[0]: one image per step"
+        W_pos, W_neg, PL, NL, cpgs = csc_weights(scores, image_tensor, gt_oh, boxes_to_rois(prop_boxes), cfg)
+        losses = csc_losses(scores, W_pos, W_neg, PL, NL, cfg.mean_loss)
+        cfg.csc_iter += 1
+        aux = {"pooled": pooled, "fc7": x, "scores": scores, "W_pos": W_pos, "W_neg": W_neg, "cpgs": cpgs}
+        return (losses, aux) if return_aux else losses
     losses = {"loss_cls": wsddn_loss(scores, nper, gt_oh, cfg.mean_loss)}
     img_scores = predict_probs_img(scores, nper).detach()
     prev_scores = list(scores.detach().split(nper, dim=0))
@@ -743,9 +814,12 @@ def model_train_losses(p, batch, cfg: OracleCfg, dropout_masks=None, return_aux=
     """rcnn.py:138-197 (training branch). batch: list of dicts with image [3,H,W], proposal_boxes
     [R,4], objectness_logits [R], gt_classes [G]."""
     x, _ = preprocess_image([b["image"] for b in batch], cfg)
+    if cfg.heads == "csc":  # rcnn.py:170-171: images.tensor.requires_grad = True
+        x = x.detach().requires_grad_(True)
     feat = backbone_forward(p, x, cfg)
     return roi_heads_train(p, feat, [b["proposal_boxes"] for b in batch], [b["objectness_logits"] for b in batch],
-                           [b["gt_classes"] for b in batch], cfg, dropout_masks, return_aux)
+                           [b["gt_classes"] for b in batch], cfg, dropout_masks, return_aux,
+                           image_tensor=x if cfg.heads == "csc" else None)
 
 
 def model_inference(p, batch, cfg: OracleCfg):

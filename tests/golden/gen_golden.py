@@ -185,6 +185,88 @@ def case_full_model(name, yaml_rel, opts, seed, n_img, R, H, W, dropmask=False, 
     print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: v for k, v in d.items() if k.startswith("step")})
 
 
+def case_csc(name, yaml_rel, opts, seed, R, H, W, tau, steps=3):
+    """CSCROIHeads (roi_heads_csc.py) end to end: image-gradient maps (_forward_cpg), CSC weights, the two weighted BCE
+    losses, SGD steps on both sides of WSL.CSC_MAX_ITER.
+
+    The reference implements `_C.csc_forward` for CUDA only (wsl/layers/csrc/csc/csc.h), so it cannot execute here; the
+    oracle's restatement (oracle/csc_ops.c) stands in for that ONE call.  Everything around it - the autograd maps, the
+    clamps, the losses, the optimizer - is the unmodified reference, and the maps / weights it saw are recorded so the
+    oracle and the HIP path are compared stage by stage.  Instance attributes set here (not code): `tau` (0.7 is never
+    reached by a random-init model), `iter` = 1 (iteration 0 dumps debug PNGs through cv2)."""
+    import tempfile
+
+    import wsl._C as wsl_c
+    from detectron2.solver import build_optimizer
+
+    ocfg_like = O.OracleCfg()
+
+    def csc_forward(cpgs, labels, preds, rois, tau_, debug, fg_threshold, mass_threshold, density_threshold, area_sqrt,
+                    context_scale):
+        ocfg_like.csc_fg_threshold, ocfg_like.csc_area_sqrt, ocfg_like.csc_context_scale = fg_threshold, area_sqrt, context_scale
+        return O.csc_forward(cpgs, labels, preds, rois, ocfg_like)[0]
+
+    wsl_c.csc_forward = csc_forward
+    out_dir = tempfile.mkdtemp(prefix="csc_golden_")
+    cfg, model = rh.build_reference_model(yaml_rel, list(opts) + ["OUTPUT_DIR", out_dir])
+    fill_reference(model, seed)
+    K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    batch = make_inputs(1, R, K, H, W, seed + 17, n_gt=2)
+    d = {"seed": np.int64(seed), "tau": np.float64(tau), "csc_max_iter": np.int64(cfg.WSL.CSC_MAX_ITER),
+         "iter0": np.int64(1)}
+    flat_batch(batch, d)
+    heads = model.roi_heads
+    heads.tau = tau
+    heads.iter = 1
+    log = []
+    orig = heads._forward_csc
+
+    def spy(masks, pred_class_logits, proposals):
+        res = orig(masks, pred_class_logits, proposals)
+        log.append((None if masks is None else masks.detach().clone(), res[0].detach().clone(), res[1].detach().clone(),
+                    pred_class_logits.detach().clone()))
+        return res
+
+    heads._forward_csc = spy
+    model.train()
+    opt = build_optimizer(cfg, model)
+    tnames = [n for n, p in model.named_parameters() if p.requires_grad]
+    d["trainable"] = np.array(tnames)
+    with EventStorage(), DropoutPatch(None):
+        for step in range(steps):
+            opt.zero_grad()
+            losses = model(to_ref_inputs(batch))
+            sum(losses.values()).backward()
+            for k, v in losses.items():
+                d["step%d_%s" % (step, k)] = np.float64(v.item())
+            masks, wpos, wneg, scores = log[-1]
+            d["step%d_scores" % step] = scores.numpy()
+            d["step%d_W_pos" % step] = wpos.numpy()
+            d["step%d_W_neg" % step] = wneg.numpy()
+            if masks is not None:
+                d["step%d_cpgs" % step] = masks.numpy()
+            if step == 0:
+                for n, p in model.named_parameters():
+                    if p.requires_grad and p.grad is not None and p.numel() <= 70000:
+                        d["grad0." + n] = p.grad.detach().numpy().copy()
+            opt.step()
+        for n, p in model.named_parameters():
+            if p.requires_grad:
+                f = p.detach().reshape(-1)
+                d["after%d.head." % steps + n] = f[:2048].numpy().copy()
+                d["after%d.sum." % steps + n] = np.float64(f.double().sum().item())
+    d["cfg_opts"] = np.array([yaml_rel] + list(opts))
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path, os.path.getsize(path) // 1024, "KiB", {k: v for k, v in d.items() if k.startswith("step") and np.ndim(v) == 0})
+    for step in range(steps):
+        sc = d["step%d_scores" % step].sum(0)
+        print(" step", step, "image scores", sc, "labels", batch[0]["gt_classes"],
+              "cpg classes", [int(c) for c in range(K) if "step%d_cpgs" % step in d and d["step%d_cpgs" % step][0, c].max() > 0],
+              "W range", float((d["step%d_W_pos" % step] - d["step%d_W_neg" % step]).min()),
+              float((d["step%d_W_pos" % step] - d["step%d_W_neg" % step]).max()))
+
+
 def case_samplers(name):
     """the data-parallel partition: the reference's TrainingSampler / InferenceSampler per rank (this
     container runs one process: comm.get_rank / get_world_size are pointed at the rank being recorded),
@@ -821,6 +903,10 @@ if __name__ == "__main__":
         np.savez_compressed(os.path.join(HERE, "model_pcl_r50c4_tiny.npz"), **dd)
         print("PCL model golden: oracle with the reference's recorded decisions reproduces both steps;",
               len(km_log), "k-means calls,", len(pick_log), "picks")
+    if "csc" in which:
+        case_csc("model_csc_r18dc5_tiny", "PascalVOC-Detection/csc_WSR_18_DC5_1x.yaml",
+                 ["MODEL.RESNETS.STEM_OUT_CHANNELS", "8", "MODEL.ROI_BOX_HEAD.DAN_DIM", "[48, 64]",
+                  "MODEL.ROI_HEADS.NUM_CLASSES", "4", "WSL.CSC_MAX_ITER", "2", "SOLVER.BASE_LR", "0.00002"], 43, 48, 96, 80, tau=0.15)
     if "r50c4_reg" in which:
         case_full_model("model_r50c4_reg_tiny", "PascalVOC-Detection/reg/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 37,
                         1, 40, 96, 96)

@@ -34,6 +34,14 @@ MODEL_CASES = {
 FREEZE_AT = {"model_r50c4_align_tiny": 3}
 
 
+def csc_case():
+    """model_csc_r18dc5_tiny.npz: CSCROIHeads on the tiny WSR-18 DC5 trunk (csc_WSR_18_DC5_1x.yaml + overrides); a fresh
+    config each call because `csc_iter` is state"""
+    return O.OracleCfg(arch="wsr18", out_feature="res5", res5_dilation=1, stem_out=8, res2_out=64, dan_dim=(48, 64),
+                       num_classes=4, heads="csc", refine_num=0, refine_reg=(), score_thresh=1e-9, nms_thresh=0.5,
+                       mean_loss=False, base_lr=0.00002, csc_max_iter=2, csc_iter=1, csc_tau=0.15, dropout=0.0)
+
+
 def load(name):
     return dict(np.load(os.path.join(GOLDEN, name + ".npz"), allow_pickle=False))
 
@@ -75,7 +83,7 @@ def drn_cfg(ocfg, device="cuda", freeze_at=5):
     L = ["MODEL.META_ARCHITECTURE", "GeneralizedRCNNWSL", "MODEL.DEVICE", device, "MODEL.LOAD_PROPOSALS", "True",
          "MODEL.PIXEL_MEAN", str(list(ocfg.pixel_mean)), "MODEL.BACKBONE.FREEZE_AT", str(freeze_at),
          "MODEL.BACKBONE.NAME", "build_vgg_backbone" if vgg else "build_ws_resnet_backbone",
-         "MODEL.ROI_HEADS.NAME", {"pcl": "PCLROIHeads", "wsddn": "WSDDNROIHeads"}.get(ocfg.heads, "OICRROIHeads"), "MODEL.ROI_HEADS.NUM_CLASSES", str(ocfg.num_classes),
+         "MODEL.ROI_HEADS.NAME", {"pcl": "PCLROIHeads", "wsddn": "WSDDNROIHeads", "csc": "CSCROIHeads"}.get(ocfg.heads, "OICRROIHeads"), "MODEL.ROI_HEADS.NUM_CLASSES", str(ocfg.num_classes),
          "MODEL.ROI_HEADS.IN_FEATURES", str([feat]), "MODEL.ROI_HEADS.SCORE_THRESH_TEST", repr(ocfg.score_thresh),
          "MODEL.ROI_HEADS.NMS_THRESH_TEST", repr(ocfg.nms_thresh), "MODEL.ROI_HEADS.PROPOSAL_APPEND_GT", "False",
          "MODEL.ROI_HEADS.BATCH_SIZE_PER_IMAGE", "4096", "MODEL.ROI_HEADS.POSITIVE_FRACTION", "1.0",
@@ -85,7 +93,7 @@ def drn_cfg(ocfg, device="cuda", freeze_at=5):
          "WSL.MEAN_LOSS", str(bool(ocfg.mean_loss)), "WSL.REFINE_NUM", str(ocfg.refine_num), "WSL.REFINE_REG", str(list(ocfg.refine_reg)),
          "SOLVER.BASE_LR", str(ocfg.base_lr), "SOLVER.WEIGHT_DECAY", "0.0005", "SOLVER.BIAS_LR_FACTOR", "2.0",
          "SOLVER.WEIGHT_DECAY_BIAS", "0.0", "SOLVER.WARMUP_ITERS", "0", "SOLVER.STEPS", "(35000, 50000)",
-         "SOLVER.MAX_ITER", "50000", "SOLVER.IMS_PER_BATCH", "4"]
+         "SOLVER.MAX_ITER", "50000", "SOLVER.IMS_PER_BATCH", "4", "WSL.CSC_MAX_ITER", str(ocfg.csc_max_iter)]
     if vgg:
         L += ["MODEL.VGG.DEPTH", "16", "MODEL.VGG.CONV5_DILATION", str(ocfg.res5_dilation)]
     else:

@@ -480,3 +480,68 @@ def test_pcl_kmeans_exact_optimum_bruteforce():
             else:
                 e_my = min(sse(0, c1) + sse(c1, c_my) + sse(c_my, n) for c1 in cuts if c1 < c_my)
             assert e_my <= best[0] + 1e-12, (n, rep)
+
+
+# ------------------------------------------------------------------ CSCROIHeads
+def test_csc_pool_table_sums_equal_direct_counts():
+    """oracle/csc_ops.c is parity-unpinned (the reference's op is CUDA-only): pin the summed-area arithmetic by brute
+    force - for random maps and boxes, every box sum read from the table equals the directly counted foreground pixels,
+    and the score is the stated frame / context contrast of those counts."""
+    import ctypes
+
+    lib = O._lib()
+    rs = np.random.RandomState(5)
+    for trial in range(6):
+        H, W = int(rs.randint(9, 70)), int(rs.randint(9, 90))
+        m = torch.from_numpy(rs.rand(H, W).astype(np.float32))
+        thr = np.float32(0.1 + 0.6 * rs.rand())
+        table = torch.empty((H, W), dtype=torch.float32)
+        lib.oracle_csc_integral(O._fp(m), O._fp(table), H, W, ctypes.c_float(thr))
+        binm = (m.numpy() >= thr).astype(np.float64)
+        assert np.array_equal(table.numpy().astype(np.float64), binm.cumsum(0).cumsum(1))
+        for _ in range(60):
+            x0, y0 = rs.rand() * (W + 6) - 3, rs.rand() * (H + 6) - 3
+            roi = torch.tensor([0.0, x0, y0, x0 + rs.rand() * W, y0 + rs.rand() * H], dtype=torch.float32)
+            boxes = (ctypes.c_int * 12)()
+            sc = lib.oracle_csc_pool_one(O._fp(table), H, W, O._fp(roi), 1, ctypes.c_float(1.8), boxes)
+            b = list(boxes)
+            cnt = [binm[b[4 * i]: b[4 * i + 2] + 1, b[4 * i + 1]: b[4 * i + 3] + 1].sum() for i in range(3)]
+            area = [(b[4 * i + 2] - b[4 * i] + 1) * (b[4 * i + 3] - b[4 * i + 1] + 1) for i in range(3)]
+            assert b[0] <= b[4] and b[5] >= b[1] and b[8] <= b[0] and b[11] >= b[3]  # inner inside roi inside outer
+            frame, ctx = cnt[0] - cnt[1], cnt[2] - cnt[0]
+            want = frame / np.sqrt(max(area[0] - area[1], 1)) - ctx / np.sqrt(max(area[2] - area[0], 1))
+            assert abs(sc - want) <= 1e-5 * max(1.0, abs(want)), (sc, want)
+
+
+def test_csc_model_three_steps():
+    """the unmodified reference CSCROIHeads (tests/golden/gen_golden.py `csc`; its CUDA-only csc_forward call served by
+    oracle/csc_ops.c): image-gradient maps, weights, both losses, gradients and three SGD steps, the third one past
+    WSL.CSC_MAX_ITER"""
+    cfg = G.csc_case()
+    d = G.load("model_csc_r18dc5_tiny")
+    assert cfg.csc_max_iter == int(d["csc_max_iter"]) and cfg.csc_iter == int(d["iter0"]) and cfg.csc_tau == float(d["tau"])
+    seed = int(d["seed"])
+    p = O.seeded_params(O.param_shapes(cfg), seed)
+    batch = G.batch_from(d)
+    assert set(d["trainable"].tolist()) == set(O.trainable_names(p, cfg, 5))
+    opt = O.SGDState(cfg)
+    for step in range(3):
+        losses, grads, aux = O.train_step(p, batch, cfg, opt, None, 5, return_aux=True)
+        for k, v in losses.items():
+            _close(v, float(d["step%d_%s" % (step, k)]), rtol=1e-4, atol=1e-9)
+        _close(aux["scores"].detach(), d["step%d_scores" % step], rtol=1e-4, atol=1e-9)
+        if step < 2:
+            got, want = aux["cpgs"].numpy(), d["step%d_cpgs" % step]
+            assert [c for c in range(4) if got[0, c].max() > 0] == [c for c in range(4) if want[0, c].max() > 0]
+            assert np.abs(got - want).max() <= 1e-4
+            # the weights count pixels over a threshold: equal unless a pixel sits within 1e-4 of it
+            assert np.abs(aux["W_pos"].numpy() - d["step%d_W_pos" % step]).max() <= 2e-3
+            assert np.abs(aux["W_neg"].numpy() - d["step%d_W_neg" % step]).max() <= 2e-3
+        else:
+            assert aux["cpgs"] is None and float(aux["W_pos"].min()) == 1.0 and float(aux["W_neg"].max()) == 0.0
+        if step == 0:
+            for n, g in grads.items():
+                if "grad0." + n in d:
+                    _close(g, d["grad0." + n], rtol=2e-3, atol=2e-6)
+    for n in grads:
+        _close(p[n].reshape(-1)[:2048], d["after3.head." + n], rtol=1e-4, atol=1e-6)
