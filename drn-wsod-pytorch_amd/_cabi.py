@@ -49,6 +49,9 @@ _SIGS = {
     "drn_sgd_step": "pppilpipififp",
     "drn_detect_topk": "ppiii" + "ffff" + "i" + "pl" + "i" + "ppp",
     "drn_detect_gather": "plippippppp",
+    "drn_csc_cpg": "piiiiippp",
+    "drn_csc_weights": "piifpipiiifppp",
+    "drn_csc_loss": "pliiiippppiiipplp",
 }
 
 _lib = None

@@ -62,7 +62,7 @@ def _table():
         "wsl.modeling.meta_arch": {"GeneralizedRCNNWSL": rcnn.GeneralizedRCNNWSL},
         "wsl.modeling.backbone": pick(backbone, "build_ws_resnet_backbone", "build_vgg_backbone", "ResNet", "VGG16", "BasicStem",
                                       "BasicBlock", "BottleneckBlock", "PlainBlock"),
-        "wsl.modeling.roi_heads": pick(roi_heads, "OICRROIHeads", "WSDDNROIHeads", "PCLROIHeads", "DiscriminativeAdaptionNeck",
+        "wsl.modeling.roi_heads": pick(roi_heads, "OICRROIHeads", "WSDDNROIHeads", "PCLROIHeads", "CSCROIHeads", "DiscriminativeAdaptionNeck",
                                        "WSDDNOutputLayers", "OICROutputLayers"),
     }
     return t

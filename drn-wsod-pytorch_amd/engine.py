@@ -712,6 +712,8 @@ class GraphedTrainStep:
 
     def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False,
                  eager_fc6=False):
+        if getattr(model, "cpg", False):
+            raise DrnError("CSCROIHeads decides per step, on the host, which class maps to compute: eager steps only")
         if self._needs_frozen_trunk and any(p.requires_grad for p in model.backbone.parameters()):
             raise DrnError("GraphedTrainStep runs the trunk of FUTURE batches on a side stream, which needs a frozen "
                            "backbone (FREEZE_AT = 5); use GraphedFullStep for a trainable trunk")

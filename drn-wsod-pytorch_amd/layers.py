@@ -13,6 +13,19 @@ from . import compute_dtype, ops
 from ._cabi import DrnError
 
 
+# CSCROIHeads' image-gradient passes walk the trunk's explicit backward for d/dx only: no weight / bias gradients are
+# written and the blocks keep their saved activations (several passes per step, then the real backward)
+_DX_ONLY = [False]
+
+
+class dx_only:
+    def __enter__(self):
+        self._was, _DX_ONLY[0] = _DX_ONLY[0], True
+
+    def __exit__(self, *a):
+        _DX_ONLY[0] = self._was
+
+
 class ShapeSpec(namedtuple("_ShapeSpec", ["channels", "height", "width", "stride"])):
     """detectron2/layers/shape_spec.py."""
 
@@ -226,14 +239,13 @@ class Conv2d(nn.Conv2d):
         return self._pack
 
     def packed_dgrad(self, dtype):
-        """weights of the data-gradient pass, which for a stride-1 conv is itself a conv over the output gradient with
+        """weights of the data-gradient pass, which for a stride-1 conv (see _dgrad for stride > 1) is itself a conv over the output gradient with
         the taps flipped and the channel roles swapped: wd[ci][(kh'*KW + kw')*Cout + co] = w[co, ci, KH-1-kh', KW-1-kw'],
         padding dil*(K-1) - pad.  Rows beyond Cin (the channel padding of x) are zero."""
         key = (dtype, self.weight.device, self.weight.data_ptr(), self.weight._version, getattr(self, "_pack_gen", 0))
         if key != getattr(self, "_packd_key", None):
             with torch.no_grad():
                 cout, cin, kh, kw = self.weight.shape
-                assert self.stride[0] == 1, "dgrad is only needed for the stride-1 convs of the trunk"
                 w = self.weight.detach().float().flip(2, 3).permute(1, 2, 3, 0).reshape(cin, kh * kw * cout)
                 wd = torch.zeros((self.cin_pad(dtype), ops.kpad(kh * kw * cout, dtype)), dtype=dtype, device=w.device)
                 wd[:cin, : kh * kw * cout] = w.to(dtype)
@@ -244,6 +256,19 @@ class Conv2d(nn.Conv2d):
         """the optimizer updated the weights in place (no _version bump): drop the packed compute copies"""
         self._pack_key = None
         self._pack_gen = getattr(self, "_pack_gen", 0) + 1
+
+    def _dgrad(self, g, x_shape, dtype):
+        """d loss / d x from the pre-activation gradient g [N,Ho,Wo,Cout]: a stride-1 conv over g with flipped taps
+        (packed_dgrad).  A strided conv (only stem.conv1 here) first spreads g over the stride-1 output grid - zeros
+        between the taken positions and after the last one, up to H + 2p - d(K-1) rows - which is conv_transpose."""
+        n, ho, wo, cout = g.shape
+        k, s, d_, pd = self.kernel_size[0], self.stride[0], self.dilation[0], self.padding[0]
+        if s > 1:
+            hs, ws = x_shape[1] + 2 * pd - d_ * (k - 1), x_shape[2] + 2 * pd - d_ * (k - 1)
+            gz = torch.zeros((n, hs, ws, cout), dtype=g.dtype, device=g.device)
+            gz[:, ::s, ::s][:, :ho, :wo] = g
+            g = gz
+        return ops.conv2d_nhwc(g, self.packed_dgrad(dtype), self.cin_pad(dtype), k, k, 1, d_ * (k - 1) - pd, d_)
 
     def backward_nhwc(self, x, y, dy, relu, need_dx, residual, accumulate):
         """Explicit backward of run_nhwc (torch.autograd of F.conv2d + FrozenBatchNorm2d + relu_ + residual add):
@@ -267,19 +292,15 @@ class Conv2d(nn.Conv2d):
             self._bw_gT = torch.zeros((cout, ops.kpad(P, dtype)), dtype=dtype, device=x.device)
             self._bw_key = key
         g = torch.empty((P, cout), dtype=dtype, device=x.device)
-        want_w = self.weight.requires_grad
-        bgrad = self.bias.grad if (self.bias is not None and self.bias.requires_grad) else None
+        want_w = self.weight.requires_grad and not _DX_ONLY[0]
+        bgrad = self.bias.grad if (self.bias is not None and self.bias.requires_grad and not _DX_ONLY[0]) else None
         ops.bias_act_bwd(dy2, P, cout, saved=saved, colscale=scale, dpre=g, dpreT=self._bw_gT if want_w else None,
                          colsum=bgrad, accumulate_colsum=accumulate)
         if want_w:
             col = ops.im2col_t(x, cin, k, k, self.stride[0], self.padding[0], self.dilation[0])
             gw = self.weight.grad.view(1, cout, cin * k * k)
             ops.gemm_nt(self._bw_gT, col, cout, cin * k * k, ops.kpad(P, dtype), out=gw, accumulate=accumulate)
-        dx = None
-        if need_dx:
-            wd = self.packed_dgrad(dtype)
-            dx = ops.conv2d_nhwc(g.view(n, ho, wo, cout), wd, self.cin_pad(dtype), k, k, 1,
-                                 self.dilation[0] * (k - 1) - self.padding[0], self.dilation[0])
+        dx = self._dgrad(g.view(n, ho, wo, cout), x.shape, dtype) if need_dx else None
         return dx, (d_res.view(n, ho, wo, cout) if d_res is not None else None)
 
     def run_nhwc(self, x, residual=None, relu=False, explicit_backward=False):

@@ -12,7 +12,8 @@ import torch
 from torch import nn
 
 from .. import compute_dtype, ops
-from ..layers import CNNBlockBase, Conv2d, FrozenBatchNorm2d, ShapeSpec, from_nhwc, get_norm, to_nhwc
+from .._cabi import DrnError
+from ..layers import _DX_ONLY, dx_only, CNNBlockBase, Conv2d, FrozenBatchNorm2d, ShapeSpec, from_nhwc, get_norm, to_nhwc
 from ..registry import BACKBONE_REGISTRY
 
 __all__ = ["Backbone", "BasicStem", "BasicBlock", "BottleneckBlock", "ResNet", "PlainBlock", "VGG16",
@@ -53,6 +54,23 @@ class Backbone(nn.Module):
         return {name: ShapeSpec(channels=self._out_feature_channels[name], stride=self._out_feature_strides[name])
                 for name in self._out_features}
 
+    # CSCROIHeads (rcnn.py:170-171 `images.tensor.requires_grad = True`): set by the meta-architecture; every unit then
+    # keeps what its explicit backward needs, frozen or not
+    input_grad = False
+
+    def input_gradient_nhwc(self, dfeat):
+        """d (scalar) / d normalised image [N, H, W, Cin_pad] given its gradient w.r.t. the (single) output feature map:
+        the explicit backward of EVERY unit for d/dx only - no weight / bias gradient is touched and the saved
+        activations stay for further passes and for the training backward."""
+        units = getattr(self, "_all_units", None)
+        if units is None:
+            raise DrnError("input_gradient_nhwc() needs a training-mode forward with `input_grad` set")
+        d = dfeat
+        with dx_only():
+            for j in range(len(units) - 1, -1, -1):
+                d = units[j].backward_nhwc(d, need_dx=True, accumulate=False)
+        return d
+
     def _input_nhwc(self, x):
         """accept an ImageList-produced padded NHWC buffer (fast path) or any [N,3,H,W] tensor"""
         dtype = compute_dtype()
@@ -84,14 +102,16 @@ class BasicStem(CNNBlockBase):
         return _pool(o3, 2)
 
     def backward_nhwc(self, dy, need_dx, accumulate):
-        """explicit backward of forward_nhwc(save=True); the image needs no gradient, so conv1 has no dgrad"""
+        """explicit backward of forward_nhwc(save=True); training needs no image gradient (need_dx False: conv1 has no
+        dgrad), CSCROIHeads' class maps do (Backbone.input_gradient_nhwc)"""
         x, o1, o2, o3 = self._sv
         d = ops.maxpool2x2_bwd_nhwc(o3, _as(dy, o3.dtype), 2)
         d, _ = self.conv3.backward_nhwc(o2, o3, d, True, True, False, accumulate)
         d, _ = self.conv2.backward_nhwc(o1, o2, d, True, True, False, accumulate)
-        self.conv1.backward_nhwc(x, o1, d, True, False, False, accumulate)
-        self._sv = None
-        return None
+        d, _ = self.conv1.backward_nhwc(x, o1, d, True, need_dx, False, accumulate)  # d/d image: CSC passes only
+        if not _DX_ONLY[0]:
+            self._sv = None
+        return d
 
     def forward(self, x):
         return from_nhwc(self.forward_nhwc(to_nhwc(x, compute_dtype(), 8 if compute_dtype() == torch.bfloat16 else 4)))
@@ -137,7 +157,8 @@ class BasicBlock(CNNBlockBase):
             dxs, _ = self.shortcut.backward_nhwc(x, sc, d_sc, False, need_dx, False, accumulate)
         else:
             dxs = d_sc
-        self._sv = None
+        if not _DX_ONLY[0]:
+            self._sv = None
         return ops.add(dx, dxs) if need_dx else None
 
     def forward(self, x):
@@ -193,7 +214,8 @@ class BottleneckBlock(CNNBlockBase):
             dxs, _ = self.shortcut.backward_nhwc(x, sc, d_sc, False, need_dx, False, accumulate)
         else:
             dxs = d_sc
-        self._sv = None
+        if not _DX_ONLY[0]:
+            self._sv = None
         return ops.add(dx, dxs) if need_dx else None
 
     def forward(self, x):
@@ -234,16 +256,19 @@ class ResNet(Backbone):
         units = [self.stem] + [b for stage, _ in self.stages_and_names for b in stage]
         first = next((i for i, u in enumerate(units) if any(p.requires_grad for p in u.parameters())), None)
         self._bw_units = units[first:] if (save and first is not None) else None
-        assert len(self._out_features) == 1 or self._bw_units is None, "trainable trunk: one output feature (as configured)"
+        keep_all = save and self.input_grad
+        self._all_units = units if keep_all else None
+        assert len(self._out_features) == 1 or (self._bw_units is None and not keep_all), \
+            "trainable trunk / image gradients: one output feature (as configured)"
         with torch.no_grad():
             i = 0
-            y = self.stem.forward_nhwc(self._input_nhwc(x), save=self._bw_units is not None and first == 0)
+            y = self.stem.forward_nhwc(self._input_nhwc(x), save=keep_all or (self._bw_units is not None and first == 0))
             if "stem" in self._out_features:
                 outputs["stem"] = from_nhwc(y)
             for stage, name in self.stages_and_names:
                 for block in stage:
                     i += 1
-                    y = block.forward_nhwc(y, save=self._bw_units is not None and i >= first)
+                    y = block.forward_nhwc(y, save=keep_all or (self._bw_units is not None and i >= first))
                 if name in self._out_features:
                     outputs[name] = from_nhwc(y)
         return outputs
@@ -407,7 +432,8 @@ class PlainBlock(nn.Module):
         for i in range(self.num_conv - 1, -1, -1):
             d, _ = getattr(self, "conv%d" % (i + 1)).backward_nhwc(acts[i], acts[i + 1], d, True, need_dx or i > 0, False,
                                                                    accumulate)
-        self._sv = None
+        if not _DX_ONLY[0]:
+            self._sv = None
         return d
 
     def forward(self, x):
@@ -445,13 +471,15 @@ class VGG16(Backbone):
         units = [b for stage, _ in self.stages_and_names for b in stage]
         first = next((i for i, u in enumerate(units) if any(p.requires_grad for p in u.parameters())), None)
         self._bw_units = units[first:] if (save and first is not None) else None
+        keep_all = save and self.input_grad
+        self._all_units = units if keep_all else None
         with torch.no_grad():
             y = self._input_nhwc(x)
             i = -1
             for stage, name in self.stages_and_names:
                 for block in stage:
                     i += 1
-                    y = block.forward_nhwc(y, save=self._bw_units is not None and i >= first)
+                    y = block.forward_nhwc(y, save=keep_all or (self._bw_units is not None and i >= first))
                 if name in self._out_features:
                     outputs[name] = from_nhwc(y)
         return outputs

@@ -37,8 +37,8 @@ class GeneralizedRCNNWSL(nn.Module):
         super().__init__()
         if proposal_generator is not None:
             raise DrnError("learned proposal generators are off the DRN-WSOD path (precomputed proposals only)")
-        if cpg:
-            raise DrnError("CPG (CSC / WSJDS heads) needs input-image gradients: off this path")
+        if cpg and not hasattr(roi_heads, "image_grad_fn"):
+            raise DrnError("input-image gradients are built for CSCROIHeads only (WSJDS / X heads are off this path)")
         self.backbone = backbone
         self.proposal_generator = None
         self.load_proposals = load_proposals
@@ -48,7 +48,12 @@ class GeneralizedRCNNWSL(nn.Module):
         self.register_buffer("pixel_mean", torch.Tensor(pixel_mean).view(-1, 1, 1))
         self.register_buffer("pixel_std", torch.Tensor(pixel_std).view(-1, 1, 1))
         self._mean, self._std = tuple(float(v) for v in pixel_mean), tuple(float(v) for v in pixel_std)
+        # rcnn.py:170-171,190-192: `images.tensor.requires_grad = True` around the forward.  Here: every trunk unit keeps
+        # what its explicit backward needs and the head gets the d feature -> d image pass
         self.cpg = cpg
+        if cpg:
+            self.backbone.input_grad = True
+            self.roi_heads.image_grad_fn = self.backbone.input_gradient_nhwc
 
     @classmethod
     def from_config(cls, cfg):
@@ -77,8 +82,8 @@ class GeneralizedRCNNWSL(nn.Module):
         """Run preprocess + backbone of a FUTURE batch on a side stream.  The shipped configs freeze the whole
         backbone (FREEZE_AT=5), so its forward has no dependency on the head update: its ~45 small, latency-bound
         conv launches hide under the current batch's fc6/fc7 GEMMs instead of serialising in front of them."""
-        if any(p.requires_grad for p in self.backbone.parameters()):
-            return  # only legal for a frozen backbone
+        if self.cpg or any(p.requires_grad for p in self.backbone.parameters()):
+            return  # only legal for a frozen backbone that nothing differentiates through
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream()
         main = torch.cuda.current_stream()

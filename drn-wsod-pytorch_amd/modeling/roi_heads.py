@@ -515,10 +515,11 @@ class _HeadEngine:
                 fc6_part=None):
         h = self.h
         fg_hook = getattr(self, "feature_grad_hook", None) if training else None
+        csc = training and getattr(h, "csc_head", False)
         if pooled is None:
-            pooled = self.pool(feat_nhwc, rois, objectness, training, want_argmax=fg_hook is not None)
-        elif fg_hook is not None:
-            raise DrnError("a trainable backbone cannot use a prefetched pooled operand")
+            pooled = self.pool(feat_nhwc, rois, objectness, training, want_argmax=fg_hook is not None or csc)
+        elif fg_hook is not None or csc:
+            raise DrnError("a trainable backbone / the CSC head cannot use a prefetched pooled operand")
         else:
             self._mark_current(pooled)  # a prefetched set is consumed by this forward
         dev, dtype = pooled["A"].device, pooled["A"].dtype
@@ -557,6 +558,9 @@ class _HeadEngine:
         col = {n: c for n, _, c, _ in self.cols}
         if not training:
             return w, col
+        if csc:
+            return self._forward_csc(w, col, M, dtype, rois, objectness, feat_nhwc, pooled, gt, img_off, n_img, masks,
+                                     drop_p, fg_hook)
         # ---- losses (fused with their dlogits) ----
         dl = w["dlogits"]
         scores, img_scores, loss_part = ops.wsddn_fwd_bwd(w["logits"], col["cls"], col["det"], K, img_off, n_img,
@@ -625,6 +629,53 @@ class _HeadEngine:
         outs = _TrainFn.apply(self.anchor, self, state)
         return dict(zip(loss_names, outs)), state
 
+    # ---- CSCROIHeads -----------------------------------------------------------------------------------
+    def _forward_csc(self, w, col, M, dtype, rois, objectness, feat_nhwc, pooled, gt, img_off, n_img, masks, drop_p,
+                     fg_hook):
+        """roi_heads_csc.py:301-352 (training branch): MIL scores, the CSC weights (image-gradient maps through
+        input_gradient(), csc.hip), the two weighted image-level losses fused with their dlogits."""
+        h = self.h
+        K = h.num_classes
+        if n_img != 1:
+            raise DrnError("CSCROIHeads works on ONE image per step (roi_heads_csc.py:433,442 read image_sizes[0] / "
+                           "gt_classes_img_oh[0])")
+        scores, img_scores, _, rowsm = ops.wsddn_fwd_bwd(w["logits"], col["cls"], col["det"], K, img_off, 1, gt["onehot"],
+                                                         dlogits=None, mean_loss=h.box_predictor.mean_loss,
+                                                         max_rows=gt["max_rows"], return_rowsm=True)
+        fg = dict(rois=rois, obj=objectness, feat_shape=tuple(feat_nhwc.shape), argmax=pooled.get("argmax"))
+        W, cpgs = h._csc_weights(self, w, col, scores, rowsm, M, dtype, fg, masks, drop_p)
+        loss = ops.csc_loss(w["logits"], col["cls"], col["det"], K, scores, rowsm, W, gt["onehot"].view(-1),
+                            h.box_predictor.mean_loss, dlogits=w["dlogits"])
+        state = dict(w=w, M=M, dtype=dtype, loss_list=[loss[0].view(()), loss[1].view(())],
+                     head_cols=[("cls", 0), ("det", 0)], masks=masks, drop_p=drop_p, csc=True,
+                     aux=dict(scores=scores, img_scores=img_scores, targets=[], W=W, cpgs=cpgs))
+        if fg_hook is not None:
+            state["fg"] = dict(fg, hook=fg_hook)
+        outs = _TrainFn.apply(self.anchor, self, state)
+        return dict(zip(["loss_cls_pos", "loss_cls_neg"], outs)), state
+
+    def input_gradient(self, w, M, dtype, fg, masks, drop_p, refresh_w1t=True):
+        """gradient of the feature map for the logits gradient sitting in w["dlogits"]: the d/dx half of backward()
+        alone (predictor -> fc7 -> fc6 -> RoIPool / ROIAlign with the objectness scaling); no weight or bias gradient
+        is written, nothing the training backward needs is overwritten except the scratch it rewrites itself."""
+        h = self.h
+        sh = self.sh
+        fc1, fc2 = h.box_head.fc1, h.box_head.fc2
+        D1, K1 = fc1.weight.shape
+        D2 = fc2.weight.shape[0]
+        NH = self.NH
+        kp = lambda k: ops.kpad(k, dtype)
+        dev = self.arena_w.device
+        ops.bias_act_bwd(w["dlogits"], M, NH, dpre=w["dS"])
+        ops.gemm_nt(w["dS"], sh["WhT"], M, D2, kp(NH), out=w["dH2"].view(1, M, D2))
+        ops.bias_act_bwd(w["dH2"], M, D2, saved=w["H2"], mask=masks[1] if masks else None, drop_p=drop_p, dpre=w["dP2"])
+        s1 = w["dH1"].shape[0]
+        ops.gemm_nt(w["dP2"], sh["W2T"], M, D1, kp(D2), out=w["dH1"], splits=s1)
+        if "dP1" not in w or w["dP1"].shape != w["H1"].shape:
+            w["dP1"] = torch.zeros_like(w["H1"])
+        ops.bias_act_bwd(w["dH1"], M, D1, saved=w["H1"], mask=masks[0] if masks else None, drop_p=drop_p, dpre=w["dP1"])
+        return self._feature_gradient(w, fg, M, D1, K1, dtype, refresh_w1t)
+
     # ---- backward ------------------------------------------------------------------------------------
     def backward(self, st, gouts):
         h = self.h
@@ -645,6 +696,10 @@ class _HeadEngine:
             colscale = self._unit_scale
         else:
             g = [torch.zeros((), device=dev) if x is None else x.float().reshape(()) for x in gouts]
+            if st.get("csc") and not (gouts[0] is not None and gouts[1] is not None and torch.equal(g[0], g[1])):
+                # both CSC losses act on the same cls / det columns and their dlogits were written as one sum
+                raise DrnError("loss_cls_pos and loss_cls_neg must be back-propagated with one common weight (the "
+                               "reference trainer sums the loss dict)")
             colscale = torch.stack(g)  # one entry per loss; columns find theirs through the static index table
         key = tuple(st["head_cols"])
         if getattr(self, "_colidx_key", None) != key:
@@ -700,9 +755,9 @@ class _HeadEngine:
         if fg is not None:
             self._feature_backward(w, fg, M, D1, K1, dtype, acc)
 
-    def _feature_backward(self, w, fg, M, D1, K1, dtype, acc):
-        """MODEL.BACKBONE.FREEZE_AT < 5: fc6 dX = dP1 . W1 (NT GEMM on a K-major copy of W1), RoIPool / ROIAlign backward
-        (with the objectness scaling) -> gradient of the feature map, handed to the backbone's explicit backward."""
+    def _feature_gradient(self, w, fg, M, D1, K1, dtype, refresh_w1t=True):
+        """MODEL.BACKBONE.FREEZE_AT < 5 (and the CSC image-gradient passes): fc6 dX = dP1 . W1 (NT GEMM on a K-major copy
+        of W1), RoIPool / ROIAlign backward (with the objectness scaling) -> gradient of the feature map."""
         h = self.h
         kp = lambda k: ops.kpad(k, dtype)
         fc1 = h.box_head.fc1
@@ -712,10 +767,14 @@ class _HeadEngine:
             self._w1t_key = (dtype, K1, D1)
         if self._dA.shape[1] != M:
             self._dA = torch.zeros((1, M, kp(K1)), dtype=dtype, device=self.arena_w.device)
-        ops.transpose2d(fc1.weight.data, D1, K1, out=self._w1t)
+        if refresh_w1t:  # the K-major copy of W1 (several CSC passes of one step share it)
+            ops.transpose2d(fc1.weight.data, D1, K1, out=self._w1t)
         ops.gemm_nt(w["dP1"], self._w1t, M, K1, kp(D1), out=self._dA[:, :, :K1])
         ka = h.box_pooler.kernel_args()
-        dfeat = ops.roi_pool_backward_nhwc(self._dA[0], fg["rois"], fg["obj"], fg["feat_shape"], argmax=fg["argmax"], **ka)
+        return ops.roi_pool_backward_nhwc(self._dA[0], fg["rois"], fg["obj"], fg["feat_shape"], argmax=fg["argmax"], **ka)
+
+    def _feature_backward(self, w, fg, M, D1, K1, dtype, acc):
+        dfeat = self._feature_gradient(w, fg, M, D1, K1, dtype)
         fg["hook"](dfeat, acc)
         hook = getattr(self, "grad_ready_hook", None)
         if hook is not None:
@@ -987,6 +1046,66 @@ class WSDDNROIHeads(OICRROIHeads):
     (WSDDNOutputLayers.inference, fast_rcnn.py:587-608)."""
 
     _refine_from_cfg = False
+
+
+@ROI_HEADS_REGISTRY.register()
+class CSCROIHeads(OICRROIHeads):
+    """roi_heads_csc.py:40-551: the WSDDN MIL head trained with two image-level BCE losses on CSC-weighted score sums.
+    Per labelled class whose image score reaches `tau`, the gradient of the summed class score w.r.t. the (normalised)
+    input image gives a saliency map (`_forward_cpg`: here the d/dx half of the explicit backward through the predictor,
+    fc7, fc6, RoIPool and EVERY trunk layer down to the pixels); the map, thresholded and summed into a table, scores
+    each proposal by its frame / context contrast (CSCPool) and becomes the signed weight W (csc.hip).  After
+    WSL.CSC_MAX_ITER iterations W_pos = 1, W_neg = 0.  Inference is WSDDN's.  Debug dumps (`_save_mask`) and the
+    `Statistic` log writer are the reference's control plane and are not rebuilt."""
+
+    _refine_from_cfg = False
+    csc_head = True
+
+    @configurable
+    def __init__(self, *, csc_max_iter=35000, **kwargs):
+        super().__init__(**kwargs)
+        self.csc_max_iter = csc_max_iter
+        self.tau, self.fg_threshold, self.bg_threshold = 0.7, 0.1, 0.005  # roi_heads_csc.py:107-109
+        self.context_scale, self.area_sqrt = 1.8, True  # :110-118 (mass / density thresholds are unused by the op)
+        self.image_grad_fn = None  # set by GeneralizedRCNNWSL: feature-map gradient -> image gradient (NHWC)
+
+    @classmethod
+    def from_config(cls, cfg, input_shape):
+        ret = super().from_config(cfg, input_shape)
+        ret["csc_max_iter"] = cfg.WSL.CSC_MAX_ITER
+        return ret
+
+    def prefetch_pooled(self, features, proposals):
+        raise DrnError("the CSC head differentiates through RoIPool and the trunk: no prefetched operands")
+
+    def _csc_weights(self, eng, w, col, scores, rowsm, M, dtype, fg, masks, drop_p):
+        """roi_heads_csc.py:423-510 (_forward_cpg + _forward_csc). Returns (W [M, K] or None past CSC_MAX_ITER, cpgs)."""
+        K = self.num_classes
+        if self.iter > self.csc_max_iter:
+            return None, None
+        if self.image_grad_fn is None:
+            raise DrnError("CSCROIHeads needs the meta-architecture's image-gradient pass (GeneralizedRCNNWSL with cpg)")
+        H, Wd = self.images.image_sizes[0]
+        if tuple(self.images.nhwc.shape[1:3]) != (H, Wd):
+            raise DrnError("CSC maps are image-sized: the padded batch tensor must equal the image (one image per step)")
+        dev = scores.device
+        labelled = [int(c) for c in self.gt_classes_img_int[0].tolist()]
+        # the reference branches on the image score per class on the host too (roi_heads_csc.py:445): one read of K floats
+        img = scores.sum(dim=0).tolist()
+        cpgs = torch.zeros((K, H, Wd), dtype=torch.float32, device=dev)
+        W = torch.ones((M, K), dtype=torch.float32, device=dev)
+        table = torch.empty((H, Wd), dtype=torch.float32, device=dev)
+        first = True
+        for c in labelled:
+            if img[c] >= self.tau:
+                ops.csc_loss(w["logits"], col["cls"], col["det"], K, scores, rowsm, None, None,
+                             self.box_predictor.mean_loss, dlogits=w["dlogits"], seed_class=c)
+                dfeat = eng.input_gradient(w, M, dtype, fg, masks, drop_p, refresh_w1t=first)
+                first = False
+                ops.csc_cpg(self.image_grad_fn(dfeat), 3, out=cpgs[c])
+            # (a labelled class below tau keeps a zero map and still goes through the op, as in the reference)
+            ops.csc_weights(cpgs[c], self.fg_threshold, fg["rois"], scores, c, self.area_sqrt, self.context_scale, W, table)
+        return W, cpgs
 
 
 def build_roi_heads(cfg, input_shape):

@@ -248,7 +248,7 @@ def colsum_reduce(colpart, nparts, N, colsum, accumulate=False):
 
 
 def wsddn_fwd_bwd(logits, c_cls, c_det, K, img_off, n_img, gt_onehot, dlogits=None, mean_loss=True, loss_scale=1.0,
-                  max_rows=None):
+                  max_rows=None, return_rowsm=False):
     M = logits.shape[0]
     max_rows = max_rows or M
     dev = logits.device
@@ -261,7 +261,43 @@ def wsddn_fwd_bwd(logits, c_cls, c_det, K, img_off, n_img, gt_onehot, dlogits=No
            C.ptr(scores), C.ptr(rowsm), C.ptr(img_scores), C.ptr(loss_part), C.ptr(dlogits),
            _2d(dlogits) if dlogits is not None else 0, C.ptr(scratch), int(max_rows), int(mean_loss), float(loss_scale),
            C.stream())
+    if return_rowsm:
+        return scores, img_scores, loss_part, rowsm
     return scores, img_scores, loss_part
+
+
+def csc_cpg(dimg_nhwc, n_colours, out=None):
+    """drn_csc_cpg: d score / d image [1, H, W, Cpad] -> the normalised map [H, W] fp32 (roi_heads_csc.py:456-464)"""
+    n, H, W, cp = dimg_nhwc.shape
+    assert n == 1 and dimg_nhwc.is_contiguous()
+    if out is None:
+        out = torch.empty((H, W), dtype=torch.float32, device=dimg_nhwc.device)
+    scratch = torch.empty((1,), dtype=torch.int32, device=dimg_nhwc.device)
+    C.call("drn_csc_cpg", C.ptr(dimg_nhwc), C.dt(dimg_nhwc.dtype), cp, n_colours, H, W, C.ptr(out), C.ptr(scratch), C.stream())
+    return out
+
+
+def csc_weights(cpg, fg_threshold, rois5, scores, c, area_sqrt, context_scale, W_out, table=None):
+    """drn_csc_weights: column c of the CSC weights W_out [M, K] from one class map (csc_cuda.cu:398-535)"""
+    H, Wd = cpg.shape
+    M, K = scores.shape
+    assert cpg.is_contiguous() and rois5.is_contiguous() and scores.is_contiguous() and W_out.is_contiguous()
+    if table is None:
+        table = torch.empty((H, Wd), dtype=torch.float32, device=cpg.device)
+    C.call("drn_csc_weights", C.ptr(cpg), H, Wd, float(fg_threshold), C.ptr(rois5), M, C.ptr(scores), K, int(c),
+           int(area_sqrt), float(context_scale), C.ptr(table), C.ptr(W_out), C.stream())
+    return W_out
+
+
+def csc_loss(logits, c_cls, c_det, K, scores, rowsm, W, onehot, mean_loss, dlogits=None, seed_class=None):
+    """drn_csc_loss.  seed_class None: the two CSC losses [2] (+ their dlogits); else d (sum_r s[r, seed_class]) / d logits"""
+    M = scores.shape[0]
+    mode = 0 if seed_class is None else 1
+    loss = torch.empty((2,), dtype=torch.float32, device=scores.device) if mode == 0 else None
+    C.call("drn_csc_loss", C.ptr(logits), _2d(logits), c_cls, c_det, K, M, C.ptr(scores), C.ptr(rowsm), C.ptr(W),
+           C.ptr(onehot), mode, int(seed_class or 0), int(mean_loss), C.ptr(loss), C.ptr(dlogits),
+           _2d(dlogits) if dlogits is not None else 0, C.stream())
+    return loss
 
 
 def oicr_targets(prev_scores, prev_boxes, props, img_off, n_img, gt_classes, gt_count, img_scores, K,

@@ -295,6 +295,34 @@ int drn_pcl_refine(const float* logits, int ld, const int* cols, int n_branch, i
                    float* img_w, int* pc_rows, float* pc_scores, int* n_pc, int pmax, float* losses, float* dlogits,
                    void* stream);
 
+/* ---- CSC head (CSCROIHeads) -------------------------------------------------------------------------
+ * projects/WSL/wsl/modeling/roi_heads/roi_heads_csc.py:423-510 and wsl/layers/csrc/csc/csc_cuda.cu.  One image per
+ * call (the reference head reads image_sizes[0] / gt_classes_img_oh[0]); K <= 128.
+ *
+ * drn_csc_cpg: the per-class map of `_forward_cpg` (roi_heads_csc.py:456-464) from d (sum_r score[r, c]) / d image
+ * (NHWC, `cpad` stored channels, the first C are colours; dtype DRN_F32 / DRN_BF16): |.|, max over the C channels,
+ * divided by the maximum of the map -> cpg [H*W] fp32.  scratch: 4 bytes. */
+int drn_csc_cpg(const void* dimg, int dtype, int cpad, int C, int H, int W, float* cpg, void* scratch, void* stream);
+
+/* drn_csc_weights: `csc_forward_cuda` for ONE labelled class c (csc_cuda.cu:398-535): cpg >= fg_threshold ->
+ * summed-area table (binary_and_integral_cpu :132-161; exact integer counts, H*W < 2^24) -> CSCPool (:184-350) per ROI
+ * (rois [M][5] = batch index + box in image coordinates) -> max / min normalisation to [-1, 1] -> blend with the
+ * image-level prediction sum_r scores[r][c] -> W[:, c] of W [M][K].  table: H*W floats of scratch.  The reference does
+ * the table, the normalisation and the blend on the host; this stays on the stream. */
+int drn_csc_weights(const float* cpg, int H, int W, float fg_threshold, const float* rois, int M, const float* scores,
+                    int K, int c, int area_sqrt, float context_scale, float* table, float* Wout, void* stream);
+
+/* drn_csc_loss: CSCOutputs.csc_loss (fast_rcnn.py:887-931) on the WSDDN scores (scores / row_softmax [M][K] as written
+ * by drn_wsddn_fwd_bwd, logits as given to it).
+ * mode 0: loss[0] = loss_cls_pos = BCE(clamp(sum_r s * max(W, 0)), onehot), loss[1] = loss_cls_neg =
+ *         BCE(clamp(sum_r s * max(-W, 0)), 0) (W NULL = ones: past WSL.CSC_MAX_ITER) and, when dlogits != NULL, the
+ *         cls / det columns of dlogits [M][ld_d] = d (loss[0] + loss[1]) / d logits.
+ * mode 1: dlogits = d (sum_r scores[r][cstar]) / d logits - the seed of the image-gradient pass
+ *         (roi_heads_csc.py:441-455, grad_outputs[:, c] = 1). */
+int drn_csc_loss(const float* logits, long ld, int c_cls, int c_det, int K, int M, const float* scores,
+                 const float* row_softmax, const float* W, const float* onehot, int mode, int cstar, int mean_loss,
+                 float* loss, float* dlogits, long ld_d, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

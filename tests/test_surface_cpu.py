@@ -115,9 +115,14 @@ def test_off_path_fails_loudly(pkg):
 
     ocfg = G.MODEL_CASES["model_r50c4_tiny"]
     cfg = G.drn_cfg(ocfg, "cpu")
-    cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "CSCROIHeads"])  # sibling head that is not built
-    with pytest.raises(KeyError):
+    cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "CSCOICRROIHeads"])  # named by csc_oicr_V_16_DC5_1x.yaml, absent from the
+    with pytest.raises(KeyError):                                     # reference's own wsl/modeling/roi_heads too
         build_model(cfg)
+    cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "CSCROIHeads", "WSL.REFINE_NUM", "0"])  # built
+    m = build_model(cfg)
+    assert type(m.roi_heads).__name__ == "CSCROIHeads" and m.cpg and m.backbone.input_grad
+    assert m.roi_heads.image_grad_fn == m.backbone.input_gradient_nhwc and m.roi_heads.refine_K == 0
+    cfg.merge_from_list(["WSL.REFINE_NUM", str(ocfg.refine_num)])
     cfg.merge_from_list(["MODEL.ROI_HEADS.NAME", "PCLROIHeads"])  # built: same module tree as OICR
     m = build_model(cfg)
     assert type(m.roi_heads).__name__ == "PCLROIHeads" and m.roi_heads.refine_mode == "pcl"
