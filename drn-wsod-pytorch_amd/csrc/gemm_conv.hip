@@ -802,12 +802,86 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
   mainloop<DT, BM, BN, decltype(la), decltype(lb), (BM == 64 && BN == 64) ? 1 : 2>(acc, smem, la, lb, 0, nslab);
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int wm = wave >> 1, wn = wave & 1;
+  // bf16 output (+ bf16 residual): the affine result goes through LDS as fp32 [BM][BN] (exactly the mainloop's LDS, now
+  // free) so that every lane then owns 8 consecutive channels of a pixel - 16-byte residual loads and 16-byte stores,
+  // whole 128/256-byte row segments per instruction.  The MFMA layout gives a lane ONE channel of 16 * MI pixels: written
+  // straight from the accumulators that is 2-byte accesses, which ran the write-heavy 1x1 convs of large maps at
+  // ~1 TB/s (res2 conv3 at 200 x 304: 72 us for 70 MB; tools/conv_bench.py).  Same arithmetic, same rounding.
+  const bool vec_epi = p.out_dt == DRN_BF16 && (!p.residual || p.res_dt == DRN_BF16) && (p.Cout & 7) == 0 &&
+                       (p.ldy & 7) == 0 && (((uintptr_t)p.Y) & 15) == 0 &&
+                       (!p.residual || ((p.ldres & 7) == 0 && (((uintptr_t)p.residual) & 15) == 0));
+  if (vec_epi) {
+    float* tile = (float*)smem;
+    __syncthreads();  // the last slab's LDS reads are done
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+      const int nl = wn * (BN / 2) + j * 32 + (lane & 31), n = bn + nl;
+      const float sc = (n < p.Cout && p.scale) ? p.scale[n] : 1.f;
+      const float bi = (n < p.Cout && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int ml = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          tile[ml * BN + nl] = acc[i][j][r] * sc + bi;
+        }
+    }
+    __syncthreads();
+    constexpr int LPR = BN / 8, RPP = 256 / LPR, NR = BM / RPP;  // lanes per row, rows per pass, rows per lane
+    const int cl = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    const int n = bn + cl * 8;
+    if (n >= p.Cout) return;
+    i32x4_t rv[NR];
+    if (p.residual) {
+#pragma unroll
+      for (int q = 0; q < NR; ++q) {
+        const int m = bm + rl + q * RPP;
+        rv[q] = *(const i32x4_t*)((const bf16_t*)p.residual + (long)(m < Mtot ? m : Mtot - 1) * p.ldres + n);
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+      const int ml = rl + q * RPP, m = bm + ml;
+      if (m >= Mtot) break;
+      const f32x4_t lo = *(const f32x4_t*)(tile + ml * BN + cl * 8), hi = *(const f32x4_t*)(tile + ml * BN + cl * 8 + 4);
+      float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+      i32x4_t o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        if (p.residual) {
+          const uint32_t w = (uint32_t)rv[q][e];
+          v[2 * e] += __builtin_bit_cast(float, w << 16) * p.res_mult;
+          v[2 * e + 1] += __builtin_bit_cast(float, w & 0xffff0000u) * p.res_mult;
+        }
+        if (p.relu) { v[2 * e] = fmaxf(v[2 * e], 0.f); v[2 * e + 1] = fmaxf(v[2 * e + 1], 0.f); }
+        o[e] = (int)((uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16));
+      }
+      *(i32x4_t*)((bf16_t*)p.Y + (long)m * p.ldy + n) = o;
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int n = bn + wn * (BN / 2) + j * 32 + (lane & 31);
     if (n >= p.Cout) continue;
     const float sc = p.scale ? p.scale[n] : 1.f;
     const float bi = p.bias ? p.bias[n] : 0.f;
+    // every residual value of this lane's column is fetched BEFORE the first store: Y and the residual may alias as far
+    // as the compiler knows, so a load placed behind a store stays there and each of the 16 * MI row steps would pay a
+    // full memory latency (measured: 36 us for the K = 256 res4 conv3 at 50 x 76, most of it here)
+    float rres[MI][16];
+    if (p.residual) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int m = bm + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+          const long ri = (long)(m < Mtot ? m : Mtot - 1) * p.ldres + n;
+          rres[i][r] = p.res_dt == DRN_BF16 ? bf16_to_f32(((const bf16_t*)p.residual)[ri])
+                       : p.res_dt == DRN_FP8 ? fp8_to_f32(((const uint8_t*)p.residual)[ri])
+                                             : ((const float*)p.residual)[ri];
+        }
+    }
 #pragma unroll
     for (int i = 0; i < MI; ++i)
 #pragma unroll
@@ -815,13 +889,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
         const int m = bm + wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
         if (m < Mtot) {
           float v = acc[i][j][r] * sc + bi;
-          if (p.residual) {
-            const long ri = (long)m * p.ldres + n;
-            const float rv = p.res_dt == DRN_BF16 ? bf16_to_f32(((const bf16_t*)p.residual)[ri])
-                             : p.res_dt == DRN_FP8 ? fp8_to_f32(((const uint8_t*)p.residual)[ri])
-                                                   : ((const float*)p.residual)[ri];
-            v += rv * p.res_mult;
-          }
+          if (p.residual) v += rres[i][r] * p.res_mult;
           if (p.relu) v = fmaxf(v, 0.f);
           const long yi = (long)m * p.ldy + n;
           if (p.out_dt == DRN_BF16) ((bf16_t*)p.Y)[yi] = f32_to_bf16(v);
