@@ -122,13 +122,21 @@ struct ConvLoader {
   int H, W, Cin, KW, dil, ntaps;
   int hi0[ROWS / 32], wi0[ROWS / 32];
   unsigned nbase[ROWS / 32];  // byte offset of image n, or OOB for rows beyond M
+  // (tap, channel) of this lane's 16-byte chunk in slab `at`: the mainloop asks for consecutive slabs, so the position is
+  // advanced by one slab (128 bytes of k) instead of being re-derived with two integer divisions per slab - ~80 VALU
+  // instructions that sat on the critical path of the latency-bound small-map layers
+  int at = -1, tap = 0, ci = 0, kh = 0, kw = 0;
+  __device__ __forceinline__ void seek(int slab, int tid) {
+    const int k = (slab * 128 + (tid & 7) * 16) / ES;
+    tap = k / Cin; ci = k - tap * Cin;
+    kh = tap / KW; kw = tap - kh * KW;
+    at = slab;
+  }
   template <int R>
-  __device__ __forceinline__ void load(i32x4_t (&r)[R / 32], int slab, int tid) const {
+  __device__ __forceinline__ void load(i32x4_t (&r)[R / 32], int slab, int tid) {
     static_assert(R == ROWS, "tile rows");
-    const int slot = tid & 7;
-    const int k = (slab * 128 + slot * 16) / ES;
-    const int tap = k / Cin, ci = k - tap * Cin;
-    const int kh = tap / KW, kw = tap - kh * KW;
+    if (slab != at) seek(slab, tid);
+    else if (Cin * ES < 128) seek(slab, tid);  // several taps per slab (the 3-channel stem): no single-step advance
 #pragma unroll
     for (int p = 0; p < ROWS / 32; ++p) {
       const int hi = hi0[p] + kh * dil, wi = wi0[p] + kw * dil;
@@ -136,6 +144,13 @@ struct ConvLoader {
       const unsigned off = ok ? nbase[p] + (unsigned)(((hi * W + wi) * Cin + ci) * ES) : OOB;
       r[p] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     }
+    ci += 128 / ES;  // next slab (exact when Cin * ES >= 128: at most one tap boundary per slab; otherwise re-sought)
+    if (ci >= Cin) {
+      ci -= Cin;
+      ++tap;
+      if (++kw == KW) { kw = 0; ++kh; }
+    }
+    at = slab + 1;
   }
 };
 
@@ -149,12 +164,15 @@ struct ConvLoader {
 // 2 x 200 VGPRs per SIMD) only with < 32 KB of LDS and <= 112 registers per wave; the two-stage version is exactly 32 KB
 // and 120 registers, so every conv launch of the frozen trunk used to wait for a GEMM workgroup to retire (a chain of ten
 // res4 convs beside the fc6 GEMM: 475 us instead of 190).
+#ifndef CONV_DEPTH1
+#define CONV_DEPTH1 4  // register-ring depth of the single-LDS-stage 64x64 conv (98 VGPRs; 5 -> 114 > the 112 that co-reside with a GEMM workgroup)
+#endif
 template <int DT, int BM, int BN, class ALoader, class BLoader, int STAGES = 2>
-__device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char* smem, const ALoader& la,
+__device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char* smem, ALoader& la,
                                          const BLoader& lb, int s0, int s1) {
   constexpr int MI = BM / 64, NJ = BN / 64;
   constexpr int A_BYTES = BM * 128, STAGE = STAGES == 2 ? (BM + BN) * 128 : 0;
-  constexpr int DEPTH = STAGES == 1 ? 3 : (BM <= 64 ? 4 : 3);
+  constexpr int DEPTH = STAGES == 1 ? CONV_DEPTH1 : (BM <= 64 ? 4 : 3);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   i32x4_t ra[DEPTH][BM / 32], rb[DEPTH][BN / 32];
@@ -900,6 +918,136 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
   }
 }
 
+// Small-map convolution: 32 x 32 output tile per workgroup, the K range of every 128-byte slab split over the FOUR WAVES
+// (wave w multiplies k-step w: one MFMA and two LDS fragment reads per wave and slab), their accumulators added in wave
+// order through LDS at the end.  For the res3 / res4 layers of a 224 x 224 image (196 .. 784 pixels) the 64 x 64 kernel
+// runs on 16 .. 26 workgroups and its per-slab chain - 8 fragment reads, 4 dependent MFMAs, two barriers - costs ~0.55 us
+// whatever the prefetch depth (measured: ring depth 3 / 4 / 5 and division-free addressing all within 5 %), so a 36-slab
+// 3 x 3 conv took 23 us on 196 pixels.  Here the chain per slab is a quarter of that and there are 4x the workgroups.
+// (Splitting K over workgroups instead - partial tiles in HBM, last arriver reduces - was built and measured slower
+// than no split: the cross-XCD coherence of the partials costs more than the split saves)
+template <int DT>
+__global__ __launch_bounds__(256) void conv_nhwc_ks_kernel(ConvParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[4 * 32 * 32 * 4];  // one 8-KB operand stage, then 4 partial tiles
+  constexpr int ES = EsOf<DT>::value;
+  constexpr int DEPTH = 4;
+  const int Mtot = p.Nb * p.Ho * p.Wo;
+  const int tiles_m = (Mtot + 31) / 32, tiles_n = (p.Cout + 31) / 32;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+  const int bm = tm * 32, bn = tn * 32;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ConvLoader<DT, 32> la;
+  la.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((long)p.Nb * p.H * p.W * p.Cin * ES), 0x00020000);
+  la.H = p.H; la.W = p.W; la.Cin = p.Cin; la.KW = p.KW; la.dil = p.dil; la.ntaps = p.KH * p.KW;
+  {
+    const int m = bm + (tid >> 3);
+    if (m < Mtot) {
+      const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      la.hi0[0] = ho * p.stride - p.pad;
+      la.wi0[0] = wo * p.stride - p.pad;
+      la.nbase[0] = (unsigned)((long)n * p.H * p.W * p.Cin * ES);
+    } else {
+      la.hi0[0] = 0; la.wi0[0] = 0; la.nbase[0] = ConvLoader<DT, 32>::OOB;
+    }
+  }
+  const RowLoader lb = make_row_loader(p.Wt, bn, p.Cout, 32, p.ldw * ES);
+  f32x16_t acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int n = (p.Ktot * ES + 127) / 128;
+  i32x4_t ra[DEPTH][1], rb[DEPTH][1];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d)
+    if (d < n) {
+      la.template load<32>(ra[d], d, tid);
+      lb.template load<32>(rb[d], d, tid);
+    }
+  lds_store_tile<32>(smem, ra[0], tid);
+  lds_store_tile<32>(smem + 32 * 128, rb[0], tid);
+  __syncthreads();
+  const int slot = wave * 2 + (lane >> 5);
+  for (int base = 0; base < n; base += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      const int i = base + d;
+      if (i < n) {
+        if (i + DEPTH < n) {
+          la.template load<32>(ra[d], i + DEPTH, tid);
+          lb.template load<32>(rb[d], i + DEPTH, tid);
+        }
+        const i32x4_t fa = *(const i32x4_t*)(smem + swz(lane & 31, slot));
+        const i32x4_t fb = *(const i32x4_t*)(smem + 32 * 128 + swz(lane & 31, slot));
+        mma_step<DT>(acc, fa, fb);
+        __syncthreads();
+        if (i + 1 < n) {
+          lds_store_tile<32>(smem, ra[(d + 1) % DEPTH], tid);
+          lds_store_tile<32>(smem + 32 * 128, rb[(d + 1) % DEPTH], tid);
+        }
+        __syncthreads();
+      }
+    }
+  }
+  // the four k-step partials, as [wave][row][col] fp32
+  float* part = (float*)smem;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int ml = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+    part[(wave * 32 + ml) * 32 + (lane & 31)] = acc[r];
+  }
+  __syncthreads();
+  const bool vec_epi = p.out_dt == DRN_BF16 && (!p.residual || p.res_dt == DRN_BF16) && (p.Cout & 7) == 0 &&
+                       (p.ldy & 7) == 0 && (((uintptr_t)p.Y) & 15) == 0 &&
+                       (!p.residual || ((p.ldres & 7) == 0 && (((uintptr_t)p.residual) & 15) == 0));
+  if (vec_epi) {  // 128 lanes: one pixel row x 8 channels each (see conv_nhwc_kernel)
+    if (tid >= 128) return;
+    const int ml = tid >> 2, cg = tid & 3, m = bm + ml, nn = bn + cg * 8;
+    if (m >= Mtot || nn >= p.Cout) return;
+    i32x4_t rv = {0, 0, 0, 0};
+    if (p.residual) rv = *(const i32x4_t*)((const bf16_t*)p.residual + (long)m * p.ldres + nn);
+    float v[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int o = ml * 32 + cg * 8 + e;
+      const float sum = ((part[o] + part[1024 + o]) + part[2048 + o]) + part[3072 + o];
+      v[e] = sum * (p.scale ? p.scale[nn + e] : 1.f) + (p.bias ? p.bias[nn + e] : 0.f);
+    }
+    i32x4_t o4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      if (p.residual) {
+        const uint32_t w = (uint32_t)rv[e];
+        v[2 * e] += __builtin_bit_cast(float, w << 16) * p.res_mult;
+        v[2 * e + 1] += __builtin_bit_cast(float, w & 0xffff0000u) * p.res_mult;
+      }
+      if (p.relu) { v[2 * e] = fmaxf(v[2 * e], 0.f); v[2 * e + 1] = fmaxf(v[2 * e + 1], 0.f); }
+      o4[e] = (int)((uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16));
+    }
+    *(i32x4_t*)((bf16_t*)p.Y + (long)m * p.ldy + nn) = o4;
+    return;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int o = tid + 256 * q, ml = o >> 5, nl = o & 31, m = bm + ml, nn = bn + nl;
+    if (m >= Mtot || nn >= p.Cout) continue;
+    const float sum = ((part[o] + part[1024 + o]) + part[2048 + o]) + part[3072 + o];
+    float v = sum * (p.scale ? p.scale[nn] : 1.f) + (p.bias ? p.bias[nn] : 0.f);
+    if (p.residual) {
+      const long ri = (long)m * p.ldres + nn;
+      const float rres = p.res_dt == DRN_BF16 ? bf16_to_f32(((const bf16_t*)p.residual)[ri])
+                         : p.res_dt == DRN_FP8 ? fp8_to_f32(((const uint8_t*)p.residual)[ri])
+                                               : ((const float*)p.residual)[ri];
+      v += rres * p.res_mult;
+    }
+    if (p.relu) v = fmaxf(v, 0.f);
+    const long yi = (long)m * p.ldy + nn;
+    if (p.out_dt == DRN_BF16) ((bf16_t*)p.Y)[yi] = f32_to_bf16(v);
+    else if (p.out_dt == DRN_FP8) ((uint8_t*)p.Y)[yi] = f32_to_fp8(v);
+    else ((float*)p.Y)[yi] = v;
+  }
+}
+
 template <int DT, int BM, int BN>
 int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   const int tiles = ((p.M + BM - 1) / BM) * ((p.N + BN - 1) / BN);
@@ -911,7 +1059,7 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
       return DRN_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(256), smem, st, p);
+  hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, st, p);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }
@@ -979,6 +1127,17 @@ static int persistent_grid(long total) {
   return (nwg >= 8 && total > nwg) ? nwg : 0;
 }
 
+static int g_conv_ksplit = 1;  // drn_tune(DRN_TUNE_CONV_KSPLIT): 0 = never use the 32x32 wave-K-split kernel
+
+template <int DT>
+int launch_conv_ks(const ConvParams& p, hipStream_t st) {
+  const int Mtot = p.Nb * p.Ho * p.Wo;
+  const int tiles = ((Mtot + 31) / 32) * ((p.Cout + 31) / 32);
+  hipLaunchKernelGGL((conv_nhwc_ks_kernel<DT>), dim3(tiles), dim3(256), 0, st, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
 template <int DT, int BM, int BN>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
@@ -1020,6 +1179,11 @@ int drn_tune(int knob, int value) {
   }
   if (knob == 2) return drn_sgd_set_grid(value);  // DRN_TUNE_SGD_GRID
   if (knob == 4) return drn_roi_set_map64(value);  // DRN_TUNE_ROI_MAP64
+  if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
+    const int old = g_conv_ksplit;
+    g_conv_ksplit = value != 0;
+    return old;
+  }
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
     const int old = g_group_rows;
     if (value >= 0 && value <= 64) g_group_rows = value;
@@ -1110,6 +1274,12 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   const bool small = ((Mtot + 127) / 128) * ((Cout + 127) / 128) < 128;
   // narrow outputs (the 64-channel stem / res2 layers at real image sizes): a 128x128 tile would run half empty
   const bool narrow = !small && Cout <= 64;
+  // few 64x64 tiles and a long K loop: latency-bound, see conv_nhwc_ks_kernel
+  const int nslab = (Ktot * es + 127) / 128;
+  const long tiles64 = ((Mtot + 63) / 64) * ((Cout + 63) / 64);
+  if (g_conv_ksplit && small && tiles64 <= cu_count() / 4 && nslab >= 8)
+    return dtype == DRN_BF16 ? launch_conv_ks<DRN_BF16>(p, st)
+           : dtype == DRN_FP8 ? launch_conv_ks<DRN_FP8>(p, st) : launch_conv_ks<DRN_F32>(p, st);
   if (dtype == DRN_BF16)
     return small ? launch_conv<DRN_BF16, 64, 64>(p, st)
                  : narrow ? launch_conv<DRN_BF16, 128, 64>(p, st) : launch_conv<DRN_BF16, 128, 128>(p, st);

@@ -143,6 +143,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_GEMM_PERSISTENT 1
 #define DRN_TUNE_SGD_GRID 2
 #define DRN_TUNE_GEMM_GROUP_ROWS 3
+#define DRN_TUNE_CONV_KSPLIT 5 /* 0/1: 32x32 wave-K-split conv kernel for latency-bound small-map layers (default 1) */
 #define DRN_TUNE_ROI_MAP64 4 /* 64-ROI x 8-channel whole-map ROIPool for the bf16 (A, A^T) pair: 0 = off, else threads per workgroup (256 / 512 / 1024, default 512) */
 int drn_tune(int knob, int value);
 

@@ -216,6 +216,49 @@ def test_conv2d_nhwc(drn, dtype, case):
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("case", [(1, 14, 14, 256, 256, 3, 1, 1, 1, True, True),     # res4 3x3 on 196 pixels (36 slabs)
+                                  (1, 14, 14, 1024, 256, 1, 1, 0, 1, False, True),   # res4 conv1 (16 slabs)
+                                  (1, 28, 28, 128, 128, 3, 1, 1, 1, False, False),   # res3 3x3
+                                  (2, 13, 17, 72, 40, 3, 1, 2, 2, True, True),       # dilation, ragged Cout, two images
+                                  (1, 21, 19, 64, 24, 3, 2, 1, 1, True, False),      # stride 2, Cout < 32
+                                  (1, 9, 9, 512, 100, 1, 1, 0, 1, True, True)])      # Cout % 8 != 0: scalar epilogue
+def test_conv2d_wave_k_split(drn, dtype, case):
+    """conv_nhwc_ks_kernel (32x32 tile, the slab's four k-steps on four waves, fixed-order LDS reduction) serves the
+    latency-bound small-map layers: against F.conv2d and against the 64x64 kernel; run-to-run identical"""
+    n, h, w, cin, cout, k, stride, pad, dil, has_res, relu = case
+    x = _rnd((n, cin, h, w), 15)
+    wt = _rnd((cout, cin, k, k), 16, math.sqrt(2.0 / (cin * k * k)))
+    scale, bias = (0.8 + 0.2 * torch.rand(cout)).to(DEV), _rnd((cout,), 17, 0.1).to(DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    ref = F.conv2d(_q(x, dtype), _q(wt, dtype), None, stride, pad, dil) * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1)
+    res = None
+    if has_res:
+        res = _rnd(tuple(ref.shape), 18)
+        ref = ref + _q(res, dtype)
+        res = res.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    if relu:
+        ref = F.relu(ref)
+    wp = _pack_w(wt, dtype, drn, cin)
+    run = lambda: drn.conv2d_nhwc(xd, wp, cout, k, k, stride, pad, dil, scale, bias, res, relu)
+    assert drn.tune(drn.TUNE_CONV_KSPLIT, 0) == 1
+    try:
+        tiled = run()
+    finally:
+        drn.tune(drn.TUNE_CONV_KSPLIT, 1)
+    ys = [run() for _ in range(3)]
+    for y in ys[1:]:
+        assert torch.equal(y, ys[0])
+    got = ys[0].float().cpu().permute(0, 3, 1, 2)
+    if dtype == torch.float32:
+        assert torch.allclose(got, ref, rtol=1e-4, atol=1e-4), float((got - ref).abs().max())
+        assert torch.allclose(ys[0], tiled, rtol=1e-5, atol=1e-5)
+        assert not torch.equal(ys[0], tiled) or cin * k * k <= 128  # another kernel, another summation order
+    else:
+        assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
+        assert (ys[0].float() - tiled.float()).abs().max() <= 2 ** -7 * float(tiled.float().abs().max())
+
+
+@pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("stride,hw", [(2, (56, 56)), (1, (28, 28)), (2, (13, 9)), (1, (5, 7))])
 def test_maxpool(drn, dtype, stride, hw):
     x = _rnd((2, 16, hw[0], hw[1]), 9)
