@@ -75,6 +75,9 @@ def lib():
             fn.restype = ctypes.c_int
         _lib.drn_detect_workspace_bytes.argtypes = [ctypes.c_int]
         _lib.drn_detect_workspace_bytes.restype = ctypes.c_long
+        for kv in filter(None, os.environ.get("DRN_TUNE", "").split(",")):  # A/B runs: DRN_TUNE="5=0,4=1024" (drn_tune knobs)
+            k, v = kv.split("=")
+            _lib.drn_tune(int(k), int(v))
     return _lib
 
 

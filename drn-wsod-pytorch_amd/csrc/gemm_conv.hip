@@ -1059,7 +1059,7 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
       return DRN_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3(tiles), dim3(256), smem, st, p);
+  hipLaunchKernelGGL(k, dim3(tiles, splits), dim3(256), smem, st, p);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }
@@ -1276,8 +1276,10 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   const bool narrow = !small && Cout <= 64;
   // few 64x64 tiles and a long K loop: latency-bound, see conv_nhwc_ks_kernel
   const int nslab = (Ktot * es + 127) / 128;
-  const long tiles64 = ((Mtot + 63) / 64) * ((Cout + 63) / 64);
-  if (g_conv_ksplit && small && tiles64 <= cu_count() / 4 && nslab >= 8)
+  // (decided on ONE image's geometry: this kernel adds the K partials in another order than the tiled ones, and a layer
+  // must round the same way whether its image runs alone or in a batch - graphed trunk pairs vs eager, 2 ranks vs 1)
+  const long tiles64 = (((long)Ho * Wo + 63) / 64) * ((Cout + 63) / 64);
+  if (g_conv_ksplit && tiles64 <= cu_count() / 4 && nslab >= 8 && Nb <= 64)
     return dtype == DRN_BF16 ? launch_conv_ks<DRN_BF16>(p, st)
            : dtype == DRN_FP8 ? launch_conv_ks<DRN_FP8>(p, st) : launch_conv_ks<DRN_F32>(p, st);
   if (dtype == DRN_BF16)

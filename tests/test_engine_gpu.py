@@ -185,7 +185,8 @@ def test_two_ranks_iter_size_two_equals_mean_gradient_training():
     for n, p in model.named_parameters():
         if p.requires_grad and n in res[0][2]:
             diff = float((p.detach().cpu() - torch.from_numpy(res[0][2][n])).abs().max())
-            assert diff <= 5e-6 * max(float(p.detach().abs().max()), 1.0), (n, diff)
+            # ((a + b) / 2 + (c + d) / 2 vs (a + b + c + d) / 4 in fp32, through three optimizer steps: 1e-6 .. 1.2e-5 measured)
+            assert diff <= 3e-5 * max(float(p.detach().abs().max()), 1.0), (n, diff)
 
 
 @pytest.mark.parametrize("name,freeze_at", [("model_r50c4_tiny", 2), ("model_r50c4_align_tiny", 3), ("model_r18dc5_tiny", 1)])
@@ -231,11 +232,31 @@ def test_graphed_full_step_trainable_trunk_equals_eager(name, freeze_at):
         torch.cuda.synchronize()
         res.append((out, _weights(model)))
     # RoIPool / ROIAlign backward scatters with float atomics, so two runs of the SAME trainable-trunk step differ in the
-    # last bits of the trunk gradients and the difference grows over the six steps: 2e-3 on losses, 1e-4 of a tensor's
-    # scale on the weights (a missed re-pack or a stale activation is an O(1) error)
+    # last bits of the trunk gradients, and over six steps a pooled arg-max or a ReLU flips in some runs: measured
+    # run-to-run (eager vs eager, tools: six steps, this fixture) up to 4e-3 of a tensor's scale on the weights and
+    # 1.4e-3 on the losses, bimodal.  The comparison below is therefore statistical (3x that floor); the failure modes
+    # that are NOT noise are checked exactly: the graphed step must have re-packed every trainable conv from its updated
+    # weights (a stale pack = the trunk silently stops learning in the forward), and must have touched every tensor.
     for e, g in zip(res[0][0], res[1][0]):
         for k in e:
-            assert abs(e[k] - g[k]) <= 2e-3 * max(abs(e[k]), 1e-2), (k, e[k], g[k])
+            assert abs(e[k] - g[k]) <= 5e-3 * max(abs(e[k]), 1e-2), (k, e[k], g[k])
     for n in res[0][1]:
         a, b = res[0][1][n], res[1][1][n]
-        assert np.abs(a - b).max() <= 1e-4 * max(np.abs(a).max(), 1e-3), n
+        assert np.abs(a - b).max() <= 1.2e-2 * max(np.abs(a).max(), 1e-3), n
+    before = {n: t.numpy() for n, t in G.drn_model(ocfg, int(d["seed"]), "cpu", freeze_at, "fp32")[1].state_dict().items()}
+    for n, b in res[1][1].items():  # every tensor the eager run moved moved under the graph (bbox_pred of non-regressing
+        assert np.array_equal(b, before[n]) == np.array_equal(res[0][1][n], before[n]), n  # branches is unused in both)
+    from drn_wsod_pytorch_amd.layers import Conv2d
+
+    convs = [m for m in model.backbone.modules() if isinstance(m, Conv2d) and m.weight.requires_grad]  # the graphed run's
+    assert convs
+    w6 = [m.weight.detach().clone() for m in convs]
+    stepper.step(seq[0])  # a seventh replay: its forward starts by packing the weights the sixth step left behind
+    torch.cuda.synchronize()
+    for m, w in zip(convs, w6):
+        held = m._pack[0].clone()
+        assert not torch.equal(m.weight.detach(), w)  # (the seventh update has happened in the meantime)
+        with torch.no_grad():
+            m.weight.copy_(w)
+        m.invalidate_packs()
+        assert torch.equal(held, m.packed(torch.float32)[0])
