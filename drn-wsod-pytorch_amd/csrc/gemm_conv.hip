@@ -1080,6 +1080,7 @@ int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
+static int g_tail_split = 1;  // drn_tune(DRN_TUNE_GEMM_TAIL_SPLIT): peel a nearly empty last round off persistent launches
 static int g_persistent = 1;  // drn_tune(DRN_TUNE_GEMM_PERSISTENT): 256x256 GEMMs with more work items than CUs loop
 
 static int cu_count() {
@@ -1184,6 +1185,11 @@ int drn_tune(int knob, int value) {
     g_conv_ksplit = value != 0;
     return old;
   }
+  if (knob == 6) {  // DRN_TUNE_GEMM_TAIL_SPLIT
+    const int old = g_tail_split;
+    g_tail_split = value != 0;
+    return old;
+  }
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
     const int old = g_group_rows;
     if (value >= 0 && value <= 64) g_group_rows = value;
@@ -1220,8 +1226,37 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, false>(p, splits, st) : launch_gemm256<DRN_F32, false>(p, splits, st);
   if ((force == 256 || (force == 0 && wg256 >= 192)) && (((uintptr_t)C) & 3) == 0) {
     p.gm = gemm256_group_rows(M, N, splits);
-    if (const int nwg = persistent_grid(wg256))
+    if (const int nwg = persistent_grid(wg256)) {
+      // Tail balancing.  The persistent kernel runs ceil(tiles / CUs) rounds: the fc6 dW row slab [1024 x 50176] is
+      // 4 x 196 = 784 tiles = 3.06 rounds on 256 CUs, i.e. FOUR rounds with 240 CUs idle in the last one (measured:
+      // 448 us for two slabs = 8 rounds of 56 us where 6.125 rounds of work exist).  When the last round is less
+      // than 3/8 full, whole tile columns are peeled off so that the persistent launch is an exact number of rounds,
+      // and the peeled columns (16 tiles of that slab) run first as their own launch of the small-tile kernel - many
+      // short workgroups that fill every CU.  Same slab order and the same MFMA per output element in both kernels,
+      // so the result is bit-identical to the unsplit launch (test_gemm_tail_split_bit_identical).
+      const int tm = (M + 255) / 256, tn = (N + 255) / 256;
+      const long rem = wg256 % nwg;
+      if (g_tail_split && splits == 1 && rem != 0 && rem * 8 <= (long)nwg * 3) {
+        int a = nwg, b = tm;
+        while (b) { const int t = a % b; a = b; b = t; }
+        const int step = nwg / a;                   // tile columns per exact multiple of nwg tiles
+        const int cols_main = (tn / step) * step;
+        if (cols_main > 0 && (long)(tn - cols_main) * tm == rem) {
+          const long n0 = (long)cols_main * 256;
+          GemmParams q = p;
+          q.B = p.B + n0 * ldb * es;
+          q.C = (float*)((char*)p.C + n0 * (p.c_bf16 ? 2 : 4));
+          q.N = N - (int)n0;
+          const bool small_t = (long)((M + 127) / 128) * ((q.N + 127) / 128) < 128;
+          const int rc = dtype == DRN_BF16
+                             ? (small_t ? launch_gemm<DRN_BF16, 64, 64>(q, 1, st) : launch_gemm<DRN_BF16, 128, 128>(q, 1, st))
+                             : (small_t ? launch_gemm<DRN_F32, 64, 64>(q, 1, st) : launch_gemm<DRN_F32, 128, 128>(q, 1, st));
+          if (rc != DRN_OK) return rc;
+          p.N = (int)n0;
+        }
+      }
       return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, false>(p, nwg, st) : launch_gemm256p<DRN_F32, false>(p, nwg, st);
+    }
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true>(p, splits, st) : launch_gemm256<DRN_F32, true>(p, splits, st);
   }
   const bool small = force == 64 || (force == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) * splits < 128);

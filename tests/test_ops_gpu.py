@@ -135,6 +135,45 @@ def test_gemm_persistent_equals_one_tile_grid(drn, dtype, M, N, K, splits):
         drn.gemm_set_tile(prev_tile)
 
 
+@pytest.mark.parametrize("dtype", DTYPES)
+@pytest.mark.parametrize("M,N,K", [(1024, 68 * 256 - 50, 256), (2000, 36 * 256 - 3, 192)])
+def test_gemm_tail_split_bit_identical(drn, dtype, M, N, K):
+    """Tail balancing of the persistent 256x256 GEMM (DRN_TUNE_GEMM_TAIL_SPLIT): the tile columns of a nearly empty last
+    round are peeled off and run on the small-tile kernel.  Both kernels consume K in the same 128-byte slabs with the
+    same MFMA per output element, so fp32, accumulate and bf16 outputs must be BIT-identical with the split on and off
+    (shapes chosen so that the split triggers: 4 x 68 = 256 + 16 tiles, 8 x 36 = 256 + 32 tiles, ragged N edge)."""
+    A, B = _rnd((M, K), 24), _rnd((N, K), 25)
+    Ad, Bd = _padded(A, dtype, drn), _padded(B, dtype, drn)
+    Kp = Ad.shape[1]
+    C0 = _rnd((M, N), 26).to(DEV)
+    prev_tile = drn.gemm_set_tile(256)
+    prev_p = drn.tune(drn.TUNE_GEMM_PERSISTENT, 1)
+    prev = drn.tune(drn.TUNE_GEMM_TAIL_SPLIT, 0)
+    try:
+        res = []
+        for split in (0, 1):
+            drn.tune(drn.TUNE_GEMM_TAIL_SPLIT, split)
+            out = [drn.gemm_nt(Ad, Bd, M, N, Kp).clone()]
+            acc = C0.clone().unsqueeze(0)
+            drn.gemm_nt(Ad, Bd, M, N, Kp, out=acc, accumulate=True)
+            out.append(acc)
+            o16 = torch.zeros((1, M, N), dtype=torch.bfloat16, device=DEV)
+            drn.gemm_nt(Ad, Bd, M, N, Kp, out=o16)
+            out.append(o16)
+            res.append(out)
+        torch.cuda.synchronize()
+        for a, b in zip(*res):
+            assert torch.equal(a, b)
+        ref = _q(A, dtype).double() @ _q(B, dtype).double().t()
+        mag = _q(A, dtype).abs().double() @ _q(B, dtype).abs().double().t()
+        got = res[1][0].sum(0).cpu().double()
+        assert ((got - ref).abs() <= 4 * 2.0 ** -24 * math.sqrt(K) * mag + 1e-6).all()
+    finally:
+        drn.tune(drn.TUNE_GEMM_TAIL_SPLIT, prev)
+        drn.tune(drn.TUNE_GEMM_PERSISTENT, prev_p)
+        drn.gemm_set_tile(prev_tile)
+
+
 def test_gemm_asymmetric_identity(drn):
     """A = I with an ASYMMETRIC B catches a transposed C write (cdna guide rule 16)."""
     n = 128
