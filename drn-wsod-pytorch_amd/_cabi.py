@@ -101,7 +101,14 @@ def ptr(t):
     return t.data_ptr()
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def stream():
+    """hipStream_t of torch's current stream (the capture stream while a hipGraph is being captured).  The raw getter
+    skips building a torch.cuda.Stream object: ~8 us -> < 1 us per launch on the eager step's ~100 launches."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 

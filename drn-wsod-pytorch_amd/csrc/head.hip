@@ -269,7 +269,8 @@ struct WsddnParams {
   float* part; int max_blocks;     // [n_img][max_blocks][3][WS_KP] per-block column partials
 };
 
-// WSDDN forward + backward as three multi-block launches over row blocks of WS_ROWS rows (grid = blocks x images):
+// WSDDN forward + backward as three multi-block launches over row blocks of WS_ROWS rows (grid = blocks x images;
+// round 2: 32-row blocks with a parallel combine of the block partials, 55 -> see profiles/r2_09 us for the three stages):
 //   A: a = softmax over classes (shuffle reduction inside the LPR lanes that own a row) -> rowsm; per-block online
 //      column-softmax partials (block max, block sum of exp relative to it)
 //   B: every block re-combines the partials of its image in a fixed order (cmax, csum), writes the scores and its
@@ -277,7 +278,7 @@ struct WsddnParams {
 //   C: combine the score sums, image scores / BCE / d loss (first block of the image), analytic backward
 // Rows are owned by LPR consecutive lanes (32 for K <= 32, else 64 with two columns per lane); all reductions have
 // a fixed order, so the result does not depend on scheduling.
-constexpr int WS_ROWS = 128;
+constexpr int WS_ROWS = 32;   // rows per block: 63 blocks for a 2000-proposal image, four row passes per block and stage
 constexpr int WS_KP = 128;  // padded column count of the partial buffers
 
 template <int LPR>
@@ -304,20 +305,31 @@ __device__ __forceinline__ void ws_colreduce(float (&v)[WsLanes<LPR>::CPL], cons
   }
 }
 
-// cmax / csum of image `img` from the per-block partials, same order in every block
+// cmax / csum of image `img` from the per-block partials, the same way in every block: phase ph takes the blocks ph,
+// ph + RPP, ... and the RPP phase results are merged in phase order through LDS (a serial walk over the 63 blocks of a
+// 2000-proposal image would be 126 dependent loads at the head of stages 1 and 2)
 template <int LPR>
 __device__ __forceinline__ void ws_combine(const WsddnParams& p, int img, int nb, const int (&col)[WsLanes<LPR>::CPL],
-                                           const bool (&ok)[WsLanes<LPR>::CPL], float (&cmax)[WsLanes<LPR>::CPL],
+                                           const bool (&ok)[WsLanes<LPR>::CPL], int ph,
+                                           float (*red)[LPR * WsLanes<LPR>::CPL], float (&cmax)[WsLanes<LPR>::CPL],
                                            float (&csum)[WsLanes<LPR>::CPL]) {
+  using L = WsLanes<LPR>;
   const float* part = p.part + (long)img * p.max_blocks * 3 * WS_KP;
 #pragma unroll
-  for (int j = 0; j < WsLanes<LPR>::CPL; ++j) {
-    cmax[j] = -FLT_MAX; csum[j] = 0.f;
-    if (!ok[j]) continue;
-    for (int q = 0; q < nb; ++q) cmax[j] = fmaxf(cmax[j], part[(q * 3 + 0) * WS_KP + col[j]]);
-    for (int q = 0; q < nb; ++q)
-      csum[j] += part[(q * 3 + 1) * WS_KP + col[j]] * expf(part[(q * 3 + 0) * WS_KP + col[j]] - cmax[j]);
+  for (int j = 0; j < L::CPL; ++j) {
+    cmax[j] = -FLT_MAX;
+    if (ok[j])
+      for (int q = ph; q < nb; q += L::RPP) cmax[j] = fmaxf(cmax[j], part[(q * 3 + 0) * WS_KP + col[j]]);
   }
+  ws_colreduce<LPR, true>(cmax, col, ph, red);
+#pragma unroll
+  for (int j = 0; j < L::CPL; ++j) {
+    csum[j] = 0.f;
+    if (ok[j])
+      for (int q = ph; q < nb; q += L::RPP)
+        csum[j] += part[(q * 3 + 1) * WS_KP + col[j]] * expf(part[(q * 3 + 0) * WS_KP + col[j]] - cmax[j]);
+  }
+  ws_colreduce<LPR, false>(csum, col, ph, red);
 }
 
 template <int LPR, int STAGE>
@@ -370,7 +382,7 @@ __global__ __launch_bounds__(256) void wsddn_stage_kernel(WsddnParams p) {
     return;
   }
   float cmax[CPL], csum[CPL];
-  ws_combine<LPR>(p, img, nb, col, ok, cmax, csum);
+  ws_combine<LPR>(p, img, nb, col, ok, ph, red, cmax, csum);
   if (STAGE == 1) {
     float S[CPL];
 #pragma unroll
@@ -396,9 +408,15 @@ __global__ __launch_bounds__(256) void wsddn_stage_kernel(WsddnParams p) {
   float S[CPL], g[CPL], lsum = 0.f;
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
-    S[j] = 0.f; g[j] = 0.f;
+    S[j] = 0.f;
+    if (ok[j])
+      for (int q = ph; q < nb; q += RPP) S[j] += ipart[(q * 3 + 2) * WS_KP + col[j]];
+  }
+  ws_colreduce<LPR, false>(S, col, ph, red);
+#pragma unroll
+  for (int j = 0; j < CPL; ++j) {
+    g[j] = 0.f;
     if (!ok[j]) continue;
-    for (int q = 0; q < nb; ++q) S[j] += ipart[(q * 3 + 2) * WS_KP + col[j]];
     const float sc = fminf(fmaxf(S[j], 1e-6f), 1.0f - 1e-6f);
     const float y = p.gt_onehot[img * K + col[j]];
     // F.binary_cross_entropy: -(y*log(s) + (1-y)*log(1-s)), logs clamped at -100

@@ -58,6 +58,28 @@ class Backbone(nn.Module):
     # keeps what its explicit backward needs, frozen or not
     input_grad = False
 
+    def trainable(self, unit=None):
+        """does `unit` (default: the whole trunk) hold a parameter with requires_grad?  Asked several times per step
+        (which blocks keep activations, whether the trunk may run ahead on a side stream): the parameter lists are
+        collected once - walking the module tree every time was ~1 ms of host time per eager step - and only the
+        requires_grad flags are re-read, so freeze() / requires_grad_() are followed."""
+        cache = self.__dict__.setdefault("_param_lists", {})
+        key = id(unit) if unit is not None else 0
+        ps = cache.get(key)
+        if ps is None:
+            ps = cache[key] = list((unit if unit is not None else self).parameters())
+        for p_ in ps:
+            if p_.requires_grad:
+                return True
+        return False
+
+    def conv_modules(self):
+        """every module with packed compute copies (Conv2d), collected once"""
+        ms = self.__dict__.get("_conv_list")
+        if ms is None:
+            ms = self.__dict__["_conv_list"] = [m for m in self.modules() if hasattr(m, "packed")]
+        return ms
+
     def input_gradient_nhwc(self, dfeat):
         """d (scalar) / d normalised image [N, H, W, Cin_pad] given its gradient w.r.t. the (single) output feature map:
         the explicit backward of EVERY unit for d/dx only - no weight / bias gradient is touched and the saved
@@ -254,7 +276,7 @@ class ResNet(Backbone):
         # stops at the first trainable block, so everything in front of it runs as pure inference
         save = self.training and torch.is_grad_enabled()
         units = [self.stem] + [b for stage, _ in self.stages_and_names for b in stage]
-        first = next((i for i, u in enumerate(units) if any(p.requires_grad for p in u.parameters())), None)
+        first = next((i for i, u in enumerate(units) if self.trainable(u)), None)
         self._bw_units = units[first:] if (save and first is not None) else None
         keep_all = save and self.input_grad
         self._all_units = units if keep_all else None
@@ -469,7 +491,7 @@ class VGG16(Backbone):
         outputs = {}
         save = self.training and torch.is_grad_enabled()
         units = [b for stage, _ in self.stages_and_names for b in stage]
-        first = next((i for i, u in enumerate(units) if any(p.requires_grad for p in u.parameters())), None)
+        first = next((i for i, u in enumerate(units) if self.trainable(u)), None)
         self._bw_units = units[first:] if (save and first is not None) else None
         keep_all = save and self.input_grad
         self._all_units = units if keep_all else None

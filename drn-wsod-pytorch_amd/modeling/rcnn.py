@@ -82,7 +82,7 @@ class GeneralizedRCNNWSL(nn.Module):
         """Run preprocess + backbone of a FUTURE batch on a side stream.  The shipped configs freeze the whole
         backbone (FREEZE_AT=5), so its forward has no dependency on the head update: its ~45 small, latency-bound
         conv launches hide under the current batch's fc6/fc7 GEMMs instead of serialising in front of them."""
-        if self.cpg or any(p.requires_grad for p in self.backbone.parameters()):
+        if self.cpg or self.backbone.trainable():
             return  # only legal for a frozen backbone that nothing differentiates through
         if getattr(self, "_side", None) is None:
             self._side = torch.cuda.Stream()
@@ -91,9 +91,15 @@ class GeneralizedRCNNWSL(nn.Module):
         # HERE, on the caller's stream, so the side stream never creates buffers that the caller's own forward of the
         # current batch reads concurrently (a first-iteration race when the prefetch precedes any forward)
         dtype = compute_dtype()
-        for m in self.backbone.modules():
-            if hasattr(m, "packed"):
-                m.packed(dtype)
+        for m in self.backbone.conv_modules():
+            m.packed(dtype)
+        # one batch ahead is the contract (the engine owns two fc6-operand sets: the batch in flight and ONE pooled ahead):
+        # a prefetched batch that was never consumed - the caller changed its mind about what comes next - is dropped
+        # here and its operand set handed back, instead of failing the new prefetch with "no free buffer set"
+        for key_ in [k for k in getattr(self, "_prefetch_cache", {}) if k != id(batched_inputs)]:
+            stale = self._prefetch_cache.pop(key_)
+            if stale[3] is not None and stale[3]["pooled"]["state"] == "pending":
+                stale[3]["pooled"]["state"] = "free"
         self._side.wait_stream(main)
         with torch.cuda.stream(self._side), torch.no_grad():
             images = self.preprocess_image(batched_inputs)
@@ -141,8 +147,7 @@ class GeneralizedRCNNWSL(nn.Module):
         eng = getattr(self.roi_heads, "_engine", None)
         if eng is not None:
             # MODEL.BACKBONE.FREEZE_AT < 5: the heads' explicit backward hands the feature-map gradient to the trunk's
-            eng.feature_grad_hook = (self._backbone_backward if any(p.requires_grad for p in self.backbone.parameters())
-                                     else None)
+            eng.feature_grad_hook = self._backbone_backward if self.backbone.trainable() else None
         # image-level labels are read on the host (they come from the loader there): no device round trip
         gt_instances = [x["instances"] for x in batched_inputs] if "instances" in batched_inputs[0] else None
         proposals = self._proposals(batched_inputs)

@@ -411,29 +411,53 @@ class _HeadEngine:
 
     # ---- workspaces ---------------------------------------------------------------------------------
     def ws(self, M, dtype, training):
-        key = (M, dtype, training)
-        if key in self._ws:
-            return self._ws[key]
-        if len(self._ws) >= 2:
-            self._ws.clear()
-        h = self.h
-        dev = self.arena_w.device
-        D1, K1 = h.box_head.fc1.weight.shape
-        D2 = h.box_head.fc2.weight.shape[0]
+        """Activation / gradient workspaces for M proposals.  The buffers are allocated for a CAPACITY (the largest M seen,
+        rounded up to 64; grow-only) and handed out as views for the M of this batch: real data has another proposal count
+        every step, and re-allocating (and zero-filling) ~150 MB of workspaces per step made the eager step allocator-
+        bound.  K-role buffers - the transposed twins, whose columns M .. kpad(M) are read by a GEMM as zero padding -
+        get that pad re-zeroed whenever M changes (a narrow strided fill), so a view never shows a previous batch's
+        columns."""
+        key = (dtype, training)
+        base = self._ws.get(key)
         kp = lambda k: ops.kpad(k, dtype)
-        z = lambda r, c, dt=dtype: torch.zeros((r, c), dtype=dt, device=dev)
-        NHp = kp(self.NH)
-        w = dict(H1=z(M, kp(D1)), H2=z(M, kp(D2)), logits=z(M, NHp, torch.float32))
-        if training:
-            Mp = kp(M)
-            w.update(H1T=z(D1, Mp), H2T=z(D2, Mp), dlogits=z(M, NHp, torch.float32), dS=z(M, NHp),
-                     dST=z(self.NH, Mp), dH2=z(M, D2, torch.float32), dP2=z(M, kp(D2)), dP2T=z(D2, Mp),
-                     dH1=torch.zeros((1, M, D1), dtype=torch.float32, device=dev), dP1T=z(D1, Mp),
-                     colpart=z((M + 63) // 64, max(D1, D2, self.NH), torch.float32),
-                     # one scratch per layer for the deferred mode (the three reductions then run later, together)
-                     colpart3=[z((M + 63) // 64, n_, torch.float32) for n_ in (self.NH, D2, D1)])
-        self._ws[key] = w
-        return w
+        if base is None or M > base["cap"]:
+            h = self.h
+            dev = self.arena_w.device
+            D1, K1 = h.box_head.fc1.weight.shape
+            D2 = h.box_head.fc2.weight.shape[0]
+            cap = (M + 63) // 64 * 64
+            z = lambda r, c, dt=dtype: torch.zeros((r, c), dtype=dt, device=dev)
+            NHp = kp(self.NH)
+            b = dict(H1=z(cap, kp(D1)), H2=z(cap, kp(D2)), logits=z(cap, NHp, torch.float32))
+            if training:
+                Cp = kp(cap)
+                b.update(H1T=z(D1, Cp), H2T=z(D2, Cp), dlogits=z(cap, NHp, torch.float32), dS=z(cap, NHp),
+                         dST=z(self.NH, Cp), dH2=z(cap, D2, torch.float32), dP2=z(cap, kp(D2)), dP2T=z(D2, Cp),
+                         dH1=torch.zeros((1, cap, D1), dtype=torch.float32, device=dev), dP1T=z(D1, Cp),
+                         colpart=z((cap + 63) // 64, max(D1, D2, self.NH), torch.float32),
+                         # one scratch per layer for the deferred mode (the three reductions then run later, together)
+                         colpart3=[z((cap + 63) // 64, n_, torch.float32) for n_ in (self.NH, D2, D1)])
+            base = self._ws[key] = dict(cap=cap, bufs=b, M=None, views=None)
+        if base["M"] != M:
+            b, Mp = base["bufs"], kp(M)
+            v = {}
+            for name, t in b.items():
+                if name in self._WS_T:          # [X, kpad(cap)] transposed twins: columns of this batch + zero pad
+                    v[name] = t[:, :Mp]
+                    if Mp > M and base["M"] is not None:
+                        t[:, M:Mp].zero_()
+                elif name == "dH1":             # [splits, cap, D1]
+                    v[name] = t[:, :M]
+                elif name == "colpart":
+                    v[name] = t[: (M + 63) // 64]
+                elif name == "colpart3":
+                    v[name] = [c[: (M + 63) // 64] for c in t]
+                else:                           # [cap, X] row-major
+                    v[name] = t[:M]
+            base["M"], base["views"] = M, v
+        return base["views"]
+
+    _WS_T = ("H1T", "H2T", "dST", "dP2T", "dP1T")
 
     def pool(self, feat_nhwc, rois, objectness, training, slot=None, want_argmax=False, prefetch=False):
         """ROIPool/ROIAlign fused with the objectness scaling -> fc6 operand A [M, C*P*P] (+ A^T for the dW GEMM when
@@ -447,12 +471,15 @@ class _HeadEngine:
         self.ensure(dev)
         M = rois.shape[0]
         K1 = h.box_head.fc1.weight.shape[1]
-        key = (M, dtype, training)
-        if getattr(self, "_pool_key", None) != key:
+        key = (dtype, training)
+        cap = getattr(self, "_pool_cap", 0)
+        if getattr(self, "_pool_key", None) != key or M > cap:
+            # capacity-based like ws(): the operand pair of the largest batch seen, views for this batch
+            cap = (M + 63) // 64 * 64
             z = lambda r_, c_: torch.zeros((r_, c_), dtype=dtype, device=dev)
-            self._pool_sets = [dict(A=z(M, ops.kpad(K1, dtype)), AT=z(K1, ops.kpad(M, dtype)) if training else None,
-                                    state="free") for _ in range(2)]
-            self._pool_key = key
+            self._pool_sets = [dict(A_buf=z(cap, ops.kpad(K1, dtype)), AT_buf=z(K1, ops.kpad(cap, dtype)) if training else None,
+                                    state="free", M=None) for _ in range(2)]
+            self._pool_key, self._pool_cap = key, cap
             self._pool_current_done = True
         if slot is None:
             free = [i for i, q in enumerate(self._pool_sets) if q["state"] == "free"]
@@ -464,6 +491,13 @@ class _HeadEngine:
             else:
                 raise DrnError("no free fc6-operand buffer set: at most one batch can be pooled ahead of the one in flight")
         s = self._pool_sets[slot]
+        if s["M"] != M:
+            Mp = ops.kpad(M, dtype)
+            s["A"] = s["A_buf"][:M]
+            s["AT"] = s["AT_buf"][:, :Mp] if s["AT_buf"] is not None else None
+            if s["AT"] is not None and Mp > M and s["M"] is not None:
+                s["AT_buf"][:, M:Mp].zero_()  # K-role pad of the dW GEMM: never a previous batch's columns
+            s["M"] = M
         if prefetch:
             s["state"] = "pending"
         else:
@@ -739,8 +773,9 @@ class _HeadEngine:
         # GEMMs and let the activation backward behind it sum the partials (63 -> ~45 us at the bench shape)
         s1 = self._splits(M, D1, kp(D2), dtype) if getattr(self, "fc7_dx_split", True) else 1
         if w["dH1"].shape[0] != s1:
-            w["dH1"] = torch.zeros((s1, M, D1), dtype=torch.float32, device=dev)
-            self._ws[(M, dtype, True)]["dH1"] = w["dH1"]
+            base = self._ws[(dtype, True)]
+            base["bufs"]["dH1"] = torch.zeros((s1, base["cap"], D1), dtype=torch.float32, device=dev)
+            w["dH1"] = base["views"]["dH1"] = base["bufs"]["dH1"][:, :M]
         ops.gemm_nt(w["dP2"], sh["W2T"], M, D1, kp(D2), out=w["dH1"], splits=s1)
         # fc6 (the backbone is frozen: no dX)
         fg = st.get("fg")

@@ -256,7 +256,7 @@ def wsddn_fwd_bwd(logits, c_cls, c_det, K, img_off, n_img, gt_onehot, dlogits=No
     img_scores = torch.empty((n_img, K), dtype=torch.float32, device=dev)
     loss_part = torch.empty((n_img,), dtype=torch.float32, device=dev)
     rowsm = torch.empty((M, K), dtype=torch.float32, device=dev)
-    scratch = torch.empty((n_img * ((max_rows + 127) // 128) * 384,), dtype=torch.float32, device=dev)
+    scratch = torch.empty((n_img * ((max_rows + 31) // 32) * 384,), dtype=torch.float32, device=dev)
     C.call("drn_wsddn_fwd_bwd", C.ptr(logits), _2d(logits), c_cls, c_det, K, C.ptr(img_off), n_img, C.ptr(gt_onehot),
            C.ptr(scores), C.ptr(rowsm), C.ptr(img_scores), C.ptr(loss_part), C.ptr(dlogits),
            _2d(dlogits) if dlogits is not None else 0, C.ptr(scratch), int(max_rows), int(mean_loss), float(loss_scale),

@@ -185,7 +185,7 @@ int drn_colsum_reduce(const float* colpart, int nparts, int N, float* colsum, in
 /* WSDDNOutputLayers.forward (fast_rcnn.py:493-527) + predict_probs_img (:689-700) +
  * WSDDNOutputs.binary_cross_entropy_loss (:317-329) + their autograd.  logits [M][ld] fp32 with the
  * cls / det heads at columns c_cls / c_det; img_off [n_img+1] row offsets.  loss = sum(loss_part).
- * scratch: n_img * ceil(max_rows/128) * 384 floats, max_rows = largest per-image proposal count. */
+ * scratch: n_img * ceil(max_rows/32) * 384 floats, max_rows = largest per-image proposal count. */
 int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K, const int* img_off, int n_img,
                       const float* gt_onehot, float* scores, float* row_softmax, float* img_scores, float* loss_part,
                       float* dlogits, long ld_d, float* scratch, int max_rows, int mean_loss, float loss_scale,
