@@ -739,6 +739,64 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
             }
           }
       }
+    } else if (p.c_bf16 && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0) {
+      // bf16 output (the fc6 dW gradient bucket: one epilogue per 32 K-slabs, 128 KB per tile): the MFMA layout gives a
+      // lane 4 consecutive columns of 32 DIFFERENT rows, i.e. 8-byte stores scattered over 32 lines per instruction.
+      // The tile goes through the free LDS stage instead, one 128-row half at a time (64 KB), and leaves as 16-byte
+      // pieces of whole 512-byte rows.  8-byte chunk c of row r sits at chunk c ^ ((r & 31) << 1): the 32 rows of a
+      // store instruction spread over all banks, and a reader's 16-byte pair stays adjacent.
+      // LDS accesses are inline asm: the compiler orders every ds access it can see behind ALL pending LDS-DMA
+      // (s_waitcnt vmcnt(0)), i.e. behind the next tile's slab that was just issued into the OTHER stage
+      const unsigned ep = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)(smem + STAGE);
+      bf16_t* C16 = (bf16_t*)p.C;
+      // (the ~40 LDS / global offsets below are functions of the thread id alone: without this the compiler hoists them
+      // out of the tile loop and keeps them alive through the mainloop - 204 -> 229 VGPRs, which would cost the conv
+      // workgroups their place beside this kernel, see DESIGN 'trunk beside the GEMMs')
+      int lane_e = lane, tid_e = tid;
+      asm volatile("" : "+v"(lane_e), "+v"(tid_e));
+      if (!more) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+#pragma unroll
+      for (int half = 0; half < 2; ++half) {
+        if (wm == half) {
+#pragma unroll
+          for (int i = 0; i < MI; ++i) {
+            const int row = i * 32 + (lane_e & 31);
+#pragma unroll
+            for (int jj = 0; jj < NJ; ++jj)
+#pragma unroll
+              for (int qq = 0; qq < 4; ++qq) {
+                const int c = wn * 16 + jj * 8 + 2 * qq + (lane_e >> 5);
+                const unsigned long long o =
+                    (unsigned long long)((uint32_t)f32_to_bf16(acc[i][jj][4 * qq]) | ((uint32_t)f32_to_bf16(acc[i][jj][4 * qq + 1]) << 16)) |
+                    ((unsigned long long)((uint32_t)f32_to_bf16(acc[i][jj][4 * qq + 2]) | ((uint32_t)f32_to_bf16(acc[i][jj][4 * qq + 3]) << 16)) << 32);
+                asm volatile("ds_write_b64 %0, %1" ::"v"(ep + row * 512 + ((c ^ ((row & 31) << 1)) << 3)), "v"(o) : "memory");
+              }
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+#pragma unroll 1
+        for (int it = 0; it < 8; ++it) {
+          const int idx = it * 512 + tid_e;
+          const int row = idx >> 5, pc = idx & 31;
+          const int m = bm + half * 128 + row, n = bn + pc * 8;
+          i32x4_t v;
+          asm volatile("ds_read_b128 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(ep + row * 512 + ((pc ^ (row & 31)) << 4)) : "memory");
+          if (m < p.M) {
+            bf16_t* dst = C16 + (long)m * p.ldc + n;
+            if (n + 8 <= p.N) {
+              *(i32x4_t*)dst = v;
+            } else {
+              const bf16_t* e8 = (const bf16_t*)&v;
+#pragma unroll
+              for (int e = 0; e < 8; ++e)
+                if (n + e < p.N) dst[e] = e8[e];
+            }
+          }
+        }
+        if (half == 0) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
+      }
     } else {
       float* C = p.C + (long)cur.split * p.c_split_stride;
       const bool vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0;

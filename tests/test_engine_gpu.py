@@ -260,3 +260,51 @@ def test_graphed_full_step_trainable_trunk_equals_eager(name, freeze_at):
             m.weight.copy_(w)
         m.invalidate_packs()
         assert torch.equal(held, m.packed(torch.float32)[0])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_workspace_views_follow_changing_proposal_counts(precision):
+    """Real data brings another proposal count every step.  The head engine's workspaces and fc6-operand sets are
+    capacity-based views (roi_heads.py `_HeadEngine.ws` / `pool`): after a LARGER batch the buffers still hold that
+    batch's values beyond the new M - the K-role pad columns of the transposed twins (read by the dW GEMMs) must be
+    zero again.  Losses and every gradient of [large, then small] must equal BIT FOR BIT those of a fresh model that
+    only ever saw the small batch (M = 37: pad up to 64 in bf16, to 40 in fp32)."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    d = G.load(NAME)
+    ocfg = G.MODEL_CASES[NAME]
+    base = G.batch_from(d)[0]
+    big = dict(base)
+    jit = torch.linspace(0.0, 3.0, 3).view(3, 1, 1)
+    big["proposal_boxes"] = (base["proposal_boxes"].unsqueeze(0) + jit).reshape(-1, 4).contiguous()
+    big["objectness_logits"] = base["objectness_logits"].repeat(3).contiguous()
+    small = dict(base)
+    small["proposal_boxes"] = base["proposal_boxes"][:37].contiguous()
+    small["objectness_logits"] = base["objectness_logits"][:37].contiguous()
+    seed = int(d["seed"])
+
+    def run(seq):
+        cfg, model = G.drn_model(ocfg, seed, "cuda", 5, precision)
+        model.roi_heads.box_head.dropout_p = 0.0
+        model.train()
+        opt = build_optimizer(cfg, model)
+        for b in seq:
+            opt.zero_grad()
+            losses = model(G.drn_inputs([b]))
+            sum(losses.values()).backward()
+        torch.cuda.synchronize()
+        return ({k: float(v.detach()) for k, v in losses.items()},
+                {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None})
+
+    l_seq, g_seq = run([big, small])
+    l_one, g_one = run([small])
+    assert l_seq == l_one
+    assert set(g_seq) == set(g_one) and len(g_one) >= 6
+    for n in g_one:
+        assert torch.equal(g_seq[n], g_one[n]), n
+    # and growing again after the small batch reproduces the large one
+    l_big2, g_big2 = run([small, big])
+    l_big1, g_big1 = run([big])
+    assert l_big2 == l_big1
+    for n in g_big1:
+        assert torch.equal(g_big2[n], g_big1[n]), n
