@@ -1187,6 +1187,7 @@ static int persistent_grid(long total) {
 }
 
 static int g_conv_ksplit = 1;  // drn_tune(DRN_TUNE_CONV_KSPLIT): 0 = never use the 32x32 wave-K-split kernel
+static int g_conv_ks_tiles = 0;  // drn_tune(DRN_TUNE_CONV_KS_TILES): largest 64x64-tile count of ONE image that still takes it (0 = CUs / 4)
 
 template <int DT>
 int launch_conv_ks(const ConvParams& p, hipStream_t st) {
@@ -1241,6 +1242,11 @@ int drn_tune(int knob, int value) {
   if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
     const int old = g_conv_ksplit;
     g_conv_ksplit = value != 0;
+    return old;
+  }
+  if (knob == 7) {  // DRN_TUNE_CONV_KS_TILES
+    const int old = g_conv_ks_tiles;
+    if (value >= 0) g_conv_ks_tiles = value;
     return old;
   }
   if (knob == 6) {  // DRN_TUNE_GEMM_TAIL_SPLIT
@@ -1372,7 +1378,10 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   // (decided on ONE image's geometry: this kernel adds the K partials in another order than the tiled ones, and a layer
   // must round the same way whether its image runs alone or in a batch - graphed trunk pairs vs eager, 2 ranks vs 1)
   const long tiles64 = (((long)Ho * Wo + 63) / 64) * ((Cout + 63) / 64);
-  if (g_conv_ksplit && tiles64 <= cu_count() / 4 && nslab >= 8 && Nb <= 64)
+  // (round 2, tools/conv_bench.py at 800x1216: up to one 64x64 tile per CU the 36-slab res4 3x3 still gains, 23.1 ->
+  // 20.5 us, while layers with few slabs lose - the 9-slab stem 3x3 8.6 -> 9.7 us at 224x224: deep K only)
+  const long ks_max = g_conv_ks_tiles > 0 ? g_conv_ks_tiles : (nslab >= 32 ? cu_count() : cu_count() / 4);
+  if (g_conv_ksplit && tiles64 <= ks_max && nslab >= 8 && Nb <= 64)
     return dtype == DRN_BF16 ? launch_conv_ks<DRN_BF16>(p, st)
            : dtype == DRN_FP8 ? launch_conv_ks<DRN_FP8>(p, st) : launch_conv_ks<DRN_F32>(p, st);
   if (dtype == DRN_BF16)
