@@ -15,7 +15,6 @@ import bisect
 import math
 
 import numpy as np
-import os
 
 import torch
 import torch.distributed as dist
@@ -823,9 +822,11 @@ class GraphedTrainStep:
     def _pool_next(self, slot=None):
         """pooled fc6 operand (A, A^T) of the staged next batch + hand its proposals over to the heads"""
         feat = self.feat_next if slot is None else self._feats[slot]
-        self.pooled = self.engine.pool(feat, self.rois_next, self.obj_next, True, slot=0)
-        # the heads only need the pooled operand and the proposal boxes (pseudo-GT mining / IoU labelling) of a batch
+        # the heads only need the pooled operand and the proposal boxes (pseudo-GT mining / IoU labelling) of a batch; the
+        # small copy goes IN FRONT of the pooling kernel (its last reader, the previous heads graph, is long done) so that
+        # nothing sits between the pooling and the fc6 forward
         self.props.copy_(self.rois_next[:, 1:])
+        self.pooled = self.engine.pool(feat, self.rois_next, self.obj_next, True, slot=0)
 
     # ---- the three captured pieces ---------------------------------------------------------------------------
     def _bb_body(self, slot=None):
@@ -839,6 +840,11 @@ class GraphedTrainStep:
     def last_state(self):
         """intermediate values (MIL scores, image scores, pseudo-GT rows, labels) of the step that ran last"""
         return self._captured_state if getattr(self, "_replayed", False) else self._eager_state
+
+    def _heads(self, eager):
+        """fc6 forward (eager, when timed) + the heads graph of the current batch on the current stream"""
+        self._fc6_eager()
+        return self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
 
     def _fc6_eager(self):
         if self.eager_fc6:
@@ -876,8 +882,7 @@ class GraphedTrainStep:
         s1, sL = (t + 1) % L, (t + L) % L
         side = self._sides[t % (L - 1)]
         side.wait_stream(main)
-        self._fc6_eager()
-        losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
+        losses = self._heads(eager)
         if self.split_tail:
             self.engine.run_fc1_tail()
         with torch.cuda.stream(side):
@@ -950,9 +955,9 @@ class GraphedTrainStep:
     def _pair_pool_body(self, ps, half):
         with torch.no_grad():
             n = self.n_img
+            self.props.copy_(self.rois_next[:, 1:])  # in front of the pooling kernel (see _pool_next)
             self.pooled = self.engine.pool(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next, True,
                                            slot=0)
-            self.props.copy_(self.rois_next[:, 1:])
 
     def _run_pairs(self, eager, next_batch, b2, b3):
         """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % 2.  Even t: the conv chain of pair t/2 + 1
@@ -961,8 +966,7 @@ class GraphedTrainStep:
         main = torch.cuda.current_stream()
         t = self._t
         self._side.wait_stream(main)
-        self._fc6_eager()
-        losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
+        losses = self._heads(eager)
         if self.split_tail:
             self.engine.run_fc1_tail()
         if t % 2 == 0:
@@ -1027,8 +1031,7 @@ class GraphedTrainStep:
         self._side.wait_stream(main)  # staged image is in place; previous pooling has consumed feat_next
         # submit the heads graph FIRST: submitting a graph costs the host ~9 us per node, and the backbone graph has
         # 49 nodes - issued first it would leave the main stream idle for ~0.45 ms in front of the fc6 GEMM
-        self._fc6_eager()
-        losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
+        losses = self._heads(eager)
         if self.split_tail:
             self.engine.run_fc1_tail()  # eager: dW slabs on this stream, all-reduce + SGD per bucket on the optimizer stream
         with torch.cuda.stream(self._side):
