@@ -17,6 +17,9 @@
 // detectron2/layers/batch_norm.py:45-65, projects/WSL/wsl/modeling/backbone/resnet_ws.py:217-237).
 #include "drn_common.h"
 
+#include <type_traits>
+#include <utility>
+
 namespace {
 
 struct GemmParams {
@@ -167,6 +170,23 @@ struct ConvLoader {
 #ifndef CONV_DEPTH1
 #define CONV_DEPTH1 4  // register-ring depth of the single-LDS-stage 64x64 conv (98 VGPRs; 5 -> 114 > the 112 that co-reside with a GEMM workgroup)
 #endif
+// compile-time loop: f(std::integral_constant<int, 0>{}) ... f(std::integral_constant<int, N - 1>{})
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// Register-staged mainloop (global -> ring of DEPTH register sets -> LDS -> MFMA).  The slab loop runs in two parts:
+// a STEADY STATE of whole groups of DEPTH slabs in which every slab issues the loads of slab i + DEPTH and stores the
+// registers of slab i + 1 unconditionally, then the last < 2 * DEPTH slabs with the bounds checks.  With the checks inside
+// the only loop (round 1 / first half of round 2) the compiler's wait-count pass lost track of the ring across the
+// branches and put `s_waitcnt vmcnt(0)` in front of every LDS store - it waited for the loads issued in the SAME
+// iteration, i.e. the ring prefetched one slab ahead whatever its depth (which is why ring depth 3 / 4 / 5 all measured
+// ~0.55 us per slab).  Branch-free, the waits become counted (vmcnt = loads of the DEPTH - 1 younger slabs).
 template <int DT, int BM, int BN, class ALoader, class BLoader, int STAGES = 2>
 __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char* smem, ALoader& la,
                                          const BLoader& lb, int s0, int s1) {
@@ -187,40 +207,44 @@ __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char
   lds_store_tile<BM>(smem, ra[0], tid);
   lds_store_tile<BN>(smem + A_BYTES, rb[0], tid);
   __syncthreads();
-  for (int base = 0; base < n; base += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      const int i = base + d;
-      if (i < n) {
-        char* cur = smem + (i & 1) * STAGE;
-        char* nxt = smem + ((i & 1) ^ 1) * STAGE;
-        if (i + DEPTH < n) {  // ring slot d held slab i, which already sits in LDS
-          la.template load<BM>(ra[d], s0 + i + DEPTH, tid);
-          lb.template load<BN>(rb[d], s0 + i + DEPTH, tid);
-        }
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          i32x4_t fa[MI], fb[NJ];
-          const int slot = ks * 2 + (lane >> 5);
-#pragma unroll
-          for (int ii = 0; ii < MI; ++ii) fa[ii] = *(const i32x4_t*)(cur + swz(wm * (BM / 2) + ii * 32 + (lane & 31), slot));
-#pragma unroll
-          for (int j = 0; j < NJ; ++j)
-            fb[j] = *(const i32x4_t*)(cur + A_BYTES + swz(wn * (BN / 2) + j * 32 + (lane & 31), slot));
-#pragma unroll
-          for (int ii = 0; ii < MI; ++ii)
-#pragma unroll
-            for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[ii][j], fa[ii], fb[j]);
-        }
-        if (STAGES == 1) __syncthreads();  // every wave is done reading the only stage
-        if (i + 1 < n) {
-          lds_store_tile<BM>(nxt, ra[(d + 1) % DEPTH], tid);
-          lds_store_tile<BN>(nxt + A_BYTES, rb[(d + 1) % DEPTH], tid);
-        }
-        __syncthreads();
-      }
+  auto slab = [&](auto dtag, int i, auto fulltag) {
+    constexpr int d = decltype(dtag)::value;
+    constexpr bool FULL = decltype(fulltag)::value;
+    char* cur = smem + (i & 1) * STAGE;
+    char* nxt = smem + ((i & 1) ^ 1) * STAGE;
+    if (FULL || i + DEPTH < n) {  // ring slot d held slab i, which already sits in LDS
+      la.template load<BM>(ra[d], s0 + i + DEPTH, tid);
+      lb.template load<BN>(rb[d], s0 + i + DEPTH, tid);
     }
-  }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      i32x4_t fa[MI], fb[NJ];
+      const int slot = ks * 2 + (lane >> 5);
+#pragma unroll
+      for (int ii = 0; ii < MI; ++ii) fa[ii] = *(const i32x4_t*)(cur + swz(wm * (BM / 2) + ii * 32 + (lane & 31), slot));
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+        fb[j] = *(const i32x4_t*)(cur + A_BYTES + swz(wn * (BN / 2) + j * 32 + (lane & 31), slot));
+#pragma unroll
+      for (int ii = 0; ii < MI; ++ii)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[ii][j], fa[ii], fb[j]);
+    }
+    if (STAGES == 1) __syncthreads();  // every wave is done reading the only stage
+    if (FULL || i + 1 < n) {
+      lds_store_tile<BM>(nxt, ra[(d + 1) % DEPTH], tid);
+      lds_store_tile<BN>(nxt + A_BYTES, rb[(d + 1) % DEPTH], tid);
+    }
+    __syncthreads();
+  };
+  int base = 0;
+  for (; base + 2 * DEPTH <= n; base += DEPTH)  // every i here has i + DEPTH < n (and i + 1 < n)
+    static_for<DEPTH>([&](auto dtag) { slab(dtag, base + decltype(dtag)::value, std::true_type{}); });
+  for (; base < n; base += DEPTH)
+    static_for<DEPTH>([&](auto dtag) {
+      const int i = base + decltype(dtag)::value;
+      if (i < n) slab(dtag, i, std::false_type{});
+    });
 }
 
 // logical tile id -> (tm, tn), grouped so that a contiguous id range (one XCD's share) covers a
@@ -1026,27 +1050,31 @@ __global__ __launch_bounds__(256) void conv_nhwc_ks_kernel(ConvParams p) {
   lds_store_tile<32>(smem + 32 * 128, rb[0], tid);
   __syncthreads();
   const int slot = wave * 2 + (lane >> 5);
-  for (int base = 0; base < n; base += DEPTH) {
-#pragma unroll
-    for (int d = 0; d < DEPTH; ++d) {
-      const int i = base + d;
-      if (i < n) {
-        if (i + DEPTH < n) {
-          la.template load<32>(ra[d], i + DEPTH, tid);
-          lb.template load<32>(rb[d], i + DEPTH, tid);
-        }
-        const i32x4_t fa = *(const i32x4_t*)(smem + swz(lane & 31, slot));
-        const i32x4_t fb = *(const i32x4_t*)(smem + 32 * 128 + swz(lane & 31, slot));
-        mma_step<DT>(acc, fa, fb);
-        __syncthreads();
-        if (i + 1 < n) {
-          lds_store_tile<32>(smem, ra[(d + 1) % DEPTH], tid);
-          lds_store_tile<32>(smem + 32 * 128, rb[(d + 1) % DEPTH], tid);
-        }
-        __syncthreads();
-      }
+  auto slab = [&](auto dtag, int i, auto fulltag) {  // steady state / bounds-checked tail: see mainloop()
+    constexpr int d = decltype(dtag)::value;
+    constexpr bool FULL = decltype(fulltag)::value;
+    if (FULL || i + DEPTH < n) {
+      la.template load<32>(ra[d], i + DEPTH, tid);
+      lb.template load<32>(rb[d], i + DEPTH, tid);
     }
-  }
+    const i32x4_t fa = *(const i32x4_t*)(smem + swz(lane & 31, slot));
+    const i32x4_t fb = *(const i32x4_t*)(smem + 32 * 128 + swz(lane & 31, slot));
+    mma_step<DT>(acc, fa, fb);
+    __syncthreads();
+    if (FULL || i + 1 < n) {
+      lds_store_tile<32>(smem, ra[(d + 1) % DEPTH], tid);
+      lds_store_tile<32>(smem + 32 * 128, rb[(d + 1) % DEPTH], tid);
+    }
+    __syncthreads();
+  };
+  int base = 0;
+  for (; base + 2 * DEPTH <= n; base += DEPTH)
+    static_for<DEPTH>([&](auto dtag) { slab(dtag, base + decltype(dtag)::value, std::true_type{}); });
+  for (; base < n; base += DEPTH)
+    static_for<DEPTH>([&](auto dtag) {
+      const int i = base + decltype(dtag)::value;
+      if (i < n) slab(dtag, i, std::false_type{});
+    });
   // the four k-step partials, as [wave][row][col] fp32
   float* part = (float*)smem;
 #pragma unroll
