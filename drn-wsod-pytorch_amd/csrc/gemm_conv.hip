@@ -189,11 +189,12 @@ __device__ __forceinline__ void static_for(F&& f) {
 // ~0.55 us per slab).  Branch-free, the waits become counted (vmcnt = loads of the DEPTH - 1 younger slabs).
 template <int DT, int BM, int BN, class ALoader, class BLoader, int STAGES = 2>
 __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char* smem, ALoader& la,
-                                         const BLoader& lb, int s0, int s1) {
+                                         const BLoader& lb, int s0, int s1, int tid = threadIdx.x) {
+  // tid: 0..255 within the four waves that share this tile's LDS stage (conv_nhwc_k2_kernel runs two such groups)
   constexpr int MI = BM / 64, NJ = BN / 64;
   constexpr int A_BYTES = BM * 128, STAGE = STAGES == 2 ? (BM + BN) * 128 : 0;
   constexpr int DEPTH = STAGES == 1 ? CONV_DEPTH1 : (BM <= 64 ? 4 : 3);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   i32x4_t ra[DEPTH][BM / 32], rb[DEPTH][BN / 32];
   const int n = s1 - s0;
@@ -863,44 +864,14 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
   }
 }
 
+// Epilogue of the tiled conv kernels: per-channel affine (+ residual, ReLU) and the store.  `tid` = 0..255 within the
+// four waves that own the accumulators; `active` = false for waves that only take part in the barriers (the second
+// K-group of conv_nhwc_k2_kernel, whose partial sums were already added in).
 template <int DT, int BM, int BN>
-__global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  constexpr int ES = EsOf<DT>::value;
+__device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&acc)[BM / 64][BN / 64], char* smem, int bm,
+                                              int bn, int Mtot, int tid, bool active) {
   constexpr int MI = BM / 64, NJ = BN / 64;
-  const int Mtot = p.Nb * p.Ho * p.Wo;
-  const int tiles_m = (Mtot + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
-  int tm, tn;
-  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
-  const int bm = tm * BM, bn = tn * BN;
-  ConvLoader<DT, BM> la;
-  la.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((long)p.Nb * p.H * p.W * p.Cin * ES), 0x00020000);
-  la.H = p.H; la.W = p.W; la.Cin = p.Cin; la.KW = p.KW; la.dil = p.dil; la.ntaps = p.KH * p.KW;
-  const int r0 = threadIdx.x >> 3;
-#pragma unroll
-  for (int q = 0; q < BM / 32; ++q) {
-    const int m = bm + r0 + 32 * q;
-    if (m < Mtot) {
-      const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
-      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
-      la.hi0[q] = ho * p.stride - p.pad;
-      la.wi0[q] = wo * p.stride - p.pad;
-      la.nbase[q] = (unsigned)((long)n * p.H * p.W * p.Cin * ES);
-    } else {
-      la.hi0[q] = 0; la.wi0[q] = 0; la.nbase[q] = ConvLoader<DT, BM>::OOB;
-    }
-  }
-  const RowLoader lb = make_row_loader(p.Wt, bn, p.Cout, BN, p.ldw * ES);
-  f32x16_t acc[MI][NJ];
-#pragma unroll
-  for (int i = 0; i < MI; ++i)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  const int nslab = (p.Ktot * ES + 127) / 128;
-  mainloop<DT, BM, BN, decltype(la), decltype(lb), (BM == 64 && BN == 64) ? 1 : 2>(acc, smem, la, lb, 0, nslab);
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   // bf16 output (+ bf16 residual): the affine result goes through LDS as fp32 [BM][BN] (exactly the mainloop's LDS, now
   // free) so that every lane then owns 8 consecutive channels of a pixel - 16-byte residual loads and 16-byte stores,
@@ -913,22 +884,25 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
   if (vec_epi) {
     float* tile = (float*)smem;
     __syncthreads();  // the last slab's LDS reads are done
+    if (active) {
 #pragma unroll
-    for (int j = 0; j < NJ; ++j) {
-      const int nl = wn * (BN / 2) + j * 32 + (lane & 31), n = bn + nl;
-      const float sc = (n < p.Cout && p.scale) ? p.scale[n] : 1.f;
-      const float bi = (n < p.Cout && p.bias) ? p.bias[n] : 0.f;
+      for (int j = 0; j < NJ; ++j) {
+        const int nl = wn * (BN / 2) + j * 32 + (lane & 31), n = bn + nl;
+        const float sc = (n < p.Cout && p.scale) ? p.scale[n] : 1.f;
+        const float bi = (n < p.Cout && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
-      for (int i = 0; i < MI; ++i)
+        for (int i = 0; i < MI; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int ml = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-          tile[ml * BN + nl] = acc[i][j][r] * sc + bi;
-        }
+          for (int r = 0; r < 16; ++r) {
+            const int ml = wm * (BM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            tile[ml * BN + nl] = acc[i][j][r] * sc + bi;
+          }
+      }
     }
     __syncthreads();
+    if (!active) return;
     constexpr int LPR = BN / 8, RPP = 256 / LPR, NR = BM / RPP;  // lanes per row, rows per pass, rows per lane
-    const int cl = threadIdx.x % LPR, rl = threadIdx.x / LPR;
+    const int cl = tid % LPR, rl = tid / LPR;
     const int n = bn + cl * 8;
     if (n >= p.Cout) return;
     i32x4_t rv[NR];
@@ -960,6 +934,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
     }
     return;
   }
+  if (!active) return;
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {
     const int n = bn + wn * (BN / 2) + j * 32 + (lane & 31);
@@ -998,6 +973,101 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
         }
       }
   }
+}
+
+template <int DT, int BM, int BN>
+__global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  constexpr int ES = EsOf<DT>::value;
+  constexpr int MI = BM / 64, NJ = BN / 64;
+  const int Mtot = p.Nb * p.Ho * p.Wo;
+  const int tiles_m = (Mtot + BM - 1) / BM, tiles_n = (p.Cout + BN - 1) / BN;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+  const int bm = tm * BM, bn = tn * BN;
+  ConvLoader<DT, BM> la;
+  la.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((long)p.Nb * p.H * p.W * p.Cin * ES), 0x00020000);
+  la.H = p.H; la.W = p.W; la.Cin = p.Cin; la.KW = p.KW; la.dil = p.dil; la.ntaps = p.KH * p.KW;
+  const int r0 = threadIdx.x >> 3;
+#pragma unroll
+  for (int q = 0; q < BM / 32; ++q) {
+    const int m = bm + r0 + 32 * q;
+    if (m < Mtot) {
+      const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      la.hi0[q] = ho * p.stride - p.pad;
+      la.wi0[q] = wo * p.stride - p.pad;
+      la.nbase[q] = (unsigned)((long)n * p.H * p.W * p.Cin * ES);
+    } else {
+      la.hi0[q] = 0; la.wi0[q] = 0; la.nbase[q] = ConvLoader<DT, BM>::OOB;
+    }
+  }
+  const RowLoader lb = make_row_loader(p.Wt, bn, p.Cout, BN, p.ldw * ES);
+  f32x16_t acc[MI][NJ];
+#pragma unroll
+  for (int i = 0; i < MI; ++i)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nslab = (p.Ktot * ES + 127) / 128;
+  mainloop<DT, BM, BN, decltype(la), decltype(lb), (BM == 64 && BN == 64) ? 1 : 2>(acc, smem, la, lb, 0, nslab);
+  conv_epilogue<DT, BM, BN>(p, acc, smem, bm, bn, Mtot, threadIdx.x, true);
+}
+
+// Mid-size layers (the res3 / res4 convs of a real-size image: a few hundred 64x64 tiles, 8 .. 72 K-slabs): one 64x64 tile
+// per CU on four waves is latency-bound (~0.5 us per slab), the 32x32 wave-K-split kernel moves 2x the operand bytes per
+// flop and runs into the L2 bandwidth (res4 3x3 on 3800 pixels: 952 workgroups x 36 slabs x 8 KB = 274 MB in 16 us).
+// Here TWO groups of four waves share one 64x64 tile: group g multiplies the K-slabs [g * n/2, (g + 1) * n/2) out of
+// its own 16-KB LDS stage with its own register ring - twice the loads in flight and twice the MFMA issue per tile, the
+// operand bytes of the 64x64 tiling - and group 1's partial tile is added to group 0's through LDS (fixed order) in
+// front of the common epilogue.  Needs an even slab count; chosen on ONE image's geometry like the other variants.
+template <int DT>
+__global__ __launch_bounds__(512) void conv_nhwc_k2_kernel(ConvParams p) {  // (forcing 128 VGPRs for two workgroups per CU: 8 B of scratch, res4 layers 3 % slower, not kept)
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 16 KB
+  constexpr int ES = EsOf<DT>::value;
+  const int Mtot = p.Nb * p.Ho * p.Wo;
+  const int tiles_m = (Mtot + 63) / 64, tiles_n = (p.Cout + 63) / 64;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn);
+  const int bm = tm * 64, bn = tn * 64;
+  const int tid = threadIdx.x & 255, g = threadIdx.x >> 8;
+  ConvLoader<DT, 64> la;
+  la.rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((long)p.Nb * p.H * p.W * p.Cin * ES), 0x00020000);
+  la.H = p.H; la.W = p.W; la.Cin = p.Cin; la.KW = p.KW; la.dil = p.dil; la.ntaps = p.KH * p.KW;
+  const int r0 = tid >> 3;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int m = bm + r0 + 32 * q;
+    if (m < Mtot) {
+      const int n = m / (p.Ho * p.Wo), rem = m - n * p.Ho * p.Wo;
+      const int ho = rem / p.Wo, wo = rem - ho * p.Wo;
+      la.hi0[q] = ho * p.stride - p.pad;
+      la.wi0[q] = wo * p.stride - p.pad;
+      la.nbase[q] = (unsigned)((long)n * p.H * p.W * p.Cin * ES);
+    } else {
+      la.hi0[q] = 0; la.wi0[q] = 0; la.nbase[q] = ConvLoader<DT, 64>::OOB;
+    }
+  }
+  const RowLoader lb = make_row_loader(p.Wt, bn, p.Cout, 64, p.ldw * ES);
+  f32x16_t acc[1][1];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+  const int half = ((p.Ktot * ES + 127) / 128) >> 1;  // launcher: the slab count is even
+  mainloop<DT, 64, 64, decltype(la), decltype(lb), 1>(acc, smem + g * (128 * 128), la, lb, g * half, (g + 1) * half, tid);
+  // group 1's partial tile -> LDS (its own stage: nobody reads it any more), added by group 0 lane for lane
+  const int lane = tid & 63, wave = tid >> 6;
+  float* part = (float*)(smem + 128 * 128) + wave * 1024 + lane;
+  if (g == 1) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) part[r * 64] = acc[0][0][r];
+  }
+  __syncthreads();
+  if (g == 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[0][0][r] += part[r * 64];
+  }
+  conv_epilogue<DT, 64, 64>(p, acc, smem, bm, bn, Mtot, tid, g == 0);
 }
 
 // Small-map convolution: 32 x 32 output tile per workgroup, the K range of every 128-byte slab split over the FOUR WAVES
@@ -1215,6 +1285,7 @@ static int persistent_grid(long total) {
 }
 
 static int g_conv_ksplit = 1;  // drn_tune(DRN_TUNE_CONV_KSPLIT): 0 = never use the 32x32 wave-K-split kernel
+static int g_conv_k2_tiles = -1;  // drn_tune(DRN_TUNE_CONV_K2_TILES): largest 64x64-tile count of ONE image for the two-K-group kernel (-1 = 2 x CUs, 0 = off)
 static int g_conv_ks_tiles = 0;  // drn_tune(DRN_TUNE_CONV_KS_TILES): largest 64x64-tile count of ONE image that still takes it (0 = CUs / 4)
 
 template <int DT>
@@ -1222,6 +1293,15 @@ int launch_conv_ks(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
   const int tiles = ((Mtot + 31) / 32) * ((p.Cout + 31) / 32);
   hipLaunchKernelGGL((conv_nhwc_ks_kernel<DT>), dim3(tiles), dim3(256), 0, st, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+template <int DT>
+int launch_conv_k2(const ConvParams& p, hipStream_t st) {
+  const int Mtot = p.Nb * p.Ho * p.Wo;
+  const int tiles = ((Mtot + 63) / 64) * ((p.Cout + 63) / 64);
+  hipLaunchKernelGGL((conv_nhwc_k2_kernel<DT>), dim3(tiles), dim3(512), 2 * 128 * 128, st, p);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }
@@ -1270,6 +1350,11 @@ int drn_tune(int knob, int value) {
   if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
     const int old = g_conv_ksplit;
     g_conv_ksplit = value != 0;
+    return old;
+  }
+  if (knob == 8) {  // DRN_TUNE_CONV_K2_TILES
+    const int old = g_conv_k2_tiles;
+    g_conv_k2_tiles = value;
     return old;
   }
   if (knob == 7) {  // DRN_TUNE_CONV_KS_TILES
@@ -1409,6 +1494,12 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   // (round 2, tools/conv_bench.py at 800x1216: up to one 64x64 tile per CU the 36-slab res4 3x3 still gains, 23.1 ->
   // 20.5 us, while layers with few slabs lose - the 9-slab stem 3x3 8.6 -> 9.7 us at 224x224: deep K only)
   const long ks_max = g_conv_ks_tiles > 0 ? g_conv_ks_tiles : (nslab >= 32 ? cu_count() : cu_count() / 4);
+  // two K-groups per 64x64 tile (conv_nhwc_k2_kernel): mid-size layers - more 64x64 tiles than the wave-K-split kernel
+  // takes, at most one per CU (the kernel keeps one 512-thread workgroup per CU) - with an even slab count >= 8
+  const long k2_max = g_conv_k2_tiles >= 0 ? g_conv_k2_tiles : cu_count();
+  if ((nslab & 1) == 0 && nslab >= 8 && tiles64 > cu_count() / 4 && tiles64 <= k2_max && Nb <= 64)
+    return dtype == DRN_BF16 ? launch_conv_k2<DRN_BF16>(p, st)
+           : dtype == DRN_FP8 ? launch_conv_k2<DRN_FP8>(p, st) : launch_conv_k2<DRN_F32>(p, st);
   if (g_conv_ksplit && tiles64 <= ks_max && nslab >= 8 && Nb <= 64)
     return dtype == DRN_BF16 ? launch_conv_ks<DRN_BF16>(p, st)
            : dtype == DRN_FP8 ? launch_conv_ks<DRN_FP8>(p, st) : launch_conv_ks<DRN_F32>(p, st);

@@ -147,6 +147,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_ROI_MAP64 4 /* 64-ROI x 8-channel whole-map ROIPool for the bf16 (A, A^T) pair: 0 = off, else threads per workgroup (256 / 512 / 1024, default 512) */
 #define DRN_TUNE_GEMM_TAIL_SPLIT 6 /* 0/1: a persistent 256x256 launch whose last round would be < 3/8 full runs an exact number of rounds; the peeled tile columns go to the small-tile kernel first (default 1; bit-identical) */
 #define DRN_TUNE_CONV_KS_TILES 7 /* largest number of 64x64 tiles of ONE image's layer that still runs on the wave-K-split conv kernel (0 = default: CUs / 4) */
+#define DRN_TUNE_CONV_K2_TILES 8 /* largest number of 64x64 tiles of ONE image's layer that runs two K-groups per tile (conv_nhwc_k2_kernel); -1 = default (2 x CUs), 0 = off */
 int drn_tune(int knob, int value);
 
 /* relu_(fc(x)) + F.dropout(p), box_head.py:88-90: sums split-K partials, adds bias, ReLU, dropout
