@@ -1015,6 +1015,174 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
   conv_epilogue<DT, BM, BN>(p, acc, smem, bm, bn, Mtot, threadIdx.x, true);
 }
 
+// 3x3 / stride 1 / 64 -> 64 channels on LARGE maps (stem.conv2/3 and the res2 3x3s of a real-size image: 60k-240k pixels).
+// The im2col tiling fetches every input pixel nine times - 128-row tiles x 9 slabs x 16 KB + the weights again per tile:
+// 420 MB through L2 for the 31-MB stem layer at 800x1216, which bounds it at ~52 us = 8 TB/s of L2 traffic.  Here a
+// workgroup owns an 8 x 32 block of output pixels of one image: the 10 x 34 x 64-channel input patch (43.5 KB) and ALL
+// weights (9 taps x 64 x 64 = 73.7 KB) are brought into LDS ONCE (zero padding = out-of-range buffer offsets), then the
+// whole K loop - 9 taps x 4 k-steps x (2 x 2) MFMAs per wave - runs out of LDS with no barrier and no global load: the
+// A fragment of tap (dy, dx) is the patch row of pixel (y + dy, x + dx), 16 bytes per lane, swizzled like every other
+// 128-byte-row LDS image here.  Same k order and MFMA as the tiled kernels (tap-major, channels ascending).
+constexpr int P3_TH = 8, P3_TW = 32, P3_PH = P3_TH + 2, P3_PW = P3_TW + 2;
+constexpr int P3_PATCH = P3_PH * P3_PW * 128, P3_WTS = 9 * 64 * 128;
+constexpr int P3_NCH = P3_PH * P3_PW * 8, P3_NIT = (P3_NCH + 255) / 256;  // 16-byte chunks of a patch, per-thread share
+// PERSISTENT: one workgroup per CU keeps the weights in LDS and walks its XCD's share of the pixel blocks; the patch of
+// the NEXT block is fetched into registers while the current one is multiplied, so per block only the LDS store of the
+// patch, the MFMA phase and the epilogue (two 128-pixel halves staged as fp32 in the dead patch area) remain.
+template <bool RES>
+__global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  char* patch = smem;
+  char* wts = smem + P3_PATCH;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tiles_x = (p.Wo + P3_TW - 1) / P3_TW, tiles_y = (p.Ho + P3_TH - 1) / P3_TH;
+  const int per_img = tiles_y * tiles_x, total = p.Nb * per_img;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((long)p.Nb * p.H * p.W * 128), 0x00020000);
+  auto fetch = [&](int t, i32x4_t (&v)[P3_NIT]) {  // block t's patch -> registers (zero padding = out-of-range offsets)
+    const int n = t / per_img, tt = t - n * per_img;
+    const int y0 = (tt / tiles_x) * P3_TH, x0 = (tt % tiles_x) * P3_TW;
+#pragma unroll
+    for (int it = 0; it < P3_NIT; ++it) {
+      const int c = it * 256 + tid, pix = c >> 3, ch = c & 7;
+      const int py = pix / P3_PW, px = pix - py * P3_PW;
+      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
+      const bool ok = c < P3_NCH && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const unsigned off = ok ? (unsigned)((((long)n * p.H + iy) * p.W + ix) * 128 + ch * 16) : 0xFFFFFFF0u;
+      v[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
+    }
+  };
+  int k = blockIdx.x;
+  if (k >= total) return;
+  i32x4_t pv[P3_NIT];
+  fetch(xcd_remap(k, total), pv);
+  // weights: [64 cout][ldw] with k = tap * 64 + ci -> LDS [tap][cout][128 B], once per workgroup
+  {
+    const char* wg = p.Wt;
+    const long ldw_b = p.ldw * 2;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      i32x4_t v[9];
+#pragma unroll
+      for (int it = 0; it < 9; ++it) {
+        const int c = (half * 9 + it) * 256 + tid;  // 0 .. 4607
+        const int tap = c >> 9, co = (c >> 3) & 63, ch = c & 7;
+        v[it] = *(const i32x4_t*)(wg + co * ldw_b + tap * 128 + ch * 16);
+      }
+#pragma unroll
+      for (int it = 0; it < 9; ++it) {
+        const int c = (half * 9 + it) * 256 + tid;
+        const int tap = c >> 9, co = (c >> 3) & 63, ch = c & 7;
+        *(i32x4_t*)(wts + tap * (64 * 128) + swz(co, ch)) = v[it];
+      }
+    }
+  }
+  const int lx = lane & 31, lh = lane >> 5;
+  // this lane's two output channels' affine, once per workgroup (inside the block loop each half of every epilogue paid
+  // a global-load latency for them: one wave per SIMD hides nothing - 16 of 38 us on the stem layer at 800x1216)
+  float sc2[2], bi2[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    sc2[j] = p.scale ? p.scale[j * 32 + lx] : 1.f;
+    bi2[j] = p.bias ? p.bias[j * 32 + lx] : 0.f;
+  }
+  for (; k < total; k += gridDim.x) {
+    const int t = xcd_remap(k, total);
+    const int n = t / per_img, tt = t - n * per_img;
+    const int y0 = (tt / tiles_x) * P3_TH, x0 = (tt % tiles_x) * P3_TW;
+#pragma unroll
+    for (int it = 0; it < P3_NIT; ++it) {
+      const int c = it * 256 + tid;
+      if (c < P3_NCH) *(i32x4_t*)(patch + swz(c >> 3, c & 7)) = pv[it];
+    }
+    __syncthreads();
+    if (k + (int)gridDim.x < total) fetch(xcd_remap(k + gridDim.x, total), pv);  // lands under the MFMA phase
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    // 36 k-steps (9 taps x 4), software-pipelined by hand: one wave per SIMD has nobody to hide its LDS latency behind,
+    // so the fragments of step s + 1 are requested before the four MFMAs of step s are issued
+    i32x4_t fa[2][2], fb[2][2];
+    auto frags = [&](int s_, i32x4_t (&a)[2], i32x4_t (&b)[2]) {
+      const int tap = s_ >> 2, ks = s_ & 3, dy = tap / 3, dx = tap - dy * 3, slot = ks * 2 + lh;
+#pragma unroll
+      for (int i = 0; i < 2; ++i) a[i] = *(const i32x4_t*)(patch + swz((wave * 2 + i + dy) * P3_PW + lx + dx, slot));
+#pragma unroll
+      for (int j = 0; j < 2; ++j) b[j] = *(const i32x4_t*)(wts + tap * (64 * 128) + swz(j * 32 + lx, slot));
+    };
+    frags(0, fa[0], fb[0]);
+#pragma unroll
+    for (int s_ = 0; s_ < 36; ++s_) {
+      if (s_ + 1 < 36) frags(s_ + 1, fa[(s_ + 1) & 1], fb[(s_ + 1) & 1]);
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) mma_step<DRN_BF16>(acc[i][j], fa[s_ & 1][i], fb[s_ & 1][j]);
+      // one k-step's reads, then one k-step's MFMAs: keep the compiler from sinking the reads to their first use
+      __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+      __builtin_amdgcn_sched_group_barrier(0x008, 4, 0);
+    }
+    // epilogue: affine -> fp32 [128 pixels][64 channels] in the (dead) patch area, one half of the block at a time -> 8
+    // channels per lane: residual, ReLU, 16-byte stores
+    float* tile = (float*)patch;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+      __syncthreads();  // patch reads (half 0) / the other half's tile reads (half 1) are done
+      if ((wave >> 1) == half) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int nl = j * 32 + lx;
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+              const int ml = (wave & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+              tile[ml * 64 + nl] = acc[i][j][r] * sc2[j] + bi2[j];
+            }
+        }
+      }
+      // (the residual chunks of this half are requested BEFORE the barrier and all stores follow in one run: with the load
+      // inside the store loop the compiler's wait for it also waited for the previous iteration's store - eight exposed
+      // store latencies per block, 16 of 38 us on the stem layer at 800x1216)
+      i32x4_t rv[4];
+      if constexpr (RES) {
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+          const int idx = it * 256 + tid, ml = idx >> 3, cg = idx & 7;
+          const int y = min(y0 + half * 4 + (ml >> 5), p.Ho - 1), x = min(x0 + (ml & 31), p.Wo - 1);
+          rv[it] = *(const i32x4_t*)((const bf16_t*)p.residual + (((long)n * p.Ho + y) * p.Wo + x) * p.ldres + cg * 8);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 4; ++it) {
+        const int idx = it * 256 + tid, ml = idx >> 3, cg = idx & 7;
+        const int y = y0 + half * 4 + (ml >> 5), x = x0 + (ml & 31);
+        const long m = ((long)n * p.Ho + y) * p.Wo + x;
+        const f32x4_t lo = *(const f32x4_t*)(tile + ml * 64 + cg * 8), hi = *(const f32x4_t*)(tile + ml * 64 + cg * 8 + 4);
+        float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        i32x4_t o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if constexpr (RES) {
+            const uint32_t w = (uint32_t)rv[it][e];
+            v[2 * e] += __builtin_bit_cast(float, w << 16) * p.res_mult;
+            v[2 * e + 1] += __builtin_bit_cast(float, w & 0xffff0000u) * p.res_mult;
+          }
+          if (p.relu) { v[2 * e] = fmaxf(v[2 * e], 0.f); v[2 * e + 1] = fmaxf(v[2 * e + 1], 0.f); }
+          o[e] = (int)((uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16));
+        }
+        if (y < p.Ho && x < p.Wo) *(i32x4_t*)((bf16_t*)p.Y + m * p.ldy + cg * 8) = o;
+      }
+    }
+    __syncthreads();  // tile reads done before the next block's patch overwrites the area
+  }
+}
+
 // Mid-size layers (the res3 / res4 convs of a real-size image: a few hundred 64x64 tiles, 8 .. 72 K-slabs): one 64x64 tile
 // per CU on four waves is latency-bound (~0.5 us per slab), the 32x32 wave-K-split kernel moves 2x the operand bytes per
 // flop and runs into the L2 bandwidth (res4 3x3 on 3800 pixels: 952 workgroups x 36 slabs x 8 KB = 274 MB in 16 us).
@@ -1285,6 +1453,8 @@ static int persistent_grid(long total) {
 }
 
 static int g_conv_ksplit = 1;  // drn_tune(DRN_TUNE_CONV_KSPLIT): 0 = never use the 32x32 wave-K-split kernel
+static int g_conv_patch = 1;  // drn_tune(DRN_TUNE_CONV_PATCH): 0 = never use conv3x3_c64_kernel; > 1 = minimum pixels per image
+static long g_conv_patch_min = 32768;
 static int g_conv_k2_tiles = -1;  // drn_tune(DRN_TUNE_CONV_K2_TILES): largest 64x64-tile count of ONE image for the two-K-group kernel (-1 = 2 x CUs, 0 = off)
 static int g_conv_ks_tiles = 0;  // drn_tune(DRN_TUNE_CONV_KS_TILES): largest 64x64-tile count of ONE image that still takes it (0 = CUs / 4)
 
@@ -1293,6 +1463,23 @@ int launch_conv_ks(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
   const int tiles = ((Mtot + 31) / 32) * ((p.Cout + 31) / 32);
   hipLaunchKernelGGL((conv_nhwc_ks_kernel<DT>), dim3(tiles), dim3(256), 0, st, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+static int launch_conv3x3_c64(const ConvParams& p, hipStream_t st) {
+  const int tiles = p.Nb * ((p.Ho + P3_TH - 1) / P3_TH) * ((p.Wo + P3_TW - 1) / P3_TW);
+  constexpr int smem = P3_PATCH + P3_WTS;  // 117 KB: one workgroup per CU
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DRN_ERR_LAUNCH;
+    attr = true;
+  }
+  const int nwg = tiles < cu_count() ? tiles : cu_count();  // persistent: one workgroup per CU walks the pixel blocks
+  if (p.residual) hipLaunchKernelGGL(conv3x3_c64_kernel<true>, dim3(nwg), dim3(256), smem, st, p);
+  else hipLaunchKernelGGL(conv3x3_c64_kernel<false>, dim3(nwg), dim3(256), smem, st, p);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }
@@ -1350,6 +1537,12 @@ int drn_tune(int knob, int value) {
   if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
     const int old = g_conv_ksplit;
     g_conv_ksplit = value != 0;
+    return old;
+  }
+  if (knob == 9) {  // DRN_TUNE_CONV_PATCH
+    const int old = g_conv_patch ? (int)g_conv_patch_min : 0;
+    g_conv_patch = value != 0;
+    if (value > 1) g_conv_patch_min = value;
     return old;
   }
   if (knob == 8) {  // DRN_TUNE_CONV_K2_TILES
@@ -1494,6 +1687,13 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   // (round 2, tools/conv_bench.py at 800x1216: up to one 64x64 tile per CU the 36-slab res4 3x3 still gains, 23.1 ->
   // 20.5 us, while layers with few slabs lose - the 9-slab stem 3x3 8.6 -> 9.7 us at 224x224: deep K only)
   const long ks_max = g_conv_ks_tiles > 0 ? g_conv_ks_tiles : (nslab >= 32 ? cu_count() : cu_count() / 4);
+  // LDS-resident patch + weights for the 64-channel 3x3 layers of large maps (conv3x3_c64_kernel; 117 KB of LDS, so only
+  // where the trunk is not meant to share CUs with the heads' GEMMs: maps of >= 32k pixels)
+  if (g_conv_patch && dtype == DRN_BF16 && out_dtype == DRN_BF16 && (!residual || res_dtype == DRN_BF16) && Cin == 64 &&
+      Cout == 64 && KH == 3 && KW == 3 && stride == 1 && dil == 1 && pad == 1 && (long)Ho * Wo >= g_conv_patch_min &&
+      (ldy & 7) == 0 && (((uintptr_t)y) & 15) == 0 && (!residual || ((ldres & 7) == 0 && (((uintptr_t)residual) & 15) == 0)) &&
+      (ldw * 2) % 16 == 0 && (((uintptr_t)w) & 15) == 0)
+    return launch_conv3x3_c64(p, st);
   // two K-groups per 64x64 tile (conv_nhwc_k2_kernel): mid-size layers - more 64x64 tiles than the wave-K-split kernel
   // takes, at most one per CU (the kernel keeps one 512-thread workgroup per CU) - with an even slab count >= 8
   const long k2_max = g_conv_k2_tiles >= 0 ? g_conv_k2_tiles : cu_count();

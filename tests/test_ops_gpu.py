@@ -254,6 +254,41 @@ def test_conv2d_nhwc(drn, dtype, case):
         assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("case", [(1, 203, 181, False, True),    # ragged tile edges in both directions (203 = 25*8+3, 181 = 5*32+21)
+                                  (2, 184, 192, True, True),     # two images, residual
+                                  (1, 181, 203, True, False)])
+def test_conv3x3_c64_patch_kernel(drn, case):
+    """conv3x3_c64_kernel (input patch + all weights resident in LDS; 3x3 / stride 1 / 64 -> 64 channels on maps of >= 32k
+    pixels, bf16) against F.conv2d and - same k order, same MFMA - BIT-identical to the tiled kernel it replaces
+    (DRN_TUNE_CONV_PATCH = 0); zero padding at every image border, ragged 8 x 32 pixel blocks."""
+    n, h, w, has_res, relu = case
+    dtype = torch.bfloat16
+    x = _rnd((n, 64, h, w), 25)
+    wt = _rnd((64, 64, 3, 3), 26, math.sqrt(2.0 / (64 * 9)))
+    scale, bias = (0.8 + 0.2 * torch.rand(64)).to(DEV), _rnd((64,), 27, 0.1).to(DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    ref = F.conv2d(_q(x, dtype), _q(wt, dtype), None, 1, 1, 1) * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1)
+    res = None
+    if has_res:
+        res = _rnd(tuple(ref.shape), 28)
+        ref = ref + _q(res, dtype)
+        res = res.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    if relu:
+        ref = F.relu(ref)
+    wp = _pack_w(wt, dtype, drn, 64)
+    prev = drn.tune(drn.TUNE_CONV_PATCH, 1)
+    try:
+        y1 = drn.conv2d_nhwc(xd, wp, 64, 3, 3, 1, 1, 1, scale, bias, res, relu)
+        drn.tune(drn.TUNE_CONV_PATCH, 0)
+        y0 = drn.conv2d_nhwc(xd, wp, 64, 3, 3, 1, 1, 1, scale, bias, res, relu)
+    finally:
+        drn.tune(drn.TUNE_CONV_PATCH, prev if prev else 1)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, y0)
+    got = y1.float().cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("case", [(1, 14, 14, 256, 256, 3, 1, 1, 1, True, True),     # res4 3x3 on 196 pixels (36 slabs)
                                   (1, 14, 14, 1024, 256, 1, 1, 0, 1, False, True),   # res4 conv1 (16 slabs)
