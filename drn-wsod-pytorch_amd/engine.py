@@ -652,12 +652,12 @@ class Trainer:
             self.model.prefetch_features(self._lookahead)  # frozen backbone of the next batch, on a side stream
         with self.storage:
             loss_dict = self.model(data)
-        losses = sum(loss_dict.values())
         if self.iter == self.start_iter:
             self.optimizer.zero_grad()
         last_micro = self.iter % self.iter_size == 0  # train_net.py:105: the optimizer steps on these iterations
         self.dp.sync_gradients = last_micro           # DDP no_sync() for the other micro-steps of the window
-        (losses / self.iter_size).backward()
+        if not (hasattr(self.model, "backward_losses") and self.model.backward_losses(1.0 / self.iter_size)):
+            (sum(loss_dict.values()) / self.iter_size).backward()  # train_net.py:100-107; the line above = the same without autograd
         if last_micro:
             self.dp.finish()
             self.optimizer.step(self.dp.grad_scale)

@@ -133,6 +133,20 @@ class GeneralizedRCNNWSL(nn.Module):
         images = self.preprocess_image(batched_inputs)
         return images, self.backbone(images.tensor), None
 
+    def backward_losses(self, scale=1.0):
+        """= (scale * sum(loss_dict.values())).backward() for the loss dict the last training forward returned, without the
+        autograd pass: the heads' explicit backward (and, through its hook, the trunk's) is called directly with one
+        common upstream gradient.  Same kernels, same arithmetic; ~0.45 ms less host time per eager step (the autograd
+        engine's thread hand-over and its scalar add / ones / stack launches).  Returns False when the model has no fused
+        head engine state to run (the caller then uses autograd)."""
+        eng = getattr(self.roi_heads, "_engine", None)
+        st = getattr(eng, "_last_state", None) if eng is not None else None
+        if st is None:
+            return False
+        eng._last_state = None
+        eng.backward(st, float(scale))
+        return True
+
     def _backbone_backward(self, dfeat_nhwc, accumulate):
         self.backbone.backward_nhwc(dfeat_nhwc, accumulate)
 

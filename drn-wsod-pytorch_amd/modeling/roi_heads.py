@@ -660,6 +660,7 @@ class _HeadEngine:
         if fg_hook is not None:  # what the gradient of the feature map needs (trainable backbone)
             state["fg"] = dict(hook=fg_hook, rois=rois, obj=objectness, feat_shape=tuple(feat_nhwc.shape),
                                argmax=pooled.get("argmax"))
+        self._last_state = state
         outs = _TrainFn.apply(self.anchor, self, state)
         return dict(zip(loss_names, outs)), state
 
@@ -685,6 +686,7 @@ class _HeadEngine:
                      aux=dict(scores=scores, img_scores=img_scores, targets=[], W=W, cpgs=cpgs))
         if fg_hook is not None:
             state["fg"] = dict(fg, hook=fg_hook)
+        self._last_state = state
         outs = _TrainFn.apply(self.anchor, self, state)
         return dict(zip(["loss_cls_pos", "loss_cls_neg"], outs)), state
 
@@ -723,11 +725,16 @@ class _HeadEngine:
         Mp = kp(M)
         dev = self.arena_w.device
         # per-loss upstream gradients -> per-column scale of dlogits (stays on the device)
-        if gouts is None:  # d(sum of losses): every loss has upstream gradient 1 (GraphedTrainStep calls this directly)
-            nl = len(st["loss_list"])
-            if getattr(self, "_unit_scale", None) is None or self._unit_scale.numel() != nl or self._unit_scale.device != dev:
-                self._unit_scale = torch.ones((nl,), dtype=torch.float32, device=dev)
-            colscale = self._unit_scale
+        if gouts is None or isinstance(gouts, float):
+            # d(scale * sum of losses): every loss has the same upstream gradient (1: GraphedTrainStep; 1 / ITER_SIZE:
+            # Trainer through backward_losses) - a cached device vector, no autograd pass
+            nl, val = len(st["loss_list"]), 1.0 if gouts is None else float(gouts)
+            cache = self.__dict__.setdefault("_scale_vecs", {})
+            colscale = cache.get((nl, val, dev))
+            if colscale is None:
+                if len(cache) > 8:
+                    cache.clear()
+                colscale = cache[(nl, val, dev)] = torch.full((nl,), val, dtype=torch.float32, device=dev)
         else:
             g = [torch.zeros((), device=dev) if x is None else x.float().reshape(()) for x in gouts]
             if st.get("csc") and not (gouts[0] is not None and gouts[1] is not None and torch.equal(g[0], g[1])):

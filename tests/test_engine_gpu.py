@@ -308,3 +308,30 @@ def test_workspace_views_follow_changing_proposal_counts(precision):
     assert l_big2 == l_big1
     for n in g_big1:
         assert torch.equal(g_big2[n], g_big1[n]), n
+
+
+def test_backward_losses_equals_autograd():
+    """GeneralizedRCNNWSL.backward_losses(scale) - the explicit backward called directly, what Trainer.run_step uses -
+    against (scale * sum(loss_dict.values())).backward() (projects/WSL/tools/train_net.py:100-107): every gradient
+    bit-equal, for scale 1 and for 1 / ITER_SIZE."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    seed, ocfg, batches = _three_batches()
+
+    def grads(direct, scale):
+        cfg, model = _model(seed, ocfg)
+        opt = build_optimizer(cfg, model)
+        opt.zero_grad()
+        losses = model(batches[0])
+        if direct:
+            assert model.backward_losses(scale)
+        else:
+            (sum(losses.values()) * scale).backward()
+        torch.cuda.synchronize()
+        return {n: p.grad.detach().cpu().clone() for n, p in model.named_parameters() if p.grad is not None}
+
+    for scale in (1.0, 0.25):
+        a, b = grads(True, scale), grads(False, scale)
+        assert set(a) == set(b) and len(a) >= 6
+        for n in a:
+            assert torch.equal(a[n], b[n]), (n, scale)

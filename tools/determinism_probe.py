@@ -8,16 +8,18 @@ B, pkg, build_model, build_optimizer, DataParallel = ns["B"], ns["pkg"], ns["bui
 batches, cfg = ns["batches"], ns["cfg"]
 PREFETCH = os.environ.get("PREFETCH", "1") == "1"
 PIPE = os.environ.get("PIPE", "1") == "1"
-def run(nsteps=24):
+def run(nsteps=int(os.environ.get("NSTEPS", "24")), nshapes=int(os.environ.get("NSHAPES", "5"))):
     torch.manual_seed(1)
     model = build_model(cfg); B.init_weights(model, seed=0); model.train()
     opt = build_optimizer(cfg, model); dp = DataParallel(model)
     if PIPE: opt.enable_pipelined(dp)
     out = []
     for i in range(nsteps):
-        losses = model(batches[i % 5])
-        if PREFETCH: model.prefetch_features(batches[(i + 1) % 5])
-        sum(losses.values()).backward(); dp.finish(); opt.step(dp.grad_scale); opt.zero_grad()
+        losses = model(batches[i % nshapes])
+        if PREFETCH: model.prefetch_features(batches[(i + 1) % nshapes])
+        if os.environ.get("DIRECT", "0") != "1" or not model.backward_losses(1.0):
+            sum(losses.values()).backward()
+        dp.finish(); opt.step(dp.grad_scale); opt.zero_grad()
         out.append([float(v.detach()) for v in losses.values()])
     torch.cuda.synchronize()
     w = model.roi_heads.box_head.fc1.weight.detach()
