@@ -674,12 +674,18 @@ __global__ __launch_bounds__(256) void roi_pool7_map_kernel(RoiParams p) {
 // the neighbouring channel chunks, which the same XCD's L2 sees right next in time.
 constexpr int ROI_G64 = 64;
 constexpr int G64_CH = 8, G64_RUN = G64_CH * 49, G64_PITCH = G64_RUN * 2 + 8, G64_THREADS = 512;
+template <int JMAX>  // (ROI, bin) items per thread: ceil(64 * 49 / threads) = 13 / 7 / 4 for 256 / 512 / 1024 threads
 __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
   constexpr int PP = 49;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = p.H * p.W;
-  char* map = smem;                                          // [HW][8 channels, order-mapped bf16]
-  char* tile = smem + (((long)HW * 16 + 15) & ~15L);         // [64][G64_PITCH]
+  // the map slice is staged in BANDS of whole rows (p.lds_px pixels at most; one band = the whole map for everything up
+  // to ~6700 pixels): larger maps - 75 x 122 for a 1200 x 1951 image - used to fall to the 8-ROI kernel that re-stages
+  // the slice per 8 ROIs (1.4 ms per call there).  A (ROI, bin) item keeps its running maximum in registers across the bands.
+  const int band_rows = p.lds_px >= HW ? p.H : p.lds_px / p.W;
+  const long map_bytes = ((long)(band_rows < p.H ? band_rows * p.W : HW) * 16 + 15) & ~15L;
+  char* map = smem;                                          // [band pixels][8 channels, order-mapped bf16]
+  char* tile = smem + map_bytes;                             // [64][G64_PITCH]
   __shared__ unsigned char hb[ROI_G64][7][2], wb[ROI_G64][7][2];
   __shared__ int bidx[ROI_G64];
   __shared__ float mulv[ROI_G64];
@@ -713,42 +719,62 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
     int r1 = r0 + 1;
     while (r1 < nr && bidx[r1] == b) ++r1;
     const char* fb = p.feat + ((long)b * HW * p.C + c0) * 2;
-    for (int px = tid; px < HW; px += nthr) {
-      i32x4_t x = *(const i32x4_t*)(fb + (long)px * p.C * 2);
+    const int lo = (int)0x80008000u;
+    i32x4_t acc[JMAX];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
-      *(i32x4_t*)(map + (long)px * 16) = x;
-    }
-    __syncthreads();
-    for (int it = r0 * PP + tid; it < r1 * PP; it += nthr) {
-      const int r = it / PP, bin = it - r * PP;
-      const int ph = bin / 7, pw = bin - ph * 7;
-      const int hs = hb[r][ph][0], he = hb[r][ph][1], ws = wb[r][pw][0], we = wb[r][pw][1];
-      const int lo = (int)0x80008000u;
-      i32x4_t acc = {lo, lo, lo, lo};
-      for (int h = hs; h < he; ++h) {
-        const char* row = map + (long)(h * p.W) * 16;
-        for (int w = ws; w < we; ++w) {
-          const i32x4_t x = *(const i32x4_t*)(row + w * 16);
+    for (int j = 0; j < JMAX; ++j) acc[j] = i32x4_t{lo, lo, lo, lo};
+    for (int y0 = 0; y0 < p.H; y0 += band_rows) {
+      const int y1 = min(p.H, y0 + band_rows), npx = (y1 - y0) * p.W;
+      const char* fbb = fb + (long)y0 * p.W * p.C * 2;
+      for (int px = tid; px < npx; px += nthr) {
+        i32x4_t x = *(const i32x4_t*)(fbb + (long)px * p.C * 2);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[e] = pk_max_i16(acc[e], x[e]);
+        for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
+        *(i32x4_t*)(map + (long)px * 16) = x;
+      }
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < JMAX; ++j) {
+        const int it = r0 * PP + tid + j * nthr;
+        if (it < r1 * PP) {
+          const int r = it / PP, bin = it - r * PP;
+          const int ph = bin / 7, pw = bin - ph * 7;
+          const int hs = max((int)hb[r][ph][0], y0), he = min((int)hb[r][ph][1], y1);
+          const int ws = wb[r][pw][0], we = wb[r][pw][1];
+          for (int h = hs; h < he; ++h) {
+            const char* row = map + (long)((h - y0) * p.W) * 16;
+            for (int w = ws; w < we; ++w) {
+              const i32x4_t x = *(const i32x4_t*)(row + w * 16);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[j][e] = pk_max_i16(acc[j][e], x[e]);
+            }
+          }
         }
       }
-      const bool empty = he <= hs || we <= ws;
-      const float mul = mulv[r];
-      bf16_t* dst = (bf16_t*)(tile + (long)r * G64_PITCH) + bin;
+      __syncthreads();  // the band may be replaced
+    }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const uint32_t y = (uint32_t)bf16x2_order(acc[e]);
-        const float f0 = empty ? 0.f : __builtin_bit_cast(float, y << 16);
-        const float f1 = empty ? 0.f : __builtin_bit_cast(float, y & 0xffff0000u);
-        dst[(2 * e) * PP] = f32_to_bf16(f0 * mul);
-        dst[(2 * e + 1) * PP] = f32_to_bf16(f1 * mul);
+    for (int j = 0; j < JMAX; ++j) {
+      const int it = r0 * PP + tid + j * nthr;
+      if (it < r1 * PP) {
+        const int r = it / PP, bin = it - r * PP;
+        const int ph = bin / 7, pw = bin - ph * 7;
+        const bool empty = hb[r][ph][1] <= hb[r][ph][0] || wb[r][pw][1] <= wb[r][pw][0];
+        const float mul = mulv[r];
+        bf16_t* dst = (bf16_t*)(tile + (long)r * G64_PITCH) + bin;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const uint32_t y = (uint32_t)bf16x2_order(acc[j][e]);
+          const float f0 = empty ? 0.f : __builtin_bit_cast(float, y << 16);
+          const float f1 = empty ? 0.f : __builtin_bit_cast(float, y & 0xffff0000u);
+          dst[(2 * e) * PP] = f32_to_bf16(f0 * mul);
+          dst[(2 * e + 1) * PP] = f32_to_bf16(f1 * mul);
+        }
       }
     }
-    __syncthreads();  // the map slice may be replaced; after the last run: the tile is complete
     r0 = r1;
   }
+  __syncthreads();  // the tile is complete
   // A: nr runs of 784 bytes (49 x 16 B), rows of the tile are 8-byte aligned
   typedef int i32x2_t __attribute__((ext_vector_type(2)));
   for (int v = tid; v < nr * PP; v += nthr) {
@@ -780,18 +806,37 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
 
 static int g_roi_map64 = 512;  // drn_tune(DRN_TUNE_ROI_MAP64): 0 = off, else threads per block (256 / 512 / 1024)
 
-static bool launch_roi_map64(const RoiParams& p, hipStream_t st) {
+static bool launch_roi_map64(const RoiParams& p0, hipStream_t st) {
+  RoiParams p = p0;
   if (!g_roi_map64 || p.C % G64_CH || p.H > 255 || p.W > 255) return false;
-  const size_t smem = (((size_t)p.H * p.W * 16 + 15) & ~(size_t)15) + (size_t)ROI_G64 * G64_PITCH;
-  if (smem > 76 * 1024) return false;  // two blocks per CU
+  const size_t tile_b = (size_t)ROI_G64 * G64_PITCH, budget = 154 * 1024 - tile_b;  // (+ ~1.5 KB of static LDS)
+  size_t map_b = ((size_t)p.H * p.W * 16 + 15) & ~(size_t)15;
+  p.lds_px = p.H * p.W;
+  if (map_b > budget) {  // bands of whole rows
+    const int rows = (int)(budget / ((size_t)p.W * 16));
+    if (rows < 8) return false;
+    p.lds_px = rows * p.W;
+    map_b = ((size_t)p.lds_px * 16 + 15) & ~(size_t)15;
+  }
+  const size_t smem = map_b + tile_b;
+  // <= 76 KB: two blocks per CU (the 14x14 .. 38x38 maps).  Up to 156 KB - the 40x60 .. 63x100 maps of real-size training
+  // images - ONE block per CU still stages its 8-channel map slice once per 64 ROIs; the 8-ROI whole-map kernel that
+  // these maps used to fall to re-stages it per 8 ROIs (2.9 GB through L2 per call at 63x92: 1.5 ms, half of the eager
+  // step at 1000x1464, `profiles/r2_15_*`)
+  if (smem > 156 * 1024) return false;
   static bool attr = false;
-  if (!attr && smem > 48 * 1024) {
-    if (hipFuncSetAttribute((const void*)roi_pool7_map64_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024) != hipSuccess)
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)roi_pool7_map64_kernel<13>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_pool7_map64_kernel<7>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_pool7_map64_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
       return false;
     attr = true;
   }
   const int ngroups = (p.M + ROI_G64 - 1) / ROI_G64;
-  hipLaunchKernelGGL(roi_pool7_map64_kernel, dim3((p.C / G64_CH) * ngroups), dim3(g_roi_map64), smem, st, p);
+  const dim3 grid((p.C / G64_CH) * ngroups), block(g_roi_map64);
+  if (g_roi_map64 >= 1024) hipLaunchKernelGGL(roi_pool7_map64_kernel<4>, grid, block, smem, st, p);
+  else if (g_roi_map64 >= 512) hipLaunchKernelGGL(roi_pool7_map64_kernel<7>, grid, block, smem, st, p);
+  else hipLaunchKernelGGL(roi_pool7_map64_kernel<13>, grid, block, smem, st, p);
   return true;
 }
 

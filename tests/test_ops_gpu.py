@@ -370,7 +370,9 @@ def _rois(R, n_img, H, W, seed):
                                              (130, 7, 0.0625, 23, 29, 80), (128, 7, 0.0625, 14, 14, 83),
                                              (64, 7, 0.125, 40, 37, 80), (64, 7, 0.125, 28, 28, 45),
                                              (16, 7, 0.125, 28, 28, 19), (64, 7, 0.0625, 43, 58, 37),
-                                             (24, 7, 0.0625, 75, 100, 21)])
+                                             (24, 7, 0.0625, 75, 100, 21),
+                                             (16, 7, 0.0625, 63, 92, 130),   # 64-ROI whole-map kernel, ONE block per CU (143 KB of LDS)
+                                             (16, 7, 0.0625, 75, 122, 130)])  # ... the map slice staged in two row bands
 def test_roi_pool(drn, dtype, C, P, scale, H, W, R):
     """7x7 pooling of maps that fit in LDS takes the whole-map kernel (ROI groups straddling images, ragged last
     group); C % 64 == 0 otherwise takes the window-staged path; everything else the direct path.  The fused transposed
