@@ -1065,8 +1065,11 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
         done = launch_roi_map64(p, st);
       if (done) {
       } else if (in_dtype == DRN_BF16)
+        // (maps too large for two 8-ROI blocks per CU - inference at real image sizes, no A^T - also take the 64-ROI
+        // kernel: the 8-ROI one would re-stage its map slice per 8 proposals)
         done = launch_roi_map<DRN_BF16, 32>(p, st, two) || launch_roi_map<DRN_BF16, 64>(p, st, two) ||
                launch_roi_map<DRN_BF16, 16>(p, st, two) || launch_roi_map<DRN_BF16, 8>(p, st, two) ||
+               (M >= ROI_G64 && launch_roi_map64(p, st)) ||
                launch_roi_map<DRN_BF16, 32>(p, st, one) || launch_roi_map<DRN_BF16, 16>(p, st, one) ||
                launch_roi_map<DRN_BF16, 8>(p, st, one);
       else if (in_dtype == DRN_F32)
