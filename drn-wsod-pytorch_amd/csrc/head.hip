@@ -71,6 +71,8 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
     cscale = ci >= 0 ? p.colscale[ci] : 0.f;
   }
   const unsigned long long seed = p.seed + ((!BWD && p.seed_dev) ? p.seed_dev[0] : 0ULL);
+  if (!BWD && p.seed_dev && p.drop_p <= 0.f && !p.mask && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    *const_cast<unsigned long long*>(p.seed_dev) += p.seed;  // no dropout here: this launch ADVANCES the mask counter
   for (int mb = mb0; mb < mb1; mb += 64) {
 #pragma unroll 4
     for (int i = ty; i < RSTEP; i += 4) {
@@ -144,6 +146,8 @@ __global__ __launch_bounds__(256) void act_vec_kernel(ActParams p) {
     }
   }
   const unsigned long long seed = p.seed + ((!BWD && p.seed_dev) ? p.seed_dev[0] : 0ULL);
+  if (!BWD && p.seed_dev && p.drop_p <= 0.f && !p.mask && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
+    *const_cast<unsigned long long*>(p.seed_dev) += p.seed;  // no dropout here: this launch ADVANCES the mask counter
   f32x4v bias4 = {0.f, 0.f, 0.f, 0.f};
   if (!BWD && p.bias && nok) bias4 = *(const f32x4v*)(p.bias + n0);
 #pragma unroll

@@ -585,10 +585,11 @@ class _HeadEngine:
                              w["H1T"] if training else None, masks[0] if masks else None, seed, drop_p, seed_dev)
         self._linear_fwd(w["H1"], sh["W2"], M, D2, kp(D1), fc2.bias.data, True, w["H2"], w["H2T"] if training else None,
                          masks[1] if masks else None, seed + 0x9E3779B1, drop_p, seed_dev)
-        if seed_dev is not None:
-            ops.counter_add(seed_dev, 2654435761)
         bo, _ = self._seg[self.cols[0][0] + ".bias"]
-        self._linear_fwd(w["H2"], sh["Wh"], M, NH, kp(D2), self.arena_w[bo: bo + NH], False, w["logits"], None, None, 0, 0.0)
+        # (the logits pass has no dropout: given the counter it advances it - behind both dropout layers - instead of a
+        # counter_add launch of its own on the heads' dependent chain)
+        self._linear_fwd(w["H2"], sh["Wh"], M, NH, kp(D2), self.arena_w[bo: bo + NH], False, w["logits"], None, None,
+                         2654435761 if seed_dev is not None else 0, 0.0, seed_dev)
         col = {n: c for n, _, c, _ in self.cols}
         if not training:
             return w, col

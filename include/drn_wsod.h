@@ -152,7 +152,9 @@ int drn_gemm_set_tile(int tile);
 int drn_tune(int knob, int value);
 
 /* relu_(fc(x)) + F.dropout(p), box_head.py:88-90: sums split-K partials, adds bias, ReLU, dropout
- * (explicit multiplier mask [M][N] if given, else counter-based mask from seed (+ *seed_dev) when drop_p > 0);
+ * (explicit multiplier mask [M][N] if given, else counter-based mask from seed (+ *seed_dev) when drop_p > 0; a launch
+ * WITHOUT dropout (drop_p == 0, no mask) that is given seed_dev advances that counter: *seed_dev += seed - the heads'
+ * logits pass does this behind the two dropout layers, so a replayed hipGraph draws fresh masks without a launch of its own);
  * writes out [M][ld_out] and/or its transpose outT [N][ld_outT]. */
 int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const float* bias, const float* mask,
                      unsigned long long seed, const unsigned long long* seed_dev, float drop_p, void* out, long ld_out,

@@ -335,3 +335,30 @@ def test_backward_losses_equals_autograd():
         assert set(a) == set(b) and len(a) >= 6
         for n in a:
             assert torch.equal(a[n], b[n]), (n, scale)
+
+
+def test_dropout_counter_advances_without_its_own_launch():
+    """The counter-based dropout masks are keyed by a device-side counter that the heads' logits pass advances behind the
+    two dropout layers (drn_bias_act_fwd without dropout + seed_dev: *seed_dev += seed).  Two training forwards of the
+    same batch with the same weights must therefore draw different masks (different losses), and rewinding the counter
+    must reproduce the first draw bit for bit."""
+    seed, ocfg, batches = _three_batches()
+    cfg, model = G.drn_model(ocfg, seed, "cuda", 5, "fp32")
+    model.train()
+    assert model.roi_heads.box_head.dropout_p > 0
+    torch.manual_seed(5)
+    eng = model.roi_heads._engine
+
+    def fwd():
+        out = {k: float(v.detach()) for k, v in model(batches[0]).items()}
+        torch.cuda.synchronize()
+        return out
+
+    a = fwd()
+    c1 = int(eng.seed_dev.item())
+    b = fwd()
+    c2 = int(eng.seed_dev.item())
+    assert c1 != 0 and c2 == 2 * c1          # advanced once per forward, by the same increment
+    assert a != b                            # fresh masks
+    eng.seed_dev.zero_()
+    assert fwd() == a                        # same counter, same masks
