@@ -4,6 +4,7 @@ fused SGD -> inference) against golden vectors of the unmodified reference and a
 fp32 parity mode: losses within 1e-4 (BASELINE north star), gradients within 2e-3 of their scale,
 feature maps within 1e-4.  bf16 fast mode: compared with the same goldens at the looser tolerance
 stated at the check (bf16 operands carry 2^-9 relative rounding per element)."""
+import copy
 import os
 
 import numpy as np
@@ -763,4 +764,51 @@ def test_tta_outputs_feed_voc_evaluator():
     assert set(res["bbox"]) == {"AP", "AP50", "AP75"} and set(res["bbox CorLoc"]) == {"CL", "CL50", "CL75"}
     assert res["per_class"]["CL50"][names[k]] == 100.0  # the top detection of that class is the annotated object
     assert res["per_class"]["AP50"][names[k]] > 0
+    load_package().set_precision("fp32")
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Ragged batches: the goldens hold images of different sizes but EQUAL proposal counts.  Real proposal files differ per
+# image (SelectiveSearch / MCG after de-duplication: a few hundred to a few thousand), so the per-image segments of
+# every [sum R_i, ...] operand - ROI batch indices, the per-image WSDDN softmax over proposals, pseudo-GT mining,
+# label_and_sample - are exercised here with very different counts, including an image with a single proposal.
+RAGGED = [((96, 128), 37, 11), ((128, 96), 1, 12), ((64, 80), 130, 13), ((72, 72), 8, 14)]
+
+
+@pytest.mark.parametrize("name", ["model_r50c4_tiny", "model_r18dc5_tiny"])
+def test_ragged_batch_matches_oracle_fp32(name):
+    """4 images per step with 37 / 1 / 130 / 8 proposals and four different sizes: every loss within 1e-4 of the
+    oracle's (north-star bound), image-level MIL scores, gradients of the heads' tensors, and a second step after one
+    SGD update (weights that moved by ragged-batch gradients)."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    ocfg = copy.deepcopy(G.MODEL_CASES[name])
+    ocfg.dropout = 0.0
+    p = O.init_params(ocfg, seed=5)
+    batch = []
+    for (h, w), r, seed in RAGGED:
+        batch += O.synthetic_batch(1, r, ocfg, seed=seed, H=h, W=w)
+    opt_o = O.SGDState(ocfg)
+    cfg, model = G.drn_model(ocfg, 5, "cuda", 5, "fp32")
+    model.roi_heads.box_head.dropout_p = 0.0
+    model.train()
+    opt = build_optimizer(cfg, model)
+    sd = dict(model.named_parameters())
+    names = [n for n in sd if n.startswith("roi_heads.") and sd[n].requires_grad and "bbox_pred" not in n]
+    for step in range(2):
+        ref_losses, ref_grads = O.train_step(p, batch, ocfg, opt_o)
+        opt.zero_grad()
+        losses = model(G.drn_inputs(batch))
+        sum(losses.values()).backward()
+        got = {k: float(v.detach()) for k, v in losses.items()}
+        assert set(got) == set(ref_losses)
+        tol = 1e-4 if step == 0 else 1e-3  # step 1 sits behind one SGD step of this toy net (see test_train_two_steps_fp32)
+        for k in got:
+            assert abs(got[k] - ref_losses[k]) <= tol * max(abs(ref_losses[k]), 1e-3), (step, k, got[k], ref_losses[k])
+        if step == 0:
+            for n in names:
+                g, rg = sd[n].grad.detach().cpu().numpy(), ref_grads[n].numpy()
+                assert _relerr(g, rg) < 2e-3, (n, _relerr(g, rg))
+        opt.step()
+    torch.cuda.synchronize()
     load_package().set_precision("fp32")
