@@ -715,7 +715,7 @@ class GraphedTrainStep:
     _needs_frozen_trunk = True
 
     def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False,
-                 eager_fc6=False):
+                 eager_fc6=False, stage_ahead=True):
         if getattr(model, "cpg", False):
             raise DrnError("CSCROIHeads decides per step, on the host, which class maps to compute: eager steps only")
         if self._needs_frozen_trunk and any(p.requires_grad for p in model.backbone.parameters()):
@@ -727,6 +727,10 @@ class GraphedTrainStep:
         # issued eagerly in front of the captured heads graph, like the fc6 dW tail behind it, so HIP events on the
         # launch stream can bracket it inside the timed region (ops.GEMM_TIMING)
         self.eager_fc6 = bool(eager_fc6)
+        # stage_ahead: the next batch's labels are staged behind this step's heads graph and its proposals on the side
+        # stream (False = the round-2 order, kept for A/B runs: proposals in front of the pooling graph on the main
+        # stream, labels at the start of their own step, i.e. between the pooling kernel and the fc6 forward)
+        self.stage_ahead = bool(stage_ahead)
         # trunk_pairs: ONE conv chain per TWO batches (t+2 and t+3, launched on even steps): the chain is latency-bound,
         # so two images cost what one costs and the per-image chain time halves - for trunks whose chain is as long as
         # the step (WS-R101).  step() then takes (batch, next, t+2, t+3).
@@ -798,6 +802,20 @@ class GraphedTrainStep:
         slot["ev"] = torch.cuda.Event()
         slot["ev"].record()
 
+    def _stage_labels_ahead(self, next_batch):
+        """Labels of the NEXT batch, issued in this step's tail (behind the heads graph, the only reader of the label
+        block, and in front of the pooling graph): the H2D copy and its launch gap leave the pooling -> fc6 forward
+        hand-over of the next step (timeline: 14 us between the two kernels for a 4-us copy).  step() skips its own
+        staging when it is handed this very batch."""
+        if next_batch is not None and self.stage_ahead:
+            self._stage_labels(next_batch)
+            self._labels_for = next_batch
+
+    def _stage_labels_now(self, batch):
+        if getattr(self, "_labels_for", None) is not batch:
+            self._stage_labels(batch)
+        self._labels_for = None
+
     def _stage_next(self, batch):
         """image + proposals of the NEXT batch (device tensors: async D2D copies)"""
         self._stage_props(batch)
@@ -808,8 +826,12 @@ class GraphedTrainStep:
         for i, x in enumerate(batch):
             n = self.nper[i]
             assert len(x["proposals"]) == n, "graphed step: proposals per image must stay fixed"
-            self.rois_next[off: off + n, 1:].copy_(x["proposals"].proposal_boxes.tensor, non_blocking=True)
-            self.obj_next[off: off + n].copy_(x["proposals"].objectness_logits, non_blocking=True)
+            bx, ob = x["proposals"].proposal_boxes.tensor, x["proposals"].objectness_logits
+            self.rois_next[off: off + n, 1:].copy_(bx, non_blocking=True)
+            self.obj_next[off: off + n].copy_(ob, non_blocking=True)
+            for src in (bx, ob):
+                if src.is_cuda:  # the caller's tensors may be read on a side stream: keep the allocator from reusing them
+                    src.record_stream(torch.cuda.current_stream())
             off += n
 
     def _stage_image(self, batch, slot):
@@ -888,14 +910,23 @@ class GraphedTrainStep:
         side = self._sides[t % (L - 1)]
         side.wait_stream(main)
         losses = self._heads(eager)
+        self._stage_labels_ahead(next_batch)  # behind the heads graph (their reader), off the pooling -> fc6 hand-over
         if self.split_tail:
             self.engine.run_fc1_tail()
         with torch.cuda.stream(side):
+            evp = None
+            if self.stage_ahead:
+                self._stage_props(next_batch)  # in front of the conv chain, off the main stream (see _run_pairs)
+                evp = torch.cuda.Event()
+                evp.record(side)
             self._stage_image(far_batch, sL)
             self._bb_body(sL) if eager else self.g_bb2[sL].replay()
             ev = torch.cuda.Event()
             ev.record(side)
-        self._stage_props(next_batch)  # behind the heads graph on this stream: off the front of the fc6 GEMM
+        if evp is not None:
+            main.wait_event(evp)
+        else:
+            self._stage_props(next_batch)
         main.wait_event(self._bb_done[s1])
         self._bb_done[sL] = ev
         self._pool_body(s1) if eager else self.g_pool2[s1].replay()
@@ -972,17 +1003,31 @@ class GraphedTrainStep:
         t = self._t
         self._side.wait_stream(main)
         losses = self._heads(eager)
+        # labels of batch t+1: behind their only reader (the heads graph above), in front of the eager tail - nothing is
+        # left between the pooling graph and the next step's fc6 forward
+        self._stage_labels_ahead(next_batch)
         if self.split_tail:
             self.engine.run_fc1_tail()
-        if t % 2 == 0:
-            ps = (t // 2 + 1) % 2
-            with torch.cuda.stream(self._side):
+        with torch.cuda.stream(self._side):
+            # proposals of batch t+1 on the side stream (ordered behind step t-1's pooling graph, their last reader, by the
+            # wait above; in front of the conv chain): three small launches that sat between the last dW slab and the
+            # pooling graph on the main stream (22 us in the timeline)
+            evp = None
+            if self.stage_ahead:
+                self._stage_props(next_batch)
+                evp = torch.cuda.Event()
+                evp.record(self._side)
+            if t % 2 == 0:
+                ps = (t // 2 + 1) % 2
                 self._pair_stage(b2, b3, ps)
                 self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
                 ev = torch.cuda.Event()
                 ev.record(self._side)
-            self._pdone[ps] = ev
-        self._stage_props(next_batch)
+                self._pdone[ps] = ev
+        if evp is not None:
+            main.wait_event(evp)
+        else:
+            self._stage_props(next_batch)
         k1, h1 = ((t + 1) // 2) % 2, (t + 1) % 2
         main.wait_event(self._pdone[k1])
         self._pair_pool_body(k1, h1) if eager else self.g_ppool[k1][h1].replay()
@@ -1047,6 +1092,7 @@ class GraphedTrainStep:
             self._bb_body() if eager else self.g_bb.replay()
             done = torch.cuda.Event()
             done.record(self._side)
+        self._stage_labels_ahead(next_batch)
         main.wait_event(done)
         self._pool_body() if eager else self.g_pool.replay()
         if self.split_tail:
@@ -1093,7 +1139,7 @@ class GraphedTrainStep:
                 raise DrnError("GraphedTrainStep(trunk_pairs=True).step needs batches t+2 and t+3")
             if not self._primed:
                 return self._prime_pairs(batch, next_batch, upcoming[0], upcoming[1])
-            self._stage_labels(batch)
+            self._stage_labels_now(batch)
             return self._run_pairs(False, next_batch, upcoming[0], upcoming[1])
         if self.lookahead >= 2:
             if len(upcoming) != self.lookahead - 1:
@@ -1101,11 +1147,11 @@ class GraphedTrainStep:
                                % (self.lookahead, self.lookahead - 1))
             if not self._primed:
                 return self._prime2(batch, next_batch, list(upcoming))
-            self._stage_labels(batch)
+            self._stage_labels_now(batch)
             return self._run2(False, next_batch, upcoming[-1])
         if not self._primed:
             return self.prime(batch, next_batch)
-        self._stage_labels(batch)
+        self._stage_labels_now(batch)
         return self._run(eager=False, next_batch=next_batch)
 
 
