@@ -808,7 +808,10 @@ def test_ragged_batch_matches_oracle_fp32(name):
         if step == 0:
             for n in names:
                 g, rg = sd[n].grad.detach().cpu().numpy(), ref_grads[n].numpy()
-                assert _relerr(g, rg) < 2e-3, (n, _relerr(g, rg))
+                if np.abs(rg).max() < 1e-6:  # analytically zero (det bias): both sides are rounding noise
+                    assert np.abs(g).max() < 1e-5, n
+                else:
+                    assert _relerr(g, rg) < 2e-3, (n, _relerr(g, rg))
         opt.step()
     torch.cuda.synchronize()
     load_package().set_precision("fp32")
