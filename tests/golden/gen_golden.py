@@ -810,6 +810,118 @@ def case_checkpoint(name, yaml_rel, opts):
     print("wrote", path, "loaded c2:", int((d["map_c2"] > 0).sum()), "of", len(sd), " d2:", int((d["map_d2"] > 0).sum()))
 
 
+def case_convert(name, seed):
+    """The reference's offline converters run UNMODIFIED on synthetic files (projects/WSL/tools/): proposal_convert.py's
+    convert_ss_box / convert_mcg_box on .mat files written here with scipy (1-indexed (y1, x1, y2, x2) boxes; an image
+    with a single proposal; the dataset catalogue replaced by a list of image ids), and the three checkpoint key
+    renaming scripts - convert_resnet_ws_pth.py, convert_resnet_ws_c2.py, convert_vgg.py (module-level scripts: run
+    with runpy under their own sys.argv).  Recorded: inputs and the files the scripts wrote."""
+    import importlib.util
+    import pickle
+    import runpy
+    import tempfile
+
+    import scipy.io
+
+    tools = os.path.join(rh.REF, "projects", "WSL", "tools")
+    rng = np.random.RandomState(seed)
+    d = {}
+    with tempfile.TemporaryDirectory() as tmp:
+        # ---- proposals -------------------------------------------------------------------------------------------
+        spec = importlib.util.spec_from_file_location("ref_proposal_convert", os.path.join(tools, "proposal_convert.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        ids = ["000005", "000007", "000012", "2008_000002"]
+        counts = [7, 1, 12, 5]
+        dicts = [{"image_id": i, "file_name": "/x/JPEGImages/%s.jpg" % i} for i in ids]
+
+        class _Catalog:
+            @staticmethod
+            def get(_name):
+                return dicts
+
+        mod.DatasetCatalog = _Catalog
+        raw = []
+        for n in counts:
+            y1, x1 = rng.randint(1, 200, n), rng.randint(1, 300, n)
+            raw.append(np.stack([y1, x1, y1 + rng.randint(0, 150, n), x1 + rng.randint(0, 180, n)], 1).astype(np.float64))
+        cell = np.empty((len(raw),), dtype=object)
+        for i, r in enumerate(raw):
+            cell[i] = r
+        ss_mat = os.path.join(tmp, "ss_boxes.mat")
+        scipy.io.savemat(ss_mat, {"boxes": cell})
+        mcg_dir = os.path.join(tmp, "mcg")
+        os.makedirs(mcg_dir)
+        mcg_scores = [rng.rand(n, 1).astype(np.float64) for n in counts]
+        for i, r, sc in zip(ids, raw, mcg_scores):
+            scipy.io.savemat(os.path.join(mcg_dir, i + ".mat"), {"boxes": r, "scores": sc})
+        argv = sys.argv
+        try:
+            sys.argv = ["proposal_convert.py", "voc_2007_train", ss_mat, os.path.join(tmp, "ss_out.pkl")]
+            mod.convert_ss_box()
+            sys.argv = ["proposal_convert.py", "voc_2007_train", mcg_dir, os.path.join(tmp, "mcg_out.pkl")]
+            mod.convert_mcg_box()
+        finally:
+            sys.argv = argv
+        d["prop_ids"] = np.array(ids)
+        for tag in ("ss", "mcg"):
+            with open(os.path.join(tmp, tag + "_out.pkl"), "rb") as f:
+                out = pickle.load(f)
+            assert sorted(out) == ["boxes", "indexes", "scores"]
+            d[tag + "_indexes"] = np.array(out["indexes"])
+            for i in range(len(ids)):
+                d["%s_boxes%d" % (tag, i)] = out["boxes"][i]
+                d["%s_scores%d" % (tag, i)] = np.asarray(out["scores"][i])
+        for i in range(len(ids)):
+            d["raw_boxes%d" % i] = raw[i]
+            d["raw_scores%d" % i] = mcg_scores[i]
+
+        # ---- checkpoint keys -------------------------------------------------------------------------------------
+        def run(script, src, dst):
+            try:
+                sys.argv = [script, src, dst]
+                runpy.run_path(os.path.join(tools, script), run_name="__main__")
+            finally:
+                sys.argv = argv
+
+        pth_keys = ["module.backbone.stem.conv1.weight", "module.backbone.res2.0.conv1.norm.running_mean",
+                    "module.backbone.res4.5.conv3.weight", "module.neck.fc1.weight", "module.neck.fc2.bias",
+                    "module.neck.pool.weight", "module.head.fc_cls.weight", "epoch_marker"]
+        src = os.path.join(tmp, "ws.pth")
+        torch.save({"state_dict": {k: torch.full((2,), float(i)) for i, k in enumerate(pth_keys)}, "epoch": 120}, src)
+        run("convert_resnet_ws_pth.py", src, os.path.join(tmp, "ws_out.pth"))
+        out = torch.load(os.path.join(tmp, "ws_out.pth"))
+        d["pth_in"] = np.array(pth_keys)
+        d["pth_out"] = np.array([k for k, _ in sorted(out.items(), key=lambda kv: float(kv[1][0]))])
+
+        c2_keys = ["conv1_1_w", "conv1_1_bn_s", "conv1_2_w", "conv1_3_bn_b", "res2_0_branch2a_w", "res2_0_branch2a_bn_s",
+                   "res3_0_branch1_w", "res_conv1_bn_s", "fc6_w", "fc6_b", "fc7_w", "fc7_b", "pred_w",
+                   "res2_0_branch2a_w_momentum"]
+        src = os.path.join(tmp, "ws_c2.pkl")
+        with open(src, "wb") as f:
+            pickle.dump({"blobs": {k: np.full((2,), float(i), np.float32) for i, k in enumerate(c2_keys)}}, f, 2)
+        run("convert_resnet_ws_c2.py", src, os.path.join(tmp, "ws_c2_out.pkl"))
+        with open(os.path.join(tmp, "ws_c2_out.pkl"), "rb") as f:
+            out = pickle.load(f)
+        d["c2_in"] = np.array(c2_keys)
+        d["c2_out_keys"] = np.array(list(out.keys()))
+        d["c2_out_src"] = np.array([int(v[0]) for v in out.values()], dtype=np.int64)
+
+        vgg_keys = ["conv1_1_w", "conv1_1_b", "conv3_2_w", "conv5_3_b", "fc6_w", "fc6_b", "fc7_w", "fc7_b", "pred_w"]
+        src = os.path.join(tmp, "vgg.pkl")
+        with open(src, "wb") as f:
+            pickle.dump({k: np.full((2,), float(i), np.float32) for i, k in enumerate(vgg_keys)}, f, 2)
+        run("convert_vgg.py", src, os.path.join(tmp, "vgg_out.pkl"))
+        with open(os.path.join(tmp, "vgg_out.pkl"), "rb") as f:
+            out = pickle.load(f)
+        d["vgg_in"] = np.array(vgg_keys)
+        d["vgg_out_keys"] = np.array(list(out.keys()))
+        d["vgg_out_src"] = np.array([int(v[0]) for v in out.values()], dtype=np.int64)
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **d)
+    print("wrote", path)
+
+
 if __name__ == "__main__":
     torch.manual_seed(0)
     torch.set_num_threads(8)
@@ -843,6 +955,8 @@ if __name__ == "__main__":
         case_voc_eval("voc_eval", 51)
     if "data" in which:
         case_data("data_mapper", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4, 41)
+    if "convert" in which:
+        case_convert("convert", seed=31)
     if "ckpt" in which:
         case_checkpoint("ckpt_r50c4_tiny", "PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml", TINY_R50 + C4)
     if "tta" in which:
