@@ -34,6 +34,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 METRIC = "images/sec training, VOC07 DRN-WSOD R50-C4 2k proposals, 1/2/4/8 GPUs"
+PMC_TRAFFIC_RECORD = "r2_22_pmc_fc6_gemm.json"  # re-measured at the end of round 2 (round 1: r1_04_pmc_fc6_gemm.json, same 1.44x)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
@@ -212,10 +213,10 @@ def hbm_rooflines(model, batch, R, device, ops, opt=None):
 
 def pmc_traffic(shape):
     """HBM bytes per launch of the roofline kernel from the committed PMC passes (rocprofv3 --pmc FETCH_SIZE and
-    WRITE_SIZE run separately on tools/pmc_gemm.py, corrected as profiles/r1_04_pmc_fc6_gemm.json records). PMC
+    WRITE_SIZE run separately on tools/pmc_gemm.py, corrected as profiles/r2_22_pmc_fc6_gemm.json records). PMC
     counters cannot be collected from inside this process, so the value is the recorded measurement for exactly this
     kernel and shape, or None when the shape differs."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r1_04_pmc_fc6_gemm.json")
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", PMC_TRAFFIC_RECORD)
     try:
         rec = json.load(open(path))
     except OSError:
@@ -475,7 +476,7 @@ def main():
         launches = []
         if fwd:
             roof = dict(fwd)
-            roof.update({"traffic": pmc_traffic((Rtot, D1, K1)), "traffic_source": "profiles/r1_04_pmc_fc6_gemm.json: "
+            roof.update({"traffic": pmc_traffic((Rtot, D1, K1)), "traffic_source": "profiles/" + PMC_TRAFFIC_RECORD + ": "
                          "separate rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over tools/pmc_gemm.py for this kernel and "
                          "shape - PMC counters cannot be read from inside this process",
                          "mfma_util_pmc": pmc_mfma_util((Rtot, D1, K1)),
