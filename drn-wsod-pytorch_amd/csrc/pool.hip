@@ -114,6 +114,8 @@ struct RoiParams {
   char* out_t;   // optional transposed copy [C*P*P][ld_out_t] (column = roi), or null
   long ld_out_t;
   int gpw;       // whole-map kernel: consecutive 8-ROI groups handled by one block (per staged map slice)
+  int dbg;       // PROBE
+  int cpb;       // 64-ROI kernel: consecutive 8-channel chunks handled by one block (bin bounds computed once per block)
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -689,12 +691,14 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
   __shared__ unsigned char hb[ROI_G64][7][2], wb[ROI_G64][7][2];
   __shared__ int bidx[ROI_G64];
   __shared__ float mulv[ROI_G64];
-  const int nchunks = p.C / G64_CH;
+  const int nchunks = p.C / G64_CH, nblk = nchunks / p.cpb;   // blocks per ROI group
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  const int group = logical / nchunks, chunk = logical - group * nchunks;
-  const int c0 = chunk * G64_CH, m0 = group * ROI_G64;
+  const int group = logical / nblk, cb = logical - group * nblk;
+  const int m0 = group * ROI_G64;
   const int nr = min(ROI_G64, p.M - m0);
   const int tid = threadIdx.x, nthr = blockDim.x;
+  if (p.dbg & 64) return;
+  if (!(p.dbg & 128))
   for (int i = tid; i < ROI_G64 * 7; i += nthr) {
     const int r = i / 7, k = i - r * 7;
     if (r < nr) {
@@ -714,10 +718,22 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
     }
   }
   __syncthreads();
+  // runs of ROIs on the same image, as a bit mask of run ends (bit r: ROI r is the last of its run).  The walk that
+  // used to find each run's end - `while (bidx[r1] == b) ++r1`: 64 dependent LDS reads in every thread, per chunk -
+  // was 40-50 us of the 141-us launch (knock-outs, profiles/r2_24_*)
+  __shared__ unsigned long long runmask;
+  if (tid < 64) {
+    const bool last = tid + 1 >= nr || bidx[tid + 1] != bidx[tid];
+    const unsigned long long m = __ballot(last && tid < nr);
+    if (tid == 0) runmask = m;
+  }
+  __syncthreads();
+  const unsigned long long runs = runmask;
+  for (int cc = 0; cc < p.cpb; ++cc) {  // the block's channel chunks: same ROIs, same bin bounds
+  const int c0 = (cb * p.cpb + cc) * G64_CH;
   for (int r0 = 0; r0 < nr;) {  // one pass per run of ROIs on the same image
     const int b = bidx[r0];
-    int r1 = r0 + 1;
-    while (r1 < nr && bidx[r1] == b) ++r1;
+    const int r1 = r0 + __builtin_ctzll(runs >> r0) + 1;
     const char* fb = p.feat + ((long)b * HW * p.C + c0) * 2;
     const int lo = (int)0x80008000u;
     i32x4_t acc[JMAX];
@@ -726,6 +742,7 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
     for (int y0 = 0; y0 < p.H; y0 += band_rows) {
       const int y1 = min(p.H, y0 + band_rows), npx = (y1 - y0) * p.W;
       const char* fbb = fb + (long)y0 * p.W * p.C * 2;
+      if (!(p.dbg & 16))
       for (int px = tid; px < npx; px += nthr) {
         i32x4_t x = *(const i32x4_t*)(fbb + (long)px * p.C * 2);
 #pragma unroll
@@ -736,11 +753,12 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
 #pragma unroll
       for (int j = 0; j < JMAX; ++j) {
         const int it = r0 * PP + tid + j * nthr;
-        if (it < r1 * PP) {
+        if (it < r1 * PP && !(p.dbg & 32)) {
           const int r = it / PP, bin = it - r * PP;
           const int ph = bin / 7, pw = bin - ph * 7;
           const int hs = max((int)hb[r][ph][0], y0), he = min((int)hb[r][ph][1], y1);
           const int ws = wb[r][pw][0], we = wb[r][pw][1];
+          if (!(p.dbg & 1))
           for (int h = hs; h < he; ++h) {
             const char* row = map + (long)((h - y0) * p.W) * 16;
             for (int w = ws; w < we; ++w) {
@@ -756,7 +774,7 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
 #pragma unroll
     for (int j = 0; j < JMAX; ++j) {
       const int it = r0 * PP + tid + j * nthr;
-      if (it < r1 * PP) {
+      if (it < r1 * PP && !(p.dbg & 2)) {
         const int r = it / PP, bin = it - r * PP;
         const int ph = bin / 7, pw = bin - ph * 7;
         const bool empty = hb[r][ph][1] <= hb[r][ph][0] || wb[r][pw][1] <= wb[r][pw][0];
@@ -777,13 +795,14 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
   __syncthreads();  // the tile is complete
   // A: nr runs of 784 bytes (49 x 16 B), rows of the tile are 8-byte aligned
   typedef int i32x2_t __attribute__((ext_vector_type(2)));
+  if (!(p.dbg & 4))
   for (int v = tid; v < nr * PP; v += nthr) {
     const int rr = v / PP, q = v - rr * PP;
     const char* src = tile + (long)rr * G64_PITCH + q * 16;
     const i32x2_t a = *(const i32x2_t*)src, b2 = *(const i32x2_t*)(src + 8);
     *(i32x4_t*)(p.out + ((long)(m0 + rr) * p.ld_out + (long)c0 * PP) * 2 + (long)q * 16) = i32x4_t{a[0], a[1], b2[0], b2[1]};
   }
-  if (p.out_t) {
+  if (p.out_t && !(p.dbg & 8)) {
     char* ot = p.out_t + ((long)c0 * PP * p.ld_out_t + m0) * 2;
     if (nr == ROI_G64) {
       for (int v = tid; v < G64_RUN * 8; v += nthr) {  // (k row, 8-ROI octet): 8 lanes write one full 128-byte line
@@ -802,12 +821,26 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
           ((bf16_t*)(ot + (long)idx * p.ld_out_t * 2))[rr] = *(const bf16_t*)(tile + (long)rr * G64_PITCH + idx * 2);
     }
   }
+  if (cc + 1 < p.cpb) __syncthreads();  // the tile is free for the next chunk
+  }  // channel chunks of this block
+}
+
+static int cu_count_pool() {
+  static int n = 0;
+  if (!n) {
+    int dev = 0;
+    hipDeviceProp_t pr;
+    n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0)
+            ? pr.multiProcessorCount : 256;
+  }
+  return n;
 }
 
 static int g_roi_map64 = 512;  // drn_tune(DRN_TUNE_ROI_MAP64): 0 = off, else threads per block (256 / 512 / 1024)
 
 static bool launch_roi_map64(const RoiParams& p0, hipStream_t st) {
   RoiParams p = p0;
+  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DRN_ROI_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   if (!g_roi_map64 || p.C % G64_CH || p.H > 255 || p.W > 255) return false;
   const size_t tile_b = (size_t)ROI_G64 * G64_PITCH, budget = 154 * 1024 - tile_b;  // (+ ~1.5 KB of static LDS)
   size_t map_b = ((size_t)p.H * p.W * 16 + 15) & ~(size_t)15;
@@ -836,7 +869,15 @@ static bool launch_roi_map64(const RoiParams& p0, hipStream_t st) {
   // one block per CU (maps beyond ~38x38): 1024 threads - the window scans are latency-bound and eight waves per CU hide
   // little of it (63x92 map, 2000 proposals: 467 -> 394 us); two blocks per CU: the tuned 512
   const int threads = smem > 76 * 1024 && g_roi_map64 == 512 ? 1024 : g_roi_map64;
-  const dim3 grid((p.C / G64_CH) * ngroups), block(threads);
+  // channel chunks per block: the bin bounds of a 64-ROI group (448 box roundings behind a global load) and the block's
+  // start-up are paid once per `cpb` chunks instead of once per chunk (knock-outs at 14x14 / R = 2000: 60 of the 141 us
+  // were this skeleton); largest power of two <= 8 that still leaves two blocks for every CU
+  int cpb = 8;
+  { static int e = -1; if (e < 0) { const char* v = getenv("DRN_ROI_CPB"); e = v ? atoi(v) : 0; } if (e > 0) cpb = e; }
+  const int nchunks = p.C / G64_CH;
+  while (cpb > 1 && (nchunks % cpb || (long)(nchunks / cpb) * ngroups < 2L * cu_count_pool())) cpb >>= 1;
+  p.cpb = cpb;
+  const dim3 grid((nchunks / cpb) * ngroups), block(threads);
   if (threads >= 1024) hipLaunchKernelGGL(roi_pool7_map64_kernel<4>, grid, block, smem, st, p);
   else if (threads >= 512) hipLaunchKernelGGL(roi_pool7_map64_kernel<7>, grid, block, smem, st, p);
   else hipLaunchKernelGGL(roi_pool7_map64_kernel<13>, grid, block, smem, st, p);
