@@ -1526,6 +1526,8 @@ int drn_gemm_set_tile(int tile) {
 // tuning knobs (A/B measurements and tests; defaults are the measured best).  Returns the previous value or -1.
 int drn_sgd_set_grid(int blocks_x);  // head.hip
 int drn_roi_set_map64(int on);        // pool.hip
+int drn_roi_set_chunks(int cpb);      // pool.hip
+int drn_roi_set_prefetch(int on);     // pool.hip
 int drn_tune(int knob, int value) {
   if (knob == 1) {  // DRN_TUNE_GEMM_PERSISTENT
     const int old = g_persistent;
@@ -1534,6 +1536,8 @@ int drn_tune(int knob, int value) {
   }
   if (knob == 2) return drn_sgd_set_grid(value);  // DRN_TUNE_SGD_GRID
   if (knob == 4) return drn_roi_set_map64(value);  // DRN_TUNE_ROI_MAP64
+  if (knob == 10) return drn_roi_set_chunks(value);    // DRN_TUNE_ROI_CPB
+  if (knob == 11) return drn_roi_set_prefetch(value);  // DRN_TUNE_ROI_PREFETCH
   if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
     const int old = g_conv_ksplit;
     g_conv_ksplit = value != 0;

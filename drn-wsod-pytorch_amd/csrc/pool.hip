@@ -114,8 +114,8 @@ struct RoiParams {
   char* out_t;   // optional transposed copy [C*P*P][ld_out_t] (column = roi), or null
   long ld_out_t;
   int gpw;       // whole-map kernel: consecutive 8-ROI groups handled by one block (per staged map slice)
-  int dbg;       // PROBE
   int cpb;       // 64-ROI kernel: consecutive 8-channel chunks handled by one block (bin bounds computed once per block)
+  int pf;        // 64-ROI kernel: two map buffers, the next chunk's slice is fetched under this chunk's scan
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -677,7 +677,7 @@ __global__ __launch_bounds__(256) void roi_pool7_map_kernel(RoiParams p) {
 constexpr int ROI_G64 = 64;
 constexpr int G64_CH = 8, G64_RUN = G64_CH * 49, G64_PITCH = G64_RUN * 2 + 8, G64_THREADS = 512;
 template <int JMAX>  // (ROI, bin) items per thread: ceil(64 * 49 / threads) = 13 / 7 / 4 for 256 / 512 / 1024 threads
-__global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
+__global__ __launch_bounds__(JMAX >= 13 ? 256 : JMAX >= 7 ? 512 : 1024, JMAX >= 13 ? 2 : 4) void roi_pool7_map64_kernel(RoiParams p) {
   constexpr int PP = 49;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = p.H * p.W;
@@ -686,8 +686,8 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
   // the slice per 8 ROIs (1.4 ms per call there).  A (ROI, bin) item keeps its running maximum in registers across the bands.
   const int band_rows = p.lds_px >= HW ? p.H : p.lds_px / p.W;
   const long map_bytes = ((long)(band_rows < p.H ? band_rows * p.W : HW) * 16 + 15) & ~15L;
-  char* map = smem;                                          // [band pixels][8 channels, order-mapped bf16]
-  char* tile = smem + map_bytes;                             // [64][G64_PITCH]
+  // [band pixels][8 channels, order-mapped bf16]; p.pf: two such buffers, chunk cc scans buffer cc & 1
+  char* tile = smem + (p.pf ? 2 : 1) * map_bytes;            // [64][G64_PITCH]
   __shared__ unsigned char hb[ROI_G64][7][2], wb[ROI_G64][7][2];
   __shared__ int bidx[ROI_G64];
   __shared__ float mulv[ROI_G64];
@@ -697,8 +697,6 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
   const int m0 = group * ROI_G64;
   const int nr = min(ROI_G64, p.M - m0);
   const int tid = threadIdx.x, nthr = blockDim.x;
-  if (p.dbg & 64) return;
-  if (!(p.dbg & 128))
   for (int i = tid; i < ROI_G64 * 7; i += nthr) {
     const int r = i / 7, k = i - r * 7;
     if (r < nr) {
@@ -729,99 +727,168 @@ __global__ __launch_bounds__(1024) void roi_pool7_map64_kernel(RoiParams p) {
   }
   __syncthreads();
   const unsigned long long runs = runmask;
-  for (int cc = 0; cc < p.cpb; ++cc) {  // the block's channel chunks: same ROIs, same bin bounds
-  const int c0 = (cb * p.cpb + cc) * G64_CH;
-  for (int r0 = 0; r0 < nr;) {  // one pass per run of ROIs on the same image
-    const int b = bidx[r0];
-    const int r1 = r0 + __builtin_ctzll(runs >> r0) + 1;
-    const char* fb = p.feat + ((long)b * HW * p.C + c0) * 2;
-    const int lo = (int)0x80008000u;
-    i32x4_t acc[JMAX];
+  // Per-thread item table, computed ONCE per block: item j of this thread is (ROI, bin) number tid + j * nthr of the
+  // group, whatever the chunk - its window, its tile / A offsets, its scale and its "empty bin" flag do not depend on
+  // the channels.  (They used to be re-derived - two divisions, four byte loads, the 64-bit output address - in the scan,
+  // again in the epilogue and again in the A store loop of every chunk: the launch is VALU-issue bound, ~1400
+  // instructions per thread and chunk at 4 cycles each.)
+  int win[JMAX];    // hs | he << 8 | ws << 16 | we << 24 (map coordinates)
+  int meta[JMAX];   // r | bin << 8 | empty << 16 | valid << 17
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) acc[j] = i32x4_t{lo, lo, lo, lo};
-    for (int y0 = 0; y0 < p.H; y0 += band_rows) {
-      const int y1 = min(p.H, y0 + band_rows), npx = (y1 - y0) * p.W;
-      const char* fbb = fb + (long)y0 * p.W * p.C * 2;
-      if (!(p.dbg & 16))
-      for (int px = tid; px < npx; px += nthr) {
-        i32x4_t x = *(const i32x4_t*)(fbb + (long)px * p.C * 2);
+  for (int j = 0; j < JMAX; ++j) {
+    const int it = tid + j * nthr;
+    const bool valid = it < nr * PP;
+    const int r = valid ? it / PP : 0, bin = valid ? it - r * PP : 0;
+    const int ph = bin / 7, pw = bin - ph * 7;
+    const int hs = hb[r][ph][0], he = hb[r][ph][1], ws = wb[r][pw][0], we = wb[r][pw][1];
+    win[j] = hs | he << 8 | ws << 16 | we << 24;
+    meta[j] = r | bin << 8 | ((he <= hs || we <= ws) ? 1 << 16 : 0) | (valid ? 1 << 17 : 0);
+  }
+  // p.pf (whole map in one band, <= 2 pixels per thread): the slice of the NEXT chunk (first run's image) is fetched
+  // into registers at the top of a chunk and moved into the other map buffer behind the scan: no chunk but the first
+  // waits for a global load, and the wait sits in front of this chunk's stores in program order (vmcnt counts loads
+  // and stores in order), so the stores drain under the next chunk's scan.
+  i32x4_t pfr[2];
+  const int b_first = bidx[0];
+  auto fetch = [&](int c0_) {
+    const char* src = p.feat + ((long)b_first * HW * p.C + c0_) * 2;
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int px = tid + q * nthr;
+      if (px < HW) pfr[q] = *(const i32x4_t*)(src + (long)px * p.C * 2);
+    }
+  };
+  auto stash = [&](char* dst) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int px = tid + q * nthr;
+      if (px < HW) {
+        i32x4_t x = pfr[q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
-        *(i32x4_t*)(map + (long)px * 16) = x;
+        *(i32x4_t*)(dst + (long)px * 16) = x;
       }
-      __syncthreads();
+    }
+  };
+  if (p.pf) {
+    fetch(cb * p.cpb * G64_CH);
+    stash(smem);
+    __syncthreads();
+  }
+  typedef int i32x2_t __attribute__((ext_vector_type(2)));
+  for (int cc = 0; cc < p.cpb; ++cc) {  // the block's channel chunks: same ROIs, same bin bounds
+    const int c0 = (cb * p.cpb + cc) * G64_CH;
+    // the packed table stays packed: without this the compiler hoists every unpacked field (and every product with a
+    // pitch) out of the chunk loop - ~60 more live registers, i.e. spills at the 128 that two blocks per CU allow
 #pragma unroll
-      for (int j = 0; j < JMAX; ++j) {
-        const int it = r0 * PP + tid + j * nthr;
-        if (it < r1 * PP && !(p.dbg & 32)) {
-          const int r = it / PP, bin = it - r * PP;
-          const int ph = bin / 7, pw = bin - ph * 7;
-          const int hs = max((int)hb[r][ph][0], y0), he = min((int)hb[r][ph][1], y1);
-          const int ws = wb[r][pw][0], we = wb[r][pw][1];
-          if (!(p.dbg & 1))
-          for (int h = hs; h < he; ++h) {
-            const char* row = map + (long)((h - y0) * p.W) * 16;
-            for (int w = ws; w < we; ++w) {
-              const i32x4_t x = *(const i32x4_t*)(row + w * 16);
+    for (int j = 0; j < JMAX; ++j) asm volatile("" : "+v"(win[j]), "+v"(meta[j]));
+    char* map = p.pf ? smem + (cc & 1) * map_bytes : smem;
+    if (p.pf && cc + 1 < p.cpb) fetch(c0 + G64_CH);
+    for (int r0 = 0; r0 < nr;) {  // one pass per run of ROIs on the same image
+      const int b = bidx[r0];
+      const int r1 = r0 + __builtin_ctzll(runs >> r0) + 1;
+      const char* fb = p.feat + ((long)b * HW * p.C + c0) * 2;
+      const int lo = (int)0x80008000u;
+      i32x4_t acc[JMAX];
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[j][e] = pk_max_i16(acc[j][e], x[e]);
+      for (int j = 0; j < JMAX; ++j) acc[j] = i32x4_t{lo, lo, lo, lo};
+      for (int y0 = 0; y0 < p.H; y0 += band_rows) {
+        const int y1 = min(p.H, y0 + band_rows), npx = (y1 - y0) * p.W;
+        const char* fbb = fb + (long)y0 * p.W * p.C * 2;
+        if (!(p.pf && r0 == 0)) {  // (prefetch mode: the first run's slice is in LDS already, behind a barrier)
+          for (int px = tid; px < npx; px += nthr) {
+            i32x4_t x = *(const i32x4_t*)(fbb + (long)px * p.C * 2);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
+            *(i32x4_t*)(map + (long)px * 16) = x;
+          }
+          __syncthreads();
+        }
+#pragma unroll
+        for (int j = 0; j < JMAX; ++j) {
+          const int r = meta[j] & 0xff;
+          if ((meta[j] >> 17 & 1) && r >= r0 && r < r1) {
+            const int hs = max(win[j] & 0xff, y0), he = min(win[j] >> 8 & 0xff, y1);
+            const int ws = win[j] >> 16 & 0xff, we = win[j] >> 24 & 0xff;
+            for (int h = hs; h < he; ++h) {
+              const char* row = map + (long)((h - y0) * p.W) * 16;
+              for (int w = ws; w < we; ++w) {
+                const i32x4_t x = *(const i32x4_t*)(row + w * 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][e] = pk_max_i16(acc[j][e], x[e]);
+              }
             }
           }
         }
+        if (!(p.pf && r1 == nr)) __syncthreads();  // the band may be replaced (prefetch mode, last run: this buffer rests for two chunks)
       }
-      __syncthreads();  // the band may be replaced
-    }
 #pragma unroll
-    for (int j = 0; j < JMAX; ++j) {
-      const int it = r0 * PP + tid + j * nthr;
-      if (it < r1 * PP && !(p.dbg & 2)) {
-        const int r = it / PP, bin = it - r * PP;
-        const int ph = bin / 7, pw = bin - ph * 7;
-        const bool empty = hb[r][ph][1] <= hb[r][ph][0] || wb[r][pw][1] <= wb[r][pw][0];
-        const float mul = mulv[r];
-        bf16_t* dst = (bf16_t*)(tile + (long)r * G64_PITCH) + bin;
+      for (int j = 0; j < JMAX; ++j) {
+        const int r = meta[j] & 0xff, bin = meta[j] >> 8 & 0xff;
+        if ((meta[j] >> 17 & 1) && r >= r0 && r < r1) {
+          const bool empty = meta[j] >> 16 & 1;
+          const float mul = mulv[r];
+          bf16_t* dst = (bf16_t*)(tile + r * G64_PITCH) + bin;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const uint32_t y = (uint32_t)bf16x2_order(acc[j][e]);
-          const float f0 = empty ? 0.f : __builtin_bit_cast(float, y << 16);
-          const float f1 = empty ? 0.f : __builtin_bit_cast(float, y & 0xffff0000u);
-          dst[(2 * e) * PP] = f32_to_bf16(f0 * mul);
-          dst[(2 * e + 1) * PP] = f32_to_bf16(f1 * mul);
+          for (int e = 0; e < 4; ++e) {
+            const uint32_t y = (uint32_t)bf16x2_order(acc[j][e]);
+            const float f0 = empty ? 0.f : __builtin_bit_cast(float, y << 16);
+            const float f1 = empty ? 0.f : __builtin_bit_cast(float, y & 0xffff0000u);
+            dst[(2 * e) * PP] = f32_to_bf16(f0 * mul);
+            dst[(2 * e + 1) * PP] = f32_to_bf16(f1 * mul);
+          }
         }
       }
+      r0 = r1;
     }
-    r0 = r1;
-  }
-  __syncthreads();  // the tile is complete
-  // A: nr runs of 784 bytes (49 x 16 B), rows of the tile are 8-byte aligned
-  typedef int i32x2_t __attribute__((ext_vector_type(2)));
-  if (!(p.dbg & 4))
-  for (int v = tid; v < nr * PP; v += nthr) {
-    const int rr = v / PP, q = v - rr * PP;
-    const char* src = tile + (long)rr * G64_PITCH + q * 16;
-    const i32x2_t a = *(const i32x2_t*)src, b2 = *(const i32x2_t*)(src + 8);
-    *(i32x4_t*)(p.out + ((long)(m0 + rr) * p.ld_out + (long)c0 * PP) * 2 + (long)q * 16) = i32x4_t{a[0], a[1], b2[0], b2[1]};
-  }
-  if (p.out_t && !(p.dbg & 8)) {
-    char* ot = p.out_t + ((long)c0 * PP * p.ld_out_t + m0) * 2;
-    if (nr == ROI_G64) {
-      for (int v = tid; v < G64_RUN * 8; v += nthr) {  // (k row, 8-ROI octet): 8 lanes write one full 128-byte line
-        const int idx = v >> 3, q = v & 7;
-        const char* src = tile + (long)(8 * q) * G64_PITCH + idx * 2;
-        uint32_t w[4];
+    if (p.pf && cc + 1 < p.cpb) stash(smem + ((cc + 1) & 1) * map_bytes);  // (that buffer's readers: chunk cc - 1, two barriers ago)
+    __syncthreads();  // the tile is complete (and the next chunk's slice visible)
+    // A: nr runs of 784 bytes (49 x 16 B), rows of the tile are 8-byte aligned; piece j of this thread = its item j
+    char* oa = p.out + ((long)m0 * p.ld_out + (long)c0 * PP) * 2;
+    const int ld2 = (int)(p.ld_out * 2);  // (64 rows x ld_out x 2 B fits 31 bits: ld_out < 16 M elements)
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-          w[k] = (uint32_t)(*(const bf16_t*)(src + (long)(2 * k) * G64_PITCH)) |
-                 ((uint32_t)(*(const bf16_t*)(src + (long)(2 * k + 1) * G64_PITCH)) << 16);
-        *(i32x4_t*)(ot + (long)idx * p.ld_out_t * 2 + q * 16) = i32x4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+    for (int j = 0; j < JMAX; ++j) {
+      if (meta[j] >> 17 & 1) {
+        const int r = meta[j] & 0xff, bin = meta[j] >> 8 & 0xff;
+        const char* src = tile + r * G64_PITCH + bin * 16;
+        const i32x2_t a = *(const i32x2_t*)src, b2 = *(const i32x2_t*)(src + 8);
+        *(i32x4_t*)(oa + (r * ld2 + bin * 16)) = i32x4_t{a[0], a[1], b2[0], b2[1]};
       }
-    } else {
-      for (int idx = tid; idx < G64_RUN; idx += nthr)
-        for (int rr = 0; rr < nr; ++rr)
-          ((bf16_t*)(ot + (long)idx * p.ld_out_t * 2))[rr] = *(const bf16_t*)(tile + (long)rr * G64_PITCH + idx * 2);
     }
-  }
-  if (cc + 1 < p.cpb) __syncthreads();  // the tile is free for the next chunk
+    if (p.out_t) {
+      char* ot = p.out_t + ((long)c0 * PP * p.ld_out_t + m0) * 2;
+      if (nr == ROI_G64) {
+        // (k row, 8-ROI octet): 8 lanes write one full 128-byte line; piece i of this thread is row (tid >> 3) + i * nthr / 8
+        const int q = tid & 7;
+        const char* src = tile + (8 * q) * G64_PITCH + (tid >> 3) * 2;
+        char* dst = ot + (long)(tid >> 3) * p.ld_out_t * 2 + q * 16;
+        const long dstep = (long)(nthr >> 3) * p.ld_out_t * 2;
+#pragma unroll
+        for (int i = 0; i < JMAX; ++i) {
+          if (tid + i * nthr < G64_RUN * 8) {
+            uint32_t w[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k)
+              w[k] = (uint32_t)(*(const bf16_t*)(src + (2 * k) * G64_PITCH)) |
+                     ((uint32_t)(*(const bf16_t*)(src + (2 * k + 1) * G64_PITCH)) << 16);
+            *(i32x4_t*)dst = i32x4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
+          }
+          src += (nthr >> 3) * 2;
+          dst += dstep;
+        }
+      } else {
+        for (int idx = tid; idx < G64_RUN; idx += nthr)
+          for (int rr = 0; rr < nr; ++rr)
+            ((bf16_t*)(ot + (long)idx * p.ld_out_t * 2))[rr] = *(const bf16_t*)(tile + (long)rr * G64_PITCH + idx * 2);
+      }
+    }
+    if (cc + 1 < p.cpb) {
+      // the tile is free for the next chunk: every wave's LDS reads have returned (their data went into the stores).  A raw
+      // barrier - __syncthreads() would also wait (vmcnt) for the A / A^T stores just issued, which are meant to drain
+      // under the next chunk's scan
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
   }  // channel chunks of this block
 }
 
@@ -836,11 +903,17 @@ static int cu_count_pool() {
   return n;
 }
 
+// Chunks per block: stand-alone the launch gets faster with 4-8 (141 -> 117-125 us at 14x14 / R = 2000: bin bounds and item
+// table once per block, next slice prefetched), but INSIDE the training step it runs beside the optimizer pass and the
+// trunk's conv chain, and 512 long-lived blocks - a static partition of the work - lose to 4096 short ones that the
+// dispatcher balances over whichever CUs are free: same-box A/B of the whole step 646 img/s (1), 643 (2), 634 (8) against
+// 646 with the previous kernel (profiles/r2_26_roi_ab.txt).  Default 1; the knob stays for stand-alone pooling (inference).
+static int g_roi_cpb = 1;  // drn_tune(DRN_TUNE_ROI_CPB): most 8-channel chunks per block of the 64-ROI kernel (power of two)
+static int g_roi_pf = 1;   // drn_tune(DRN_TUNE_ROI_PREFETCH): 0/1 - second map buffer, next chunk's slice fetched under the scan
 static int g_roi_map64 = 512;  // drn_tune(DRN_TUNE_ROI_MAP64): 0 = off, else threads per block (256 / 512 / 1024)
 
 static bool launch_roi_map64(const RoiParams& p0, hipStream_t st) {
   RoiParams p = p0;
-  { static int dbg = -1; if (dbg < 0) { const char* e = getenv("DRN_ROI_DBG"); dbg = e ? atoi(e) : 0; } p.dbg = dbg; }
   if (!g_roi_map64 || p.C % G64_CH || p.H > 255 || p.W > 255) return false;
   const size_t tile_b = (size_t)ROI_G64 * G64_PITCH, budget = 154 * 1024 - tile_b;  // (+ ~1.5 KB of static LDS)
   size_t map_b = ((size_t)p.H * p.W * 16 + 15) & ~(size_t)15;
@@ -851,7 +924,15 @@ static bool launch_roi_map64(const RoiParams& p0, hipStream_t st) {
     p.lds_px = rows * p.W;
     map_b = ((size_t)p.lds_px * 16 + 15) & ~(size_t)15;
   }
-  const size_t smem = map_b + tile_b;
+  size_t smem = map_b + tile_b;
+  {
+    // prefetch mode: whole map in one band, two buffers within the same blocks-per-CU class, <= 2 pixels per thread
+    const int e = g_roi_pf;
+    const size_t cls = smem <= 76 * 1024 ? 76 * 1024 : 156 * 1024;
+    const int thr = smem > 76 * 1024 && g_roi_map64 == 512 ? 1024 : g_roi_map64;
+    p.pf = e && p.lds_px == p.H * p.W && smem + map_b <= cls && p.H * p.W <= 2 * thr;
+    if (p.pf) smem += map_b;
+  }
   // <= 76 KB: two blocks per CU (the 14x14 .. 38x38 maps).  Up to 156 KB - the 40x60 .. 63x100 maps of real-size training
   // images - ONE block per CU still stages its 8-channel map slice once per 64 ROIs; the 8-ROI whole-map kernel that
   // these maps used to fall to re-stages it per 8 ROIs (2.9 GB through L2 per call at 63x92: 1.5 ms, half of the eager
@@ -869,11 +950,10 @@ static bool launch_roi_map64(const RoiParams& p0, hipStream_t st) {
   // one block per CU (maps beyond ~38x38): 1024 threads - the window scans are latency-bound and eight waves per CU hide
   // little of it (63x92 map, 2000 proposals: 467 -> 394 us); two blocks per CU: the tuned 512
   const int threads = smem > 76 * 1024 && g_roi_map64 == 512 ? 1024 : g_roi_map64;
-  // channel chunks per block: the bin bounds of a 64-ROI group (448 box roundings behind a global load) and the block's
-  // start-up are paid once per `cpb` chunks instead of once per chunk (knock-outs at 14x14 / R = 2000: 60 of the 141 us
-  // were this skeleton); largest power of two <= 8 that still leaves two blocks for every CU
-  int cpb = 8;
-  { static int e = -1; if (e < 0) { const char* v = getenv("DRN_ROI_CPB"); e = v ? atoi(v) : 0; } if (e > 0) cpb = e; }
+  // channel chunks per block (tune knob, default 1): the bin bounds of a 64-ROI group and the per-thread item table are
+  // paid once per `cpb` chunks instead of once per chunk; largest power of two <= the knob that still leaves two blocks
+  // for every CU
+  int cpb = g_roi_cpb;
   const int nchunks = p.C / G64_CH;
   while (cpb > 1 && (nchunks % cpb || (long)(nchunks / cpb) * ngroups < 2L * cu_count_pool())) cpb >>= 1;
   p.cpb = cpb;
@@ -982,6 +1062,18 @@ static bool launch_roi_map(const RoiParams& p, hipStream_t st, size_t lds_budget
 }
 
 extern "C" {
+
+int drn_roi_set_chunks(int cpb) {
+  const int old = g_roi_cpb;
+  if (cpb >= 1 && cpb <= 64 && (cpb & (cpb - 1)) == 0) g_roi_cpb = cpb;
+  return old;
+}
+
+int drn_roi_set_prefetch(int on) {
+  const int old = g_roi_pf;
+  g_roi_pf = on != 0;
+  return old;
+}
 
 int drn_roi_set_map64(int on) {
   const int old = g_roi_map64;

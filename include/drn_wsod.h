@@ -148,6 +148,8 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_GEMM_TAIL_SPLIT 6 /* 0/1: a persistent 256x256 launch whose last round would be < 3/8 full runs an exact number of rounds; the peeled tile columns go to the small-tile kernel first (default 1; bit-identical) */
 #define DRN_TUNE_CONV_KS_TILES 7 /* largest number of 64x64 tiles of ONE image's layer that still runs on the wave-K-split conv kernel (0 = default: CUs / 4) */
 #define DRN_TUNE_CONV_K2_TILES 8 /* largest number of 64x64 tiles of ONE image's layer that runs two K-groups per tile (conv_nhwc_k2_kernel); -1 = default (2 x CUs), 0 = off */
+#define DRN_TUNE_ROI_CPB 10 /* 64-ROI ROIPool: most 8-channel chunks one workgroup walks (power of two, default 1; halved until two workgroups per CU remain): bin bounds / item table once per workgroup - faster stand-alone (4-8), slower inside the training step */
+#define DRN_TUNE_ROI_PREFETCH 11 /* 0/1 (default 1): 64-ROI ROIPool keeps two map-slice buffers and fetches the next chunk's slice under the scan */
 #define DRN_TUNE_CONV_PATCH 9 /* 0 = never use the LDS-resident-patch kernel for 3x3 / 64 -> 64 channel convs; 1 = default (maps of >= 32768 pixels); > 1 = that many pixels per image at least */
 int drn_tune(int knob, int value);
 
