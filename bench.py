@@ -483,10 +483,19 @@ def main():
                          "mfma_util_source": "profiles/r1_08_pmc_mfma_fc6_gemm.json (same method)", "timed_in": where})
             launches.append(fwd)
         ends = getattr(model.roi_heads._engine, "fc1_slab_ends", None) or [D1]
+        # joint peel (run_fc1_tail): the slabs' trailing columns [n0, K1) are one small-tile launch over all rows, the slabs
+        # themselves cover columns [0, n0); without it a slab's launch is [rows x K1] (its own peel inside the call)
+        cols = {ops.gemm_nt_main_cols(b - a, K1) for a, b in zip([0] + list(ends[:-1]), ends)}
+        n0 = cols.pop() if len(cols) == 1 and len(ends) > 1 and getattr(model.roi_heads._engine, "fc1_joint_peel", 1) else K1
+        if n0 < K1:
+            e_ = entry("gemm_nt_kernel<bf16> fc6 dW peeled columns %d:%d of all rows  [%d x %d] . [%d x %d]^T"
+                       % (n0, K1, D1, Rtot, K1 - n0, Rtot), {(D1, K1 - n0, Mp)}, 2.0 * D1 * (K1 - n0) * Rtot)
+            if e_:
+                launches.append(e_)
         r0 = 0
         for r1 in ends:
-            e_ = entry("gemm_nt256_kernel<bf16> fc6 dW rows %d:%d  [%d x %d] . [%d x %d]^T" % (r0, r1, r1 - r0, Rtot, K1, Rtot),
-                       {(r1 - r0, K1, Mp)}, 2.0 * (r1 - r0) * K1 * Rtot)
+            e_ = entry("gemm_nt256_kernel<bf16> fc6 dW rows %d:%d  [%d x %d] . [%d x %d]^T" % (r0, r1, r1 - r0, Rtot, n0, Rtot),
+                       {(r1 - r0, n0, Mp)}, 2.0 * (r1 - r0) * n0 * Rtot)
             if e_:
                 launches.append(e_)
             r0 = r1

@@ -75,6 +75,8 @@ def lib():
             fn.restype = ctypes.c_int
         _lib.drn_detect_workspace_bytes.argtypes = [ctypes.c_int]
         _lib.drn_detect_workspace_bytes.restype = ctypes.c_long
+        _lib.drn_gemm_nt_main_cols.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
+        _lib.drn_gemm_nt_main_cols.restype = ctypes.c_long
         for kv in filter(None, os.environ.get("DRN_TUNE", "").split(",")):  # A/B runs: DRN_TUNE="5=0,4=1024" (drn_tune knobs)
             k, v = kv.split("=")
             _lib.drn_tune(int(k), int(v))
@@ -82,7 +84,7 @@ def lib():
 
 
 def exported_symbols():
-    return sorted(list(_SIGS) + ["drn_detect_workspace_bytes"])
+    return sorted(list(_SIGS) + ["drn_detect_workspace_bytes", "drn_gemm_nt_main_cols"])
 
 
 _ERR = {-1: "invalid argument", -2: "kernel launch failure", -3: "unsupported"}

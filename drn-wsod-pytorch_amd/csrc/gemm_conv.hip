@@ -1512,6 +1512,20 @@ int launch_conv(const ConvParams& p, hipStream_t st) {
 
 }  // namespace
 
+// Tail balancing of a persistent 256x256 launch (see drn_gemm_nt): number of leading output columns that form an exact
+// number of rounds of `nwg` resident workgroups; N when nothing is peeled.
+static long tail_split_main_cols(int M, int N, int splits, int nwg) {
+  const int tm = (M + 255) / 256, tn = (N + 255) / 256;
+  const long wg256 = (long)tm * tn * splits, rem = wg256 % nwg;
+  if (!g_tail_split || splits != 1 || rem == 0 || rem * 8 > (long)nwg * 3) return N;
+  int a = nwg, b = tm;
+  while (b) { const int t = a % b; a = b; b = t; }
+  const int step = nwg / a;                   // tile columns per exact multiple of nwg tiles
+  const int cols_main = (tn / step) * step;
+  if (cols_main > 0 && (long)(tn - cols_main) * tm == rem) return (long)cols_main * 256;
+  return N;
+}
+
 static int g_force_tile = 0;  // 0 = heuristic; 64 / 128 / 256 pin the tile (tuning + tests)
 
 extern "C" {
@@ -1572,6 +1586,16 @@ int drn_tune(int knob, int value) {
   return -1;
 }
 
+// Columns [0, n0) of an [M, N] output that drn_gemm_nt keeps for its persistent 256x256 launch; the columns from n0 on
+// are the ones it peels off into a small-tile launch first (n0 == N: no peel, or another kernel takes the shape).
+long drn_gemm_nt_main_cols(int M, int N, int splits) {
+  if (M <= 0 || N <= 0 || splits < 1) return N;
+  const long wg256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
+  if (!((g_force_tile == 256 || (g_force_tile == 0 && wg256 >= 192)))) return N;
+  const int nwg = persistent_grid(wg256);
+  return nwg ? tail_split_main_cols(M, N, splits, nwg) : N;
+}
+
 // C[split][M,N] (fp32) = A[M,K] * B[N,K]^T over this split's K range.  See include/drn_wsod.h.
 int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
                 int c_dtype, int splits, long c_split_stride, int accumulate, void* stream) {
@@ -1608,26 +1632,18 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
       // and the peeled columns (16 tiles of that slab) run first as their own launch of the small-tile kernel - many
       // short workgroups that fill every CU.  Same slab order and the same MFMA per output element in both kernels,
       // so the result is bit-identical to the unsplit launch (test_gemm_tail_split_bit_identical).
-      const int tm = (M + 255) / 256, tn = (N + 255) / 256;
-      const long rem = wg256 % nwg;
-      if (g_tail_split && splits == 1 && rem != 0 && rem * 8 <= (long)nwg * 3) {
-        int a = nwg, b = tm;
-        while (b) { const int t = a % b; a = b; b = t; }
-        const int step = nwg / a;                   // tile columns per exact multiple of nwg tiles
-        const int cols_main = (tn / step) * step;
-        if (cols_main > 0 && (long)(tn - cols_main) * tm == rem) {
-          const long n0 = (long)cols_main * 256;
-          GemmParams q = p;
-          q.B = p.B + n0 * ldb * es;
-          q.C = (float*)((char*)p.C + n0 * (p.c_bf16 ? 2 : 4));
-          q.N = N - (int)n0;
-          const bool small_t = (long)((M + 127) / 128) * ((q.N + 127) / 128) < 128;
-          const int rc = dtype == DRN_BF16
-                             ? (small_t ? launch_gemm<DRN_BF16, 64, 64>(q, 1, st) : launch_gemm<DRN_BF16, 128, 128>(q, 1, st))
-                             : (small_t ? launch_gemm<DRN_F32, 64, 64>(q, 1, st) : launch_gemm<DRN_F32, 128, 128>(q, 1, st));
-          if (rc != DRN_OK) return rc;
-          p.N = (int)n0;
-        }
+      const long n0 = tail_split_main_cols(M, N, splits, nwg);
+      if (n0 < N) {
+        GemmParams q = p;
+        q.B = p.B + n0 * ldb * es;
+        q.C = (float*)((char*)p.C + n0 * (p.c_bf16 ? 2 : 4));
+        q.N = N - (int)n0;
+        const bool small_t = (long)((M + 127) / 128) * ((q.N + 127) / 128) < 128;
+        const int rc = dtype == DRN_BF16
+                           ? (small_t ? launch_gemm<DRN_BF16, 64, 64>(q, 1, st) : launch_gemm<DRN_BF16, 128, 128>(q, 1, st))
+                           : (small_t ? launch_gemm<DRN_F32, 64, 64>(q, 1, st) : launch_gemm<DRN_F32, 128, 128>(q, 1, st));
+        if (rc != DRN_OK) return rc;
+        p.N = (int)n0;
       }
       return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, false>(p, nwg, st) : launch_gemm256p<DRN_F32, false>(p, nwg, st);
     }

@@ -853,14 +853,21 @@ class _HeadEngine:
             if fused is not None or (bucket is not None and acc):
                 raise DrnError("fused / bucketed fc6 gradient cannot be combined with gradient accumulation")
             gw = bucket if bucket is not None else self._gview("fc1.weight", (D1, K1))
-            r0 = 0
-            for r1 in ends:
-                if r0 >= r1:
-                    continue
-                ops.gemm_nt(dP1T[r0:r1], AT, r1 - r0, K1, Mp, out=gw[r0:r1].unsqueeze(0), accumulate=acc)
+            # Tail balancing peels the same trailing columns off every equal-height slab (drn_gemm_nt: a small-tile launch
+            # in front of each persistent one - 14 + 22 us and two launch gaps per step for two slabs).  When all slabs
+            # agree on the split, ONE launch computes the peeled columns of all rows first and the slabs' main columns -
+            # exact rounds - follow; same kernels' arithmetic per element (tile size does not change the summation order)
+            n0 = K1
+            slabs = [(a, b) for a, b in zip([0] + list(ends[:-1]), ends) if a < b]
+            if getattr(self, "fc1_joint_peel", 1) and len(slabs) > 1 and not acc:
+                cols = {ops.gemm_nt_main_cols(b - a, K1) for a, b in slabs}
+                if len(cols) == 1 and 0 < min(cols) < K1:
+                    n0 = cols.pop()
+                    ops.gemm_nt(dP1T, AT[n0:], D1, K1 - n0, Mp, out=gw[:, n0:].unsqueeze(0))
+            for r0, r1 in slabs:
+                ops.gemm_nt(dP1T[r0:r1], AT[:n0], r1 - r0, n0, Mp, out=gw[r0:r1, :n0].unsqueeze(0), accumulate=acc)
                 if hook is not None:
                     hook(("fc1", r0, r1))
-                r0 = r1
         self._grads_valid = True
         self._pool_current_done = True  # the last reader of this batch's A^T has been issued
         skip = fused is not None or bucket is not None

@@ -66,6 +66,12 @@ def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
     return out
 
 
+def gemm_nt_main_cols(M, N, splits=1):
+    """columns [0, n0) that drn_gemm_nt keeps for its persistent launch (n0 == N: no tail balancing for this shape)"""
+    fn = C.lib().drn_gemm_nt_main_cols
+    return int(fn(int(M), int(N), int(splits)))
+
+
 def gemm_nt_sgd(A, B, M, N, K, weights, mom, shadow, seg_dev, momentum, first_step, grad_scale=1.0):
     """weights[M,N] <- SGD step with the gradient A[M,:K] @ B[N,:K]^T, which is never materialised."""
     assert A.dtype == B.dtype and weights.dtype == torch.float32 and mom.dtype == torch.float32

@@ -113,6 +113,12 @@ int drn_cast2d(const void* in, void* out, int rows, int cols, long ld_in, long l
 
 /* ---- dense contractions ---------------------------------------------------------------------- */
 
+/* Which output columns drn_gemm_nt's persistent 256x256 launch keeps for an [M, N] output: [0, n0); the columns from n0 on
+ * are peeled into a small-tile launch first (tail balancing, DRN_TUNE_GEMM_TAIL_SPLIT).  n0 == N when nothing is peeled.
+ * Lets a caller that issues several row slabs of one product (the fc6 weight gradient: F.linear's dW, box_head.py:82-91)
+ * compute ALL slabs' peeled columns in one launch and hand the slabs' main columns - exact rounds - to drn_gemm_nt. */
+long drn_gemm_nt_main_cols(int M, int N, int splits);
+
 /* nn.Linear / F.linear and its autograd (fc6/fc7 of box_head.py:82-91, predictors of
  * fast_rcnn.py:453-461,1316-1327).  C[s][M][N] (fp32) = A[M][K] * B[N][K]^T over K-split s.
  * K*esize must be a multiple of 128 bytes (callers zero-pad K), lda/ldb multiples of 16 bytes.

@@ -135,6 +135,34 @@ def test_gemm_persistent_equals_one_tile_grid(drn, dtype, M, N, K, splits):
         drn.gemm_set_tile(prev_tile)
 
 
+def test_gemm_joint_peel_of_row_slabs_bit_identical(drn):
+    """run_fc1_tail's joint peel: two equal row slabs of one product [2048 x (68 * 256)] - each 4 x 68 = 256 + 16 tiles,
+    so drn_gemm_nt peels the same 4 trailing tile columns off both - computed (a) slab by slab, each call peeling its
+    own columns, (b) the peeled columns of ALL rows in one launch + the slabs' main columns (drn_gemm_nt_main_cols) as
+    exact rounds.  Every output element sees the same K slabs in the same order: the bf16 buckets must be bit-equal."""
+    M, N, K = 2048, 68 * 256, 256
+    A, B = _rnd((M, K), 34), _rnd((N, K), 35)
+    Ad, Bd = _padded(A, torch.bfloat16, drn), _padded(B, torch.bfloat16, drn)
+    Kp = Ad.shape[1]
+    prev_tile = drn.gemm_set_tile(0)
+    try:
+        n0 = drn.gemm_nt_main_cols(M // 2, N)
+        assert n0 == 64 * 256 and drn.gemm_nt_main_cols(M // 2, n0) == n0  # the main columns are not peeled again
+        a = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        b = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        for r0 in (0, M // 2):
+            drn.gemm_nt(Ad[r0:r0 + M // 2], Bd, M // 2, N, Kp, out=a[r0:r0 + M // 2].unsqueeze(0))
+        drn.gemm_nt(Ad, Bd[n0:], M, N - n0, Kp, out=b[:, n0:].unsqueeze(0))
+        for r0 in (0, M // 2):
+            drn.gemm_nt(Ad[r0:r0 + M // 2], Bd[:n0], M // 2, n0, Kp, out=b[r0:r0 + M // 2, :n0].unsqueeze(0))
+        torch.cuda.synchronize()
+        assert torch.equal(a, b)
+        ref = _q(A, torch.bfloat16).double() @ _q(B, torch.bfloat16).double().t()
+        assert (b.cpu().double() - ref).abs().max() <= 2.0 ** -8 * ref.abs().max() + 1e-6
+    finally:
+        drn.gemm_set_tile(prev_tile)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K", [(1024, 68 * 256 - 50, 256), (2000, 36 * 256 - 3, 192)])
 def test_gemm_tail_split_bit_identical(drn, dtype, M, N, K):
