@@ -142,13 +142,13 @@ class FusedSGD:
         d1 = self.model.roi_heads.box_head.fc1.weight.shape[0]
         world = dp.world if dp is not None else 1
         if slab_rows is None:
-            # 256-row tile granularity of the dW GEMM.  Single GPU: two equal slabs (measured: 3+ forked buckets make the
-            # HIP graph executor schedule the branches badly, 395 -> 310 img/s).  N > 1: two slabs at 5/8 of the rows -
-            # with 196 column tiles per row-tile the launches are 980 and 588 tiles = 3.83 and 2.3 rounds of the 256
-            # CUs (7 rounds, like one launch; four equal slabs would be 8), and the first fc6 bucket is final about
-            # when the all-reduce of the small tensors in front of it has drained
+            # 256-row tile granularity of the dW GEMM: two equal slabs (measured: 3+ forked buckets make the HIP graph
+            # executor schedule the branches badly, 395 -> 310 img/s).  N > 1 used 5/8 + 3/8 of the rows until the end of
+            # round 2 (980 + 588 tiles = 4 + 3 rounds of the 256 CUs where two equal slabs took 4 + 4); with tail
+            # balancing and the joint peel (run_fc1_tail) two equal slabs are 3 + 3 exact rounds + one small launch -
+            # 36 us less GEMM time, the first bucket is final earlier and both exchanges move the same bytes
             t = (d1 + 255) // 256
-            slab_rows = [min(d1, ((t + 1) // 2) * 256)] if world == 1 else [min(d1, ((5 * t + 7) // 8) * 256)]
+            slab_rows = [min(d1, ((t + 1) // 2) * 256)]
             slab_rows = sorted(set(r for r in slab_rows if 0 < r < d1)) + [d1]
         if exchange not in (None, "sharded", "allreduce"):
             raise DrnError("exchange must be 'sharded' or 'allreduce'")
