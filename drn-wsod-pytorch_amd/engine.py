@@ -765,6 +765,9 @@ class GraphedTrainStep:
         self.props = torch.zeros((M, 4), dtype=torch.float32, device=dev)
         # image-level labels live in ONE device block (one H2D copy per step): [onehot f32 | classes i32 | count i32]
         self._gt_block = torch.zeros((2 * n_img * K + n_img,), dtype=torch.int32, device=dev)
+        # labels of the NEXT batch land here (H2D on the side stream); the pooling graph moves them into the block the
+        # heads graph reads - a node inside a graph instead of an eager copy with two launch gaps on the main stream
+        self._gt_stage = torch.zeros_like(self._gt_block)
         nk = n_img * K
         self.gt = dict(onehot=self._gt_block[:nk].view(torch.float32).view(n_img, K),
                        classes=self._gt_block[nk: 2 * nk].view(n_img, K), count=self._gt_block[2 * nk:],
@@ -777,7 +780,7 @@ class GraphedTrainStep:
         self.engine.defer_fc1_tail = self.split_tail
 
     # ---- host side of one step: stage inputs into the static buffers (tiny async copies) -----------------------
-    def _stage_labels(self, batch):
+    def _stage_labels(self, batch, dst=None):
         """Image-level labels of the CURRENT batch.  They are built on the host and go through a ring of PINNED
         staging buffers so the H2D copies are truly asynchronous - a pageable source would block the host until the
         previous replay has drained and leave the GPU idle between replays."""
@@ -798,17 +801,19 @@ class GraphedTrainStep:
             oh[i, g] = 1
             cl[i, : len(g)] = g.to(torch.int32)
             buf[2 * nk + i] = len(g)
-        self._gt_block.copy_(buf, non_blocking=True)
+        (self._gt_block if dst is None else dst).copy_(buf, non_blocking=True)
         slot["ev"] = torch.cuda.Event()
         slot["ev"].record()
 
-    def _stage_labels_ahead(self, next_batch):
-        """Labels of the NEXT batch, issued in this step's tail (behind the heads graph, the only reader of the label
-        block, and in front of the pooling graph): the H2D copy and its launch gap leave the pooling -> fc6 forward
-        hand-over of the next step (timeline: 14 us between the two kernels for a 4-us copy).  step() skips its own
-        staging when it is handed this very batch."""
+    def _stage_labels_ahead(self, next_batch, via_stage=False):
+        """Labels of the NEXT batch, issued during this step instead of at the start of their own (where a 4-us H2D copy
+        and its two launch gaps sat between the pooling kernel and the fc6 forward).  via_stage (lookahead >= 2 / pairs,
+        called on the side stream next to the proposals): into `_gt_stage`, from where the pooling graph - which runs
+        behind this step's heads graph, the label block's reader - copies them into the block; otherwise straight into
+        the block on the current stream, behind the heads graph.  step() skips its own staging when it is handed this
+        very batch."""
         if next_batch is not None and self.stage_ahead:
-            self._stage_labels(next_batch)
+            self._stage_labels(next_batch, self._gt_stage if via_stage else None)
             self._labels_for = next_batch
 
     def _stage_labels_now(self, batch):
@@ -853,6 +858,8 @@ class GraphedTrainStep:
         # small copy goes IN FRONT of the pooling kernel (its last reader, the previous heads graph, is long done) so that
         # nothing sits between the pooling and the fc6 forward
         self.props.copy_(self.rois_next[:, 1:])
+        if slot is not None and self.stage_ahead:
+            self._gt_block.copy_(self._gt_stage)  # the next batch's labels (staged on the side stream, see _stage_labels_ahead)
         self.pooled = self.engine.pool(feat, self.rois_next, self.obj_next, True, slot=0)
 
     # ---- the three captured pieces ---------------------------------------------------------------------------
@@ -910,13 +917,13 @@ class GraphedTrainStep:
         side = self._sides[t % (L - 1)]
         side.wait_stream(main)
         losses = self._heads(eager)
-        self._stage_labels_ahead(next_batch)  # behind the heads graph (their reader), off the pooling -> fc6 hand-over
         if self.split_tail:
             self.engine.run_fc1_tail()
         with torch.cuda.stream(side):
             evp = None
             if self.stage_ahead:
                 self._stage_props(next_batch)  # in front of the conv chain, off the main stream (see _run_pairs)
+                self._stage_labels_ahead(next_batch, via_stage=True)
                 evp = torch.cuda.Event()
                 evp.record(side)
             self._stage_image(far_batch, sL)
@@ -992,6 +999,8 @@ class GraphedTrainStep:
         with torch.no_grad():
             n = self.n_img
             self.props.copy_(self.rois_next[:, 1:])  # in front of the pooling kernel (see _pool_next)
+            if self.stage_ahead:
+                self._gt_block.copy_(self._gt_stage)
             self.pooled = self.engine.pool(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next, True,
                                            slot=0)
 
@@ -1003,9 +1012,6 @@ class GraphedTrainStep:
         t = self._t
         self._side.wait_stream(main)
         losses = self._heads(eager)
-        # labels of batch t+1: behind their only reader (the heads graph above), in front of the eager tail - nothing is
-        # left between the pooling graph and the next step's fc6 forward
-        self._stage_labels_ahead(next_batch)
         if self.split_tail:
             self.engine.run_fc1_tail()
         with torch.cuda.stream(self._side):
@@ -1015,6 +1021,7 @@ class GraphedTrainStep:
             evp = None
             if self.stage_ahead:
                 self._stage_props(next_batch)
+                self._stage_labels_ahead(next_batch, via_stage=True)  # -> _gt_stage; the pooling graph hands them on
                 evp = torch.cuda.Event()
                 evp.record(self._side)
             if t % 2 == 0:
