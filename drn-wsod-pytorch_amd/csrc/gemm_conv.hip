@@ -1649,7 +1649,10 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
     }
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true>(p, splits, st) : launch_gemm256<DRN_F32, true>(p, splits, st);
   }
-  const bool small = force == 64 || (force == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) * splits < 128);
+  // 64x64 tiles (4x the workgroups) when 128x128 tiles would not even give every CU one workgroup: these launches are
+  // latency-bound per K slab, not MFMA-bound (the joint peel of the fc6 dW, [2048 x 1024] x K 2000: 128 tiles of 128 took
+  // 31 us; bit-identical either way)
+  const bool small = force == 64 || (force == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) * splits < cu_count());
   if (dtype == DRN_BF16) return small ? launch_gemm<DRN_BF16, 64, 64>(p, splits, st) : launch_gemm<DRN_BF16, 128, 128>(p, splits, st);
   return small ? launch_gemm<DRN_F32, 64, 64>(p, splits, st) : launch_gemm<DRN_F32, 128, 128>(p, splits, st);
 }
