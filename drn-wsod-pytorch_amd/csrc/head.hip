@@ -42,7 +42,7 @@ struct ActParams {
   const int* colidx;      // bwd: [N] index into colscale per column (-1 = 0.0), or null (colscale is [N])
   float* colpart;      // bwd: [ceil(M/ACT_ROWS)][N] scratch for the two-stage column sums
   int M, N; long ld_in; int relu; int accumulate_colsum;
-  int rows_fwd;  // fwd: rows per block (64, or 16 for skinny outputs without a transposed copy)
+  int rows_fwd;  // fwd: rows per block (64, or 4 for skinny outputs without a transposed copy)
   int in_bf16;   // bwd: grad_out holds bf16 (gradients flowing through the conv trunk in the bf16 mode)
 };
 
@@ -820,9 +820,12 @@ int drn_bias_act_fwd(const float* partials, int splits, long split_stride, const
   if (M == 0 || N == 0) return DRN_OK;
   ActParams p{partials, splits, split_stride, bias, mask, seed, drop_p, seed_dev, nullptr, (char*)out, ld_out, (char*)outT,
               ld_outT, nullptr, nullptr, nullptr, nullptr, M, N, ld_in, relu, 0, 64, 0};
-  // skinny outputs (the 103 predictor columns): 64-row blocks would give only ~64 blocks, each walking
-  // 16 rows x splits partials per thread; 16-row blocks fill the chip (no transposed copy in that case)
-  if (!outT && (long)((N + 63) / 64) * ((M + 63) / 64) < 256) p.rows_fwd = 16;
+  // skinny outputs (the 103 predictor columns; no transposed copy in that case): 64-row blocks would give only ~64
+  // blocks, each thread walking 16 rows x splits partials one row after the other.  4-row blocks: ONE row per thread,
+  // all of its split partials in flight at once (16-row blocks took 12.6 us for 8 MB - four dependent row trips; now
+  // 6.4 us).  (The same idea for the backward pass - fetch a thread's 16 rows before processing them - needed a full
+  // unroll, 253 VGPRs, and measured 18.6 instead of 12.7 us: not kept.)
+  if (!outT && (long)((N + 63) / 64) * ((M + 63) / 64) < 256) p.rows_fwd = 4;
   dim3 grid((N + 63) / 64, (M + p.rows_fwd - 1) / p.rows_fwd), block(256);
   hipStream_t st = (hipStream_t)stream;
   if (act_vec_ok(p, out_dtype)) hipLaunchKernelGGL((act_vec_kernel<false>), grid, block, 0, st, p);
