@@ -265,6 +265,7 @@ def main():
     ap.add_argument("--tune", default="", help="comma-separated knob=value pairs for drn_tune (A/B runs), e.g. 3=4")
     ap.add_argument("--engine-opt", default="", help="comma-separated attr=int pairs set on the head engine (A/B runs)")
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
+    ap.add_argument("--graph-pool", action="store_true", help="A/B: replay the pooling piece as its own graph instead of issuing it eagerly")
     ap.add_argument("--no-stage-ahead", action="store_true",
                     help="A/B: stage the next batch's proposals / labels on the main stream (round-2 order)")
     ap.add_argument("--no-eager-fc6", action="store_true",
@@ -400,7 +401,7 @@ def main():
         # behind it), so all three launches of the dominant kernel are bracketed by HIP events INSIDE the timed region
         stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead,
                                    trunk_pairs=args.trunk_pairs, eager_fc6=not args.no_eager_fc6,
-                                   stage_ahead=not args.no_stage_ahead)
+                                   stage_ahead=not args.no_stage_ahead, eager_pool=not args.graph_pool)
         try:
             for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
                 last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])

@@ -715,7 +715,7 @@ class GraphedTrainStep:
     _needs_frozen_trunk = True
 
     def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False,
-                 eager_fc6=False, stage_ahead=True):
+                 eager_fc6=False, stage_ahead=True, eager_pool=True):
         if getattr(model, "cpg", False):
             raise DrnError("CSCROIHeads decides per step, on the host, which class maps to compute: eager steps only")
         if self._needs_frozen_trunk and any(p.requires_grad for p in model.backbone.parameters()):
@@ -731,6 +731,10 @@ class GraphedTrainStep:
         # stream (False = the round-2 order, kept for A/B runs: proposals in front of the pooling graph on the main
         # stream, labels at the start of their own step, i.e. between the pooling kernel and the fc6 forward)
         self.stage_ahead = bool(stage_ahead)
+        # eager_pool: the pooling piece (two small copies + the pooling kernel) is issued eagerly instead of replayed as
+        # its own graph (lookahead >= 2 / pairs): a graph's hand-over to the next launch costs more than an eager launch gap
+        # (+0.65 % same-box A/B, profiles/r2_39_eager_pool_ab.txt); False = the graph (kept for A/B runs)
+        self.eager_pool = bool(eager_pool)
         # trunk_pairs: ONE conv chain per TWO batches (t+2 and t+3, launched on even steps): the chain is latency-bound,
         # so two images cost what one costs and the per-image chain time halves - for trunks whose chain is as long as
         # the step (WS-R101).  step() then takes (batch, next, t+2, t+3).
@@ -936,7 +940,7 @@ class GraphedTrainStep:
             self._stage_props(next_batch)
         main.wait_event(self._bb_done[s1])
         self._bb_done[sL] = ev
-        self._pool_body(s1) if eager else self.g_pool2[s1].replay()
+        self._pool_body(s1) if (eager or self.eager_pool) else self.g_pool2[s1].replay()
         if self.split_tail:
             self.opt.step(1.0)
         self._t = t + 1
@@ -973,7 +977,7 @@ class GraphedTrainStep:
                 self._bb_body(sl)
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.losses = self._main_body()
-        for sl in range(L):
+        for sl in range(L if not self.eager_pool else 0):
             with torch.cuda.graph(self.g_pool2[sl], capture_error_mode="thread_local"):
                 self._pool_body(sl)
         self._primed = True
@@ -1037,7 +1041,7 @@ class GraphedTrainStep:
             self._stage_props(next_batch)
         k1, h1 = ((t + 1) // 2) % 2, (t + 1) % 2
         main.wait_event(self._pdone[k1])
-        self._pair_pool_body(k1, h1) if eager else self.g_ppool[k1][h1].replay()
+        self._pair_pool_body(k1, h1) if (eager or self.eager_pool) else self.g_ppool[k1][h1].replay()
         if self.split_tail:
             self.opt.step(1.0)
         self._t = t + 1
@@ -1070,7 +1074,7 @@ class GraphedTrainStep:
                 self._pair_bb_body(ps)
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.losses = self._main_body()
-        for ps in (0, 1):
+        for ps in ((0, 1) if not self.eager_pool else ()):
             for h in (0, 1):
                 with torch.cuda.graph(self.g_ppool[ps][h], capture_error_mode="thread_local"):
                     self._pair_pool_body(ps, h)
