@@ -26,6 +26,7 @@ _SIGS = {
     "drn_im2col_t": "pp" + "iiiiiiiiii" + "lip",
     "drn_maxpool2x2_bwd_nhwc": "pppiiiiiip",
     "drn_add": "ppplip",
+    "drn_stage_heads_inputs": "ppippip",
     "drn_roi_pool_backward_nhwc": "ppppp" + "iiiiii" + "f" + "l" + "iiiip",
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliiilip",

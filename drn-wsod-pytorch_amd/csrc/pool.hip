@@ -1157,6 +1157,27 @@ int drn_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int Nb, int
   return DRN_OK;
 }
 
+// props[M][4] <- rois[M][1:5] and (optional) words_dst[n_words] <- words_src: the two hand-overs from the staged next
+// batch to the buffers the heads read (proposal boxes for pseudo-GT mining / IoU labelling; the image-level label block),
+// in ONE launch in front of the pooling kernel.  See include/drn_wsod.h.
+__global__ void stage_heads_kernel(const float* __restrict__ rois, float* __restrict__ props, int M,
+                                   const int* __restrict__ words_src, int* __restrict__ words_dst, int n_words) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < M * 4) props[i] = rois[(i >> 2) * 5 + 1 + (i & 3)];
+  if (i < n_words) words_dst[i] = words_src[i];
+}
+
+int drn_stage_heads_inputs(const float* rois, float* props, int M, const int* words_src, int* words_dst, int n_words,
+                           void* stream) {
+  if (M < 0 || n_words < 0 || (M > 0 && (!rois || !props)) || (n_words > 0 && (!words_src || !words_dst))) return DRN_ERR_ARG;
+  const long n = (long)M * 4 > n_words ? (long)M * 4 : n_words;
+  if (n == 0) return DRN_OK;
+  hipLaunchKernelGGL(stage_heads_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, rois, props, M,
+                     words_src, words_dst, n_words);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
 int drn_add(const void* a, const void* b, void* out, long n, int dtype, void* stream) {
   if (!a || !b || !out || n < 0) return DRN_ERR_ARG;
   if (n == 0) return DRN_OK;

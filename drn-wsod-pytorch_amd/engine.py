@@ -861,9 +861,10 @@ class GraphedTrainStep:
         # the heads only need the pooled operand and the proposal boxes (pseudo-GT mining / IoU labelling) of a batch; the
         # small copy goes IN FRONT of the pooling kernel (its last reader, the previous heads graph, is long done) so that
         # nothing sits between the pooling and the fc6 forward
-        self.props.copy_(self.rois_next[:, 1:])
-        if slot is not None and self.stage_ahead:
-            self._gt_block.copy_(self._gt_stage)  # the next batch's labels (staged on the side stream, see _stage_labels_ahead)
+        # one launch: proposal boxes -> props, and (lookahead >= 2) the next batch's labels, staged on the side stream
+        # (_stage_labels_ahead), -> the label block
+        via = slot is not None and self.stage_ahead
+        ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if via else None, self._gt_block if via else None)
         self.pooled = self.engine.pool(feat, self.rois_next, self.obj_next, True, slot=0)
 
     # ---- the three captured pieces ---------------------------------------------------------------------------
@@ -1002,9 +1003,9 @@ class GraphedTrainStep:
     def _pair_pool_body(self, ps, half):
         with torch.no_grad():
             n = self.n_img
-            self.props.copy_(self.rois_next[:, 1:])  # in front of the pooling kernel (see _pool_next)
-            if self.stage_ahead:
-                self._gt_block.copy_(self._gt_stage)
+            # in front of the pooling kernel (see _pool_next)
+            ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if self.stage_ahead else None,
+                                   self._gt_block if self.stage_ahead else None)
             self.pooled = self.engine.pool(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next, True,
                                            slot=0)
 

@@ -66,6 +66,18 @@ def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
     return out
 
 
+def stage_heads_inputs(rois, props, words_src=None, words_dst=None):
+    """props[M,4] <- rois[M,1:5]; words_dst <- words_src (int32 blocks of equal length), one launch"""
+    assert rois.dtype == torch.float32 and props.dtype == torch.float32 and rois.is_contiguous() and props.is_contiguous()
+    assert rois.shape[1] == 5 and props.shape == (rois.shape[0], 4)
+    n = 0
+    if words_src is not None:
+        assert words_src.dtype == torch.int32 and words_dst.dtype == torch.int32 and words_src.numel() == words_dst.numel()
+        n = words_src.numel()
+    C.call("drn_stage_heads_inputs", C.ptr(rois), C.ptr(props), rois.shape[0], C.ptr(words_src), C.ptr(words_dst), n,
+           C.stream())
+
+
 def gemm_nt_main_cols(M, N, splits=1):
     """columns [0, n0) that drn_gemm_nt keeps for its persistent launch (n0 == N: no tail balancing for this shape)"""
     fn = C.lib().drn_gemm_nt_main_cols

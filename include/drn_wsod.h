@@ -80,6 +80,14 @@ int drn_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int Nb, int
 /* out = a + b (gradient fan-in of a residual block). */
 int drn_add(const void* a, const void* b, void* out, long n, int dtype, void* stream);
 
+/* Hand-over from the staged NEXT batch to the buffers the heads read, one launch in front of the pooling kernel:
+ * props[M][4] <- rois[M][1:5] (the proposal boxes `label_and_sample_proposals` / `get_pgt` work on,
+ * roi_heads_oicr.py:320-421: the reference keeps them in the Instances it carries along) and, when n_words > 0,
+ * words_dst[0:n_words] <- words_src (the image-level label block of `get_image_level_gt`, roi_heads_oicr.py:287-318).
+ * Replaces two tensor copies of the host framework on the launch stream. */
+int drn_stage_heads_inputs(const float* rois, float* props, int M, const int* words_src, int* words_dst, int n_words,
+                           void* stream);
+
 /* ---- region pooling -------------------------------------------------------------------------- */
 
 /* ROIPooler.forward single-level path, detectron2/modeling/poolers.py:191-226:

@@ -202,6 +202,19 @@ def test_gemm_tail_split_bit_identical(drn, dtype, M, N, K):
         drn.gemm_set_tile(prev_tile)
 
 
+def test_stage_heads_inputs(drn):
+    """drn_stage_heads_inputs: props <- rois[:, 1:5] and the label block copy, one launch (bit-exact copies; edge sizes)"""
+    for M, n in ((2000, 41), (1, 3), (37, 0), (0, 5)):
+        rois = torch.from_numpy(np.random.RandomState(M + 1).standard_normal((M, 5)).astype(np.float32)).to(DEV)
+        props = torch.full((M, 4), -7.0, device=DEV)
+        src = torch.arange(n, dtype=torch.int32, device=DEV) * 3 - 5
+        dst = torch.full((n,), 99, dtype=torch.int32, device=DEV)
+        drn.stage_heads_inputs(rois, props, src if n else None, dst if n else None)
+        torch.cuda.synchronize()
+        assert torch.equal(props, rois[:, 1:].contiguous())
+        assert torch.equal(dst, src)
+
+
 def test_gemm_asymmetric_identity(drn):
     """A = I with an ASYMMETRIC B catches a transposed C write (cdna guide rule 16)."""
     n = 128
