@@ -68,11 +68,18 @@ def _table():
     return t
 
 
+class OffPathName(DrnError, AttributeError):
+    """An off-path name was asked of an alias module.  It is a DrnError (loud, with the reason) AND an AttributeError,
+    so Python's attribute and import protocols keep working: hasattr() / getattr(mod, x, default) return
+    False / the default, and `from detectron2.utils import comm` becomes the interpreter's own ImportError, which try/except guards
+    catch."""
+
+
 class _AliasModule(types.ModuleType):
     def __getattr__(self, name):
         if name.startswith("__"):
             raise AttributeError(name)
-        raise DrnError("%s.%s is not behind the DRN-WSOD hot path this package rebuilds (control plane / other model "
+        raise OffPathName("%s.%s is not behind the DRN-WSOD hot path this package rebuilds (control plane / other model "
                        "families of the reference are out of scope; see INTEGRATION.md)" % (self.__name__, name))
 
 

@@ -310,6 +310,156 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// PING-PONG mainloop of the 256x256 kernels (round 3; bf16).  Same tile, same wave layout (2 x 4 waves, 128x64 outputs per
+// wave as 4x2 MFMA 32x32 tiles), same MFMA and the same k order per output element as the pipelined mainloop it replaces
+// (bit-identical results), another SCHEDULE.  What the round-3 PMC passes said about the old one
+// (profiles/r3_00_pmc_fwd.json, _dw.json): the MFMA pipes are 64 % / 56 % busy at the sustained clock, every wave is
+// parked at a wait / barrier 40 % of its cycles and stalled at issue another 40-44 %, the LDS array is active 24 % of the
+// CU cycles and sees no bank conflicts - operand FEED, not LDS bandwidth.  In the old loop all eight waves run the same
+// stream in lock-step: the eight LDS-DMA issues of a slab (60-185 cycles each once the phase also carries fragment
+// reads) sit in ONE k-step group of every wave at the same time, and at the single barrier per slab both waves of a SIMD
+// are parked together, so nobody feeds the matrix pipe.  Here the two waves that share a SIMD (wave w and w + 4: the two
+// rows of the 2 x 4 layout) run HALF A PHASE APART: a K slab is four phases of
+//     [fragment reads + 2 LDS-DMA issues]  barrier  [8 MFMAs = one 64x32 quadrant x K 64, s_setprio 1]  barrier
+// and the lower wave row enters the loop one barrier late, so while one wave of a SIMD multiplies, its partner reads
+// fragments and issues DMA - the pipe always has a wave in its matrix section (cdna_hip_programming.md 8-phase
+// template, restated for 32x32x16 MFMAs and the D^T epilogue of this file).
+// LDS: a stage (64 KB) is four half tiles of 16 KB, each the rows ONE phase starts to read: A0 = the first 64 rows of both
+// wave rows' 128-row blocks, B0 = the first 32 rows of the four wave columns' 64-row blocks, B1, A1 the second halves.
+// Phase p of slab t stages ONE half tile of slab t + 1 (A0, B0, B1, A1: the order they are first read), 16 DMA pieces of
+// 1 KB spread over the slab instead of one burst; a counted vmcnt(4) in phases 4, 1 and 2 retires exactly the half tile the
+// NEXT phase starts to read and leaves the two younger ones in flight across the barriers.
+// Hazards (the lower wave row runs one barrier interval late): a half tile is read one phase after the wait that
+// retires it (every wave's wait precedes a barrier the reader passes); a half tile of stage b^1 is re-staged at phase p
+// of slab t when its last fragment read was phase <= p of slab t - 1 - six or more barriers earlier.
+constexpr int PP_A0 = 0, PP_B0 = 16384, PP_B1 = 32768, PP_A1 = 49152, PP_STAGE = 65536;
+
+// per-thread source offsets of its two 16-byte chunks of every half tile (index = half * 2 + piece): the LDS image of a
+// half tile is row-major [128][128 B], piece `pc` of thread tid lands in LDS row pc * 64 + tid / 8, slot tid & 7, and
+// fetches the k-slot pre-swizzled with that row (same involution as the fragment reads)
+__device__ __forceinline__ void pp_offsets(unsigned lda_b, unsigned ldb_b, int tid, unsigned (&voa)[4], unsigned (&vob)[4]) {
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int pc = 0; pc < 2; ++pc) {
+      const unsigned row = pc * 64 + (tid >> 3), ks = (tid & 7) ^ ((row >> 1) & 7);
+      const unsigned ga = pc * 128 + h * 64 + (tid >> 3);                             // A row: wave row pc, half h
+      const unsigned gb = (2 * pc + (tid >> 8)) * 64 + h * 32 + ((tid >> 3) & 31);    // B row: wave column 2 pc + tid / 256
+      voa[h * 2 + pc] = ga * lda_b + ks * 16;
+      vob[h * 2 + pc] = gb * ldb_b + ks * 16;
+    }
+}
+
+template <int WHICH>  // 0: A0, 1: B0, 2: B1, 3: A1 - one half tile = 2 DMA pieces per thread
+__device__ __forceinline__ void pp_issue(char* stage, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+                                         const unsigned (&voa)[4], const unsigned (&vob)[4], int wave, int slab) {
+  constexpr int off = WHICH == 0 ? PP_A0 : WHICH == 1 ? PP_B0 : WHICH == 2 ? PP_B1 : PP_A1;
+  constexpr bool isA = WHICH == 0 || WHICH == 3;
+  constexpr int h = (WHICH == 2 || WHICH == 3) ? 1 : 0;
+#pragma unroll
+  for (int pc = 0; pc < 2; ++pc) {
+    char* dst = stage + off + (pc * 64 + wave * 8) * 128;  // wave-uniform LDS base of this 1-KB piece
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)dst, 16,
+                                             isA ? voa[h * 2 + pc] : vob[h * 2 + pc], slab * 128, 0, 0);
+  }
+}
+
+#define PP_BARRIER()                        \
+  do {                                      \
+    __builtin_amdgcn_sched_barrier(0);      \
+    __builtin_amdgcn_s_barrier();           \
+    __builtin_amdgcn_sched_barrier(0);      \
+  } while (0)
+
+// prologue half: the four half tiles of slab `slab` into stage 0 (the persistent kernel issues it ahead of the previous
+// tile's epilogue)
+__device__ __forceinline__ void pp_issue_first(char* smem, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
+                                               const unsigned (&voa)[4], const unsigned (&vob)[4], int wave, int slab) {
+  pp_issue<0>(smem, ra, rb, voa, vob, wave, slab);
+  pp_issue<1>(smem, ra, rb, voa, vob, wave, slab);
+  pp_issue<2>(smem, ra, rb, voa, vob, wave, slab);
+  pp_issue<3>(smem, ra, rb, voa, vob, wave, slab);
+}
+
+// slabs [s0, s1), s0 < s1; slab s0 has been issued into stage 0 by pp_issue_first.  Every wave passes the same number of
+// barriers (wave row 1 one extra in front, wave row 0 one extra behind).
+template <int DT>
+__device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, __amdgpu_buffer_rsrc_t ra,
+                                            __amdgpu_buffer_rsrc_t rb, const unsigned (&voa)[4], const unsigned (&vob)[4],
+                                            int s0, int s1, int lane, int wave) {
+  const int wm = wave >> 2, wn = wave & 3;
+  const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
+  // LDS byte addresses of this lane's fragment of k-step ks inside the A0 / B0 half tile of the CURRENT stage; the other
+  // half tiles are immediate offsets, the other stage one XOR per slab (in place: no second register set)
+  unsigned oa[4], ob[4];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks) {
+    oa[ks] = lds0 + PP_A0 + (wm * 64 + l31) * 128 + (((ks * 2 + hi) ^ sw) << 4);
+    ob[ks] = lds0 + PP_B0 + (wn * 32 + l31) * 128 + (((ks * 2 + hi) ^ sw) << 4);
+  }
+  typedef __attribute__((address_space(3))) const i32x4_t* lds_v4;
+  i32x4_t fa[2][4], fb[4];
+  auto rdA = [&](int ks, int off) {
+    fa[0][ks] = *(lds_v4)(uintptr_t)(oa[ks] + off);
+    fa[1][ks] = *(lds_v4)(uintptr_t)(oa[ks] + off + 4096);
+  };
+  auto rdB = [&](int ks, int off) { fb[ks] = *(lds_v4)(uintptr_t)(ob[ks] + off); };
+  auto mm = [&](f32x16_t& c0, f32x16_t& c1) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      mma_step<DT>(c0, fb[ks], fa[0][ks]);  // swapped: D^T[n][m]
+      mma_step<DT>(c1, fb[ks], fa[1][ks]);
+    }
+    __builtin_amdgcn_s_setprio(0);
+  };
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PP_BARRIER();
+  if (wm == 1) PP_BARRIER();  // the lower wave row runs one barrier interval behind the upper one
+  for (int s = s0; s < s1; ++s) {
+    char* nxt = smem + (((s - s0) & 1) ^ 1) * PP_STAGE;
+    const int sn = s + 1 < s1 ? s + 1 : s1 - 1;  // past the end: the last slab again, into a stage nobody reads
+    // ---- phase 1: quadrant (a0, b0); reads in the order the MFMAs consume them (counted lgkmcnt waits)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { rdB(ks, 0); rdA(ks, 0); }
+    pp_issue<0>(nxt, ra, rb, voa, vob, wave, sn);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // B1 of this slab has landed (read in phase 2)
+    PP_BARRIER();
+    mm(acc[0][0], acc[1][0]);
+    PP_BARRIER();
+    // ---- phase 2: (a0, b1)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rdB(ks, PP_B1 - PP_B0);
+    pp_issue<1>(nxt, ra, rb, voa, vob, wave, sn);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A1 of this slab (phase 3)
+    PP_BARRIER();
+    mm(acc[0][1], acc[1][1]);
+    PP_BARRIER();
+    // ---- phase 3: (a1, b1)
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rdA(ks, PP_A1 - PP_A0);
+    pp_issue<2>(nxt, ra, rb, voa, vob, wave, sn);
+    PP_BARRIER();
+    mm(acc[2][1], acc[3][1]);
+    PP_BARRIER();
+    // ---- phase 4: (a1, b0); b0 is read again (4 reads in a phase that has none) rather than kept: 16 registers, which
+    // decide whether a trunk conv workgroup still fits beside this kernel (DESIGN 'trunk beside the GEMMs')
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) rdB(ks, 0);
+    pp_issue<3>(nxt, ra, rb, voa, vob, wave, sn);
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A0 and B0 of the next slab (its phase 1)
+    PP_BARRIER();
+    mm(acc[2][0], acc[3][0]);
+    PP_BARRIER();
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) { oa[ks] ^= PP_STAGE; ob[ks] ^= PP_STAGE; }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before LDS is reused
+  if (wm == 0) PP_BARRIER();
+}
+
+// ------------------------------------------------------------------------------------------------
 // 256x256 tile, 8 waves (2 x 4, 128x64 per wave = 4x2 MFMA 32x32 tiles), LDS-DMA staging.
 //   * global -> LDS by `buffer_load_dwordx4 ... lds` (no staging VGPRs, hardware bounds check keeps the free zero
 //     fill of ragged edges).  An LDS-DMA wave-instruction writes base + lane*16, i.e. 8 rows x 128 B, so the LDS
@@ -324,7 +474,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmParams p) {
 //     the accumulators and W / momentum / the bf16 shadow are updated in place (same arithmetic and order as
 //     sgd_kernel in head.hip), so the 411 MB gradient is neither written nor re-read and the HBM-bound optimizer
 //     pass over the largest tensor disappears as a separate launch.  Single-GPU, no-accumulation steps only.
-template <int DT, bool PIPE, bool SGD = false>
+template <int DT, bool PIPE, bool SGD = false, bool PP = false>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
@@ -384,7 +534,12 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
       for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[i][j], fb[j], fa[i]);  // swapped: D^T[n][m]
   };
   if (s0 < s1) {
-    if constexpr (PIPE) {
+    if constexpr (PP) {
+      unsigned pva[4], pvb[4];
+      pp_offsets(la.ld_bytes, lb.ld_bytes, tid, pva, pvb);
+      pp_issue_first(smem, la.rsrc, lb.rsrc, pva, pvb, wave, s0);
+      pp_mainloop<DT>(acc, smem, la.rsrc, lb.rsrc, pva, pvb, s0, s1, lane, wave);
+    } else if constexpr (PIPE) {
       // Software-pipelined schedule: fragments of k-step k+1 are read while the MFMAs of k-step k run (two register
       // sets), and ONE barrier per slab - placed after the slab's last fragment read and before its last MFMA block -
       // serves both as "slab s+1 has landed" and "everybody is done reading slab s"; the DMA of slab s+2 is issued
@@ -576,7 +731,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
 // dispatcher's round-robin, so the L2 reuse pattern of the XCD patch mapping is unchanged.
 struct GemmWork { int bm, bn, s0, s1, split; __amdgpu_buffer_rsrc_t ra, rb; };  // one (tile, K-split) work item
 
-template <int DT, bool SGD>
+template <int DT, bool SGD, bool PP = false>
 __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
@@ -637,9 +792,14 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
 #pragma unroll
       for (int jj = 0; jj < NJ; ++jj) mma_step<DT>(acc[i][jj], fb[jj], fa[i]);  // swapped: D^T[n][m]
   };
+  unsigned pva[4], pvb[4];
+  if constexpr (PP) pp_offsets(lda_b, ldb_b, tid, pva, pvb);
   Work cur;
   setup(base + j, cur);
-  if (cur.s0 < cur.s1) issue(cur, smem, cur.s0);
+  if (cur.s0 < cur.s1) {
+    if constexpr (PP) pp_issue_first(smem, cur.ra, cur.rb, pva, pvb, wave, cur.s0);
+    else issue(cur, smem, cur.s0);
+  }
   for (;;) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -648,7 +808,9 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
 #pragma unroll
         for (int rr = 0; rr < 16; ++rr) acc[i][jj][rr] = 0.f;
     const int s0 = cur.s0, s1 = cur.s1;
-    if (s0 < s1) {
+    if constexpr (PP) {
+      if (s0 < s1) pp_mainloop<DT>(acc, smem, cur.ra, cur.rb, pva, pvb, s0, s1, lane, wave);
+    } else if (s0 < s1) {
       i32x4_t fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab s0 (issued ahead of the previous tile's epilogue) has landed
       __builtin_amdgcn_s_barrier();
@@ -713,7 +875,10 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
       setup(base + j, nxt);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave is done reading both stages
-      if (nxt.s0 < nxt.s1) issue(nxt, smem, nxt.s0);
+      if (nxt.s0 < nxt.s1) {
+        if constexpr (PP) pp_issue_first(smem, nxt.ra, nxt.rb, pva, pvb, wave, nxt.s0);
+        else issue(nxt, smem, nxt.s0);
+      }
     }
     const int bm = cur.bm, bn = cur.bn;
     // D^T layout: lane -> m (A row) = lane&31, register r -> n = (r&3) + 8*(r>>2) + 4*(lane>>5)
@@ -1388,11 +1553,11 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
-template <int DT, bool PIPE, bool SGD = false>
+template <int DT, bool PIPE, bool SGD = false, bool PP = false>
 int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256_kernel<DT, PIPE, SGD>;
+  auto k = gemm_nt256_kernel<DT, PIPE, SGD, PP>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -1404,6 +1569,7 @@ int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
+static int g_pingpong = 1;  // drn_tune(DRN_TUNE_GEMM_PINGPONG = 12): bf16 256x256 GEMMs run the ping-pong mainloop
 static int g_tail_split = 1;  // drn_tune(DRN_TUNE_GEMM_TAIL_SPLIT): peel a nearly empty last round off persistent launches
 static int g_persistent = 1;  // drn_tune(DRN_TUNE_GEMM_PERSISTENT): 256x256 GEMMs with more work items than CUs loop
 
@@ -1418,10 +1584,10 @@ static int cu_count() {
   return n;
 }
 
-template <int DT, bool SGD>
+template <int DT, bool SGD, bool PP = false>
 int launch_gemm256p(const GemmParams& p, int nwg, hipStream_t st) {
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256p_kernel<DT, SGD>;
+  auto k = gemm_nt256p_kernel<DT, SGD, PP>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -1578,6 +1744,11 @@ int drn_tune(int knob, int value) {
     g_tail_split = value != 0;
     return old;
   }
+  if (knob == 12) {  // DRN_TUNE_GEMM_PINGPONG
+    const int old = g_pingpong;
+    g_pingpong = value != 0;
+    return old;
+  }
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
     const int old = g_group_rows;
     if (value >= 0 && value <= 64) g_group_rows = value;
@@ -1645,8 +1816,10 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
         if (rc != DRN_OK) return rc;
         p.N = (int)n0;
       }
+      if (dtype == DRN_BF16 && g_pingpong) return launch_gemm256p<DRN_BF16, false, true>(p, nwg, st);
       return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, false>(p, nwg, st) : launch_gemm256p<DRN_F32, false>(p, nwg, st);
     }
+    if (dtype == DRN_BF16 && g_pingpong) return launch_gemm256<DRN_BF16, true, false, true>(p, splits, st);
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true>(p, splits, st) : launch_gemm256<DRN_F32, true>(p, splits, st);
   }
   // 64x64 tiles (4x the workgroups) when 128x128 tiles would not even give every CU one workgroup: these launches are

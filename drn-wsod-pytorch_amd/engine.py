@@ -162,7 +162,18 @@ class FusedSGD:
                                        "(slab %d:%d)" % (world, r0, r1))
                     self._sharded = False  # default mode: fall back to the all-reduce for shapes that do not divide
                 r0 = r1
+            # the all-gather lands in the flat bf16 shadow arena, which is the forward's fc6 operand only when a row of
+            # fc1.weight needs no K padding (C*P*P a multiple of the 128-byte slab); a padded operand is its own buffer,
+            # re-cast from the fp32 master - stale for the rows other ranks own
+            k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
+            if self._sharded and ops.kpad(k1, torch.bfloat16) != k1:
+                if exchange == "sharded":
+                    raise DrnError("sharded exchange: fc1.weight rows of %d elements are K-padded in the bf16 compute copy; "
+                                   "use exchange='allreduce'" % k1)
+                self._sharded = False
         self._master_stale = False
+        if self._sharded:
+            self._install_state_dict_hook()
         self._slab_ends = slab_rows
         e.fc1_slab_ends = slab_rows
         e.grad_ready_hook = self._on_grad_ready
@@ -260,7 +271,10 @@ class FusedSGD:
                 if self._sharded:
                     # reduce-scatter: this rank receives the summed gradient of ITS rows of the slab
                     q = (r1 - r0) // self._dp.world
-                    out = self._shard_bufs().setdefault(what, torch.empty((q, k1), dtype=src.dtype, device=src.device))
+                    bufs = self._shard_bufs()
+                    out = bufs.get(what)
+                    if out is None or out.shape != (q, k1) or out.dtype != src.dtype:
+                        out = bufs[what] = torch.empty((q, k1), dtype=src.dtype, device=src.device)
                     dist.reduce_scatter_tensor(out, src, group=self._dp.group)
                     return out
                 dist.all_reduce(src, group=self._dp.group)
@@ -300,6 +314,7 @@ class FusedSGD:
         are gathered so that every rank holds the full fp32 state again."""
         if not getattr(self, "_sharded", False) or not self._master_stale:
             return
+        self._rendezvous("sync_master() / state_dict() / DetectionCheckpointer.save()")
         if self._opt_stream is not None:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
         r0 = 0
@@ -307,6 +322,54 @@ class FusedSGD:
             self._gather_rows(("fc1", r0, r1), master_too=True)
             r0 = r1
         self._master_stale = False
+
+    sync_timeout = 120.0  # seconds sync_master() waits for the other ranks before it raises instead of hanging
+
+    def _rendezvous(self, what):
+        """The gather of the owners' rows is a COLLECTIVE, while the reference checkpoints on rank 0 only
+        (detectron2/engine/defaults.py:352 registers PeriodicCheckpointer under comm.is_main_process()).  A driver ported
+        line by line would therefore block forever inside the all-gather; this one-word all-reduce is issued
+        asynchronously first and polled with a deadline, so a lone caller gets a DrnError that says what to do
+        (ADVICE r2).  After the error the process group is unusable - the run must stop, which is the point."""
+        import time
+
+        dev = self.engine.arena_w.device
+        flag = torch.ones(1, dtype=torch.float32, device=dev)
+        work = dist.all_reduce(flag, group=self._dp.group, async_op=True)
+        t0 = time.monotonic()
+        while not work.is_completed():
+            if time.monotonic() - t0 > self.sync_timeout:
+                raise DrnError("%s is a collective in the sharded exchange (every rank holds the fp32 master / momentum "
+                               "of its own fc6 rows only): rank %d waited %.0f s for the other ranks.  Call it on EVERY "
+                               "rank - DetectionCheckpointer.save() writes the file on the rank with save_to_disk only - or "
+                               "call optimizer.sync_master() on all ranks right before a rank-0-only save, or train with "
+                               "exchange='allreduce'" % (what, dist.get_rank(self._dp.group), self.sync_timeout))
+            time.sleep(0.002)
+
+    def _install_state_dict_hook(self):
+        """Staleness lives with the model, not with whoever happens to hold the optimizer: a bare model.state_dict(), or a
+        checkpointer built without the optimizer, gathers the owners' rows first (it is then a collective as well, with
+        the same fail-fast rendezvous) instead of silently writing the other ranks' stale fp32 rows."""
+        heads = self.model.roi_heads
+        if getattr(heads, "_drn_sync_hook", None) is None:
+            import weakref
+
+            ref = weakref.ref(self)
+
+            def hook(module, prefix, keep_vars):
+                opt = module.__dict__.get("_drn_sync_owner")
+                opt = opt() if opt is not None else None
+                if opt is not None:
+                    opt.sync_master()
+
+            # (model.state_dict() reaches this hook when it recurses into roi_heads; the tensors it returns are views of the
+            # arena, which the gather fills in place)
+            heads._drn_sync_hook = heads.register_state_dict_pre_hook(hook)
+            heads.__dict__["_drn_sync_owner"] = ref
+        else:
+            import weakref
+
+            heads.__dict__["_drn_sync_owner"] = weakref.ref(self)
 
     def _on_grad_ready(self, what):
         e = self.engine
@@ -866,6 +929,20 @@ class GraphedTrainStep:
         via = slot is not None and self.stage_ahead
         ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if via else None, self._gt_block if via else None)
         self.pooled = self.engine.pool(feat, self.rois_next, self.obj_next, True, slot=0)
+        self._check_pooled()
+
+    def _check_pooled(self):
+        """The captured heads graph reads the fc6 operand pair (A, A^T) at the addresses it saw when it was captured; the
+        pooling piece is issued eagerly (eager_pool) and asks the head engine for its buffers on every step.  Once primed,
+        the two must agree - a re-allocation in between (an inference pass used to replace the sets) would
+        make the replayed graph read freed memory without any error."""
+        ptrs = (self.pooled["A"].data_ptr(), self.pooled["AT"].data_ptr())
+        if not getattr(self, "_primed", False):
+            self._pool_ptrs = ptrs
+            self.engine.pool_sets_pinned = (self.pooled["A"].dtype, True)
+        elif ptrs != self._pool_ptrs:
+            raise DrnError("the fc6 operand buffers moved after the step was captured (%s -> %s): re-create the "
+                           "GraphedTrainStep" % (self._pool_ptrs, ptrs))
 
     # ---- the three captured pieces ---------------------------------------------------------------------------
     def _bb_body(self, slot=None):
@@ -1008,6 +1085,7 @@ class GraphedTrainStep:
                                    self._gt_block if self.stage_ahead else None)
             self.pooled = self.engine.pool(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next, True,
                                            slot=0)
+            self._check_pooled()
 
     def _run_pairs(self, eager, next_batch, b2, b3):
         """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % 2.  Even t: the conv chain of pair t/2 + 1

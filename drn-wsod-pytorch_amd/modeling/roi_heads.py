@@ -472,14 +472,26 @@ class _HeadEngine:
         M = rois.shape[0]
         K1 = h.box_head.fc1.weight.shape[1]
         key = (dtype, training)
-        cap = getattr(self, "_pool_cap", 0)
-        if getattr(self, "_pool_key", None) != key or M > cap:
+        if getattr(self, "_pool_key", None) != key:
+            # one pair of operand sets per (dtype, training), like ws(): an inference pass between two training steps
+            # (EvalHook) must never replace - i.e. free - the training sets, whose addresses a captured heads graph and
+            # the eagerly issued pooling piece of GraphedTrainStep both hold
+            by_key = self.__dict__.setdefault("_pool_by_key", {})
+            if getattr(self, "_pool_key", None) is not None:
+                by_key[self._pool_key] = (self._pool_sets, self._pool_cap, self._pool_current_done)
+            self._pool_sets, self._pool_cap, self._pool_current_done = by_key.get(key, (None, 0, True))
+            self._pool_key = key
+        cap = self._pool_cap
+        if self._pool_sets is None or M > cap:
             # capacity-based like ws(): the operand pair of the largest batch seen, views for this batch
+            if getattr(self, "pool_sets_pinned", None) == key and self._pool_sets is not None:
+                raise DrnError("the fc6 operand sets of %s are pinned by a captured step (GraphedTrainStep) and cannot "
+                               "grow from %d to %d proposals" % (key, cap, M))
             cap = (M + 63) // 64 * 64
             z = lambda r_, c_: torch.zeros((r_, c_), dtype=dtype, device=dev)
             self._pool_sets = [dict(A_buf=z(cap, ops.kpad(K1, dtype)), AT_buf=z(K1, ops.kpad(cap, dtype)) if training else None,
                                     state="free", M=None) for _ in range(2)]
-            self._pool_key, self._pool_cap = key, cap
+            self._pool_cap = cap
             self._pool_current_done = True
         if slot is None:
             free = [i for i, q in enumerate(self._pool_sets) if q["state"] == "free"]

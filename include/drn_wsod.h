@@ -164,6 +164,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_CONV_K2_TILES 8 /* largest number of 64x64 tiles of ONE image's layer that runs two K-groups per tile (conv_nhwc_k2_kernel); -1 = default (2 x CUs), 0 = off */
 #define DRN_TUNE_ROI_CPB 10 /* 64-ROI ROIPool: most 8-channel chunks one workgroup walks (power of two, default 1; halved until two workgroups per CU remain): bin bounds / item table once per workgroup - faster stand-alone (4-8), slower inside the training step */
 #define DRN_TUNE_ROI_PREFETCH 11 /* 0/1 (default 1): 64-ROI ROIPool keeps two map-slice buffers and fetches the next chunk's slice under the scan */
+#define DRN_TUNE_GEMM_PINGPONG 12 /* 0/1 (default 1): bf16 256x256 GEMMs run the ping-pong mainloop - the two waves of a SIMD half a phase apart, four [reads + DMA | 8 MFMAs] phases per K slab, half-tile LDS-DMA spread over the slab; bit-identical to the lock-step pipeline it replaces (0) */
 #define DRN_TUNE_CONV_PATCH 9 /* 0 = never use the LDS-resident-patch kernel for 3x3 / 64 -> 64 channel convs; 1 = default (maps of >= 32768 pixels); > 1 = that many pixels per image at least */
 int drn_tune(int knob, int value);
 

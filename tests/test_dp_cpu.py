@@ -175,3 +175,84 @@ def test_gradient_exchange_two_ranks_gloo():
     for p in procs:
         p.join(timeout=60)
     assert sorted(res) == [(0, "ok"), (1, "ok")], res
+
+
+def _lone_saver(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from __graft_entry__ import load_package
+
+        load_package()
+        from drn_wsod_pytorch_amd._cabi import DrnError
+        from drn_wsod_pytorch_amd.checkpoint import DetectionCheckpointer
+        from drn_wsod_pytorch_amd.engine import DataParallel, build_optimizer
+        from drn_wsod_pytorch_amd.modeling import build_model
+
+        torch.manual_seed(5)
+        cfg = G.drn_cfg(G.MODEL_CASES["model_r50c4_tiny"], "cpu")
+        model = build_model(cfg)
+        dp = DataParallel(model, slabs=3, backend_stream=False)
+        opt = build_optimizer(cfg, model)
+        d1, k1 = model.roi_heads.box_head.fc1.weight.shape
+        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.bfloat16, exchange="sharded")
+        e = model.roi_heads._engine
+        o, c = e._seg["fc1.weight"]
+        opt._mom = torch.zeros_like(e.arena_w)
+        # ---- 1. both ranks: a bare model.state_dict() gathers the owners' rows (no optimizer in sight) ----------------
+        r0 = 0
+        for r1 in opt._slab_ends:
+            a, b = opt._own_rows(("fc1", r0, r1))
+            e.arena_w[o + a * k1: o + b * k1] = 10.0 * (rank + 1)  # stand-in for the owned-shard SGD kernel
+            r0 = r1
+        opt._master_stale = True
+        sd = model.state_dict()
+        w = sd["roi_heads.box_head.fc1.weight"]
+        r0 = 0
+        for r1 in opt._slab_ends:
+            nq = (r1 - r0) // 2
+            assert torch.equal(w[r0: r0 + nq], torch.full((nq, k1), 10.0)), "rank 0's rows"
+            assert torch.equal(w[r0 + nq: r1], torch.full((nq, k1), 20.0)), "rank 1's rows"
+            r0 = r1
+        assert not opt._master_stale
+        dist.barrier()
+        # ---- 2. the reference's pattern: rank 0 alone checkpoints -> a DrnError within the deadline, not a hang -----
+        opt._master_stale = True
+        opt.sync_timeout = 3.0
+        if rank == 0:
+            ck = DetectionCheckpointer(model, save_dir="", optimizer=opt)
+            try:
+                ck.save("model_final")
+                q.put((rank, "FAIL: a lone save() returned"))
+            except DrnError as ex:
+                assert "EVERY" in str(ex) and "rank 0" in str(ex), str(ex)
+                q.put((rank, "ok"))
+        else:
+            import time
+
+            time.sleep(6.0)  # never joins the collective
+            q.put((rank, "ok"))
+    except Exception as ex:  # noqa: BLE001
+        import traceback
+
+        q.put((rank, "FAIL: %r\n%s" % (ex, traceback.format_exc())))
+    finally:
+        q.close()
+        q.join_thread()  # flush the result before the hard exit
+        os._exit(0)  # the group is poisoned by design (a pending all-reduce on rank 0): no orderly teardown
+
+
+def test_sharded_state_dict_gathers_and_lone_save_fails_fast():
+    """(1) model.state_dict() alone must not write stale rows in the sharded exchange; (2) a rank-0-only
+    save() - what a driver ported from the reference does (defaults.py:352) - must raise instead of deadlocking."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_lone_saver, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert sorted(res) == [(0, "ok"), (1, "ok")], res

@@ -135,6 +135,53 @@ def test_gemm_persistent_equals_one_tile_grid(drn, dtype, M, N, K, splits):
         drn.gemm_set_tile(prev_tile)
 
 
+@pytest.mark.parametrize("M,N,K,splits", [(2000, 2048, 3136, 4), (256, 256, 64, 1), (1030, 17000, 192, 1), (300, 70000, 128, 1),
+                                          (2304, 8192, 320, 3), (2000, 4500, 512, 2)])
+def test_gemm_pingpong_bit_identical(drn, M, N, K, splits):
+    """Round 3: the ping-pong mainloop of the bf16 256x256 kernels (DRN_TUNE_GEMM_PINGPONG: the two wave rows half a phase
+    apart, half-tile LDS-DMA with counted waits) against the lock-step pipeline it replaces, in the one-tile grid AND the
+    persistent kernel: the same MFMA sees the same K slabs in the same order for every output element, so fp32 split-K
+    partials, accumulate and bf16 outputs must be BIT-identical.  Shapes: one slab, odd slab counts, slab ranges that
+    differ per K-split, ragged M / N edges, more work items than CUs; repeated launches (a schedule race would show as
+    run-to-run differences)."""
+    dtype = torch.bfloat16
+    A, B = _rnd((M, K), 44), _rnd((N, K), 45)
+    Ad, Bd = _padded(A, dtype, drn), _padded(B, dtype, drn)
+    Kp = Ad.shape[1]
+    C0 = _rnd((M, N), 46).to(DEV)
+    prev_tile = drn.gemm_set_tile(256)
+    prev_p = drn.tune(drn.TUNE_GEMM_PERSISTENT, 1)
+    prev = drn.tune(drn.TUNE_GEMM_PINGPONG, 1)
+    try:
+        res = {}
+        for persistent in (0, 1):
+            drn.tune(drn.TUNE_GEMM_PERSISTENT, persistent)
+            for pp in (0, 1, 1, 1):
+                drn.tune(drn.TUNE_GEMM_PINGPONG, pp)
+                out = [drn.gemm_nt(Ad, Bd, M, N, Kp, splits=splits).clone()]
+                acc = C0.clone().unsqueeze(0)
+                drn.gemm_nt(Ad, Bd, M, N, Kp, out=acc, accumulate=True)
+                out.append(acc)
+                o16 = torch.zeros((1, M, N), dtype=torch.bfloat16, device=DEV)
+                drn.gemm_nt(Ad, Bd, M, N, Kp, out=o16)
+                out.append(o16)
+                res.setdefault((persistent, pp), []).append(out)
+        torch.cuda.synchronize()
+        base = res[(0, 0)][0]
+        for key, runs in res.items():
+            for out in runs:
+                for a, b in zip(base, out):
+                    assert torch.equal(a, b), key
+        ref = _q(A, dtype).double() @ _q(B, dtype).double().t()
+        mag = _q(A, dtype).abs().double() @ _q(B, dtype).abs().double().t()
+        got = res[(1, 1)][0][0].sum(0).cpu().double()
+        assert ((got - ref).abs() <= 4 * 2.0 ** -24 * math.sqrt(K) * mag + 1e-6).all()
+    finally:
+        drn.tune(drn.TUNE_GEMM_PINGPONG, prev)
+        drn.tune(drn.TUNE_GEMM_PERSISTENT, prev_p)
+        drn.gemm_set_tile(prev_tile)
+
+
 def test_gemm_joint_peel_of_row_slabs_bit_identical(drn):
     """run_fc1_tail's joint peel: two equal row slabs of one product [2048 x (68 * 256)] - each 4 x 68 = 256 + 16 tiles,
     so drn_gemm_nt peels the same 4 trailing tile columns off both - computed (a) slab by slab, each call peeling its

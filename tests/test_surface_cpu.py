@@ -423,11 +423,24 @@ if os.path.exists(yaml):
     model = build_model(cfg)
     assert type(model).__name__ == "GeneralizedRCNNWSL" and type(model.roi_heads).__name__ == "OICRROIHeads"
 from drn_wsod_pytorch_amd._cabi import DrnError
+import detectron2.evaluation as ev
+try:
+    ev.COCOEvaluator
+    raise SystemExit("control-plane name resolved")
+except DrnError as e:  # loud, with the reason
+    assert "COCOEvaluator" in str(e) and isinstance(e, AttributeError)
+# ... and Python's attribute / import protocols keep working (ADVICE r2)
+assert not hasattr(ev, "COCOEvaluator") and getattr(ev, "COCOEvaluator", 7) == 7
 try:
     from detectron2.evaluation import COCOEvaluator
     raise SystemExit("control-plane name resolved")
-except DrnError as e:
+except ImportError as e:
     assert "COCOEvaluator" in str(e)
+try:
+    from detectron2.utils import comm
+    raise SystemExit("control-plane module resolved")
+except ImportError:
+    pass
 A.uninstall()
 assert "detectron2" not in sys.modules
 print("ALIAS_OK", len(names))

@@ -1,0 +1,42 @@
+"""Interleaved A/B of the two mainloops of the bf16 256x256 GEMM kernels (DRN_TUNE_GEMM_PINGPONG 0 / 1) on the fc6
+shapes and a square, HIP-event timed, N rounds in ONE process (cdna_hip_programming.md rule 24), random operands."""
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.abspath(os.path.join(os.path.dirname(__file__), "..")))
+from __graft_entry__ import load_package
+
+load_package()
+ops = importlib.import_module("drn_wsod_pytorch_amd.ops")
+bf = torch.bfloat16
+SHAPES = [("fc6 fwd", 2000, 2048, 50176, 4, False), ("fc6 dW slab", 1024, 49152, 2048, 1, True),
+          ("fc7 fwd", 2000, 4096, 2048, 1, False), ("square 4096", 4096, 4096, 4096, 1, False),
+          ("square 8192", 8192, 8192, 8192, 1, False)]
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+n = 40
+ops.gemm_set_tile(256)
+for name, M, N, K, S, b16 in SHAPES:
+    A = (torch.randn((M, K), device="cuda") * 0.5).to(bf)
+    B = (torch.randn((N, K), device="cuda") * 0.05).to(bf)
+    out = torch.empty((S, M, N), dtype=bf if b16 else torch.float32, device="cuda")
+    res = {0: [], 1: []}
+    for r in range(rounds):
+        for pp in (0, 1):
+            ops.tune(ops.TUNE_GEMM_PINGPONG, pp)
+            for _ in range(5):
+                ops.gemm_nt(A, B, M, N, K, out=out, splits=S)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(n):
+                ops.gemm_nt(A, B, M, N, K, out=out, splits=S)
+            e1.record()
+            torch.cuda.synchronize()
+            res[pp].append(e0.elapsed_time(e1) / n)
+    for pp in (0, 1):
+        t = sorted(res[pp])
+        med = t[len(t) // 2]
+        print("%-12s pp=%d  median %.1f us (min %.1f)  %.0f TFLOP/s" % (name, pp, med * 1e3, t[0] * 1e3, 2.0 * M * N * K / med / 1e9))
+ops.tune(ops.TUNE_GEMM_PINGPONG, 1)

@@ -1,0 +1,82 @@
+"""Summarise the passes of tools/pmc_attrib.sh into one JSON record.
+usage: pmc_attrib_summary.py <raw-dir-prefix> <out.json>     (directories <prefix>_<group>)
+Units (MI355X_MICROARCH.md): SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles per wave,
+SQ_VALU_MFMA_BUSY_CYCLES counts cycles (32 per v_mfma_f32_32x32x16_bf16), GRBM_GUI_ACTIVE is summed over the 8 XCDs,
+FETCH_SIZE / WRITE_SIZE are KiB with the gfx950 x2 correction on FETCH_SIZE for 16-B/lane streaming reads."""
+import glob
+import json
+import os
+import sqlite3
+import sys
+
+prefix, out_path = sys.argv[1], sys.argv[2]
+M, N, K, S = [int(x) for x in os.environ.get("PMC_SHAPE", "2000,2048,50176,4").split(",")]
+bf16_out = bool(os.environ.get("PMC_BF16_OUT"))
+rec = {"shape": [M, N, K], "splits": S, "c_dtype": "bf16" if bf16_out else "f32", "counters": {}, "duration_us": {}}
+kernels = set()
+for d in sorted(glob.glob(prefix + "_*")):
+    group = d[len(prefix) + 1:]
+    dbs = glob.glob(d + "/**/*.db", recursive=True)
+    if not dbs:
+        rec["counters"][group] = "no database (pass failed)"
+        continue
+    cur = sqlite3.connect(dbs[0]).cursor()
+    q = ("select kernel_name, counter_name, value, duration, dispatch_id from counters_collection "
+         "where kernel_name like '%gemm_nt256%' order by dispatch_id")
+    rows = list(cur.execute(q))
+    if not rows:
+        rec["counters"][group] = "no gemm_nt256 dispatch"
+        continue
+    first = rows[0][4]
+    per = {}
+    durs = {}
+    for kn, cn, v, dur, did in rows:
+        if did == first:
+            continue  # the first launch pays the cold caches
+        kernels.add(kn.split("(")[0][:90])
+        per.setdefault(cn, []).append(v)
+        durs[did] = dur
+    rec["counters"][group] = {cn: sum(v) / len(v) for cn, v in per.items()}
+    rec["duration_us"][group] = sum(durs.values()) / max(len(durs), 1) / 1e3
+rec["kernels"] = sorted(kernels)
+c = {}
+for g in rec["counters"].values():
+    if isinstance(g, dict):
+        c.update(g)
+d = {}
+flops = 2.0 * M * N * K
+n_mfma = flops / (2 * 32 * 32 * 16)
+if "GRBM_GUI_ACTIVE" in c and "sq_time" in rec["duration_us"]:
+    cyc = c["GRBM_GUI_ACTIVE"] / 8.0
+    d["shader_clock_GHz"] = cyc / rec["duration_us"]["sq_time"] / 1e3
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in c:
+        d["mfma_busy_cycles_per_expected_mfma"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / n_mfma
+        d["mfma_util_at_sustained_clock"] = c["SQ_VALU_MFMA_BUSY_CYCLES"] / (1024.0 * cyc)
+    d["tflops_under_pmc"] = flops / rec["duration_us"]["sq_time"] / 1e6
+if "SQ_WAVE_CYCLES" in c:
+    w = c["SQ_WAVE_CYCLES"]
+    for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_WAIT_INST_LDS"):
+        if k in c:
+            d[k + "_over_WAVE_CYCLES"] = c[k] / w
+for k in ("SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_SCA", "SQ_ACTIVE_INST_MISC"):
+    if k in c and "SQ_WAVE_CYCLES" in c:
+        d[k + "_over_WAVE_CYCLES"] = c[k] / c["SQ_WAVE_CYCLES"]
+if "SQ_LDS_IDX_ACTIVE" in c and "GRBM_GUI_ACTIVE" in c:
+    d["lds_array_active_frac_of_cu_cycles"] = c["SQ_LDS_IDX_ACTIVE"] / (256.0 * c["GRBM_GUI_ACTIVE"] / 8.0)
+if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
+    d["l2_hit_rate"] = c["TCC_HIT_sum"] / max(c["TCC_HIT_sum"] + c["TCC_MISS_sum"], 1.0)
+if "TCP_TCC_READ_REQ_LATENCY_sum" in c and c.get("TCP_TCC_READ_REQ_sum"):
+    d["l1_to_l2_read_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"]
+alg = (M + N) * K * 2 + S * M * N * (2 if bf16_out else 4)
+if "FETCH_SIZE" in c:
+    d["fetch_bytes"] = c["FETCH_SIZE"] * 1024 * 2
+if "WRITE_SIZE" in c:
+    d["write_bytes"] = c["WRITE_SIZE"] * 1024
+if "fetch_bytes" in d and "write_bytes" in d:
+    d["traffic_bytes"] = d["fetch_bytes"] + d["write_bytes"]
+    d["algorithmic_bytes"] = alg
+    d["traffic_over_algorithmic"] = d["traffic_bytes"] / alg
+rec["derived"] = d
+json.dump(rec, open(out_path, "w"), indent=1)
+print(json.dumps(rec["derived"], indent=1))
+print(json.dumps(rec["duration_us"]))
