@@ -383,7 +383,7 @@ __device__ __forceinline__ void pp_issue_first(char* smem, __amdgpu_buffer_rsrc_
 
 // slabs [s0, s1), s0 < s1; slab s0 has been issued into stage 0 by pp_issue_first.  Every wave passes the same number of
 // barriers (wave row 1 one extra in front, wave row 0 one extra behind).
-template <int DT>
+template <int DT, int VAR>
 __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, __amdgpu_buffer_rsrc_t ra,
                                             __amdgpu_buffer_rsrc_t rb, const unsigned (&voa)[4], const unsigned (&vob)[4],
                                             int s0, int s1, int lane, int wave) {
@@ -406,14 +406,26 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
   };
   auto rdB = [&](int ks, int off) { fb[ks] = *(lds_v4)(uintptr_t)(ob[ks] + off); };
   auto mm = [&](f32x16_t& c0, f32x16_t& c1) {
-    __builtin_amdgcn_s_setprio(1);
+    if (VAR != 3) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       mma_step<DT>(c0, fb[ks], fa[0][ks]);  // swapped: D^T[n][m]
       mma_step<DT>(c1, fb[ks], fa[1][ks]);
     }
-    __builtin_amdgcn_s_setprio(0);
+    if (VAR != 3) __builtin_amdgcn_s_setprio(0);
   };
+  // one 1-KB DMA piece: q = 0..7 in staging order A0.0 A0.1 B0.0 B0.1 B1.0 B1.1 A1.0 A1.1
+  auto piece = [&](char* stage, auto qtag, int slab) {
+    constexpr int q = decltype(qtag)::value;
+    constexpr int which = q >> 1, pc = q & 1;
+    constexpr int off = which == 0 ? PP_A0 : which == 1 ? PP_B0 : which == 2 ? PP_B1 : PP_A1;
+    constexpr bool isA = which == 0 || which == 3;
+    constexpr int h = (which == 2 || which == 3) ? 1 : 0;
+    char* dst = stage + off + (pc * 64 + wave * 8) * 128;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)dst, 16,
+                                             isA ? voa[h * 2 + pc] : vob[h * 2 + pc], slab * 128, 0, 0);
+  };
+#define PP_PIECE(q) piece(nxt, std::integral_constant<int, q>{}, sn)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PP_BARRIER();
   if (wm == 1) PP_BARRIER();  // the lower wave row runs one barrier interval behind the upper one
@@ -423,23 +435,32 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     // ---- phase 1: quadrant (a0, b0); reads in the order the MFMAs consume them (counted lgkmcnt waits)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { rdB(ks, 0); rdA(ks, 0); }
-    pp_issue<0>(nxt, ra, rb, voa, vob, wave, sn);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // B1 of this slab has landed (read in phase 2)
+    if (VAR == 2) {  // rebalanced: the phase with 12 fragment reads issues no DMA (pieces 0 / 3 / 2 / 3 per phase)
+      asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // B1 of this slab: A1's two pieces may stay in flight
+    } else {
+      PP_PIECE(0); PP_PIECE(1);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // B1 of this slab has landed (read in phase 2)
+    }
     PP_BARRIER();
     mm(acc[0][0], acc[1][0]);
     PP_BARRIER();
     // ---- phase 2: (a0, b1)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rdB(ks, PP_B1 - PP_B0);
-    pp_issue<1>(nxt, ra, rb, voa, vob, wave, sn);
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A1 of this slab (phase 3)
+    if (VAR == 2) {
+      PP_PIECE(0); PP_PIECE(1); PP_PIECE(2);
+      asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // A1 of this slab (phase 3)
+    } else {
+      PP_PIECE(2); PP_PIECE(3);
+      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A1 of this slab (phase 3)
+    }
     PP_BARRIER();
     mm(acc[0][1], acc[1][1]);
     PP_BARRIER();
     // ---- phase 3: (a1, b1)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rdA(ks, PP_A1 - PP_A0);
-    pp_issue<2>(nxt, ra, rb, voa, vob, wave, sn);
+    if (VAR == 2) { PP_PIECE(3); PP_PIECE(4); } else { PP_PIECE(4); PP_PIECE(5); }
     PP_BARRIER();
     mm(acc[2][1], acc[3][1]);
     PP_BARRIER();
@@ -447,7 +468,7 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     // decide whether a trunk conv workgroup still fits beside this kernel (DESIGN 'trunk beside the GEMMs')
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rdB(ks, 0);
-    pp_issue<3>(nxt, ra, rb, voa, vob, wave, sn);
+    if (VAR == 2) { PP_PIECE(5); PP_PIECE(6); PP_PIECE(7); } else { PP_PIECE(6); PP_PIECE(7); }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A0 and B0 of the next slab (its phase 1)
     PP_BARRIER();
     mm(acc[2][0], acc[3][0]);
@@ -457,6 +478,7 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before LDS is reused
   if (wm == 0) PP_BARRIER();
+#undef PP_PIECE
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -474,7 +496,7 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
 //     the accumulators and W / momentum / the bf16 shadow are updated in place (same arithmetic and order as
 //     sgd_kernel in head.hip), so the 411 MB gradient is neither written nor re-read and the HBM-bound optimizer
 //     pass over the largest tensor disappears as a separate launch.  Single-GPU, no-accumulation steps only.
-template <int DT, bool PIPE, bool SGD = false, bool PP = false>
+template <int DT, bool PIPE, bool SGD = false, int PP = 0>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
@@ -538,7 +560,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
       unsigned pva[4], pvb[4];
       pp_offsets(la.ld_bytes, lb.ld_bytes, tid, pva, pvb);
       pp_issue_first(smem, la.rsrc, lb.rsrc, pva, pvb, wave, s0);
-      pp_mainloop<DT>(acc, smem, la.rsrc, lb.rsrc, pva, pvb, s0, s1, lane, wave);
+      pp_mainloop<DT, PP>(acc, smem, la.rsrc, lb.rsrc, pva, pvb, s0, s1, lane, wave);
     } else if constexpr (PIPE) {
       // Software-pipelined schedule: fragments of k-step k+1 are read while the MFMAs of k-step k run (two register
       // sets), and ONE barrier per slab - placed after the slab's last fragment read and before its last MFMA block -
@@ -731,7 +753,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
 // dispatcher's round-robin, so the L2 reuse pattern of the XCD patch mapping is unchanged.
 struct GemmWork { int bm, bn, s0, s1, split; __amdgpu_buffer_rsrc_t ra, rb; };  // one (tile, K-split) work item
 
-template <int DT, bool SGD, bool PP = false>
+template <int DT, bool SGD, int PP = 0>
 __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
@@ -809,7 +831,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
         for (int rr = 0; rr < 16; ++rr) acc[i][jj][rr] = 0.f;
     const int s0 = cur.s0, s1 = cur.s1;
     if constexpr (PP) {
-      if (s0 < s1) pp_mainloop<DT>(acc, smem, cur.ra, cur.rb, pva, pvb, s0, s1, lane, wave);
+      if (s0 < s1) pp_mainloop<DT, PP>(acc, smem, cur.ra, cur.rb, pva, pvb, s0, s1, lane, wave);
     } else if (s0 < s1) {
       i32x4_t fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab s0 (issued ahead of the previous tile's epilogue) has landed
@@ -1553,7 +1575,7 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
-template <int DT, bool PIPE, bool SGD = false, bool PP = false>
+template <int DT, bool PIPE, bool SGD = false, int PP = 0>
 int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   constexpr int smem = 2 * 512 * 128;
@@ -1584,7 +1606,7 @@ static int cu_count() {
   return n;
 }
 
-template <int DT, bool SGD, bool PP = false>
+template <int DT, bool SGD, int PP = 0>
 int launch_gemm256p(const GemmParams& p, int nwg, hipStream_t st) {
   constexpr int smem = 2 * 512 * 128;
   auto k = gemm_nt256p_kernel<DT, SGD, PP>;
@@ -1746,7 +1768,7 @@ int drn_tune(int knob, int value) {
   }
   if (knob == 12) {  // DRN_TUNE_GEMM_PINGPONG
     const int old = g_pingpong;
-    g_pingpong = value != 0;
+    g_pingpong = value < 0 ? 0 : value;
     return old;
   }
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
@@ -1816,10 +1838,14 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
         if (rc != DRN_OK) return rc;
         p.N = (int)n0;
       }
-      if (dtype == DRN_BF16 && g_pingpong) return launch_gemm256p<DRN_BF16, false, true>(p, nwg, st);
+      if (dtype == DRN_BF16 && g_pingpong == 1) return launch_gemm256p<DRN_BF16, false, 1>(p, nwg, st);
+      if (dtype == DRN_BF16 && g_pingpong == 2) return launch_gemm256p<DRN_BF16, false, 2>(p, nwg, st);
+      if (dtype == DRN_BF16 && g_pingpong == 3) return launch_gemm256p<DRN_BF16, false, 3>(p, nwg, st);
       return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, false>(p, nwg, st) : launch_gemm256p<DRN_F32, false>(p, nwg, st);
     }
-    if (dtype == DRN_BF16 && g_pingpong) return launch_gemm256<DRN_BF16, true, false, true>(p, splits, st);
+    if (dtype == DRN_BF16 && g_pingpong == 1) return launch_gemm256<DRN_BF16, true, false, 1>(p, splits, st);
+    if (dtype == DRN_BF16 && g_pingpong == 2) return launch_gemm256<DRN_BF16, true, false, 2>(p, splits, st);
+    if (dtype == DRN_BF16 && g_pingpong == 3) return launch_gemm256<DRN_BF16, true, false, 3>(p, splits, st);
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true>(p, splits, st) : launch_gemm256<DRN_F32, true>(p, splits, st);
   }
   // 64x64 tiles (4x the workgroups) when 128x128 tiles would not even give every CU one workgroup: these launches are

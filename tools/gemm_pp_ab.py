@@ -16,15 +16,16 @@ SHAPES = [("fc6 fwd", 2000, 2048, 50176, 4, False), ("fc6 dW slab", 1024, 49152,
           ("fc7 fwd", 2000, 4096, 2048, 1, False), ("square 4096", 4096, 4096, 4096, 1, False),
           ("square 8192", 8192, 8192, 8192, 1, False)]
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+VARS = [int(x) for x in sys.argv[2].split(",")] if len(sys.argv) > 2 else [0, 1]
 n = 40
 ops.gemm_set_tile(256)
 for name, M, N, K, S, b16 in SHAPES:
     A = (torch.randn((M, K), device="cuda") * 0.5).to(bf)
     B = (torch.randn((N, K), device="cuda") * 0.05).to(bf)
     out = torch.empty((S, M, N), dtype=bf if b16 else torch.float32, device="cuda")
-    res = {0: [], 1: []}
+    res = {v: [] for v in VARS}
     for r in range(rounds):
-        for pp in (0, 1):
+        for pp in VARS:
             ops.tune(ops.TUNE_GEMM_PINGPONG, pp)
             for _ in range(5):
                 ops.gemm_nt(A, B, M, N, K, out=out, splits=S)
@@ -35,7 +36,7 @@ for name, M, N, K, S, b16 in SHAPES:
             e1.record()
             torch.cuda.synchronize()
             res[pp].append(e0.elapsed_time(e1) / n)
-    for pp in (0, 1):
+    for pp in VARS:
         t = sorted(res[pp])
         med = t[len(t) // 2]
         print("%-12s pp=%d  median %.1f us (min %.1f)  %.0f TFLOP/s" % (name, pp, med * 1e3, t[0] * 1e3, 2.0 * M * N * K / med / 1e9))
