@@ -10,6 +10,7 @@ from . import _cabi as C
 
 SCALE_CLAMP = math.log(1000.0 / 16)  # detectron2/modeling/box_regression.py:9
 GEMM_TIMING = None  # set to a list by bench.py to time GEMM launches with HIP events
+HBM_TIMING = None   # likewise for the two HBM-bound kernels of the step (pooling launch, optimizer launches) - in-step figures
 
 
 FP8 = torch.float8_e4m3fn  # OCP e4m3fn: gfx950's native fp8
@@ -166,9 +167,17 @@ def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, al
     arg = torch.empty((m, c * P * P), dtype=torch.int32, device=feat.device) if want_argmax else None
     if out_t is not None:
         assert out_t.dtype == out.dtype
+    if HBM_TIMING is not None:  # bench.py: HIP events on the launching stream around this launch
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     C.call("drn_roi_pool_nhwc", C.ptr(feat), C.ptr(rois), C.ptr(objectness), C.ptr(out), C.ptr(out_t), C.ptr(arg), n, h,
            w, c, P, m, float(scale), _2d(out), _2d(out_t) if out_t is not None else 0, mode, sampling_ratio,
            int(aligned), C.dt(feat.dtype), C.dt(out.dtype), C.stream())
+    if HBM_TIMING is not None:
+        e1.record()
+        es = esize(out.dtype)
+        nbytes = (2 if out_t is not None else 1) * m * c * P * P * es + feat.numel() * esize(feat.dtype) + rois.numel() * 4
+        HBM_TIMING.append((e0, e1, nbytes, ("roi_pool", m, c * P * P, out_t is not None)))
     return (out, arg) if want_argmax else out
 
 
@@ -417,9 +426,16 @@ def sgd_step(weights, momentum_buf, grads, segs_dev, nseg, momentum, first_step,
              grad_off=0):
     """grads: the fp32 gradient arena, or (grad_off > 0) a bucket buffer - fp32 or bf16 - whose element 0 is arena
     element grad_off."""
+    if HBM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     C.call("drn_sgd_step", C.ptr(weights), C.ptr(momentum_buf), C.ptr(grads), C.dt(grads.dtype), int(grad_off),
            C.ptr(shadow), C.dt(shadow.dtype) if shadow is not None else 0, C.ptr(segs_dev), nseg, float(momentum),
            int(first_step), float(grad_scale), C.stream())
+    if HBM_TIMING is not None:
+        e1.record()
+        # bytes are the caller's to know (the segment table lives on the device): keyed by (segments, bucket offset)
+        HBM_TIMING.append((e0, e1, None, ("sgd", int(nseg), int(grad_off), str(grads.dtype), shadow is not None)))
 
 
 def detect_topk(boxes, scores, image_shape, score_thresh, nms_thresh, topk):
