@@ -38,7 +38,8 @@ PMC_RECORD = "r3_02_pmc_fwd_pingpong.json"  # round 3: the ping-pong kernel, too
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
-CONV_GF = {"r50c4": 7.90, "r50c4_fp8": 7.90, "r50dc5": 37.24, "r101c4_k80": 15.33}  # trunk forward GFLOP at 224x224
+# trunk forward GFLOP at 224x224 (v16: 13 3x3 convs, conv5 dilated on the 28x28 map: 19.51 GMAC)
+CONV_GF = {"r50c4": 7.90, "r50c4_fp8": 7.90, "r50dc5": 37.24, "r101c4_k80": 15.33, "v16": 39.02}
 
 
 def step_gflop(workload, R, K1, D1, D2, NH, ims=1):
@@ -231,10 +232,12 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--workload", choices=["r50c4", "r50dc5", "r101c4_k80", "r50c4_fp8"], default="r50c4",
+    ap.add_argument("--workload", choices=["r50c4", "r50dc5", "r101c4_k80", "r50c4_fp8", "v16"], default="r50c4",
                     help="r50c4 = BASELINE configs[1], the headline metric; r50dc5 (configs[2]: WS-R50 dilated C5, use with "
                          "--proposals 4000), r101c4_k80 (configs[3]: WS-R101 C4, 80 classes) and r50c4_fp8 (configs[4]: the "
-                         "R50-C4 trunk on the fp8 MFMA conv path, calibrated on two synthetic images) are side measurements")
+                         "R50-C4 trunk on the fp8 MFMA conv path, calibrated on two synthetic images) and v16 (configs[0]'s model at "
+                         "full size on the GPU: VGG16 dilated conv5, DAN_DIM [4096, 4096] = oicr_V_16_DC5_1x.yaml) are side "
+                         "measurements")
     ap.add_argument("--lookahead", type=int, choices=[1, 2, 3, 4], default=2,
                     help="how many batches ahead the frozen trunk runs (L: L-1 conv chains in flight on L-1 side streams, "
                          "each with L-1 steps to finish)")
@@ -328,6 +331,10 @@ def main():
     if args.workload == "r50dc5":
         cfg.merge_from_list(["MODEL.RESNETS.OUT_FEATURES", "['res5']", "MODEL.ROI_HEADS.IN_FEATURES", "['res5']",
                              "MODEL.RESNETS.RES5_DILATION", "2"])
+    elif args.workload == "v16":
+        cfg.merge_from_list(["MODEL.BACKBONE.NAME", "build_vgg_backbone", "MODEL.VGG.DEPTH", "16", "MODEL.VGG.CONV5_DILATION", "2",
+                             "MODEL.ROI_HEADS.IN_FEATURES", "['plain5']", "MODEL.ROI_BOX_HEAD.DAN_DIM", "[4096, 4096]",
+                             "MODEL.PIXEL_MEAN", "[103.939, 116.779, 123.68]", "SOLVER.BASE_LR", "0.001"])
     elif args.workload == "r101c4_k80":
         cfg.merge_from_list(["MODEL.RESNETS.DEPTH", "101", "MODEL.ROI_HEADS.NUM_CLASSES", "80"])
     if args.heads == "pcl":
@@ -520,7 +527,8 @@ def main():
                "config": {"workload": {"r50c4": "DRN-WSOD ResNet50-WS C4 (res4 out, stride 16)",
                                        "r50c4_fp8": "SIDE MEASUREMENT configs[4]: DRN-WSOD ResNet50-WS C4, fp8 MFMA conv path",
                                        "r50dc5": "SIDE MEASUREMENT configs[2]: DRN-WSOD ResNet50-WS dilated C5 (res5 out, stride 8)",
-                                       "r101c4_k80": "SIDE MEASUREMENT configs[3]: DRN-WSOD ResNet101-WS C4, 80 classes"}[args.workload]
+                                       "r101c4_k80": "SIDE MEASUREMENT configs[3]: DRN-WSOD ResNet101-WS C4, 80 classes",
+                                       "v16": "SIDE MEASUREMENT configs[0]'s model on the GPU: OICR VGG16 dilated conv5 (plain5 out, stride 8)"}[args.workload]
                                       + ", VOC07-shaped synthetic 224x224, "
                                       "%d proposals/img, %d img/GPU/iter, K=%d, 3 %s refinements, frozen backbone "
                                       "(FREEZE_AT=5), fwd+bwd+allreduce+SGD" % (R, args.ims_per_gpu, K, args.heads.upper()),

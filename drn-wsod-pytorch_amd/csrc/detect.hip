@@ -10,7 +10,6 @@
 // before it, so we walk the sorted list 64 candidates (one wave) at a time against the <= topk
 // survivors held in LDS and stop as soon as topk are kept - identical output, O(n*topk) work.
 #include "drn_common.h"
-#include <hipcub/hipcub.hpp>
 
 namespace {
 
@@ -105,9 +104,140 @@ __global__ __launch_bounds__(1024) void candidates_kernel(CandParams p) {
   }
 }
 
-__global__ void iota_kernel(int* v, int n) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < n) v[i] = i;
+// ---- stable descending sort of the candidates by score (round 3: own kernels, replaces hipcub::DeviceRadixSort) ------
+// torchvision's nms orders candidates with scores.sort(stable, descending); the value sorted along is the candidate's
+// index, so "stable descending" = ascending on the key ~asc(score) with ties in index order - exactly what an LSD radix
+// sort with stable passes delivers.  Three passes of 11 / 11 / 10 bits over the n = count[0] live candidates (the
+// count stays on the device: grids are sized for `cap`, tiles beyond n retire at once):
+//   sort_hist_kernel    per-tile digit histogram (LDS atomics: counts are order-free)      -> hist[digit][tile]
+//   sort_scan_kernel    one workgroup: exclusive prefix over (digit-major, tile-minor)     -> hist becomes offsets
+//   sort_scatter_kernel per tile, 256 elements per round IN INDEX ORDER: a lane's rank among equal digits = equal
+//                       digits of earlier rounds (run[d]) + of earlier waves this round (cnt[w][d]) + of earlier lanes of
+//                       its wave (ballot match over the digit's bits) - no atomics decide an order, so every pass is
+//                       stable and the result is a function of the input alone
+constexpr int SORT_THREADS = 256, SORT_ROUNDS = 16, SORT_TILE = SORT_THREADS * SORT_ROUNDS, SORT_BINS = 2048;
+
+__device__ __forceinline__ unsigned sort_key_desc(float f) {
+  const unsigned u = __builtin_bit_cast(unsigned, f);
+  const unsigned asc = u ^ ((u >> 31) ? 0xFFFFFFFFu : 0x80000000u);  // ascending total order on the bits
+  return ~asc;
+}
+
+struct SortPass {
+  const float* score;      // pass 0: keys are derived from the scores and the value is the index itself
+  const unsigned* key_in; const int* val_in;
+  unsigned* key_out; int* val_out;
+  int* hist;               // [SORT_BINS][tiles]
+  const int* count;
+  int tiles, shift, bits, first;
+};
+
+__device__ __forceinline__ unsigned sort_load_key(const SortPass& p, int i) {
+  return p.first ? sort_key_desc(p.score[i]) : p.key_in[i];
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_hist_kernel(SortPass p) {
+  __shared__ int h[SORT_BINS];
+  const int n = p.count[0], tile = blockIdx.x, nb = 1 << p.bits;
+  for (int d = threadIdx.x; d < nb; d += SORT_THREADS) h[d] = 0;
+  __syncthreads();
+  const int t0 = tile * SORT_TILE;
+  if (t0 < n)
+    for (int j = 0; j < SORT_ROUNDS; ++j) {
+      const int i = t0 + j * SORT_THREADS + threadIdx.x;
+      if (i < n) atomicAdd(&h[(sort_load_key(p, i) >> p.shift) & (nb - 1)], 1);
+    }
+  __syncthreads();
+  for (int d = threadIdx.x; d < nb; d += SORT_THREADS) p.hist[(long)d * p.tiles + tile] = h[d];
+}
+
+// exclusive prefix of hist in (digit, tile) order; one workgroup of 1024 threads, two digits per thread at most
+__global__ __launch_bounds__(1024) void sort_scan_kernel(SortPass p) {
+  __shared__ int tot[SORT_BINS];
+  __shared__ int wsum[16];
+  const int nb = 1 << p.bits;
+  for (int d = threadIdx.x; d < SORT_BINS; d += 1024) {
+    int s = 0;
+    if (d < nb)
+      for (int t = 0; t < p.tiles; ++t) s += p.hist[(long)d * p.tiles + t];
+    tot[d] = s;
+  }
+  __syncthreads();
+  // block-wide exclusive scan of tot[0 .. 2048): thread t owns digits 2t, 2t+1
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int a = tot[2 * threadIdx.x], b = tot[2 * threadIdx.x + 1];
+  int v = a + b;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(v, o, 64);
+    if (lane >= o) v += u;
+  }
+  if (lane == 63) wsum[w] = v;
+  __syncthreads();
+  int base = 0;
+  for (int q = 0; q < w; ++q) base += wsum[q];
+  const int excl = base + v - (a + b);
+  __syncthreads();
+  tot[2 * threadIdx.x] = excl;
+  tot[2 * threadIdx.x + 1] = excl + a;
+  __syncthreads();
+  for (int d = threadIdx.x; d < nb; d += 1024) {
+    int run = tot[d];
+    for (int t = 0; t < p.tiles; ++t) {
+      const long k = (long)d * p.tiles + t;
+      const int c = p.hist[k];
+      p.hist[k] = run;
+      run += c;
+    }
+  }
+}
+
+__global__ __launch_bounds__(SORT_THREADS) void sort_scatter_kernel(SortPass p) {
+  __shared__ int run[SORT_BINS];                     // this tile's next output slot per digit
+  __shared__ int cnt[SORT_THREADS / 64][SORT_BINS];  // per wave and round; every entry is reset by whoever set it
+  const int n = p.count[0], tile = blockIdx.x, nb = 1 << p.bits;
+  const int t0 = tile * SORT_TILE;
+  if (t0 >= n) return;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  for (int d = threadIdx.x; d < nb; d += SORT_THREADS) {
+    run[d] = p.hist[(long)d * p.tiles + tile];
+#pragma unroll
+    for (int q = 0; q < SORT_THREADS / 64; ++q) cnt[q][d] = 0;
+  }
+  __syncthreads();
+  for (int j = 0; j < SORT_ROUNDS; ++j) {
+    const int i = t0 + j * SORT_THREADS + threadIdx.x;
+    const bool valid = i < n;
+    unsigned key = 0;
+    int val = 0, d = 0;
+    if (valid) {
+      key = sort_load_key(p, i);
+      val = p.first ? i : p.val_in[i];
+      d = (key >> p.shift) & (nb - 1);
+    }
+    // lanes of this wave with the same digit (and valid)
+    unsigned long long m = __ballot(valid);
+    for (int b = 0; b < p.bits; ++b) {
+      const unsigned long long bal = __ballot((d >> b) & 1);
+      m &= ((d >> b) & 1) ? bal : ~bal;
+    }
+    const int lrank = __popcll(m & ((1ULL << lane) - 1ULL));
+    const bool leader = valid && lrank == 0;
+    if (leader) cnt[w][d] = __popcll(m);
+    __syncthreads();
+    if (valid) {
+      int pos = run[d] + lrank;
+      for (int q = 0; q < w; ++q) pos += cnt[q][d];
+      p.key_out[pos] = key;
+      p.val_out[pos] = val;
+    }
+    __syncthreads();
+    if (leader) {
+      atomicAdd(&run[d], cnt[w][d]);  // integer adds commute: run[d] is the same whatever order the waves arrive in
+      cnt[w][d] = 0;
+    }
+    __syncthreads();
+  }
 }
 
 struct NmsParams {
@@ -181,11 +311,6 @@ __global__ __launch_bounds__(64) void nms_topk_kernel(NmsParams p) {
 
 namespace {
 
-__global__ void fill_tail_kernel(float* c_score, const int* count, int cap) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < cap && i >= count[0]) c_score[i] = -INFINITY;  // unused slots sort last
-}
-
 __global__ void gather_kernel(const float* c_box, const float* c_score, const int* c_row, const int* c_cls,
                               const int* keep, const int* n_keep, float* ob, float* os, int* oc, int* orow) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -196,24 +321,27 @@ __global__ void gather_kernel(const float* c_box, const float* c_score, const in
 }
 
 struct Ws {
-  float* c_box; float* c_score; float* s_score; int* c_row; int* c_cls; int* iota; int* order; int* count;
-  float* maxcoord; char* cub; size_t cub_bytes;
+  float* c_box; float* c_score; unsigned* key0; int* c_row; int* c_cls; int* val0; int* order; int* count;
+  float* maxcoord; unsigned* key1; int* hist;
 };
 
-inline long ws_fixed_bytes(int cap) { return (long)cap * (16 + 4 * 6) + 256; }
+inline int sort_tiles(int cap) { return (cap + SORT_TILE - 1) / SORT_TILE; }
+inline long ws_fixed_bytes(int cap) { return (long)cap * (16 + 4 * 7) + 256 + (long)SORT_BINS * sort_tiles(cap) * 4; }
 
 inline Ws carve(void* workspace, long bytes, int cap) {
+  (void)bytes;
   Ws k;
   char* w = (char*)workspace;
   k.c_box = (float*)w; w += (long)cap * 16;
   k.c_score = (float*)w; w += (long)cap * 4;
-  k.s_score = (float*)w; w += (long)cap * 4;
+  k.key0 = (unsigned*)w; w += (long)cap * 4;   // sort ping (doubles as the finite-row map until pass 1 writes it)
   k.c_row = (int*)w; w += (long)cap * 4;
   k.c_cls = (int*)w; w += (long)cap * 4;
-  k.iota = (int*)w; w += (long)cap * 4;
-  k.order = (int*)w; w += (long)cap * 4;
+  k.val0 = (int*)w; w += (long)cap * 4;
+  k.order = (int*)w; w += (long)cap * 4;        // sort pong values = the final order
+  k.key1 = (unsigned*)w; w += (long)cap * 4;
   k.count = (int*)w; k.maxcoord = (float*)(w + 8); w += 256;
-  k.cub = w; k.cub_bytes = (size_t)(bytes - ws_fixed_bytes(cap));
+  k.hist = (int*)w;
   return k;
 }
 
@@ -252,12 +380,7 @@ __global__ void tta_accumulate_kernel(const float* __restrict__ boxes, const flo
 extern "C" {
 
 // bytes of scratch drn_detect_topk needs for up to `cap` candidates (cap = R*K is always enough)
-long drn_detect_workspace_bytes(int cap) {
-  size_t tmp = 0;
-  float* kf = nullptr; int* vi = nullptr;
-  (void)hipcub::DeviceRadixSort::SortPairsDescending(nullptr, tmp, kf, kf, vi, vi, cap);
-  return ws_fixed_bytes(cap) + (long)tmp + 256;
-}
+long drn_detect_workspace_bytes(int cap) { return ws_fixed_bytes(cap < 1 ? 1 : cap) + 256; }
 
 // Single image.  boxes [R][4*nreg], scores [R][K+1] (last column = background).  Leaves the kept
 // candidate ids (descending score) in keep_ids[0..n_keep) on the device; drn_detect_gather expands them.
@@ -272,13 +395,19 @@ int drn_detect_topk(const float* boxes, const float* scores, int R, int K, int n
   hipStream_t st = (hipStream_t)stream;
   Ws k = carve(workspace, workspace_bytes, cap);
   CandParams cp{boxes, scores, R, K, nreg, img_h, img_w, score_thresh, k.c_box, k.c_score, k.c_row, k.c_cls, k.count,
-                k.maxcoord, cap, (int*)k.s_score};  // s_score doubles as the row map until the sort overwrites it
+                k.maxcoord, cap, (int*)k.key0};  // key0 doubles as the row map until the sort's second pass overwrites it
   hipLaunchKernelGGL(candidates_kernel, dim3(1), dim3(1024), 0, st, cp);
-  hipLaunchKernelGGL(iota_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, k.iota, cap);
-  hipLaunchKernelGGL(fill_tail_kernel, dim3((cap + 255) / 256), dim3(256), 0, st, k.c_score, k.count, cap);
-  if (hipcub::DeviceRadixSort::SortPairsDescending((void*)k.cub, k.cub_bytes, k.c_score, k.s_score, k.iota, k.order,
-                                                   cap, 0, 32, st) != hipSuccess)
-    return DRN_ERR_LAUNCH;
+  // stable descending order of the live candidates: (score, index) -> key1/order -> key0/val0 -> key1/order
+  const int tiles = sort_tiles(cap);
+  const int shifts[3] = {0, 11, 22}, bits[3] = {11, 11, 10};
+  for (int ps = 0; ps < 3; ++ps) {
+    const bool even = (ps & 1) == 0;
+    SortPass sp{k.c_score, even ? k.key0 : k.key1, even ? k.val0 : k.order, even ? k.key1 : k.key0,
+                even ? k.order : k.val0, k.hist, k.count, tiles, shifts[ps], bits[ps], ps == 0};
+    hipLaunchKernelGGL(sort_hist_kernel, dim3(tiles), dim3(SORT_THREADS), 0, st, sp);
+    hipLaunchKernelGGL(sort_scan_kernel, dim3(1), dim3(1024), 0, st, sp);
+    hipLaunchKernelGGL(sort_scatter_kernel, dim3(tiles), dim3(SORT_THREADS), 0, st, sp);
+  }
   NmsParams np{k.c_box, k.c_score, k.c_cls, k.order, k.count, k.maxcoord, nms_thresh, topk, 40000, keep_ids, n_keep};
   hipLaunchKernelGGL(nms_topk_kernel, dim3(1), dim3(64), 0, st, np);
   DRN_CHECK_LAUNCH();

@@ -449,6 +449,10 @@ FULL_CASES = {
     "r101c4_r2000_k80": (dict(arch="wsr101", out_feature="res4", res5_dilation=1, num_classes=80), 2000),
     # configs[2] shape: WS-R50-DilatedC5, R=4000 (27x27x2048 map: the window-staged ROIPool path, fc6 K = 100352)
     "r50dc5_r4000_k20": (dict(arch="wsr50", out_feature="res5", res5_dilation=2, num_classes=20), 4000),
+    # configs[0] at full size (round 3): VGG16 with dilated conv5 (28x28x512 map), fc6 [4096 x 25088], fc7 4096 -> 4096 - the
+    # N = 4096 GEMM shapes of oicr_V_16_DC5_1x.yaml, which only the small V16 golden covered before
+    "vgg16_r2000_k20": (dict(arch="vgg16", out_feature="plain5", res5_dilation=2, num_classes=20, dan_dim=(4096, 4096),
+                             pixel_mean=(103.939, 116.779, 123.68), base_lr=0.001), 2000),
     # PCLROIHeads on the bench trunk: proposal clustering of 2000 boxes on the device
     "pcl_r50c4_r2000_k20": (dict(arch="wsr50", out_feature="res4", res5_dilation=1, num_classes=20, heads="pcl"), 2000),
 }

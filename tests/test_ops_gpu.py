@@ -950,6 +950,26 @@ def test_detect_random(drn, R, K, thr):
     assert torch.equal(s.cpu(), rs_) and torch.equal(b.cpu(), rb)
 
 
+@pytest.mark.parametrize("R,K,levels", [(2500, 20, 32), (700, 20, 4), (2100, 20, 0)])
+def test_detect_sort_ties_and_many_tiles(drn, R, K, levels):
+    """Round 3: the candidate sort is this library's own LSD radix sort (sort_hist / sort_scan / sort_scatter kernels,
+    three stable passes) instead of hipcub's.  The order it must deliver is torch's scores.sort(stable, descending): ties
+    keep candidate (row-major) order.  Scores quantised to a few levels make almost every comparison a tie, spread over
+    several 4096-element tiles; R*K >= 40000 also takes batched_nms's per-class branch (detectron2/layers/nms.py:19-29).
+    Output rows / classes / scores / boxes must equal the oracle's bit for bit."""
+    rs = np.random.RandomState(171 + levels)
+    props = _boxes(R, 172)
+    boxes = O.apply_deltas(torch.from_numpy(rs.standard_normal((R, 4 * K)).astype(np.float32) * 0.5), props)
+    scores = F.softmax(torch.from_numpy(rs.standard_normal((R, K + 1)).astype(np.float32) * 2), 1)
+    if levels:
+        scores = (scores * levels).ceil() / levels  # every value > 0 passes the threshold; `levels` distinct values
+    rb, rs_, rc, rr = O.fast_rcnn_inference_single_image(boxes.clone(), scores.clone(), (150, 200), 1e-5, 0.3, 100)
+    for _ in range(2):  # twice: the result may not depend on how the workgroups were scheduled
+        b, s, c, rows = drn.detect_topk(boxes.to(DEV), scores.to(DEV), (150, 200), 1e-5, 0.3, 100)
+        assert torch.equal(rows.cpu(), rr) and torch.equal(c.cpu(), rc)
+        assert torch.equal(s.cpu(), rs_) and torch.equal(b.cpu(), rb)
+
+
 def test_detect_empty_and_all_filtered(drn):
     boxes = torch.zeros((10, 8)) + torch.tensor([0, 0, 5, 5, 0, 0, 5, 5.0])
     scores = torch.zeros((10, 3))
