@@ -278,6 +278,9 @@ def main():
                     help='torch.distributed backend ("nccl" = RCCL); gloo + --single-device runs N ranks on ONE GPU to '
                          "exercise the N>1 flow of this script where only one GPU is available (not a measurement)")
     ap.add_argument("--single-device", action="store_true", help="every rank uses cuda:0 (with --backend gloo)")
+    ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the collective self-test in front of the warm-up")
+    ap.add_argument("--selftest-timeout", type=float, default=120.0,
+                    help="seconds a self-test collective may take before the run fails loudly instead of hanging")
     ap.add_argument("--exchange", choices=["sharded", "allreduce"], default=None,
                     help="N > 1: sharded (default) = reduce-scatter of each fc6 gradient slab, SGD on the owned rows (1/N of "
                          "the optimizer traffic), all-gather of the updated bf16 rows; allreduce = DDP's all-reduce + "
@@ -347,6 +350,21 @@ def main():
     opt = build_optimizer(cfg, model)
     dp = DataParallel(model, force_exchange=args.force_exchange)
     dp.broadcast_parameters(0)
+    selftest = None
+    if dp.exchange and not args.no_selftest:
+        # the step's collectives on scratch buffers of the real bucket sizes, 3 iterations each, BEFORE any warm-up: a wedged
+        # RCCL bootstrap / a missing peer mapping / a missing rank raises here with the collective's name instead of
+        # hanging the measurement (DataParallel.selftest polls every collective against a deadline)
+        d1_, k1_ = model.roi_heads.box_head.fc1.weight.shape
+        model.roi_heads._engine.ensure(torch.device(device))
+        o_fc1_ = model.roi_heads._engine._seg["fc1.weight"][0]
+        half_ = ((d1_ + 255) // 256 + 1) // 2 * 256
+        slabs_ = [(half_, k1_), (d1_ - half_, k1_)] if 0 < half_ < d1_ else [(d1_, k1_)]
+        selftest = dp.selftest({"small": o_fc1_, "slabs": slabs_}, iters=3, timeout=args.selftest_timeout,
+                               wire_dtype=torch.float32 if args.comm_dtype == "fp32" else torch.bfloat16)
+        if rank == 0:
+            print("[bench] collective self-test ok: " + ", ".join("%s %.2f ms (%.0f GB/s bus)" % (k, v["ms"], v["busbw_GBps"])
+                                                                  for k, v in selftest.items()), file=sys.stderr, flush=True)
     if not args.no_pipelined_sgd:
         # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
@@ -427,6 +445,28 @@ def main():
             last2 = stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
         host_unblocked = (time.perf_counter() - th) / 6 * 1e3
         barrier()
+        local_ms = None
+        if dp.exchange and getattr(opt, "_exchange_on", False):
+            # what the exchange costs on the critical path: the SAME graphed step with the collectives switched off (every
+            # rank updates all rows from its local gradient - the replicas diverge, the measurement above is over),
+            # timed the same way; exposed = step with exchange - step without
+            opt._exchange_on = False
+            n_loc = min(args.steps, 50)
+            for i in range(3):
+                j = args.warmup + args.steps + 6 + i
+                stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+            barrier()
+            tl = time.perf_counter()
+            for i in range(n_loc):
+                j = args.warmup + args.steps + 9 + i
+                stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+            barrier()
+            local_ms = (time.perf_counter() - tl) / n_loc * 1e3
+            if world > 1:
+                tt = torch.tensor([local_ms], device=device, dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                local_ms = float(tt)
+            opt._exchange_on = True
     else:
         ops.GEMM_TIMING = timing = []
         ops.HBM_TIMING = hbm_timing = []
@@ -542,7 +582,13 @@ def main():
                    "collective": ("RCCL reduce-scatter per fc6 dW row slab -> fused SGD on the owned rows -> all-gather of the "
                                   "updated compute copy; all-reduce for the small tensors" if getattr(opt, "_sharded", False)
                                   else "RCCL all-reduce per bucket (small tensors and fc6 dW row slabs)") + ", fc6_grad_dtype on the wire",
-                   "slab_ends": getattr(opt, "_slab_ends", None), "ranks": rank_info},
+                   "slab_ends": getattr(opt, "_slab_ends", None), "ranks": rank_info,
+                   "selftest": selftest,
+                   "step_ms_without_exchange": local_ms if use_graph else None,
+                   "exposed_ms": (dt / args.steps * 1e3 - local_ms) if (use_graph and local_ms is not None) else None,
+                   "exposed_ms_definition": "ms_per_step - the same graphed step with the collectives switched off (full local "
+                                            "update on every rank), max over ranks; in the sharded exchange the step WITH "
+                                            "exchange updates only 1/N of the fc6 rows, so this can be negative"},
                "roofline": roof, "roofline_step": roof_step, "roofline_launches": launches}
         if world == 1 and not dp.exchange:
             try:

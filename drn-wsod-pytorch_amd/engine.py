@@ -664,6 +664,99 @@ class DataParallel:
             k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
             self._reduce(e.arena_g[o + r0 * k1: o + r1 * k1])
 
+    def selftest(self, buckets, iters=3, timeout=120.0, wire_dtype=torch.bfloat16):
+        """Run the collectives of the training step ONCE on scratch buffers of the real bucket sizes before any warm-up:
+        all-reduce of the small bucket, reduce-scatter + all-gather of every fc6 row slab (and the all-reduce form of the
+        slab).  Every collective is issued asynchronously and polled against `timeout`, so a wedged RCCL bootstrap, a
+        missing peer mapping (HSA_ENABLE_IPC_MODE_LEGACY) or a rank that never arrives raises a DrnError that names the
+        collective and the rank instead of hanging the job.  Checks the arithmetic too (every rank
+        contributes rank + 1).  Returns {collective: {"bytes", "ms", "algbw_GBps", "busbw_GBps"}} with the NCCL-tests
+        bus-bandwidth convention (all-reduce 2 (N-1)/N, reduce-scatter / all-gather (N-1)/N of the buffer).
+        buckets: {"small": elements, "slabs": [(rows, cols), ...]}"""
+        import time
+
+        if not (dist.is_available() and dist.is_initialized()):
+            raise DrnError("DataParallel.selftest needs an initialised process group")
+        g, W = self.group, self.world
+        rank = dist.get_rank(g)
+        dev = self.engine.arena_w.device if getattr(self.engine, "arena_w", None) is not None else \
+            next(self.model.roi_heads.parameters()).device
+        es = torch.empty((), dtype=wire_dtype).element_size()
+
+        polled = dist.get_backend(g) == "nccl"  # gloo completes some ops only inside wait(): use its own timeout there
+
+        def wait(work, what):
+            t0 = time.monotonic()
+            if not polled:
+                import datetime
+
+                try:
+                    work.wait(timeout=datetime.timedelta(seconds=timeout))
+                except RuntimeError as ex:
+                    raise DrnError("collective self-test: %s failed or timed out on rank %d of %d (backend %s): %s" % (
+                        what, rank, W, dist.get_backend(g), ex)) from ex
+                return
+            while not work.is_completed():
+                if time.monotonic() - t0 > timeout:
+                    raise DrnError("RCCL self-test: %s did not complete within %.0f s on rank %d of %d (backend %s) - a rank "
+                                   "is missing, or the peer-to-peer mapping failed (is HSA_ENABLE_IPC_MODE_LEGACY=0 set "
+                                   "in every rank's environment?)" % (what, timeout, rank, W, dist.get_backend(g)))
+                time.sleep(0.001)
+            if dev.type == "cuda":
+                torch.cuda.synchronize(dev)
+
+        def timed(fn, what, nbytes, bus_factor):
+            try:
+                wait(fn(), what)  # first call: communicator setup, untimed
+                t0 = time.perf_counter()
+                for _ in range(iters):
+                    wait(fn(), what)
+                ms = (time.perf_counter() - t0) / iters * 1e3
+            except RuntimeError as ex:  # torch surfaces RCCL errors as RuntimeError (DistBackendError)
+                if isinstance(ex, DrnError):
+                    raise
+                raise DrnError("RCCL self-test: %s failed on rank %d of %d: %s" % (what, rank, W, ex)) from ex
+            alg = nbytes / ms / 1e6
+            return {"bytes": int(nbytes), "ms": ms, "algbw_GBps": alg, "busbw_GBps": alg * bus_factor}
+
+        out = {}
+        n = int(buckets["small"])
+        small = torch.empty((n,), dtype=wire_dtype, device=dev)
+
+        def ar_small():
+            small.fill_(rank + 1.0)
+            return dist.all_reduce(small, group=g, async_op=True)
+
+        out["all_reduce small bucket"] = timed(ar_small, "all_reduce of the small bucket (%d elements)" % n, n * es, 2.0 * (W - 1) / W)
+        exp = W * (W + 1) / 2.0
+        if float(small[0]) != exp or float(small[-1]) != exp:
+            raise DrnError("RCCL self-test: all_reduce returned %r, expected %r" % (float(small[0]), exp))
+        for i, (rows, cols) in enumerate(buckets["slabs"]):
+            if rows % W:
+                continue  # the step falls back to the all-reduce for such a slab
+            full = torch.empty((rows, cols), dtype=wire_dtype, device=dev)
+            mine = torch.empty((rows // W, cols), dtype=wire_dtype, device=dev)
+
+            def rs():
+                full.fill_(rank + 1.0)
+                return dist.reduce_scatter_tensor(mine, full, group=g, async_op=True)
+
+            out["reduce_scatter fc6 slab %d" % i] = timed(rs, "reduce_scatter of fc6 slab %d [%d x %d]" % (i, rows, cols),
+                                                          rows * cols * es, (W - 1.0) / W)
+            if float(mine[0, 0]) != exp:
+                raise DrnError("RCCL self-test: reduce_scatter returned %r, expected %r" % (float(mine[0, 0]), exp))
+
+            def ag():
+                mine.fill_(rank + 1.0)
+                return dist.all_gather_into_tensor(full, mine, group=g, async_op=True)
+
+            out["all_gather fc6 slab %d" % i] = timed(ag, "all_gather of fc6 slab %d" % i, rows * cols * es, (W - 1.0) / W)
+            if float(full[rows - 1, cols - 1]) != float(W):
+                raise DrnError("RCCL self-test: all_gather returned %r in the last rank's rows, expected %r" % (
+                    float(full[rows - 1, cols - 1]), float(W)))
+            del full, mine
+        return out
+
     def finish(self):
         """make the optimizer stream wait for the exchanged gradients"""
         if self.world > 1 and self._comm is not None:

@@ -404,7 +404,7 @@ def resnet_ws_forward(p: Dict[str, torch.Tensor], x: torch.Tensor, cfg: OracleCf
     x = q(F.relu(_conv_bn(x, p, s + "conv2", padding=1, cfg=cfg)), s + "conv2")
     x = q(F.relu(_conv_bn(x, p, s + "conv3", padding=1, cfg=cfg)), s + "conv3")
     x = F.max_pool2d(x, 2, 2)
-    feats = {}
+    feats = {"stem": x}
     for name, nblk, dil, pool in resnet_ws_stage_plan(cfg):
         for b in range(nblk):
             bp = "%s%s.%d." % (prefix, name, b)

@@ -155,6 +155,15 @@ def _worker(rank, world, port, q):
         opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.float32, exchange="allreduce")
         assert opt._exchange("small") is None
         assert torch.allclose(e.arena_g[:o_fc1], exp[:o_fc1])
+        # the collective self-test bench.py runs in front of its warm-up (DataParallel.selftest): sizes of this tiny model
+        res = dp.selftest({"small": o_fc1, "slabs": [(16, k1), (24, k1), (d1 - 40, k1)]}, iters=2, timeout=30.0,
+                          wire_dtype=torch.float32)
+        assert "all_reduce small bucket" in res and res["all_reduce small bucket"]["bytes"] == 4 * o_fc1
+        for i, rows_ in enumerate((16, 24, d1 - 40)):
+            if rows_ % 2 == 0:
+                assert res["reduce_scatter fc6 slab %d" % i]["ms"] > 0 and res["all_gather fc6 slab %d" % i]["busbw_GBps"] > 0
+            else:
+                assert "reduce_scatter fc6 slab %d" % i not in res  # the step falls back to the all-reduce there
         q.put((rank, "ok"))
     except Exception as ex:  # noqa: BLE001
         import traceback

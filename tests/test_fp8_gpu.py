@@ -104,6 +104,20 @@ def test_maxpool_fp8(drn):
         assert torch.equal(y.float().cpu(), ref)
 
 
+# per-stage bounds of the fp8 trunk against its emulator (set from profiles/r3_08_fp8_by_stage.txt with ~2x margin):
+# relative rms of a stage's output when the stage is fed the EMULATOR's input, the fraction of identical fp8 codes there,
+# and the relative rms of the product's own chain (flips compound along the 45 convs)
+# measured: forced 2.2e-3 / 1.09e-2 / 2.4e-2 / 3.9e-2, same code 99.82 / 94.1 / 77.9 %, own chain 2.2e-3 / 2.0e-2 / 5.0e-2 /
+# 8.1e-2 (within a stage the flips of one conv perturb the next conv's sums and breed further flips); a wrong tap,
+# channel, scale or residual path gives a relative rms of O(1) and a same-code fraction near the chance level
+FP8_STAGE_FORCED_REL = {"stem": 5e-3, "res2": 2.5e-2, "res3": 5e-2, "res4": 8e-2}
+FP8_STAGE_FORCED_SAME = {"stem": 0.995, "res2": 0.88, "res3": 0.60, "res4": 0.0}
+FP8_STAGE_CHAIN_REL = {"stem": 5e-3, "res2": 4e-2, "res3": 1e-1, "res4": 1.6e-1}
+# relative bound of a refinement loss against an oracle that mined the SAME pseudo-GT rows (set from
+# profiles/r3_07_fp8_by_stage.txt with ~2x margin): vs the fp8 emulator / vs the fp32 oracle
+FP8_LOSS_SAME_ROWS = {"emu": 0.10, "fp32": 0.25}
+
+
 def _within(v, e, r, floor, k=5.0, rel=2e-2):
     tol = k * abs(e - r) + rel * max(abs(r), floor)
     return abs(v - e) <= tol and abs(v - r) <= tol, tol
@@ -145,9 +159,97 @@ def test_fp8_trunk_and_train_step_full_size():
         rms(f32), d_pe, d_pr, d_er, d_bf))
     assert d_er > d_bf, "fp8 rounding must cost more than bf16 rounding, or the fp8 path is not running"
     assert max(d_pe, d_pr) <= 3.0 * d_er + 1e-2 * rms(f32)
+    # (a') round 3: the trunk stage by stage against its emulator, in units of the fp8 spacing.  Both
+    # run their own chain from the same image, so what separates them is rounding flips (a 1e-6 summation-order difference
+    # lands an element on the neighbouring fp8 code) and their propagation: few flips after the 3-conv stem, more after
+    # each stage.  An indexing / scale / layout defect in any fp8 layer moves whole channels by many codes and shows at
+    # the first stage it touches, long before the flips of the 45-conv chain have compounded.
+    bb = model.backbone
+    with torch.no_grad():
+        y = bb.stem.forward_nhwc(bb._input_nhwc(model.preprocess_image(ins(batch)).tensor))
+        prod = {"stem": y}
+        for stage, name in bb.stages_and_names:
+            for block in stage:
+                y = block.forward_nhwc(y)
+            prod[name] = y
+    femu = O.resnet_ws_forward(p, xe, emu_cfg)
+    last_conv = {"stem": "stem.conv3", "res2": "res2.2.conv3", "res3": "res3.3.conv3", "res4": "res4.5.conv3"}
+
+    def compare(t, ev, name, tag):
+        sc = getattr(t, "_drn_scale", 1.0)
+        pv = (t.float() / sc).permute(0, 3, 1, 2).cpu().double().numpy()
+        assert pv.shape == ev.shape, (name, pv.shape, ev.shape)
+        rel = rms(pv - ev) / rms(ev)
+        same = None
+        if t.dtype == FP8:
+            assert abs(sc - scales[last_conv[name]]) <= 1e-6 * sc
+            same = float((np.abs(pv - ev) * sc < 2.0 ** -10).mean())  # identical fp8 codes (spacing >= 2^-9 in code units)
+        print("[fp8 %-14s %-5s] rel rms %.2e%s" % (tag, name, rel, "" if same is None else ", %.2f %% of the elements on the same fp8 code" % (100 * same)))
+        return rel, same
+
+    # (i) the product's own chain against the emulator's own chain (flips compound from stage to stage)
+    chain = {name: compare(prod[name], femu[name].double().numpy(), name, "own chain") for name in ("stem", "res2", "res3", "res4")}
+    # (ii) every stage FROM THE EMULATOR'S INPUT of that stage: only the flips of the stage's own 9-18 convs remain, so the
+    # bound can be tight - a wrong tap, channel, scale or residual path in any fp8 layer fails here by orders of magnitude
+    forced = {"stem": chain["stem"]}  # the stem's input is the bf16 image in both
+    prev = "stem"
+    with torch.no_grad():
+        for stage, name in bb.stages_and_names:
+            src = femu[prev]
+            s_in = scales[last_conv[prev]]
+            xin = _quant(src, s_in).permute(0, 2, 3, 1).contiguous().to(DEV)  # exact: the emulator's values are on the fp8 grid
+            assert torch.equal(xin.float().cpu() / s_in, src.permute(0, 2, 3, 1)), "emulator output off the fp8 grid"
+            xin._drn_scale = s_in
+            y = xin
+            for block in stage:
+                y = block.forward_nhwc(y)
+            forced[name] = compare(y, femu[name].double().numpy(), name, "emulator input")
+            prev = name
+    for name in ("stem", "res2", "res3", "res4"):
+        rel, same = forced[name]
+        assert rel <= FP8_STAGE_FORCED_REL[name], (name, rel)
+        if same is not None:
+            assert same >= FP8_STAGE_FORCED_SAME[name], (name, same)
+        assert chain[name][0] <= FP8_STAGE_CHAIN_REL[name], (name, chain[name][0])
     # (b) one train step
     model.train()
     opt = build_optimizer(cfg, model)
+    opt.zero_grad()
+    # (b') round 3: the HEADS on the emulator's res4 map.  With the trunk pinned stage by stage above, what is left of the
+    # step is the bf16 heads; fed the emulator's own feature map they differ from the emulating oracle by bf16 rounding
+    # flips only - the regime tests/test_bench_mode_gpu.py measured at <= 3.6 % on every loss - so the 2x loss error
+    # the end-to-end comparison below lets through (its pseudo-GT rows differ: loss_cls_r1 0.178 vs 0.089) cannot hide a
+    # defect here: every loss within 1e-3 of the emulating oracle (measured 1.7e-5), image scores within 3 x |emu - fp32| + 1 %, and a
+    # pseudo-GT row the emulator did not pick must be a near-tie in its scores
+    emu_l, _, emu_aux = O.train_step(O.init_params(emu_cfg, seed=3), batch, emu_cfg, O.SGDState(emu_cfg), return_aux=True)
+    f32_l, _, f32_aux = O.train_step(O.init_params(ocfg, seed=3), batch, ocfg, O.SGDState(ocfg), return_aux=True)
+    fe_dev = fe.to(torch.bfloat16).cuda().contiguous(memory_format=torch.channels_last)
+    assert torch.equal(fe_dev.float().cpu(), fe), "the emulator's res4 map is stored in bf16"
+    model.backbone.forward = lambda x: {"res4": fe_dev}
+    try:
+        forced = {k: float(v.detach()) for k, v in model(ins(batch)).items()}
+    finally:
+        del model.backbone.forward
+    st = model.roi_heads._last_state
+    img_f = st["aux"]["img_scores"].cpu().numpy().astype(np.float64)
+    e_img, r_img = emu_aux["img_scores"].numpy().astype(np.float64), f32_aux["img_scores"].numpy().astype(np.float64)
+    tol = 3.0 * np.abs(e_img - r_img).max() + 1e-2 * np.abs(r_img).max()
+    print("[fp8 heads on the emulator's res4] image scores |p-emu| %.2e (bound %.2e)" % (np.abs(img_f - e_img).max(), tol))
+    assert np.abs(img_f - e_img).max() <= tol
+    prev = [emu_aux["scores"].detach()] + [torch.softmax(l.detach(), dim=-1) for l in emu_aux["logits"][:-1]]
+    for k in range(ocfg.refine_num):
+        mine = st["aux"]["targets"][k]["pgt_idx"].cpu().numpy()[0]
+        (_, pc, _, _, idx) = emu_aux["pgt"][k][0]
+        for g, c in enumerate(pc.numpy()):
+            if int(mine[g]) != int(idx[g]):
+                col = prev[k][:, int(c)].numpy()
+                ratio = float(col[int(mine[g])] / col.max())
+                print("   pgt branch %d class %d: product row %d, emu %d, score ratio %.4f" % (k, int(c), int(mine[g]), int(idx[g]), ratio))
+                assert ratio >= 0.9, ("pgt row not a near-tie", k, g, ratio)
+    for k_, v in forced.items():
+        rel = abs(v - emu_l[k_]) / max(abs(emu_l[k_]), 1e-2)
+        print("   %-12s %.6f  emu %.6f  fp32 %.6f  rel(p, emu) %.2e" % (k_, v, emu_l[k_], f32_l[k_], rel))
+        assert rel <= 1e-3, (k_, v, emu_l[k_])  # measured <= 1.7e-5 (dropout off in this test: no {0, 2} mask amplifies the flips)
     opt.zero_grad()
     w0 = model.roi_heads.box_head.fc1.weight.detach().reshape(-1)[::4099].cpu().clone()
     losses = model(ins(batch))
@@ -156,6 +258,7 @@ def test_fp8_trunk_and_train_step_full_size():
     torch.cuda.synchronize()
     got = {k: float(v.detach()) for k, v in losses.items()}
     img = model.roi_heads._last_state["aux"]["img_scores"].cpu().numpy().astype(np.float64)
+    rows_p = [tg["pgt_idx"].cpu().numpy().copy() for tg in model.roi_heads._last_state["aux"]["targets"]]
     dw = (model.roi_heads.box_head.fc1.weight.detach().reshape(-1)[::4099].cpu() - w0).numpy()
     res = {}
     for tag, c in (("emu", emu_cfg), ("fp32", ocfg)):
@@ -163,8 +266,22 @@ def test_fp8_trunk_and_train_step_full_size():
         w_before = pp["roi_heads.box_head.fc1.weight"].reshape(-1)[::4099].clone()
         l, _, aux = O.train_step(pp, batch, c, O.SGDState(c), return_aux=True)
         res[tag] = (l, aux["img_scores"].numpy().astype(np.float64),
-                    (pp["roi_heads.box_head.fc1.weight"].reshape(-1)[::4099] - w_before).numpy())
+                    (pp["roi_heads.box_head.fc1.weight"].reshape(-1)[::4099] - w_before).numpy(),
+                    [[idx.numpy().copy() for (_, _, _, _, idx) in aux["pgt"][k]] for k in range(c.refine_num)])
     bad = []
+    # round 3: a refinement loss is a CONTINUOUS function of the logits only for fixed pseudo-GT rows (get_pgt's arg-max,
+    # roi_heads_oicr.py:504-506, is the discontinuity).  Where the product mined the same rows as an oracle, its loss is
+    # held to that oracle tightly (FP8_LOSS_SAME_ROWS); the group bound below remains for branches whose rows differ.
+    for k in range(ocfg.refine_num):
+        name = "loss_cls_r%d" % k
+        for tag in ("emu", "fp32"):
+            o_idx = np.asarray(res[tag][3][k][0]).reshape(-1)  # image 0 (the batch holds one image)
+            same = np.array_equal(np.asarray(rows_p[k][0]).reshape(-1)[: len(o_idx)], o_idx)
+            v, o = got[name], res[tag][0][name]
+            rel = abs(v - o) / max(abs(o), 1e-2)
+            print("   %-12s rows %s as %-4s: product %.6f  %s %.6f  rel %.3e" % (name, "SAME" if same else "differ", tag, v, tag, o, rel))
+            if same and rel > FP8_LOSS_SAME_ROWS[tag]:
+                bad.append((name, tag, v, o, rel))
     # the refinement losses share one mechanism (pseudo-GT mining on noisy scores): their bf/fp8 effect is estimated as
     # a group - the largest |emu - fp32| among them - because a single pair of draws can be close by chance
     branch = [k for k in got if k != "loss_cls"]

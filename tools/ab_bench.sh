@@ -1,11 +1,13 @@
 #!/bin/bash
-# A/B of bench.py variants on ONE box (same process sequence, 300 steps each): tools/ab_bench.sh out.txt "args1" "args2" ...
-out=$1; shift
-: > $out
-for a in "$@"; do
-  python bench.py --no-cpu-baseline --steps 300 --no-launch-timing $a 2>/dev/null | python -c "
-import sys, json
-d = json.loads(sys.stdin.read().strip().splitlines()[-1])
-print('%-50s %7.1f img/s  %.4f ms/step  host %.3f (unblocked %.3f)' % ('$a', d['value'], d['ms_per_step'], d['host_enqueue_ms_per_step'], d.get('host_ms_per_step_unblocked') or 0))" >> $out 2>&1
+# interleaved A/B of bench.py argument sets on one box: tools/ab_bench.sh <rounds> <steps> "<args A>" "<args B>" ...
+rounds=$1; steps=$2; shift 2
+for r in $(seq $rounds); do
+  i=0
+  for a in "$@"; do
+    python bench.py --steps $steps --no-cpu-baseline $a 2>/dev/null | tail -1 | python -c "
+import sys,json
+d=json.loads(sys.stdin.readline()); rs=d['roofline_step']
+print('[%d] %-40s %.1f img/s  %.4f ms  dominant %.0f TF' % ($i, '''$a''', d['value'], d['ms_per_step'], rs.get('dominant_kernel_tflops_in_step', 0)))"
+    i=$((i+1))
+  done
 done
-cat $out
