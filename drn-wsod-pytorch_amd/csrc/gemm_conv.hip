@@ -57,6 +57,7 @@ struct ConvParams {
   // fp8, fp8 -> bf16 feature map), and an fp8 residual carries its own per-tensor scale (res_mult = s_out / s_res)
   int out_dt, res_dt;
   float res_mult;
+  int fp8_k64;  // fp8 operands: 1 = the K = 64 scaled MFMA (fp8 rate), 0 = the K = 16 form (DRN_TUNE_FP8_K64)
 };
 
 template <int DT>
@@ -78,6 +79,21 @@ __device__ __forceinline__ void mma_step(f32x16_t& acc, const i32x4_t& a, const 
     for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[e], bf[e], acc, 0, 0, 0);
   }
 }
+
+// fp8 at the fp8 RATE (round 3): v_mfma_scale_f32_32x32x64_f8f6f4 with both formats e4m3 and unit E8M0 scales (0x7f = 2^0),
+// the only K = 64 fp8 MFMA on gfx950 - the non-scaled 32x32x16 form above runs at the bf16 rate (MI355X_MICROARCH.md,
+// matrix-core table).  A lane's 32 operand bytes are two 16-byte fragments of consecutive k-steps; A and B use the same
+// (lane half, byte) -> k assignment, so whatever the hardware's assignment is, it is a permutation of the contraction
+// index, and fp8 x fp8 products are exact in fp32 (4-bit significands): only the fp32 summation order differs from the
+// K = 16 form.
+typedef int i32x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void mma_step64_fp8(f32x16_t& acc, const i32x4_t& a0, const i32x4_t& a1, const i32x4_t& b0,
+                                               const i32x4_t& b1) {
+  const i32x8_t A = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+  const i32x8_t B = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+  acc = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, acc, 0, 0, 0, 0x7f7f7f7f, 0, 0x7f7f7f7f);
+}
+static int g_fp8_k64 = 1;  // drn_tune(DRN_TUNE_FP8_K64 = 13): 0 = the K = 16 non-scaled fp8 MFMA (A/B; bf16 rate)
 
 __device__ __forceinline__ int swz(int row, int slot) { return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4); }
 
@@ -187,7 +203,7 @@ __device__ __forceinline__ void static_for(F&& f) {
 // branches and put `s_waitcnt vmcnt(0)` in front of every LDS store - it waited for the loads issued in the SAME
 // iteration, i.e. the ring prefetched one slab ahead whatever its depth (which is why ring depth 3 / 4 / 5 all measured
 // ~0.55 us per slab).  Branch-free, the waits become counted (vmcnt = loads of the DEPTH - 1 younger slabs).
-template <int DT, int BM, int BN, class ALoader, class BLoader, int STAGES = 2>
+template <int DT, int BM, int BN, class ALoader, class BLoader, int STAGES = 2, bool K64 = true>
 __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char* smem, ALoader& la,
                                          const BLoader& lb, int s0, int s1, int tid = threadIdx.x) {
   // tid: 0..255 within the four waves that share this tile's LDS stage (conv_nhwc_k2_kernel runs two such groups)
@@ -217,6 +233,34 @@ __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char
       la.template load<BM>(ra[d], s0 + i + DEPTH, tid);
       lb.template load<BN>(rb[d], s0 + i + DEPTH, tid);
     }
+    if constexpr (DT == DRN_FP8 && K64) {  // two k-steps per MFMA (K = 64 scaled form: the fp8 rate)
+#pragma unroll
+      for (int k2 = 0; k2 < 2; ++k2) {
+        i32x4_t fa[2][MI], fb[2][NJ];
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int slot = (k2 * 2 + h) * 2 + (lane >> 5);
+#pragma unroll
+          for (int ii = 0; ii < MI; ++ii)
+            fa[h][ii] = *(const i32x4_t*)(cur + swz(wm * (BM / 2) + ii * 32 + (lane & 31), slot));
+#pragma unroll
+          for (int j = 0; j < NJ; ++j)
+            fb[h][j] = *(const i32x4_t*)(cur + A_BYTES + swz(wn * (BN / 2) + j * 32 + (lane & 31), slot));
+        }
+#pragma unroll
+        for (int ii = 0; ii < MI; ++ii)
+#pragma unroll
+          for (int j = 0; j < NJ; ++j) mma_step64_fp8(acc[ii][j], fa[0][ii], fa[1][ii], fb[0][j], fb[1][j]);
+      }
+      // keep a slab's MFMAs in the slab (an empty volatile asm that "uses" the accumulators): left alone, the compiler
+      // sinks the register-only K = 64 MFMAs out of their blocks to the end of the unrolled slab group and holds every
+      // slab's fragments live until then (208 VGPRs for the 64x64 tile instead of ~120: no longer co-resident with a
+      // 256x256 GEMM workgroup)
+#pragma unroll
+      for (int ii = 0; ii < MI; ++ii)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j) asm volatile("" : "+v"(acc[ii][j]));
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
       i32x4_t fa[MI], fb[NJ];
@@ -230,6 +274,7 @@ __device__ __forceinline__ void mainloop(f32x16_t (&acc)[BM / 64][BN / 64], char
       for (int ii = 0; ii < MI; ++ii)
 #pragma unroll
         for (int j = 0; j < NJ; ++j) mma_step<DT>(acc[ii][j], fa[ii], fb[j]);
+    }
     }
     if (STAGES == 1) __syncthreads();  // every wave is done reading the only stage
     if (FULL || i + 1 < n) {
@@ -1054,6 +1099,53 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
 // Epilogue of the tiled conv kernels: per-channel affine (+ residual, ReLU) and the store.  `tid` = 0..255 within the
 // four waves that own the accumulators; `active` = false for waves that only take part in the barriers (the second
 // K-group of conv_nhwc_k2_kernel, whose partial sums were already added in).
+// 8 consecutive channels of one pixel, packed: bf16 = 16 bytes, fp8 = 8 bytes (the vector epilogues below)
+__device__ __forceinline__ bool vec8_ok(int dt, const void* ptr, long ld) {
+  return dt == DRN_BF16 ? ((ld & 7) == 0 && (((uintptr_t)ptr) & 15) == 0)
+                        : dt == DRN_FP8 ? ((ld & 7) == 0 && (((uintptr_t)ptr) & 7) == 0) : false;
+}
+__device__ __forceinline__ i32x4_t load8(int dt, const char* base, long elem) {
+  if (dt == DRN_BF16) return *(const i32x4_t*)(base + elem * 2);
+  const uint2 v = *(const uint2*)(base + elem);
+  return i32x4_t{(int)v.x, (int)v.y, 0, 0};
+}
+__device__ __forceinline__ void add8(int dt, const i32x4_t& rv, float mult, float (&v)[8]) {
+  if (dt == DRN_BF16) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t w = (uint32_t)rv[e];
+      v[2 * e] += __builtin_bit_cast(float, w << 16) * mult;
+      v[2 * e + 1] += __builtin_bit_cast(float, w & 0xffff0000u) * mult;
+    }
+  } else {
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      v[4 * e] += __builtin_amdgcn_cvt_f32_fp8(rv[e], 0) * mult;
+      v[4 * e + 1] += __builtin_amdgcn_cvt_f32_fp8(rv[e], 1) * mult;
+      v[4 * e + 2] += __builtin_amdgcn_cvt_f32_fp8(rv[e], 2) * mult;
+      v[4 * e + 3] += __builtin_amdgcn_cvt_f32_fp8(rv[e], 3) * mult;
+    }
+  }
+}
+__device__ __forceinline__ void store8(int dt, char* base, long elem, const float (&v)[8]) {
+  if (dt == DRN_BF16) {
+    i32x4_t o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) o[e] = (int)((uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16));
+    *(i32x4_t*)(base + elem * 2) = o;
+  } else {  // saturating RNE like f32_to_fp8, two values per v_cvt_pk_fp8_f32
+    float c[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) c[e] = fminf(fmaxf(v[e], -448.f), 448.f);
+    uint2 o;
+    int w = __builtin_amdgcn_cvt_pk_fp8_f32(c[0], c[1], 0, false);
+    o.x = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c[2], c[3], w, true);
+    w = __builtin_amdgcn_cvt_pk_fp8_f32(c[4], c[5], 0, false);
+    o.y = (uint32_t)__builtin_amdgcn_cvt_pk_fp8_f32(c[6], c[7], w, true);
+    *(uint2*)(base + elem) = o;
+  }
+}
+
 template <int DT, int BM, int BN>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&acc)[BM / 64][BN / 64], char* smem, int bm,
                                               int bn, int Mtot, int tid, bool active) {
@@ -1065,9 +1157,10 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
   // whole 128/256-byte row segments per instruction.  The MFMA layout gives a lane ONE channel of 16 * MI pixels: written
   // straight from the accumulators that is 2-byte accesses, which ran the write-heavy 1x1 convs of large maps at
   // ~1 TB/s (res2 conv3 at 200 x 304: 72 us for 70 MB; tools/conv_bench.py).  Same arithmetic, same rounding.
-  const bool vec_epi = p.out_dt == DRN_BF16 && (!p.residual || p.res_dt == DRN_BF16) && (p.Cout & 7) == 0 &&
-                       (p.ldy & 7) == 0 && (((uintptr_t)p.Y) & 15) == 0 &&
-                       (!p.residual || ((p.ldres & 7) == 0 && (((uintptr_t)p.residual) & 15) == 0));
+  // (round 3: fp8 outputs / residuals take the same path with 8-byte accesses - written from the accumulators an fp8
+  // layer stores single BYTES)
+  const bool vec_epi = (p.Cout & 7) == 0 && vec8_ok(p.out_dt, p.Y, p.ldy) &&
+                       (!p.residual || vec8_ok(p.res_dt, p.residual, p.ldres));
   if (vec_epi) {
     float* tile = (float*)smem;
     __syncthreads();  // the last slab's LDS reads are done
@@ -1097,7 +1190,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
 #pragma unroll
       for (int q = 0; q < NR; ++q) {
         const int m = bm + rl + q * RPP;
-        rv[q] = *(const i32x4_t*)((const bf16_t*)p.residual + (long)(m < Mtot ? m : Mtot - 1) * p.ldres + n);
+        rv[q] = load8(p.res_dt, p.residual, (long)(m < Mtot ? m : Mtot - 1) * p.ldres + n);
       }
     }
 #pragma unroll
@@ -1106,18 +1199,12 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
       if (m >= Mtot) break;
       const f32x4_t lo = *(const f32x4_t*)(tile + ml * BN + cl * 8), hi = *(const f32x4_t*)(tile + ml * BN + cl * 8 + 4);
       float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-      i32x4_t o;
+      if (p.residual) add8(p.res_dt, rv[q], p.res_mult, v);
+      if (p.relu) {
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        if (p.residual) {
-          const uint32_t w = (uint32_t)rv[q][e];
-          v[2 * e] += __builtin_bit_cast(float, w << 16) * p.res_mult;
-          v[2 * e + 1] += __builtin_bit_cast(float, w & 0xffff0000u) * p.res_mult;
-        }
-        if (p.relu) { v[2 * e] = fmaxf(v[2 * e], 0.f); v[2 * e + 1] = fmaxf(v[2 * e + 1], 0.f); }
-        o[e] = (int)((uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16));
+        for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
       }
-      *(i32x4_t*)((bf16_t*)p.Y + (long)m * p.ldy + n) = o;
+      store8(p.out_dt, p.Y, (long)m * p.ldy + n, v);
     }
     return;
   }
@@ -1162,8 +1249,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16_t (&ac
   }
 }
 
-template <int DT, int BM, int BN>
-__global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
+template <int DT, int BM, int BN, bool K64 = true>
+__global__ __launch_bounds__(256, (DT == DRN_FP8 && K64 && BM == 128) ? 2 : 1) void conv_nhwc_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = EsOf<DT>::value;
   constexpr int MI = BM / 64, NJ = BN / 64;
@@ -1198,7 +1285,7 @@ __global__ __launch_bounds__(256) void conv_nhwc_kernel(ConvParams p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
   const int nslab = (p.Ktot * ES + 127) / 128;
-  mainloop<DT, BM, BN, decltype(la), decltype(lb), (BM == 64 && BN == 64) ? 1 : 2>(acc, smem, la, lb, 0, nslab);
+  mainloop<DT, BM, BN, decltype(la), decltype(lb), (BM == 64 && BN == 64) ? 1 : 2, K64>(acc, smem, la, lb, 0, nslab);
   conv_epilogue<DT, BM, BN>(p, acc, smem, bm, bn, Mtot, threadIdx.x, true);
 }
 
@@ -1377,7 +1464,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
 // its own 16-KB LDS stage with its own register ring - twice the loads in flight and twice the MFMA issue per tile, the
 // operand bytes of the 64x64 tiling - and group 1's partial tile is added to group 0's through LDS (fixed order) in
 // front of the common epilogue.  Needs an even slab count; chosen on ONE image's geometry like the other variants.
-template <int DT>
+template <int DT, bool K64 = true>
 __global__ __launch_bounds__(512) void conv_nhwc_k2_kernel(ConvParams p) {  // (forcing 128 VGPRs for two workgroups per CU: 8 B of scratch, res4 layers 3 % slower, not kept)
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x 16 KB
   constexpr int ES = EsOf<DT>::value;
@@ -1409,7 +1496,8 @@ __global__ __launch_bounds__(512) void conv_nhwc_k2_kernel(ConvParams p) {  // (
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
   const int half = ((p.Ktot * ES + 127) / 128) >> 1;  // launcher: the slab count is even
-  mainloop<DT, 64, 64, decltype(la), decltype(lb), 1>(acc, smem + g * (128 * 128), la, lb, g * half, (g + 1) * half, tid);
+  mainloop<DT, 64, 64, decltype(la), decltype(lb), 1, K64>(acc, smem + g * (128 * 128), la, lb, g * half, (g + 1) * half,
+                                                           tid);
   // group 1's partial tile -> LDS (its own stage: nobody reads it any more), added by group 0 lane for lane
   const int lane = tid & 63, wave = tid >> 6;
   float* part = (float*)(smem + 128 * 128) + wave * 1024 + lane;
@@ -1433,7 +1521,7 @@ __global__ __launch_bounds__(512) void conv_nhwc_k2_kernel(ConvParams p) {  // (
 // 3 x 3 conv took 23 us on 196 pixels.  Here the chain per slab is a quarter of that and there are 4x the workgroups.
 // (Splitting K over workgroups instead - partial tiles in HBM, last arriver reduces - was built and measured slower
 // than no split: the cross-XCD coherence of the partials costs more than the split saves)
-template <int DT>
+template <int DT, bool K64 = true>
 __global__ __launch_bounds__(256) void conv_nhwc_ks_kernel(ConvParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * 32 * 32 * 4];  // one 8-KB operand stage, then 4 partial tiles
   constexpr int ES = EsOf<DT>::value;
@@ -1482,9 +1570,20 @@ __global__ __launch_bounds__(256) void conv_nhwc_ks_kernel(ConvParams p) {
       la.template load<32>(ra[d], i + DEPTH, tid);
       lb.template load<32>(rb[d], i + DEPTH, tid);
     }
-    const i32x4_t fa = *(const i32x4_t*)(smem + swz(lane & 31, slot));
-    const i32x4_t fb = *(const i32x4_t*)(smem + 32 * 128 + swz(lane & 31, slot));
-    mma_step<DT>(acc, fa, fb);
+    if constexpr (DT == DRN_FP8 && K64) {
+      // K = 64 scaled MFMA: waves 0 / 1 multiply the two halves of the slab (k-steps 2w, 2w + 1), waves 2 / 3 add zeros
+      if (wave < 2) {
+        const int s2 = wave * 4 + (lane >> 5);
+        const i32x4_t fa0 = *(const i32x4_t*)(smem + swz(lane & 31, s2)), fa1 = *(const i32x4_t*)(smem + swz(lane & 31, s2 + 2));
+        const i32x4_t fb0 = *(const i32x4_t*)(smem + 32 * 128 + swz(lane & 31, s2));
+        const i32x4_t fb1 = *(const i32x4_t*)(smem + 32 * 128 + swz(lane & 31, s2 + 2));
+        mma_step64_fp8(acc, fa0, fa1, fb0, fb1);
+      }
+    } else {
+      const i32x4_t fa = *(const i32x4_t*)(smem + swz(lane & 31, slot));
+      const i32x4_t fb = *(const i32x4_t*)(smem + 32 * 128 + swz(lane & 31, slot));
+      mma_step<DT>(acc, fa, fb);
+    }
     __syncthreads();
     if (FULL || i + 1 < n) {
       lds_store_tile<32>(smem, ra[(d + 1) % DEPTH], tid);
@@ -1508,15 +1607,14 @@ __global__ __launch_bounds__(256) void conv_nhwc_ks_kernel(ConvParams p) {
     part[(wave * 32 + ml) * 32 + (lane & 31)] = acc[r];
   }
   __syncthreads();
-  const bool vec_epi = p.out_dt == DRN_BF16 && (!p.residual || p.res_dt == DRN_BF16) && (p.Cout & 7) == 0 &&
-                       (p.ldy & 7) == 0 && (((uintptr_t)p.Y) & 15) == 0 &&
-                       (!p.residual || ((p.ldres & 7) == 0 && (((uintptr_t)p.residual) & 15) == 0));
+  const bool vec_epi = (p.Cout & 7) == 0 && vec8_ok(p.out_dt, p.Y, p.ldy) &&
+                       (!p.residual || vec8_ok(p.res_dt, p.residual, p.ldres));
   if (vec_epi) {  // 128 lanes: one pixel row x 8 channels each (see conv_nhwc_kernel)
     if (tid >= 128) return;
     const int ml = tid >> 2, cg = tid & 3, m = bm + ml, nn = bn + cg * 8;
     if (m >= Mtot || nn >= p.Cout) return;
     i32x4_t rv = {0, 0, 0, 0};
-    if (p.residual) rv = *(const i32x4_t*)((const bf16_t*)p.residual + (long)m * p.ldres + nn);
+    if (p.residual) rv = load8(p.res_dt, p.residual, (long)m * p.ldres + nn);
     float v[8];
 #pragma unroll
     for (int e = 0; e < 8; ++e) {
@@ -1524,18 +1622,12 @@ __global__ __launch_bounds__(256) void conv_nhwc_ks_kernel(ConvParams p) {
       const float sum = ((part[o] + part[1024 + o]) + part[2048 + o]) + part[3072 + o];
       v[e] = sum * (p.scale ? p.scale[nn + e] : 1.f) + (p.bias ? p.bias[nn + e] : 0.f);
     }
-    i32x4_t o4;
+    if (p.residual) add8(p.res_dt, rv, p.res_mult, v);
+    if (p.relu) {
 #pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      if (p.residual) {
-        const uint32_t w = (uint32_t)rv[e];
-        v[2 * e] += __builtin_bit_cast(float, w << 16) * p.res_mult;
-        v[2 * e + 1] += __builtin_bit_cast(float, w & 0xffff0000u) * p.res_mult;
-      }
-      if (p.relu) { v[2 * e] = fmaxf(v[2 * e], 0.f); v[2 * e + 1] = fmaxf(v[2 * e + 1], 0.f); }
-      o4[e] = (int)((uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16));
+      for (int e = 0; e < 8; ++e) v[e] = fmaxf(v[e], 0.f);
     }
-    *(i32x4_t*)((bf16_t*)p.Y + (long)m * p.ldy + nn) = o4;
+    store8(p.out_dt, p.Y, (long)m * p.ldy + nn, v);
     return;
   }
 #pragma unroll
@@ -1646,11 +1738,11 @@ static long g_conv_patch_min = 32768;
 static int g_conv_k2_tiles = -1;  // drn_tune(DRN_TUNE_CONV_K2_TILES): largest 64x64-tile count of ONE image for the two-K-group kernel (-1 = 2 x CUs, 0 = off)
 static int g_conv_ks_tiles = 0;  // drn_tune(DRN_TUNE_CONV_KS_TILES): largest 64x64-tile count of ONE image that still takes it (0 = CUs / 4)
 
-template <int DT>
+template <int DT, bool K64 = true>
 int launch_conv_ks(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
   const int tiles = ((Mtot + 31) / 32) * ((p.Cout + 31) / 32);
-  hipLaunchKernelGGL((conv_nhwc_ks_kernel<DT>), dim3(tiles), dim3(256), 0, st, p);
+  hipLaunchKernelGGL((conv_nhwc_ks_kernel<DT, K64>), dim3(tiles), dim3(256), 0, st, p);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }
@@ -1672,21 +1764,21 @@ static int launch_conv3x3_c64(const ConvParams& p, hipStream_t st) {
   return DRN_OK;
 }
 
-template <int DT>
+template <int DT, bool K64 = true>
 int launch_conv_k2(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
   const int tiles = ((Mtot + 63) / 64) * ((p.Cout + 63) / 64);
-  hipLaunchKernelGGL((conv_nhwc_k2_kernel<DT>), dim3(tiles), dim3(512), 2 * 128 * 128, st, p);
+  hipLaunchKernelGGL((conv_nhwc_k2_kernel<DT, K64>), dim3(tiles), dim3(512), 2 * 128 * 128, st, p);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }
 
-template <int DT, int BM, int BN>
+template <int DT, int BM, int BN, bool K64 = true>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
   const int tiles = ((Mtot + BM - 1) / BM) * ((p.Cout + BN - 1) / BN);
   constexpr int smem = ((BM == 64 && BN == 64) ? 1 : 2) * (BM + BN) * 128;
-  auto k = conv_nhwc_kernel<DT, BM, BN>;
+  auto k = conv_nhwc_kernel<DT, BM, BN, K64>;
   static bool attr = false;
   if (!attr && smem > 48 * 1024) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -1769,6 +1861,11 @@ int drn_tune(int knob, int value) {
   if (knob == 12) {  // DRN_TUNE_GEMM_PINGPONG
     const int old = g_pingpong;
     g_pingpong = value < 0 ? 0 : value;
+    return old;
+  }
+  if (knob == 13) {  // DRN_TUNE_FP8_K64
+    const int old = g_fp8_k64;
+    g_fp8_k64 = value != 0;
     return old;
   }
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
@@ -1895,7 +1992,7 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   const int Ktot = KH * KW * Cin;
   if (ldw * es < ((Ktot * es + 127) / 128) * 128) return DRN_ERR_ARG;  // weight rows zero-padded to 128-B slabs
   ConvParams p{(const char*)x, (const char*)w, (char*)y, scale, bias, (const char*)residual, Nb, H, W, Cin, Ho, Wo,
-               Cout, KH, KW, stride, pad, dil, relu, Ktot, ldw, ldy, ldres, out_dtype, res_dtype, res_mult};
+               Cout, KH, KW, stride, pad, dil, relu, Ktot, ldw, ldy, ldres, out_dtype, res_dtype, res_mult, g_fp8_k64};
   hipStream_t st = (hipStream_t)stream;
   const long Mtot = (long)Nb * Ho * Wo;
   const bool small = ((Mtot + 127) / 128) * ((Cout + 127) / 128) < 128;
@@ -1921,16 +2018,21 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   const long k2_max = g_conv_k2_tiles >= 0 ? g_conv_k2_tiles : cu_count();
   if ((nslab & 1) == 0 && nslab >= 8 && tiles64 > cu_count() / 4 && tiles64 <= k2_max && Nb <= 64)
     return dtype == DRN_BF16 ? launch_conv_k2<DRN_BF16>(p, st)
-           : dtype == DRN_FP8 ? launch_conv_k2<DRN_FP8>(p, st) : launch_conv_k2<DRN_F32>(p, st);
+           : dtype == DRN_FP8 ? (p.fp8_k64 ? launch_conv_k2<DRN_FP8>(p, st) : launch_conv_k2<DRN_FP8, false>(p, st))
+                              : launch_conv_k2<DRN_F32>(p, st);
   if (g_conv_ksplit && tiles64 <= ks_max && nslab >= 8 && Nb <= 64)
     return dtype == DRN_BF16 ? launch_conv_ks<DRN_BF16>(p, st)
-           : dtype == DRN_FP8 ? launch_conv_ks<DRN_FP8>(p, st) : launch_conv_ks<DRN_F32>(p, st);
+           : dtype == DRN_FP8 ? (p.fp8_k64 ? launch_conv_ks<DRN_FP8>(p, st) : launch_conv_ks<DRN_FP8, false>(p, st))
+                              : launch_conv_ks<DRN_F32>(p, st);
   if (dtype == DRN_BF16)
     return small ? launch_conv<DRN_BF16, 64, 64>(p, st)
                  : narrow ? launch_conv<DRN_BF16, 128, 64>(p, st) : launch_conv<DRN_BF16, 128, 128>(p, st);
-  if (dtype == DRN_FP8)
+  if (dtype == DRN_FP8 && p.fp8_k64)
     return small ? launch_conv<DRN_FP8, 64, 64>(p, st)
                  : narrow ? launch_conv<DRN_FP8, 128, 64>(p, st) : launch_conv<DRN_FP8, 128, 128>(p, st);
+  if (dtype == DRN_FP8)
+    return small ? launch_conv<DRN_FP8, 64, 64, false>(p, st)
+                 : narrow ? launch_conv<DRN_FP8, 128, 64, false>(p, st) : launch_conv<DRN_FP8, 128, 128, false>(p, st);
   return small ? launch_conv<DRN_F32, 64, 64>(p, st)
                : narrow ? launch_conv<DRN_F32, 128, 64>(p, st) : launch_conv<DRN_F32, 128, 128>(p, st);
 }

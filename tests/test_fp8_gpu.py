@@ -43,8 +43,25 @@ def _quant(t, s):
 @pytest.mark.parametrize("N,H,W,cin,cout,k,pad,dil,res,relu,out", [
     (1, 14, 14, 64, 64, 3, 1, 1, False, True, "fp8"), (2, 14, 14, 256, 1024, 1, 0, 1, True, True, "fp8"),
     (1, 28, 28, 128, 128, 3, 2, 2, False, True, "fp8"), (1, 56, 56, 64, 256, 1, 0, 1, False, False, "fp8"),
-    (2, 14, 14, 256, 1024, 1, 0, 1, True, True, "bf16"), (1, 112, 112, 64, 64, 3, 1, 1, False, True, "fp8")])
-def test_conv_fp8(drn, N, H, W, cin, cout, k, pad, dil, res, relu, out):
+    (2, 14, 14, 256, 1024, 1, 0, 1, True, True, "bf16"), (1, 112, 112, 64, 64, 3, 1, 1, False, True, "fp8"),
+    # round 3: the 128x128 / 128x64 tiles and the two-K-group kernel at real-size maps, fp8 residual through the vector
+    # epilogue (8-byte loads / stores), a bf16 residual into an fp8 output
+    (1, 100, 152, 64, 256, 1, 0, 1, True, True, "fp8"), (1, 100, 152, 256, 64, 1, 0, 1, False, True, "fp8"),
+    (1, 50, 76, 128, 128, 3, 1, 1, False, True, "fp8"), (1, 50, 76, 512, 128, 1, 0, 1, True, False, "fp8bf16res")])
+@pytest.mark.parametrize("k64", [1, 0])
+def test_conv_fp8(drn, N, H, W, cin, cout, k, pad, dil, res, relu, out, k64):
+    """k64 = 1: v_mfma_scale_f32_32x32x64_f8f6f4 (the fp8 rate, round 3); 0: the K = 16 non-scaled form.  Both multiply
+    exactly, so both sit within fp32 summation order of the fp64-free reference."""
+    bf_res = out == "fp8bf16res"
+    out = "fp8" if bf_res else out
+    old = drn.tune(drn.TUNE_FP8_K64, k64)
+    try:
+        _conv_fp8_case(drn, N, H, W, cin, cout, k, pad, dil, res, relu, out, bf_res)
+    finally:
+        drn.tune(drn.TUNE_FP8_K64, old)
+
+
+def _conv_fp8_case(drn, N, H, W, cin, cout, k, pad, dil, res, relu, out, bf_res):
     rs = np.random.RandomState(3)
     x = torch.from_numpy(np.abs(rs.standard_normal((N, H, W, cin))).astype(np.float32))
     w = torch.from_numpy((rs.standard_normal((cout, cin, k, k)) / np.sqrt(cin * k * k)).astype(np.float32))
@@ -59,8 +76,8 @@ def test_conv_fp8(drn, N, H, W, cin, cout, k, pad, dil, res, relu, out):
     r_q = None
     if res:
         r = torch.from_numpy(rs.standard_normal(tuple(ref.permute(0, 2, 3, 1).shape)).astype(np.float32))
-        s_r = 448.0 / float(r.abs().max())
-        r_q = _quant(r, s_r)
+        s_r = 1.0 if bf_res else 448.0 / float(r.abs().max())
+        r_q = r.to(torch.bfloat16) if bf_res else _quant(r, s_r)
         ref = ref + (r_q.float() / s_r).permute(0, 3, 1, 2)
     if relu:
         ref = F.relu(ref)

@@ -1,7 +1,9 @@
 """Per-layer timing of the trunk's conv kernel on the WS-ResNet50 C4 layer shapes (FrozenBN affine + ReLU / residual
 epilogue as in the model), stand-alone: each layer is replayed 20x from a hipGraph so launch gaps do not count.
 Reports us, TFLOP/s and the algorithmic HBM rate (input + weights + output + residual, once each).
-  python tools/conv_bench.py [H W]      (image size; default 800 1216)"""
+  python tools/conv_bench.py [H W]      (image size; default 800 1216)
+CONV_DTYPE=fp8: the fp8 trunk's layers (drn_conv2d_nhwc_q: fp8 x / w / y / residual), TFLOP/s against the 5 PFLOP/s dense
+fp8 peak; CONV_FP8_K64=0 runs them on the K = 16 non-scaled MFMA (round 2's path) for the A/B."""
 import importlib
 import os
 import sys
@@ -14,7 +16,11 @@ from __graft_entry__ import load_package
 load_package()
 ops = importlib.import_module("drn_wsod_pytorch_amd.ops")
 H, W = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (800, 1216)
-dt = torch.bfloat16
+FP8 = os.environ.get("CONV_DTYPE", "bf16") == "fp8"
+dt = torch.float8_e4m3fn if FP8 else torch.bfloat16
+es = 1 if FP8 else 2
+if FP8:
+    ops.tune(ops.TUNE_FP8_K64, int(os.environ.get("CONV_FP8_K64", "1")))
 dev = "cuda"
 # (name, stride-of-map, cin, cout, k, residual, count per trunk)
 LAYERS = [("stem.conv2/3 3x3 64", 2, 64, 64, 3, False, 2),
@@ -36,7 +42,10 @@ for name, s, cin, cout, k, res, cnt in LAYERS:
     scale = torch.rand(cout, device=dev) + 0.5
     bias = torch.randn(cout, device=dev) * 0.1
     r = (torch.randn((1, h, w, cout), device=dev) * 0.5).to(dt) if res else None
-    f = lambda: ops.conv2d_nhwc(x, wt, cout, k, k, 1, k // 2, 1, scale, bias, r, True)
+    if FP8:
+        f = lambda: ops.conv2d_nhwc_q(x, wt, cout, k, k, 1, k // 2, 1, scale, bias, dt, r, 1.0, True)
+    else:
+        f = lambda: ops.conv2d_nhwc(x, wt, cout, k, k, 1, k // 2, 1, scale, bias, r, True)
     for _ in range(3):
         f()
     g = torch.cuda.CUDAGraph()
@@ -53,8 +62,9 @@ for name, s, cin, cout, k, res, cnt in LAYERS:
     torch.cuda.synchronize()
     us = a.elapsed_time(b) / 100 * 1e3
     gf = 2.0 * h * w * k * k * cin * cout / 1e9
-    mb = (h * w * (cin + cout * (2 if res else 1)) + k * k * cin * cout) * 2 / 1e6
+    mb = (h * w * (cin + cout * (2 if res else 1)) + k * k * cin * cout) * es / 1e6
     print("%-30s %9d %8.1f %8.1f %9.0f %8d" % (name, h * w, us, gf / us * 1e3, mb / us * 1e3, cnt))
     tot_us += us * cnt
     tot_gf += gf * cnt
-print("sum over the trunk's convs (stem.conv1 excluded): %.0f us, %.1f GF -> %.0f TFLOP/s" % (tot_us, tot_gf, tot_gf / tot_us * 1e3))
+print("sum over the trunk's convs (stem.conv1 excluded): %.0f us, %.1f GF -> %.0f TFLOP/s = %.3f of the dense %s MFMA peak" % (
+    tot_us, tot_gf, tot_gf / tot_us * 1e3, tot_gf / tot_us * 1e3 / (5000.0 if FP8 else 2500.0), "fp8" if FP8 else "bf16"))
