@@ -53,7 +53,22 @@ _SIGS = {
     "drn_csc_cpg": "piiiiippp",
     "drn_csc_weights": "piifpipiiifppp",
     "drn_csc_loss": "pliiiippppiiipplp",
+    "drn_trunk_shapes": "p" + "iiiiiiii" + "pp",
+    "drn_trunk_forward": "piiip" + "iiiii" + "p",
 }
+
+
+class DrnTrunkOp(ctypes.Structure):
+    """include/drn_wsod.h `DrnTrunkOp`, field for field"""
+    _fields_ = [("kind", ctypes.c_int), ("src", ctypes.c_int), ("dst", ctypes.c_int), ("res", ctypes.c_int),
+                ("w", ctypes.c_void_p), ("scale", ctypes.c_void_p), ("bias", ctypes.c_void_p),
+                ("cin", ctypes.c_int), ("cout", ctypes.c_int), ("ksize", ctypes.c_int), ("stride", ctypes.c_int),
+                ("pad", ctypes.c_int), ("dil", ctypes.c_int), ("relu", ctypes.c_int), ("ldw", ctypes.c_long),
+                ("dtype", ctypes.c_int), ("out_dtype", ctypes.c_int), ("res_dtype", ctypes.c_int),
+                ("res_mult", ctypes.c_float)]
+
+
+TRUNK_MAX_SLOTS = 16
 
 _lib = None
 

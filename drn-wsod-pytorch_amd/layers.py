@@ -210,6 +210,15 @@ class Conv2d(nn.Conv2d):
         y._drn_scale = q["out_scale"]
         return y
 
+    def _source_tensors(self):
+        """the tensors the packed compute copies are derived from (a launch plan re-checks their `_version`s)"""
+        pr = self._parameters
+        tens = [pr["weight"]] + ([pr["bias"]] if pr.get("bias") is not None else [])
+        n_ = self._modules.get("norm")
+        if n_ is not None:
+            tens += list(n_.parameters()) + list(n_.buffers())
+        return tens
+
     def packed(self, dtype):
         """(w [Cout, ldw] K-major with k = (kh*KW + kw)*Cin_pad + ci, scale [Cout], bias [Cout]) cached until
         a parameter / buffer changes (load_state_dict bumps _version)."""

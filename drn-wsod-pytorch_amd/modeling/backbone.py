@@ -7,10 +7,13 @@ BasicBlock :32-112, BottleneckBlock :115-237, ResNet :419-600) and `build_vgg_ba
 Execution is MI355X-first: every block runs NHWC, each conv is one implicit-GEMM MFMA launch with the
 FrozenBN affine + residual add + ReLU fused in its epilogue, pools are vectorised NHWC kernels; the
 [N,C,H,W] tensors returned by forward() are channels-last views of those buffers."""
+import ctypes
+
 import numpy as np
 import torch
 from torch import nn
 
+from .. import _cabi as C
 from .. import compute_dtype, ops
 from .._cabi import DrnError
 from ..layers import _DX_ONLY, dx_only, CNNBlockBase, Conv2d, FrozenBatchNorm2d, ShapeSpec, from_nhwc, get_norm, to_nhwc
@@ -43,8 +46,148 @@ def c2_msra_fill(module):
         nn.init.constant_(module.bias, 0)
 
 
+class _PlanBuilder:
+    """Records the trunk's layer sequence as `DrnTrunkOp`s (include/drn_wsod.h) over VALUES (one per layer output), then
+    maps the values to a handful of reusable activation slots by their last use.  The entries mirror what
+    Conv2d.run_nhwc / _run_fp8 and _pool pass to the per-layer entry points, so a plan issues the same launches."""
+
+    def __init__(self, in_dtype, in_channels):
+        self.vals = [dict(dtype=in_dtype, scale=1.0, c=in_channels)]  # value 0: the (normalised, padded) image
+        self.ops, self.keep, self.srcs = [], [], []
+
+    def conv(self, m, src, res=None, relu=False):
+        v = self.vals[src]
+        if m._fp8 is not None:
+            q = m._fp8
+            w, scale, bias, _ = m.packed_fp8(v["dtype"], v["scale"])
+            out_dtype, out_scale = q["out_dtype"], q["out_scale"]
+            res_mult = q["out_scale"] / self.vals[res]["scale"] if res is not None else 1.0
+        else:
+            w, scale, bias = m.packed(v["dtype"])
+            out_dtype, out_scale, res_mult = v["dtype"], 1.0, 1.0
+        if v["c"] != m.cin_pad(v["dtype"]):
+            raise DrnError("trunk plan: %d stored input channels, the conv expects %d" % (v["c"], m.cin_pad(v["dtype"])))
+        self.keep += [w, scale, bias]
+        self.srcs += m._source_tensors()
+        self.ops.append(dict(kind=0, src=src, res=-1 if res is None else res, w=C.ptr(w), scale=C.ptr(scale),
+                             bias=C.ptr(bias), cin=v["c"], cout=m.out_channels, ksize=m.kernel_size[0],
+                             stride=m.stride[0], pad=m.padding[0], dil=m.dilation[0], relu=int(bool(relu)),
+                             ldw=w.stride(0), dtype=C.dt(v["dtype"]), out_dtype=C.dt(out_dtype),
+                             res_dtype=C.dt(self.vals[res]["dtype"]) if res is not None else C.dt(out_dtype),
+                             res_mult=float(res_mult)))
+        self.vals.append(dict(dtype=out_dtype, scale=out_scale, c=m.out_channels))
+        return len(self.vals) - 1
+
+    def pool(self, src, stride):
+        v = self.vals[src]
+        self.ops.append(dict(kind=1, src=src, res=-1, w=None, scale=None, bias=None, cin=v["c"], cout=v["c"], ksize=2,
+                             stride=int(stride), pad=0, dil=1, relu=0, ldw=0, dtype=C.dt(v["dtype"]),
+                             out_dtype=C.dt(v["dtype"]), res_dtype=C.dt(v["dtype"]), res_mult=1.0))
+        self.vals.append(dict(v))
+        return len(self.vals) - 1
+
+    def finish(self, outputs):
+        """outputs: {feature name: value}.  Linear scan: a value's slot returns to the free list behind its last reader;
+        the image and the output features are never overwritten."""
+        last = {}
+        for i, o in enumerate(self.ops):
+            last[o["src"]] = i
+            if o["res"] >= 0:
+                last[o["res"]] = i
+        pinned = {0} | set(outputs.values())
+        slot_of, free, n_slots = {0: 0}, [], 1
+        arr = (C.DrnTrunkOp * max(len(self.ops), 1))()
+        for i, o in enumerate(self.ops):
+            dst_val = i + 1  # op i defines value i + 1
+            if free and dst_val not in pinned:  # an output feature owns its slot: it is sized for that feature alone
+                slot = free.pop()
+            else:
+                slot, n_slots = n_slots, n_slots + 1
+            slot_of[dst_val] = slot
+            a = arr[i]
+            for k, val in o.items():
+                if k in ("src", "res"):
+                    val = slot_of[val] if val >= 0 else -1
+                setattr(a, k, val)
+            a.dst = slot
+            for val in {o["src"], o["res"]} - {-1}:
+                if last.get(val) == i and val not in pinned:
+                    free.append(slot_of[val])
+            if dst_val not in last and dst_val not in pinned:  # never read (cannot happen in the built trunks)
+                free.append(slot)
+        if n_slots > C.TRUNK_MAX_SLOTS:
+            raise DrnError("trunk plan needs %d activation slots (> %d)" % (n_slots, C.TRUNK_MAX_SLOTS))
+        return dict(ops=arr, n_ops=len(self.ops), n_slots=n_slots, keep=self.keep, srcs=self.srcs,
+                    outputs={name: (slot_of[v], self.vals[v]["dtype"], self.vals[v]["scale"]) for name, v in outputs.items()},
+                    out_slots={slot_of[v] for v in outputs.values()})
+
+
 class Backbone(nn.Module):
     """detectron2/modeling/backbone/backbone.py."""
+
+    # ---- launch plan of the frozen trunk (csrc/executor.hip, round 3) ------------------------------------------------
+    # forward() of a trunk that keeps nothing for a backward pass is ONE drn_trunk_forward call instead of ~50 per-layer
+    # Python walks (the eager step on changing image shapes was bound by that host time).  `use_plan = False` keeps the
+    # per-layer path (A/B, and the test that pins plan == per-layer bit for bit).
+    use_plan = True
+
+    def _plan_emit(self, b, x):
+        """-> {feature name: value} (ResNet / VGG16 walk their units through b)"""
+        raise NotImplementedError
+
+    def _apply(self, fn, *a, **k):  # .to() / .cuda() / .float(): parameters and buffers may move
+        self.__dict__.pop("_plans", None)
+        return super()._apply(fn, *a, **k)
+
+    def _plan_for(self, dtype, cin):
+        convs = self.conv_modules()
+        cfg = tuple([id(m._fp8) for m in convs])
+        plans = self.__dict__.setdefault("_plans", {})
+        p = plans.get((dtype, cin))
+        if p is not None and p["cfg"] == cfg and p["versions"] == [t._version for t in p["srcs"]]:
+            return p
+        b = _PlanBuilder(dtype, cin)
+        p = b.finish(self._plan_emit(b, 0))
+        p["cfg"], p["versions"] = cfg, [t._version for t in p["srcs"]]
+        p["bytes"], p["hwc"] = (ctypes.c_long * p["n_slots"])(), (ctypes.c_int * (3 * p["n_slots"]))()
+        p["ptrs"], p["scratch"] = (ctypes.c_void_p * p["n_slots"])(), {}
+        plans[(dtype, cin)] = p
+        return p
+
+    def _run_plan(self, x_nhwc):
+        """x_nhwc: [N, H, W, Cpad] contiguous in the compute dtype -> {feature name: NHWC tensor}"""
+        n, h, w, c = x_nhwc.shape
+        p = self._plan_for(x_nhwc.dtype, c)
+        dt_in = C.dt(x_nhwc.dtype)
+        C.call("drn_trunk_shapes", p["ops"], p["n_ops"], p["n_slots"], 0, n, h, w, c, dt_in, p["bytes"], p["hwc"])
+        st = C.stream()
+        capturing = torch.cuda.is_current_stream_capturing()
+        # scratch slots: grow-only per stream (launches of one stream are ordered, so the next forward may overwrite
+        # them); under stream capture they are allocated inside the capture, where the graph's pool keeps them
+        scratch = None if capturing else p["scratch"].setdefault(st, {})
+        ptrs, outs, hold = p["ptrs"], {}, []
+        ptrs[0] = x_nhwc.data_ptr()
+        by_slot = {slot: (name, dtype, scale) for name, (slot, dtype, scale) in p["outputs"].items()}
+        for s_ in range(1, p["n_slots"]):
+            nb = p["bytes"][s_]
+            if s_ in by_slot:
+                name, dtype, scale = by_slot[s_]
+                y = torch.empty((n, p["hwc"][3 * s_], p["hwc"][3 * s_ + 1], p["hwc"][3 * s_ + 2]), dtype=dtype,
+                                device=x_nhwc.device)
+                if dtype == ops.FP8:
+                    y._drn_scale = scale
+                outs[name] = y
+                ptrs[s_] = y.data_ptr()
+            elif capturing:
+                hold.append(torch.empty((max(nb, 16),), dtype=torch.uint8, device=x_nhwc.device))
+                ptrs[s_] = hold[-1].data_ptr()
+            else:
+                buf = scratch.get(s_)
+                if buf is None or buf.numel() < nb:
+                    buf = scratch[s_] = torch.empty((max(nb, 16),), dtype=torch.uint8, device=x_nhwc.device)
+                ptrs[s_] = buf.data_ptr()
+        C.call("drn_trunk_forward", p["ops"], p["n_ops"], p["n_slots"], 0, ptrs, n, h, w, c, dt_in, st)
+        return outs
 
     @property
     def size_divisibility(self):
@@ -123,6 +266,10 @@ class BasicStem(CNNBlockBase):
         self._sv = (x, o1, o2, o3) if save else None
         return _pool(o3, 2)
 
+    def plan(self, b, x):
+        o3 = b.conv(self.conv3, b.conv(self.conv2, b.conv(self.conv1, x, relu=True), relu=True), relu=True)
+        return b.pool(o3, 2)
+
     def backward_nhwc(self, dy, need_dx, accumulate):
         """explicit backward of forward_nhwc(save=True); training needs no image gradient (need_dx False: conv1 has no
         dgrad), CSCROIHeads' class maps do (Backbone.input_gradient_nhwc)"""
@@ -167,6 +314,12 @@ class BasicBlock(CNNBlockBase):
         if self.has_pool:
             out = _pool(out, self.pool_stride)
         return out
+
+    def plan(self, b, x):
+        o1 = b.conv(self.conv1, x, relu=True)
+        sc = b.conv(self.shortcut, x) if self.shortcut is not None else x
+        out = b.conv(self.conv2, o1, res=sc, relu=True)
+        return b.pool(out, self.pool_stride) if self.has_pool else out
 
     def backward_nhwc(self, dy, need_dx, accumulate):
         x, o1, sc, out = self._sv
@@ -221,6 +374,12 @@ class BottleneckBlock(CNNBlockBase):
         if self.has_pool:
             out = _pool(out, self.pool_stride)
         return out
+
+    def plan(self, b, x):
+        o2 = b.conv(self.conv2, b.conv(self.conv1, x, relu=True), relu=True)
+        sc = b.conv(self.shortcut, x) if self.shortcut is not None else x
+        out = b.conv(self.conv3, o2, res=sc, relu=True)
+        return b.pool(out, self.pool_stride) if self.has_pool else out
 
     def backward_nhwc(self, dy, need_dx, accumulate):
         """torch.autograd of resnet_ws.py:217-237: pool -> relu(conv3 + shortcut) -> conv2 -> conv1, with the gradient
@@ -282,6 +441,9 @@ class ResNet(Backbone):
         self._all_units = units if keep_all else None
         assert len(self._out_features) == 1 or (self._bw_units is None and not keep_all), \
             "trainable trunk / image gradients: one output feature (as configured)"
+        if self.use_plan and self._bw_units is None and not keep_all and not getattr(self, "_calibrating", False):
+            with torch.no_grad():
+                return {k: from_nhwc(v) for k, v in self._run_plan(self._input_nhwc(x)).items()}
         with torch.no_grad():
             i = 0
             y = self.stem.forward_nhwc(self._input_nhwc(x), save=keep_all or (self._bw_units is not None and first == 0))
@@ -294,6 +456,18 @@ class ResNet(Backbone):
                 if name in self._out_features:
                     outputs[name] = from_nhwc(y)
         return outputs
+
+    def _plan_emit(self, b, x):
+        outs = {}
+        y = self.stem.plan(b, x)
+        if "stem" in self._out_features:
+            outs["stem"] = y
+        for stage, name in self.stages_and_names:
+            for block in stage:
+                y = block.plan(b, y)
+            if name in self._out_features:
+                outs[name] = y
+        return outs
 
     # ---- fp8 MFMA conv path (BASELINE configs[4]) -------------------------------------------------------------------
     def calibrate_fp8(self, images, margin=1.0):
@@ -312,9 +486,13 @@ class ResNet(Backbone):
         self.disable_fp8()
         for m in convs.values():
             m._calib_amax = 0.0
-        with torch.no_grad():
-            for x in images:
-                self.forward(x)
+        self._calibrating = True  # the per-layer walk records every conv's output range
+        try:
+            with torch.no_grad():
+                for x in images:
+                    self.forward(x)
+        finally:
+            self._calibrating = False
         last_block = self.stages_and_names[-1][0][-1]
         final = last_block.conv3 if hasattr(last_block, "conv3") else last_block.conv2
         scales = {}
@@ -446,6 +624,11 @@ class PlainBlock(nn.Module):
             x = ops.maxpool2x2_nhwc(x, self.pool_stride)
         return x
 
+    def plan(self, b, x):
+        for i in range(self.num_conv):
+            x = b.conv(getattr(self, "conv%d" % (i + 1)), x, relu=True)
+        return b.pool(x, self.pool_stride) if self.has_pool else x
+
     def backward_nhwc(self, dy, need_dx, accumulate):
         acts = self._sv
         d = _as(dy, acts[-1].dtype)
@@ -495,6 +678,9 @@ class VGG16(Backbone):
         self._bw_units = units[first:] if (save and first is not None) else None
         keep_all = save and self.input_grad
         self._all_units = units if keep_all else None
+        if self.use_plan and self._bw_units is None and not keep_all and not getattr(self, "_calibrating", False):
+            with torch.no_grad():
+                return {k: from_nhwc(v) for k, v in self._run_plan(self._input_nhwc(x)).items()}
         with torch.no_grad():
             y = self._input_nhwc(x)
             i = -1
@@ -505,6 +691,15 @@ class VGG16(Backbone):
                 if name in self._out_features:
                     outputs[name] = from_nhwc(y)
         return outputs
+
+    def _plan_emit(self, b, x):
+        outs = {}
+        for stage, name in self.stages_and_names:
+            for block in stage:
+                x = block.plan(b, x)
+            if name in self._out_features:
+                outs[name] = x
+        return outs
 
     backward_nhwc = ResNet.backward_nhwc
 

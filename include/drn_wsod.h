@@ -348,6 +348,39 @@ int drn_csc_loss(const float* logits, long ld, int c_cls, int c_det, int K, int 
                  const float* row_softmax, const float* W, const float* onehot, int mode, int cstar, int mean_loss,
                  float* loss, float* dlogits, long ld_d, void* stream);
 
+/* ---- launch plans (round 3): the frozen trunk's whole layer sequence in ONE call ----
+ * Replaces the per-layer Python walk of `ResNet.forward` / `BasicStem.forward` / `BottleneckBlock.forward` /
+ * `BasicBlock.forward` (projects/WSL/wsl/modeling/backbone/resnet_ws.py:479-502, :405-416, :217-237, :93-112) and
+ * `VGG16.forward` / `PlainBlock.forward` (vgg.py:213-231, :104-122) when nothing has to be kept for a backward pass.
+ * A plan is an array of ops over numbered activation SLOTS (buffers the caller owns; an op never writes its own input
+ * or residual slot).  Geometry per op follows from the input size; every op runs through drn_conv2d_nhwc_q /
+ * drn_maxpool2x2_nhwc, so the kernels, their selection and the results are those of the per-layer calls. */
+#define DRN_TRUNK_CONV 0
+#define DRN_TRUNK_MAXPOOL 1
+#define DRN_TRUNK_MAX_SLOTS 16
+typedef struct DrnTrunkOp {
+  int kind;           /* DRN_TRUNK_CONV | DRN_TRUNK_MAXPOOL */
+  int src, dst, res;  /* slot indices; res = -1: no residual (conv only) */
+  const void* w;      /* conv: packed weights [cout][ldw] as for drn_conv2d_nhwc_q */
+  const float* scale; /* per-cout affine (folded FrozenBN / quantisation scales) or NULL */
+  const float* bias;
+  int cin, cout, ksize, stride, pad, dil, relu; /* cin = stored channels of the input slot; pool: stride only */
+  long ldw;
+  int dtype, out_dtype, res_dtype; /* element types of x / w, of y, of the residual (pool: dtype) */
+  float res_mult;
+} DrnTrunkOp;
+
+/* Bytes every slot must hold for an [Nb, H, W, C0] input of element type in_dtype sitting in slot in_slot
+ * (slot_bytes[n_slots]; 0 for slots the plan never writes), and the (h, w, c) each slot holds when the plan ends
+ * (slot_hwc[3 * n_slots], may be NULL).  Host-only: launches nothing. */
+int drn_trunk_shapes(const DrnTrunkOp* ops_host, int n_ops, int n_slots, int in_slot, int Nb, int H, int W, int C0,
+                     int in_dtype, long* slot_bytes_host, int* slot_hwc_host);
+
+/* Enqueue the whole plan.  slots_host[n_slots]: device pointers (16-byte aligned), each at least as large as
+ * drn_trunk_shapes reported. */
+int drn_trunk_forward(const DrnTrunkOp* ops_host, int n_ops, int n_slots, int in_slot, void* const* slots_host, int Nb,
+                      int H, int W, int C0, int in_dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -159,6 +159,11 @@ def test_fp8_trunk_and_train_step_full_size():
         bf16_feat = model.backbone(model.preprocess_image(ins(batch)).tensor)["res4"].float().cpu()
         scales = model.backbone.calibrate_fp8([model.preprocess_image(ins(b)).tensor for b in calib])
         feat = model.backbone(model.preprocess_image(ins(batch)).tensor)["res4"].float().cpu()
+        # the launch plan of the fp8 trunk (csrc/executor.hip) against the per-layer walk it replaces: bit-identical
+        model.backbone.use_plan = False
+        walk = model.backbone(model.preprocess_image(ins(batch)).tensor)["res4"].float().cpu()
+        model.backbone.use_plan = True
+        assert torch.equal(feat, walk)
     assert all(np.isfinite(v) and v > 0 for v in scales.values()) and len(scales) == 45  # 3 stem + 13 blocks x 3 + 3 shortcuts
     last = [n for n, m in model.backbone.named_modules() if getattr(m, "_fp8", None) and m._fp8["out_dtype"] == torch.bfloat16]
     assert last == ["res4.5.conv3"]

@@ -1,4 +1,5 @@
-"""Inference (eval) pass of R50-C4 at TTA-like image sizes: wall time per image and the top kernels."""
+"""Inference (eval) pass of R50-C4 at TTA-like image sizes: wall time per image and the top kernels.
+INFER_SIZES="688x920,224x224" picks the sizes, INFER_PLAN=0 runs the trunk layer by layer instead of through its launch plan."""
 import os
 import sys
 import time
@@ -19,7 +20,9 @@ model = build_model(cfg)
 bench.init_weights(model, seed=0)
 model.eval()
 R = 2000
-for (H, W) in [(224, 224), (480, 640), (688, 920), (1200, 1600)]:
+model.backbone.use_plan = os.environ.get("INFER_PLAN", "1") == "1"
+SIZES = [tuple(int(v) for v in s.split("x")) for s in os.environ.get("INFER_SIZES", "224x224,480x640,688x920,1200x1600").split(",")]
+for (H, W) in SIZES:
     g = torch.Generator().manual_seed(1)
     img = torch.randint(0, 256, (3, H, W), generator=g).float().cuda()
     x0 = torch.rand(R, generator=g) * (W - 60)
