@@ -20,6 +20,7 @@ _SIGS = {
     "drn_conv2d_nhwc_q": "pppppp" + "iiiiiiiiii" + "lll" + "iiiifp",
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
+    "drn_roi_pool_nhwc_t": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiiip",
     "drn_tta_accumulate": "ppppllfffiip",
     "drn_pcl_adjacency": "pifpp",
     "drn_pcl_refine": "pipiipipppip" + "ppppppppppi" + "ppp",
@@ -31,6 +32,7 @@ _SIGS = {
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliiilip",
     "drn_gemm_nt_sgd": "ppiiilli" + "ppplp" + "fifp",
+    "drn_gemm_tn": "ppp" + "iiii" + "lll" + "iilip",
     "drn_gemm_set_tile": "i",
     "drn_tune": "ii",
     "drn_bias_act_fwd": "pilppQpfplpliiliip",

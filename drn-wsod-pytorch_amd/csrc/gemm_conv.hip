@@ -41,6 +41,9 @@ struct GemmParams {
   int c_bf16;  // C holds bf16 (gradient buckets that cross xGMI in bf16); splits == 1, no accumulate
   int nsplit;  // number of K-splits (the persistent kernel's grid is 1-D: it cannot read it from gridDim.y)
   int gm;      // tile rows per group of the XCD patch mapping (tile_coords)
+  // TN operand (drn_gemm_tn): B is given as Bt [kb_rows][ldb] row-major - the contraction index is the ROW index - and the
+  // 256x256 ping-pong kernels read it through transposing LDS reads (ds_read_b64_tr_b16); rows >= kb_rows read as zeros
+  int kb_rows;
 };
 
 struct ConvParams {
@@ -382,6 +385,21 @@ constexpr int PP_A0 = 0, PP_B0 = 16384, PP_B1 = 32768, PP_A1 = 49152, PP_STAGE =
 // per-thread source offsets of its two 16-byte chunks of every half tile (index = half * 2 + piece): the LDS image of a
 // half tile is row-major [128][128 B], piece `pc` of thread tid lands in LDS row pc * 64 + tid / 8, slot tid & 7, and
 // fetches the k-slot pre-swizzled with that row (same involution as the fragment reads)
+//
+// TN = true (round 3, the fc6 weight gradient reading the pooled matrix A [R][C*49] itself instead of a materialised A^T):
+// the B operand arrives as Bt [k][n] row-major and is consumed through ds_read_b64_tr_b16, which hands lane l the 4-element
+// COLUMN (l & 15) of a [4 k][16 n] block whose rows the 16 lanes of its group address freely, 8 bytes each.
+//   * Wave columns: wave wn owns the 32-column blocks wn of the tile's two 128-column halves (b0: n = wn * 32 .., b1:
+//     n = 128 + wn * 32 ..; the NT form owns 64 adjacent columns), so that the half tiles B0 / B1 of the staging order are
+//     whole 256-byte row segments of Bt.
+//   * LDS image of a half tile: 16 pieces of 1 KB, piece (k-step ks, quarter kq) = Bt rows ks * 16 + 4 * kq + j (j = 0..3)
+//     x 128 columns, row pitch 256 B, the 32-byte column units u of row j stored at u ^ 2j.  One LDS-DMA instruction
+//     fills one piece lane-linearly from four FULL 256-byte row segments (the first version fetched 16 rows x 64 bytes
+//     per instruction and ran the fc6 dW slab at 206 us against 178 us for the NT form).
+//   * A fragment half (k = 8 * (g >> 1) + 4 * i + j for lane group g) is one ds_read_b64_tr_b16: lanes 0-31 read piece
+//     kq = i, lanes 32-63 piece kq = 2 + i, each group its 4 rows x 32 bytes at unit (2 * wn + (g & 1)) ^ 2j - the 32 lanes
+//     of an LDS cycle cover 8 different units = all 64 banks once.
+template <bool TN = false>
 __device__ __forceinline__ void pp_offsets(unsigned lda_b, unsigned ldb_b, int tid, unsigned (&voa)[4], unsigned (&vob)[4]) {
 #pragma unroll
   for (int h = 0; h < 2; ++h)
@@ -389,15 +407,24 @@ __device__ __forceinline__ void pp_offsets(unsigned lda_b, unsigned ldb_b, int t
     for (int pc = 0; pc < 2; ++pc) {
       const unsigned row = pc * 64 + (tid >> 3), ks = (tid & 7) ^ ((row >> 1) & 7);
       const unsigned ga = pc * 128 + h * 64 + (tid >> 3);                             // A row: wave row pc, half h
-      const unsigned gb = (2 * pc + (tid >> 8)) * 64 + h * 32 + ((tid >> 3) & 31);    // B row: wave column 2 pc + tid / 256
       voa[h * 2 + pc] = ga * lda_b + ks * 16;
-      vob[h * 2 + pc] = gb * ldb_b + ks * 16;
+      if constexpr (TN) {
+        const unsigned L = tid & 63, wv = tid >> 6;          // piece f = pc * 8 + wave: (ks = f >> 2, kq = f & 3)
+        const unsigned ks_f = pc * 2 + (wv >> 2), kq_f = wv & 3;
+        const unsigned j = L >> 4, pos = L & 15, u = (pos >> 1) ^ (2 * j);  // LDS row j, 16-byte position pos of 16
+        const unsigned k = ks_f * 16 + kq_f * 4 + j;
+        vob[h * 2 + pc] = k * ldb_b + h * 256 + u * 32 + (pos & 1) * 16;
+      } else {
+        const unsigned gb = (2 * pc + (tid >> 8)) * 64 + h * 32 + ((tid >> 3) & 31);  // B row: wave column 2 pc + tid / 256
+        vob[h * 2 + pc] = gb * ldb_b + ks * 16;
+      }
     }
 }
 
 template <int WHICH>  // 0: A0, 1: B0, 2: B1, 3: A1 - one half tile = 2 DMA pieces per thread
 __device__ __forceinline__ void pp_issue(char* stage, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
-                                         const unsigned (&voa)[4], const unsigned (&vob)[4], int wave, int slab) {
+                                         const unsigned (&voa)[4], const unsigned (&vob)[4], int wave, int slab,
+                                         unsigned bstep = 128) {  // bytes a K slab advances in B: 128 (NT) or 64 rows (TN)
   constexpr int off = WHICH == 0 ? PP_A0 : WHICH == 1 ? PP_B0 : WHICH == 2 ? PP_B1 : PP_A1;
   constexpr bool isA = WHICH == 0 || WHICH == 3;
   constexpr int h = (WHICH == 2 || WHICH == 3) ? 1 : 0;
@@ -405,7 +432,7 @@ __device__ __forceinline__ void pp_issue(char* stage, __amdgpu_buffer_rsrc_t ra,
   for (int pc = 0; pc < 2; ++pc) {
     char* dst = stage + off + (pc * 64 + wave * 8) * 128;  // wave-uniform LDS base of this 1-KB piece
     __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)dst, 16,
-                                             isA ? voa[h * 2 + pc] : vob[h * 2 + pc], slab * 128, 0, 0);
+                                             isA ? voa[h * 2 + pc] : vob[h * 2 + pc], isA ? slab * 128 : slab * bstep, 0, 0);
   }
 }
 
@@ -419,19 +446,20 @@ __device__ __forceinline__ void pp_issue(char* stage, __amdgpu_buffer_rsrc_t ra,
 // prologue half: the four half tiles of slab `slab` into stage 0 (the persistent kernel issues it ahead of the previous
 // tile's epilogue)
 __device__ __forceinline__ void pp_issue_first(char* smem, __amdgpu_buffer_rsrc_t ra, __amdgpu_buffer_rsrc_t rb,
-                                               const unsigned (&voa)[4], const unsigned (&vob)[4], int wave, int slab) {
-  pp_issue<0>(smem, ra, rb, voa, vob, wave, slab);
-  pp_issue<1>(smem, ra, rb, voa, vob, wave, slab);
-  pp_issue<2>(smem, ra, rb, voa, vob, wave, slab);
-  pp_issue<3>(smem, ra, rb, voa, vob, wave, slab);
+                                               const unsigned (&voa)[4], const unsigned (&vob)[4], int wave, int slab,
+                                               unsigned bstep = 128) {
+  pp_issue<0>(smem, ra, rb, voa, vob, wave, slab, bstep);
+  pp_issue<1>(smem, ra, rb, voa, vob, wave, slab, bstep);
+  pp_issue<2>(smem, ra, rb, voa, vob, wave, slab, bstep);
+  pp_issue<3>(smem, ra, rb, voa, vob, wave, slab, bstep);
 }
 
 // slabs [s0, s1), s0 < s1; slab s0 has been issued into stage 0 by pp_issue_first.  Every wave passes the same number of
 // barriers (wave row 1 one extra in front, wave row 0 one extra behind).
-template <int DT, int VAR>
+template <int DT, int VAR, bool TN = false>
 __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, __amdgpu_buffer_rsrc_t ra,
                                             __amdgpu_buffer_rsrc_t rb, const unsigned (&voa)[4], const unsigned (&vob)[4],
-                                            int s0, int s1, int lane, int wave) {
+                                            int s0, int s1, int lane, int wave, unsigned bstep = 128) {
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
   // LDS byte addresses of this lane's fragment of k-step ks inside the A0 / B0 half tile of the CURRENT stage; the other
@@ -441,7 +469,9 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) {
     oa[ks] = lds0 + PP_A0 + (wm * 64 + l31) * 128 + (((ks * 2 + hi) ^ sw) << 4);
-    ob[ks] = lds0 + PP_B0 + (wn * 32 + l31) * 128 + (((ks * 2 + hi) ^ sw) << 4);
+    const int tg = lane >> 4, tj = (lane >> 2) & 3, tc = lane & 3;  // TN: lane group, row of its [4][16] block, 8-byte piece
+    ob[ks] = TN ? lds0 + PP_B0 + (ks * 4 + 2 * (tg >> 1)) * 1024 + tj * 256 + (((wn * 2 + (tg & 1)) ^ (2 * tj)) << 5) + tc * 8
+                : lds0 + PP_B0 + (wn * 32 + l31) * 128 + (((ks * 2 + hi) ^ sw) << 4);
   }
   typedef __attribute__((address_space(3))) const i32x4_t* lds_v4;
   i32x4_t fa[2][4], fb[4];
@@ -449,16 +479,45 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     fa[0][ks] = *(lds_v4)(uintptr_t)(oa[ks] + off);
     fa[1][ks] = *(lds_v4)(uintptr_t)(oa[ks] + off + 4096);
   };
-  auto rdB = [&](int ks, int off) { fb[ks] = *(lds_v4)(uintptr_t)(ob[ks] + off); };
-  auto mm = [&](f32x16_t& c0, f32x16_t& c1) {
-    if (VAR != 3) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int ks = 0; ks < 4; ++ks) {
-      mma_step<DT>(c0, fb[ks], fa[0][ks]);  // swapped: D^T[n][m]
-      mma_step<DT>(c1, fb[ks], fa[1][ks]);
+  // TN: the transposing reads are INLINE ASM.  Through the builtin (__builtin_amdgcn_ds_read_tr16_b64_*) the compiler puts
+  // `s_waitcnt vmcnt(0)` in front of every group of them - it orders the intrinsic behind ALL pending LDS-DMA, i.e. it
+  // drains the half tiles that are meant to stay in flight across the phase (measured: the fc6 dW slab 194 us vs 178 us
+  // for the NT form, SQ_WAIT_ANY 0.49 vs 0.36 of the wave cycles, same LDS array cycles and no bank conflicts -
+  // profiles/r3_15_pmc_dw*.json).  The compiler therefore does not count them in lgkmcnt: a phase that reads only B
+  // fragments waits for them itself (mm<true>: counted waits tied to the fragment registers), and phase 1 issues its B
+  // reads FIRST - LDS returns in order, so the compiler's own waits for the A fragments behind them cover them.
+  auto rdB = [&](int ks, int off) {
+    if constexpr (TN) {
+      typedef int i32x2_t __attribute__((ext_vector_type(2)));
+      i32x2_t l2, h2;
+      const unsigned addr = ob[ks] + off;
+      asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(l2) : "v"(addr));
+      asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=v"(h2) : "v"(addr));
+      fb[ks] = i32x4_t{l2[0], l2[1], h2[0], h2[1]};
+    } else {
+      fb[ks] = *(lds_v4)(uintptr_t)(ob[ks] + off);
     }
+  };
+  auto mm = [&](f32x16_t& c0, f32x16_t& c1, auto wait_b_tag) {
+    constexpr bool WAIT_B = decltype(wait_b_tag)::value;  // TN, a phase whose only LDS reads are this phase's 8 tr reads
+    if (VAR != 3) __builtin_amdgcn_s_setprio(1);
+    // (the sched barriers keep each counted wait in front of ITS two MFMAs; left alone the scheduler hoists all four)
+    if constexpr (TN && WAIT_B) asm volatile("s_waitcnt lgkmcnt(6)" : "+v"(fb[0]));
+    mma_step<DT>(c0, fb[0], fa[0][0]);  // swapped: D^T[n][m]
+    mma_step<DT>(c1, fb[0], fa[1][0]);
+    if constexpr (TN && WAIT_B) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(4)" : "+v"(fb[1])); }
+    mma_step<DT>(c0, fb[1], fa[0][1]);
+    mma_step<DT>(c1, fb[1], fa[1][1]);
+    if constexpr (TN && WAIT_B) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fb[2])); }
+    mma_step<DT>(c0, fb[2], fa[0][2]);
+    mma_step<DT>(c1, fb[2], fa[1][2]);
+    if constexpr (TN && WAIT_B) { __builtin_amdgcn_sched_barrier(0); asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fb[3])); }
+    mma_step<DT>(c0, fb[3], fa[0][3]);
+    mma_step<DT>(c1, fb[3], fa[1][3]);
     if (VAR != 3) __builtin_amdgcn_s_setprio(0);
   };
+  constexpr std::false_type NOWAIT{};
+  constexpr std::true_type WAITB{};
   // one 1-KB DMA piece: q = 0..7 in staging order A0.0 A0.1 B0.0 B0.1 B1.0 B1.1 A1.0 A1.1
   auto piece = [&](char* stage, auto qtag, int slab) {
     constexpr int q = decltype(qtag)::value;
@@ -468,7 +527,7 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     constexpr int h = (which == 2 || which == 3) ? 1 : 0;
     char* dst = stage + off + (pc * 64 + wave * 8) * 128;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(isA ? ra : rb, (__attribute__((address_space(3))) void*)dst, 16,
-                                             isA ? voa[h * 2 + pc] : vob[h * 2 + pc], slab * 128, 0, 0);
+                                             isA ? voa[h * 2 + pc] : vob[h * 2 + pc], isA ? slab * 128 : slab * bstep, 0, 0);
   };
 #define PP_PIECE(q) piece(nxt, std::integral_constant<int, q>{}, sn)
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -478,8 +537,15 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     char* nxt = smem + (((s - s0) & 1) ^ 1) * PP_STAGE;
     const int sn = s + 1 < s1 ? s + 1 : s1 - 1;  // past the end: the last slab again, into a stage nobody reads
     // ---- phase 1: quadrant (a0, b0); reads in the order the MFMAs consume them (counted lgkmcnt waits)
+    if constexpr (TN) {
 #pragma unroll
-    for (int ks = 0; ks < 4; ++ks) { rdB(ks, 0); rdA(ks, 0); }
+      for (int ks = 0; ks < 4; ++ks) rdB(ks, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) rdA(ks, 0);
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) { rdB(ks, 0); rdA(ks, 0); }
+    }
     if (VAR == 2) {  // rebalanced: the phase with 12 fragment reads issues no DMA (pieces 0 / 3 / 2 / 3 per phase)
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // B1 of this slab: A1's two pieces may stay in flight
     } else {
@@ -487,7 +553,7 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // B1 of this slab has landed (read in phase 2)
     }
     PP_BARRIER();
-    mm(acc[0][0], acc[1][0]);
+    mm(acc[0][0], acc[1][0], NOWAIT);
     PP_BARRIER();
     // ---- phase 2: (a0, b1)
 #pragma unroll
@@ -500,14 +566,14 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
       asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A1 of this slab (phase 3)
     }
     PP_BARRIER();
-    mm(acc[0][1], acc[1][1]);
+    mm(acc[0][1], acc[1][1], WAITB);
     PP_BARRIER();
     // ---- phase 3: (a1, b1)
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rdA(ks, PP_A1 - PP_A0);
     if (VAR == 2) { PP_PIECE(3); PP_PIECE(4); } else { PP_PIECE(4); PP_PIECE(5); }
     PP_BARRIER();
-    mm(acc[2][1], acc[3][1]);
+    mm(acc[2][1], acc[3][1], NOWAIT);
     PP_BARRIER();
     // ---- phase 4: (a1, b0); b0 is read again (4 reads in a phase that has none) rather than kept: 16 registers, which
     // decide whether a trunk conv workgroup still fits beside this kernel (DESIGN 'trunk beside the GEMMs')
@@ -516,7 +582,7 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     if (VAR == 2) { PP_PIECE(5); PP_PIECE(6); PP_PIECE(7); } else { PP_PIECE(6); PP_PIECE(7); }
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A0 and B0 of the next slab (its phase 1)
     PP_BARRIER();
-    mm(acc[2][0], acc[3][0]);
+    mm(acc[2][0], acc[3][0], WAITB);
     PP_BARRIER();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { oa[ks] ^= PP_STAGE; ob[ks] ^= PP_STAGE; }
@@ -541,7 +607,16 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
 //     the accumulators and W / momentum / the bf16 shadow are updated in place (same arithmetic and order as
 //     sgd_kernel in head.hip), so the 411 MB gradient is neither written nor re-read and the HBM-bound optimizer
 //     pass over the largest tensor disappears as a separate launch.  Single-GPU, no-accumulation steps only.
-template <int DT, bool PIPE, bool SGD = false, int PP = 0>
+// Buffer descriptor of the TN operand's tile: Bt [kb_rows][ldb] from column bn on; rows beyond kb_rows (the K padding) and
+// everything behind the matrix read as zeros.  (Columns beyond N inside a row run into the next row: finite values that
+// only reach output columns >= N, which are never stored.)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_tn_rsrc(const char* B, int bn, int kb_rows, long ldb_bytes, int es) {
+  long bytes = (long)kb_rows * ldb_bytes - (long)bn * es;
+  if (bytes < 0) bytes = 0;
+  return __builtin_amdgcn_make_buffer_rsrc((void*)(B + (long)bn * es), 0, (unsigned)bytes, 0x00020000);
+}
+
+template <int DT, bool PIPE, bool SGD = false, int PP = 0, bool TN = false>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
@@ -603,9 +678,11 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   if (s0 < s1) {
     if constexpr (PP) {
       unsigned pva[4], pvb[4];
-      pp_offsets(la.ld_bytes, lb.ld_bytes, tid, pva, pvb);
-      pp_issue_first(smem, la.rsrc, lb.rsrc, pva, pvb, wave, s0);
-      pp_mainloop<DT, PP>(acc, smem, la.rsrc, lb.rsrc, pva, pvb, s0, s1, lane, wave);
+      pp_offsets<TN>(la.ld_bytes, lb.ld_bytes, tid, pva, pvb);
+      const unsigned bstep = TN ? 64u * lb.ld_bytes : 128u;
+      const __amdgpu_buffer_rsrc_t rbb = TN ? make_tn_rsrc(p.B, bn, p.kb_rows, p.ldb * ES, ES) : lb.rsrc;
+      pp_issue_first(smem, la.rsrc, rbb, pva, pvb, wave, s0, bstep);
+      pp_mainloop<DT, PP, TN>(acc, smem, la.rsrc, rbb, pva, pvb, s0, s1, lane, wave, bstep);
     } else if constexpr (PIPE) {
       // Software-pipelined schedule: fragments of k-step k+1 are read while the MFMAs of k-step k run (two register
       // sets), and ONE barrier per slab - placed after the slab's last fragment read and before its last MFMA block -
@@ -712,7 +789,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = bn + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+          const int n = bn + (TN ? j * 128 + wn * 32 : wn * 64 + j * 32) + 8 * q + 4 * (lane >> 5);
           pw[j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
           mm[j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
           if (n < p.N) {  // N % 4 == 0 (launcher): a 4-column group is inside or outside as a whole
@@ -724,7 +801,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
       for (int j = 0; j < NJ; ++j)
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          const int n = bn + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+          const int n = bn + (TN ? j * 128 + wn * 32 : wn * 64 + j * 32) + 8 * q + 4 * (lane >> 5);
           if (n >= p.N) continue;
           f32x4_t nb, nw;
 #pragma unroll
@@ -756,7 +833,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
-        const int n = bn + wn * 64 + j * 32 + 8 * q + 4 * (lane >> 5);
+        const int n = bn + (TN ? j * 128 + wn * 32 : wn * 64 + j * 32) + 8 * q + 4 * (lane >> 5);
         float* dst = C + (long)m * p.ldc + n;
         f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
         if (p.c_bf16) {
@@ -798,7 +875,7 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
 // dispatcher's round-robin, so the L2 reuse pattern of the XCD patch mapping is unchanged.
 struct GemmWork { int bm, bn, s0, s1, split; __amdgpu_buffer_rsrc_t ra, rb; };  // one (tile, K-split) work item
 
-template <int DT, bool SGD, int PP = 0>
+template <int DT, bool SGD, int PP = 0, bool TN = false>
 __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
@@ -835,8 +912,9 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
     w.s0 = w.split * p.k_slabs_per_split;
     w.s1 = w.s0 + p.k_slabs_per_split < nslab ? w.s0 + p.k_slabs_per_split : nslab;
     w.ra = make_row_loader(p.A, w.bm, p.M, BM, p.lda * ES).rsrc;
-    w.rb = make_row_loader(p.B, w.bn, p.N, BN, p.ldb * ES).rsrc;
+    w.rb = TN ? make_tn_rsrc(p.B, w.bn, p.kb_rows, p.ldb * ES, ES) : make_row_loader(p.B, w.bn, p.N, BN, p.ldb * ES).rsrc;
   };
+  const unsigned bstep = TN ? 64u * ldb_b : 128u;
   auto issue = [&](const Work& w, char* stage, int slab) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -860,11 +938,11 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
       for (int jj = 0; jj < NJ; ++jj) mma_step<DT>(acc[i][jj], fb[jj], fa[i]);  // swapped: D^T[n][m]
   };
   unsigned pva[4], pvb[4];
-  if constexpr (PP) pp_offsets(lda_b, ldb_b, tid, pva, pvb);
+  if constexpr (PP) pp_offsets<TN>(lda_b, ldb_b, tid, pva, pvb);
   Work cur;
   setup(base + j, cur);
   if (cur.s0 < cur.s1) {
-    if constexpr (PP) pp_issue_first(smem, cur.ra, cur.rb, pva, pvb, wave, cur.s0);
+    if constexpr (PP) pp_issue_first(smem, cur.ra, cur.rb, pva, pvb, wave, cur.s0, bstep);
     else issue(cur, smem, cur.s0);
   }
   for (;;) {
@@ -876,7 +954,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
         for (int rr = 0; rr < 16; ++rr) acc[i][jj][rr] = 0.f;
     const int s0 = cur.s0, s1 = cur.s1;
     if constexpr (PP) {
-      if (s0 < s1) pp_mainloop<DT, PP>(acc, smem, cur.ra, cur.rb, pva, pvb, s0, s1, lane, wave);
+      if (s0 < s1) pp_mainloop<DT, PP, TN>(acc, smem, cur.ra, cur.rb, pva, pvb, s0, s1, lane, wave, bstep);
     } else if (s0 < s1) {
       i32x4_t fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab s0 (issued ahead of the previous tile's epilogue) has landed
@@ -943,7 +1021,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();  // every wave is done reading both stages
       if (nxt.s0 < nxt.s1) {
-        if constexpr (PP) pp_issue_first(smem, nxt.ra, nxt.rb, pva, pvb, wave, nxt.s0);
+        if constexpr (PP) pp_issue_first(smem, nxt.ra, nxt.rb, pva, pvb, wave, nxt.s0, bstep);
         else issue(nxt, smem, nxt.s0);
       }
     }
@@ -964,7 +1042,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
         for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) {
-            const int n = bn + wn * 64 + jj * 32 + 8 * qq + 4 * (lane >> 5);
+            const int n = bn + (TN ? jj * 128 + wn * 32 : wn * 64 + jj * 32) + 8 * qq + 4 * (lane >> 5);
             pw[jj][qq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             mm[jj][qq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
             if (n < p.N) {
@@ -976,7 +1054,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
         for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) {
-            const int n = bn + wn * 64 + jj * 32 + 8 * qq + 4 * (lane >> 5);
+            const int n = bn + (TN ? jj * 128 + wn * 32 : wn * 64 + jj * 32) + 8 * qq + 4 * (lane >> 5);
             if (n >= p.N) continue;
             f32x4_t nb, nw;
 #pragma unroll
@@ -1022,7 +1100,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
             for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
               for (int qq = 0; qq < 4; ++qq) {
-                const int c = wn * 16 + jj * 8 + 2 * qq + (lane_e >> 5);
+                const int c = (TN ? jj * 32 + wn * 8 : wn * 16 + jj * 8) + 2 * qq + (lane_e >> 5);
                 const unsigned long long o =
                     (unsigned long long)((uint32_t)f32_to_bf16(acc[i][jj][4 * qq]) | ((uint32_t)f32_to_bf16(acc[i][jj][4 * qq + 1]) << 16)) |
                     ((unsigned long long)((uint32_t)f32_to_bf16(acc[i][jj][4 * qq + 2]) | ((uint32_t)f32_to_bf16(acc[i][jj][4 * qq + 3]) << 16)) << 32);
@@ -1065,7 +1143,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
         for (int jj = 0; jj < NJ; ++jj)
 #pragma unroll
           for (int qq = 0; qq < 4; ++qq) {
-            const int n = bn + wn * 64 + jj * 32 + 8 * qq + 4 * (lane >> 5);
+            const int n = bn + (TN ? jj * 128 + wn * 32 : wn * 64 + jj * 32) + 8 * qq + 4 * (lane >> 5);
             float* dst = C + (long)m * p.ldc + n;
             f32x4_t v = {acc[i][jj][4 * qq], acc[i][jj][4 * qq + 1], acc[i][jj][4 * qq + 2], acc[i][jj][4 * qq + 3]};
             if (p.c_bf16) {
@@ -1667,11 +1745,11 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
-template <int DT, bool PIPE, bool SGD = false, int PP = 0>
+template <int DT, bool PIPE, bool SGD = false, int PP = 0, bool TN = false>
 int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256_kernel<DT, PIPE, SGD, PP>;
+  auto k = gemm_nt256_kernel<DT, PIPE, SGD, PP, TN>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -1698,10 +1776,10 @@ static int cu_count() {
   return n;
 }
 
-template <int DT, bool SGD, int PP = 0>
+template <int DT, bool SGD, int PP = 0, bool TN = false>
 int launch_gemm256p(const GemmParams& p, int nwg, hipStream_t st) {
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256p_kernel<DT, SGD, PP>;
+  auto k = gemm_nt256p_kernel<DT, SGD, PP, TN>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -1822,6 +1900,7 @@ int drn_sgd_set_grid(int blocks_x);  // head.hip
 int drn_roi_set_map64(int on);        // pool.hip
 int drn_roi_set_chunks(int cpb);      // pool.hip
 int drn_roi_set_prefetch(int on);     // pool.hip
+int drn_roi_set_map64_a(int on);      // pool.hip
 int drn_tune(int knob, int value) {
   if (knob == 1) {  // DRN_TUNE_GEMM_PERSISTENT
     const int old = g_persistent;
@@ -1832,6 +1911,7 @@ int drn_tune(int knob, int value) {
   if (knob == 4) return drn_roi_set_map64(value);  // DRN_TUNE_ROI_MAP64
   if (knob == 10) return drn_roi_set_chunks(value);    // DRN_TUNE_ROI_CPB
   if (knob == 11) return drn_roi_set_prefetch(value);  // DRN_TUNE_ROI_PREFETCH
+  if (knob == 14) return drn_roi_set_map64_a(value);   // DRN_TUNE_ROI_MAP64_A
   if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
     const int old = g_conv_ksplit;
     g_conv_ksplit = value != 0;
@@ -1951,6 +2031,32 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
   const bool small = force == 64 || (force == 0 && (long)((M + 127) / 128) * ((N + 127) / 128) * splits < cu_count());
   if (dtype == DRN_BF16) return small ? launch_gemm<DRN_BF16, 64, 64>(p, splits, st) : launch_gemm<DRN_BF16, 128, 128>(p, splits, st);
   return small ? launch_gemm<DRN_F32, 64, 64>(p, splits, st) : launch_gemm<DRN_F32, 128, 128>(p, splits, st);
+}
+
+// C[M,N] = A[M,K] * Bt[K,N]: the B operand given K-major ("TN"), read by the 256x256 ping-pong kernels through
+// transposing LDS reads.  Same tile, slab order and MFMA per output element as drn_gemm_nt on a materialised transpose of
+// Bt (bit-identical: test_gemm_tn_equals_nt_on_the_transpose).  bf16 only.  See include/drn_wsod.h.
+int drn_gemm_tn(const void* A, const void* Bt, void* C, int M, int N, int K, int kb_rows, long lda, long ldb, long ldc,
+                int c_dtype, int splits, long c_split_stride, int accumulate, void* stream) {
+  if (!A || !Bt || !C || M < 0 || N < 0 || K < 0 || kb_rows < 0 || kb_rows > K) return DRN_ERR_ARG;
+  if (M == 0 || N == 0) return DRN_OK;
+  if ((K * 2) % 128 != 0 || (lda * 2) % 16 != 0 || (ldb * 2) % 16 != 0 || lda < K || ldb < N) return DRN_ERR_ARG;
+  if ((((uintptr_t)A | (uintptr_t)Bt) & 15) || (((uintptr_t)C) & 3)) return DRN_ERR_ARG;
+  if (splits < 1 || (splits > 1 && accumulate)) return DRN_ERR_ARG;
+  if (c_dtype != DRN_F32 && c_dtype != DRN_BF16) return DRN_ERR_ARG;
+  if (c_dtype == DRN_BF16 && (splits != 1 || accumulate)) return DRN_ERR_ARG;
+  if ((long)K * ldb * 2 >= 0xFFFFFFF0L) return DRN_ERR_UNSUPPORTED;  // one 32-bit buffer offset spans Bt
+  const int nslab = K * 2 / 128;
+  GemmParams p{(const char*)A, (const char*)Bt, (float*)C, M, N, K, lda, ldb, ldc, (nslab + splits - 1) / splits,
+               c_split_stride, accumulate};
+  p.c_bf16 = c_dtype == DRN_BF16;
+  p.nsplit = splits;
+  p.gm = gemm256_group_rows(M, N, splits);
+  p.kb_rows = kb_rows;
+  hipStream_t st = (hipStream_t)stream;
+  const long wg256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
+  if (const int nwg = persistent_grid(wg256)) return launch_gemm256p<DRN_BF16, false, 1, true>(p, nwg, st);
+  return launch_gemm256<DRN_BF16, true, false, 1, true>(p, splits, st);
 }
 
 // W[M,N] <- SGD(W, momentum_buf, G = A[M,K] * B[N,K]^T) with G kept in registers.  See include/drn_wsod.h.

@@ -116,6 +116,7 @@ struct RoiParams {
   int gpw;       // whole-map kernel: consecutive 8-ROI groups handled by one block (per staged map slice)
   int cpb;       // 64-ROI kernel: consecutive 8-channel chunks handled by one block (bin bounds computed once per block)
   int pf;        // 64-ROI kernel: two map buffers, the next chunk's slice is fetched under this chunk's scan
+  int t_c0;      // first channel whose rows of out_t are needed (drn_roi_pool_nhwc_t); kernels may write more
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -855,7 +856,7 @@ __global__ __launch_bounds__(JMAX >= 13 ? 256 : JMAX >= 7 ? 512 : 1024, JMAX >= 
         *(i32x4_t*)(oa + (r * ld2 + bin * 16)) = i32x4_t{a[0], a[1], b2[0], b2[1]};
       }
     }
-    if (p.out_t) {
+    if (p.out_t && c0 + G64_CH > p.t_c0) {  // (round 3: the fc6 dW reads A itself; only the peeled tail columns keep an A^T)
       char* ot = p.out_t + ((long)c0 * PP * p.ld_out_t + m0) * 2;
       if (nr == ROI_G64) {
         // (k row, 8-ROI octet): 8 lanes write one full 128-byte line; piece i of this thread is row (tid >> 3) + i * nthr / 8
@@ -1069,6 +1070,13 @@ int drn_roi_set_chunks(int cpb) {
   return old;
 }
 
+static int g_roi_map64_a = 0;  // drn_tune(DRN_TUNE_ROI_MAP64_A = 14): 1 = the 64-ROI kernel also for A alone (no A^T)
+int drn_roi_set_map64_a(int on) {
+  const int old = g_roi_map64_a;
+  g_roi_map64_a = on != 0;
+  return old;
+}
+
 int drn_roi_set_prefetch(int on) {
   const int old = g_roi_pf;
   g_roi_pf = on != 0;
@@ -1192,16 +1200,33 @@ int drn_add(const void* a, const void* b, void* out, long n, int dtype, void* st
   return DRN_OK;
 }
 
+int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
+                        int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
+                        long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
+                        int t_first_channel, void* stream);
+
 // mode 0 = RoIPool, 1 = ROIAlign. in_dtype = feature dtype, out_dtype = pooled dtype.
 int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
                       int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
                       long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
                       void* stream) {
+  return drn_roi_pool_nhwc_t(feat, rois, objectness, out, out_t, argmax, N, H, W, C, P, M, spatial_scale, ld_out, ld_out_t,
+                             mode, sampling_ratio, aligned, in_dtype, out_dtype, 0, stream);
+}
+
+// The same with a hint: rows of out_t below channel t_first_channel need not be written (the 64-ROI training kernel then
+// skips its A^T store loop for those channel chunks; every other path writes all of out_t).
+int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
+                        int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
+                        long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
+                        int t_first_channel, void* stream) {
   if (!feat || !rois || !out || P < 1 || P * P > RP_MAXBIN || M < 0 || (mode != 0 && mode != 1)) return DRN_ERR_ARG;
+  if (t_first_channel < 0) return DRN_ERR_ARG;
   if (ld_out < (long)C * P * P || (out_t && ld_out_t < M)) return DRN_ERR_ARG;
   if (M == 0) return DRN_OK;
   RoiParams p{(const char*)feat, rois, objectness, (char*)out, argmax, N, H, W, C, P, M, spatial_scale, ld_out,
               sampling_ratio, aligned, 0, (char*)out_t, ld_out_t};
+  p.t_c0 = out_t ? t_first_channel : 0;
   dim3 grid(M, (C + RP_CH - 1) / RP_CH), block(256);
   hipStream_t st = (hipStream_t)stream;
   {
@@ -1215,7 +1240,7 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
       // slice whose map fits at all - the 43x58 .. 75x100 maps of test-time scales need 16 or 8 channels and most of
       // a CU's LDS (one block per CU), which still beats the per-ROI window kernels by 3-4x there
       const size_t two = 80 * 1024, one = 156 * 1024;
-      if (in_dtype == DRN_BF16 && out_t && M >= ROI_G64)  // the training operand pair: full-line A^T rows
+      if (in_dtype == DRN_BF16 && (out_t || g_roi_map64_a) && M >= ROI_G64)  // the training operand pair: full-line A^T rows
         done = launch_roi_map64(p, st);
       if (done) {
       } else if (in_dtype == DRN_BF16)

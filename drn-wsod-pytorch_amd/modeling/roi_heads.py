@@ -515,10 +515,35 @@ class _HeadEngine:
         else:
             self._mark_current(s)
         ka = h.box_pooler.kernel_args()
+        # round 3: in the bf16 mode the fc6 weight gradient reads A itself (drn_gemm_tn); of A^T only the rows of the columns
+        # its tail-balancing launch peels off are still needed (run_fc1_tail) - the pooling launch skips the rest
+        s["t_row0"] = self._fc1_tail_row0(dtype, h.box_head.fc1.weight.shape[0], K1) if s["AT"] is not None else 0
+        pp = ka["P"] * ka["P"] if "P" in ka else 49
         res = ops.roi_pool_nhwc(feat_nhwc, rois, objectness, out=s["A"], out_t=s["AT"],
-                                want_argmax=want_argmax and ka["mode"] == 0, **ka)
+                                want_argmax=want_argmax and ka["mode"] == 0, t_first_channel=s["t_row0"] // pp, **ka)
         s["argmax"] = res[1] if (want_argmax and ka["mode"] == 0) else None
         return s
+
+    # ---- fc6 weight gradient: row slabs, tail balancing, TN operand -------------------------------------------------
+    fc1_tn = True  # bf16: dW = dP1^T . A through drn_gemm_tn (no materialised A^T); False keeps the NT form on A^T (A/B)
+
+    def _fc1_slabs(self, D1):
+        ends = getattr(self, "fc1_slab_ends", None)
+        if ends is None:
+            nslab = getattr(self, "fc1_grad_slabs", 1)
+            rows = (D1 + nslab - 1) // nslab
+            ends = [min(D1, (s_ + 1) * rows) for s_ in range(nslab)]
+        return [(a, b) for a, b in zip([0] + list(ends[:-1]), ends) if a < b]
+
+    def _fc1_use_tn(self, dtype):
+        return self.fc1_tn and dtype == torch.bfloat16 and getattr(self, "fc1_fused_update", None) is None
+
+    def _fc1_tail_row0(self, dtype, D1, K1):
+        """first row of A^T the fc6 dW still reads: the smallest main-column count over the row slabs (the columns from
+        there on are peeled into the small-tile NT launch, which takes A^T); 0 when the NT form is used throughout"""
+        if not self._fc1_use_tn(dtype):
+            return 0
+        return min(ops.gemm_nt_main_cols(b - a, K1) for a, b in self._fc1_slabs(D1))
 
     def _mark_current(self, s):
         for q in getattr(self, "_pool_sets", ()):
@@ -573,7 +598,7 @@ class _HeadEngine:
         self.refresh_shadows(dtype)
         M = rois.shape[0]
         w = dict(self.ws(M, dtype, training))
-        w["A"], w["AT"] = pooled["A"], pooled["AT"]
+        w["A"], w["AT"], w["AT_row0"] = pooled["A"], pooled["AT"], pooled.get("t_row0", 0)
         sh = self.sh
         fc1, fc2 = h.box_head.fc1, h.box_head.fc2
         D1, K1 = fc1.weight.shape
@@ -804,7 +829,7 @@ class _HeadEngine:
         ops.bias_act_bwd(w["dH1"], M, D1, saved=w["H1"], mask=st["masks"][0] if st["masks"] else None,
                          drop_p=st["drop_p"], dpre=w["dP1"] if fg is not None else None, dpreT=w["dP1T"],
                          **colsum_args(2, D1, self._gview("fc1.bias")))
-        self._tail = (w["dP1T"], w["AT"], D1, K1, Mp, acc)
+        self._tail = (w["dP1T"], w["AT"], D1, K1, Mp, acc, w["A"], M, w.get("AT_row0", 0))
         if not getattr(self, "defer_fc1_tail", False):
             self.run_fc1_tail()
         if fg is not None:
@@ -847,19 +872,16 @@ class _HeadEngine:
         slabs (each announced as soon as its GEMM is queued).  Normally called by backward() itself; the multi-GPU
         graphed step sets `defer_fc1_tail` and calls it eagerly after replaying the captured part, so the RCCL calls
         issued from the hooks are ordinary stream work and never part of a hipGraph."""
-        dP1T, AT, D1, K1, Mp, acc = self._tail
+        dP1T, AT, D1, K1, Mp, acc, A, M, at_row0 = self._tail
         hook = getattr(self, "grad_ready_hook", None)
         if hook is not None:
             hook("small")  # everything except fc1.weight is final: the DP engine starts reducing it now
-        ends = getattr(self, "fc1_slab_ends", None)
-        if ends is None:
-            nslab = getattr(self, "fc1_grad_slabs", 1)
-            rows = (D1 + nslab - 1) // nslab
-            ends = [min(D1, (s + 1) * rows) for s in range(nslab)]
         fused = getattr(self, "fc1_fused_update", None)
         bucket = getattr(self, "fc1_grad_bucket", None)  # [D1, K1] exchange buffer (bf16 or fp32) instead of the arena
         if fused is not None and not acc:
             # the optimizer consumes this gradient inside the GEMM epilogue: fc1.weight.grad is never materialised
+            if at_row0 > 0:
+                raise DrnError("the fused fc6 update needs the whole A^T; this batch was pooled before it was enabled")
             fused(dP1T, AT, D1, K1, Mp)
         else:
             if fused is not None or (bucket is not None and acc):
@@ -870,14 +892,34 @@ class _HeadEngine:
             # agree on the split, ONE launch computes the peeled columns of all rows first and the slabs' main columns -
             # exact rounds - follow; same kernels' arithmetic per element (tile size does not change the summation order)
             n0 = K1
-            slabs = [(a, b) for a, b in zip([0] + list(ends[:-1]), ends) if a < b]
+            slabs = self._fc1_slabs(D1)
+            tn = self._fc1_use_tn(dP1T.dtype)
+            if at_row0 > 0 and not tn:
+                raise DrnError("this batch was pooled for the TN form of the fc6 weight gradient (A^T rows below %d were "
+                               "not written) but the backward runs the NT form: fc1_tn / the fused update changed in "
+                               "between" % at_row0)
             if getattr(self, "fc1_joint_peel", 1) and len(slabs) > 1 and not acc:
                 cols = {ops.gemm_nt_main_cols(b - a, K1) for a, b in slabs}
                 if len(cols) == 1 and 0 < min(cols) < K1:
                     n0 = cols.pop()
+                    if n0 < at_row0:
+                        raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (n0, at_row0))
                     ops.gemm_nt(dP1T, AT[n0:], D1, K1 - n0, Mp, out=gw[:, n0:].unsqueeze(0))
             for r0, r1 in slabs:
-                ops.gemm_nt(dP1T[r0:r1], AT[:n0], r1 - r0, n0, Mp, out=gw[r0:r1, :n0].unsqueeze(0), accumulate=acc)
+                if tn:
+                    # main columns (exact rounds of the persistent kernel) straight from A; a slab whose peel was not part
+                    # of a joint launch peels its own trailing columns through the NT small-tile kernel first
+                    m0 = min(n0, ops.gemm_nt_main_cols(r1 - r0, K1))
+                    if m0 < n0:
+                        if m0 < at_row0:
+                            raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (m0, at_row0))
+                        ops.gemm_nt(dP1T[r0:r1], AT[m0:n0], r1 - r0, n0 - m0, Mp, out=gw[r0:r1, m0:n0].unsqueeze(0),
+                                    accumulate=acc)
+                    if m0 > 0:
+                        ops.gemm_tn(dP1T[r0:r1], A[:, :m0], r1 - r0, m0, Mp, M, out=gw[r0:r1, :m0].unsqueeze(0),
+                                    accumulate=acc)
+                else:
+                    ops.gemm_nt(dP1T[r0:r1], AT[:n0], r1 - r0, n0, Mp, out=gw[r0:r1, :n0].unsqueeze(0), accumulate=acc)
                 if hook is not None:
                     hook(("fc1", r0, r1))
         self._grads_valid = True

@@ -38,7 +38,7 @@ def gemm_set_tile(tile):
 
 
 TUNE_GEMM_PERSISTENT, TUNE_SGD_GRID, TUNE_GEMM_GROUP_ROWS, TUNE_ROI_MAP64, TUNE_CONV_KSPLIT, TUNE_GEMM_TAIL_SPLIT, TUNE_CONV_KS_TILES, TUNE_CONV_K2_TILES, TUNE_CONV_PATCH = 1, 2, 3, 4, 5, 6, 7, 8, 9
-TUNE_ROI_CPB, TUNE_ROI_PREFETCH, TUNE_GEMM_PINGPONG, TUNE_FP8_K64 = 10, 11, 12, 13
+TUNE_ROI_CPB, TUNE_ROI_PREFETCH, TUNE_GEMM_PINGPONG, TUNE_FP8_K64, TUNE_ROI_MAP64_A = 10, 11, 12, 13, 14
 
 
 def tune(knob, value):
@@ -61,6 +61,29 @@ def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
     C.call("drn_gemm_nt", C.ptr(A), C.ptr(B), C.ptr(out), M, N, K, lda, ldb, ldc, C.dt(A.dtype), C.dt(out.dtype), splits,
+           sstride, int(accumulate), C.stream())
+    if GEMM_TIMING is not None:
+        e1.record()
+        GEMM_TIMING.append((e0, e1, 2.0 * M * N * K, (M, N, K)))
+    return out
+
+
+def gemm_tn(A, Bt, M, N, K, kb_rows, out=None, splits=1, accumulate=False):
+    """C[s,M,N] = A[M,:K] @ Bt[:K,:N] with the second operand K-major (Bt [kb_rows, ldb] row-major; rows kb_rows..K-1
+    count as zeros and need not exist): drn_gemm_tn, bf16 operands.  The fc6 weight gradient reads the pooled matrix
+    through it, so no transposed copy of it is written."""
+    assert A.dtype == torch.bfloat16 and Bt.dtype == torch.bfloat16 and Bt.shape[0] >= kb_rows
+    lda, ldb = _2d(A), _2d(Bt)
+    if out is None:
+        out = torch.empty((splits, M, N), dtype=torch.float32, device=A.device)
+    assert out.dtype == torch.float32 or (out.dtype == torch.bfloat16 and splits == 1 and not accumulate)
+    ldc = out.stride(-2)
+    sstride = out.stride(0) if out.dim() == 3 else 0
+    assert out.dim() == 3 or splits == 1
+    if GEMM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    C.call("drn_gemm_tn", C.ptr(A), C.ptr(Bt), C.ptr(out), M, N, K, int(kb_rows), lda, ldb, ldc, C.dt(out.dtype), splits,
            sstride, int(accumulate), C.stream())
     if GEMM_TIMING is not None:
         e1.record()
@@ -156,9 +179,10 @@ def preprocess_nhwc(images, mean, std, dtype, cpad):
 
 
 def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, aligned=False, out=None, out_dtype=None,
-                  want_argmax=False, out_t=None):
+                  want_argmax=False, out_t=None, t_first_channel=0):
     """feat [N,H,W,C]; rois [M,5] f32; -> out [M, ld] (first C*P*P columns valid, k = c*P*P + bin); out_t (optional,
-    [C*P*P, ld_t]) receives the transposed copy in the same call."""
+    [C*P*P, ld_t]) receives the transposed copy in the same call - with t_first_channel > 0 only its rows from channel
+    t_first_channel on are guaranteed (drn_roi_pool_nhwc_t)."""
     n, h, w, c = feat.shape
     m = rois.shape[0]
     out_dtype = out_dtype or feat.dtype
@@ -170,13 +194,14 @@ def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, al
     if HBM_TIMING is not None:  # bench.py: HIP events on the launching stream around this launch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    C.call("drn_roi_pool_nhwc", C.ptr(feat), C.ptr(rois), C.ptr(objectness), C.ptr(out), C.ptr(out_t), C.ptr(arg), n, h,
+    C.call("drn_roi_pool_nhwc_t", C.ptr(feat), C.ptr(rois), C.ptr(objectness), C.ptr(out), C.ptr(out_t), C.ptr(arg), n, h,
            w, c, P, m, float(scale), _2d(out), _2d(out_t) if out_t is not None else 0, mode, sampling_ratio,
-           int(aligned), C.dt(feat.dtype), C.dt(out.dtype), C.stream())
+           int(aligned), C.dt(feat.dtype), C.dt(out.dtype), int(t_first_channel), C.stream())
     if HBM_TIMING is not None:
         e1.record()
         es = esize(out.dtype)
-        nbytes = (2 if out_t is not None else 1) * m * c * P * P * es + feat.numel() * esize(feat.dtype) + rois.numel() * 4
+        t_rows = 0 if out_t is None else (c - min(c, t_first_channel // 8 * 8)) * P * P  # rows of out_t really written
+        nbytes = m * c * P * P * es + m * t_rows * es + feat.numel() * esize(feat.dtype) + rois.numel() * 4
         HBM_TIMING.append((e0, e1, nbytes, ("roi_pool", m, c * P * P, out_t is not None)))
     return (out, arg) if want_argmax else out
 

@@ -103,6 +103,15 @@ int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectne
                       long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
                       void* stream);
 
+/* drn_roi_pool_nhwc with a hint for out_t: only the rows of channels >= t_first_channel (row index c*P*P + bin) are
+ * needed - the fc6 weight gradient reads `out` itself through drn_gemm_tn and keeps a transposed copy only for the few
+ * trailing columns its tail-balancing launch takes (drn_gemm_nt_main_cols).  The 64-ROI training kernel skips the A^T
+ * store loop of the other channel chunks; every other kernel writes all of out_t (a superset). */
+int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
+                        int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
+                        long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
+                        int t_first_channel, void* stream);
+
 /* Backward of the above w.r.t. the feature map: torchvision RoIPool's backward (scatter to the arg-max the forward
  * returned) and roi_align_backward (detectron2/layers/csrc/ROIAlign/ROIAlign.h:93-128, ROIAlign_cuda.cu:141-250),
  * with the forward's objectness scaling applied to grad_out.  grad_out [M][ld_g] (column c*P*P + bin, fp32 or bf16);
@@ -135,6 +144,15 @@ long drn_gemm_nt_main_cols(int M, int N, int splits);
 int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
                 int c_dtype, int splits, long c_split_stride, int accumulate, void* stream);
 
+/* drn_gemm_tn: C[M,N] = A[M,K] . Bt[K,N] with the second operand given K-MAJOR (Bt row-major [kb_rows][ldb]; rows
+ * kb_rows..K-1 - the K padding - are read as zeros and need not exist).  bf16 operands, fp32 accumulate, C fp32
+ * (splits / accumulate as drn_gemm_nt) or bf16.  The fc6 weight gradient dW = dP1^T . A (the autograd of
+ * box_head.py:82-91's fc1) reads the pooled matrix A [R][C*49] through it directly, so the pooling launch no longer
+ * writes a transposed copy A^T.  256x256 ping-pong kernel with transposing LDS reads (ds_read_b64_tr_b16); results are
+ * bit-identical to drn_gemm_nt on a materialised transpose.  K % 64 == 0, (ldb * 2) % 16 == 0, ldb >= N. */
+int drn_gemm_tn(const void* A, const void* Bt, void* C, int M, int N, int K, int kb_rows, long lda, long ldb, long ldc,
+                int c_dtype, int splits, long c_split_stride, int accumulate, void* stream);
+
 /* The weight-gradient contraction of a Linear layer with the optimizer step as its epilogue
  * (torch.autograd's dW = dY^T X of F.linear followed by torch.optim.SGD.step on that tensor,
  * detectron2/solver/build.py:93-137 builds the optimizer; plain_train_net/train_loop.py:232-236 calls it):
@@ -165,6 +183,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_ROI_CPB 10 /* 64-ROI ROIPool: most 8-channel chunks one workgroup walks (power of two, default 1; halved until two workgroups per CU remain): bin bounds / item table once per workgroup - faster stand-alone (4-8), slower inside the training step */
 #define DRN_TUNE_ROI_PREFETCH 11 /* 0/1 (default 1): 64-ROI ROIPool keeps two map-slice buffers and fetches the next chunk's slice under the scan */
 #define DRN_TUNE_GEMM_PINGPONG 12 /* 0/1 (default 1): bf16 256x256 GEMMs run the ping-pong mainloop - the two waves of a SIMD half a phase apart, four [reads + DMA | 8 MFMAs] phases per K slab, half-tile LDS-DMA spread over the slab; bit-identical to the lock-step pipeline it replaces (0) */
+#define DRN_TUNE_ROI_MAP64_A 14 /* 0/1 (default 0): the 64-ROI ROIPool kernel also when only A is asked for (no A^T) */
 #define DRN_TUNE_FP8_K64 13 /* 0/1 (default 1): fp8 convolutions multiply with v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales; the fp8 MFMA rate) instead of the K = 16 non-scaled form (bf16 rate); same exact products, another fp32 summation order */
 #define DRN_TUNE_CONV_PATCH 9 /* 0 = never use the LDS-resident-patch kernel for 3x3 / 64 -> 64 channel convs; 1 = default (maps of >= 32768 pixels); > 1 = that many pixels per image at least */
 int drn_tune(int knob, int value);

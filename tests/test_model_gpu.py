@@ -263,6 +263,44 @@ def test_train_step_bf16(name):
     load_package().set_precision("fp32")
 
 
+@pytest.mark.parametrize("case", ["tiny", "full"])
+def test_fc6_weight_gradient_tn_equals_nt(case):
+    """bf16 mode: the fc6 weight gradient read from the pooled matrix A itself (drn_gemm_tn; the pooling launch writes
+    only the tail rows of A^T) against the NT form on the fully materialised A^T: every gradient bit for bit - with the
+    benchmark's two row slabs + joint peel at full size (R50-C4, R = 2000), and on the tiny fixture (no peel at all)."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    if case == "tiny":
+        ocfg, d, cfg, model = _setup("model_r50c4_tiny", "bf16")
+        batch = G.drn_inputs(G.batch_from(d))
+    else:
+        kw = dict(arch="wsr50", out_feature="res4", res5_dilation=1, num_classes=20)
+        ocfg = O.OracleCfg(dropout=0.0, base_lr=2e-4, **kw)
+        cfg, model = G.drn_model(ocfg, 3, "cuda", 5, "bf16")
+        model.roi_heads.box_head.dropout_p = 0.0
+        b = O.synthetic_batch(1, 2000, ocfg, seed=77)
+        batch = G.drn_inputs([dict(x, gt_boxes=torch.zeros(len(x["gt_classes"]), 4)) for x in b])
+    model.train()
+    eng = model.roi_heads._engine
+    grads = {}
+    for tn in (True, False):
+        eng.fc1_tn = tn
+        eng.fc1_grad_slabs = 2 if case == "full" else 1
+        for p_ in model.parameters():
+            p_.grad = None
+        eng._grads_valid = False
+        sum(model(batch).values()).backward()
+        torch.cuda.synchronize()
+        if tn and case == "full":
+            assert eng._last_state["w"]["AT_row0"] > 40000  # the pooling launch really skipped most of A^T
+        grads[tn] = {n: p_.grad.detach().clone() for n, p_ in model.named_parameters() if p_.grad is not None}
+    eng.fc1_tn = True
+    assert "roi_heads.box_head.fc1.weight" in grads[True]
+    for n in grads[True]:
+        assert torch.equal(grads[True][n], grads[False][n]), n
+    load_package().set_precision("fp32")
+
+
 def test_grad_accumulation_iter_size():
     """WSL.ITER_SIZE semantics (train_net.py:100-113): two backward() calls accumulate before one step."""
     ocfg, d, cfg, model = _setup("model_r50c4_tiny", "fp32")

@@ -135,6 +135,50 @@ def test_gemm_persistent_equals_one_tile_grid(drn, dtype, M, N, K, splits):
         drn.gemm_set_tile(prev_tile)
 
 
+@pytest.mark.parametrize("M,N,Kb,splits", [(256, 256, 64, 1), (1024, 6400, 2000, 1), (700, 1000, 130, 1), (2048, 1024, 2000, 1),
+                                           (512, 33000, 200, 1), (1000, 2304, 700, 3), (2048, 25088, 37, 1)])
+def test_gemm_tn_equals_nt_on_the_transpose(drn, M, N, Kb, splits):
+    """drn_gemm_tn (second operand K-major, read through ds_read_b64_tr_b16) against drn_gemm_nt on a materialised
+    transpose with the 256x256 ping-pong kernel: same tile, slab order and MFMA operands per output element, so the
+    results are BIT-identical - fp32 with split-K, accumulate, bf16 output; persistent and one-tile grids, ragged M / N,
+    contraction lengths that are not a multiple of the 64-row slab (the missing rows read as zeros), a column slice of
+    a wider matrix as Bt (the fc6 dW's main columns)."""
+    dtype = torch.bfloat16
+    K = (Kb + 63) // 64 * 64
+    A = _rnd((M, Kb), 21)
+    Bt = _rnd((Kb, N + 40), 22)  # wider than N: the operand is a column slice, its tail columns must not leak in
+    Ad = torch.zeros((M, K), dtype=dtype, device=DEV)
+    Ad[:, :Kb] = A.to(dtype)
+    Btd = Bt.to(dtype).to(DEV).contiguous()
+    Bd = torch.zeros((N, K), dtype=dtype, device=DEV)  # the materialised transpose, K padded with zeros
+    Bd[:, :Kb] = Btd[:, :N].t()
+    C0 = _rnd((M, N), 23).to(DEV)
+    prev_tile = drn.gemm_set_tile(256)
+    prev_pp = drn.tune(drn.TUNE_GEMM_PINGPONG, 1)
+    prev_ts = drn.tune(drn.TUNE_GEMM_TAIL_SPLIT, 0)  # (the NT side would peel columns into the small-tile kernel: same bits, other kernel)
+    try:
+        nt = drn.gemm_nt(Ad, Bd, M, N, K, splits=splits)
+        tn = drn.gemm_tn(Ad, Btd[:, :N], M, N, K, Kb, splits=splits)
+        torch.cuda.synchronize()
+        assert torch.equal(nt, tn), float((nt - tn).abs().max())
+        a1, a2 = C0.clone().unsqueeze(0), C0.clone().unsqueeze(0)
+        drn.gemm_nt(Ad, Bd, M, N, K, out=a1, accumulate=True)
+        drn.gemm_tn(Ad, Btd[:, :N], M, N, K, Kb, out=a2, accumulate=True)
+        o1 = torch.zeros((1, M, N), dtype=torch.bfloat16, device=DEV)
+        o2 = torch.zeros((1, M, N), dtype=torch.bfloat16, device=DEV)
+        drn.gemm_nt(Ad, Bd, M, N, K, out=o1)
+        drn.gemm_tn(Ad, Btd[:, :N], M, N, K, Kb, out=o2)
+        torch.cuda.synchronize()
+        assert torch.equal(a1, a2) and torch.equal(o1, o2)
+        ref = _q(A, dtype).double() @ _q(Bt[:, :N], dtype).double()
+        mag = _q(A, dtype).abs().double() @ _q(Bt[:, :N], dtype).abs().double()
+        assert ((tn.sum(0).cpu().double() - ref).abs() <= 4 * 2.0 ** -24 * math.sqrt(K) * mag + 1e-6).all()
+    finally:
+        drn.tune(drn.TUNE_GEMM_TAIL_SPLIT, prev_ts)
+        drn.tune(drn.TUNE_GEMM_PINGPONG, prev_pp)
+        drn.gemm_set_tile(prev_tile)
+
+
 @pytest.mark.parametrize("M,N,K,splits", [(2000, 2048, 3136, 4), (256, 256, 64, 1), (1030, 17000, 192, 1), (300, 70000, 128, 1),
                                           (2304, 8192, 320, 3), (2000, 4500, 512, 2)])
 def test_gemm_pingpong_bit_identical(drn, M, N, K, splits):
@@ -485,6 +529,30 @@ def test_roi_pool(drn, dtype, C, P, scale, H, W, R):
     assert torch.equal(out3, out)
     assert torch.equal(out_t[:, :R], out[:, :k].t())
     assert (out_t[:, R:] == 0).all()
+
+
+@pytest.mark.parametrize("C,H,W,R,t0", [(1024, 14, 14, 2000, 1003), (64, 14, 14, 200, 40), (128, 50, 76, 130, 127),
+                                        (70, 19, 23, 100, 30)])
+def test_roi_pool_transposed_tail_hint(drn, C, H, W, R, t0):
+    """drn_roi_pool_nhwc_t: with the fc6 dW reading A itself, only the rows of A^T from channel t0 on are needed (the
+    columns the dW's tail-balancing launch peels off).  A is unchanged, the rows of A^T from t0 * 49 on equal the full
+    transposed copy bit for bit (the 64-ROI kernel skips whole 8-channel chunks below t0, every other kernel writes all)."""
+    dtype, P, scale, n_img = torch.bfloat16, 7, 1.0 / 16, 2
+    feat = _rnd((n_img, C, H, W), 31)
+    rois = _rois(R, n_img, W / scale, H / scale, 32).to(DEV)
+    obj = torch.rand(R).to(DEV)
+    fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    k = C * P * P
+    mk = lambda: (torch.zeros((R, drn.kpad(k, dtype)), dtype=dtype, device=DEV),
+                  torch.full((k, drn.kpad(R, dtype)), 7.0, dtype=dtype, device=DEV))
+    a_full, t_full = mk()
+    drn.roi_pool_nhwc(fd, rois, obj, P, scale, out=a_full, out_t=t_full)
+    a_hint, t_hint = mk()
+    drn.roi_pool_nhwc(fd, rois, obj, P, scale, out=a_hint, out_t=t_hint, t_first_channel=t0)
+    torch.cuda.synchronize()
+    assert torch.equal(a_full, a_hint)
+    assert torch.equal(t_full[t0 * 49:, :R], t_hint[t0 * 49:, :R])
+    assert torch.equal(t_full[:, :R], a_full[:, :k].t())
 
 
 @pytest.mark.parametrize("dtype", DTYPES)

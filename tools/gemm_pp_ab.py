@@ -41,3 +41,31 @@ for name, M, N, K, S, b16 in SHAPES:
         med = t[len(t) // 2]
         print("%-12s pp=%d  median %.1f us (min %.1f)  %.0f TFLOP/s" % (name, pp, med * 1e3, t[0] * 1e3, 2.0 * M * N * K / med / 1e9))
 ops.tune(ops.TUNE_GEMM_PINGPONG, 1)
+# round 3: the fc6 dW slab with its second operand K-major (drn_gemm_tn reads the pooled matrix A [R][C*49] itself)
+# against the NT form on a materialised A^T, interleaved
+M, N, K, R = 1024, 49152, 2048, 2000
+A = (torch.randn((M, K), device="cuda") * 0.5).to(bf)
+A[:, R:] = 0
+Bt = (torch.randn((R, 50176), device="cuda") * 0.05).to(bf)
+B = torch.zeros((50176, K), dtype=bf, device="cuda")
+B[:, :R] = Bt.t()
+o1 = torch.empty((1, M, N), dtype=bf, device="cuda")
+o2 = torch.empty((1, M, N), dtype=bf, device="cuda")
+fns = {"NT": lambda: ops.gemm_nt(A, B[:N], M, N, K, out=o1), "TN": lambda: ops.gemm_tn(A, Bt[:, :N], M, N, K, R, out=o2)}
+res = {k: [] for k in fns}
+for r in range(rounds):
+    for k, f in fns.items():
+        for _ in range(5):
+            f()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(n):
+            f()
+        e1.record()
+        torch.cuda.synchronize()
+        res[k].append(e0.elapsed_time(e1) / n)
+print("fc6 dW slab, outputs equal:", bool(torch.equal(o1, o2)))
+for k in fns:
+    t = sorted(res[k])
+    med = t[len(t) // 2]
+    print("fc6 dW slab  %s  median %.1f us (min %.1f)  %.0f TFLOP/s" % (k, med * 1e3, t[0] * 1e3, 2.0 * M * N * K / med / 1e9))

@@ -28,5 +28,11 @@ run_shape() {  # name, PMC_SHAPE, bf16-out flag
   PMC_SHAPE=$shape PMC_BF16_OUT=$bf python $R/tools/pmc_attrib_summary.py $O/${tag}_pmcraw_${name} $O/${tag}_pmc_${name}.json
   rm -rf $O/${tag}_pmcraw_${name}_*
 }
+if [ "${PMC_ONLY:-}" = "dw_tn" ]; then  # the fc6 dW slab reading the pooled matrix K-major (drn_gemm_tn) next to the NT form
+  run_shape dw 1024,49152,2048,1 1
+  export PMC_TN=1
+  run_shape dw_tn 1024,49152,2048,1 1
+  exit 0
+fi
 run_shape fwd 2000,2048,50176,4 ""
 run_shape dw 1024,49152,2048,1 1

@@ -17,7 +17,14 @@ M, N, K, S = [int(x) for x in os.environ.get("PMC_SHAPE", "2000,2048,50176,4").s
 A = (torch.randn((M, K), device="cuda") * 0.5).to(torch.bfloat16)
 B = (torch.randn((N, K), device="cuda") * 0.05).to(torch.bfloat16)
 out = torch.empty((S, M, N), dtype=torch.bfloat16 if os.environ.get("PMC_BF16_OUT") else torch.float32, device="cuda")
+TN = os.environ.get("PMC_TN")  # the second operand K-major (drn_gemm_tn): Bt [kb_rows][N], kb_rows = K - 48 like R = 2000
+if TN:
+    kb = K - 48
+    Bt = (torch.randn((kb, N), device="cuda") * 0.05).to(torch.bfloat16)
 for _ in range(6):
-    ops.gemm_nt(A, B, M, N, K, out=out, splits=S)
+    if TN:
+        ops.gemm_tn(A, Bt, M, N, K, kb, out=out, splits=S)
+    else:
+        ops.gemm_nt(A, B, M, N, K, out=out, splits=S)
 torch.cuda.synchronize()
 print("done")

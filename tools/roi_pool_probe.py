@@ -50,3 +50,10 @@ for (R, C, H, W, stride) in ((2000, 1024, 14, 14, 16), (4000, 2048, 27, 27, 8)):
     nb = 2 * R * K1 * 2
     print("%s  R=%d C=%d %dx%d  A+A^T %.1f MB  %.1f us  %.2f TB/s" % (" ".join(sys.argv[1:]) or "default", R, C, H, W,
                                                                  nb / 1e6, t, nb / t / 1e6))
+    # A alone (what the pooling launch would cost if the fc6 dW read A itself): the 8-ROI whole-map kernel, then the
+    # 64-ROI kernel without its A^T store loop
+    for knob, label in ((0, "A only, 8-ROI kernel"), (1, "A only, 64-ROI kernel")):
+        ops.tune(ops.TUNE_ROI_MAP64_A, knob)
+        t = timed(lambda: ops.roi_pool_nhwc(feat, rois, obj, 7, 1.0 / stride, out=A))
+        print("    %-24s %.1f MB  %.1f us  %.2f TB/s" % (label, nb / 2e6, t, nb / 2 / t / 1e6))
+    ops.tune(ops.TUNE_ROI_MAP64_A, 0)
