@@ -1346,16 +1346,25 @@ class GraphedFullStep(GraphedTrainStep):
     top of the next replay.  ~250 launches of 5-60 us that the eager Python host cannot enqueue as fast as the GPU runs
     them; a replay costs one graph launch.  Nothing of a future batch can run ahead here - the trunk's weights change
     every step - so there is no side stream and no lookahead: step(batch) stages `batch` and replays.
-    Static shapes (image size, proposals per image, images per GPU), ITER_SIZE 1, one process (with N > 1 the trunk
-    gradients are exchanged by the eager path: DataParallel's "backbone" bucket)."""
+    Static shapes (image size, proposals per image, images per GPU), ITER_SIZE 1.
+    N > 1 (`parallel` = the model's DataParallel, round 3): no collective is ever captured - the step becomes TWO graphs
+    around an eager exchange: [forward + backward] -> all-reduce of the head engine's gradient arena (everything up to the
+    end of fc1.weight: the unused bbox_pred tail never travels) and of the trunk's flat gradient arena -> [SGD of both
+    arenas with 1 / world + zero_grad].  DataParallel's per-bucket hooks stay silent (`sync_gradients` off): the buckets
+    only pay when the optimizer can update one while the next is still being produced, which the plain optimizer step of a
+    trainable trunk does not do."""
 
     _needs_frozen_trunk = False
 
-    def __init__(self, model, optimizer, example_batch):
+    def __init__(self, model, optimizer, example_batch, parallel=None):
         if getattr(optimizer, "_pipelined", False):
             raise DrnError("GraphedFullStep uses the plain optimizer step (the pipelined mode assumes a frozen trunk)")
         super().__init__(model, optimizer, example_batch, split_tail=False, lookahead=1)
         self.g_step = None
+        self.g_opt = None
+        self.dp = parallel if (parallel is not None and parallel.exchange) else None
+        if self.dp is not None:
+            self.dp.sync_gradients = False  # the exchange below replaces the per-bucket hooks
 
     def _stage(self, batch):
         self._stage_labels(batch)
@@ -1369,7 +1378,7 @@ class GraphedFullStep(GraphedTrainStep):
         self.props.copy_(self.rois[:, 1:])
         self._stage_image(batch, 0)
 
-    def _full_body(self):
+    def _fwd_bwd(self):
         m, eng = self.model, self.engine
         imgs = m.preprocess_image([{"image": im} for im in self._images[0]])
         feats = m.backbone(imgs.tensor)  # training mode + trainable blocks: activations are kept for backward_nhwc()
@@ -1382,8 +1391,27 @@ class GraphedFullStep(GraphedTrainStep):
         else:
             self._eager_state = st
         eng.backward(st, None)
-        self.opt.step(1.0)
+        return losses
+
+    def _opt_body(self):
+        self.opt.step(1.0 if self.dp is None else self.dp.grad_scale)
         self.opt.zero_grad()
+
+    def _exchange(self):
+        """sum of the trainable gradients over the ranks (the SGD kernels apply 1 / world): two all-reduces on the
+        current stream, between the two graphs"""
+        e = self.engine
+        o, n = e._seg["fc1.weight"]
+        dist.all_reduce(e.arena_g[: o + n], group=self.dp.group)
+        bg = getattr(self.model, "_bb_grad_arena", None)
+        if bg is not None:
+            dist.all_reduce(bg, group=self.dp.group)
+
+    def _full_body(self):
+        losses = self._fwd_bwd()
+        if self.dp is not None:
+            self._exchange()
+        self._opt_body()
         return losses
 
     def step(self, batch):
@@ -1397,9 +1425,20 @@ class GraphedFullStep(GraphedTrainStep):
             first = {k: v.detach().clone() for k, v in self._full_body().items()}
             torch.cuda.synchronize()
             self.g_step = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.g_step, capture_error_mode="thread_local"):
-                self.losses = self._full_body()
+            if self.dp is None:
+                with torch.cuda.graph(self.g_step, capture_error_mode="thread_local"):
+                    self.losses = self._full_body()
+            else:
+                # the capture pass RUNS nothing: the gradient arenas and weights are exactly as step 0 left them
+                with torch.cuda.graph(self.g_step, capture_error_mode="thread_local"):
+                    self.losses = self._fwd_bwd()
+                self.g_opt = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
+                    self._opt_body()
             return first
         self.opt.refresh_tables()
         self.g_step.replay()
+        if self.dp is not None:
+            self._exchange()
+            self.g_opt.replay()
         return self.losses
