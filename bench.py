@@ -158,7 +158,8 @@ def hbm_rooflines(model, batch, R, device, ops, opt=None):
     """The two dominant HBM-bound kernels of the step, timed on their own with HIP events (5 launches each, scratch
     buffers of the workload's sizes, after the timed region): achieved = ALGORITHMIC bytes / launch duration against
     the 8 TB/s HBM3E peak (MI355X_MICROARCH.md).
-      roi_pool7_map64_kernel: writes A and A^T (2 x R x C*49 x 2 B), reads the 14x14xC map + R boxes
+      roi_pool7_map64_kernel: writes A (R x C*49 x 2 B) and the tail rows of A^T the dW's peel still takes, reads the
+                              14x14xC map + R boxes
       sgd_kernel (fc6 half): per parameter reads w, momentum (fp32) + gradient (bf16), writes w, momentum (fp32) +
                              bf16 shadow = 20 B"""
     import numpy as np
@@ -186,10 +187,17 @@ def hbm_rooflines(model, batch, R, device, ops, opt=None):
         A = torch.zeros((R, ops.kpad(K1, nhwc.dtype)), dtype=nhwc.dtype, device=device)
         AT = torch.zeros((K1, ops.kpad(R, nhwc.dtype)), dtype=nhwc.dtype, device=device)
         ka = heads.box_pooler.kernel_args()
-        t = timed(lambda: ops.roi_pool_nhwc(nhwc, rois, obj, out=A, out_t=AT, **ka))
+        # what the step launches: A in full; of A^T only the rows of the columns the fc6 dW's tail-balancing peel takes
+        # (round 3: the dW reads A itself through drn_gemm_tn) - all of A^T with --fc1-nt / in the fp32 mode
+        D1_ = heads.box_head.fc1.weight.shape[0]
+        t_row0 = eng._fc1_tail_row0(nhwc.dtype, D1_, K1)
+        t_c0 = t_row0 // 49
+        t = timed(lambda: ops.roi_pool_nhwc(nhwc, rois, obj, out=A, out_t=AT, t_first_channel=t_c0, **ka))
         es = 2 if nhwc.dtype == torch.bfloat16 else 4
-        nbytes = 2 * R * K1 * es + nhwc.numel() * es + rois.numel() * 4
-        out.append({"kernel": "roi_pool7_map64_kernel (ROIPool + objectness scale -> A and A^T)", "bound": "hbm",
+        t_rows = (C - min(C, t_c0 // 8 * 8)) * 49
+        nbytes = R * K1 * es + R * t_rows * es + nhwc.numel() * es + rois.numel() * 4
+        out.append({"kernel": "roi_pool7_map64_kernel (ROIPool + objectness scale -> A [R x %d] and A^T rows %d..%d)" % (K1, K1 - t_rows, K1),
+                    "bound": "hbm",
                     "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
                     "bytes_per_launch": nbytes, "avg_launch_ms": t * 1e3})
         D1 = heads.box_head.fc1.weight.shape[0]
@@ -608,7 +616,7 @@ def main():
         if pool:
             ms = sum(t for t, _ in pool) / len(pool)
             nb = pool[0][1]
-            in_step.append({"kernel": "roi_pool7_map64_kernel (ROIPool + objectness scale -> A and A^T), in step", "bound": "hbm",
+            in_step.append({"kernel": "roi_pool7_map64_kernel (ROIPool + objectness scale -> A and the A^T tail rows), in step", "bound": "hbm",
                             "achieved": nb / ms / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": nb / ms / 1e6 / 8000.0,
                             "bytes_per_launch": nb, "avg_launch_ms": ms, "min_launch_ms": min(t for t, _ in pool),
                             "max_launch_ms": max(t for t, _ in pool), "launches_timed": len(pool)})
