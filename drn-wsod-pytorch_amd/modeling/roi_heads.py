@@ -1120,6 +1120,13 @@ class OICRROIHeads(ROIHeads):
                                      bg_first=getattr(self, "refine_mode", "oicr") == "pcl")
             boxes = ops.apply_deltas(None, props, K, last.box2box_transform.weights)
         results, all_scores, all_boxes = [], [], []
+        if getattr(self, "scores_only", False):
+            # GeneralizedRCNNWithTTAAVG's per-augmentation passes use all_scores / all_boxes alone
+            # (test_time_augmentation_avg.py:269-294 drops the first return value): no threshold / sort / NMS per pass
+            for s, b in zip(probs.split(nper), boxes.split(nper)):
+                all_scores.append(s.unsqueeze(0))
+                all_boxes.append(b.unsqueeze(0))
+            return None, all_scores, all_boxes
         for p, s, b in zip(proposals, probs.split(nper), boxes.split(nper)):
             ob, os_, oc, _ = ops.detect_topk(b, s, p.image_size, last.test_score_thresh, last.test_nms_thresh,
                                              last.test_topk_per_image)

@@ -141,9 +141,15 @@ class GeneralizedRCNNWithTTAAVG(nn.Module):
         """:269-294, on the device: running means of the back-transformed boxes and of the scores"""
         acc_b = acc_s = None
         n = len(augmented_inputs)
+        heads = self.model.roi_heads
         for i, inp in enumerate(augmented_inputs):
             sx, sy, flip_w = inp["tta"]
-            _, scores, boxes = self.model.inference([{k: v for k, v in inp.items() if k != "tta"}], do_postprocess=False)
+            # the per-pass detections are never used here (the reference computes and drops them): skip the inference tail
+            prev, heads.scores_only = getattr(heads, "scores_only", False), True
+            try:
+                _, scores, boxes = self.model.inference([{k: v for k, v in inp.items() if k != "tta"}], do_postprocess=False)
+            finally:
+                heads.scores_only = prev
             b, s = boxes[0][0].contiguous(), scores[0][0].contiguous()
             if acc_b is None:
                 acc_b, acc_s = torch.empty_like(b), torch.empty_like(s)

@@ -21,6 +21,7 @@ bench.init_weights(model, seed=0)
 model.eval()
 R = 2000
 model.backbone.use_plan = os.environ.get("INFER_PLAN", "1") == "1"
+model.roi_heads.scores_only = os.environ.get("INFER_SCORES_ONLY", "0") == "1"  # what a TTA pass runs (no per-pass NMS)
 SIZES = [tuple(int(v) for v in s.split("x")) for s in os.environ.get("INFER_SIZES", "224x224,480x640,688x920,1200x1600").split(",")]
 for (H, W) in SIZES:
     g = torch.Generator().manual_seed(1)
