@@ -161,6 +161,7 @@ class FusedSGD:
                         raise DrnError("sharded exchange: every fc6 row slab must split evenly over the %d ranks "
                                        "(slab %d:%d)" % (world, r0, r1))
                     self._sharded = False  # default mode: fall back to the all-reduce for shapes that do not divide
+                    self._fallback = "fc6 row slab %d:%d does not split evenly over %d ranks" % (r0, r1, world)
                 r0 = r1
             # the all-gather lands in the flat bf16 shadow arena, which is the forward's fc6 operand only when a row of
             # fc1.weight needs no K padding (C*P*P a multiple of the 128-byte slab); a padded operand is its own buffer,
@@ -171,6 +172,13 @@ class FusedSGD:
                     raise DrnError("sharded exchange: fc1.weight rows of %d elements are K-padded in the bf16 compute copy; "
                                    "use exchange='allreduce'" % k1)
                 self._sharded = False
+                self._fallback = "fc1.weight rows of %d elements are K-padded in the bf16 compute copy" % k1
+        if world > 1 and exchange is None and not self._sharded:
+            # (this used to be silent) the default exchange for N > 1 is the sharded one
+            import warnings
+
+            warnings.warn("FusedSGD.enable_pipelined: the sharded gradient exchange does not apply (%s); using the "
+                          "all-reduce exchange - every rank runs the full optimizer pass" % getattr(self, "_fallback", "?"))
         self._master_stale = False
         if self._sharded:
             self._install_state_dict_hook()

@@ -141,7 +141,9 @@ class Backbone(nn.Module):
 
     def _plan_for(self, dtype, cin):
         convs = self.conv_modules()
-        cfg = tuple([id(m._fp8) for m in convs])
+        # (fp8 configuration, pack generation) of every conv: Conv2d.invalidate_packs() - DataParallel.broadcast_parameters
+        # and the trunk optimizer write `.data` in place, which bumps no `_version` - must drop the recorded pack pointers too
+        cfg = tuple([(id(m._fp8), m.__dict__.get("_pack_gen", 0)) for m in convs])
         plans = self.__dict__.setdefault("_plans", {})
         p = plans.get((dtype, cin))
         if p is not None and p["cfg"] == cfg and p["versions"] == [t._version for t in p["srcs"]]:

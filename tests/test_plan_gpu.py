@@ -63,6 +63,13 @@ def test_plan_follows_weight_updates():
     a1, b1 = _both(model, xs[0])
     k = next(iter(a0))
     assert torch.equal(a1[k], b1[k]) and not torch.equal(a0[k], a1[k])
+    # a write through `.data` bumps no version counter (DataParallel.broadcast_parameters, the trunk optimizer): those
+    # callers drop the packs with Conv2d.invalidate_packs(), which must drop the plan's recorded pack pointers as well
+    with torch.no_grad():
+        bb.res3[0].conv2.weight.data.mul_(0.5)
+    bb.res3[0].conv2.invalidate_packs()
+    a1b, b1b = _both(model, xs[0])
+    assert torch.equal(a1b[k], b1b[k]) and not torch.equal(a1b[k], a1[k])
     model.float()  # Module._apply: parameters / buffers may have moved - the plans are dropped
     assert "_plans" not in bb.__dict__
     a2, b2 = _both(model, xs[1])
