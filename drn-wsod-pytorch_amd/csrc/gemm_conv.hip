@@ -1901,6 +1901,7 @@ int drn_roi_set_map64(int on);        // pool.hip
 int drn_roi_set_chunks(int cpb);      // pool.hip
 int drn_roi_set_prefetch(int on);     // pool.hip
 int drn_roi_set_map64_a(int on);      // pool.hip
+int drn_roi_set_lds_kb(int kb);       // pool.hip
 int drn_tune(int knob, int value) {
   if (knob == 1) {  // DRN_TUNE_GEMM_PERSISTENT
     const int old = g_persistent;
@@ -1912,6 +1913,7 @@ int drn_tune(int knob, int value) {
   if (knob == 10) return drn_roi_set_chunks(value);    // DRN_TUNE_ROI_CPB
   if (knob == 11) return drn_roi_set_prefetch(value);  // DRN_TUNE_ROI_PREFETCH
   if (knob == 14) return drn_roi_set_map64_a(value);   // DRN_TUNE_ROI_MAP64_A
+  if (knob == 15) return drn_roi_set_lds_kb(value);    // DRN_TUNE_ROI_LDS_KB
   if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
     const int old = g_conv_ksplit;
     g_conv_ksplit = value != 0;

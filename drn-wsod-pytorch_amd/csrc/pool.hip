@@ -913,10 +913,13 @@ static int g_roi_cpb = 1;  // drn_tune(DRN_TUNE_ROI_CPB): most 8-channel chunks 
 static int g_roi_pf = 1;   // drn_tune(DRN_TUNE_ROI_PREFETCH): 0/1 - second map buffer, next chunk's slice fetched under the scan
 static int g_roi_map64 = 512;  // drn_tune(DRN_TUNE_ROI_MAP64): 0 = off, else threads per block (256 / 512 / 1024)
 
+static int g_roi_lds_kb = 154;  // drn_tune(DRN_TUNE_ROI_LDS_KB = 15)
 static bool launch_roi_map64(const RoiParams& p0, hipStream_t st) {
   RoiParams p = p0;
   if (!g_roi_map64 || p.C % G64_CH || p.H > 255 || p.W > 255) return false;
-  const size_t tile_b = (size_t)ROI_G64 * G64_PITCH, budget = 154 * 1024 - tile_b;  // (+ ~1.5 KB of static LDS)
+  // LDS a block may take for its map slice + result tile (+ ~1.5 KB static): 154 KB = one block per CU with the whole
+  // slice of maps up to ~80x80; DRN_TUNE_ROI_LDS_KB = 76 stages larger maps in bands so that TWO blocks share a CU
+  const size_t tile_b = (size_t)ROI_G64 * G64_PITCH, budget = (size_t)g_roi_lds_kb * 1024 - tile_b;
   size_t map_b = ((size_t)p.H * p.W * 16 + 15) & ~(size_t)15;
   p.lds_px = p.H * p.W;
   if (map_b > budget) {  // bands of whole rows
@@ -1074,6 +1077,12 @@ static int g_roi_map64_a = 0;  // drn_tune(DRN_TUNE_ROI_MAP64_A = 14): 1 = the 6
 int drn_roi_set_map64_a(int on) {
   const int old = g_roi_map64_a;
   g_roi_map64_a = on != 0;
+  return old;
+}
+
+int drn_roi_set_lds_kb(int kb) {
+  const int old = g_roi_lds_kb;
+  if (kb >= 60 && kb <= 154) g_roi_lds_kb = kb;
   return old;
 }
 

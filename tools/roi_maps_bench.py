@@ -4,7 +4,10 @@ from __graft_entry__ import load_package
 load_package()
 ops = importlib.import_module("drn_wsod_pytorch_amd.ops")
 dev = "cuda"
-for (H, W, R) in ((14, 14, 2000), (43, 58, 1800), (63, 92, 1947), (75, 122, 1500)):
+for kv in sys.argv[1:]:  # tune knobs: 15=76 (LDS budget), 4=1024 (threads), 10=4 (chunks per block) ...
+    ops.tune(*[int(x) for x in kv.split("=")])
+TAIL = os.environ.get("ROI_TAIL", "1") == "1"  # what the training step launches: A + the A^T rows of channels >= 1000
+for (H, W, R) in ((14, 14, 2000), (43, 58, 1800), (50, 76, 2000), (63, 92, 1947), (75, 122, 1500)):
     C = 1024
     feat = torch.randn((1, H, W, C), device=dev).to(torch.bfloat16)
     g = torch.Generator().manual_seed(0)
@@ -16,7 +19,7 @@ for (H, W, R) in ((14, 14, 2000), (43, 58, 1800), (63, 92, 1947), (75, 122, 1500
     K = C * 49
     A = torch.zeros((R, K), dtype=torch.bfloat16, device=dev)
     AT = torch.zeros((K, ops.kpad(R, torch.bfloat16)), dtype=torch.bfloat16, device=dev)
-    f = lambda: ops.roi_pool_nhwc(feat, rois, obj, 7, 1 / 16, out=A, out_t=AT)
+    f = lambda: ops.roi_pool_nhwc(feat, rois, obj, 7, 1 / 16, out=A, out_t=AT, t_first_channel=1000 if TAIL else 0)
     for _ in range(3): f()
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record()
