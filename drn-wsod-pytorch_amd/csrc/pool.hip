@@ -797,11 +797,35 @@ __global__ __launch_bounds__(JMAX >= 13 ? 256 : JMAX >= 7 ? 512 : 1024, JMAX >= 
         const int y1 = min(p.H, y0 + band_rows), npx = (y1 - y0) * p.W;
         const char* fbb = fb + (long)y0 * p.W * p.C * 2;
         if (!(p.pf && r0 == 0)) {  // (prefetch mode: the first run's slice is in LDS already, behind a barrier)
-          for (int px = tid; px < npx; px += nthr) {
-            i32x4_t x = *(const i32x4_t*)(fbb + (long)px * p.C * 2);
+          // four pixels per thread and trip, all four loads issued before the first conversion: at real map sizes (50x76:
+          // 3800 pixels of 16 bytes, 2 KB apart) the one-pixel loop waited out a full memory latency per pixel -
+          // 47 of the launch's 256 us there (knock-outs, profiles/r3_23_roi_large_maps.txt)
+          // (JMAX <= 4 = the 1024-thread variant these maps take; in the 512-thread variant of the 14x14 .. 38x38 maps the
+          // extra live registers would spill at its 128-register cap, and its slice comes from the prefetch path anyway)
+          if (JMAX > 4) {
+            for (int px = tid; px < npx; px += nthr) {
+              i32x4_t x = *(const i32x4_t*)(fbb + (long)px * p.C * 2);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
-            *(i32x4_t*)(map + (long)px * 16) = x;
+              for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
+              *(i32x4_t*)(map + (long)px * 16) = x;
+            }
+          } else
+          for (int px0 = tid; px0 < npx; px0 += 4 * nthr) {
+            i32x4_t x[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int px = px0 + q * nthr;
+              if (px < npx) x[q] = *(const i32x4_t*)(fbb + (long)px * p.C * 2);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const int px = px0 + q * nthr;
+              if (px < npx) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[q][e] = bf16x2_order(x[q][e]);
+                *(i32x4_t*)(map + (long)px * 16) = x[q];
+              }
+            }
           }
           __syncthreads();
         }
@@ -813,7 +837,14 @@ __global__ __launch_bounds__(JMAX >= 13 ? 256 : JMAX >= 7 ? 512 : 1024, JMAX >= 
             const int ws = win[j] >> 16 & 0xff, we = win[j] >> 24 & 0xff;
             for (int h = hs; h < he; ++h) {
               const char* row = map + (long)((h - y0) * p.W) * 16;
-              for (int w = ws; w < we; ++w) {
+              int w = ws;
+              if (JMAX <= 4)
+              for (; w + 1 < we; w += 2) {  // two pixels per trip, both reads in flight before the first max
+                const i32x4_t x0 = *(const i32x4_t*)(row + w * 16), x1 = *(const i32x4_t*)(row + w * 16 + 16);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[j][e] = pk_max_i16(pk_max_i16(acc[j][e], x0[e]), x1[e]);
+              }
+              for (; w < we; ++w) {
                 const i32x4_t x = *(const i32x4_t*)(row + w * 16);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[j][e] = pk_max_i16(acc[j][e], x[e]);
