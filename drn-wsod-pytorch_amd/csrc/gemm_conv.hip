@@ -1810,6 +1810,7 @@ static int persistent_grid(long total) {
   return (nwg >= 8 && total > nwg) ? nwg : 0;
 }
 
+static int g_conv_coresident = 0;  // drn_tune(DRN_TUNE_CONV_CORESIDENT = 17): 1 = only kernels that fit beside a 256x256 GEMM workgroup
 static int g_conv_ksplit = 1;  // drn_tune(DRN_TUNE_CONV_KSPLIT): 0 = never use the 32x32 wave-K-split kernel
 static int g_conv_patch = 1;  // drn_tune(DRN_TUNE_CONV_PATCH): 0 = never use conv3x3_c64_kernel; > 1 = minimum pixels per image
 static long g_conv_patch_min = 32768;
@@ -1914,6 +1915,11 @@ int drn_tune(int knob, int value) {
   if (knob == 11) return drn_roi_set_prefetch(value);  // DRN_TUNE_ROI_PREFETCH
   if (knob == 14) return drn_roi_set_map64_a(value);   // DRN_TUNE_ROI_MAP64_A
   if (knob == 15) return drn_roi_set_lds_kb(value);    // DRN_TUNE_ROI_LDS_KB
+  if (knob == 17) {  // DRN_TUNE_CONV_CORESIDENT
+    const int old = g_conv_coresident;
+    g_conv_coresident = value != 0;
+    return old;
+  }
   if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
     const int old = g_conv_ksplit;
     g_conv_ksplit = value != 0;
@@ -2116,6 +2122,14 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   const long ks_max = g_conv_ks_tiles > 0 ? g_conv_ks_tiles : (nslab >= 32 ? cu_count() : cu_count() / 4);
   // LDS-resident patch + weights for the 64-channel 3x3 layers of large maps (conv3x3_c64_kernel; 117 KB of LDS, so only
   // where the trunk is not meant to share CUs with the heads' GEMMs: maps of >= 32k pixels)
+  if (g_conv_coresident) {  // A/B: the trunk made of kernels with <= 16 KB of LDS and <= ~100 VGPRs only (64x64 single-stage
+    // tile, 32x32 wave-K-split), which share a CU with a resident 256x256 GEMM workgroup instead of waiting for it
+    if (g_conv_ksplit && tiles64 <= ks_max && nslab >= 8 && Nb <= 64)
+      return dtype == DRN_BF16 ? launch_conv_ks<DRN_BF16>(p, st)
+             : dtype == DRN_FP8 ? launch_conv_ks<DRN_FP8>(p, st) : launch_conv_ks<DRN_F32>(p, st);
+    return dtype == DRN_BF16 ? launch_conv<DRN_BF16, 64, 64>(p, st)
+           : dtype == DRN_FP8 ? launch_conv<DRN_FP8, 64, 64>(p, st) : launch_conv<DRN_F32, 64, 64>(p, st);
+  }
   if (g_conv_patch && dtype == DRN_BF16 && out_dtype == DRN_BF16 && (!residual || res_dtype == DRN_BF16) && Cin == 64 &&
       Cout == 64 && KH == 3 && KW == 3 && stride == 1 && dil == 1 && pad == 1 && (long)Ho * Wo >= g_conv_patch_min &&
       (ldy & 7) == 0 && (((uintptr_t)y) & 15) == 0 && (!residual || ((ldres & 7) == 0 && (((uintptr_t)residual) & 15) == 0)) &&

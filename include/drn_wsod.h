@@ -183,6 +183,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_ROI_CPB 10 /* 64-ROI ROIPool: most 8-channel chunks one workgroup walks (power of two, default 1; halved until two workgroups per CU remain): bin bounds / item table once per workgroup - faster stand-alone (4-8), slower inside the training step */
 #define DRN_TUNE_ROI_PREFETCH 11 /* 0/1 (default 1): 64-ROI ROIPool keeps two map-slice buffers and fetches the next chunk's slice under the scan */
 #define DRN_TUNE_GEMM_PINGPONG 12 /* 0/1 (default 1): bf16 256x256 GEMMs run the ping-pong mainloop - the two waves of a SIMD half a phase apart, four [reads + DMA | 8 MFMAs] phases per K slab, half-tile LDS-DMA spread over the slab; bit-identical to the lock-step pipeline it replaces (0) */
+#define DRN_TUNE_CONV_CORESIDENT 17 /* 0/1 (default 0): convolutions only on the kernels that share a CU with a resident 256x256 GEMM workgroup (64x64 single-stage tile, 32x32 wave-K-split) - A/B for the trunk beside the fc6 GEMMs at real image sizes */
 #define DRN_TUNE_ROI_LDS_KB 15 /* 60..154 (default 154): LDS a 64-ROI pooling block may take for map slice + tile; 76 stages larger maps in row bands so that two blocks share a CU */
 #define DRN_TUNE_ROI_MAP64_A 14 /* 0/1 (default 0): the 64-ROI ROIPool kernel also when only A is asked for (no A^T) */
 #define DRN_TUNE_FP8_K64 13 /* 0/1 (default 1): fp8 convolutions multiply with v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales; the fp8 MFMA rate) instead of the K = 16 non-scaled form (bf16 rate); same exact products, another fp32 summation order */
