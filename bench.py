@@ -276,6 +276,8 @@ def main():
     ap.add_argument("--fused-sgd", action="store_true",
                     help="N=1 only: fc6 dW GEMM with the SGD update as its epilogue (drn_gemm_nt_sgd; measured "
                          "neutral: its HBM-heavy epilogues run in lock-step across CUs, see DESIGN.md)")
+    ap.add_argument("--no-fc7-pair", action="store_true",
+                    help="A/B: fc7 weight gradient and fc7 dX as two launches instead of one paired persistent launch")
     ap.add_argument("--fc1-nt", action="store_true",
                     help="A/B: the fc6 weight gradient in its NT form on a fully materialised A^T (round 2) instead of "
                          "reading the pooled matrix itself through drn_gemm_tn")
@@ -378,6 +380,8 @@ def main():
                                                                   for k, v in selftest.items()), file=sys.stderr, flush=True)
     if args.fc1_nt:
         model.roi_heads._engine.fc1_tn = False
+    if args.no_fc7_pair:
+        model.roi_heads._engine.fc7_bwd_pair = False
     if not args.no_pipelined_sgd:
         # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,

@@ -875,9 +875,16 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
 // dispatcher's round-robin, so the L2 reuse pattern of the XCD patch mapping is unchanged.
 struct GemmWork { int bm, bn, s0, s1, split; __amdgpu_buffer_rsrc_t ra, rb; };  // one (tile, K-split) work item
 
-template <int DT, bool SGD, int PP = 0, bool TN = false>
-__global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
+// PAIR (round 3): TWO independent GEMMs in one persistent launch - the first `pair_wg0` workgroups of every XCD walk
+// problem 0, the others problem 1 (drn_gemm_nt_pair splits them by work).  For two launches that each leave CUs idle:
+// the fc7 weight gradient (128 tiles: half the CUs in one round) and the fc7 dX (64 tiles x 4 K-splits of half the
+// length), 46 + 41 us one after the other.  (Two concurrent launches on a forked stream do the same on paper and cost
+// 250 us in the captured step: the graph executor starts the branch late.)
+template <int DT, bool SGD, int PP = 0, bool TN = false, bool PAIR = false>
+__global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p_in, GemmParams p2_in, int pair_wg0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  const bool second = PAIR && (int)(blockIdx.x >> 3) >= pair_wg0;
+  const GemmParams p = second ? p2_in : p_in;
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
   constexpr int BM = 256, BN = 256, MI = 4, NJ = 2;
   constexpr int A_BYTES = BM * 128, STAGE = (BM + BN) * 128;
@@ -888,11 +895,12 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 2, wn = wave & 3;
-  const int bid = blockIdx.x, per = gridDim.x >> 3;
+  const int bid = blockIdx.x;
+  const int per = PAIR ? (second ? (int)(gridDim.x >> 3) - pair_wg0 : pair_wg0) : (int)(gridDim.x >> 3);
   const int xcd = bid & 7, q = total >> 3, r = total & 7;
   const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
   const int len = q + (xcd < r ? 1 : 0);
-  int j = bid >> 3;
+  int j = PAIR ? (second ? (bid >> 3) - pair_wg0 : (bid >> 3)) : (bid >> 3);
   if (j >= len) return;
   const unsigned lda_b = (unsigned)(p.lda * ES), ldb_b = (unsigned)(p.ldb * ES);
   unsigned voa[4], vob[4];
@@ -1786,7 +1794,21 @@ int launch_gemm256p(const GemmParams& p, int nwg, hipStream_t st) {
       return DRN_ERR_LAUNCH;
     attr = true;
   }
-  hipLaunchKernelGGL(k, dim3(nwg), dim3(512), smem, st, p);
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(512), smem, st, p, p, 0);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+static int launch_gemm256p_pair(const GemmParams& p0, const GemmParams& p1, int nwg, int wg0, hipStream_t st) {
+  constexpr int smem = 2 * 512 * 128;
+  auto k = gemm_nt256p_kernel<DRN_BF16, false, 1, false, true>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DRN_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(512), smem, st, p0, p1, wg0);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }
@@ -2065,6 +2087,44 @@ int drn_gemm_tn(const void* A, const void* Bt, void* C, int M, int N, int K, int
   const long wg256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
   if (const int nwg = persistent_grid(wg256)) return launch_gemm256p<DRN_BF16, false, 1, true>(p, nwg, st);
   return launch_gemm256<DRN_BF16, true, false, 1, true>(p, splits, st);
+}
+
+// Two independent NT GEMMs (bf16 operands, fp32 outputs) in ONE persistent launch of the 256x256 ping-pong kernel: the
+// workgroups of every XCD are divided between the problems in proportion to their work.  Same kernel arithmetic as two
+// drn_gemm_nt calls (bit-identical).  Falls back to two calls when a problem is empty or the device has no 8-XCD grid.
+int drn_gemm_nt_pair(const void* A0, const void* B0, void* C0, int M0, int N0, int K0, long lda0, long ldb0, long ldc0,
+                     int splits0, long stride0, int accumulate0, const void* A1, const void* B1, void* C1, int M1, int N1,
+                     int K1, long lda1, long ldb1, long ldc1, int splits1, long stride1, int accumulate1, void* stream) {
+  auto two_calls = [&]() {
+    const int rc = drn_gemm_nt(A0, B0, C0, M0, N0, K0, lda0, ldb0, ldc0, DRN_BF16, DRN_F32, splits0, stride0, accumulate0, stream);
+    return rc != DRN_OK ? rc
+                        : drn_gemm_nt(A1, B1, C1, M1, N1, K1, lda1, ldb1, ldc1, DRN_BF16, DRN_F32, splits1, stride1, accumulate1, stream);
+  };
+  if (M0 <= 0 || N0 <= 0 || M1 <= 0 || N1 <= 0 || !g_persistent || g_pingpong != 1 || g_force_tile == 64 || g_force_tile == 128)
+    return two_calls();
+  auto ok = [](const void* A, const void* B, void* C, int K, long lda, long ldb, int splits, int acc) {
+    return A && B && C && K > 0 && (K * 2) % 128 == 0 && (lda * 2) % 16 == 0 && (ldb * 2) % 16 == 0 && lda >= K && ldb >= K &&
+           !(((uintptr_t)A | (uintptr_t)B) & 15) && !(((uintptr_t)C) & 3) && splits >= 1 && !(splits > 1 && acc);
+  };
+  if (!ok(A0, B0, C0, K0, lda0, ldb0, splits0, accumulate0) || !ok(A1, B1, C1, K1, lda1, ldb1, splits1, accumulate1))
+    return DRN_ERR_ARG;
+  auto mk = [](const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int splits, long stride,
+               int acc) {
+    const int nslab = K * 2 / 128;
+    GemmParams p{(const char*)A, (const char*)B, (float*)C, M, N, K, lda, ldb, ldc, (nslab + splits - 1) / splits, stride, acc};
+    p.nsplit = splits;
+    p.gm = gemm256_group_rows(M, N, splits);
+    return p;
+  };
+  const GemmParams p0 = mk(A0, B0, C0, M0, N0, K0, lda0, ldb0, ldc0, splits0, stride0, accumulate0);
+  const GemmParams p1 = mk(A1, B1, C1, M1, N1, K1, lda1, ldb1, ldc1, splits1, stride1, accumulate1);
+  const int nwg = (cu_count() / 8) * 8, per = nwg / 8;
+  if (per < 2) return two_calls();
+  const double w0 = (double)((M0 + 255) / 256) * ((N0 + 255) / 256) * splits0 * p0.k_slabs_per_split;
+  const double w1 = (double)((M1 + 255) / 256) * ((N1 + 255) / 256) * splits1 * p1.k_slabs_per_split;
+  int wg0 = (int)(per * w0 / (w0 + w1) + 0.5);
+  wg0 = wg0 < 1 ? 1 : (wg0 > per - 1 ? per - 1 : wg0);
+  return launch_gemm256p_pair(p0, p1, nwg, wg0, (hipStream_t)stream);
 }
 
 // W[M,N] <- SGD(W, momentum_buf, G = A[M,K] * B[N,K]^T) with G kept in registers.  See include/drn_wsod.h.

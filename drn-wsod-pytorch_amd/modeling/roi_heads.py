@@ -813,7 +813,6 @@ class _HeadEngine:
         # fc7
         ops.bias_act_bwd(w["dH2"], M, D2, saved=w["H2"], mask=st["masks"][1] if st["masks"] else None,
                          drop_p=st["drop_p"], dpre=w["dP2"], dpreT=w["dP2T"], **colsum_args(1, D2, self._gview("fc2.bias")))
-        ops.gemm_nt(w["dP2T"], w["H1T"], D2, D1, Mp, out=self._gview("fc2.weight", (1, D2, D1)), accumulate=acc)
         # fc7 dX: [M, D1] over K = D2 is too few 256x256 tiles for one pass (64 at R = 2000) - split K like the forward
         # GEMMs and let the activation backward behind it sum the partials (63 -> ~45 us at the bench shape)
         s1 = self._splits(M, D1, kp(D2), dtype) if getattr(self, "fc7_dx_split", True) else 1
@@ -821,7 +820,15 @@ class _HeadEngine:
             base = self._ws[(dtype, True)]
             base["bufs"]["dH1"] = torch.zeros((s1, base["cap"], D1), dtype=torch.float32, device=dev)
             w["dH1"] = base["views"]["dH1"] = base["bufs"]["dH1"][:, :M]
-        ops.gemm_nt(w["dP2"], sh["W2T"], M, D1, kp(D2), out=w["dH1"], splits=s1)
+        g_w = dict(A=w["dP2T"], B=w["H1T"], M=D2, N=D1, K=Mp, out=self._gview("fc2.weight", (1, D2, D1)), accumulate=acc)
+        g_x = dict(A=w["dP2"], B=sh["W2T"], M=M, N=D1, K=kp(D2), out=w["dH1"], splits=s1)
+        if dtype == torch.bfloat16 and getattr(self, "fc7_bwd_pair", True):
+            # fc7 weight gradient and fc7 dX are independent (both read dP2) and each leaves CUs idle on its own (128 tiles;
+            # 64 tiles x 4 short K-splits): ONE persistent launch whose workgroups are divided between the two (round 3)
+            ops.gemm_nt_pair(g_w, g_x)
+        else:
+            ops.gemm_nt(g_w["A"], g_w["B"], D2, D1, Mp, out=g_w["out"], accumulate=acc)
+            ops.gemm_nt(g_x["A"], g_x["B"], M, D1, kp(D2), out=w["dH1"], splits=s1)
         # fc6 (the backbone is frozen: no dX)
         fg = st.get("fg")
         if fg is not None and ("dP1" not in w or w["dP1"].shape != w["H1"].shape):

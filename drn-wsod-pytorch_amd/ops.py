@@ -68,6 +68,25 @@ def gemm_nt(A, B, M, N, K, out=None, splits=1, accumulate=False):
     return out
 
 
+def gemm_nt_pair(g0, g1):
+    """two independent gemm_nt problems in one persistent launch (drn_gemm_nt_pair); g = dict(A, B, M, N, K, out,
+    splits=1, accumulate=False) with fp32 `out` [splits, M, N]"""
+    args = []
+    for g in (g0, g1):
+        A, B, out = g["A"], g["B"], g["out"]
+        assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and out.dtype == torch.float32 and out.dim() == 3
+        s_ = int(g.get("splits", 1))
+        args += [C.ptr(A), C.ptr(B), C.ptr(out), int(g["M"]), int(g["N"]), int(g["K"]), _2d(A), _2d(B), out.stride(-2), s_,
+                 out.stride(0), int(bool(g.get("accumulate", False)))]
+    if GEMM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    C.call("drn_gemm_nt_pair", *args, C.stream())
+    if GEMM_TIMING is not None:
+        e1.record()
+        GEMM_TIMING.append((e0, e1, 2.0 * (g0["M"] * g0["N"] * g0["K"] + g1["M"] * g1["N"] * g1["K"]), ("pair",)))
+
+
 def gemm_tn(A, Bt, M, N, K, kb_rows, out=None, splits=1, accumulate=False):
     """C[s,M,N] = A[M,:K] @ Bt[:K,:N] with the second operand K-major (Bt [kb_rows, ldb] row-major; rows kb_rows..K-1
     count as zeros and need not exist): drn_gemm_tn, bf16 operands.  The fc6 weight gradient reads the pooled matrix

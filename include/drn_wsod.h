@@ -144,6 +144,15 @@ long drn_gemm_nt_main_cols(int M, int N, int splits);
 int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long lda, long ldb, long ldc, int dtype,
                 int c_dtype, int splits, long c_split_stride, int accumulate, void* stream);
 
+/* drn_gemm_nt_pair: two independent drn_gemm_nt problems (bf16 operands, fp32 outputs; splits / accumulate per problem
+ * as there) in ONE persistent launch of the 256x256 kernel - the workgroups of every XCD are divided between the two
+ * problems in proportion to their work.  Serves pairs of launches that each leave CUs idle: the fc7 weight gradient and
+ * the fc7 input gradient of the explicit backward (torch.autograd of box_head.py:82-91's fc2: dW = dY^T X, dX = dY W,
+ * both from dY).  Bit-identical to the two separate calls. */
+int drn_gemm_nt_pair(const void* A0, const void* B0, void* C0, int M0, int N0, int K0, long lda0, long ldb0, long ldc0,
+                     int splits0, long stride0, int accumulate0, const void* A1, const void* B1, void* C1, int M1, int N1,
+                     int K1, long lda1, long ldb1, long ldc1, int splits1, long stride1, int accumulate1, void* stream);
+
 /* drn_gemm_tn: C[M,N] = A[M,K] . Bt[K,N] with the second operand given K-MAJOR (Bt row-major [kb_rows][ldb]; rows
  * kb_rows..K-1 - the K padding - are read as zeros and need not exist).  bf16 operands, fp32 accumulate, C fp32
  * (splits / accumulate as drn_gemm_nt) or bf16.  The fc6 weight gradient dW = dP1^T . A (the autograd of

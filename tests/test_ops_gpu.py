@@ -135,6 +135,35 @@ def test_gemm_persistent_equals_one_tile_grid(drn, dtype, M, N, K, splits):
         drn.gemm_set_tile(prev_tile)
 
 
+@pytest.mark.parametrize("shapes", [((4096, 2048, 2048, 1, True), (2000, 2048, 4096, 4, False)),
+                                    ((300, 500, 128, 1, False), (700, 260, 192, 2, False)),
+                                    ((2000, 2048, 4096, 4, False), (256, 256, 64, 1, True)),
+                                    ((1030, 4600, 320, 1, True), (1030, 4600, 320, 3, False))])
+def test_gemm_nt_pair_equals_two_calls(drn, shapes):
+    """drn_gemm_nt_pair: two independent NT GEMMs in one persistent launch (the workgroups of every XCD divided between
+    them by work) against the two separate 256x256 launches: same tiles, slab order and MFMA per output element, so
+    BIT-identical - the fc7 weight-gradient / input-gradient pair of the bench shape, ragged shapes, very unequal work,
+    accumulate and split-K outputs."""
+    dtype = torch.bfloat16
+    prev_tile = drn.gemm_set_tile(256)
+    try:
+        gs, refs = [], []
+        for i, (M, N, K, splits, acc) in enumerate(shapes):
+            A, B = _padded(_rnd((M, K), 41 + i), dtype, drn), _padded(_rnd((N, K), 51 + i), dtype, drn)
+            Kp = A.shape[1]
+            c0 = _rnd((splits, M, N), 61 + i).to(DEV)
+            ref = c0.clone()
+            drn.gemm_nt(A, B, M, N, Kp, out=ref, splits=splits, accumulate=acc)
+            refs.append(ref)
+            gs.append(dict(A=A, B=B, M=M, N=N, K=Kp, out=c0.clone(), splits=splits, accumulate=acc))
+        drn.gemm_nt_pair(gs[0], gs[1])
+        torch.cuda.synchronize()
+        for g, ref in zip(gs, refs):
+            assert torch.equal(g["out"], ref)
+    finally:
+        drn.gemm_set_tile(prev_tile)
+
+
 @pytest.mark.parametrize("M,N,Kb,splits", [(256, 256, 64, 1), (1024, 6400, 2000, 1), (700, 1000, 130, 1), (2048, 1024, 2000, 1),
                                            (512, 33000, 200, 1), (1000, 2304, 700, 3), (2048, 25088, 37, 1)])
 def test_gemm_tn_equals_nt_on_the_transpose(drn, M, N, Kb, splits):
