@@ -276,6 +276,7 @@ def main():
     ap.add_argument("--fused-sgd", action="store_true",
                     help="N=1 only: fc6 dW GEMM with the SGD update as its epilogue (drn_gemm_nt_sgd; measured "
                          "neutral: its HBM-heavy epilogues run in lock-step across CUs, see DESIGN.md)")
+    ap.add_argument("--fc7-dx-splits", type=int, default=0, help="A/B: K-splits of the fc7 dX inside the paired launch (0 = heuristic)")
     ap.add_argument("--no-fc7-pair", action="store_true",
                     help="A/B: fc7 weight gradient and fc7 dX as two launches instead of one paired persistent launch")
     ap.add_argument("--fc1-nt", action="store_true",
@@ -382,6 +383,8 @@ def main():
         model.roi_heads._engine.fc1_tn = False
     if args.no_fc7_pair:
         model.roi_heads._engine.fc7_bwd_pair = False
+    if args.fc7_dx_splits:
+        model.roi_heads._engine.fc7_pair_dx_splits = args.fc7_dx_splits
     if not args.no_pipelined_sgd:
         # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,

@@ -816,13 +816,20 @@ class _HeadEngine:
         # fc7 dX: [M, D1] over K = D2 is too few 256x256 tiles for one pass (64 at R = 2000) - split K like the forward
         # GEMMs and let the activation backward behind it sum the partials (63 -> ~45 us at the bench shape)
         s1 = self._splits(M, D1, kp(D2), dtype) if getattr(self, "fc7_dx_split", True) else 1
+        pair = dtype == torch.bfloat16 and getattr(self, "fc7_bwd_pair", True)
+        if pair:
+            # in the paired launch the dX has about half the CUs to fill: as many (tile, K-split) items as that, not as the
+            # whole chip - half the partial sums to write and for the activation backward to read (R50-C4: 4 -> 2 splits,
+            # +1.3 % same box, profiles/r3_27)
+            t256 = ((M + 255) // 256) * ((D1 + 255) // 256)
+            s1 = getattr(self, "fc7_pair_dx_splits", 0) or max(1, min(s1, 128 // max(t256, 1)))
         if w["dH1"].shape[0] != s1:
             base = self._ws[(dtype, True)]
             base["bufs"]["dH1"] = torch.zeros((s1, base["cap"], D1), dtype=torch.float32, device=dev)
             w["dH1"] = base["views"]["dH1"] = base["bufs"]["dH1"][:, :M]
         g_w = dict(A=w["dP2T"], B=w["H1T"], M=D2, N=D1, K=Mp, out=self._gview("fc2.weight", (1, D2, D1)), accumulate=acc)
         g_x = dict(A=w["dP2"], B=sh["W2T"], M=M, N=D1, K=kp(D2), out=w["dH1"], splits=s1)
-        if dtype == torch.bfloat16 and getattr(self, "fc7_bwd_pair", True):
+        if pair:
             # fc7 weight gradient and fc7 dX are independent (both read dP2) and each leaves CUs idle on its own (128 tiles;
             # 64 tiles x 4 short K-splits): ONE persistent launch whose workgroups are divided between the two (round 3)
             ops.gemm_nt_pair(g_w, g_x)
