@@ -74,7 +74,9 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
   if (!BWD && p.seed_dev && p.drop_p <= 0.f && !p.mask && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     *const_cast<unsigned long long*>(p.seed_dev) += p.seed;  // no dropout here: this launch ADVANCES the mask counter
   for (int mb = mb0; mb < mb1; mb += 64) {
-#pragma unroll 4
+    // (all 16 row steps of a thread unrolled: the skinny backward head - dlogits [2000 x 103] -> dS, dS^T, column sums, 64
+    // workgroups - is latency-bound, its loads should all be in flight)
+#pragma unroll 16
     for (int i = ty; i < RSTEP; i += 4) {
       const int m = mb + i;
       float v = 0.f;
