@@ -255,6 +255,9 @@ def main():
                          "r101c4_k80 +40 %); this flag goes back to one chain per batch (--lookahead)")
     ap.add_argument("--slab-rows", default=None,
                     help="comma-separated row ends of the fc6 dW slabs (experiment knob; default = the engine's choice)")
+    ap.add_argument("--col-rounds", type=int, default=None,
+                    help="N=1: fc6 dW in COLUMN slabs of this many exact rounds of the persistent GEMM, each updated by the "
+                         "optimizer the moment it is queued (0 = the two row slabs of round 3)")
     ap.add_argument("--ims-per-gpu", type=int, default=1,
                     help="images per GPU per iteration; 1 = the reference's operating point and the headline metric, "
                          "larger values are the side measurement SURVEY 8(d) asks for")
@@ -389,7 +392,7 @@ def main():
         # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
                              comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype],
-                             exchange=args.exchange)
+                             exchange=args.exchange, col_rounds=args.col_rounds)
         if world == 1 and args.fused_sgd:
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
@@ -556,6 +559,24 @@ def main():
                        % (n0, K1, D1, Rtot, K1 - n0, Rtot), {(D1, K1 - n0, Mp)}, 2.0 * D1 * (K1 - n0) * Rtot)
             if e_:
                 launches.append(e_)
+        col_plan = model.roi_heads._engine._fc1_col_plan(torch.bfloat16, D1, K1) if not getattr(opt, "_exchange_on", False) else None
+        if col_plan is not None:
+            # column slabs (round 4): the trailing columns first, then slabs of exact rounds
+            n_main, wcols = col_plan
+            ends, n0 = [], K1
+            if n_main < K1:
+                e_ = entry("gemm_nt_kernel<bf16> fc6 dW trailing columns %d:%d of all rows  [%d x %d] . [%d x %d]^T"
+                           % (n_main, K1, D1, Rtot, K1 - n_main, Rtot), {(D1, K1 - n_main, Mp)}, 2.0 * D1 * (K1 - n_main) * Rtot)
+                if e_:
+                    launches.append(e_)
+            widths = [min(n_main, c + wcols) - c for c in range(0, n_main, wcols)]
+            seen_w = {}
+            for i_, (c_, w_) in enumerate(zip(range(0, n_main, wcols), widths)):
+                e_ = entry("gemm_nt256p_kernel<bf16, TN> fc6 dW columns %d:%d  [%d x %d] . [%d x %d]" % (c_, c_ + w_, D1, Rtot, Rtot, w_),
+                           {(D1, w_, Mp)}, 2.0 * D1 * w_ * Rtot, nth=seen_w.get(w_, 0), of=widths.count(w_))
+                seen_w[w_] = seen_w.get(w_, 0) + 1
+                if e_:
+                    launches.append(e_)
         r0 = 0
         slab_rows = [b - a for a, b in zip([0] + list(ends[:-1]), ends)]
         seen = {}
@@ -636,6 +657,18 @@ def main():
                             "bound": "hbm", "achieved": nb / ms / 1e6, "peak": 8000.0, "unit": "GB/s",
                             "frac": nb / ms / 1e6 / 8000.0, "bytes_per_launch": nb, "avg_launch_ms": ms,
                             "min_launch_ms": min(slabs), "max_launch_ms": max(slabs), "launches_timed": len(slabs)})
+        blocks = [(a.elapsed_time(b), n_) for (a, b, n_, key) in hbm_timing if key[0] == "sgd_block"]
+        if blocks and world == 1:
+            # column-slab updates (drn_sgd_step_block, optimizer stream): all launches of the sampled steps together
+            per_param = 20 if getattr(opt, "_comm_dtype", None) == torch.bfloat16 else 22
+            ms = sum(t for t, _ in blocks)
+            nb = per_param * sum(n_ for _, n_ in blocks)
+            nstep = max(1, len(blocks) // max(1, len({k for (_, _, _, k) in hbm_timing if k[0] == "sgd_block"})))
+            in_step.append({"kernel": "sgd_block_kernel<shadow, bf16 grad> (fc6 column slabs, %d launches per step), in step"
+                                      % (len(blocks) // nstep), "bound": "hbm", "achieved": nb / ms / 1e6, "peak": 8000.0,
+                            "unit": "GB/s", "frac": nb / ms / 1e6 / 8000.0, "bytes_per_step": nb // nstep,
+                            "ms_per_step": ms / nstep, "min_launch_ms": min(t for t, _ in blocks),
+                            "max_launch_ms": max(t for t, _ in blocks), "launches_timed": len(blocks)})
         out["roofline_hbm_in_step"] = in_step
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batches)

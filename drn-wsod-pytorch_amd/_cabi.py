@@ -51,6 +51,7 @@ _SIGS = {
     "drn_apply_deltas": "plppiipfp",
     "drn_sum_small": "pifpp",
     "drn_sgd_step": "pppilpipififp",
+    "drn_sgd_step_block": "pppilpip" + "iiiil" + "fifp",
     "drn_detect_topk": "ppiii" + "ffff" + "i" + "pl" + "i" + "ppp",
     "drn_detect_gather": "plippippppp",
     "drn_csc_cpg": "piiiiippp",

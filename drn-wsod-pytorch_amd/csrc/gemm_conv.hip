@@ -1826,9 +1826,11 @@ static int gemm256_group_rows(int M, int N, int splits) {
 }
 
 // number of workgroups of the persistent launch, or 0 when the one-tile grid should be used
+static int g_nwg = 0;  // drn_tune(DRN_TUNE_GEMM_NWG = 18): resident workgroups of persistent launches (0 = one per CU); for launches
+                       // on a CU-masked stream (the GEMM on a subset of the CUs, an HBM-bound kernel on the others)
 static int persistent_grid(long total) {
   if (!g_persistent) return 0;
-  const int nwg = (cu_count() / 8) * 8;
+  const int nwg = g_nwg > 0 ? g_nwg : (cu_count() / 8) * 8;
   return (nwg >= 8 && total > nwg) ? nwg : 0;
 }
 
@@ -1919,12 +1921,12 @@ int drn_gemm_set_tile(int tile) {
 }
 
 // tuning knobs (A/B measurements and tests; defaults are the measured best).  Returns the previous value or -1.
-int drn_sgd_set_grid(int blocks_x);  // head.hip
-int drn_roi_set_map64(int on);        // pool.hip
-int drn_roi_set_chunks(int cpb);      // pool.hip
-int drn_roi_set_prefetch(int on);     // pool.hip
-int drn_roi_set_map64_a(int on);      // pool.hip
-int drn_roi_set_lds_kb(int kb);       // pool.hip
+__attribute__((visibility("hidden"))) int drn_sgd_set_grid(int blocks_x);  // head.hip
+__attribute__((visibility("hidden"))) int drn_roi_set_map64(int on);        // pool.hip
+__attribute__((visibility("hidden"))) int drn_roi_set_chunks(int cpb);      // pool.hip
+__attribute__((visibility("hidden"))) int drn_roi_set_prefetch(int on);     // pool.hip
+__attribute__((visibility("hidden"))) int drn_roi_set_map64_a(int on);      // pool.hip
+__attribute__((visibility("hidden"))) int drn_roi_set_lds_kb(int kb);       // pool.hip
 int drn_tune(int knob, int value) {
   if (knob == 1) {  // DRN_TUNE_GEMM_PERSISTENT
     const int old = g_persistent;
@@ -1976,6 +1978,11 @@ int drn_tune(int knob, int value) {
   if (knob == 13) {  // DRN_TUNE_FP8_K64
     const int old = g_fp8_k64;
     g_fp8_k64 = value != 0;
+    return old;
+  }
+  if (knob == 18) {  // DRN_TUNE_GEMM_NWG
+    const int old = g_nwg;
+    if (value >= 0 && value % 8 == 0 && value <= 4096) g_nwg = value;
     return old;
   }
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS

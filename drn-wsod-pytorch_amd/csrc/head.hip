@@ -803,6 +803,55 @@ __global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ w, float* 
   }
 }
 
+// The same update on a rectangular BLOCK of one 2-D parameter (rows r0..r1, columns c0..c1 of a [.., ld] tensor that starts at
+// arena element sg.off): the fc6 weight gradient leaves its GEMM in COLUMN slabs (one exact round of the persistent
+// kernel each, run_fc1_tail), and each slab's update starts the moment its GEMM is queued.  Arithmetic, access width
+// and cache policy are sgd_kernel's; only the index map differs (a row of the block is a contiguous run of cols / 4
+// 16-byte vectors).  c0, cols, ld, sg.off and goff are multiples of 4 (launcher).
+template <bool SHADOW, int GDT>
+__global__ __launch_bounds__(256) void sgd_block_kernel(float* __restrict__ w, float* __restrict__ mom,
+                                                        const void* __restrict__ gv, long goff, bf16_t* __restrict__ shadow,
+                                                        const SgdSeg* seg, int r0, int rows, int c0, int cols, long ld,
+                                                        float momentum, int first_step, float grad_scale) {
+  using GT = typename ElemOf<GDT>::type;
+  const GT* g = (const GT*)gv - goff;
+  const SgdSeg sg = seg[0];
+  const unsigned cv = (unsigned)cols >> 2, nvec = (unsigned)rows * cv;
+  const unsigned nthr = gridDim.x * blockDim.x;
+  for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < nvec; i += nthr) {
+    const unsigned r = i / cv, c = i - r * cv;
+    const long j = sg.off + (long)(r0 + (int)r) * ld + c0 + 4 * (long)c;
+    const f32x4_t pw = __builtin_nontemporal_load((const f32x4_t*)(w + j));
+    f32x4_t gg;
+    if constexpr (GDT == DRN_BF16) {
+      typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+      const u32x2_t x = __builtin_nontemporal_load((const u32x2_t*)(g + j));
+      gg = f32x4_t{__builtin_bit_cast(float, x.x << 16), __builtin_bit_cast(float, x.x & 0xffff0000u),
+                   __builtin_bit_cast(float, x.y << 16), __builtin_bit_cast(float, x.y & 0xffff0000u)};
+    } else {
+      gg = __builtin_nontemporal_load((const f32x4_t*)(g + j));
+    }
+    f32x4_t mm = {0.f, 0.f, 0.f, 0.f};
+    if (!first_step) mm = __builtin_nontemporal_load((const f32x4_t*)(mom + j));
+    f32x4_t nb, nw;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float d = gg[e] * grad_scale;
+      if (sg.wd != 0.f) d = d + sg.wd * pw[e];
+      nb[e] = first_step ? d : momentum * mm[e] + d;
+      nw[e] = pw[e] - sg.lr * nb[e];
+    }
+    __builtin_nontemporal_store(nb, (f32x4_t*)(mom + j));
+    __builtin_nontemporal_store(nw, (f32x4_t*)(w + j));
+    if (SHADOW) {
+      uint2 o;
+      o.x = (uint32_t)f32_to_bf16(nw[0]) | ((uint32_t)f32_to_bf16(nw[1]) << 16);
+      o.y = (uint32_t)f32_to_bf16(nw[2]) | ((uint32_t)f32_to_bf16(nw[3]) << 16);
+      *(uint2*)(shadow + j) = o;
+    }
+  }
+}
+
 __global__ void sum_small_kernel(const float* in, int n, float scale, float* out) {
   if (threadIdx.x == 0 && blockIdx.x == 0) {
     float s = 0.f;
@@ -1041,7 +1090,7 @@ int drn_apply_deltas(const float* deltas, long ld_d, const float* boxes, float* 
 // workgroups (x) of the optimizer kernel; each runs a grid-stride loop, i.e. lives for the whole launch.  At most two
 // 256-thread workgroups (34 VGPRs) fit on a CU beside a resident 256x256 GEMM workgroup - see drn_tune in gemm_conv.hip
 static int g_sgd_grid_x = 512;  // measured (tools/overlap_bench.py): 512 -> 6.5 TB/s, 1024 -> 5.8, 256 -> 5.3 on the fc6 slabs
-int drn_sgd_set_grid(int blocks_x) {
+__attribute__((visibility("hidden"))) int drn_sgd_set_grid(int blocks_x) {
   const int old = g_sgd_grid_x;
   if (blocks_x >= 8 && blocks_x <= 65535) g_sgd_grid_x = blocks_x;
   return old;
@@ -1060,6 +1109,31 @@ int drn_sgd_step(float* weights, float* momentum_buf, const void* grads, int gra
 #define SGD_LAUNCH(SH, GD)                                                                                       \
   hipLaunchKernelGGL((sgd_kernel<SH, GD>), grid, block, 0, st, weights, momentum_buf, grads, grad_off,           \
                      (bf16_t*)shadow, (const SgdSeg*)segs_dev, nseg, momentum, first_step, grad_scale)
+  if (shadow) { if (grad_dtype == DRN_BF16) SGD_LAUNCH(true, DRN_BF16); else SGD_LAUNCH(true, DRN_F32); }
+  else { if (grad_dtype == DRN_BF16) SGD_LAUNCH(false, DRN_BF16); else SGD_LAUNCH(false, DRN_F32); }
+#undef SGD_LAUNCH
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// drn_sgd_step on a rectangular block of ONE 2-D tensor: seg_dev = that tensor's {offset, count, lr, wd} entry (lr / wd are
+// read on the device: a captured launch follows the schedule), the block = rows r0 .. r0+rows, columns c0 .. c0+cols of
+// its [count / ld][ld] view.
+int drn_sgd_step_block(float* weights, float* momentum_buf, const void* grads, int grad_dtype, long grad_off, void* shadow,
+                       int shadow_dtype, const void* seg_dev, int r0, int rows, int c0, int cols, long ld, float momentum,
+                       int first_step, float grad_scale, void* stream) {
+  if (!weights || !momentum_buf || !grads || !seg_dev || r0 < 0 || rows < 0 || c0 < 0 || cols < 0 || ld < c0 + cols)
+    return DRN_ERR_ARG;
+  if (shadow && shadow_dtype != DRN_BF16) return DRN_ERR_ARG;
+  if (grad_dtype != DRN_F32 && grad_dtype != DRN_BF16) return DRN_ERR_ARG;
+  if ((c0 & 3) || (cols & 3) || (ld & 3) || (grad_off & 3)) return DRN_ERR_UNSUPPORTED;  // (the tensor's offset: checked by the caller's table)
+  if ((long)rows * (cols >> 2) >= (1L << 32)) return DRN_ERR_UNSUPPORTED;
+  if (rows == 0 || cols == 0) return DRN_OK;
+  dim3 grid(g_sgd_grid_x), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define SGD_LAUNCH(SH, GD)                                                                                          \
+  hipLaunchKernelGGL((sgd_block_kernel<SH, GD>), grid, block, 0, st, weights, momentum_buf, grads, grad_off,        \
+                     (bf16_t*)shadow, (const SgdSeg*)seg_dev, r0, rows, c0, cols, ld, momentum, first_step, grad_scale)
   if (shadow) { if (grad_dtype == DRN_BF16) SGD_LAUNCH(true, DRN_BF16); else SGD_LAUNCH(true, DRN_F32); }
   else { if (grad_dtype == DRN_BF16) SGD_LAUNCH(false, DRN_BF16); else SGD_LAUNCH(false, DRN_F32); }
 #undef SGD_LAUNCH

@@ -1098,32 +1098,32 @@ static bool launch_roi_map(const RoiParams& p, hipStream_t st, size_t lds_budget
 
 extern "C" {
 
-int drn_roi_set_chunks(int cpb) {
+__attribute__((visibility("hidden"))) int drn_roi_set_chunks(int cpb) {
   const int old = g_roi_cpb;
   if (cpb >= 1 && cpb <= 64 && (cpb & (cpb - 1)) == 0) g_roi_cpb = cpb;
   return old;
 }
 
 static int g_roi_map64_a = 0;  // drn_tune(DRN_TUNE_ROI_MAP64_A = 14): 1 = the 64-ROI kernel also for A alone (no A^T)
-int drn_roi_set_map64_a(int on) {
+__attribute__((visibility("hidden"))) int drn_roi_set_map64_a(int on) {
   const int old = g_roi_map64_a;
   g_roi_map64_a = on != 0;
   return old;
 }
 
-int drn_roi_set_lds_kb(int kb) {
+__attribute__((visibility("hidden"))) int drn_roi_set_lds_kb(int kb) {
   const int old = g_roi_lds_kb;
   if (kb >= 60 && kb <= 154) g_roi_lds_kb = kb;
   return old;
 }
 
-int drn_roi_set_prefetch(int on) {
+__attribute__((visibility("hidden"))) int drn_roi_set_prefetch(int on) {
   const int old = g_roi_pf;
   g_roi_pf = on != 0;
   return old;
 }
 
-int drn_roi_set_map64(int on) {
+__attribute__((visibility("hidden"))) int drn_roi_set_map64(int on) {
   const int old = g_roi_map64;
   g_roi_map64 = on == 1 ? 512 : (on == 0 || on == 256 || on == 512 || on == 1024) ? on : old;
   return old;

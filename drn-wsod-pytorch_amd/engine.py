@@ -115,7 +115,7 @@ class FusedSGD:
         return self._segs_dev, self._nseg
 
     # ---- pipelined mode: the update of a gradient bucket starts as soon as the bucket is final ----------------
-    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None, exchange=None):
+    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None, exchange=None, col_rounds=None):
         """ITER_SIZE == 1 only.  The explicit backward finishes gradients in a known order: first every small tensor
         (predictors, fc7, fc6 bias), then fc6.weight in row slabs.  In pipelined mode each bucket is (all-reduced when
         N > 1 and then) updated by the SGD kernel on a second stream the moment its dW GEMM is queued, so the HBM-bound
@@ -184,6 +184,10 @@ class FusedSGD:
             self._install_state_dict_hook()
         self._slab_ends = slab_rows
         e.fc1_slab_ends = slab_rows
+        # col_rounds (single process): the fc6 dW in column slabs of that many exact rounds of the persistent GEMM, each
+        # updated by drn_sgd_step_block the moment it is queued (_HeadEngine.fc1_col_rounds); None = keep the engine's value
+        if col_rounds is not None:
+            e.fc1_col_rounds = 0 if (dp is not None and dp.exchange) else int(col_rounds)
         e.grad_ready_hook = self._on_grad_ready
         e.defer_colsum = True
         self._dp, self._pipelined = dp, True
@@ -238,7 +242,7 @@ class FusedSGD:
             if what == "small" and g["name"] != "fc1.weight":
                 rows.append((g["off"], g["cnt"], g["lr"], g["weight_decay"]))
             elif what != "small" and g["name"] == "fc1.weight":
-                _, r0, r1 = what
+                r0, r1 = what[1], what[2]
                 k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
                 rows.append((g["off"] + r0 * k1, (r1 - r0) * k1, g["lr"], g["weight_decay"]))
         arr = np.zeros(len(rows), dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
@@ -383,7 +387,14 @@ class FusedSGD:
         e = self.engine
         if self._mom is None:
             self._mom = torch.zeros_like(e.arena_w)
-        segs, nseg = self._bucket_table(what)
+        if what[0] == "fc1b":
+            if self._exchange_on:
+                raise DrnError("column slabs of the fc6 weight gradient (fc1_col_rounds) are a single-process schedule; "
+                               "with a gradient exchange the slabs are row ranges")
+            # the block kernel takes the whole tensor's table entry (lr / wd on the device) + the block's bounds
+            segs, nseg = self._bucket_table(("fc1", 0, self.model.roi_heads.box_head.fc1.weight.shape[0]))
+        else:
+            segs, nseg = self._bucket_table(what)
         world = self._dp.world if self._dp is not None else 1
         cur = torch.cuda.current_stream()
         ev = torch.cuda.Event()
@@ -403,6 +414,14 @@ class FusedSGD:
     def _update(self, what, bucket, segs, nseg):
         e = self.engine
         world = self._dp.world if self._dp is not None else 1
+        if what[0] == "fc1b":
+            # a rectangular block of fc1.weight (column slabs of the dW GEMM, _HeadEngine.fc1_col_rounds)
+            _, r0, r1, c0, c1 = what
+            k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
+            ops.sgd_step_block(e.arena_w, self._mom, bucket if bucket is not None else e.arena_g, segs, r0, r1 - r0, c0,
+                               c1 - c0, k1, self.momentum, self._steps == 0, 1.0 / world, shadow=e.arena_s,
+                               grad_off=e._seg["fc1.weight"][0] if bucket is not None else 0)
+            return
         if what != "small" and getattr(self, "_sharded", False) and self._exchange_on:
             # `bucket` = this rank's reduce-scattered rows: update them alone
             a, b = self._own_rows(what)

@@ -538,11 +538,38 @@ class _HeadEngine:
     def _fc1_use_tn(self, dtype):
         return self.fc1_tn and dtype == torch.bfloat16 and getattr(self, "fc1_fused_update", None) is None
 
+    # round 4: the fc6 weight gradient in COLUMN slabs of `fc1_col_rounds` exact rounds of the persistent GEMM each (0 = row
+    # slabs).  All tile rows x (rounds * CUs / tile rows) tile columns = rounds * CUs tiles per launch, so a slab costs no
+    # partial round whatever its width; its optimizer update (drn_sgd_step_block, the pipelined optimizer's hook) starts
+    # one round behind the GEMM instead of half the GEMM behind it (two row slabs), and only the LAST slab's update - 1/6
+    # of the 2-GB pass at R50-C4 - is exposed behind the GEMM.  (Row slabs cannot be made this fine: a slab of 2 tile rows
+    # is 392 tiles = 1.53 rounds, i.e. two rounds with the second half empty - the '4 slabs' experiment of round 3.)
+    fc1_col_rounds = 0
+
+    def _fc1_col_plan(self, dtype, D1, K1):
+        """(n_main, slab width in columns) of the column-slab form, or None when it does not apply: TN operand form, a
+        gradient bucket or the arena as the destination, whole 256-column tiles"""
+        r = int(getattr(self, "fc1_col_rounds", 0) or 0)
+        if r <= 0 or not self._fc1_use_tn(dtype) or getattr(self, "fc1_fused_update", None) is not None:
+            return None
+        tiles_m = (D1 + 255) // 256
+        ncu = getattr(self, "_ncu", None)
+        if ncu is None:
+            ncu = self._ncu = torch.cuda.get_device_properties(self.arena_w.device).multi_processor_count
+        wt = (r * ncu) // tiles_m
+        if wt < 1 or (r * ncu) % tiles_m or K1 // 256 < wt:
+            return None
+        n_main = (K1 // 256) // wt * wt * 256
+        return n_main, wt * 256
+
     def _fc1_tail_row0(self, dtype, D1, K1):
         """first row of A^T the fc6 dW still reads: the smallest main-column count over the row slabs (the columns from
         there on are peeled into the small-tile NT launch, which takes A^T); 0 when the NT form is used throughout"""
         if not self._fc1_use_tn(dtype):
             return 0
+        plan = self._fc1_col_plan(dtype, D1, K1)
+        if plan is not None:
+            return plan[0]
         return min(ops.gemm_nt_main_cols(b - a, K1) for a, b in self._fc1_slabs(D1))
 
     def _mark_current(self, s):
@@ -912,6 +939,24 @@ class _HeadEngine:
                 raise DrnError("this batch was pooled for the TN form of the fc6 weight gradient (A^T rows below %d were "
                                "not written) but the backward runs the NT form: fc1_tn / the fused update changed in "
                                "between" % at_row0)
+            plan = None if acc else self._fc1_col_plan(dP1T.dtype, D1, K1)
+            if plan is not None:
+                # column slabs: the trailing columns that do not fill a slab first (small-tile NT launch on the A^T tail rows,
+                # all fc6 rows), then slabs of exact rounds straight from A; every piece is announced as a block
+                # ("fc1b", r0, r1, c0, c1) the moment its GEMM is queued
+                n_main, wcols = plan
+                if n_main < at_row0:
+                    raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (n_main, at_row0))
+                if n_main < K1:
+                    ops.gemm_nt(dP1T, AT[n_main:], D1, K1 - n_main, Mp, out=gw[:, n_main:].unsqueeze(0))
+                    if hook is not None:
+                        hook(("fc1b", 0, D1, n_main, K1))
+                for c0 in range(0, n_main, wcols):
+                    c1 = min(n_main, c0 + wcols)
+                    ops.gemm_tn(dP1T, A[:, c0:c1], D1, c1 - c0, Mp, M, out=gw[:, c0:c1].unsqueeze(0))
+                    if hook is not None:
+                        hook(("fc1b", 0, D1, c0, c1))
+                slabs = []
             if getattr(self, "fc1_joint_peel", 1) and len(slabs) > 1 and not acc:
                 cols = {ops.gemm_nt_main_cols(b - a, K1) for a, b in slabs}
                 if len(cols) == 1 and 0 < min(cols) < K1:

@@ -482,6 +482,23 @@ def sgd_step(weights, momentum_buf, grads, segs_dev, nseg, momentum, first_step,
         HBM_TIMING.append((e0, e1, None, ("sgd", int(nseg), int(grad_off), str(grads.dtype), shadow is not None)))
 
 
+def sgd_step_block(weights, momentum_buf, grads, seg_dev, r0, rows, c0, cols, ld, momentum, first_step, grad_scale=1.0,
+                   shadow=None, grad_off=0):
+    """drn_sgd_step on rows r0 .. r0+rows, columns c0 .. c0+cols of the [., ld] tensor described by seg_dev (ONE
+    {offset, count, lr, wd} entry on the device); weights / momentum_buf / shadow are the flat arenas, grads as in
+    sgd_step."""
+    if HBM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    C.call("drn_sgd_step_block", C.ptr(weights), C.ptr(momentum_buf), C.ptr(grads), C.dt(grads.dtype), int(grad_off),
+           C.ptr(shadow), C.dt(shadow.dtype) if shadow is not None else 0, C.ptr(seg_dev), int(r0), int(rows), int(c0),
+           int(cols), int(ld), float(momentum), int(first_step), float(grad_scale), C.stream())
+    if HBM_TIMING is not None:
+        e1.record()
+        HBM_TIMING.append((e0, e1, int(rows) * int(cols), ("sgd_block", int(r0), int(rows), int(c0), int(cols),
+                                                            str(grads.dtype), shadow is not None)))
+
+
 def detect_topk(boxes, scores, image_shape, score_thresh, nms_thresh, topk):
     """Single image: boxes [R, 4*nreg] f32, scores [R, K+1] f32 -> (boxes [n,4], scores [n], classes [n] i64,
     rows [n] i64) exactly as fast_rcnn_inference_single_image."""

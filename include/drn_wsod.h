@@ -196,6 +196,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_ROI_LDS_KB 15 /* 60..154 (default 154): LDS a 64-ROI pooling block may take for map slice + tile; 76 stages larger maps in row bands so that two blocks share a CU */
 #define DRN_TUNE_ROI_MAP64_A 14 /* 0/1 (default 0): the 64-ROI ROIPool kernel also when only A is asked for (no A^T) */
 #define DRN_TUNE_FP8_K64 13 /* 0/1 (default 1): fp8 convolutions multiply with v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales; the fp8 MFMA rate) instead of the K = 16 non-scaled form (bf16 rate); same exact products, another fp32 summation order */
+#define DRN_TUNE_GEMM_NWG 18 /* resident workgroups of persistent 256x256 launches (multiple of 8; 0 = default: one per CU) - for launches on a CU-masked stream */
 #define DRN_TUNE_CONV_PATCH 9 /* 0 = never use the LDS-resident-patch kernel for 3x3 / 64 -> 64 channel convs; 1 = default (maps of >= 32768 pixels); > 1 = that many pixels per image at least */
 int drn_tune(int knob, int value);
 
@@ -302,6 +303,17 @@ int drn_sum_small(const float* in, int n, float scale, float* out, void* stream)
 int drn_sgd_step(float* weights, float* momentum_buf, const void* grads, int grad_dtype, long grad_off, void* shadow,
                  int shadow_dtype, const void* segs_dev, int nseg, float momentum, int first_step, float grad_scale,
                  void* stream);
+
+/* The same update (torch.optim.SGD.step, detectron2/solver/build.py:93-137; projects/WSL/tools/train_net.py:104-113 calls
+ * it once per iteration) on a rectangular BLOCK of one 2-D parameter: rows r0 .. r0+rows, columns c0 .. c0+cols of the
+ * [count / ld][ld] view of the tensor that seg_dev ({offset, count, lr, wd}, ONE entry) describes.  The fc6 weight
+ * gradient is produced in column slabs of exactly one round of the persistent GEMM each, and a slab's update is
+ * issued the moment its GEMM is queued - the optimizer pass of step t then trails the weight-gradient GEMM by one round
+ * instead of by half of it.  Per-element arithmetic is drn_sgd_step's (bit-identical results); c0, cols, ld, grad_off
+ * multiples of 4. */
+int drn_sgd_step_block(float* weights, float* momentum_buf, const void* grads, int grad_dtype, long grad_off, void* shadow,
+                       int shadow_dtype, const void* seg_dev, int r0, int rows, int c0, int cols, long ld, float momentum,
+                       int first_step, float grad_scale, void* stream);
 
 /* ---- inference tail -------------------------------------------------------------------------- */
 

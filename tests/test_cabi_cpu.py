@@ -24,6 +24,12 @@ def test_header_symbols_exported(pkg):
     for name in declared:
         assert hasattr(lib, name), "library does not export %s" % name
     assert sorted(pkg._cabi.exported_symbols()) == declared
+    # exports == header, both ways (cross-TU helpers of drn_tune used to leak into the ABI)
+    import subprocess
+
+    nm = subprocess.run(["nm", "-D", "--defined-only", pkg._cabi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in nm.splitlines() if ln.split()[-1].startswith("drn_")})
+    assert exported == declared, (set(exported) ^ set(declared))
 
 
 def test_no_cpu_fallback(pkg):

@@ -301,6 +301,43 @@ def test_fc6_weight_gradient_tn_equals_nt(case):
     load_package().set_precision("fp32")
 
 
+@pytest.mark.parametrize("rounds", [1, 2, 3])
+def test_fc6_column_slabs_equal_row_slabs(rounds):
+    """Round 4: the fc6 weight gradient in column slabs of exact rounds of the persistent GEMM, each updated by
+    drn_sgd_step_block from the pipelined optimizer's hook (`enable_pipelined(col_rounds=...)`), against the two row slabs of
+    round 3 at the bench shape (R50-C4, R = 2000, bf16 bucket): three SGD steps, every parameter, the momentum arena and
+    the bf16 weight shadow bit for bit (same MFMA k order per element, same rounding into the bucket, same update)."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    kw = dict(arch="wsr50", out_feature="res4", res5_dilation=1, num_classes=20)
+    ocfg = O.OracleCfg(dropout=0.0, base_lr=2e-4, **kw)
+    b = O.synthetic_batch(1, 2000, ocfg, seed=78)
+    batch = G.drn_inputs([dict(x, gt_boxes=torch.zeros(len(x["gt_classes"]), 4)) for x in b])
+    res = []
+    for cr in (0, rounds):
+        cfg, model = G.drn_model(ocfg, 3, "cuda", 5, "bf16")
+        model.roi_heads.box_head.dropout_p = 0.0
+        model.train()
+        opt = build_optimizer(cfg, model)
+        opt.enable_pipelined(None, col_rounds=cr)
+        eng = model.roi_heads._engine
+        for _ in range(3):
+            opt.zero_grad()
+            sum(model(batch).values()).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        D1, K1 = model.roi_heads.box_head.fc1.weight.shape
+        plan = eng._fc1_col_plan(torch.bfloat16, D1, K1)
+        assert (plan is None) == (cr == 0)
+        if cr:
+            assert plan == (49152, 8192 * rounds) and eng._last_state["w"]["AT_row0"] == 49152
+        res.append(dict(w=eng.arena_w.clone(), m=opt._mom.clone(), s=eng.arena_s.clone()))
+        del model, opt
+    for k in ("w", "m", "s"):
+        assert torch.equal(res[0][k], res[1][k]), k
+    load_package().set_precision("fp32")
+
+
 def test_grad_accumulation_iter_size():
     """WSL.ITER_SIZE semantics (train_net.py:100-113): two backward() calls accumulate before one step."""
     ocfg, d, cfg, model = _setup("model_r50c4_tiny", "fp32")

@@ -860,6 +860,40 @@ def test_sgd_step_bf16_bucket(drn):
     assert torch.equal(wa[:n0], w[:n0]) and not torch.equal(wa[n0:], w[n0:])
 
 
+@pytest.mark.parametrize("gdt", [torch.float32, torch.bfloat16])
+def test_sgd_step_block_equals_flat(drn, gdt):
+    """drn_sgd_step_block over a 2-D partition of one tensor (column slabs + a trailing block, the fc6 dW schedule of round
+    4) == ONE drn_sgd_step over the tensor, bit for bit: weights, momentum, bf16 shadow; elements outside the tensor are
+    untouched; bf16 gradient bucket addressed through grad_off."""
+    rs = np.random.RandomState(17)
+    n0, rows, ld = 192, 70, 1000  # the tensor starts at arena element n0 (a multiple of 4)
+    tot = n0 + rows * ld + 64
+    w = torch.from_numpy(rs.standard_normal(tot).astype(np.float32)).to(DEV)
+    seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+    seg[0] = (n0, rows * ld, 0.01, 5e-4)
+    seg_dev = torch.from_numpy(seg.view(np.uint8)).to(DEV)
+    wa, wb = w.clone(), w.clone()
+    ma, mb = torch.zeros_like(w), torch.zeros_like(w)
+    sa, sb = torch.zeros_like(w, dtype=torch.bfloat16), torch.zeros_like(w, dtype=torch.bfloat16)
+    blocks = [(0, rows, 768, 1000), (0, rows, 0, 256), (0, 32, 256, 768), (32, rows, 256, 512), (32, rows, 512, 768)]
+    for step in range(3):
+        g = torch.from_numpy(rs.standard_normal(rows * ld).astype(np.float32)).to(DEV).to(gdt)
+        if gdt == torch.float32:  # fp32 gradients live in an arena-shaped buffer (grad_off = 0)
+            gfull = torch.zeros_like(w)
+            gfull[n0: n0 + rows * ld] = g
+            ga, goff = gfull, 0
+        else:
+            ga, goff = g, n0
+        drn.sgd_step(wa, ma, ga, seg_dev, 1, 0.9, step == 0, 0.5, shadow=sa, grad_off=goff)
+        for r0, r1, c0, c1 in blocks:
+            drn.sgd_step_block(wb, mb, ga, seg_dev, r0, r1 - r0, c0, c1 - c0, ld, 0.9, step == 0, 0.5, shadow=sb, grad_off=goff)
+        assert torch.equal(wa, wb) and torch.equal(ma, mb) and torch.equal(sa, sb), step
+    assert torch.equal(wb[:n0], w[:n0]) and torch.equal(wb[n0 + rows * ld:], w[n0 + rows * ld:])
+    assert not torch.equal(wb[n0: n0 + rows * ld], w[n0: n0 + rows * ld])
+    with pytest.raises(Exception):
+        drn.sgd_step_block(wb, mb, ga, seg_dev, 0, rows, 2, 8, ld, 0.9, False, shadow=sb, grad_off=goff)  # c0 % 4 != 0
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("M,N,K,wd", [(300, 520, 200, 1e-4), (512, 1024, 2000, 0.0), (77, 36, 64, 5e-4),
                                       (2300, 8192, 128, 1e-4)])  # last: 288 tiles > #CUs -> the persistent kernel
