@@ -591,6 +591,28 @@ def main():
         fused = entry("gemm_nt256_kernel<bf16, SGD> fc6 dW + optimizer epilogue", {("sgd", D1, K1, Mp)}, 2.0 * D1 * K1 * Rtot)
         if fused:
             launches.append(fused)
+        # `roofline` (round 4): the fc6 GEMM FAMILY in the step - forward + every weight-gradient launch,
+        # algorithmic FLOPs / the sum of their in-step launch durations - not its best launch; the forward launch alone stays
+        # in `roofline.forward_launch` and in `roofline_launches`
+        if roof is not None and len(launches) > 1:
+            fam_ms = sum(l["avg_launch_ms"] for l in launches)
+            fam_gf = sum(l["gflop_per_launch"] for l in launches)
+            ach = fam_gf / 1e3 / (fam_ms * 1e-3)
+            fwd_only = {k: roof[k] for k in ("kernel", "achieved", "frac", "gflop_per_launch", "avg_launch_ms", "launches_timed")}
+            fam = {"kernel": "fc6 GEMM family in the step: forward [%d x %d] . [%d x %d]^T + weight gradient [%d x %d] . [%d x %d] "
+                             "(gemm_nt256_kernel / gemm_nt256p_kernel<bf16>, %d launches per step)" % (Rtot, K1, D1, K1, D1, Rtot, Rtot, K1, len(launches)),
+                   "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                   "frac": ach / BF16_MFMA_PEAK_TFLOPS, "gflop_per_step": fam_gf, "ms_per_step": fam_ms,
+                   "definition": "sum of the launches' ALGORITHMIC FLOPs (SURVEY 8(d): 2 R D1 K1 each for forward and dW, per image) / "
+                                 "sum of their average launch durations, HIP events on the launch stream inside the timed region",
+                   "forward_launch": fwd_only}
+            for k in ("traffic", "traffic_source", "mfma_util_pmc", "shader_clock_GHz_pmc", "l2_hit_rate_pmc", "mfma_util_source", "timed_in"):
+                fam[k] = roof.get(k)
+            fam["traffic_scope"] = "the forward launch (per launch, like forward_launch.achieved); dW: profiles/r3_15_pmc_dw_nt.json (1.32x)"
+            fam["power_note"] = ("these launches run AT the 1400 W package cap with the shader clock throttled to 1.64-1.70 GHz; the "
+                                 "same forward launch on zero-valued operands reaches 1645 TFLOP/s = 0.66 at 2.40 GHz "
+                                 "(tools/power_probe.py, profiles/r4_03_power_probe.txt)")
+            roof = fam
         gf_step = step_gflop(args.workload, R, K1, D1, D2, NH, args.ims_per_gpu)
         step_tf = gf_step * 1e9 / (dt / args.steps) / 1e12
         roof_step = {"bound": "mfma", "achieved": step_tf, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
@@ -670,6 +692,35 @@ def main():
                             "ms_per_step": ms / nstep, "min_launch_ms": min(t for t, _ in blocks),
                             "max_launch_ms": max(t for t, _ in blocks), "launches_timed": len(blocks)})
         out["roofline_hbm_in_step"] = in_step
+        # the launch family that takes the most TIME in the step (the dW launches and the optimizer pass,
+        # not the forward): name, in-step time per step, fraction of ITS roofline
+        if roof is not None and "forward_launch" in roof:
+            cands = []
+            dwl = [l for l in launches if "dW" in l["kernel"] and "forward" not in l["kernel"]]
+            if dwl:
+                ms = sum(l["avg_launch_ms"] for l in dwl)
+                gf = sum(l["gflop_per_launch"] for l in dwl)
+                cands.append({"kernel": "fc6 weight-gradient launches (gemm_nt256p_kernel<bf16> + the trailing-column launch), in step",
+                              "bound": "mfma", "us_per_step": ms * 1e3, "launches_per_step": len(dwl),
+                              "achieved": gf / ms, "unit": "TFLOP/s", "frac": gf / ms / BF16_MFMA_PEAK_TFLOPS})
+            cands.append({"kernel": roof["forward_launch"]["kernel"] + ", in step", "bound": "mfma",
+                          "us_per_step": roof["forward_launch"]["avg_launch_ms"] * 1e3, "launches_per_step": 1,
+                          "achieved": roof["forward_launch"]["achieved"], "unit": "TFLOP/s", "frac": roof["forward_launch"]["frac"]})
+            for e_ in in_step:
+                if "sgd" in e_["kernel"]:
+                    per_step = e_.get("ms_per_step")
+                    n_l = 1
+                    if per_step is None:  # one row slab per entry: all slabs of the step
+                        n_l = len(slab_rows)
+                        per_step = e_["avg_launch_ms"] * n_l
+                    cands.append({"kernel": e_["kernel"], "bound": "hbm", "us_per_step": per_step * 1e3, "launches_per_step": n_l,
+                                  "achieved": e_["achieved"], "unit": "GB/s", "frac": e_["frac"]})
+            roof["time_dominant_kernel"] = max(cands, key=lambda c: c["us_per_step"])
+            roof["time_by_kernel_family"] = sorted(cands, key=lambda c: -c["us_per_step"])
+        out["timed_region_s"] = dt
+        if dt < 0.2:
+            out["timed_region_note"] = ("the timed region is %.0f ms (%d steps): shorter than clock / power transients; the default "
+                                        "run (100 steps) and profiles/ hold the sustained figure" % (dt * 1e3, args.steps))
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(batches)
     if dist.is_initialized():

@@ -349,6 +349,17 @@ class FusedSGD:
         flag = torch.ones(1, dtype=torch.float32, device=dev)
         work = dist.all_reduce(flag, group=self._dp.group, async_op=True)
         t0 = time.monotonic()
+        nccl = dist.get_backend(self._dp.group) == "nccl"
+        if not nccl:
+            # gloo completes some operations only inside wait() (DataParallel.selftest notes the same): a bounded wait
+            # instead of polling is_completed()
+            import datetime
+
+            try:
+                work.wait(timeout=datetime.timedelta(seconds=self.sync_timeout))
+                return
+            except Exception:  # noqa: BLE001 - timeout / peer missing: the error below says what to do
+                t0 = time.monotonic() - self.sync_timeout - 1.0
         while not work.is_completed():
             if time.monotonic() - t0 > self.sync_timeout:
                 raise DrnError("%s is a collective in the sharded exchange (every rank holds the fp32 master / momentum "
@@ -965,6 +976,17 @@ class GraphedTrainStep:
         self._primed = False
         self.split_tail = bool(split_tail)
         self.engine.defer_fc1_tail = self.split_tail
+        self.engine.pool_sets_pinned = None  # a new step captures anew: the previous owner's pin (if any) is void
+        self.engine.pool_sets_pin_owner = None
+
+    def release(self):
+        """give the fc6 operand sets back (they may grow again); the captured graphs of this object must not be replayed
+        afterwards"""
+        own = getattr(self.engine, "pool_sets_pin_owner", None)
+        if own is not None and own() is self:
+            self.engine.pool_sets_pinned = None
+            self.engine.pool_sets_pin_owner = None
+        self._primed = False
 
     # ---- host side of one step: stage inputs into the static buffers (tiny async copies) -----------------------
     def _stage_labels(self, batch, dst=None):
@@ -1060,6 +1082,11 @@ class GraphedTrainStep:
         if not getattr(self, "_primed", False):
             self._pool_ptrs = ptrs
             self.engine.pool_sets_pinned = (self.pooled["A"].dtype, True)
+            import weakref
+
+            # the pin belongs to THIS step object: it lapses when the object dies or another step is built on the model
+            # (it used to outlive its owner and made the re-creation the error message asks for fail)
+            self.engine.pool_sets_pin_owner = weakref.ref(self)
         elif ptrs != self._pool_ptrs:
             raise DrnError("the fc6 operand buffers moved after the step was captured (%s -> %s): re-create the "
                            "GraphedTrainStep" % (self._pool_ptrs, ptrs))
@@ -1388,10 +1415,14 @@ class GraphedFullStep(GraphedTrainStep):
             raise DrnError("GraphedFullStep uses the plain optimizer step (the pipelined mode assumes a frozen trunk)")
         super().__init__(model, optimizer, example_batch, split_tail=False, lookahead=1)
         self.g_step = None
+        self.g_trunk = None
         self.g_opt = None
+        if parallel is None and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            #  without the DataParallel object the step would run with NO gradient exchange and no error
+            raise DrnError("GraphedFullStep in a %d-rank job needs parallel=DataParallel(model): without it the replicas "
+                           "train on their local gradients and diverge" % dist.get_world_size())
         self.dp = parallel if (parallel is not None and parallel.exchange) else None
-        if self.dp is not None:
-            self.dp.sync_gradients = False  # the exchange below replaces the per-bucket hooks
+        self._comm = None
 
     def _stage(self, batch):
         self._stage_labels(batch)
@@ -1411,33 +1442,67 @@ class GraphedFullStep(GraphedTrainStep):
         feats = m.backbone(imgs.tensor)  # training mode + trainable blocks: activations are kept for backward_nhwc()
         f = feats[self.heads.box_in_features[0]].permute(0, 2, 3, 1)
         assert f.is_contiguous()
-        eng.feature_grad_hook = m._backbone_backward
+        # N > 1: the trunk's backward is a piece of its own (_trunk_bwd), so that the all-reduce of the heads' gradient arena -
+        # final when the heads' backward ends - runs under it; the hook only keeps what that piece needs
+        eng.feature_grad_hook = m._backbone_backward if self.dp is None else self._keep_feature_grad
         losses, st = eng.forward(f, self.rois, self.obj, True, self.img_off, self.n_img, self.gt)
         if torch.cuda.is_current_stream_capturing():
             self._captured_state = st
         else:
             self._eager_state = st
-        eng.backward(st, None)
+        # the per-bucket hooks of DataParallel (eager trainer) are replaced by _exchange_* below: off while THIS step's
+        # backward runs, restored right after (the flag used to stay off on the shared object for good)
+        flag = None if self.dp is None else self.dp.sync_gradients
+        if self.dp is not None:
+            self.dp.sync_gradients = False
+        try:
+            eng.backward(st, None)
+        finally:
+            if self.dp is not None:
+                self.dp.sync_gradients = flag
         return losses
+
+    def _keep_feature_grad(self, dfeat, acc):
+        self._dfeat = (dfeat, acc)
+
+    def _trunk_bwd(self):
+        dfeat, acc = self._dfeat
+        self.model._backbone_backward(dfeat, acc)
 
     def _opt_body(self):
         self.opt.step(1.0 if self.dp is None else self.dp.grad_scale)
         self.opt.zero_grad()
 
-    def _exchange(self):
-        """sum of the trainable gradients over the ranks (the SGD kernels apply 1 / world): two all-reduces on the
-        current stream, between the two graphs"""
+    def _exchange_heads(self):
+        """all-reduce of the heads' gradient arena (the SGD kernels apply 1 / world) on the exchange stream, started the
+        moment the heads' backward is queued: it runs under the trunk's backward (round 4; one eager call between two
+        graphs with nothing beside it before)"""
         e = self.engine
         o, n = e._seg["fc1.weight"]
-        dist.all_reduce(e.arena_g[: o + n], group=self.dp.group)
+        main = torch.cuda.current_stream()
+        if self._comm is None:
+            self._comm = torch.cuda.Stream()
+        self._comm.wait_stream(main)
+        with torch.cuda.stream(self._comm):
+            dist.all_reduce(e.arena_g[: o + n], group=self.dp.group)
+
+    def _exchange_trunk(self):
+        """all-reduce of the trunk's gradient arena behind the heads' one (same stream: RCCL runs one collective of a
+        communicator at a time anyway), then the main stream joins"""
+        main = torch.cuda.current_stream()
         bg = getattr(self.model, "_bb_grad_arena", None)
         if bg is not None:
-            dist.all_reduce(bg, group=self.dp.group)
+            self._comm.wait_stream(main)
+            with torch.cuda.stream(self._comm):
+                dist.all_reduce(bg, group=self.dp.group)
+        main.wait_stream(self._comm)
 
     def _full_body(self):
         losses = self._fwd_bwd()
         if self.dp is not None:
-            self._exchange()
+            self._exchange_heads()
+            self._trunk_bwd()
+            self._exchange_trunk()
         self._opt_body()
         return losses
 
@@ -1459,6 +1524,9 @@ class GraphedFullStep(GraphedTrainStep):
                 # the capture pass RUNS nothing: the gradient arenas and weights are exactly as step 0 left them
                 with torch.cuda.graph(self.g_step, capture_error_mode="thread_local"):
                     self.losses = self._fwd_bwd()
+                self.g_trunk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(self.g_trunk, capture_error_mode="thread_local"):
+                    self._trunk_bwd()
                 self.g_opt = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(self.g_opt, capture_error_mode="thread_local"):
                     self._opt_body()
@@ -1466,6 +1534,8 @@ class GraphedFullStep(GraphedTrainStep):
         self.opt.refresh_tables()
         self.g_step.replay()
         if self.dp is not None:
-            self._exchange()
+            self._exchange_heads()   # exchange stream: under the trunk's backward
+            self.g_trunk.replay()
+            self._exchange_trunk()
             self.g_opt.replay()
         return self.losses

@@ -143,14 +143,17 @@ class Backbone(nn.Module):
         convs = self.conv_modules()
         # (fp8 configuration, pack generation) of every conv: Conv2d.invalidate_packs() - DataParallel.broadcast_parameters
         # and the trunk optimizer write `.data` in place, which bumps no `_version` - must drop the recorded pack pointers too
-        cfg = tuple([(id(m._fp8), m.__dict__.get("_pack_gen", 0)) for m in convs])
+        # keyed on VALUES: `id(m._fp8)` collides when disable_fp8() + enable_fp8(new scale) hands out a new dict at
+        # the old address, and a re-assigned `weight.data` / parameter moves data_ptr without touching `_version`
+        cfg = tuple([(None if m._fp8 is None else (m._fp8["out_scale"], m._fp8["out_dtype"]), m.__dict__.get("_pack_gen", 0))
+                     for m in convs])
         plans = self.__dict__.setdefault("_plans", {})
         p = plans.get((dtype, cin))
-        if p is not None and p["cfg"] == cfg and p["versions"] == [t._version for t in p["srcs"]]:
+        if p is not None and p["cfg"] == cfg and p["versions"] == [(t._version, t.data_ptr()) for t in p["srcs"]]:
             return p
         b = _PlanBuilder(dtype, cin)
         p = b.finish(self._plan_emit(b, 0))
-        p["cfg"], p["versions"] = cfg, [t._version for t in p["srcs"]]
+        p["cfg"], p["versions"] = cfg, [(t._version, t.data_ptr()) for t in p["srcs"]]
         p["bytes"], p["hwc"] = (ctypes.c_long * p["n_slots"])(), (ctypes.c_int * (3 * p["n_slots"]))()
         p["ptrs"], p["scratch"] = (ctypes.c_void_p * p["n_slots"])(), {}
         plans[(dtype, cin)] = p

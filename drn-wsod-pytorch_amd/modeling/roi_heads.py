@@ -484,7 +484,8 @@ class _HeadEngine:
         cap = self._pool_cap
         if self._pool_sets is None or M > cap:
             # capacity-based like ws(): the operand pair of the largest batch seen, views for this batch
-            if getattr(self, "pool_sets_pinned", None) == key and self._pool_sets is not None:
+            own = getattr(self, "pool_sets_pin_owner", None)
+            if getattr(self, "pool_sets_pinned", None) == key and self._pool_sets is not None and (own is None or own() is not None):
                 raise DrnError("the fc6 operand sets of %s are pinned by a captured step (GraphedTrainStep) and cannot "
                                "grow from %d to %d proposals" % (key, cap, M))
             cap = (M + 63) // 64 * 64
@@ -536,7 +537,36 @@ class _HeadEngine:
         return [(a, b) for a, b in zip([0] + list(ends[:-1]), ends) if a < b]
 
     def _fc1_use_tn(self, dtype):
-        return self.fc1_tn and dtype == torch.bfloat16 and getattr(self, "fc1_fused_update", None) is None
+        return (self.fc1_tn and dtype == torch.bfloat16 and getattr(self, "fc1_fused_update", None) is None
+                and self._tn_selfcheck())
+
+    _tn_ok = None
+
+    @classmethod
+    def _tn_selfcheck(cls):
+        """First use, once per process: drn_gemm_tn's transposing LDS reads are inline asm with hand-counted
+        `lgkmcnt` waits that the compiler does not see; another hipcc version or register allocation could read a fragment
+        before it has landed and produce silently wrong gradients.  One small TN launch (the persistent ping-pong kernel:
+        288 tiles, ragged K rows) against drn_gemm_nt on the materialised transpose - bit-identical by construction -
+        decides whether the TN form is used; on a mismatch the NT form on A^T takes over, loudly."""
+        if cls._tn_ok is None:
+            if torch.cuda.is_current_stream_capturing():
+                return True  # decided by the eager priming step that precedes every capture
+            g = torch.Generator(device="cpu").manual_seed(11)
+            M, N, K, kb = 2304, 2048, 192, 150
+            a = torch.randn((M, K), generator=g).to("cuda", torch.bfloat16)
+            bt = torch.randn((kb, N), generator=g).to("cuda", torch.bfloat16)
+            b = torch.zeros((N, K), dtype=torch.bfloat16, device="cuda")
+            b[:, :kb] = bt.t()
+            a[:, kb:] = 1.0  # the K padding of Bt reads as zeros whatever A holds there
+            ok = torch.equal(ops.gemm_tn(a, bt, M, N, K, kb), ops.gemm_nt(a, b, M, N, K))
+            if not ok:
+                import warnings
+
+                warnings.warn("drn_gemm_tn failed its first-use self-check against drn_gemm_nt on this toolchain: the fc6 "
+                              "weight gradient falls back to the NT form on a materialised A^T (fc1_tn = False)")
+            cls._tn_ok = bool(ok)
+        return cls._tn_ok
 
     # round 4: the fc6 weight gradient in COLUMN slabs of `fc1_col_rounds` exact rounds of the persistent GEMM each (0 = row
     # slabs).  All tile rows x (rounds * CUs / tile rows) tile columns = rounds * CUs tiles per launch, so a slab costs no

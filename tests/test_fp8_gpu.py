@@ -164,6 +164,20 @@ def test_fp8_trunk_and_train_step_full_size():
         walk = model.backbone(model.preprocess_image(ins(batch)).tensor)["res4"].float().cpu()
         model.backbone.use_plan = True
         assert torch.equal(feat, walk)
+        # the plan is keyed on the fp8 configuration's VALUES - a conv re-enabled with another output scale
+        # (disable_fp8 + enable_fp8 hands out a new dict, possibly at the old address) must rebuild it
+        c2 = model.backbone.res2[0].conv2
+        old_q = dict(c2._fp8)
+        c2.disable_fp8()
+        c2.enable_fp8(old_q["out_scale"] * 0.5, old_q["out_dtype"])
+        moved = model.backbone(model.preprocess_image(ins(batch)).tensor)["res4"].float().cpu()
+        model.backbone.use_plan = False
+        moved_walk = model.backbone(model.preprocess_image(ins(batch)).tensor)["res4"].float().cpu()
+        model.backbone.use_plan = True
+        assert torch.equal(moved, moved_walk) and not torch.equal(moved, feat)
+        c2.disable_fp8()
+        c2.enable_fp8(old_q["out_scale"], old_q["out_dtype"])
+        assert torch.equal(model.backbone(model.preprocess_image(ins(batch)).tensor)["res4"].float().cpu(), feat)
     assert all(np.isfinite(v) and v > 0 for v in scales.values()) and len(scales) == 45  # 3 stem + 13 blocks x 3 + 3 shortcuts
     last = [n for n, m in model.backbone.named_modules() if getattr(m, "_fp8", None) and m._fp8["out_dtype"] == torch.bfloat16]
     assert last == ["res4.5.conv3"]

@@ -30,6 +30,15 @@ def _relerr(a, b, floor=1e-6):
     return float(np.abs(a - b).max() / (np.abs(b).max() + floor))
 
 
+def _record(key, value):
+    """DRN_RECORD_SPREAD=<file>: append the measured error behind a tolerance, so that bounds are set from measurements
+    (profiles/r4_04_parity_spreads.txt) instead of guessed"""
+    path = os.environ.get("DRN_RECORD_SPREAD")
+    if path:
+        with open(path, "a") as fh:
+            fh.write("%s %.3e\n" % (key, value))
+
+
 def _setup(name, precision):
     assert torch.cuda.is_available()
     ocfg = G.MODEL_CASES[name]
@@ -40,6 +49,11 @@ def _setup(name, precision):
     if masks is None:
         model.roi_heads.box_head.dropout_p = 0.0  # fixtures were generated with dropout patched to identity
     return ocfg, d, cfg, model
+
+
+# measured (profiles/r4_04_parity_spreads.txt): step-1 losses of every reference-pinned fixture sit within 7.8e-6 of the
+# reference's (step 0: 5.4e-6) - the 2e-2 of round 3 was a guess about "an ill-conditioned toy net"; the north-star bound holds
+STEP1_LOSS_TOL = 1e-4
 
 
 @pytest.mark.parametrize("name", REF_PINNED_TRAIN)
@@ -58,7 +72,8 @@ def test_train_two_steps_fp32(name):
         got = {k: float(v.detach()) for k, v in losses.items()}
         for k, v in got.items():
             ref = float(d["step%d_%s" % (step, k)])
-            tol = 1e-4 if step == 0 else 2e-2  # step 1 sits behind one lr=0.01 SGD step on an ill-conditioned toy net
+            tol = 1e-4 if step == 0 else STEP1_LOSS_TOL  # step 1 sits behind one lr=0.01 SGD step on an ill-conditioned toy net
+            _record("two_steps.%s.step%d.%s" % (name, step, k), abs(v - ref) / max(abs(ref), 1e-3))
             assert abs(v - ref) <= tol * max(abs(ref), 1e-3), (step, k, v, ref)
         if step == 0:
             for n, p in model.named_parameters():
@@ -533,6 +548,11 @@ FULL_CASES = {
 }
 
 
+# measured: the L1 norm of the full fc6 weight gradient (100-200 M entries) is within 9.7e-6 of the oracle's on every case,
+# while single entries differ by up to 2.3e-3 of the largest one (RoIPool arg-max flips, below)
+FULL_FC1_L1_TOL = 1e-4
+
+
 @pytest.mark.parametrize("case", list(FULL_CASES))
 def test_full_size_train_step_matches_oracle_fp32(case):
     """One full-size train step (fwd + bwd + SGD) in the fp32 parity mode vs the CPU oracle on the same seeded
@@ -566,7 +586,11 @@ def test_full_size_train_step_matches_oracle_fp32(case):
     for n in names:
         g, rg = sd[n].grad.detach().cpu(), ref_grads[n]
         if n.endswith("fc1.weight"):  # 100-200 M entries: compare a strided sample and the L1 norm
+            l1, rl1 = float(g.double().abs().sum()), float(rg.double().abs().sum())
+            _record("full_size.%s.fc1_l1" % case, abs(l1 - rl1) / rl1)
+            assert abs(l1 - rl1) < FULL_FC1_L1_TOL * rl1, (case, l1, rl1)
             g, rg = g.reshape(-1)[::4099], rg.reshape(-1)[::4099]
+        _record("full_size.%s.grad.%s" % (case, n), _relerr(g.numpy(), rg.numpy()))
         # (4e-3: fc1.weight's gradient holds single pooled activations - a RoIPool window whose two largest values differ
         # by less than the trunk's fp32 rounding picks the other one; 1.4e-3 .. 2.3e-3 depending on which conv kernel
         # (summation order) served the res4 layers, with all losses within 1e-4)
@@ -607,6 +631,7 @@ def test_pcl_heads_two_steps_vs_oracle_fp32():
         assert set(got) == set(ref_losses)
         for k in got:
             tol = 1e-4 if step == 0 else 2e-2
+            _record("pcl_two_steps.step%d.%s" % (step, k), abs(got[k] - float(ref_losses[k])) / max(abs(float(ref_losses[k])), 1e-3))
             assert abs(got[k] - float(ref_losses[k])) <= tol * max(abs(float(ref_losses[k])), 1e-3), (step, k, got[k])
         if step == 0:
             tg = model.roi_heads._last_state["aux"]["targets"]

@@ -70,6 +70,11 @@ def test_plan_follows_weight_updates():
     bb.res3[0].conv2.invalidate_packs()
     a1b, b1b = _both(model, xs[0])
     assert torch.equal(a1b[k], b1b[k]) and not torch.equal(a1b[k], a1[k])
+    # a re-assigned `.data` (another tensor, same version counter): the plan's key holds data_ptr as well
+    with torch.no_grad():
+        bb.res3[0].conv2.weight.data = bb.res3[0].conv2.weight.data.clone() * 2.0
+    a1c, b1c = _both(model, xs[0])
+    assert torch.equal(a1c[k], b1c[k]) and not torch.equal(a1c[k], a1b[k])
     model.float()  # Module._apply: parameters / buffers may have moved - the plans are dropped
     assert "_plans" not in bb.__dict__
     a2, b2 = _both(model, xs[1])
