@@ -258,6 +258,8 @@ def main():
     ap.add_argument("--col-rounds", type=int, default=None,
                     help="N=1: fc6 dW in COLUMN slabs of this many exact rounds of the persistent GEMM, each updated by the "
                          "optimizer the moment it is queued (0 = the two row slabs of round 3)")
+    ap.add_argument("--peel-side", type=int, default=0,
+                    help="A/B: 1 = the joint peel of the fc6 dW on the optimizer stream instead of in front of the first slab")
     ap.add_argument("--ims-per-gpu", type=int, default=1,
                     help="images per GPU per iteration; 1 = the reference's operating point and the headline metric, "
                          "larger values are the side measurement SURVEY 8(d) asks for")
@@ -388,6 +390,7 @@ def main():
         model.roi_heads._engine.fc7_bwd_pair = False
     if args.fc7_dx_splits:
         model.roi_heads._engine.fc7_pair_dx_splits = args.fc7_dx_splits
+    opt.peel_on_opt_stream = bool(args.peel_side)
     if not args.no_pipelined_sgd:
         # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,

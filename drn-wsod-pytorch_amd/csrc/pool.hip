@@ -117,6 +117,8 @@ struct RoiParams {
   int cpb;       // 64-ROI kernel: consecutive 8-channel chunks handled by one block (bin bounds computed once per block)
   int pf;        // 64-ROI kernel: two map buffers, the next chunk's slice is fetched under this chunk's scan
   int t_c0;      // first channel whose rows of out_t are needed (drn_roi_pool_nhwc_t); kernels may write more
+  int c_begin;   // 64-ROI kernel: first channel it handles (the lane-per-bin kernel writes A; this one then only the A^T tail)
+  int lane_g;    // lane-per-bin kernel: ROIs per block
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -692,7 +694,7 @@ __global__ __launch_bounds__(JMAX >= 13 ? 256 : JMAX >= 7 ? 512 : 1024, JMAX >= 
   __shared__ unsigned char hb[ROI_G64][7][2], wb[ROI_G64][7][2];
   __shared__ int bidx[ROI_G64];
   __shared__ float mulv[ROI_G64];
-  const int nchunks = p.C / G64_CH, nblk = nchunks / p.cpb;   // blocks per ROI group
+  const int nchunks = (p.C - p.c_begin) / G64_CH, nblk = nchunks / p.cpb;   // blocks per ROI group
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int group = logical / nblk, cb = logical - group * nblk;
   const int m0 = group * ROI_G64;
@@ -772,13 +774,13 @@ __global__ __launch_bounds__(JMAX >= 13 ? 256 : JMAX >= 7 ? 512 : 1024, JMAX >= 
     }
   };
   if (p.pf) {
-    fetch(cb * p.cpb * G64_CH);
+    fetch(p.c_begin + cb * p.cpb * G64_CH);
     stash(smem);
     __syncthreads();
   }
   typedef int i32x2_t __attribute__((ext_vector_type(2)));
   for (int cc = 0; cc < p.cpb; ++cc) {  // the block's channel chunks: same ROIs, same bin bounds
-    const int c0 = (cb * p.cpb + cc) * G64_CH;
+    const int c0 = p.c_begin + (cb * p.cpb + cc) * G64_CH;
     // the packed table stays packed: without this the compiler hoists every unpacked field (and every product with a
     // pitch) out of the chunk loop - ~60 more live registers, i.e. spills at the 128 that two blocks per CU allow
 #pragma unroll
@@ -924,6 +926,193 @@ __global__ __launch_bounds__(JMAX >= 13 ? 256 : JMAX >= 7 ? 512 : 1024, JMAX >= 
   }  // channel chunks of this block
 }
 
+// 7x7 ROIPool, LANE-PER-BIN variant (round 4): the training operand A in bf16.
+// What bounded the 64-ROI kernel above (88 us for the 201 MB of A at the bench shape = 0.29 of the HBM roofline, its
+// traffic 1.03x algorithmic): ~240 VALU instructions per (ROI, bin, 8 channels) item - a per-pixel window loop whose
+// trip counts differ lane by lane and that waits out the LDS latency at every pixel (ISA: ds_read_b128, s_waitcnt
+// lgkmcnt(0), four v_pk_max_i16, six loop-control instructions), an epilogue that scatters every item's 8 channels into a
+// [ROI][channel][bin] LDS tile as eight 2-byte writes, and a second pass that reads the tile back for the stores.
+// Here a WAVE owns one ROI and lane l < 49 owns bin l:
+//   * channel c's 49 bins sit in 49 consecutive lanes, and A[r][c * 49 + bin] is exactly that order: every channel
+//     leaves as ONE 98-byte run per store instruction (global_store_short / _short_d16_hi on the packed pair) - no LDS
+//     tile, no transposition, no second pass, no barrier per chunk;
+//   * the bin windows are computed once per ROI and serve all NCK 8-channel chunks of the block's slice: per window
+//     pixel one address and NCK independent 16-byte LDS reads (all in flight together) feed NCK x 4 v_pk_max_i16;
+//   * window loops run to the wave's LARGEST window with clamped coordinates (a pixel read twice does not change a
+//     maximum): uniform trip counts, no divergence, nothing waits per pixel.
+// LDS: [NCK][H*W][16 B] (8 channels of a pixel, order-mapped bf16), staged once per run of same-image ROIs of the block.
+// Bit-identical to the kernels above (same maxima, same fp32 scaling, same RNE conversion).  15 of 64 lanes idle.
+template <int NCK, int NWV = 8>
+__global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = p.H * p.W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = NWV;
+  // window pixels per trip of the scan: with one or two chunks per block (large maps: windows of 4-15 pixels a side) four
+  // clamped pixels of a row go out together - four independent LDS reads in flight instead of one per trip
+  constexpr int UNR = NCK <= 2 ? 4 : 1;
+  const int nslice = p.C / (8 * NCK);
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int group = logical / nslice, sl = logical - group * nslice;
+  const int m0 = group * p.lane_g;
+  const int nr = min(p.lane_g, p.M - m0);
+  const int c0 = sl * 8 * NCK;
+  const int ph = lane / 7, pw = lane - ph * 7;
+  const bool is_bin = lane < 49;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned cstride = (unsigned)HW * 16u;
+  // every wave keeps the group's ROIs in its lanes (lane l: ROI m0 + l; <= 64 per block): box corners on the map, image
+  // index, scale - one round of loads per block instead of a dependent scalar load chain per ROI; a ROI's values reach all
+  // lanes through v_readlane (the ROI index is wave-uniform)
+  int vx1 = 0, vy1 = 0, vx2 = 0, vy2 = 0, vimg = -1;
+  float vmul = 1.f;
+  if (lane < nr) {
+    const float* roi = p.rois + 5 * (long)(m0 + lane);
+    vimg = (int)roi[0];
+    vx1 = (int)roundf(roi[1] * p.scale);
+    vy1 = (int)roundf(roi[2] * p.scale);
+    vx2 = (int)roundf(roi[3] * p.scale);
+    vy2 = (int)roundf(roi[4] * p.scale);
+    vmul = p.obj ? p.obj[m0 + lane] + 1.f : 1.f;
+  }
+  // runs of ROIs on the same image as a bit mask of run ends (one run in all but ragged batches)
+  const int nxt = __shfl_down(vimg, 1, 64);
+  const unsigned long long runs = __ballot(lane < nr && (lane + 1 >= nr || nxt != vimg));
+  int cur_img = -1;
+  for (int r0 = 0; r0 < nr;) {
+    const int b = __builtin_amdgcn_readlane(vimg, r0);
+    const int r1 = r0 + __builtin_ctzll(runs >> r0) + 1;
+    if (b != cur_img) {
+      if (cur_img >= 0) __syncthreads();  // every wave is done with the previous image's slice
+      // (built and measured: staging from a chunk-major copy of the map, [N][C / 8][H * W][8] - every slice one contiguous run
+      // instead of 16 bytes of each 2-KB pixel - moved the launch by 2-5 % at 43x58 .. 63x92: the scan bounds it, not the
+      // staging's sector over-fetch; the extra entry points were removed again)
+      const char* fb = p.feat + ((long)b * HW * p.C + c0) * 2;
+      for (int idx = tid; idx < HW * NCK; idx += NW * 64) {
+        const int px = idx / NCK, c = idx - px * NCK;
+        i32x4_t x = *(const i32x4_t*)(fb + (long)px * p.C * 2 + c * 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
+        *(i32x4_t*)(smem + ((long)c * HW + px) * 16) = x;
+      }
+      __syncthreads();
+      cur_img = b;
+    }
+    for (int r = r0 + wave; r < r1; r += NW) {
+      const int x1 = __builtin_amdgcn_readlane(vx1, r), y1 = __builtin_amdgcn_readlane(vy1, r);
+      const int x2 = __builtin_amdgcn_readlane(vx2, r), y2 = __builtin_amdgcn_readlane(vy2, r);
+      const float mul = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vmul), r));
+      const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+      const float bin_h = (float)rh / 7.f, bin_w = (float)rw / 7.f;
+      const int hs = min(max((int)floorf((float)ph * bin_h) + y1, 0), p.H);
+      const int he = min(max((int)ceilf((float)(ph + 1) * bin_h) + y1, 0), p.H);
+      const int ws = min(max((int)floorf((float)pw * bin_w) + x1, 0), p.W);
+      const int we = min(max((int)ceilf((float)(pw + 1) * bin_w) + x1, 0), p.W);
+      const bool empty = he <= hs || we <= ws;
+      const int nh = (is_bin && !empty) ? he - hs : 0, nw = (is_bin && !empty) ? we - ws : 0;
+      int max_nh = 0, max_nw = 0;  // the wave's largest window (uniform)
+      while (__ballot(max_nh < nh) != 0) ++max_nh;
+      while (__ballot(max_nw < nw) != 0) ++max_nw;
+      const int lo = (int)0x80008000u;
+      i32x4_t acc[NCK];
+#pragma unroll
+      for (int c = 0; c < NCK; ++c) acc[c] = i32x4_t{lo, lo, lo, lo};
+      // (built and measured: the same loops with every read PREDICATED on the lane's own window instead of clamped - a third
+      // of the LDS bytes - are slower at every map size, 61 -> 67 us at 14x14 and 350 -> 404 us at 63x92: the exec-mask
+      // bookkeeping and the re-initialised operands cost more issue slots than the reads cost LDS cycles)
+      for (int hi = 0; hi < max_nh; ++hi) {
+        const int hr = min(max(min(hs + hi, he - 1), 0), p.H - 1);
+        const unsigned arow = lds0 + (unsigned)(hr * p.W) * 16u;
+        const int wlast = min(max(we - 1, 0), p.W - 1), wfirst = min(max(ws, 0), p.W - 1);
+        for (int wi = 0; wi < max_nw; wi += UNR) {
+          i32x4_t x[UNR][NCK];
+#pragma unroll
+          for (int u = 0; u < UNR; ++u) {
+            const int wc = min(wfirst + wi + u, wlast);  // clamped: a pixel read twice does not change a maximum
+            const unsigned a = arow + (unsigned)wc * 16u;
+#pragma unroll
+            for (int c = 0; c < NCK; ++c)
+              x[u][c] = *(__attribute__((address_space(3))) const i32x4_t*)(uintptr_t)(a + (unsigned)c * cstride);
+          }
+#pragma unroll
+          for (int u = 0; u < UNR; ++u)
+#pragma unroll
+            for (int c = 0; c < NCK; ++c)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) acc[c][e] = pk_max_i16(acc[c][e], x[u][c][e]);
+        }
+      }
+      if (is_bin) {
+        bf16_t* dst = (bf16_t*)p.out + (long)(m0 + r) * p.ld_out + (long)c0 * 49 + lane;
+
+#pragma unroll
+        for (int c = 0; c < NCK; ++c)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            // (an empty bin is +0 in both halves; one packed conversion - v_cvt_pk_bf16_f32, RNE like f32_to_bf16 - and the
+            // two halves of its result leave through global_store_short / global_store_short_d16_hi)
+            const uint32_t y = empty ? 0u : (uint32_t)bf16x2_order(acc[c][e]);
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t f = f32x2_t{__builtin_bit_cast(float, y << 16), __builtin_bit_cast(float, y & 0xffff0000u)} * mul;
+            const uint32_t o = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+            dst[(c * 8 + 2 * e) * 49] = (bf16_t)(o & 0xffffu);
+            dst[(c * 8 + 2 * e + 1) * 49] = (bf16_t)(o >> 16);
+          }
+      }
+    }
+    r0 = r1;
+  }
+}
+
+static int g_roi_lane = 1;  // drn_tune(DRN_TUNE_ROI_LANE = 19): 0 = the 64-ROI kernel writes A as before
+// A (all channels) through the lane-per-bin kernel; false when the map slice of even ONE chunk does not fit
+// chunks per block: as many as fit 38 KB (four 8-wave blocks per CU), else 76 KB (two), else one chunk in <= 154 KB; 0: none fits
+static int roi_lane_chunks(int H, int W, int C) {
+  if (C % 8) return 0;
+  const size_t per_chunk = (size_t)H * W * 16;
+  size_t budget = 38 * 1024;
+  for (int pass = 0; pass < 3; ++pass, budget = pass == 1 ? 76 * 1024 : 154 * 1024)
+    for (int k = 8; k >= 1; k >>= 1)
+      if ((C / 8) % k == 0 && per_chunk * k <= budget) return k;
+  return 0;
+}
+
+static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
+  RoiParams p = p0;
+  if (!g_roi_lane || p.C % 8) return false;
+  const size_t per_chunk = (size_t)p.H * p.W * 16;
+  const int nck = roi_lane_chunks(p.H, p.W, p.C);
+  if (!nck) return false;
+  const size_t smem = per_chunk * nck;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+      return false;
+    attr = true;
+  }
+  // ROIs per block: 32 (four per wave) - the staging of the slice is then ~1/8 of the block's output bytes at 14x14; large
+  // maps (one chunk of 60+ KB per block) take 64 so that the slice is staged half as often
+  p.lane_g = smem > 38 * 1024 ? 64 : 32;
+  const int ngroups = (p.M + p.lane_g - 1) / p.lane_g;
+  const bool big = smem > 76 * 1024;  // one block per CU: 16 waves
+  // one block per CU (maps beyond ~4700 pixels): measured 372 vs 325 us for the 64-ROI kernel at 63x92, but 368 vs 415 us
+  // at 75x122, where that kernel stages its slice in two row bands - this kernel takes those (19=2 forces it everywhere)
+  if (big && per_chunk + (size_t)ROI_G64 * G64_PITCH <= (size_t)154 * 1024 && (int)g_roi_lane < 2) return false;
+  const dim3 grid((unsigned)ngroups * (p.C / (8 * nck))), block(big ? 1024 : 512);
+  p.out_t = nullptr;  // (A only; the caller launches the 64-ROI kernel for the A^T tail chunks)
+  if (nck == 8) hipLaunchKernelGGL(roi_pool7_lane_kernel<8>, grid, block, smem, st, p);
+  else if (nck == 4) hipLaunchKernelGGL(roi_pool7_lane_kernel<4>, grid, block, smem, st, p);
+  else if (nck == 2) hipLaunchKernelGGL(roi_pool7_lane_kernel<2>, grid, block, smem, st, p);
+  else if (big) hipLaunchKernelGGL((roi_pool7_lane_kernel<1, 16>), grid, block, smem, st, p);
+  else hipLaunchKernelGGL(roi_pool7_lane_kernel<1>, grid, block, smem, st, p);
+  return true;
+}
+
 static int cu_count_pool() {
   static int n = 0;
   if (!n) {
@@ -989,7 +1178,7 @@ static bool launch_roi_map64(const RoiParams& p0, hipStream_t st) {
   // paid once per `cpb` chunks instead of once per chunk; largest power of two <= the knob that still leaves two blocks
   // for every CU
   int cpb = g_roi_cpb;
-  const int nchunks = p.C / G64_CH;
+  const int nchunks = (p.C - p.c_begin) / G64_CH;
   while (cpb > 1 && (nchunks % cpb || (long)(nchunks / cpb) * ngroups < 2L * cu_count_pool())) cpb >>= 1;
   p.cpb = cpb;
   const dim3 grid((nchunks / cpb) * ngroups), block(threads);
@@ -1114,6 +1303,12 @@ __attribute__((visibility("hidden"))) int drn_roi_set_map64_a(int on) {
 __attribute__((visibility("hidden"))) int drn_roi_set_lds_kb(int kb) {
   const int old = g_roi_lds_kb;
   if (kb >= 60 && kb <= 154) g_roi_lds_kb = kb;
+  return old;
+}
+
+__attribute__((visibility("hidden"))) int drn_roi_set_lane(int on) {
+  const int old = g_roi_lane;
+  g_roi_lane = on < 0 ? 0 : on > 2 ? 2 : on;
   return old;
 }
 
@@ -1280,8 +1475,25 @@ int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* object
       // slice whose map fits at all - the 43x58 .. 75x100 maps of test-time scales need 16 or 8 channels and most of
       // a CU's LDS (one block per CU), which still beats the per-ROI window kernels by 3-4x there
       const size_t two = 80 * 1024, one = 156 * 1024;
-      if (in_dtype == DRN_BF16 && (out_t || g_roi_map64_a) && M >= ROI_G64)  // the training operand pair: full-line A^T rows
-        done = launch_roi_map64(p, st);
+      if (in_dtype == DRN_BF16 && (out_t || g_roi_map64_a) && M >= ROI_G64) {  // the training operand pair
+        // round 4: A from the lane-per-bin kernel; the 64-ROI kernel - full 128-byte A^T lines - then only for the channel
+        // chunks whose A^T rows the fc6 dW still reads (the tail its peel takes; it writes their A runs again, same values)
+        // (built and measured: the tail's A^T rows as 2-byte stores from the lane kernel itself - 49 partial lines per
+        // instruction - cost 40 us for 4.7 MB at the bench shape; the 64-ROI kernel's full lines cost ~8 us as a launch)
+        const int cb = out_t ? p.t_c0 / G64_CH * G64_CH : C;
+        const bool few_t = !out_t || (long)(C - cb) * 8 <= C;
+        if (few_t && C % G64_CH == 0 && launch_roi_lane(p, st)) {
+          done = true;
+          if (out_t && cb < C) {
+            RoiParams q = p;
+            q.c_begin = cb;
+            done = launch_roi_map64(q, st);
+            if (!done) done = launch_roi_map64(p, st);  // (cannot happen for shapes the lane kernel took)
+          }
+        } else {
+          done = launch_roi_map64(p, st);
+        }
+      }
       if (done) {
       } else if (in_dtype == DRN_BF16)
         // (maps too large for two 8-ROI blocks per CU - inference at real image sizes, no A^T - also take the 64-ROI

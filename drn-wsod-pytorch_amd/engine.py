@@ -192,6 +192,10 @@ class FusedSGD:
         e.defer_colsum = True
         self._dp, self._pipelined = dp, True
         self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+        # the joint peel of the fc6 dW (run_fc1_tail) may run on the optimizer stream, off the main stream's chain:
+        # single-process schedule only (with an exchange that stream carries the collectives, which must not queue behind it)
+        e.fc1_peel_stream = self._opt_stream if (getattr(self, "peel_on_opt_stream", False) and
+                                                 not (dp is not None and dp.exchange)) else None
         self._bucket_segs = {}
         # with an exchange the optimizer stream carries only the link-bound all-reduces (one event per bucket); the
         # HBM-bound SGD launches are issued by step() on the caller's stream, each behind its bucket's event, so the

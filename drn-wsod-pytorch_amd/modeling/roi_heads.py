@@ -993,7 +993,19 @@ class _HeadEngine:
                     n0 = cols.pop()
                     if n0 < at_row0:
                         raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (n0, at_row0))
-                    ops.gemm_nt(dP1T, AT[n0:], D1, K1 - n0, Mp, out=gw[:, n0:].unsqueeze(0))
+                    side = getattr(self, "fc1_peel_stream", None)
+                    if side is not None and not torch.cuda.is_current_stream_capturing():
+                        # round 4: the peeled columns (512 short small-tile workgroups, 20 us) leave the main stream's dependent
+                        # chain - they run on the optimizer stream beside the first slab's persistent launch (they share its
+                        # CUs like the trunk's conv workgroups do) and in front of every slab's update, which that stream
+                        # carries in order
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream())
+                        side.wait_event(ev)
+                        with torch.cuda.stream(side):
+                            ops.gemm_nt(dP1T, AT[n0:], D1, K1 - n0, Mp, out=gw[:, n0:].unsqueeze(0))
+                    else:
+                        ops.gemm_nt(dP1T, AT[n0:], D1, K1 - n0, Mp, out=gw[:, n0:].unsqueeze(0))
             for r0, r1 in slabs:
                 if tn:
                     # main columns (exact rounds of the persistent kernel) straight from A; a slab whose peel was not part

@@ -584,6 +584,42 @@ def test_roi_pool_transposed_tail_hint(drn, C, H, W, R, t0):
     assert torch.equal(t_full[:, :R], a_full[:, :k].t())
 
 
+@pytest.mark.parametrize("C,H,W,R,t0,n_img", [(1024, 14, 14, 2000, 1003, 1), (128, 14, 14, 83, 117, 3), (64, 28, 28, 200, 58, 2),
+                                              (128, 50, 76, 300, 120, 2), (16, 63, 92, 130, 15, 2), (24, 40, 37, 65, 22, 4),
+                                              (16, 75, 122, 130, 15, 2), (64, 14, 14, 100, 0, 2)])
+def test_roi_pool_lane_kernel_equals_map64(drn, C, H, W, R, t0, n_img):
+    """Round 4: the lane-per-bin kernel (a wave per ROI, lane = bin, every channel one 98-byte store run; DRN_TUNE_ROI_LANE)
+    writes the bf16 training operand A; the 64-ROI kernel keeps only the A^T tail.  Against the 64-ROI kernel alone and
+    against the oracle, bit for bit: ragged image runs inside a block's ROI group, degenerate / clipped boxes, 1 .. 8 channel
+    chunks per block, maps from 14x14 to one chunk per CU, and a map too large for it (falls back, same result)."""
+    dtype, P, scale = torch.bfloat16, 7, 1.0 / 16
+    feat = _rnd((n_img, C, H, W), 41)
+    rois = _rois(R, n_img, W / scale, H / scale, 42)
+    rois[:, 0] = torch.sort(rois[:, 0]).values if n_img != 3 else rois[:, 0]  # n_img == 3: image index changes every few ROIs
+    obj = torch.rand(R)
+    fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    k = C * P * P
+    res = {}
+    for lane in (2, 1, 0):  # 2: also for maps that leave one block per CU (default 1 hands most of those to the 64-ROI kernel)
+        old = drn.tune(19, lane)
+        try:
+            a = torch.full((R, drn.kpad(k, dtype)), 3.0, dtype=dtype, device=DEV)
+            a[:, k:] = 0
+            t = torch.full((k, drn.kpad(R, dtype)), 7.0, dtype=dtype, device=DEV)
+            drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale, out=a, out_t=t, t_first_channel=t0)
+            torch.cuda.synchronize()
+            res[lane] = (a, t)
+        finally:
+            drn.tune(19, old)
+    ref, _ = O.roi_pool_forward(_q(feat, dtype), rois, P, scale)
+    ref = _q(ref * (obj + 1).view(-1, 1, 1, 1), dtype).reshape(R, -1)
+    for lane in (2, 1):
+        assert torch.equal(res[lane][0], res[0][0]), lane
+        assert torch.equal(res[lane][0][:, :k].float().cpu(), ref), lane
+        assert torch.equal(res[lane][1][t0 * 49:, :R], res[lane][0][:, t0 * 49: k].t()), lane
+        assert torch.equal(res[lane][1][t0 * 49:, :R], res[0][1][t0 * 49:, :R]), lane
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("aligned,sr", [(False, 0), (True, 0), (True, 2)])
 def test_roi_align(drn, dtype, aligned, sr):
