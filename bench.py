@@ -300,7 +300,7 @@ def main():
     ap.add_argument("--no-selftest", action="store_true", help="N > 1: skip the collective self-test in front of the warm-up")
     ap.add_argument("--selftest-timeout", type=float, default=120.0,
                     help="seconds a self-test collective may take before the run fails loudly instead of hanging")
-    ap.add_argument("--exchange", choices=["sharded", "allreduce"], default=None,
+    ap.add_argument("--exchange", choices=["sharded", "allreduce", "fc6_kshard"], default=None,
                     help="N > 1: sharded (default) = reduce-scatter of each fc6 gradient slab, SGD on the owned rows (1/N of "
                          "the optimizer traffic), all-gather of the updated bf16 rows; allreduce = DDP's all-reduce + "
                          "replicated update")
@@ -537,8 +537,15 @@ def main():
                     "frac": ach / BF16_MFMA_PEAK_TFLOPS, "gflop_per_launch": fl / 1e9, "avg_launch_ms": ms,
                     "launches_timed": len(sel)}
 
-        fwd = entry("gemm_nt256_kernel<bf16> fc6 forward [%d x %d] . [%d x %d]^T (split-K)" % (Rtot, K1, D1, K1),
-                    {(Rtot, D1, K1p)}, 2.0 * Rtot * D1 * K1)
+        kshard = bool(getattr(opt, "_kshard", False))
+        if kshard:
+            # fc6 sharded along K: this rank multiplies every rank's proposals with its K / N columns - the same FLOPs
+            kc = K1 // world
+            fwd = entry("gemm_nt256p_kernel<bf16> fc6 forward, K-sharded: [%d x %d] . [%d x %d]^T" % (world * Rtot, kc, D1, kc),
+                        {(world * Rtot, D1, kc)}, 2.0 * world * Rtot * D1 * kc)
+        else:
+            fwd = entry("gemm_nt256_kernel<bf16> fc6 forward [%d x %d] . [%d x %d]^T (split-K)" % (Rtot, K1, D1, K1),
+                        {(Rtot, D1, K1p)}, 2.0 * Rtot * D1 * K1)
         roof = None
         launches = []
         if fwd:
@@ -562,6 +569,13 @@ def main():
                        % (n0, K1, D1, Rtot, K1 - n0, Rtot), {(D1, K1 - n0, Mp)}, 2.0 * D1 * (K1 - n0) * Rtot)
             if e_:
                 launches.append(e_)
+        if kshard:
+            kc = K1 // world
+            e_ = entry("gemm_nt256(p)_kernel<bf16, TN> fc6 dW, K-sharded: [%d x %d] . [%d x %d]" % (D1, world * Rtot, world * Rtot, kc),
+                       {(D1, kc, ops.kpad(world * Rtot, torch.bfloat16))}, 2.0 * D1 * kc * world * Rtot)
+            if e_:
+                launches.append(e_)
+            ends = []
         col_plan = model.roi_heads._engine._fc1_col_plan(torch.bfloat16, D1, K1) if not getattr(opt, "_exchange_on", False) else None
         if col_plan is not None:
             # column slabs (round 4): the trailing columns first, then slabs of exact rounds
@@ -645,7 +659,11 @@ def main():
                                   else "lookahead %d" % args.lookahead) if use_graph else "eager prefetch of the next batch",
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
                "grad_exchange": None if not dp.exchange else {
-                   "collective": ("RCCL reduce-scatter per fc6 dW row slab -> fused SGD on the owned rows -> all-gather of the "
+                   "collective": ("fc6 sharded along K over the ranks: all-gather of the feature maps / proposals -> this rank's channel "
+                                  "slice pooled for every rank's image -> fc6 partial GEMM -> RCCL reduce-scatter of the fp32 partial H1; "
+                                  "all-gather of dP1 -> dW of the owned columns -> SGD on them (no fc6 gradient exchange, no weight "
+                                  "gather); all-reduce for the small tensors" if getattr(opt, "_kshard", False) else
+                                  "RCCL reduce-scatter per fc6 dW row slab -> fused SGD on the owned rows -> all-gather of the "
                                   "updated compute copy; all-reduce for the small tensors" if getattr(opt, "_sharded", False)
                                   else "RCCL all-reduce per bucket (small tensors and fc6 dW row slabs)") + ", fc6_grad_dtype on the wire",
                    "slab_ends": getattr(opt, "_slab_ends", None), "ranks": rank_info,

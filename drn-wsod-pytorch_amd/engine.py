@@ -150,9 +150,18 @@ class FusedSGD:
             t = (d1 + 255) // 256
             slab_rows = [min(d1, ((t + 1) // 2) * 256)]
             slab_rows = sorted(set(r for r in slab_rows if 0 < r < d1)) + [d1]
-        if exchange not in (None, "sharded", "allreduce"):
-            raise DrnError("exchange must be 'sharded' or 'allreduce'")
-        self._sharded = world > 1 and exchange != "allreduce"
+        if exchange not in (None, "sharded", "allreduce", "fc6_kshard"):
+            raise DrnError("exchange must be 'sharded', 'allreduce' or 'fc6_kshard'")
+        # "fc6_kshard" (round 4, opt-in): fc6 is sharded along K over the ranks instead of replicated - rank k keeps the
+        # columns k of fc1.weight, pools that channel slice of every rank's image, and a reduce-scatter of the partial H1
+        # (forward) / an all-gather of dP1 (backward) replace the exchange of the 205-MB weight gradient; the optimizer
+        # updates only the owned columns (_HeadEngine.kshard).  The small tensors keep the all-reduce.  Fixed-shape batches,
+        # eager steps.
+        self._kshard = exchange == "fc6_kshard" and dp is not None and dp.exchange
+        if self._kshard:
+            e.kshard = dict(group=dp.group, world=world, rank=dist.get_rank(dp.group))
+            slab_rows = [d1]
+        self._sharded = world > 1 and exchange not in ("allreduce", "fc6_kshard")
         if self._sharded:
             r0 = 0
             for r1 in slab_rows:
@@ -180,7 +189,7 @@ class FusedSGD:
             warnings.warn("FusedSGD.enable_pipelined: the sharded gradient exchange does not apply (%s); using the "
                           "all-reduce exchange - every rank runs the full optimizer pass" % getattr(self, "_fallback", "?"))
         self._master_stale = False
-        if self._sharded:
+        if self._sharded or self._kshard:
             self._install_state_dict_hook()
         self._slab_ends = slab_rows
         e.fc1_slab_ends = slab_rows
@@ -266,6 +275,8 @@ class FusedSGD:
         optimizer must read when this bucket lives there instead of the fp32 arena."""
         e = self.engine
         bucket = e.fc1_grad_bucket if what != "small" else None
+        if what[0] == "fc1b":
+            return bucket  # K-sharded fc6: this rank's columns are already the sum over every rank's image
         if self._exchange_on:
             if what == "small":
                 o_fc1, _ = e._seg["fc1.weight"]  # arena order: everything else precedes fc1.weight
@@ -328,11 +339,29 @@ class FusedSGD:
         """Sharded exchange, bf16 mode: every rank's fp32 master weights and momentum are current only for the rows it
         updates (the forward reads the all-gathered bf16 shadow).  Before a checkpoint / state_dict() the owners' rows
         are gathered so that every rank holds the full fp32 state again."""
-        if not getattr(self, "_sharded", False) or not self._master_stale:
+        if not (getattr(self, "_sharded", False) or getattr(self, "_kshard", False)) or not self._master_stale:
             return
         self._rendezvous("sync_master() / state_dict() / DetectionCheckpointer.save()")
         if self._opt_stream is not None:
             torch.cuda.current_stream().wait_stream(self._opt_stream)
+        if getattr(self, "_kshard", False):
+            # K-sharded fc6: every rank owns a column block of fc1.weight (master, momentum, compute copy)
+            e = self.engine
+            o, n = e._seg["fc1.weight"]
+            d1, k1 = self.model.roi_heads.box_head.fc1.weight.shape
+            world = self._dp.world
+            q = k1 // world
+            rank = dist.get_rank(self._dp.group)
+            for t in (e.arena_w, self._mom, e.arena_s):
+                if t is None:
+                    continue
+                full = t[o: o + n].view(d1, k1)
+                mine = full[:, rank * q: (rank + 1) * q].contiguous()
+                allc = torch.empty((world, d1, q), dtype=t.dtype, device=t.device)
+                dist.all_gather_into_tensor(allc.view(-1), mine.view(-1), group=self._dp.group)
+                full.view(d1, world, q).copy_(allc.permute(1, 0, 2))
+            self._master_stale = False
+            return
         r0 = 0
         for r1 in self._slab_ends:
             self._gather_rows(("fc1", r0, r1), master_too=True)
@@ -403,7 +432,7 @@ class FusedSGD:
         if self._mom is None:
             self._mom = torch.zeros_like(e.arena_w)
         if what[0] == "fc1b":
-            if self._exchange_on:
+            if self._exchange_on and not getattr(self, "_kshard", False):
                 raise DrnError("column slabs of the fc6 weight gradient (fc1_col_rounds) are a single-process schedule; "
                                "with a gradient exchange the slabs are row ranges")
             # the block kernel takes the whole tensor's table entry (lr / wd on the device) + the block's bounds
@@ -436,6 +465,8 @@ class FusedSGD:
             ops.sgd_step_block(e.arena_w, self._mom, bucket if bucket is not None else e.arena_g, segs, r0, r1 - r0, c0,
                                c1 - c0, k1, self.momentum, self._steps == 0, 1.0 / world, shadow=e.arena_s,
                                grad_off=e._seg["fc1.weight"][0] if bucket is not None else 0)
+            if getattr(self, "_kshard", False):
+                self._master_stale = True  # the other ranks' columns of fc1.weight / momentum / shadow live on those ranks
             return
         if what != "small" and getattr(self, "_sharded", False) and self._exchange_on:
             # `bucket` = this rank's reduce-scattered rows: update them alone
@@ -476,7 +507,7 @@ class FusedSGD:
                 for what, bucket, segs, nseg, evc in self._deferred:
                     cur.wait_event(evc)
                     self._update(what, bucket, segs, nseg)
-                    if what != "small" and getattr(self, "_sharded", False):
+                    if what != "small" and what[0] != "fc1b" and getattr(self, "_sharded", False):
                         # the rows this rank just updated go to every other rank (optimizer stream: link-bound, beside
                         # the next bucket's update on this stream); the next forward waits for the last gather below
                         ev = torch.cuda.Event()
@@ -979,6 +1010,10 @@ class GraphedTrainStep:
         self._side = torch.cuda.Stream()
         self._primed = False
         self.split_tail = bool(split_tail)
+        if self.engine.kshard is not None and not (self.split_tail and self.eager_fc6 and self.eager_pool and
+                                                   (lookahead >= 2 or trunk_pairs)):
+            raise DrnError("K-sharded fc6 holds collectives in the pooling piece, behind the fc6 GEMM and in the dW tail: "
+                           "GraphedTrainStep(split_tail=True, eager_fc6=True, eager_pool=True, lookahead >= 2 or trunk_pairs)")
         self.engine.defer_fc1_tail = self.split_tail
         self.engine.pool_sets_pinned = None  # a new step captures anew: the previous owner's pin (if any) is void
         self.engine.pool_sets_pin_owner = None
@@ -1074,6 +1109,9 @@ class GraphedTrainStep:
         # (_stage_labels_ahead), -> the label block
         via = slot is not None and self.stage_ahead
         ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if via else None, self._gt_block if via else None)
+        if self.engine.kshard is not None:  # K-sharded fc6: this rank's channel slice of every rank's image (collectives, eager)
+            self.pooled = self.engine.pool_kshard(feat, self.rois_next, self.obj_next)
+            return
         self.pooled = self.engine.pool(feat, self.rois_next, self.obj_next, True, slot=0)
         self._check_pooled()
 
@@ -1234,6 +1272,9 @@ class GraphedTrainStep:
             # in front of the pooling kernel (see _pool_next)
             ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if self.stage_ahead else None,
                                    self._gt_block if self.stage_ahead else None)
+            if self.engine.kshard is not None:
+                self.pooled = self.engine.pool_kshard(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next)
+                return
             self.pooled = self.engine.pool(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next, True,
                                            slot=0)
             self._check_pooled()

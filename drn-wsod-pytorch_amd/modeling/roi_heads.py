@@ -21,6 +21,7 @@ import math
 from typing import Dict, List, Optional
 
 import torch
+import torch.distributed as dist
 from torch import nn
 
 from .. import compute_dtype, ops
@@ -628,6 +629,8 @@ class _HeadEngine:
         h = self.h
         dev, dtype = pooled["A"].device, pooled["A"].dtype
         self.ensure(dev)
+        if pooled.get("kshard"):
+            return self._fc6_partials_kshard(pooled, M)
         self.refresh_shadows(dtype)
         D1, K1 = h.box_head.fc1.weight.shape
         w = self.ws(M, dtype, training)
@@ -638,13 +641,119 @@ class _HeadEngine:
         ops.gemm_nt(pooled["A"], self.sh["W1v"], M, D1, K1p, out=w["part1"], splits=s)
         return w["part1"]
 
+    # ---- fc6 sharded along K over the data-parallel ranks (round 4; FusedSGD.enable_pipelined(exchange="fc6_kshard")) ------
+    # Data parallelism exchanges the fc6 weight gradient - 205 MB in bf16 per step and GPU, against 1.3 ms of compute with one
+    # image per GPU - and has every rank run the 2-GB optimizer pass (or, sharded, gather 205 MB of updated weights).  fc6
+    # is H1 = A . W^T with K = C*49 = 50176: rank k keeps the COLUMNS k of W (channels k*C/N .. (k+1)*C/N of the pooled
+    # features - `c*49 + bin` makes a channel range a column range), pools that channel slice of ALL N ranks' images (the
+    # ranks all-gather their 0.4-MB feature maps and 40-KB proposal lists, not their 200-MB pooled matrices), multiplies
+    # [N*R x K/N] . [D1 x K/N]^T - the same FLOPs as its own [R x K] . [D1 x K]^T - and a reduce-scatter over row blocks hands
+    # every rank the complete H1 of its own image.  Backward: all-gather of dP1 (8 MB per rank), dW[:, columns k] =
+    # dP1_all^T . A_k - again the same FLOPs - and the optimizer updates only those columns: no gradient exchange and no
+    # weight gather for fc6 at all, 1/N of the optimizer traffic.  Wire bytes per step and GPU at N = 8: 2 x 57 MB
+    # (fp32 partial sums of H1 out, bf16 dP1 in) instead of 2 x 180 MB.  The arithmetic is the mean-gradient step of DDP
+    # (detectron2/engine/defaults.py:279-282) up to the fp32 summation order of the K blocks.
+    kshard = None  # dict(group, world, rank) once enabled
+
+    def _ks_gather(self, t):
+        ks = self.kshard
+        out = torch.empty((ks["world"],) + tuple(t.shape), dtype=t.dtype, device=t.device)
+        dist.all_gather_into_tensor(out.view(-1), t.contiguous().view(-1), group=ks["group"])
+        return out
+
+    def pool_kshard(self, feat_nhwc, rois, objectness):
+        """pooled operand of the K-sharded fc6: this rank's channel slice of EVERY rank's image -> A_k [N*M, (C/N)*P*P]
+        (collectives on the current stream: all-gather of the feature maps, proposals and objectness)"""
+        h, ks = self.h, self.kshard
+        N, rank = ks["world"], ks["rank"]
+        dtype = feat_nhwc.dtype
+        M = rois.shape[0]
+        n, H, W, C = feat_nhwc.shape
+        ka = h.box_pooler.kernel_args()
+        pp = ka["P"] * ka["P"] if "P" in ka else 49
+        if C % N or ((C // N) * pp * ops.esize(dtype)) % 128:
+            raise DrnError("fc6 K-sharding needs the channel count %d to split over %d ranks into whole 128-byte K slabs" % (C, N))
+        # equal shapes on all ranks (fixed-size batches; ragged real data keeps the sharded gradient exchange)
+        key = (n, H, W, C, M)
+        if ks.get("checked") != key:
+            shp = torch.tensor(key, dtype=torch.int64, device=feat_nhwc.device)
+            allshp = self._ks_gather(shp)
+            if not bool((allshp == shp).all()):
+                raise DrnError("fc6 K-sharding needs the same image / proposal shapes on every rank (got %s)" % allshp.tolist())
+            ks["checked"] = key
+        c0, c1 = rank * (C // N), (rank + 1) * (C // N)
+        feats = self._ks_gather(feat_nhwc)[..., c0:c1].reshape(N * n, H, W, c1 - c0).contiguous()
+        rois_all = self._ks_gather(rois)
+        rois_all[:, :, 0] += (torch.arange(N, device=rois.device, dtype=rois.dtype) * n).view(N, 1)
+        rois_all = rois_all.view(N * M, 5)
+        obj_all = self._ks_gather(objectness).view(N * M) if objectness is not None else None
+        cols = (c1 - c0) * pp
+        MA = N * M
+        D1 = h.box_head.fc1.weight.shape[0]
+        buf = ks.get("A")
+        if buf is None or buf.shape != (MA, cols) or buf.dtype != dtype:
+            buf = ks["A"] = torch.zeros((MA, cols), dtype=dtype, device=feat_nhwc.device)
+            ks["part"] = torch.empty((1, MA, D1), dtype=torch.float32, device=feat_nhwc.device)
+            ks["h1"] = torch.empty((1, M, D1), dtype=torch.float32, device=feat_nhwc.device)
+        ops.roi_pool_nhwc(feats, rois_all, obj_all, out=buf, **ka)
+        ks["cols"] = (c0 * pp, c1 * pp, MA)
+        return dict(A=buf, AT=None, t_row0=0, kshard=True, state="current", M=M)
+
+    def _fc6_partials_kshard(self, pooled, M):
+        """[N*M x K/N] . [D1 x K/N]^T on this rank's columns of the compute copy, then the reduce-scatter over row blocks:
+        -> the complete fp32 pre-activation of THIS rank's proposals, [1, M, D1]"""
+        ks = self.kshard
+        k0, k1, MA = ks["cols"]
+        dtype = pooled["A"].dtype
+        self.refresh_shadows(dtype)
+        D1 = self.h.box_head.fc1.weight.shape[0]
+        W1k = self.sh["W1v"][:, k0:k1]  # (row pitch K1)
+        # few ranks leave too few 256x256 tiles for the CUs (N = 2: 16 x 8): split K like the replicated forward does and
+        # add the splits up in split order before the wire
+        tiles = ((MA + 255) // 256) * ((D1 + 255) // 256)
+        nslab = (k1 - k0) * ops.esize(dtype) // 128
+        sp = max(1, min(256 // max(tiles, 1), nslab // 16, 8))
+        if sp > 1:
+            if ks.get("parts") is None or ks["parts"].shape[0] != sp:
+                ks["parts"] = torch.empty((sp, MA, D1), dtype=torch.float32, device=pooled["A"].device)
+            ops.gemm_nt(pooled["A"], W1k, MA, D1, k1 - k0, out=ks["parts"], splits=sp)
+            torch.sum(ks["parts"], dim=0, keepdim=True, out=ks["part"])
+        else:
+            ops.gemm_nt(pooled["A"], W1k, MA, D1, k1 - k0, out=ks["part"])
+        dist.reduce_scatter_tensor(ks["h1"].view(-1), ks["part"].view(-1), group=ks["group"])
+        return ks["h1"]
+
+    def _fc6_tail_kshard(self, w, M, D1, K1, dtype, gw, hook):
+        """dW[:, own columns] = dP1_all^T . A_k (run_fc1_tail, K-sharded fc6)"""
+        ks = self.kshard
+        k0, k1, MA = ks["cols"]
+        dP1_all = self._ks_gather(w["dP1"][:M, :D1].contiguous()).view(MA, D1)
+        dPT = ops.transpose2d(dP1_all, MA, D1)            # [D1, kpad(N*M)]: the K-major operand of the dW GEMM
+        Kp = dPT.shape[1]
+        out = gw[:, k0:k1].unsqueeze(0)
+        if dtype == torch.bfloat16:
+            ops.gemm_tn(dPT, ks["A"], D1, k1 - k0, Kp, MA, out=out)
+        else:
+            AT = ops.transpose2d(ks["A"], MA, k1 - k0)    # fp32 parity mode: the NT form on a transposed copy
+            ops.gemm_nt(dPT, AT, D1, k1 - k0, Kp, out=out)
+        if hook is not None:
+            hook(("fc1b", 0, D1, k0, k1))
+
     # ---- forward -------------------------------------------------------------------------------------
     def forward(self, feat_nhwc, rois, objectness, training, img_off=None, n_img=1, gt=None, pooled=None,
                 fc6_part=None):
         h = self.h
         fg_hook = getattr(self, "feature_grad_hook", None) if training else None
         csc = training and getattr(h, "csc_head", False)
-        if pooled is None:
+        kshard = training and self.kshard is not None
+        if kshard:
+            if fg_hook is not None or csc:
+                raise DrnError("fc6 K-sharding needs a frozen trunk (FREEZE_AT = 5) and the OICR / WSDDN / PCL heads")
+            if pooled is None:
+                pooled = self.pool_kshard(feat_nhwc, rois, objectness)
+            elif not pooled.get("kshard"):
+                raise DrnError("fc6 K-sharding: the prefetched operand was pooled for the replicated fc6")
+        elif pooled is None:
             pooled = self.pool(feat_nhwc, rois, objectness, training, want_argmax=fg_hook is not None or csc)
         elif fg_hook is not None or csc:
             raise DrnError("a trainable backbone / the CSC head cannot use a prefetched pooled operand")
@@ -671,6 +780,8 @@ class _HeadEngine:
             if getattr(self, "seed_dev", None) is None or self.seed_dev.device != dev:
                 self.seed_dev = torch.zeros((1,), dtype=torch.int64, device=dev)
             seed, seed_dev = torch.initial_seed() & 0xFFFFFFFFFFFF, self.seed_dev
+        if kshard and fc6_part is None:
+            fc6_part = self._fc6_partials_kshard(pooled, M)
         if fc6_part is not None:  # the GEMM was issued by fc6_partials() (eagerly, in front of a captured graph)
             ops.bias_act_fwd(fc6_part, M, D1, fc1.bias.data, True, masks[0] if masks else None, seed, drop_p,
                              out=w["H1"], outT=w["H1T"] if training else None, seed_dev=seed_dev)
@@ -895,12 +1006,14 @@ class _HeadEngine:
             ops.gemm_nt(g_x["A"], g_x["B"], M, D1, kp(D2), out=w["dH1"], splits=s1)
         # fc6 (the backbone is frozen: no dX)
         fg = st.get("fg")
-        if fg is not None and ("dP1" not in w or w["dP1"].shape != w["H1"].shape):
+        need_dp1 = fg is not None or self.kshard is not None  # (K-sharded fc6: the ranks all-gather dP1 row-major)
+        if need_dp1 and ("dP1" not in w or w["dP1"].shape != w["H1"].shape):
             w["dP1"] = torch.zeros_like(w["H1"])
         ops.bias_act_bwd(w["dH1"], M, D1, saved=w["H1"], mask=st["masks"][0] if st["masks"] else None,
-                         drop_p=st["drop_p"], dpre=w["dP1"] if fg is not None else None, dpreT=w["dP1T"],
+                         drop_p=st["drop_p"], dpre=w["dP1"] if need_dp1 else None, dpreT=w["dP1T"],
                          **colsum_args(2, D1, self._gview("fc1.bias")))
         self._tail = (w["dP1T"], w["AT"], D1, K1, Mp, acc, w["A"], M, w.get("AT_row0", 0))
+        self._tail_w = w
         if not getattr(self, "defer_fc1_tail", False):
             self.run_fc1_tail()
         if fg is not None:
@@ -958,6 +1071,16 @@ class _HeadEngine:
             if fused is not None or (bucket is not None and acc):
                 raise DrnError("fused / bucketed fc6 gradient cannot be combined with gradient accumulation")
             gw = bucket if bucket is not None else self._gview("fc1.weight", (D1, K1))
+            if self.kshard is not None:
+                if acc:
+                    raise DrnError("fc6 K-sharding cannot be combined with gradient accumulation")
+                self._fc6_tail_kshard(self._tail_w, M, D1, K1, dP1T.dtype, gw, hook)
+                self._grads_valid = True
+                self._pool_current_done = True
+                for name, p, o, n, used in self.segments:
+                    if used and p.grad is None and name != "fc1.weight":
+                        p.grad = self.arena_g[o: o + n].view(p.shape)
+                return
             # Tail balancing peels the same trailing columns off every equal-height slab (drn_gemm_nt: a small-tile launch
             # in front of each persistent one - 14 + 22 us and two launch gaps per step for two slabs).  When all slabs
             # agree on the split, ONE launch computes the peeled columns of all rows first and the slabs' main columns -
@@ -1146,6 +1269,8 @@ class OICRROIHeads(ROIHeads):
 
     def prefetch_pooled(self, features, proposals):
         """pool a FUTURE batch's proposals (on whatever stream is current) into the engine's spare buffer set"""
+        if getattr(self._engine, "kshard", None) is not None:
+            return None  # K-sharded fc6: the operand is built from every rank's features inside the forward
         nhwc, rois, obj = self._gather_inputs(features, proposals)
         return dict(rois=rois, obj=obj, pooled=self._engine.pool(nhwc, rois, obj, self.training, prefetch=True))
 

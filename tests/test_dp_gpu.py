@@ -44,15 +44,38 @@ def _worker(rank, world, port, comm, exchange, q, precision="fp32"):
         dp = DataParallel(model)
         assert dp.world == 2 and dp.exchange
         dp.broadcast_parameters(0)
+        graphed_ks = exchange == "fc6_kshard+graph"
+        exchange = exchange.split("+")[0]
         opt.enable_pipelined(dp, slab_rows=[16, 48], comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32,
                              exchange=exchange)
         assert opt._sharded == (exchange == "sharded")
+        if exchange == "fc6_kshard":
+            assert model.roi_heads._engine.kshard is not None
         mine = batches[rank]
-        stepper = GraphedTrainStep(model, opt, mine, split_tail=True, trunk_pairs=True)  # bench.py's default schedule
         losses = []
-        for _ in range(3):
-            out = stepper.step(mine, mine, mine, mine)
-            losses.append({k: float(v.detach()) for k, v in out.items()})
+        if graphed_ks:
+            # the same inside bench.py's schedule: pooling piece, fc6 GEMM + reduce-scatter and the dW tail eager around the
+            # captured heads graph
+            stepper = GraphedTrainStep(model, opt, mine, split_tail=True, trunk_pairs=True, eager_fc6=True)
+            for _ in range(3):
+                out = stepper.step(mine, mine, mine, mine)
+                losses.append({k: float(v.detach()) for k, v in out.items()})
+        elif exchange == "fc6_kshard":
+            # K-sharded fc6 (round 4): eager steps - the forward holds collectives (all-gather of the ranks' feature maps,
+            # reduce-scatter of the partial H1), the backward an all-gather of dP1; no fc6 gradient exchange at all
+            assert opt._kshard and model.roi_heads._engine.kshard["world"] == 2
+            for _ in range(3):
+                opt.zero_grad()
+                out = model(mine)
+                sum(out.values()).backward()
+                dp.finish()
+                opt.step(dp.grad_scale)
+                losses.append({k: float(v.detach()) for k, v in out.items()})
+        else:
+            stepper = GraphedTrainStep(model, opt, mine, split_tail=True, trunk_pairs=True)  # bench.py's default schedule
+            for _ in range(3):
+                out = stepper.step(mine, mine, mine, mine)
+                losses.append({k: float(v.detach()) for k, v in out.items()})
         opt.sync_master()  # sharded exchange: the fp32 master rows the other rank owns (a collective; no-op otherwise)
         torch.cuda.synchronize()
         sd = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.requires_grad}  # by value
@@ -72,7 +95,8 @@ def _worker(rank, world, port, comm, exchange, q, precision="fp32"):
 
 
 @pytest.mark.parametrize("comm,exchange", [("fp32", "allreduce"), ("bf16", "allreduce"), ("fp32", "sharded"),
-                                           ("bf16", "sharded")])
+                                           ("bf16", "sharded"), ("fp32", "fc6_kshard"), ("bf16", "fc6_kshard"),
+                                           ("bf16", "fc6_kshard+graph")])
 def test_two_rank_step_equals_mean_gradient_training(comm, exchange):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -162,12 +186,13 @@ def _worker_full(rank, world, port, q):
         dp = DataParallel(model)
         dp.broadcast_parameters(0)
         stepper = GraphedFullStep(model, opt, batches[rank], parallel=dp)
-        assert stepper.dp is dp and not dp.sync_gradients
+        assert stepper.dp is dp and dp.sync_gradients  #  the shared flag is only off WHILE the step's backward runs
         losses = []
         for _ in range(4):
             out = stepper.step(batches[rank])
             losses.append({k: float(v.detach()) for k, v in out.items()})
-        assert stepper.g_opt is not None
+            assert dp.sync_gradients
+        assert stepper.g_opt is not None and stepper.g_trunk is not None  # heads all-reduce runs under the trunk-backward graph
         torch.cuda.synchronize()
         sd = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.requires_grad}
         q.put((rank, "ok", sd, losses))

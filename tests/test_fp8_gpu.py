@@ -169,7 +169,7 @@ def test_fp8_trunk_and_train_step_full_size():
         c2 = model.backbone.res2[0].conv2
         old_q = dict(c2._fp8)
         c2.disable_fp8()
-        c2.enable_fp8(old_q["out_scale"] * 0.5, old_q["out_dtype"])
+        c2.enable_fp8(old_q["out_scale"] * 0.75, old_q["out_dtype"])  # (not a power of two: other fp8 codes, another res4 map)
         moved = model.backbone(model.preprocess_image(ins(batch)).tensor)["res4"].float().cpu()
         model.backbone.use_plan = False
         moved_walk = model.backbone(model.preprocess_image(ins(batch)).tensor)["res4"].float().cpu()
