@@ -304,6 +304,8 @@ def main():
                     help="N > 1: sharded (default) = reduce-scatter of each fc6 gradient slab, SGD on the owned rows (1/N of "
                          "the optimizer traffic), all-gather of the updated bf16 rows; allreduce = DDP's all-reduce + "
                          "replicated update")
+    ap.add_argument("--kshard-wire", choices=["fp32", "bf16"], default="fp32",
+                    help="--exchange fc6_kshard: dtype of the partial fc6 pre-activations on the wire (reduce-scatter)")
     ap.add_argument("--comm-dtype", choices=["bf16", "fp32"], default=None,
                     help="dtype of the fc6 weight-gradient buckets (HBM and xGMI); default bf16 = the compute dtype, the "
                          "rounding torch.autocast(bf16) applies to a Linear's weight gradient")
@@ -395,7 +397,8 @@ def main():
         # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
                              comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype],
-                             exchange=args.exchange, col_rounds=args.col_rounds)
+                             exchange=args.exchange, col_rounds=args.col_rounds,
+                             kshard_wire=torch.bfloat16 if args.kshard_wire == "bf16" else None)
         if world == 1 and args.fused_sgd:
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES

@@ -115,7 +115,7 @@ class FusedSGD:
         return self._segs_dev, self._nseg
 
     # ---- pipelined mode: the update of a gradient bucket starts as soon as the bucket is final ----------------
-    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None, exchange=None, col_rounds=None):
+    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None, exchange=None, col_rounds=None, kshard_wire=None):
         """ITER_SIZE == 1 only.  The explicit backward finishes gradients in a known order: first every small tensor
         (predictors, fc7, fc6 bias), then fc6.weight in row slabs.  In pipelined mode each bucket is (all-reduced when
         N > 1 and then) updated by the SGD kernel on a second stream the moment its dW GEMM is queued, so the HBM-bound
@@ -159,7 +159,7 @@ class FusedSGD:
         # eager steps.
         self._kshard = exchange == "fc6_kshard" and dp is not None and dp.exchange
         if self._kshard:
-            e.kshard = dict(group=dp.group, world=world, rank=dist.get_rank(dp.group))
+            e.kshard = dict(group=dp.group, world=world, rank=dist.get_rank(dp.group), wire=kshard_wire)
             slab_rows = [d1]
         self._sharded = world > 1 and exchange not in ("allreduce", "fc6_kshard")
         if self._sharded:

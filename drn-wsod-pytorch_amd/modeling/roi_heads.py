@@ -720,7 +720,17 @@ class _HeadEngine:
             torch.sum(ks["parts"], dim=0, keepdim=True, out=ks["part"])
         else:
             ops.gemm_nt(pooled["A"], W1k, MA, D1, k1 - k0, out=ks["part"])
-        dist.reduce_scatter_tensor(ks["h1"].view(-1), ks["part"].view(-1), group=ks["group"])
+        if ks.get("wire") == torch.bfloat16:
+            # optional: the partial sums cross the wire in bf16 (half the bytes of the step's largest collective; RCCL adds
+            # them in bf16 - N roundings of 2^-9 in front of an activation that is stored in bf16 anyway)
+            if ks.get("part16") is None or ks["part16"].shape != ks["part"].shape:
+                ks["part16"] = torch.empty_like(ks["part"], dtype=torch.bfloat16)
+                ks["h16"] = torch.empty_like(ks["h1"], dtype=torch.bfloat16)
+            ks["part16"].copy_(ks["part"])
+            dist.reduce_scatter_tensor(ks["h16"].view(-1), ks["part16"].view(-1), group=ks["group"])
+            ks["h1"].copy_(ks["h16"])
+        else:
+            dist.reduce_scatter_tensor(ks["h1"].view(-1), ks["part"].view(-1), group=ks["group"])
         return ks["h1"]
 
     def _fc6_tail_kshard(self, w, M, D1, K1, dtype, gw, hook):

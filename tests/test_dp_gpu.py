@@ -44,10 +44,11 @@ def _worker(rank, world, port, comm, exchange, q, precision="fp32"):
         dp = DataParallel(model)
         assert dp.world == 2 and dp.exchange
         dp.broadcast_parameters(0)
-        graphed_ks = exchange == "fc6_kshard+graph"
+        graphed_ks = exchange.startswith("fc6_kshard+graph")
+        wire16 = exchange.endswith("+wire16")
         exchange = exchange.split("+")[0]
         opt.enable_pipelined(dp, slab_rows=[16, 48], comm_dtype=torch.bfloat16 if comm == "bf16" else torch.float32,
-                             exchange=exchange)
+                             exchange=exchange, kshard_wire=torch.bfloat16 if wire16 else None)
         assert opt._sharded == (exchange == "sharded")
         if exchange == "fc6_kshard":
             assert model.roi_heads._engine.kshard is not None
@@ -96,7 +97,7 @@ def _worker(rank, world, port, comm, exchange, q, precision="fp32"):
 
 @pytest.mark.parametrize("comm,exchange", [("fp32", "allreduce"), ("bf16", "allreduce"), ("fp32", "sharded"),
                                            ("bf16", "sharded"), ("fp32", "fc6_kshard"), ("bf16", "fc6_kshard"),
-                                           ("bf16", "fc6_kshard+graph")])
+                                           ("bf16", "fc6_kshard+graph"), ("bf16", "fc6_kshard+graph+wire16")])
 def test_two_rank_step_equals_mean_gradient_training(comm, exchange):
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -136,6 +137,8 @@ def test_two_rank_step_equals_mean_gradient_training(comm, exchange):
     # the GEMMs - the same numbers up to fp32 rounding of the scaling; bf16 buckets round every gradient once per rank
     # and once in the sum (measured: 1.1e-3 on fc7's weight after 3 steps)
     tol = 2e-6 if comm == "fp32" else 2e-3  # bf16: 3 steps x lr x 2^-8 relative rounding of a gradient of O(10)
+    if exchange.endswith("+wire16"):
+        tol = 4e-3  # the partial fc6 pre-activations also cross the wire in bf16 (measured 2.0e-3 on fc1.weight)
     for n, p in model.named_parameters():
         if not p.requires_grad or n not in res[0][2]:
             continue
