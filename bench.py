@@ -281,6 +281,9 @@ def main():
     ap.add_argument("--fused-sgd", action="store_true",
                     help="N=1 only: fc6 dW GEMM with the SGD update as its epilogue (drn_gemm_nt_sgd; measured "
                          "neutral: its HBM-heavy epilogues run in lock-step across CUs, see DESIGN.md)")
+    ap.add_argument("--fused-tn", type=int, default=1,
+                    help="N=1 (default 1): fc6 dW + SGD in ONE launch with the update of each tile pipelined into the next tile's "
+                         "mainloop (drn_gemm_tn_sgd); 0 = two row slabs + sgd_kernel on the optimizer stream (round 3)")
     ap.add_argument("--fc7-dx-splits", type=int, default=0, help="A/B: K-splits of the fc7 dX inside the paired launch (0 = heuristic)")
     ap.add_argument("--no-fc7-pair", action="store_true",
                     help="A/B: fc7 weight gradient and fc7 dX as two launches instead of one paired persistent launch")
@@ -398,7 +401,7 @@ def main():
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
                              comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype],
                              exchange=args.exchange, col_rounds=args.col_rounds,
-                             kshard_wire=torch.bfloat16 if args.kshard_wire == "bf16" else None)
+                             kshard_wire=torch.bfloat16 if args.kshard_wire == "bf16" else None, fused_tn=bool(args.fused_tn))
         if world == 1 and args.fused_sgd:
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
@@ -608,6 +611,11 @@ def main():
             if e_:
                 launches.append(e_)
             r0 = r1
+        if col_plan is not None:
+            e_ = entry("gemm_nt256p_kernel<bf16, TN, SGDP> fc6 dW columns 0:%d + the optimizer step of every tile in the next tile's mainloop"
+                       % col_plan[0], {("tn_sgd", D1, col_plan[0], Mp)}, 2.0 * D1 * col_plan[0] * Rtot)
+            if e_:
+                launches.append(e_)
         fused = entry("gemm_nt256_kernel<bf16, SGD> fc6 dW + optimizer epilogue", {("sgd", D1, K1, Mp)}, 2.0 * D1 * K1 * Rtot)
         if fused:
             launches.append(fused)

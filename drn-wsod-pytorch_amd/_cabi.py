@@ -33,6 +33,7 @@ _SIGS = {
     "drn_gemm_nt": "pppiiillliiilip",
     "drn_gemm_nt_sgd": "ppiiilli" + "ppplp" + "fifp",
     "drn_gemm_tn": "ppp" + "iiii" + "lll" + "iilip",
+    "drn_gemm_tn_sgd": "ppp" + "iiii" + "lll" + "ppplp" + "fifp",
     "drn_gemm_nt_pair": ("ppp" + "iii" + "lll" + "ili") * 2 + "p",
     "drn_gemm_set_tile": "i",
     "drn_tune": "ii",

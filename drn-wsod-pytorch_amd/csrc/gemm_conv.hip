@@ -38,6 +38,7 @@ struct GemmParams {
   const SgdSeg* sgd_seg;  // lr / wd of this tensor, read on the device (a replayed hipGraph follows the schedule)
   float sgd_momentum, sgd_grad_scale;
   int sgd_first_step;
+  long sgd_ld;  // SGDP (drn_gemm_tn_sgd): row pitch of sgd_w / sgd_mom / sgd_shadow in elements (C = the bf16 gradient bucket, ldc)
   int c_bf16;  // C holds bf16 (gradient buckets that cross xGMI in bf16); splits == 1, no accumulate
   int nsplit;  // number of K-splits (the persistent kernel's grid is 1-D: it cannot read it from gridDim.y)
   int gm;      // tile rows per group of the XCD patch mapping (tile_coords)
@@ -454,12 +455,70 @@ __device__ __forceinline__ void pp_issue_first(char* smem, __amdgpu_buffer_rsrc_
   pp_issue<3>(smem, ra, rb, voa, vob, wave, slab, bstep);
 }
 
+// ---- optimizer step of the PREVIOUS tile inside this tile's mainloop (round 4: drn_gemm_tn_sgd) ------------------------------
+// The fc6 weight gradient leaves its GEMM as a bf16 tile of the gradient bucket (the persistent kernel's LDS-staged
+// epilogue).  Instead of a second kernel that streams w / momentum / gradient / shadow behind it - HBM-bound phases with the
+// matrix pipes idle, or a co-resident kernel competing for the same power budget in bursts - every workgroup applies the
+// update of the tile it finished LAST while it multiplies the next one: a tile is 256 rows x 1 KB of fp32 weights, a K slab
+// is 1/32 of the mainloop, so slab i carries chunk i = 8 rows (one per wave; a lane owns 4 consecutive parameters): three
+// 16/16/8-byte loads (w, momentum, the bf16 gradient the workgroup itself wrote - visible after the vmcnt(0) + barrier at
+// the head of the mainloop) issued in phase 1 of slab i, ~30 VALU instructions and three stores in phase 3 of slab i + 1,
+// i.e. in the fragment-read phases, while the SIMD's other wave is in its MFMA phase.  HBM traffic becomes a steady
+// stream under the MFMA work instead of a burst between launches, and the gradient is read back from L2, not from HBM.
+// All of it is inline asm: the mainloop's LDS-DMA pipeline lives on hand-counted vmcnt waits, vector memory operations
+// retire in order, and every wait below is the old count plus the optimizer operations issued behind the piece it guards:
+//   phase 1 / 2: vmcnt(4) -> vmcnt(7)   (3 loads of this slab's phase 1)      phase 4: vmcnt(4) -> vmcnt(7) from slab 1 on
+//   (3 stores of phase 3);  chunk i - 1's loads have 18 (slab 1: 15) younger operations when phase 3 of slab i needs them.
+// Same arithmetic, element for element, as sgd_kernel on the bf16 bucket (bit-identical: tests).
+struct SgdPipe {
+  float* w; float* m; const bf16_t* g; bf16_t* s;  // bases (wave-uniform); in-place update
+  unsigned off, step;    // byte offset of this lane's 16 B in chunk 0 of the tile (fp32 arrays), bytes per chunk (8 rows)
+  unsigned goff, gstep;  // the same in the bf16 gradient bucket (8 B per lane); the shadow uses off / 2, step / 2
+  float lr, wd, mom, gs;
+  int first;
+};
+typedef float f32x2_t_ __attribute__((ext_vector_type(2)));
+struct SgdRegs { f32x4_t w, m; f32x2_t_ g; };
+
+// (plain, compiler-visible accesses: the compiler's own counted vmcnt wait in front of the first use is exact - it counts
+// the LDS-DMA pieces as the vector memory operations they are.  A first version issued them as inline asm with hand-placed
+// waits: the compiler, taking an asm output for valid at once, spilled the registers to scratch right behind the loads.)
+__device__ __forceinline__ void sgdp_load(const SgdPipe& sp, SgdRegs& r, unsigned off, unsigned goff) {
+  r.w = __builtin_nontemporal_load((const f32x4_t*)((const char*)sp.w + off));
+  r.m = __builtin_nontemporal_load((const f32x4_t*)((const char*)sp.m + off));
+  r.g = __builtin_nontemporal_load((const f32x2_t_*)((const char*)sp.g + goff));
+}
+__device__ __forceinline__ void sgdp_apply_store(const SgdPipe& sp, const SgdRegs& r, unsigned off) {
+#pragma clang fp contract(off)
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const u32x2_t x = __builtin_bit_cast(u32x2_t, r.g);
+  const f32x4_t gg = {__builtin_bit_cast(float, x.x << 16), __builtin_bit_cast(float, x.x & 0xffff0000u),
+                      __builtin_bit_cast(float, x.y << 16), __builtin_bit_cast(float, x.y & 0xffff0000u)};
+  f32x4_t nb, nw;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float d = gg[e] * sp.gs;
+    if (sp.wd != 0.f) d = d + sp.wd * r.w[e];
+    nb[e] = sp.first ? d : sp.mom * r.m[e] + d;
+    nw[e] = r.w[e] - sp.lr * nb[e];
+  }
+  u32x2_t o;
+  o.x = (uint32_t)f32_to_bf16(nw[0]) | ((uint32_t)f32_to_bf16(nw[1]) << 16);
+  o.y = (uint32_t)f32_to_bf16(nw[2]) | ((uint32_t)f32_to_bf16(nw[3]) << 16);
+  __builtin_nontemporal_store(nb, (f32x4_t*)((char*)sp.m + off));
+  __builtin_nontemporal_store(nw, (f32x4_t*)((char*)sp.w + off));
+  *(u32x2_t*)((char*)sp.s + (off >> 1)) = o;
+}
+
 // slabs [s0, s1), s0 < s1; slab s0 has been issued into stage 0 by pp_issue_first.  Every wave passes the same number of
 // barriers (wave row 1 one extra in front, wave row 0 one extra behind).
-template <int DT, int VAR, bool TN = false>
+// SGDP: the optimizer step of the previous tile rides along (above); needs s1 - s0 == 32 and VAR == 1.
+template <int DT, int VAR, bool TN = false, bool SGDP = false>
 __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, __amdgpu_buffer_rsrc_t ra,
                                             __amdgpu_buffer_rsrc_t rb, const unsigned (&voa)[4], const unsigned (&vob)[4],
-                                            int s0, int s1, int lane, int wave, unsigned bstep = 128) {
+                                            int s0, int s1, int lane, int wave, unsigned bstep = 128,
+                                            const SgdPipe* spp = nullptr) {
+  SgdRegs srA, srB;  // chunk i is loaded into A (even slabs) / B (odd slabs) and applied one slab later
   const int wm = wave >> 2, wn = wave & 3;
   const int l31 = lane & 31, hi = lane >> 5, sw = (l31 >> 1) & 7;
   // LDS byte addresses of this lane's fragment of k-step ks inside the A0 / B0 half tile of the CURRENT stage; the other
@@ -533,7 +592,7 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   PP_BARRIER();
   if (wm == 1) PP_BARRIER();  // the lower wave row runs one barrier interval behind the upper one
-  for (int s = s0; s < s1; ++s) {
+  auto slab = [&](int s, SgdRegs& sr_ld, const SgdRegs& sr_use) __attribute__((always_inline)) {
     char* nxt = smem + (((s - s0) & 1) ^ 1) * PP_STAGE;
     const int sn = s + 1 < s1 ? s + 1 : s1 - 1;  // past the end: the last slab again, into a stage nobody reads
     // ---- phase 1: quadrant (a0, b0); reads in the order the MFMAs consume them (counted lgkmcnt waits)
@@ -550,7 +609,13 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
       asm volatile("s_waitcnt vmcnt(2)" ::: "memory");  // B1 of this slab: A1's two pieces may stay in flight
     } else {
       PP_PIECE(0); PP_PIECE(1);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // B1 of this slab has landed (read in phase 2)
+      if constexpr (SGDP) {
+        const unsigned i_ = (unsigned)(s - s0);
+        sgdp_load(*spp, sr_ld, spp->off + i_ * spp->step, spp->goff + i_ * spp->gstep);
+        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // B1 of this slab (3 optimizer loads younger than the pieces)
+      } else {
+        asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // B1 of this slab has landed (read in phase 2)
+      }
     }
     PP_BARRIER();
     mm(acc[0][0], acc[1][0], NOWAIT);
@@ -563,7 +628,8 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
       asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // A1 of this slab (phase 3)
     } else {
       PP_PIECE(2); PP_PIECE(3);
-      asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A1 of this slab (phase 3)
+      if constexpr (SGDP) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // A1 of this slab; P0 P1 L L L P2 P3 may be in flight
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A1 of this slab (phase 3)
     }
     PP_BARRIER();
     mm(acc[0][1], acc[1][1], WAITB);
@@ -572,6 +638,11 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rdA(ks, PP_A1 - PP_A0);
     if (VAR == 2) { PP_PIECE(3); PP_PIECE(4); } else { PP_PIECE(4); PP_PIECE(5); }
+    if constexpr (SGDP) {
+      const unsigned i_ = (unsigned)(s - s0);
+      // chunk i - 1: its loads went out in phase 1 of the previous slab (18 vector memory operations ago; 15 in slab 1)
+      if (i_ >= 1) sgdp_apply_store(*spp, sr_use, spp->off + (i_ - 1) * spp->step);
+    }
     PP_BARRIER();
     mm(acc[2][1], acc[3][1], NOWAIT);
     PP_BARRIER();
@@ -580,14 +651,29 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) rdB(ks, 0);
     if (VAR == 2) { PP_PIECE(5); PP_PIECE(6); PP_PIECE(7); } else { PP_PIECE(6); PP_PIECE(7); }
+    if constexpr (SGDP) {
+      // A0 and B0 of the next slab; behind them P4 P5 [S S S] P6 P7 may be in flight (no stores yet in slab 0)
+      if (s > s0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A0 and B0 of the next slab (its phase 1)
     PP_BARRIER();
     mm(acc[2][0], acc[3][0], WAITB);
     PP_BARRIER();
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) { oa[ks] ^= PP_STAGE; ob[ks] ^= PP_STAGE; }
+  };
+  if constexpr (SGDP) {
+    for (int s = s0; s < s1; s += 2) {  // (an even number of slabs: 32)
+      slab(s, srA, srB);
+      slab(s + 1, srB, srA);
+    }
+  } else {
+    for (int s = s0; s < s1; ++s) slab(s, srA, srA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before LDS is reused
+  if constexpr (SGDP)  // the last chunk (loaded in phase 1 of the last, odd slab)
+    sgdp_apply_store(*spp, srB, spp->off + (unsigned)(s1 - 1 - s0) * spp->step);
   if (wm == 0) PP_BARRIER();
 #undef PP_PIECE
 }
@@ -880,7 +966,7 @@ struct GemmWork { int bm, bn, s0, s1, split; __amdgpu_buffer_rsrc_t ra, rb; };  
 // the fc7 weight gradient (128 tiles: half the CUs in one round) and the fc7 dX (64 tiles x 4 K-splits of half the
 // length), 46 + 41 us one after the other.  (Two concurrent launches on a forked stream do the same on paper and cost
 // 250 us in the captured step: the graph executor starts the branch late.)
-template <int DT, bool SGD, int PP = 0, bool TN = false, bool PAIR = false>
+template <int DT, bool SGD, int PP = 0, bool TN = false, bool PAIR = false, bool SGDP = false>
 __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p_in, GemmParams p2_in, int pair_wg0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bool second = PAIR && (int)(blockIdx.x >> 3) >= pair_wg0;
@@ -953,6 +1039,16 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p_in, GemmP
     if constexpr (PP) pp_issue_first(smem, cur.ra, cur.rb, pva, pvb, wave, cur.s0, bstep);
     else issue(cur, smem, cur.s0);
   }
+  // SGDP: the optimizer step of the tile finished last rides in the next tile's mainloop (SgdPipe above)
+  [[maybe_unused]] SgdPipe sp;
+  [[maybe_unused]] bool have_prev = false;
+  if constexpr (SGDP) {
+    sp.w = p.sgd_w; sp.m = p.sgd_mom; sp.g = (const bf16_t*)p.C; sp.s = p.sgd_shadow;
+    sp.step = (unsigned)(8 * p.sgd_ld * 4); sp.gstep = (unsigned)(8 * p.ldc * 2);
+    sp.lr = p.sgd_seg->lr; sp.wd = p.sgd_seg->wd; sp.mom = p.sgd_momentum; sp.gs = p.sgd_grad_scale;
+    sp.first = p.sgd_first_step;
+    sp.off = sp.goff = 0;
+  }
   for (;;) {
 #pragma unroll
     for (int i = 0; i < MI; ++i)
@@ -962,7 +1058,10 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p_in, GemmP
         for (int rr = 0; rr < 16; ++rr) acc[i][jj][rr] = 0.f;
     const int s0 = cur.s0, s1 = cur.s1;
     if constexpr (PP) {
-      if (s0 < s1) pp_mainloop<DT, PP, TN>(acc, smem, cur.ra, cur.rb, pva, pvb, s0, s1, lane, wave, bstep);
+      if constexpr (SGDP) {
+        if (have_prev) pp_mainloop<DT, PP, TN, true>(acc, smem, cur.ra, cur.rb, pva, pvb, s0, s1, lane, wave, bstep, &sp);
+        else pp_mainloop<DT, PP, TN>(acc, smem, cur.ra, cur.rb, pva, pvb, s0, s1, lane, wave, bstep);
+      } else if (s0 < s1) pp_mainloop<DT, PP, TN>(acc, smem, cur.ra, cur.rb, pva, pvb, s0, s1, lane, wave, bstep);
     } else if (s0 < s1) {
       i32x4_t fa0[MI], fb0[NJ], fa1[MI], fb1[NJ];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // slab s0 (issued ahead of the previous tile's epilogue) has landed
@@ -1177,8 +1276,25 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p_in, GemmP
           }
       }
     }
+    if constexpr (SGDP) {  // this tile's update: in the next tile's mainloop, or in the drain below
+      sp.off = (unsigned)(((long)(bm + wave) * p.sgd_ld + bn + lane * 4) * 4);
+      sp.goff = (unsigned)(((long)(bm + wave) * p.ldc + bn + lane * 4) * 2);
+      have_prev = true;
+    }
     if (!more) break;
     cur = nxt;
+  }
+  if constexpr (SGDP) {
+    // drain: the update of the workgroup's LAST tile, two chunks (rows) in flight per trip
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // every wave's gradient stores of this tile have reached L2
+    for (unsigned c = 0; c < 32; c += 2) {
+      SgdRegs q0, q1;
+      sgdp_load(sp, q0, sp.off + c * sp.step, sp.goff + c * sp.gstep);
+      sgdp_load(sp, q1, sp.off + (c + 1) * sp.step, sp.goff + (c + 1) * sp.gstep);
+      sgdp_apply_store(sp, q0, sp.off + c * sp.step);
+      sgdp_apply_store(sp, q1, sp.off + (c + 1) * sp.step);
+    }
   }
 }
 
@@ -1799,6 +1915,20 @@ int launch_gemm256p(const GemmParams& p, int nwg, hipStream_t st) {
   return DRN_OK;
 }
 
+static int launch_gemm256p_tn_sgdp(const GemmParams& p, int nwg, hipStream_t st) {
+  constexpr int smem = 2 * 512 * 128;
+  auto k = gemm_nt256p_kernel<DRN_BF16, false, 1, true, false, true>;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DRN_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(k, dim3(nwg), dim3(512), smem, st, p, p, 0);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
 static int launch_gemm256p_pair(const GemmParams& p0, const GemmParams& p1, int nwg, int wg0, hipStream_t st) {
   constexpr int smem = 2 * 512 * 128;
   auto k = gemm_nt256p_kernel<DRN_BF16, false, 1, false, true>;
@@ -2134,6 +2264,36 @@ int drn_gemm_nt_pair(const void* A0, const void* B0, void* C0, int M0, int N0, i
   int wg0 = (int)(per * w0 / (w0 + w1) + 0.5);
   wg0 = wg0 < 1 ? 1 : (wg0 > per - 1 ? per - 1 : wg0);
   return launch_gemm256p_pair(p0, p1, nwg, wg0, (hipStream_t)stream);
+}
+
+// G[M,N] = A[M,K] . Bt[K,N] (bf16, the TN form of drn_gemm_tn) into the bf16 gradient bucket AND W <- SGD(W, momentum_buf, G)
+// in the same launch: every workgroup applies the update of the tile it finished last inside the next tile's mainloop
+// (SgdPipe).  DRN_ERR_UNSUPPORTED outside its shape class (the caller then runs drn_gemm_tn + drn_sgd_step_block).
+int drn_gemm_tn_sgd(const void* A, const void* Bt, void* grad_bucket, int M, int N, int K, int kb_rows, long lda, long ldb,
+                    long ldc, float* weights, float* momentum_buf, void* shadow, long ld_w, const void* seg_dev,
+                    float momentum, int first_step, float grad_scale, void* stream) {
+  if (!A || !Bt || !grad_bucket || !weights || !momentum_buf || !seg_dev || M <= 0 || N <= 0 || K <= 0 || kb_rows < 0 ||
+      kb_rows > K)
+    return DRN_ERR_ARG;
+  if ((lda * 2) % 16 != 0 || (ldb * 2) % 16 != 0 || lda < K || ldb < N || ldc < N || ld_w < N) return DRN_ERR_ARG;
+  if ((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)grad_bucket | (uintptr_t)weights | (uintptr_t)momentum_buf | (uintptr_t)shadow) & 15))
+    return DRN_ERR_ARG;
+  // shape class of the pipelined update: 32 K slabs (one 8-row chunk of the previous tile per slab), whole tiles, a bf16
+  // shadow, 32-bit byte offsets, enough tiles for the persistent grid, the ping-pong mainloop
+  if (K != 2048 || (M & 255) || (N & 255) || !shadow || (ldc & 7) || (ld_w & 3) || g_pingpong != 1 ||
+      (long)M * ld_w * 4 >= 0xFFFFFFF0L || (long)K * ldb * 2 >= 0xFFFFFFF0L)
+    return DRN_ERR_UNSUPPORTED;
+  const long tiles = (long)(M / 256) * (N / 256);
+  const int nwg = persistent_grid(tiles);
+  if (!nwg) return DRN_ERR_UNSUPPORTED;
+  GemmParams p{(const char*)A, (const char*)Bt, (float*)grad_bucket, M, N, K, lda, ldb, ldc, K * 2 / 128, 0, 0,
+               weights, momentum_buf, (bf16_t*)shadow, (const SgdSeg*)seg_dev, momentum, grad_scale, first_step};
+  p.sgd_ld = ld_w;
+  p.c_bf16 = 1;
+  p.nsplit = 1;
+  p.gm = gemm256_group_rows(M, N, 1);
+  p.kb_rows = kb_rows;
+  return launch_gemm256p_tn_sgdp(p, nwg, (hipStream_t)stream);
 }
 
 // W[M,N] <- SGD(W, momentum_buf, G = A[M,K] * B[N,K]^T) with G kept in registers.  See include/drn_wsod.h.

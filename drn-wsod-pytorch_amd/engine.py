@@ -115,7 +115,8 @@ class FusedSGD:
         return self._segs_dev, self._nseg
 
     # ---- pipelined mode: the update of a gradient bucket starts as soon as the bucket is final ----------------
-    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None, exchange=None, col_rounds=None, kshard_wire=None):
+    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None, exchange=None, col_rounds=None, kshard_wire=None,
+                         fused_tn=None):
         """ITER_SIZE == 1 only.  The explicit backward finishes gradients in a known order: first every small tensor
         (predictors, fc7, fc6 bias), then fc6.weight in row slabs.  In pipelined mode each bucket is (all-reduced when
         N > 1 and then) updated by the SGD kernel on a second stream the moment its dW GEMM is queued, so the HBM-bound
@@ -222,6 +223,12 @@ class FusedSGD:
             k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
             e.ensure(next(self.model.roi_heads.parameters()).device)
             e.fc1_grad_bucket = torch.zeros((d1, k1), dtype=torch.bfloat16, device=e.arena_w.device)
+        # fused_tn (single process, bf16 bucket; default on): fc6 dW + its optimizer step as ONE launch, the update of every
+        # tile inside the next tile's mainloop (enable_fused_fc1_tn; +0.8 .. +2.4 % same-box, bit-identical).  Shapes outside
+        # the kernel's class fall back per call.
+        e.fc1_fused_tn = None
+        if (fused_tn is None or fused_tn) and not self._exchange_on and e.fc1_grad_bucket is not None and not col_rounds:
+            self.enable_fused_fc1_tn()
 
     def enable_fused_fc1(self):
         """Single process, ITER_SIZE == 1, on top of the pipelined mode: the fc6 weight gradient (the largest tensor by
@@ -233,6 +240,31 @@ class FusedSGD:
         if self._dp is not None and self._dp.world > 1:
             raise DrnError("fused fc6 dW+SGD is a single-process mode: with N > 1 the gradient must be all-reduced")
         self.engine.fc1_fused_update = self._fused_fc1
+
+    def enable_fused_fc1_tn(self):
+        """Single process, ITER_SIZE == 1, bf16 mode, on top of the pipelined mode (round 4): the fc6 weight gradient's main
+        columns - exact rounds of the persistent kernel - go through drn_gemm_tn_sgd, which applies the optimizer step of
+        every tile inside the NEXT tile's mainloop of the same launch (steady HBM traffic under the MFMA work, gradient read
+        back from L2, no optimizer launches for fc6 on the other stream).  The trailing columns keep the small-tile launch +
+        drn_sgd_step_block.  Bit-identical to the unfused step (same bf16 rounding of the gradient, same update)."""
+        if not getattr(self, "_pipelined", False):
+            raise DrnError("enable_pipelined() first")
+        if self._exchange_on:
+            raise DrnError("the fused fc6 dW + SGD launch is a single-process schedule")
+        self.engine.fc1_fused_tn = self._fused_fc1_tn
+
+    def _fused_fc1_tn(self, dPT, A, D1, n_main, Mp, M, gw):
+        e = self.engine
+        if e.arena_s is None or gw.dtype != torch.bfloat16:
+            return False
+        if self._mom is None:
+            self._mom = torch.zeros_like(e.arena_w)
+        segs, _ = self._bucket_table(("fc1", 0, D1))
+        o, n = e._seg["fc1.weight"]
+        k1 = n // D1
+        view = lambda t: t[o: o + n].view(D1, k1)[:, :n_main]
+        return ops.gemm_tn_sgd(dPT, A[:, :n_main], D1, n_main, Mp, M, gw[:, :n_main], view(e.arena_w), view(self._mom),
+                               view(e.arena_s), segs, self.momentum, self._steps == 0, 1.0)
 
     def _fused_fc1(self, dPT, AT, D1, K1, Mp):
         e = self.engine

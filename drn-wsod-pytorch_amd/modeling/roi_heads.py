@@ -581,6 +581,16 @@ class _HeadEngine:
         """(n_main, slab width in columns) of the column-slab form, or None when it does not apply: TN operand form, a
         gradient bucket or the arena as the destination, whole 256-column tiles"""
         r = int(getattr(self, "fc1_col_rounds", 0) or 0)
+        if getattr(self, "fc1_fused_tn", None) is not None and D1 % 256 == 0:
+            # fused dW + SGD launch (drn_gemm_tn_sgd): ONE slab of all exact rounds, the rest are the trailing columns
+            tiles_m = D1 // 256
+            ncu = getattr(self, "_ncu", None)
+            if ncu is None:
+                ncu = self._ncu = torch.cuda.get_device_properties(self.arena_w.device).multi_processor_count
+            step = ncu // math.gcd(ncu, tiles_m)
+            nt = (K1 // 256) // step * step
+            if nt > 0 and self._fc1_use_tn(dtype):
+                return nt * 256, nt * 256
         if r <= 0 or not self._fc1_use_tn(dtype) or getattr(self, "fc1_fused_update", None) is not None:
             return None
         tiles_m = (D1 + 255) // 256
@@ -1111,11 +1121,27 @@ class _HeadEngine:
                 if n_main < at_row0:
                     raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (n_main, at_row0))
                 if n_main < K1:
-                    ops.gemm_nt(dP1T, AT[n_main:], D1, K1 - n_main, Mp, out=gw[:, n_main:].unsqueeze(0))
-                    if hook is not None:
-                        hook(("fc1b", 0, D1, n_main, K1))
+                    side = getattr(self, "fc1_peel_stream", None)
+                    if side is not None and not torch.cuda.is_current_stream_capturing():
+                        # the trailing columns off the main stream's chain: small-tile GEMM + their block update on the
+                        # optimizer stream, beside the main launch (under its drain, where the matrix pipes idle)
+                        ev = torch.cuda.Event()
+                        ev.record(torch.cuda.current_stream())
+                        side.wait_event(ev)
+                        with torch.cuda.stream(side):
+                            ops.gemm_nt(dP1T, AT[n_main:], D1, K1 - n_main, Mp, out=gw[:, n_main:].unsqueeze(0))
+                            if hook is not None:
+                                hook(("fc1b", 0, D1, n_main, K1))
+                    else:
+                        ops.gemm_nt(dP1T, AT[n_main:], D1, K1 - n_main, Mp, out=gw[:, n_main:].unsqueeze(0))
+                        if hook is not None:
+                            hook(("fc1b", 0, D1, n_main, K1))
+                ftn = getattr(self, "fc1_fused_tn", None)
                 for c0 in range(0, n_main, wcols):
                     c1 = min(n_main, c0 + wcols)
+                    if ftn is not None and c0 == 0 and c1 == n_main and bucket is not None and \
+                            ftn(dP1T, A, D1, n_main, Mp, M, gw):
+                        continue  # gradient AND update done by the one launch (drn_gemm_tn_sgd)
                     ops.gemm_tn(dP1T, A[:, c0:c1], D1, c1 - c0, Mp, M, out=gw[:, c0:c1].unsqueeze(0))
                     if hook is not None:
                         hook(("fc1b", 0, D1, c0, c1))

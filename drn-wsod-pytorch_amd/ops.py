@@ -110,6 +110,29 @@ def gemm_tn(A, Bt, M, N, K, kb_rows, out=None, splits=1, accumulate=False):
     return out
 
 
+def gemm_tn_sgd(A, Bt, M, N, K, kb_rows, bucket, weights, mom, shadow, seg_dev, momentum, first_step, grad_scale=1.0):
+    """drn_gemm_tn_sgd: bucket[M, N] (bf16) = A[M,:K] @ Bt[:K,:N] and, in the same launch, the SGD step of weights[M, N] /
+    mom / shadow (2-D views with a common row pitch) with that gradient.  Returns False when the shape is outside the
+    kernel's class (nothing was launched: run gemm_tn + sgd_step_block instead)."""
+    assert A.dtype == torch.bfloat16 and Bt.dtype == torch.bfloat16 and bucket.dtype == torch.bfloat16
+    assert weights.dtype == torch.float32 and mom.dtype == torch.float32 and shadow.dtype == torch.bfloat16
+    assert _2d(weights) == _2d(mom) == _2d(shadow)
+    if GEMM_TIMING is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+    rc = C.lib().drn_gemm_tn_sgd(C.ptr(A), C.ptr(Bt), C.ptr(bucket), M, N, K, int(kb_rows), _2d(A), _2d(Bt), _2d(bucket),
+                                 C.ptr(weights), C.ptr(mom), C.ptr(shadow), _2d(weights), C.ptr(seg_dev), float(momentum),
+                                 int(bool(first_step)), float(grad_scale), C.stream())
+    if rc == -3:
+        return False
+    if rc != 0:
+        raise C.DrnError("drn_gemm_tn_sgd failed (%d)" % rc)
+    if GEMM_TIMING is not None:
+        e1.record()
+        GEMM_TIMING.append((e0, e1, 2.0 * M * N * K, ("tn_sgd", M, N, K)))
+    return True
+
+
 def stage_heads_inputs(rois, props, words_src=None, words_dst=None):
     """props[M,4] <- rois[M,1:5]; words_dst <- words_src (int32 blocks of equal length), one launch"""
     assert rois.dtype == torch.float32 and props.dtype == torch.float32 and rois.is_contiguous() and props.is_contiguous()

@@ -174,6 +174,20 @@ int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda,
                     float* momentum_buf, void* shadow, long ld_w, const void* seg_dev, float momentum, int first_step,
                     float grad_scale, void* stream);
 
+/* The same pair of reference operations (dW = dY^T X of box_head.py:82-91's fc1 through torch.autograd, then
+ * torch.optim.SGD.step on it: detectron2/solver/build.py:93-137, projects/WSL/tools/train_net.py:104-113) in the TN operand
+ * form of drn_gemm_tn and with the gradient rounded to bf16 exactly as the unfused pair does (drn_gemm_tn into a bf16 bucket,
+ * then drn_sgd_step / drn_sgd_step_block reading it): G = A[M][K] . Bt[K][N] is written to grad_bucket (bf16, [M][ldc]) and
+ *   d = G*grad_scale + wd*W;  buf = first_step ? d : momentum*buf + d;  W -= lr*buf;  shadow = bf16(W)
+ * is applied by the SAME launch: every workgroup of the persistent 256x256 kernel updates the tile it finished last while it
+ * multiplies the next one (one 8-row chunk per K slab, loads / stores interleaved with the LDS-DMA pipeline), so the
+ * optimizer's HBM traffic is a steady stream under the MFMA work and the gradient is read back from L2.  Bit-identical to
+ * the unfused pair.  Shape class: K == 2048 (R <= 2048 proposals), M, N multiples of 256, bf16 shadow given;
+ * DRN_ERR_UNSUPPORTED otherwise (callers then run the unfused pair). */
+int drn_gemm_tn_sgd(const void* A, const void* Bt, void* grad_bucket, int M, int N, int K, int kb_rows, long lda, long ldb,
+                    long ldc, float* weights, float* momentum_buf, void* shadow, long ld_w, const void* seg_dev,
+                    float momentum, int first_step, float grad_scale, void* stream);
+
 /* tuning / test hook: pin the GEMM tile to 64, 128 or 256 (0 = heuristic); returns the previous setting. */
 int drn_gemm_set_tile(int tile);
 

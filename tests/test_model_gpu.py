@@ -334,7 +334,7 @@ def test_fc6_column_slabs_equal_row_slabs(rounds):
         model.roi_heads.box_head.dropout_p = 0.0
         model.train()
         opt = build_optimizer(cfg, model)
-        opt.enable_pipelined(None, col_rounds=cr)
+        opt.enable_pipelined(None, col_rounds=cr, fused_tn=False)  # (baseline: the two row slabs + sgd_kernel of round 3)
         eng = model.roi_heads._engine
         for _ in range(3):
             opt.zero_grad()
@@ -346,6 +346,42 @@ def test_fc6_column_slabs_equal_row_slabs(rounds):
         assert (plan is None) == (cr == 0)
         if cr:
             assert plan == (49152, 8192 * rounds) and eng._last_state["w"]["AT_row0"] == 49152
+        res.append(dict(w=eng.arena_w.clone(), m=opt._mom.clone(), s=eng.arena_s.clone()))
+        del model, opt
+    for k in ("w", "m", "s"):
+        assert torch.equal(res[0][k], res[1][k]), k
+    load_package().set_precision("fp32")
+
+
+def test_fc6_fused_tn_step_equals_unfused():
+    """Round 4: `FusedSGD.enable_fused_fc1_tn()` - the fc6 weight gradient's main columns and their optimizer step in ONE launch
+    (drn_gemm_tn_sgd: every tile's update inside the next tile's mainloop) - against the default pipelined step (two row slabs +
+    sgd_kernel on the optimizer stream) at the bench shape: three SGD steps, weight / momentum / bf16-shadow arenas bit for bit."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    kw = dict(arch="wsr50", out_feature="res4", res5_dilation=1, num_classes=20)
+    ocfg = O.OracleCfg(dropout=0.0, base_lr=2e-4, **kw)
+    b = O.synthetic_batch(1, 2000, ocfg, seed=79)
+    batch = G.drn_inputs([dict(x, gt_boxes=torch.zeros(len(x["gt_classes"]), 4)) for x in b])
+    res = []
+    for fused in (False, True):
+        cfg, model = G.drn_model(ocfg, 3, "cuda", 5, "bf16")
+        model.roi_heads.box_head.dropout_p = 0.0
+        model.train()
+        opt = build_optimizer(cfg, model)
+        opt.enable_pipelined(None, fused_tn=fused)
+        eng = model.roi_heads._engine
+        from drn_wsod_pytorch_amd import ops
+
+        ops.GEMM_TIMING = []
+        for _ in range(3):
+            opt.zero_grad()
+            sum(model(batch).values()).backward()
+            opt.step()
+        torch.cuda.synchronize()
+        kinds = {t[3][0] for t in ops.GEMM_TIMING}
+        ops.GEMM_TIMING = None
+        assert ("tn_sgd" in kinds) == fused  # the fused launch really ran (and only then)
         res.append(dict(w=eng.arena_w.clone(), m=opt._mom.clone(), s=eng.arena_s.clone()))
         del model, opt
     for k in ("w", "m", "s"):

@@ -962,6 +962,38 @@ def test_gemm_nt_sgd_equals_gemm_then_sgd(drn, dtype, M, N, K, wd):
     assert not torch.equal(wa, w0)
 
 
+@pytest.mark.parametrize("M,N,wd", [(1024, 20480, 5e-4), (768, 24576 + 256, 0.0), (2048, 8192 + 512, 1e-4)])
+def test_gemm_tn_sgd_equals_unfused_pair(drn, M, N, wd):
+    """Round 4: drn_gemm_tn_sgd - the fc6 weight gradient (TN form, bf16 bucket) with the optimizer step of every tile applied
+    by the same launch, inside the NEXT tile's mainloop (loads / stores interleaved with the LDS-DMA pipeline on counted
+    waits) - against drn_gemm_tn into the bucket followed by drn_sgd_step: bucket, weights, momentum and bf16 shadow bit for
+    bit over a first step and two momentum steps.  320 / 291 / 272 tiles on 256 resident workgroups: workgroups with one
+    tile (first mainloop + drain only) and with two (pipelined update + drain)."""
+    rs = np.random.RandomState(23)
+    K, kb = 2048, 2000
+    w0 = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).to(DEV) * 0.02
+    seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+    seg[0] = (0, M * N, 0.01, wd)
+    seg_dev = torch.from_numpy(seg.view(np.uint8)).to(DEV)
+    wa, ma, sa = w0.clone(), torch.zeros_like(w0), torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    wb, mb, sb = w0.clone(), torch.zeros_like(w0), torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+    for step in range(3):
+        A = torch.zeros((M, K), dtype=torch.bfloat16, device=DEV)
+        A[:, :kb] = torch.from_numpy(rs.standard_normal((M, kb)).astype(np.float32)).to(DEV).to(torch.bfloat16) * 0.1
+        Bt = (torch.from_numpy(rs.standard_normal((kb, N)).astype(np.float32)).to(DEV) * 0.1).to(torch.bfloat16)
+        ga = torch.zeros((1, M, N), dtype=torch.bfloat16, device=DEV)
+        drn.gemm_tn(A, Bt, M, N, K, kb, out=ga)
+        drn.sgd_step(wa.view(-1), ma.view(-1), ga.view(-1), seg_dev, 1, 0.9, step == 0, 0.5, shadow=sa.view(-1))
+        gb = torch.full((M, N), 3.0, dtype=torch.bfloat16, device=DEV)
+        assert drn.gemm_tn_sgd(A, Bt, M, N, K, kb, gb, wb, mb, sb, seg_dev, 0.9, step == 0, 0.5)
+        torch.cuda.synchronize()
+        assert torch.equal(ga[0], gb), step
+        assert torch.equal(wa, wb) and torch.equal(ma, mb) and torch.equal(sa, sb), step
+    assert not torch.equal(wa, w0)
+    # outside the shape class nothing is launched
+    assert not drn.gemm_tn_sgd(A[:, :1024].contiguous(), Bt[:1024].contiguous(), M, N, 1024, 1024, gb, wb, mb, sb, seg_dev, 0.9, False)
+
+
 # ------------------------------------------------------------------------------------------- conv trunk backward
 def _relerr(a, b, floor=1e-6):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
