@@ -281,6 +281,8 @@ def main():
     ap.add_argument("--fused-sgd", action="store_true",
                     help="N=1 only: fc6 dW GEMM with the SGD update as its epilogue (drn_gemm_nt_sgd; measured "
                          "neutral: its HBM-heavy epilogues run in lock-step across CUs, see DESIGN.md)")
+    ap.add_argument("--pool-overlap", type=int, default=0,
+                    help="1 = the next batch's pooling piece on its own stream beside the fc6 dW tail (the two operand sets alternate)")
     ap.add_argument("--fused-tn", type=int, default=1,
                     help="N=1 (default 1): fc6 dW + SGD in ONE launch with the update of each tile pipelined into the next tile's "
                          "mainloop (drn_gemm_tn_sgd); 0 = two row slabs + sgd_kernel on the optimizer stream (round 3)")
@@ -446,7 +448,8 @@ def main():
         # behind it), so all three launches of the dominant kernel are bracketed by HIP events INSIDE the timed region
         stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead,
                                    trunk_pairs=args.trunk_pairs, eager_fc6=not args.no_eager_fc6,
-                                   stage_ahead=not args.no_stage_ahead, eager_pool=not args.graph_pool)
+                                   stage_ahead=not args.no_stage_ahead, eager_pool=not args.graph_pool,
+                                   pool_overlap=bool(args.pool_overlap))
         try:
             for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
                 last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])

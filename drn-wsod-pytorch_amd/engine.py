@@ -976,7 +976,7 @@ class GraphedTrainStep:
     _needs_frozen_trunk = True
 
     def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False,
-                 eager_fc6=False, stage_ahead=True, eager_pool=True):
+                 eager_fc6=False, stage_ahead=True, eager_pool=True, pool_overlap=False):
         if getattr(model, "cpg", False):
             raise DrnError("CSCROIHeads decides per step, on the host, which class maps to compute: eager steps only")
         if self._needs_frozen_trunk and any(p.requires_grad for p in model.backbone.parameters()):
@@ -1041,6 +1041,13 @@ class GraphedTrainStep:
         self.losses = None
         self._side = torch.cuda.Stream()
         self._primed = False
+        # pool_overlap: the next batch's pooling piece on its own stream beside the dW tail, the two fc6 operand sets
+        # alternating (_run_pairs_overlap); needs the eager pieces around the heads graph
+        self.pool_overlap = bool(pool_overlap) and bool(split_tail) and self.eager_fc6 and self.eager_pool and \
+            self.trunk_pairs and self.engine.kshard is None
+        self._pool_stream = torch.cuda.Stream() if self.pool_overlap else None
+        self._pool_done = None
+        self._pooled_slot = [None, None]
         self.split_tail = bool(split_tail)
         if self.engine.kshard is not None and not (self.split_tail and self.eager_fc6 and self.eager_pool and
                                                    (lookahead >= 2 or trunk_pairs)):
@@ -1153,6 +1160,13 @@ class GraphedTrainStep:
         the two must agree - a re-allocation in between (an inference pass used to replace the sets) would
         make the replayed graph read freed memory without any error."""
         ptrs = (self.pooled["A"].data_ptr(), self.pooled["AT"].data_ptr())
+        if self.pool_overlap:  # (no captured kernel reads the operand sets in this mode: fc6 forward and dW tail are eager)
+            if not getattr(self, "_primed", False):
+                self.engine.pool_sets_pinned = (self.pooled["A"].dtype, True)
+                import weakref
+
+                self.engine.pool_sets_pin_owner = weakref.ref(self)
+            return
         if not getattr(self, "_primed", False):
             self._pool_ptrs = ptrs
             self.engine.pool_sets_pinned = (self.pooled["A"].dtype, True)
@@ -1298,7 +1312,7 @@ class GraphedTrainStep:
         with torch.no_grad():
             self._pfeats[ps].copy_(self._pair_backbone(ps))
 
-    def _pair_pool_body(self, ps, half):
+    def _pair_pool_body(self, ps, half, slot=0):
         with torch.no_grad():
             n = self.n_img
             # in front of the pooling kernel (see _pool_next)
@@ -1308,13 +1322,73 @@ class GraphedTrainStep:
                 self.pooled = self.engine.pool_kshard(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next)
                 return
             self.pooled = self.engine.pool(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next, True,
-                                           slot=0)
+                                           slot=slot)
             self._check_pooled()
+
+    def _run_pairs_overlap(self, eager, next_batch, b2, b3):
+        """_run_pairs with the pooling piece of batch t+1 BESIDE the fc6 dW tail of step t (pool_overlap; round 4): the two
+        fc6 operand sets of the head engine alternate (batch t lives in set t & 1), so the pooling launch no longer has to
+        wait for the dW - the last reader of its own set was step t-1's.  It is issued on a stream of its own behind the
+        heads graph (the proposal / label blocks it overwrites are that graph's inputs) and runs under the power-capped
+        dW + optimizer launch, where an HBM-bound kernel costs its energy share instead of its stand-alone time."""
+        main = torch.cuda.current_stream()
+        t = self._t
+        eng = self.engine
+        if self._pool_done is not None:
+            main.wait_event(self._pool_done)  # this batch's operand set (pooled during the previous step)
+        self._side.wait_stream(main)
+        self.pooled = self._pooled_slot[t & 1]
+        losses = self._heads(eager)
+        ev_heads = torch.cuda.Event()
+        ev_heads.record(main)
+        with torch.cuda.stream(self._side):
+            evp = None
+            if self.stage_ahead:
+                self._stage_props(next_batch)
+                self._stage_labels_ahead(next_batch, via_stage=True)
+                evp = torch.cuda.Event()
+                evp.record(self._side)
+        if evp is None:
+            self._stage_props(next_batch)
+        k1, h1 = ((t + 1) // 2) % 2, (t + 1) % 2
+        ps_ = self._pool_stream
+        ps_.wait_event(ev_heads)
+        if evp is not None:
+            ps_.wait_event(evp)
+        ps_.wait_event(self._pdone[k1])
+        with torch.cuda.stream(ps_):
+            cur = self.pooled
+            self._pair_pool_body(k1, h1, slot=(t + 1) & 1)
+            self._pooled_slot[(t + 1) & 1] = self.pooled
+            self.pooled = cur
+            self._pool_done = torch.cuda.Event()
+            self._pool_done.record(ps_)
+        if self.split_tail:
+            # the captured backward recorded the operand set it was captured with: hand the tail this step's
+            tl = list(eng._tail)
+            tl[1], tl[6], tl[8] = self.pooled["AT"], self.pooled["A"], self.pooled.get("t_row0", 0)
+            eng._tail = tuple(tl)
+            eng.run_fc1_tail()
+        with torch.cuda.stream(self._side):
+            if t % 2 == 0:
+                ps = (t // 2 + 1) % 2
+                self._side.wait_event(self._pool_done)  # (pair slot ps was last read by the pooling of batch t-1: long done)
+                self._pair_stage(b2, b3, ps)
+                self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                self._pdone[ps] = ev
+        if self.split_tail:
+            self.opt.step(1.0)
+        self._t = t + 1
+        return losses
 
     def _run_pairs(self, eager, next_batch, b2, b3):
         """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % 2.  Even t: the conv chain of pair t/2 + 1
         (batches t+2, t+3) starts on the side stream - its slot was last read by the pooling of batch t-1.  Every t: the
         pooling of batch t+1 reads its half of its pair's features (pair (t+1)/2, launched at step 2 ((t+1)/2) - 2)."""
+        if self.pool_overlap:
+            return self._run_pairs_overlap(eager, next_batch, b2, b3)
         main = torch.cuda.current_stream()
         t = self._t
         self._side.wait_stream(main)
@@ -1361,6 +1435,7 @@ class GraphedTrainStep:
             self._pfeats[1] = torch.zeros_like(self._pfeats[0])
             self._stage_props(b0)
             self._pair_pool_body(0, 0)
+            self._pooled_slot[0] = self.pooled
         self._pdone[0] = torch.cuda.Event()
         self._pdone[0].record(main)
         self._stage_labels(b0)

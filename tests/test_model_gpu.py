@@ -451,6 +451,51 @@ def test_hipgraph_step_equals_eager(lookahead):
             assert abs(e[k] - g[k]) <= 1e-5 * max(abs(e[k]), 1e-3), (k, e[k], g[k])
 
 
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_pool_overlap_schedule_equals_serial_pooling(precision):
+    """GraphedTrainStep(pool_overlap=True) - the next batch's pooling piece on its own stream beside the fc6 dW tail, the
+    two fc6 operand sets alternating, the captured backward's tail handed this step's set - against the same schedule with
+    the pooling behind the tail: 9 steps over a non-periodic sequence of three batches, losses and every weight bit for bit
+    (a wrong set, a stale tail operand or a missing stream dependency shows as another gradient)."""
+    from drn_wsod_pytorch_amd.engine import GraphedTrainStep, build_optimizer
+
+    name = "model_r50c4_tiny"
+    d = G.load(name)
+    ocfg = G.MODEL_CASES[name]
+    base = G.batch_from(d)
+    b0 = G.drn_inputs([base[0]])
+    alt = dict(base[0])
+    alt["image"] = (255.0 - base[0]["image"]).contiguous()
+    alt["objectness_logits"] = base[0]["objectness_logits"].flip(0).contiguous()
+    b1 = G.drn_inputs([alt])
+    alt2 = dict(base[0])
+    alt2["image"] = base[0]["image"].flip(2).contiguous()
+    alt2["proposal_boxes"] = base[0]["proposal_boxes"].flip(0).contiguous()
+    alt2["gt_classes"] = (base[0]["gt_classes"] + 1) % ocfg.num_classes
+    b2 = G.drn_inputs([alt2])
+    seq = [b0, b1, b2, b0, b1, b1, b0, b2, b1, b0, b2, b2, b1]
+    res = []
+    for overlap in (False, True):
+        cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, precision)
+        model.roi_heads.box_head.dropout_p = 0.0
+        model.train()
+        opt = build_optimizer(cfg, model)
+        opt.enable_pipelined(None, slab_rows=[16, 48])
+        stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True, trunk_pairs=True, eager_fc6=True, pool_overlap=overlap)
+        assert stepper.pool_overlap == overlap
+        out = []
+        for i in range(9):
+            losses = stepper.step(*seq[i: i + 4])
+            out.append({k: float(v.detach()) for k, v in losses.items()})
+        torch.cuda.synchronize()
+        res.append((out, model.roi_heads._engine.arena_w.clone()))
+        del stepper, model, opt
+    for a, b in zip(res[0][0], res[1][0]):
+        assert a == b
+    assert torch.equal(res[0][1], res[1][1])
+    load_package().set_precision("fp32")
+
+
 @pytest.mark.parametrize("comm,lookahead", [("fp32", 1), ("bf16", 1), ("fp32", 2), ("fp32", "pairs")])
 def test_split_tail_exchange_step_equals_eager(comm, lookahead):
     """The N>1 step on one GPU: a 1-rank RCCL group with the exchange forced on, GraphedTrainStep(split_tail=True)
