@@ -512,7 +512,7 @@ __device__ __forceinline__ void sgdp_apply_store(const SgdPipe& sp, const SgdReg
 
 // slabs [s0, s1), s0 < s1; slab s0 has been issued into stage 0 by pp_issue_first.  Every wave passes the same number of
 // barriers (wave row 1 one extra in front, wave row 0 one extra behind).
-// SGDP: the optimizer step of the previous tile rides along (above); needs s1 - s0 == 32 and VAR == 1.
+// SGDP: the optimizer step of the previous tile rides along (above); needs s1 - s0 >= 32 and VAR == 1.
 template <int DT, int VAR, bool TN = false, bool SGDP = false>
 __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, __amdgpu_buffer_rsrc_t ra,
                                             __amdgpu_buffer_rsrc_t rb, const unsigned (&voa)[4], const unsigned (&vob)[4],
@@ -611,8 +611,12 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
       PP_PIECE(0); PP_PIECE(1);
       if constexpr (SGDP) {
         const unsigned i_ = (unsigned)(s - s0);
-        sgdp_load(*spp, sr_ld, spp->off + i_ * spp->step, spp->goff + i_ * spp->gstep);
-        asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // B1 of this slab (3 optimizer loads younger than the pieces)
+        if (i_ < 32) {  // (32 chunks per tile; longer K loops - R > 2048 - carry nothing in their later slabs)
+          sgdp_load(*spp, sr_ld, spp->off + i_ * spp->step, spp->goff + i_ * spp->gstep);
+          asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // B1 of this slab (3 optimizer loads younger than the pieces)
+        } else {
+          asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
       } else {
         asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // B1 of this slab has landed (read in phase 2)
       }
@@ -628,8 +632,10 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
       asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // A1 of this slab (phase 3)
     } else {
       PP_PIECE(2); PP_PIECE(3);
-      if constexpr (SGDP) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // A1 of this slab; P0 P1 L L L P2 P3 may be in flight
-      else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A1 of this slab (phase 3)
+      if constexpr (SGDP) {
+        if ((unsigned)(s - s0) < 32) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");  // A1 of this slab; P0 P1 L L L P2 P3 may be in flight
+        else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A1 of this slab (phase 3)
     }
     PP_BARRIER();
     mm(acc[0][1], acc[1][1], WAITB);
@@ -641,7 +647,7 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     if constexpr (SGDP) {
       const unsigned i_ = (unsigned)(s - s0);
       // chunk i - 1: its loads went out in phase 1 of the previous slab (18 vector memory operations ago; 15 in slab 1)
-      if (i_ >= 1) sgdp_apply_store(*spp, sr_use, spp->off + (i_ - 1) * spp->step);
+      if (i_ >= 1 && i_ <= 32) sgdp_apply_store(*spp, sr_use, spp->off + (i_ - 1) * spp->step);
     }
     PP_BARRIER();
     mm(acc[2][1], acc[3][1], NOWAIT);
@@ -653,7 +659,7 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     if (VAR == 2) { PP_PIECE(5); PP_PIECE(6); PP_PIECE(7); } else { PP_PIECE(6); PP_PIECE(7); }
     if constexpr (SGDP) {
       // A0 and B0 of the next slab; behind them P4 P5 [S S S] P6 P7 may be in flight (no stores yet in slab 0)
-      if (s > s0) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
+      if (s > s0 && s - s0 <= 32) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
       else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
     } else
     asm volatile("s_waitcnt vmcnt(4)" ::: "memory");  // A0 and B0 of the next slab (its phase 1)
@@ -664,16 +670,19 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     for (int ks = 0; ks < 4; ++ks) { oa[ks] ^= PP_STAGE; ob[ks] ^= PP_STAGE; }
   };
   if constexpr (SGDP) {
-    for (int s = s0; s < s1; s += 2) {  // (an even number of slabs: 32)
+    int s = s0;
+    for (; s + 1 < s1; s += 2) {  // chunk i lives in A (even slabs) / B (odd slabs): static register sets
       slab(s, srA, srB);
       slab(s + 1, srB, srA);
     }
+    if (s < s1) slab(s, srA, srB);  // (odd slab counts: R = 4000 is 63 slabs)
   } else {
     for (int s = s0; s < s1; ++s) slab(s, srA, srA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before LDS is reused
-  if constexpr (SGDP)  // the last chunk (loaded in phase 1 of the last, odd slab)
-    sgdp_apply_store(*spp, srB, spp->off + (unsigned)(s1 - 1 - s0) * spp->step);
+  if constexpr (SGDP) {  // exactly 32 slabs: the last chunk (loaded in phase 1 of the last, odd slab) is still due
+    if (s1 - s0 == 32) sgdp_apply_store(*spp, srB, spp->off + 31u * spp->step);
+  }
   if (wm == 0) PP_BARRIER();
 #undef PP_PIECE
 }
@@ -2278,9 +2287,9 @@ int drn_gemm_tn_sgd(const void* A, const void* Bt, void* grad_bucket, int M, int
   if ((lda * 2) % 16 != 0 || (ldb * 2) % 16 != 0 || lda < K || ldb < N || ldc < N || ld_w < N) return DRN_ERR_ARG;
   if ((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)grad_bucket | (uintptr_t)weights | (uintptr_t)momentum_buf | (uintptr_t)shadow) & 15))
     return DRN_ERR_ARG;
-  // shape class of the pipelined update: 32 K slabs (one 8-row chunk of the previous tile per slab), whole tiles, a bf16
+  // shape class of the pipelined update: >= 32 K slabs (one 8-row chunk of the previous tile per slab), whole tiles, a bf16
   // shadow, 32-bit byte offsets, enough tiles for the persistent grid, the ping-pong mainloop
-  if (K != 2048 || (M & 255) || (N & 255) || !shadow || (ldc & 7) || (ld_w & 3) || g_pingpong != 1 ||
+  if (K < 2048 || (K & 63) || (M & 255) || (N & 255) || !shadow || (ldc & 7) || (ld_w & 3) || g_pingpong != 1 ||
       (long)M * ld_w * 4 >= 0xFFFFFFF0L || (long)K * ldb * 2 >= 0xFFFFFFF0L)
     return DRN_ERR_UNSUPPORTED;
   const long tiles = (long)(M / 256) * (N / 256);

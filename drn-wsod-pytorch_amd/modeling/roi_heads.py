@@ -589,6 +589,11 @@ class _HeadEngine:
                 ncu = self._ncu = torch.cuda.get_device_properties(self.arena_w.device).multi_processor_count
             step = ncu // math.gcd(ncu, tiles_m)
             nt = (K1 // 256) // step * step
+            if getattr(self, "fc1_fused_all", 1) and K1 % 256 == 0:
+                # the trailing tile columns ride in the same launch as a partial last round - it runs while the other
+                # workgroups drain - instead of a small-tile launch + block update of their own: no A^T rows at all, the
+                # pooling launch loses its 64-ROI tail launch (+2 % same box, profiles/r4_17; fc1_fused_all = 0: A/B)
+                nt = K1 // 256
             if nt > 0 and self._fc1_use_tn(dtype):
                 return nt * 256, nt * 256
         if r <= 0 or not self._fc1_use_tn(dtype) or getattr(self, "fc1_fused_update", None) is not None:

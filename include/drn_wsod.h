@@ -182,7 +182,7 @@ int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda,
  * is applied by the SAME launch: every workgroup of the persistent 256x256 kernel updates the tile it finished last while it
  * multiplies the next one (one 8-row chunk per K slab, loads / stores interleaved with the LDS-DMA pipeline), so the
  * optimizer's HBM traffic is a steady stream under the MFMA work and the gradient is read back from L2.  Bit-identical to
- * the unfused pair.  Shape class: K == 2048 (R <= 2048 proposals), M, N multiples of 256, bf16 shadow given;
+ * the unfused pair.  Shape class: K >= 2048 (at least 32 K slabs: 1985+ proposals), M, N multiples of 256, bf16 shadow given;
  * DRN_ERR_UNSUPPORTED otherwise (callers then run the unfused pair). */
 int drn_gemm_tn_sgd(const void* A, const void* Bt, void* grad_bucket, int M, int N, int K, int kb_rows, long lda, long ldb,
                     long ldc, float* weights, float* momentum_buf, void* shadow, long ld_w, const void* seg_dev,

@@ -962,15 +962,16 @@ def test_gemm_nt_sgd_equals_gemm_then_sgd(drn, dtype, M, N, K, wd):
     assert not torch.equal(wa, w0)
 
 
-@pytest.mark.parametrize("M,N,wd", [(1024, 20480, 5e-4), (768, 24576 + 256, 0.0), (2048, 8192 + 512, 1e-4)])
-def test_gemm_tn_sgd_equals_unfused_pair(drn, M, N, wd):
+@pytest.mark.parametrize("M,N,wd,K,kb", [(1024, 20480, 5e-4, 2048, 2000), (768, 24576 + 256, 0.0, 2048, 2000),
+                                         (2048, 8192 + 512, 1e-4, 2048, 2048), (1024, 20480, 5e-4, 4032, 4000),
+                                         (512, 40960 + 256, 1e-4, 2112, 2100)])
+def test_gemm_tn_sgd_equals_unfused_pair(drn, M, N, wd, K, kb):
     """Round 4: drn_gemm_tn_sgd - the fc6 weight gradient (TN form, bf16 bucket) with the optimizer step of every tile applied
     by the same launch, inside the NEXT tile's mainloop (loads / stores interleaved with the LDS-DMA pipeline on counted
     waits) - against drn_gemm_tn into the bucket followed by drn_sgd_step: bucket, weights, momentum and bf16 shadow bit for
     bit over a first step and two momentum steps.  320 / 291 / 272 tiles on 256 resident workgroups: workgroups with one
     tile (first mainloop + drain only) and with two (pipelined update + drain)."""
     rs = np.random.RandomState(23)
-    K, kb = 2048, 2000
     w0 = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).to(DEV) * 0.02
     seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
     seg[0] = (0, M * N, 0.01, wd)
