@@ -283,8 +283,8 @@ def main():
                          "neutral: its HBM-heavy epilogues run in lock-step across CUs, see DESIGN.md)")
     ap.add_argument("--pool-overlap", type=int, default=0,
                     help="1 = the next batch's pooling piece on its own stream beside the fc6 dW tail (the two operand sets alternate)")
-    ap.add_argument("--fused-tn", type=int, default=1,
-                    help="N=1 (default 1): fc6 dW + SGD in ONE launch with the update of each tile pipelined into the next tile's "
+    ap.add_argument("--fused-tn", type=int, default=-1, choices=[-1, 0, 1],
+                    help="N=1 (default -1 = the engine's choice: on for R50 / VGG16 trunks): fc6 dW + SGD in ONE launch with the update of each tile pipelined into the next tile's "
                          "mainloop (drn_gemm_tn_sgd); 0 = two row slabs + sgd_kernel on the optimizer stream (round 3)")
     ap.add_argument("--fc7-dx-splits", type=int, default=0, help="A/B: K-splits of the fc7 dX inside the paired launch (0 = heuristic)")
     ap.add_argument("--no-fc7-pair", action="store_true",
@@ -403,7 +403,7 @@ def main():
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
                              comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype],
                              exchange=args.exchange, col_rounds=args.col_rounds,
-                             kshard_wire=torch.bfloat16 if args.kshard_wire == "bf16" else None, fused_tn=bool(args.fused_tn))
+                             kshard_wire=torch.bfloat16 if args.kshard_wire == "bf16" else None, fused_tn={-1: None, 0: False, 1: True}[args.fused_tn])
         if world == 1 and args.fused_sgd:
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
     R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES

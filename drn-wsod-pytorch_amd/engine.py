@@ -227,7 +227,15 @@ class FusedSGD:
         # tile inside the next tile's mainloop (enable_fused_fc1_tn; +0.8 .. +2.4 % same-box, bit-identical).  Shapes outside
         # the kernel's class fall back per call.
         e.fc1_fused_tn = None
-        if (fused_tn is None or fused_tn) and not self._exchange_on and e.fc1_grad_bucket is not None and not col_rounds:
+        if fused_tn is None:
+            # the fused launch holds every CU with two 248-register waves per SIMD: a trunk conv workgroup (~100 registers)
+            # no longer fits beside it, and a trunk whose conv chain is as long as the step (WS-R101: ~100 launches) loses more
+            # than the fusion gains (647 vs 658 img/s, profiles/r4_19_side_workloads.txt); R50 / VGG16 trunks gain
+            try:
+                fused_tn = len(self.model.backbone.conv_modules()) <= 64
+            except Exception:  # noqa: BLE001
+                fused_tn = True
+        if fused_tn and not self._exchange_on and e.fc1_grad_bucket is not None and not col_rounds:
             self.enable_fused_fc1_tn()
 
     def enable_fused_fc1(self):
