@@ -268,6 +268,7 @@ def main():
                          "measurement, not the headline metric)")
     ap.add_argument("--tune", default="", help="comma-separated knob=value pairs for drn_tune (A/B runs), e.g. 3=4")
     ap.add_argument("--engine-opt", default="", help="comma-separated attr=int pairs set on the head engine (A/B runs)")
+    ap.add_argument("--step-opt", default="", help="comma-separated attr=int pairs set on the GraphedTrainStep (A/B runs: late_join, stage_before_tail)")
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
     ap.add_argument("--graph-pool", action="store_true", help="A/B: replay the pooling piece as its own graph instead of issuing it eagerly")
     ap.add_argument("--no-stage-ahead", action="store_true",
@@ -373,6 +374,7 @@ def main():
     model.train()
     for kv in filter(None, args.engine_opt.split(",")):
         setattr(model.roi_heads._engine, kv.split("=")[0], int(kv.split("=")[1]))
+    step_opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in filter(None, args.step_opt.split(",")))
     opt = build_optimizer(cfg, model)
     dp = DataParallel(model, force_exchange=args.force_exchange)
     dp.broadcast_parameters(0)
@@ -450,6 +452,8 @@ def main():
                                    trunk_pairs=args.trunk_pairs, eager_fc6=not args.no_eager_fc6,
                                    stage_ahead=not args.no_stage_ahead, eager_pool=not args.graph_pool,
                                    pool_overlap=bool(args.pool_overlap))
+        for k_, v_ in step_opts.items():
+            setattr(stepper, k_, v_)
         try:
             for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
                 last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])

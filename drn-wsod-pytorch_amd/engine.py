@@ -161,6 +161,7 @@ class FusedSGD:
         self._kshard = exchange == "fc6_kshard" and dp is not None and dp.exchange
         if self._kshard:
             e.kshard = dict(group=dp.group, world=world, rank=dist.get_rank(dp.group), wire=kshard_wire)
+            e.fc1_fused_cols = self._fused_fc1_cols if (fused_tn is None or fused_tn) else None
             slab_rows = [d1]
         self._sharded = world > 1 and exchange not in ("allreduce", "fc6_kshard")
         if self._sharded:
@@ -273,6 +274,24 @@ class FusedSGD:
         view = lambda t: t[o: o + n].view(D1, k1)[:, :n_main]
         return ops.gemm_tn_sgd(dPT, A[:, :n_main], D1, n_main, Mp, M, gw[:, :n_main], view(e.arena_w), view(self._mom),
                                view(e.arena_s), segs, self.momentum, self._steps == 0, 1.0)
+
+    def _fused_fc1_cols(self, dPT, A, D1, k0, k1, Kp, kb, gw):
+        """K-sharded fc6: dW of the owned columns k0:k1 and their update as one launch (drn_gemm_tn_sgd; N = 2 / 4: the
+        column count is a multiple of 256); False -> the caller runs the unfused pair"""
+        e = self.engine
+        if e.arena_s is None or gw.dtype != torch.bfloat16 or not getattr(self, "_kshard", False):
+            return False
+        if self._mom is None:
+            self._mom = torch.zeros_like(e.arena_w)
+        segs, _ = self._bucket_table(("fc1", 0, D1))
+        o, n = e._seg["fc1.weight"]
+        kk = n // D1
+        view = lambda t: t[o: o + n].view(D1, kk)[:, k0:k1]
+        ok = ops.gemm_tn_sgd(dPT, A, D1, k1 - k0, Kp, kb, gw[:, k0:k1], view(e.arena_w), view(self._mom), view(e.arena_s),
+                             segs, self.momentum, self._steps == 0, 1.0 / self._dp.world)
+        if ok:
+            self._master_stale = True
+        return ok
 
     def _fused_fc1(self, dPT, AT, D1, K1, Mp):
         e = self.engine
@@ -469,6 +488,8 @@ class FusedSGD:
 
     def _on_grad_ready(self, what):
         e = self.engine
+        if what != "small":
+            self._fc1_on_opt_stream = True  # fc6's update (or a part of it) runs on the optimizer stream this step: step() must join
         if self._mom is None:
             self._mom = torch.zeros_like(e.arena_w)
         if what[0] == "fc1b":
@@ -535,7 +556,18 @@ class FusedSGD:
                 p.grad = None
         self.engine._grads_valid = False
 
-    def step(self, grad_scale=1.0):
+    def join(self):
+        """the caller's stream waits for the optimizer stream (see step(join=False))"""
+        if getattr(self, "_join_pending", False):
+            torch.cuda.current_stream().wait_stream(self._opt_stream)
+            self._join_pending = False
+
+    def step(self, grad_scale=1.0, join=True):
+        """join=False (pipelined mode without an exchange; GraphedTrainStep with the eager fc6 forward): the optimizer
+        stream - by then only the small tensors' chain: bias column sums, their SGD launch, the K-major twins of fc7 / the
+        predictors - is NOT joined here; the caller calls join() in front of the first reader of those weights (the heads
+        graph), so that chain runs beside the next batch's pooling and fc6 forward instead of in front of them.  (With
+        fc6's update inside its dW launch, which holds every CU, the chain only starts when that launch ends.)"""
         e = self.engine
         if not e._grads_valid:
             raise DrnError("optimizer.step() before any backward()")
@@ -561,9 +593,14 @@ class FusedSGD:
                 for g in gathered:
                     cur.wait_event(g)
                 self._deferred = []
-            else:
+            elif join or getattr(self, "_fc1_on_opt_stream", False) or e.arena_s is None:
                 # every bucket was already updated on the optimizer stream during backward(): join it
+                # (also whenever fc6's own update ran there - the next fc6 forward reads it - or the forward re-casts shadows)
                 cur.wait_stream(self._opt_stream)
+                self._join_pending = False
+            else:
+                self._join_pending = True
+            self._fc1_on_opt_stream = False
             self._steps += 1
             e.mark_dirty(shadow_fresh=e.arena_s is not None)
             return
@@ -1203,6 +1240,8 @@ class GraphedTrainStep:
     def _heads(self, eager):
         """fc6 forward (eager, when timed) + the heads graph of the current batch on the current stream"""
         self._fc6_eager()
+        if hasattr(self.opt, "join"):
+            self.opt.join()  # (late_join) the small tensors' update chain: its first reader is the heads graph, not the fc6 forward
         return self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
 
     def _fc6_eager(self):
@@ -1401,14 +1440,23 @@ class GraphedTrainStep:
         t = self._t
         self._side.wait_stream(main)
         losses = self._heads(eager)
+        early = self.split_tail and self.stage_ahead and getattr(self, "stage_before_tail", False)
+        evp = None
+        if early:
+            # (round 4, A/B knob - measured neutral, profiles/r4_21) the proposal / label staging of batch t+1 BEFORE the dW tail:
+            # the fused dW + SGD launch holds every CU for ~0.5 ms and tiny copies queued behind it only start when it ends
+            with torch.cuda.stream(self._side):
+                self._stage_props(next_batch)
+                self._stage_labels_ahead(next_batch, via_stage=True)
+                evp = torch.cuda.Event()
+                evp.record(self._side)
         if self.split_tail:
             self.engine.run_fc1_tail()
         with torch.cuda.stream(self._side):
             # proposals of batch t+1 on the side stream (ordered behind step t-1's pooling graph, their last reader, by the
             # wait above; in front of the conv chain): three small launches that sat between the last dW slab and the
             # pooling graph on the main stream (22 us in the timeline)
-            evp = None
-            if self.stage_ahead:
+            if self.stage_ahead and not early:
                 self._stage_props(next_batch)
                 self._stage_labels_ahead(next_batch, via_stage=True)  # -> _gt_stage; the pooling graph hands them on
                 evp = torch.cuda.Event()
@@ -1428,7 +1476,8 @@ class GraphedTrainStep:
         main.wait_event(self._pdone[k1])
         self._pair_pool_body(k1, h1) if (eager or self.eager_pool) else self.g_ppool[k1][h1].replay()
         if self.split_tail:
-            self.opt.step(1.0)
+            late = self.eager_fc6 and getattr(self, "late_join", False) and not getattr(self.opt, "_exchange_on", False)
+            self.opt.step(1.0, join=not late)
         self._t = t + 1
         return losses
 

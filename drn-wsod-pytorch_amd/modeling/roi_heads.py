@@ -697,11 +697,25 @@ class _HeadEngine:
                 raise DrnError("fc6 K-sharding needs the same image / proposal shapes on every rank (got %s)" % allshp.tolist())
             ks["checked"] = key
         c0, c1 = rank * (C // N), (rank + 1) * (C // N)
-        feats = self._ks_gather(feat_nhwc)[..., c0:c1].reshape(N * n, H, W, c1 - c0).contiguous()
-        rois_all = self._ks_gather(rois)
+        # ONE all-gather: [feature map | proposals | objectness] of every rank as bytes (three small collectives were three
+        # launch + rendezvous latencies on the step's dependent chain)
+        fb, rb = feat_nhwc.numel() * feat_nhwc.element_size(), rois.numel() * 4
+        ob = objectness.numel() * 4 if objectness is not None else 0
+        pack = ks.get("pack")
+        if pack is None or pack.numel() != fb + rb + ob:
+            pack = ks["pack"] = torch.empty((fb + rb + ob,), dtype=torch.uint8, device=feat_nhwc.device)
+            ks["pack_all"] = torch.empty((N, fb + rb + ob), dtype=torch.uint8, device=feat_nhwc.device)
+        pack[:fb].view(feat_nhwc.dtype).copy_(feat_nhwc.reshape(-1))
+        pack[fb: fb + rb].view(torch.float32).copy_(rois.reshape(-1))
+        if ob:
+            pack[fb + rb:].view(torch.float32).copy_(objectness.reshape(-1))
+        allp = ks["pack_all"]
+        dist.all_gather_into_tensor(allp.view(-1), pack, group=ks["group"])
+        feats = allp[:, :fb].view(feat_nhwc.dtype).view(N, n, H, W, C)[..., c0:c1].reshape(N * n, H, W, c1 - c0).contiguous()
+        rois_all = allp[:, fb: fb + rb].view(torch.float32).view(N, M, 5).clone()
         rois_all[:, :, 0] += (torch.arange(N, device=rois.device, dtype=rois.dtype) * n).view(N, 1)
         rois_all = rois_all.view(N * M, 5)
-        obj_all = self._ks_gather(objectness).view(N * M) if objectness is not None else None
+        obj_all = allp[:, fb + rb:].view(torch.float32).reshape(N * M).contiguous() if ob else None
         cols = (c1 - c0) * pp
         MA = N * M
         D1 = h.box_head.fc1.weight.shape[0]
@@ -756,6 +770,9 @@ class _HeadEngine:
         dPT = ops.transpose2d(dP1_all, MA, D1)            # [D1, kpad(N*M)]: the K-major operand of the dW GEMM
         Kp = dPT.shape[1]
         out = gw[:, k0:k1].unsqueeze(0)
+        fused = getattr(self, "fc1_fused_cols", None)
+        if dtype == torch.bfloat16 and fused is not None and fused(dPT, ks["A"], D1, k0, k1, Kp, MA, gw):
+            return  # gradient and update of the owned columns in one launch
         if dtype == torch.bfloat16:
             ops.gemm_tn(dPT, ks["A"], D1, k1 - k0, Kp, MA, out=out)
         else:
