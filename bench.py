@@ -400,11 +400,19 @@ def main():
     if args.fc7_dx_splits:
         model.roi_heads._engine.fc7_pair_dx_splits = args.fc7_dx_splits
     opt.peel_on_opt_stream = bool(args.peel_side)
+    exchange = args.exchange
+    if exchange is None and world > 1 and not args.no_pipelined_sgd and not args.no_graph:
+        # round 4: for N > 1 the bench's fixed-shape batches take the K-sharded fc6 (no fc6 gradient exchange, no weight gather;
+        # priced 1.7x / 3.2x / 5.8-6.4x for N = 2 / 4 / 8 against 0.75x / 2.0-2.3x / 5.0-6.5x) when the channel
+        # count splits over the ranks into whole K slabs; --exchange sharded | allreduce select the gradient exchanges
+        c_feat = 1024 if args.workload in ("r50c4", "r50c4_fp8", "r101c4_k80") else (2048 if args.workload == "r50dc5" else 512)
+        if c_feat % world == 0 and ((c_feat // world) * 49 * 2) % 128 == 0:
+            exchange = "fc6_kshard"
     if not args.no_pipelined_sgd:
         # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
         opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
                              comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype],
-                             exchange=args.exchange, col_rounds=args.col_rounds,
+                             exchange=exchange, col_rounds=args.col_rounds,
                              kshard_wire=torch.bfloat16 if args.kshard_wire == "bf16" else None, fused_tn={-1: None, 0: False, 1: True}[args.fused_tn])
         if world == 1 and args.fused_sgd:
             opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
