@@ -34,5 +34,10 @@ if [ "${PMC_ONLY:-}" = "dw_tn" ]; then  # the fc6 dW slab reading the pooled mat
   run_shape dw_tn 1024,49152,2048,1 1
   exit 0
 fi
+if [ "${PMC_ONLY:-}" = "sgdp" ]; then  # round 4: the fused fc6 dW + SGD launch (drn_gemm_tn_sgd), all 196 tile columns
+  export PMC_SGDP=1
+  run_shape dw_sgdp 2048,50176,2048,1 1
+  exit 0
+fi
 run_shape fwd 2000,2048,50176,4 ""
 run_shape dw 1024,49152,2048,1 1

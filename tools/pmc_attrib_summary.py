@@ -68,6 +68,11 @@ if "TCC_HIT_sum" in c and "TCC_MISS_sum" in c:
 if "TCP_TCC_READ_REQ_LATENCY_sum" in c and c.get("TCP_TCC_READ_REQ_sum"):
     d["l1_to_l2_read_latency_cycles"] = c["TCP_TCC_READ_REQ_LATENCY_sum"] / c["TCP_TCC_READ_REQ_sum"]
 alg = (M + N) * K * 2 + S * M * N * (2 if bf16_out else 4)
+if os.environ.get("PMC_SGDP"):
+    # fused dW + SGD: operands + the bf16 bucket written + per parameter w / momentum read and written (16 B) + the bf16 shadow
+    # (2 B); the gradient is read back from L2 (not counted)
+    alg = (M + N) * K * 2 + M * N * 2 + M * N * 18
+    rec["kernel_mode"] = "drn_gemm_tn_sgd (gemm_nt256p_kernel<bf16, TN, SGDP>)"
 if "FETCH_SIZE" in c:
     d["fetch_bytes"] = c["FETCH_SIZE"] * 1024 * 2
 if "WRITE_SIZE" in c:

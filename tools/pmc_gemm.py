@@ -21,6 +21,24 @@ TN = os.environ.get("PMC_TN")  # the second operand K-major (drn_gemm_tn): Bt [k
 if TN:
     kb = K - 48
     Bt = (torch.randn((kb, N), device="cuda") * 0.05).to(torch.bfloat16)
+SGDP = os.environ.get("PMC_SGDP")  # round 4: the fused fc6 dW + SGD launch (drn_gemm_tn_sgd): PMC_SHAPE = D1,K1,Rpad,1
+if SGDP:
+    import numpy as np
+
+    kb = K - 48
+    Bt = (torch.randn((kb, N), device="cuda") * 0.05).to(torch.bfloat16)
+    w = torch.randn((M, N), device="cuda") * 0.02
+    mom = torch.randn((M, N), device="cuda") * 0.01
+    sh = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    g16 = torch.zeros((M, N), dtype=torch.bfloat16, device="cuda")
+    seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
+    seg[0] = (0, M * N, 0.0, 5e-4)
+    seg_dev = torch.from_numpy(seg.view(np.uint8)).to("cuda")
+    for _ in range(6):
+        assert ops.gemm_tn_sgd(A, Bt, M, N, K, kb, g16, w, mom, sh, seg_dev, 0.9, False, 1.0)
+    torch.cuda.synchronize()
+    print("done")
+    sys.exit(0)
 for _ in range(6):
     if TN:
         ops.gemm_tn(A, Bt, M, N, K, kb, out=out, splits=S)
