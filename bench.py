@@ -630,6 +630,14 @@ def main():
             e_ = entry("gemm_nt256p_kernel<bf16, TN, SGDP> fc6 dW columns 0:%d + the optimizer step of every tile in the next tile's mainloop"
                        % col_plan[0], {("tn_sgd", D1, col_plan[0], Mp)}, 2.0 * D1 * col_plan[0] * Rtot)
             if e_:
+                # the same launch also streams the optimizer's bytes (w / momentum read + written, bf16 shadow written: 18 B per
+                # parameter; the bf16 gradient goes out and is read back through L2): both resources of ONE launch
+                nb_ = 18.0 * D1 * col_plan[0]
+                e_["carries_optimizer_bytes"] = nb_
+                e_["optimizer_GBps_in_this_launch"] = nb_ / (e_["avg_launch_ms"] * 1e-3) / 1e9
+                e_["note"] = ("MFMA work and the fc6 optimizer pass share this launch under the 1400 W cap: FLOPs / time is not "
+                              "comparable with a GEMM-only launch (the unfused pair took 20 + 180 + 280 us of GEMM launches plus a "
+                              "229-us optimizer slab behind them for the same work)")
                 launches.append(e_)
         fused = entry("gemm_nt256_kernel<bf16, SGD> fc6 dW + optimizer epilogue", {("sgd", D1, K1, Mp)}, 2.0 * D1 * K1 * Rtot)
         if fused:
