@@ -2,7 +2,7 @@
   rocprofv3 --kernel-trace --pmc FETCH_SIZE -d out1 -- python tools/pmc_hbm.py
   rocprofv3 --kernel-trace --pmc WRITE_SIZE -d out2 -- python tools/pmc_hbm.py
 (separate passes; tools/pmc_hbm_round.sh runs both and summarises them).
-  * roi_pool7_map64_kernel: 14x14x1024 bf16 map, 2000 SURVEY 8(d) boxes -> A [2000 x 50176] and A^T [50176 x 2048]
+  * roi_pool7_lane_kernel (round 4): 14x14x1024 bf16 map, 2000 SURVEY 8(d) boxes -> A [2000 x 50176] (no A^T row is needed any more)
   * sgd_kernel<shadow, bf16 grad>: one fc6 row slab (1024 x 50176 parameters) of RANDOM fp32 weights / momentum, a bf16
     gradient bucket and the bf16 shadow (zero-filled operands clock higher: MI355X_MICROARCH.md, DVFS note)"""
 import importlib
@@ -29,7 +29,7 @@ K1 = C * 49
 A = torch.zeros((R, ops.kpad(K1, torch.bfloat16)), dtype=torch.bfloat16, device=dev)
 AT = torch.zeros((K1, ops.kpad(R, torch.bfloat16)), dtype=torch.bfloat16, device=dev)
 for _ in range(6):
-    ops.roi_pool_nhwc(feat, rois, obj, 7, 1.0 / 16, out=A, out_t=AT)
+    ops.roi_pool_nhwc(feat, rois, obj, 7, 1.0 / 16, out=A, out_t=AT, t_first_channel=C)  # what the step launches since round 4: A alone, lane-per-bin kernel
 torch.cuda.synchronize()
 
 n = 1024 * K1

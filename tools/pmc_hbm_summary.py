@@ -18,8 +18,8 @@ def rows(d, kernel, name):
 R, K1 = 2000, 1024 * 49
 n = 1024 * K1
 spec = {
-    "roi_pool7_map64_kernel": {"read": 14 * 14 * 1024 * 2 + R * 5 * 4 + R * 4, "write": 2 * R * K1 * 2,
-                                "what": "A [2000 x 50176] + A^T [50176 x 2000] bf16 written, 0.4 MB map + boxes read"},
+    "roi_pool7_lane_kernel": {"read": 14 * 14 * 1024 * 2 + R * 5 * 4 + R * 4, "write": R * K1 * 2,
+                               "what": "A [2000 x 50176] bf16 written as 98-byte runs (2-byte stores), 0.4 MB map + boxes read"},
     "sgd_kernel": {"read": n * (4 + 4 + 2), "write": n * (4 + 4 + 2),
                    "what": "per parameter: w, momentum fp32 + bf16 gradient read; w, momentum fp32 + bf16 shadow written"},
 }
