@@ -196,7 +196,8 @@ def hbm_rooflines(model, batch, R, device, ops, opt=None):
         es = 2 if nhwc.dtype == torch.bfloat16 else 4
         t_rows = (C - min(C, t_c0 // 8 * 8)) * 49
         nbytes = R * K1 * es + R * t_rows * es + nhwc.numel() * es + rois.numel() * 4
-        out.append({"kernel": "roi_pool7_lane_kernel + roi_pool7_map64_kernel for the A^T tail (ROIPool + objectness scale -> A [R x %d] and A^T rows %d..%d)" % (K1, K1 - t_rows, K1),
+        out.append({"kernel": ("roi_pool7_lane_kernel (ROIPool + objectness scale -> A [R x %d]; no A^T row is needed)" % K1) if t_rows == 0 else
+                              ("roi_pool7_lane_kernel + roi_pool7_map64_kernel for the A^T tail (ROIPool + objectness scale -> A [R x %d] and A^T rows %d..%d)" % (K1, K1 - t_rows, K1)),
                     "bound": "hbm",
                     "achieved": nbytes / t / 1e9, "peak": 8000.0, "unit": "GB/s", "frac": nbytes / t / 1e9 / 8000.0,
                     "bytes_per_launch": nbytes, "avg_launch_ms": t * 1e3})
@@ -721,7 +722,7 @@ def main():
         if pool:
             ms = sum(t for t, _ in pool) / len(pool)
             nb = pool[0][1]
-            in_step.append({"kernel": "roi_pool7_lane_kernel + roi_pool7_map64_kernel for the A^T tail (ROIPool + objectness scale -> A and the A^T tail rows), in step", "bound": "hbm",
+            in_step.append({"kernel": "roi_pool7_lane_kernel (+ roi_pool7_map64_kernel when A^T tail rows are needed): ROIPool + objectness scale -> A, in step", "bound": "hbm",
                             "achieved": nb / ms / 1e6, "peak": 8000.0, "unit": "GB/s", "frac": nb / ms / 1e6 / 8000.0,
                             "bytes_per_launch": nb, "avg_launch_ms": ms, "min_launch_ms": min(t for t, _ in pool),
                             "max_launch_ms": max(t for t, _ in pool), "launches_timed": len(pool)})
