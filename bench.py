@@ -636,6 +636,12 @@ def main():
                 nb_ = 18.0 * D1 * col_plan[0]
                 e_["carries_optimizer_bytes"] = nb_
                 e_["optimizer_GBps_in_this_launch"] = nb_ / (e_["avg_launch_ms"] * 1e-3) / 1e9
+                # both rooflines of the one launch: algorithmic bytes = operands + bf16 bucket written + 18 B per parameter
+                # (profiles/r4_24_pmc_dw_sgdp.json: PMC traffic 1.29x of it)
+                alg_ = (D1 + col_plan[0]) * Mp * 2.0 + D1 * col_plan[0] * 2.0 + nb_
+                e_["algorithmic_bytes"] = alg_
+                e_["hbm_frac_of_peak"] = alg_ / (e_["avg_launch_ms"] * 1e-3) / 8e12
+                e_["mfma_plus_hbm_frac"] = e_["frac"] + e_["hbm_frac_of_peak"]
                 e_["note"] = ("MFMA work and the fc6 optimizer pass share this launch under the 1400 W cap: FLOPs / time is not "
                               "comparable with a GEMM-only launch (the unfused pair took 20 + 180 + 280 us of GEMM launches plus a "
                               "229-us optimizer slab behind them for the same work)")
