@@ -670,6 +670,22 @@ def main():
             fam["power_note"] = ("these launches run AT the 1400 W package cap with the shader clock throttled to 1.64-1.70 GHz; the "
                                  "same forward launch on zero-valued operands reaches 1645 TFLOP/s = 0.66 at 2.40 GHz "
                                  "(tools/power_probe.py, profiles/r4_03_power_probe.txt)")
+            fz = [l for l in launches if "carries_optimizer_bytes" in l]
+            if fz:
+                # the dW launch of this family also IS the fc6 optimizer pass (drn_gemm_tn_sgd): its duration buys 411 GF and
+                # 1.85 GB - comparable with round 3's family figure only together with the optimizer slabs that ran beside / behind it
+                gemm_only = [l for l in launches if "carries_optimizer_bytes" not in l]
+                fam["frac_note"] = ("the weight-gradient launch carries the fc6 optimizer pass (%.2f GB at %.0f GB/s inside the launch, "
+                                    "%.2f of the HBM peak by algorithmic bytes): `frac` divides the family's FLOPs by a duration that "
+                                    "also pays for those bytes; GEMM-only launches of the family: %.3f"
+                                    % (fz[0]["carries_optimizer_bytes"] / 1e9, fz[0]["optimizer_GBps_in_this_launch"],
+                                       fz[0]["hbm_frac_of_peak"],
+                                       (sum(l["gflop_per_launch"] for l in gemm_only) / 1e3 /
+                                        (sum(l["avg_launch_ms"] for l in gemm_only) * 1e-3) / BF16_MFMA_PEAK_TFLOPS) if gemm_only else 0.0))
+                fam["frac_gemm_only_launches"] = ((sum(l["gflop_per_launch"] for l in gemm_only) / 1e3 /
+                                                   (sum(l["avg_launch_ms"] for l in gemm_only) * 1e-3) / BF16_MFMA_PEAK_TFLOPS)
+                                                  if gemm_only else None)
+                fam["fused_launch_mfma_plus_hbm_frac"] = fz[0]["mfma_plus_hbm_frac"]
             roof = fam
         gf_step = step_gflop(args.workload, R, K1, D1, D2, NH, args.ims_per_gpu)
         step_tf = gf_step * 1e9 / (dt / args.steps) / 1e12
