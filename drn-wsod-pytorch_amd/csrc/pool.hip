@@ -1475,7 +1475,8 @@ int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* object
       // slice whose map fits at all - the 43x58 .. 75x100 maps of test-time scales need 16 or 8 channels and most of
       // a CU's LDS (one block per CU), which still beats the per-ROI window kernels by 3-4x there
       const size_t two = 80 * 1024, one = 156 * 1024;
-      if (in_dtype == DRN_BF16 && (out_t || g_roi_map64_a) && M >= ROI_G64) {  // the training operand pair
+      if (in_dtype == DRN_BF16 && M >= ROI_G64) {  // the training operand (pair), and A alone at inference (46 vs 83 us at
+        // 14x14, 194 vs 433 us at 50x76 against the 8-ROI whole-map kernels: tools/roi_a_alone_bench.py)
         // round 4: A from the lane-per-bin kernel; the 64-ROI kernel - full 128-byte A^T lines - then only for the channel
         // chunks whose A^T rows the fc6 dW still reads (the tail its peel takes; it writes their A runs again, same values)
         // (built and measured: the tail's A^T rows as 2-byte stores from the lane kernel itself - 49 partial lines per
@@ -1490,7 +1491,7 @@ int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* object
             done = launch_roi_map64(q, st);
             if (!done) done = launch_roi_map64(p, st);  // (cannot happen for shapes the lane kernel took)
           }
-        } else {
+        } else if (out_t || g_roi_map64_a) {
           done = launch_roi_map64(p, st);
         }
       }
