@@ -254,6 +254,9 @@ def main():
                     help="default: ONE conv chain per TWO batches (t+2, t+3; launched on even steps) - the chain is "
                          "latency-bound, so two images cost what one costs and the per-image chain time halves (r50c4 +2.6 %, "
                          "r101c4_k80 +40 %); this flag goes back to one chain per batch (--lookahead)")
+    ap.add_argument("--trunk-group", type=int, default=0,
+                    help="batches per conv chain of the frozen trunk (0 = default: 4; 8 for the WS-R101 trunk, whose chain is longer "
+                         "than two steps)")
     ap.add_argument("--slab-rows", default=None,
                     help="comma-separated row ends of the fc6 dW slabs (experiment knob; default = the engine's choice)")
     ap.add_argument("--col-rounds", type=int, default=None,
@@ -318,6 +321,10 @@ def main():
                          "rounding torch.autocast(bf16) applies to a Linear's weight gradient")
     args = ap.parse_args()
 
+    if args.trunk_group <= 0:
+        # measured (profiles/r4_31_trunk_group_ab.txt): R50-C4 786-796 img/s with pairs, 793-801 with groups of 4; WS-R101 / K = 80
+        # 670 (pairs), 695-697 (4), 699-706 (8)
+        args.trunk_group = 8 if args.workload == "r101c4_k80" else 4
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -458,14 +465,14 @@ def main():
         # eager_fc6: the fc6 forward GEMM is issued eagerly in front of the heads graph (the fc6 dW slabs already are,
         # behind it), so all three launches of the dominant kernel are bracketed by HIP events INSIDE the timed region
         stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead,
-                                   trunk_pairs=args.trunk_pairs, eager_fc6=not args.no_eager_fc6,
+                                   trunk_pairs=(args.trunk_group if args.trunk_pairs else False), eager_fc6=not args.no_eager_fc6,
                                    stage_ahead=not args.no_stage_ahead, eager_pool=not args.graph_pool,
                                    pool_overlap=bool(args.pool_overlap))
         for k_, v_ in step_opts.items():
             setattr(stepper, k_, v_)
         try:
             for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
-                last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+                last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
         except Exception as ex:  # noqa: BLE001 - a failed capture must not cost the measurement: run the eager step
             print("[bench] hipGraph capture failed (%r); falling back to the eager step" % (ex,), file=sys.stderr)
             use_graph = False
@@ -481,7 +488,7 @@ def main():
             # the step rate, measured A/B on one box: 585 vs 601 img/s; sampled: within noise)
             ops.GEMM_TIMING = timing if (not args.no_launch_timing and i % 5 == 2) else None
             ops.HBM_TIMING = hbm_timing if (not args.no_launch_timing and i % 5 == 2) else None
-            last = stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+            last = stepper.step(*[batches[(j + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
         t_enq = time.perf_counter() - t0
         barrier()
         dt = time.perf_counter() - t0
@@ -490,7 +497,7 @@ def main():
         th = time.perf_counter()
         for i in range(6):
             j = args.warmup + args.steps + i
-            last2 = stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+            last2 = stepper.step(*[batches[(j + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
         host_unblocked = (time.perf_counter() - th) / 6 * 1e3
         barrier()
         local_ms = None
@@ -502,12 +509,12 @@ def main():
             n_loc = min(args.steps, 50)
             for i in range(3):
                 j = args.warmup + args.steps + 6 + i
-                stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+                stepper.step(*[batches[(j + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
             barrier()
             tl = time.perf_counter()
             for i in range(n_loc):
                 j = args.warmup + args.steps + 9 + i
-                stepper.step(*[batches[(j + q) % len(batches)] for q in range(4 if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+                stepper.step(*[batches[(j + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
             barrier()
             local_ms = (time.perf_counter() - tl) / n_loc * 1e3
             if world > 1:
@@ -712,7 +719,7 @@ def main():
                           "global_batch": world * args.ims_per_gpu, "proposals": R, "parallelism": "dp%d" % world},
                "losses_last_step": loss_vals, "host_enqueue_ms_per_step": t_enq / args.steps * 1e3,
                "host_ms_per_step_unblocked": host_unblocked if use_graph else None, "hipgraph": bool(use_graph),
-               "trunk_schedule": ("pairs: one conv chain per two batches, two batches ahead" if args.trunk_pairs
+               "trunk_schedule": ("groups: one conv chain per %d batches, %d batches ahead" % (args.trunk_group, args.trunk_group) if args.trunk_pairs
                                   else "lookahead %d" % args.lookahead) if use_graph else "eager prefetch of the next batch",
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
                "grad_exchange": None if not dp.exchange else {

@@ -1045,6 +1045,12 @@ class GraphedTrainStep:
         # so two images cost what one costs and the per-image chain time halves - for trunks whose chain is as long as
         # the step (WS-R101).  step() then takes (batch, next, t+2, t+3).
         self.trunk_pairs = bool(trunk_pairs)
+        # (round 4) an int G > 2 generalises the pair to a GROUP of G batches per conv chain, launched every G-th step for
+        # batches t+G .. t+2G-1: trunks whose chain is longer than TWO steps (WS-R101: ~100 launches, 0.7 ms of every 1.5-ms
+        # step spent waiting for it) get G steps per chain.  step() then takes batches t .. t+2G-1.
+        self.G = (2 if trunk_pairs is True else int(trunk_pairs)) if trunk_pairs else 0
+        if self.trunk_pairs and self.G < 2:
+            raise DrnError("trunk_pairs: True (two batches per conv chain) or an int >= 2")
         self.model, self.opt = model, optimizer
         self.heads = model.roi_heads
         self.engine = self.heads._engine
@@ -1351,8 +1357,8 @@ class GraphedTrainStep:
         assert f.is_contiguous()
         return f
 
-    def _pair_stage(self, b_a, b_b, ps):
-        for i, x in enumerate(list(b_a) + list(b_b)):
+    def _pair_stage(self, group, ps):
+        for i, x in enumerate([x for b in group for x in b]):
             self._pimages[ps][i].copy_(x["image"], non_blocking=True)
 
     def _pair_bb_body(self, ps):
@@ -1372,7 +1378,7 @@ class GraphedTrainStep:
                                            slot=slot)
             self._check_pooled()
 
-    def _run_pairs_overlap(self, eager, next_batch, b2, b3):
+    def _run_pairs_overlap(self, eager, next_batch, *ahead):
         """_run_pairs with the pooling piece of batch t+1 BESIDE the fc6 dW tail of step t (pool_overlap; round 4): the two
         fc6 operand sets of the head engine alternate (batch t lives in set t & 1), so the pooling launch no longer has to
         wait for the dW - the last reader of its own set was step t-1's.  It is issued on a stream of its own behind the
@@ -1397,7 +1403,8 @@ class GraphedTrainStep:
                 evp.record(self._side)
         if evp is None:
             self._stage_props(next_batch)
-        k1, h1 = ((t + 1) // 2) % 2, (t + 1) % 2
+        G = self.G
+        k1, h1 = ((t + 1) // G) % 2, (t + 1) % G
         ps_ = self._pool_stream
         ps_.wait_event(ev_heads)
         if evp is not None:
@@ -1417,10 +1424,10 @@ class GraphedTrainStep:
             eng._tail = tuple(tl)
             eng.run_fc1_tail()
         with torch.cuda.stream(self._side):
-            if t % 2 == 0:
-                ps = (t // 2 + 1) % 2
+            if t % G == 0:
+                ps = (t // G + 1) % 2
                 self._side.wait_event(self._pool_done)  # (pair slot ps was last read by the pooling of batch t-1: long done)
-                self._pair_stage(b2, b3, ps)
+                self._pair_stage(ahead[G - 2: 2 * G - 2], ps)
                 self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
                 ev = torch.cuda.Event()
                 ev.record(self._side)
@@ -1430,12 +1437,13 @@ class GraphedTrainStep:
         self._t = t + 1
         return losses
 
-    def _run_pairs(self, eager, next_batch, b2, b3):
+    def _run_pairs(self, eager, next_batch, *ahead):
         """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % 2.  Even t: the conv chain of pair t/2 + 1
         (batches t+2, t+3) starts on the side stream - its slot was last read by the pooling of batch t-1.  Every t: the
         pooling of batch t+1 reads its half of its pair's features (pair (t+1)/2, launched at step 2 ((t+1)/2) - 2)."""
         if self.pool_overlap:
-            return self._run_pairs_overlap(eager, next_batch, b2, b3)
+            return self._run_pairs_overlap(eager, next_batch, *ahead)
+        G = self.G
         main = torch.cuda.current_stream()
         t = self._t
         self._side.wait_stream(main)
@@ -1461,9 +1469,9 @@ class GraphedTrainStep:
                 self._stage_labels_ahead(next_batch, via_stage=True)  # -> _gt_stage; the pooling graph hands them on
                 evp = torch.cuda.Event()
                 evp.record(self._side)
-            if t % 2 == 0:
-                ps = (t // 2 + 1) % 2
-                self._pair_stage(b2, b3, ps)
+            if t % G == 0:
+                ps = (t // G + 1) % 2
+                self._pair_stage(ahead[G - 2: 2 * G - 2], ps)  # batches t+G .. t+2G-1 (ahead[0] is batch t+2)
                 self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
                 ev = torch.cuda.Event()
                 ev.record(self._side)
@@ -1472,7 +1480,7 @@ class GraphedTrainStep:
             main.wait_event(evp)
         else:
             self._stage_props(next_batch)
-        k1, h1 = ((t + 1) // 2) % 2, (t + 1) % 2
+        k1, h1 = ((t + 1) // G) % 2, (t + 1) % G
         main.wait_event(self._pdone[k1])
         self._pair_pool_body(k1, h1) if (eager or self.eager_pool) else self.g_ppool[k1][h1].replay()
         if self.split_tail:
@@ -1481,13 +1489,14 @@ class GraphedTrainStep:
         self._t = t + 1
         return losses
 
-    def _prime_pairs(self, b0, b1, b2, b3):
+    def _prime_pairs(self, b0, b1, *ahead):
         self.heads.train()
         main = torch.cuda.current_stream()
-        self._pimages = [[im.clone() for im in self.image] + [im.clone() for im in self.image] for _ in range(2)]
+        G = self.G
+        self._pimages = [[im.clone() for _ in range(G) for im in self.image] for _ in range(2)]
         self._pfeats, self._pdone = [None, None], [None, None]
         with torch.no_grad():
-            self._pair_stage(b0, b1, 0)
+            self._pair_stage([b0, b1] + list(ahead[: G - 2]), 0)
             self._pfeats[0] = self._pair_backbone(0).clone()
             self._pfeats[1] = torch.zeros_like(self._pfeats[0])
             self._stage_props(b0)
@@ -1498,19 +1507,19 @@ class GraphedTrainStep:
         self._stage_labels(b0)
         self.opt.zero_grad()
         self._t = 0
-        first = {k: v.detach().clone() for k, v in self._run_pairs(True, b1, b2, b3).items()}
+        first = {k: v.detach().clone() for k, v in self._run_pairs(True, b1, *ahead).items()}
         self.opt.zero_grad()
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
         self.g_pbb = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
-        self.g_ppool = [[torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()] for _ in range(2)]
+        self.g_ppool = [[torch.cuda.CUDAGraph() for _ in range(G)] for _ in range(2)]
         for ps in (0, 1):
             with torch.cuda.graph(self.g_pbb[ps], capture_error_mode="thread_local"):
                 self._pair_bb_body(ps)
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.losses = self._main_body()
         for ps in ((0, 1) if not self.eager_pool else ()):
-            for h in (0, 1):
+            for h in range(G):
                 with torch.cuda.graph(self.g_ppool[ps][h], capture_error_mode="thread_local"):
                     self._pair_pool_body(ps, h)
         self._primed = True
@@ -1581,12 +1590,12 @@ class GraphedTrainStep:
             # the captured (or eagerly issued) SGD launches read lr / weight decay from device tables: follow the schedule
             self.opt.refresh_tables()
         if self.trunk_pairs:
-            if len(upcoming) != 2:
-                raise DrnError("GraphedTrainStep(trunk_pairs=True).step needs batches t+2 and t+3")
+            if len(upcoming) != 2 * self.G - 2:
+                raise DrnError("GraphedTrainStep(trunk_pairs=%d).step needs batches t+2 .. t+%d" % (self.G, 2 * self.G - 1))
             if not self._primed:
-                return self._prime_pairs(batch, next_batch, upcoming[0], upcoming[1])
+                return self._prime_pairs(batch, next_batch, *upcoming)
             self._stage_labels_now(batch)
-            return self._run_pairs(False, next_batch, upcoming[0], upcoming[1])
+            return self._run_pairs(False, next_batch, *upcoming)
         if self.lookahead >= 2:
             if len(upcoming) != self.lookahead - 1:
                 raise DrnError("GraphedTrainStep(lookahead=%d).step needs the %d batches after next_batch"

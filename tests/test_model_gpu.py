@@ -402,7 +402,7 @@ def test_grad_accumulation_iter_size():
     assert torch.allclose(model.roi_heads.box_refinery_0.cls_score.bias.grad, 1.5 * b1, rtol=1e-4, atol=1e-7)
 
 
-@pytest.mark.parametrize("lookahead", [1, 2, 3, "pairs"])
+@pytest.mark.parametrize("lookahead", [1, 2, 3, "pairs", "group3", "group4"])
 def test_hipgraph_step_equals_eager(lookahead):
     """GraphedTrainStep (whole step captured into a hipGraph, next image's backbone forked onto a side stream) must
     reproduce the eager trainer step for step: same losses over the steps on a cycle of three different batches (with
@@ -424,7 +424,7 @@ def test_hipgraph_step_equals_eager(lookahead):
     alt2["proposal_boxes"] = base[0]["proposal_boxes"].flip(0).contiguous()
     alt2["gt_classes"] = (base[0]["gt_classes"] + 1) % ocfg.num_classes
     b2 = G.drn_inputs([alt2])
-    seq = [b0, b1, b2, b0, b1, b1, b0, b2, b1, b0]  # not periodic in 2 or 3: a wrong slot shows
+    seq = [b0, b1, b2, b0, b1, b1, b0, b2, b1, b0, b2, b2, b0, b1, b0, b2]  # not periodic in 2, 3 or 4: a wrong slot shows
     results = []
     for graphed in (False, True):
         cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, "fp32")
@@ -433,10 +433,13 @@ def test_hipgraph_step_equals_eager(lookahead):
         opt = build_optimizer(cfg, model)
         out = []
         if graphed:
-            pairs = lookahead == "pairs"  # one conv chain per two batches (t+2, t+3)
-            stepper = GraphedTrainStep(model, opt, seq[0], lookahead=1 if pairs else lookahead, trunk_pairs=pairs)
+            # one conv chain per two batches (t+2, t+3), or per group of G (round 4: batches t+G .. t+2G-1)
+            grp = {"pairs": 2, "group3": 3, "group4": 4}.get(lookahead, 0)
+            pairs = grp > 0
+            stepper = GraphedTrainStep(model, opt, seq[0], lookahead=1 if pairs else lookahead,
+                                       trunk_pairs=(True if grp == 2 else grp) if pairs else False)
             for i in range(6):
-                losses = stepper.step(*seq[i: i + (4 if pairs else max(lookahead, 2) + 1)])
+                losses = stepper.step(*seq[i: i + (2 * grp if pairs else max(lookahead, 2) + 1)])
                 out.append({k: float(v.detach()) for k, v in losses.items()})
         else:
             for i in range(6):
