@@ -1,7 +1,7 @@
 """The BENCHMARKED mode at the BENCHMARKED sizes against the oracle ("pin the benchmarked mode").
 
 What bench.py times is: set_precision("bf16") + FusedSGD.enable_pipelined() with the bf16 fc6 gradient bucket +
-GraphedTrainStep(split_tail=True, trunk_pairs=True, eager_fc6=True).  Here exactly that configuration runs 5 steps over
+GraphedTrainStep(split_tail=True, trunk_pairs=4, eager_fc6=True).  Here exactly that configuration runs 5 steps over
 3 distinct SURVEY 8(d) batches in a non-periodic order (a wrong staging slot, a stale weight shadow or a bucket bug
 shows as an O(1) error) for BASELINE configs[1] (R50-C4, R=2000), configs[2]'s shape (R50-DC5, R=4000) and configs[3]'s
 shape (R101-C4, K=80), and is compared per step with TWO oracles:
@@ -55,7 +55,7 @@ CASES = {
     "r50dc5_r4000_k20": (dict(arch="wsr50", out_feature="res5", res5_dilation=2, num_classes=20), 4000),
     "r101c4_r2000_k80": (dict(arch="wsr101", out_feature="res4", res5_dilation=1, num_classes=80), 2000),
 }
-ORDER = [0, 1, 2, 0, 1, 1, 0, 2, 1, 0]  # not periodic in 2 or 3
+ORDER = [0, 1, 2, 0, 1, 1, 0, 2, 1, 0, 2, 2]  # not periodic in 2, 3 or 4
 STEPS = 5
 SEED = 3
 SAMPLE = 4099  # stride of the fc6 weight sample
@@ -104,10 +104,10 @@ def _product_run(ocfg, batches, masks, graphed, steps=STEPS):
     out = []
     eng = model.roi_heads._engine
     if graphed:
-        stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True, trunk_pairs=True, eager_fc6=True)  # = bench.py
+        stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True, trunk_pairs=4, eager_fc6=True)  # = bench.py (round 4: groups of 4)
     for t in range(steps):
         if graphed:
-            losses = stepper.step(*seq[t: t + 4])
+            losses = stepper.step(*seq[t: t + 8])
             st = stepper.last_state
         else:
             losses = model(seq[t])
