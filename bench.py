@@ -807,7 +807,11 @@ def main():
             out["timed_region_note"] = ("the timed region is %.0f ms (%d steps): shorter than clock / power transients; the default "
                                         "run (100 steps) and profiles/ hold the sustained figure" % (dt * 1e3, args.steps))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(batches)
+            if args.workload in ("r50c4", "r50c4_fp8"):
+                out["cpu_baseline"] = cpu_baseline(batches)
+            else:  # the oracle leg is timed on the BASELINE workload only (its config is the R50-C4 / K = 20 model)
+                out["cpu_baseline"] = None
+                out["cpu_baseline_note"] = "side workload: the CPU port is timed on the r50c4 workload only (default run)"
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:

@@ -287,9 +287,14 @@ struct WsddnParams {
 constexpr int WS_ROWS = 32;   // rows per block: 63 blocks for a 2000-proposal image, four row passes per block and stage
 constexpr int WS_KP = 128;  // padded column count of the partial buffers
 
+// (K > 32 - the 80-class configs - runs 64 lanes x 2 columns per row; with 256 threads that was 4 rows per pass and 16-deep
+// serial loops over the 63 block partials: 28-30 us per stage against 10-11 us at K = 20.  Those shapes now take 1024
+// threads - 16 rows per pass, 4-deep loops; same per-row lane reductions, the block combine adds 16 phase partials
+// instead of 4: another fixed summation order for K > 32.)
 template <int LPR>
 struct WsLanes {
-  static constexpr int RPP = 256 / LPR, CPL = LPR == 64 ? 2 : 1;
+  static constexpr int NT = LPR == 64 ? 1024 : 256;
+  static constexpr int RPP = NT / LPR, CPL = LPR == 64 ? 2 : 1;
   static __device__ __forceinline__ float gmax(float v) { for (int o = LPR / 2; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, LPR)); return v; }
   static __device__ __forceinline__ float gsum(float v) { for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, LPR); return v; }
 };
@@ -339,7 +344,7 @@ __device__ __forceinline__ void ws_combine(const WsddnParams& p, int img, int nb
 }
 
 template <int LPR, int STAGE>
-__global__ __launch_bounds__(256) void wsddn_stage_kernel(WsddnParams p) {
+__global__ __launch_bounds__(WsLanes<LPR>::NT) void wsddn_stage_kernel(WsddnParams p) {
   using L = WsLanes<LPR>;
   constexpr int RPP = L::RPP, CPL = L::CPL;
   __shared__ float red[RPP][LPR * CPL];
@@ -949,7 +954,7 @@ int drn_wsddn_fwd_bwd(const float* logits, long ld, int c_cls, int c_det, int K,
   const int nb = (max_rows + WS_ROWS - 1) / WS_ROWS;
   WsddnParams p{logits, ld, c_cls, c_det, K, img_off, gt_onehot, scores, row_softmax, img_scores, loss_part, dlogits, ld_d,
                 n_img, mean_loss, loss_scale, scratch, nb};
-  dim3 grid(nb, n_img), block(256);
+  dim3 grid(nb, n_img), block(K <= 32 ? 256 : 1024);
   hipStream_t st = (hipStream_t)stream;
   if (K <= 32) {
     hipLaunchKernelGGL((wsddn_stage_kernel<32, 0>), grid, block, 0, st, p);
