@@ -287,6 +287,43 @@ struct WsddnParams {
 constexpr int WS_ROWS = 32;   // rows per block: 63 blocks for a 2000-proposal image, four row passes per block and stage
 constexpr int WS_KP = 128;  // padded column count of the partial buffers
 
+// Where a stage reads its logits: the [M][ld] matrix, or (launch A of drn_mil_oicr_losses) the predictor GEMM's split-K
+// partials - summed in split order, plus the bias, exactly what drn_bias_act_fwd writes - with the logit stored on the way,
+// so that each one is formed once, by the thread that needs it first.
+struct LogitsSrc {
+  const float* part; int splits; long split_stride, ld_part;  // [splits][M][ld_part] partial sums of H2 . Wh^T
+  const float* bias;                                          // [NH] or null
+  float* logits; long ld;                                     // [M][ld]
+  unsigned long long* seed_dev; unsigned long long seed_inc;  // the dropout counter this pass advances (or null)
+};
+// FROM_PARTS: 0 = the logits matrix, 1 = split-K partials with splits <= 8 (straight-line: all loads of all the caller's
+// logits can be in flight together), 2 = any number of splits
+template <int FROM_PARTS>
+__device__ __forceinline__ float logit_at(const LogitsSrc* s, const float* logits, long ld, int r, int c) {
+  if (FROM_PARTS == 0) return logits[(long)r * ld + c];
+  // eight partials in flight at a time (a runtime-length loop of load + add waits for every load in turn); the caller
+  // stores the logit (logit_put) once all of its loads are issued - a store in between would fence the later loads.
+  // (loads are unconditional, from clamped indices - a predicated load is a branch, and the scheduler does not gather
+  // loads across branches; what an out-of-range slot fetched is dropped by a select)
+  const float* src = s->part + (long)r * s->ld_part + c;
+  const float b = s->bias ? s->bias[c] : 0.f;
+  float v = 0.f;
+  const int nq = FROM_PARTS == 1 ? 1 : s->splits;
+  for (int q0 = 0; q0 < nq; q0 += 8) {
+    float t[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t[q] = src[(long)min(q0 + q, s->splits - 1) * s->split_stride];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v = q0 + q < s->splits ? v + t[q] : v;
+  }
+  if (s->bias) v += b;
+  return v;
+}
+template <int FROM_PARTS>
+__device__ __forceinline__ void logit_put(const LogitsSrc* s, int r, int c, float v) {
+  if (FROM_PARTS) s->logits[(long)r * s->ld + c] = v;
+}
+
 // (K > 32 - the 80-class configs - runs 64 lanes x 2 columns per row; with 256 threads that was 4 rows per pass and 16-deep
 // serial loops over the 63 block partials: 28-30 us per stage against 10-11 us at K = 20.  Those shapes now take 1024
 // threads - 16 rows per pass, 4-deep loops; same per-row lane reductions, the block combine adds 16 phase partials
@@ -326,27 +363,48 @@ __device__ __forceinline__ void ws_combine(const WsddnParams& p, int img, int nb
                                            float (&csum)[WsLanes<LPR>::CPL]) {
   using L = WsLanes<LPR>;
   const float* part = p.part + (long)img * p.max_blocks * 3 * WS_KP;
+  // (eight partial blocks per trip with their loads issued together: same order of max / add as a plain loop over q)
 #pragma unroll
   for (int j = 0; j < L::CPL; ++j) {
     cmax[j] = -FLT_MAX;
-    if (ok[j])
-      for (int q = ph; q < nb; q += L::RPP) cmax[j] = fmaxf(cmax[j], part[(q * 3 + 0) * WS_KP + col[j]]);
+    {  // (lanes of columns >= K read column K-1: their results are never used)
+      for (int q0 = ph; q0 < nb; q0 += 8 * L::RPP) {
+        float t[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) t[k] = part[(min(q0 + k * L::RPP, nb - 1) * 3 + 0) * WS_KP + min(col[j], p.K - 1)];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cmax[j] = q0 + k * L::RPP < nb ? fmaxf(cmax[j], t[k]) : cmax[j];
+      }
+    }
   }
   ws_colreduce<LPR, true>(cmax, col, ph, red);
 #pragma unroll
   for (int j = 0; j < L::CPL; ++j) {
     csum[j] = 0.f;
-    if (ok[j])
-      for (int q = ph; q < nb; q += L::RPP)
-        csum[j] += part[(q * 3 + 1) * WS_KP + col[j]] * expf(part[(q * 3 + 0) * WS_KP + col[j]] - cmax[j]);
+    {
+      for (int q0 = ph; q0 < nb; q0 += 8 * L::RPP) {
+        float t0[8], t1[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int q = min(q0 + k * L::RPP, nb - 1);
+          t0[k] = part[(q * 3 + 0) * WS_KP + min(col[j], p.K - 1)];
+          t1[k] = part[(q * 3 + 1) * WS_KP + min(col[j], p.K - 1)];
+        }
+#pragma unroll
+        for (int k = 0; k < 8; ++k) csum[j] = q0 + k * L::RPP < nb ? csum[j] + t1[k] * expf(t0[k] - cmax[j]) : csum[j];
+      }
+    }
   }
   ws_colreduce<LPR, false>(csum, col, ph, red);
 }
 
-template <int LPR, int STAGE>
-__global__ __launch_bounds__(WsLanes<LPR>::NT) void wsddn_stage_kernel(WsddnParams p) {
+// Every stage is a handful of DEPENDENT memory round trips, not arithmetic: a thread's WS_ROWS / RPP rows are fetched
+// together, ahead of the cross-block combine, and kept in registers (stage 0 used to read its det logits twice, stages 1 / 2
+// took one round trip per row pass).  Same operations on the same values in the same order as the row-by-row form.
+template <int LPR, int STAGE, int FROM_PARTS = 0>
+__device__ __forceinline__ void wsddn_stage_body(const WsddnParams& p, const LogitsSrc* src = nullptr) {
   using L = WsLanes<LPR>;
-  constexpr int RPP = L::RPP, CPL = L::CPL;
+  constexpr int RPP = L::RPP, CPL = L::CPL, NP = WS_ROWS / RPP;
   __shared__ float red[RPP][LPR * CPL];
   const int img = blockIdx.y, blk = blockIdx.x;
   const int r0 = p.img_off[img], r1 = p.img_off[img + 1];
@@ -361,36 +419,72 @@ __global__ __launch_bounds__(WsLanes<LPR>::NT) void wsddn_stage_kernel(WsddnPara
   for (int j = 0; j < CPL; ++j) { col[j] = l + j * LPR; ok[j] = col[j] < K; }
   float* part = p.part + ((long)img * p.max_blocks + blk) * 3 * WS_KP;
   if (STAGE == 0) {
-    float bmax[CPL], bsum[CPL];
+    float bmax[CPL], bsum[CPL], xc[NP][CPL], xd[NP][CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) { bmax[j] = -FLT_MAX; bsum[j] = 0.f; }
-    for (int r = rb0 + ph; r < rb1; r += RPP) {
-      const float* row = p.logits + (long)r * p.ld;
-      float x[CPL], e[CPL], mx = -FLT_MAX;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int r = rb0 + ph + i * RPP, rc = min(r, rb1 - 1);  // clamped: unconditional loads, dropped by the selects
 #pragma unroll
       for (int j = 0; j < CPL; ++j) {
-        x[j] = ok[j] ? row[p.c_cls + col[j]] : -FLT_MAX;
-        if (ok[j]) bmax[j] = fmaxf(bmax[j], row[p.c_det + col[j]]);
-        mx = fmaxf(mx, x[j]);
+        const bool v = ok[j] && r < rb1;
+        const int cc = min(col[j], K - 1);
+        const float a = logit_at<FROM_PARTS>(src, p.logits, p.ld, rc, p.c_cls + cc);
+        const float d = logit_at<FROM_PARTS>(src, p.logits, p.ld, rc, p.c_det + cc);
+        xc[i][j] = v ? a : -FLT_MAX;
+        xd[i][j] = v ? d : -FLT_MAX;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int r = rb0 + ph + i * RPP;
+      if (r >= rb1) continue;
+      float e[CPL], mx = -FLT_MAX;
+#pragma unroll
+      for (int j = 0; j < CPL; ++j) {
+        if (ok[j]) {
+          logit_put<FROM_PARTS>(src, r, p.c_cls + col[j], xc[i][j]);
+          logit_put<FROM_PARTS>(src, r, p.c_det + col[j], xd[i][j]);
+          bmax[j] = fmaxf(bmax[j], xd[i][j]);
+        }
+        mx = fmaxf(mx, xc[i][j]);
       }
       mx = L::gmax(mx);
       float se = 0.f;
 #pragma unroll
-      for (int j = 0; j < CPL; ++j) { e[j] = ok[j] ? expf(x[j] - mx) : 0.f; se += e[j]; }
+      for (int j = 0; j < CPL; ++j) { e[j] = ok[j] ? expf(xc[i][j] - mx) : 0.f; se += e[j]; }
       se = L::gsum(se);
 #pragma unroll
       for (int j = 0; j < CPL; ++j) if (ok[j]) p.rowsm[(long)r * K + col[j]] = e[j] / se;
     }
     ws_colreduce<LPR, true>(bmax, col, ph, red);
-    for (int r = rb0 + ph; r < rb1; r += RPP)
 #pragma unroll
-      for (int j = 0; j < CPL; ++j)
-        if (ok[j]) bsum[j] += expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - bmax[j]);
+    for (int i = 0; i < NP; ++i)
+      if (rb0 + ph + i * RPP < rb1)
+#pragma unroll
+        for (int j = 0; j < CPL; ++j)
+          if (ok[j]) bsum[j] += expf(xd[i][j] - bmax[j]);
     ws_colreduce<LPR, false>(bsum, col, ph, red);
     if (ph == 0)
 #pragma unroll
       for (int j = 0; j < CPL; ++j) if (ok[j]) { part[0 * WS_KP + col[j]] = bmax[j]; part[1 * WS_KP + col[j]] = bsum[j]; }
     return;
+  }
+  // this thread's rows, ahead of the combine: det logits and row softmax (stages 1, 2), scores (stage 2)
+  float xd[NP][CPL], rs[NP][CPL], sc[NP][CPL];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int r = rb0 + ph + i * RPP, rc = min(r, rb1 - 1);
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) {
+      const bool v = ok[j] && r < rb1;
+      const int cc = min(col[j], K - 1);
+      const float a = p.logits[(long)rc * p.ld + p.c_det + cc], b = p.rowsm[(long)rc * K + cc];
+      const float c = STAGE == 2 ? p.scores[(long)rc * K + cc] : 0.f;
+      xd[i][j] = v ? a : 0.f;
+      rs[i][j] = v ? b : 0.f;
+      sc[i][j] = v ? c : 0.f;
+    }
   }
   float cmax[CPL], csum[CPL];
   ws_combine<LPR>(p, img, nb, col, ok, ph, red, cmax, csum);
@@ -398,15 +492,19 @@ __global__ __launch_bounds__(WsLanes<LPR>::NT) void wsddn_stage_kernel(WsddnPara
     float S[CPL];
 #pragma unroll
     for (int j = 0; j < CPL; ++j) S[j] = 0.f;
-    for (int r = rb0 + ph; r < rb1; r += RPP)
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int r = rb0 + ph + i * RPP;
+      if (r >= rb1) continue;
 #pragma unroll
       for (int j = 0; j < CPL; ++j)
         if (ok[j]) {
-          const float b = expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - cmax[j]) / csum[j];
-          const float sc = p.rowsm[(long)r * K + col[j]] * b;
-          p.scores[(long)r * K + col[j]] = sc;
-          S[j] += sc;
+          const float b = expf(xd[i][j] - cmax[j]) / csum[j];
+          const float s_ = rs[i][j] * b;
+          p.scores[(long)r * K + col[j]] = s_;
+          S[j] += s_;
         }
+    }
     ws_colreduce<LPR, false>(S, col, ph, red);
     if (ph == 0)
 #pragma unroll
@@ -420,39 +518,50 @@ __global__ __launch_bounds__(WsLanes<LPR>::NT) void wsddn_stage_kernel(WsddnPara
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     S[j] = 0.f;
-    if (ok[j])
-      for (int q = ph; q < nb; q += RPP) S[j] += ipart[(q * 3 + 2) * WS_KP + col[j]];
+    for (int q0 = ph; q0 < nb; q0 += 8 * RPP) {
+      float t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = ipart[(min(q0 + k * RPP, nb - 1) * 3 + 2) * WS_KP + min(col[j], K - 1)];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) S[j] = q0 + k * RPP < nb ? S[j] + t[k] : S[j];
+    }
   }
   ws_colreduce<LPR, false>(S, col, ph, red);
 #pragma unroll
   for (int j = 0; j < CPL; ++j) {
     g[j] = 0.f;
     if (!ok[j]) continue;
-    const float sc = fminf(fmaxf(S[j], 1e-6f), 1.0f - 1e-6f);
+    const float s_ = fminf(fmaxf(S[j], 1e-6f), 1.0f - 1e-6f);
     const float y = p.gt_onehot[img * K + col[j]];
     // F.binary_cross_entropy: -(y*log(s) + (1-y)*log(1-s)), logs clamped at -100
-    lsum += -(y * fmaxf(logf(sc), -100.f) + (1.f - y) * fmaxf(logf(1.f - sc), -100.f));
-    g[j] = (S[j] >= 1e-6f && S[j] <= 1.0f - 1e-6f) ? (-(y / sc) + (1.f - y) / (1.f - sc)) * norm * p.loss_scale : 0.f;
-    if (blk == 0 && ph == 0) p.img_scores[img * K + col[j]] = sc;
+    lsum += -(y * fmaxf(logf(s_), -100.f) + (1.f - y) * fmaxf(logf(1.f - s_), -100.f));
+    g[j] = (S[j] >= 1e-6f && S[j] <= 1.0f - 1e-6f) ? (-(y / s_) + (1.f - y) / (1.f - s_)) * norm * p.loss_scale : 0.f;
+    if (blk == 0 && ph == 0) p.img_scores[img * K + col[j]] = s_;
   }
   lsum = L::gsum(lsum);
   if (blk == 0 && threadIdx.x == 0) p.loss_part[img] = lsum * norm;
   if (!p.dlogits) return;
   // d cls = g_c*s - a*dot, dot = sum_k g_k s_rk;  d det = g_c*(s - b*S_c)
-  for (int r = rb0 + ph; r < rb1; r += RPP) {
-    float sc[CPL], dot = 0.f;
 #pragma unroll
-    for (int j = 0; j < CPL; ++j) { sc[j] = ok[j] ? p.scores[(long)r * K + col[j]] : 0.f; dot += g[j] * sc[j]; }
+  for (int i = 0; i < NP; ++i) {
+    const int r = rb0 + ph + i * RPP;
+    if (r >= rb1) continue;
+    float dot = 0.f;
+#pragma unroll
+    for (int j = 0; j < CPL; ++j) dot += g[j] * sc[i][j];
     dot = L::gsum(dot);
 #pragma unroll
     for (int j = 0; j < CPL; ++j)
       if (ok[j]) {
-        const float b = expf(p.logits[(long)r * p.ld + p.c_det + col[j]] - cmax[j]) / csum[j];
-        p.dlogits[(long)r * p.ld_d + p.c_cls + col[j]] = g[j] * sc[j] - p.rowsm[(long)r * K + col[j]] * dot;
-        p.dlogits[(long)r * p.ld_d + p.c_det + col[j]] = g[j] * (sc[j] - b * S[j]);
+        const float b = expf(xd[i][j] - cmax[j]) / csum[j];
+        p.dlogits[(long)r * p.ld_d + p.c_cls + col[j]] = g[j] * sc[i][j] - rs[i][j] * dot;
+        p.dlogits[(long)r * p.ld_d + p.c_det + col[j]] = g[j] * (sc[i][j] - b * S[j]);
       }
   }
 }
+
+template <int LPR, int STAGE>
+__global__ __launch_bounds__(WsLanes<LPR>::NT) void wsddn_stage_kernel(WsddnParams p) { wsddn_stage_body<LPR, STAGE>(p); }
 
 struct TargetParams {
   const float* prev_scores; long ld_s;  // [M][ld_s], class columns 0..K-1 (bg column, if any, ignored)
@@ -472,8 +581,8 @@ constexpr int MAX_CHAIN_HEADS = 8;
 struct TargetMulti { TargetParams h[MAX_CHAIN_HEADS]; };
 
 __device__ __forceinline__ void oicr_targets_body(const TargetParams& p) {
-  __shared__ float sv[16];
-  __shared__ int si[16];
+  __shared__ float sv[128][17];
+  __shared__ int si[128][17];
   __shared__ float gbox[128][4];
   __shared__ float gw[128];
   __shared__ int gcls[128];
@@ -481,44 +590,78 @@ __device__ __forceinline__ void oicr_targets_body(const TargetParams& p) {
   const int r0 = p.img_off[img], r1 = p.img_off[img + 1];
   const int G = p.gt_count[img];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int g = 0; g < G; ++g) {
-    const int cls = p.gt_classes[img * p.gmax + g];
-    float best = -FLT_MAX; int bi = 0x7fffffff;
-    for (int r = r0 + threadIdx.x; r < r1; r += 1024) {
-      const float v = p.prev_scores[(long)r * p.ld_s + cls];
-      if (v > best) { best = v; bi = r; }  // ascending r per thread => first index kept on ties
+  // this thread's first two proposals (all of them for images of <= 2048 proposals): fetched now, used by the labelling
+  // pass at the end - they depend on nothing that is computed here
+  float pb[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const long rc = max(min(r0 + (int)threadIdx.x + 1024 * i, r1 - 1), 0);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) pb[i][e] = p.props[4 * rc + e];
+  }
+  // Mining: argmax over the image's rows of the previous scores in each ground-truth class column (first index on
+  // ties).  Four classes per trip with their loads in flight together, the 16 wave results of every class parked in LDS,
+  // then ONE thread per class finishes its class (the serial form - a class after the other, thread 0 fetching the box of
+  // each - was ~3 dependent memory round trips per class).
+  for (int g0 = 0; g0 < G; g0 += 4) {
+    int cls[4], bi[4];
+    float best[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      cls[k] = p.gt_classes[img * p.gmax + min(g0 + k, G - 1)];
+      best[k] = -FLT_MAX; bi[k] = 0x7fffffff;
+    }
+    for (int r = r0 + threadIdx.x; r < r1; r += 2048) {
+      float va[4], vb[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const float a = p.prev_scores[(long)r * p.ld_s + cls[k]];
+        const float b = p.prev_scores[(long)min(r + 1024, r1 - 1) * p.ld_s + cls[k]];
+        va[k] = g0 + k < G ? a : -FLT_MAX;
+        vb[k] = (g0 + k < G && r + 1024 < r1) ? b : -FLT_MAX;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {  // ascending r per thread => first index kept on ties
+        if (va[k] > best[k]) { best[k] = va[k]; bi[k] = r; }
+        if (r + 1024 < r1 && vb[k] > best[k]) { best[k] = vb[k]; bi[k] = r + 1024; }
+      }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-      const float ov = __shfl_xor(best, o, 64); const int oi = __shfl_xor(bi, o, 64);
-      if (ov > best || (ov == best && oi < bi)) { best = ov; bi = oi; }
-    }
-    __syncthreads();
-    if (lane == 0) { sv[w] = best; si[w] = bi; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      for (int q = 1; q < 16; ++q) if (sv[q] > best || (sv[q] == best && si[q] < bi)) { best = sv[q]; bi = si[q]; }
-      if (bi == 0x7fffffff) bi = r0;
-      const float* bx = p.prev_boxes + (long)bi * p.box_cols + (p.box_cols == 4 ? 0 : 4 * cls);
-      float bb[4] = {bx[0], bx[1], bx[2], bx[3]};
-      if (p.zero_delta_decode) {
-        // Box2BoxTransform.apply_deltas with all-zero deltas (box_regression.py:73-110), op for op: what a
-        // non-regressing refinement head hands to the next stage (equal to the proposal up to 1 ulp)
-        const float w = bb[2] - bb[0], h = bb[3] - bb[1];
-        const float cx = bb[0] + 0.5f * w, cy = bb[1] + 0.5f * h;
-        const float pcx = 0.f * w + cx, pcy = 0.f * h + cy;
-        const float pw = expf(0.f) * w, ph = expf(0.f) * h;
-        bb[0] = pcx - 0.5f * pw; bb[1] = pcy - 0.5f * ph; bb[2] = pcx + 0.5f * pw; bb[3] = pcy + 0.5f * ph;
+    for (int k = 0; k < 4; ++k) {
+      if (g0 + k >= G) break;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(best[k], o, 64); const int oi = __shfl_xor(bi[k], o, 64);
+        if (ov > best[k] || (ov == best[k] && oi < bi[k])) { best[k] = ov; bi[k] = oi; }
       }
-      for (int e = 0; e < 4; ++e) { gbox[g][e] = bb[e]; p.pgt_boxes[((long)img * p.gmax + g) * 4 + e] = bb[e]; }
-      gw[g] = p.img_scores[img * p.K + cls];
-      gcls[g] = cls;
-      p.pgt_idx[img * p.gmax + g] = bi - r0;
+      if (lane == 0) { sv[g0 + k][w] = best[k]; si[g0 + k][w] = bi[k]; }
+      if (threadIdx.x == 0) gcls[g0 + k] = cls[k];
     }
   }
   __syncthreads();
-  for (int r = r0 + threadIdx.x; r < r1; r += 1024) {
-    const float x1 = p.props[4 * (long)r], y1 = p.props[4 * (long)r + 1], x2 = p.props[4 * (long)r + 2], y2 = p.props[4 * (long)r + 3];
+  if ((int)threadIdx.x < G) {
+    const int g = threadIdx.x;
+    const int cls = gcls[g];
+    float best = sv[g][0]; int bi = si[g][0];
+    for (int q = 1; q < 16; ++q) if (sv[g][q] > best || (sv[g][q] == best && si[g][q] < bi)) { best = sv[g][q]; bi = si[g][q]; }
+    if (bi == 0x7fffffff) bi = r0;
+    const float* bx = p.prev_boxes + (long)bi * p.box_cols + (p.box_cols == 4 ? 0 : 4 * cls);
+    float bb[4] = {bx[0], bx[1], bx[2], bx[3]};
+    if (p.zero_delta_decode) {
+      // Box2BoxTransform.apply_deltas with all-zero deltas (box_regression.py:73-110), op for op: what a
+      // non-regressing refinement head hands to the next stage (equal to the proposal up to 1 ulp)
+      const float w = bb[2] - bb[0], h = bb[3] - bb[1];
+      const float cx = bb[0] + 0.5f * w, cy = bb[1] + 0.5f * h;
+      const float pcx = 0.f * w + cx, pcy = 0.f * h + cy;
+      const float pw = expf(0.f) * w, ph = expf(0.f) * h;
+      bb[0] = pcx - 0.5f * pw; bb[1] = pcy - 0.5f * ph; bb[2] = pcx + 0.5f * pw; bb[3] = pcy + 0.5f * ph;
+    }
+    for (int e = 0; e < 4; ++e) { gbox[g][e] = bb[e]; p.pgt_boxes[((long)img * p.gmax + g) * 4 + e] = bb[e]; }
+    gw[g] = p.img_scores[img * p.K + cls];
+    p.pgt_idx[img * p.gmax + g] = bi - r0;
+  }
+  __syncthreads();
+  auto label_row = [&](int r, float x1, float y1, float x2, float y2) {
     const float a2 = (x2 - x1) * (y2 - y1);
     float best = -1.f; int bg = 0;
     for (int g = 0; g < G; ++g) {
@@ -545,7 +688,14 @@ __device__ __forceinline__ void oicr_targets_body(const TargetParams& p) {
     p.matched[r] = bg;
     p.weights[r] = (G > 0 && cls != -1) ? gw[bg] : 0.f;
     for (int e = 0; e < 4; ++e) p.gt_boxes[4 * (long)r + e] = G > 0 ? gbox[bg][e] : 0.f;
+  };
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = r0 + threadIdx.x + 1024 * i;
+    if (r < r1) label_row(r, pb[i][0], pb[i][1], pb[i][2], pb[i][3]);
   }
+  for (int r = r0 + threadIdx.x + 2048; r < r1; r += 1024)
+    label_row(r, p.props[4 * (long)r], p.props[4 * (long)r + 1], p.props[4 * (long)r + 2], p.props[4 * (long)r + 3]);
 }
 
 __global__ __launch_bounds__(1024) void oicr_targets_kernel(TargetParams p) { oicr_targets_body(p); }
@@ -569,26 +719,57 @@ constexpr int CE_ROWS = 16;
 
 struct CeMulti { CeParams h[MAX_CHAIN_HEADS]; float* partial[MAX_CHAIN_HEADS]; };
 
-__device__ __forceinline__ void ce_rows_body(const CeParams& p, float* partial) {
+template <int FROM_PARTS = 0>
+__device__ __forceinline__ void ce_rows_body(const CeParams& p, float* partial, const LogitsSrc* src = nullptr) {
   __shared__ float sl[4], sv[4];
+  constexpr int NP = CE_ROWS / 4;
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   float lsum = 0.f, vsum = 0.f;
-  for (int i = w; i < CE_ROWS; i += 4) {
-    const int r = blockIdx.x * CE_ROWS + i;
+  // the wave's four rows are fetched together (one memory round trip instead of four), then the label's logit
+  float x0[NP], x1[NP], wt[NP], xl[NP];
+  int lab[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int r = blockIdx.x * CE_ROWS + w + 4 * k;
+    const bool v = r < p.M;
+    const int rc = min(r, p.M - 1);  // clamped: unconditional loads, dropped by the selects
+    const float a = logit_at<FROM_PARTS>(src, p.logits, p.ld, rc, p.col0 + min(lane, p.C - 1));
+    x0[k] = v && lane < p.C ? a : -FLT_MAX;
+    x1[k] = -FLT_MAX;
+    if (p.C > 64) {  // uniform
+      const float b = logit_at<FROM_PARTS>(src, p.logits, p.ld, rc, p.col0 + min(lane + 64, p.C - 1));
+      x1[k] = v && lane + 64 < p.C ? b : -FLT_MAX;
+    }
+    lab[k] = -1; wt[k] = 0.f;
+    if (p.labels) {  // uniform
+      const int lb = p.labels[rc];
+      const float wb = p.weights[rc];
+      lab[k] = v ? lb : -1; wt[k] = v ? wb : 0.f;
+    }
+  }
+  if (p.labels) {
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int rc = min(blockIdx.x * CE_ROWS + w + 4 * k, p.M - 1);
+      const float a = p.logits[(long)rc * p.ld + p.col0 + max(lab[k], 0)];
+      xl[k] = lab[k] >= 0 ? a : 0.f;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int r = blockIdx.x * CE_ROWS + w + 4 * k;
     if (r >= p.M) break;
-    const float* row = p.logits + (long)r * p.ld + p.col0;
-    const float x0 = lane < p.C ? row[lane] : -FLT_MAX;
-    const float x1 = lane + 64 < p.C ? row[lane + 64] : -FLT_MAX;
-    const float mx = wave_max(fmaxf(x0, x1));
-    const float e0 = lane < p.C ? expf(x0 - mx) : 0.f, e1 = lane + 64 < p.C ? expf(x1 - mx) : 0.f;
+    if (lane < p.C) logit_put<FROM_PARTS>(src, r, p.col0 + lane, x0[k]);
+    if (lane + 64 < p.C) logit_put<FROM_PARTS>(src, r, p.col0 + lane + 64, x1[k]);
+    const float mx = wave_max(fmaxf(x0[k], x1[k]));
+    const float e0 = lane < p.C ? expf(x0[k] - mx) : 0.f, e1 = lane + 64 < p.C ? expf(x1[k] - mx) : 0.f;
     const float se = wave_sum(e0 + e1);
     if (lane < p.C) p.probs[(long)r * p.C + lane] = e0 / se;
     if (lane + 64 < p.C) p.probs[(long)r * p.C + lane + 64] = e1 / se;
     if (p.labels && lane == 0) {
-      const int lab = p.labels[r];
-      const float wt = lab == -1 ? 0.f : p.weights[r];
-      if (lab >= 0) lsum += (logf(se) - (row[lab] - mx)) * wt;
-      vsum += wt > 1e-12f ? 1.f : 0.f;
+      const float wk = lab[k] == -1 ? 0.f : wt[k];
+      if (lab[k] >= 0) lsum += (logf(se) - (xl[k] - mx)) * wk;
+      vsum += wk > 1e-12f ? 1.f : 0.f;
     }
   }
   if (!p.labels) return;
@@ -599,11 +780,29 @@ __device__ __forceinline__ void ce_rows_body(const CeParams& p, float* partial) 
     partial[2 * blockIdx.x + 1] = ((sv[0] + sv[1]) + sv[2]) + sv[3];
   }
 }
-__global__ __launch_bounds__(256) void ce_rows_kernel(CeParams p, float* partial) { ce_rows_body(p, partial); }
-__global__ __launch_bounds__(256) void ce_rows_multi_kernel(CeMulti mp) { ce_rows_body(mp.h[blockIdx.y], mp.partial[blockIdx.y]); }
+__global__ __launch_bounds__(256) void ce_rows_kernel(CeParams p, float* partial) { ce_rows_body<0>(p, partial); }
+__global__ __launch_bounds__(256) void ce_rows_multi_kernel(CeMulti mp) { ce_rows_body<0>(mp.h[blockIdx.y], mp.partial[blockIdx.y]); }
 
 __device__ __forceinline__ void ce_grad_body(const CeParams& p, const float* partial, int nparts) {
   __shared__ float sh[2][256];
+  constexpr int NP = CE_ROWS / 4;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  // the rows' labels / weights / probabilities first: they do not depend on the combine below
+  int lab[NP];
+  float wt[NP], pr0[NP], pr1[NP];
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int r = blockIdx.x * CE_ROWS + w + 4 * k;
+    const bool v = r < p.M;
+    const int rc = min(r, p.M - 1);
+    lab[k] = -1; wt[k] = 0.f; pr0[k] = 0.f; pr1[k] = 0.f;
+    if (p.dlogits) {  // uniform
+      const int lb = p.labels[rc];
+      const float wb = p.weights[rc], a = p.probs[(long)rc * p.C + min(lane, p.C - 1)];
+      lab[k] = v ? lb : -1; wt[k] = v ? wb : 0.f; pr0[k] = v ? a : 0.f;
+      if (p.C > 64) pr1[k] = p.probs[(long)rc * p.C + min(lane + 64, p.C - 1)];
+    }
+  }
   float l = 0.f, v = 0.f;
   for (int q = threadIdx.x; q < nparts; q += 256) { l += partial[2 * q]; v += partial[2 * q + 1]; }
   sh[0][threadIdx.x] = l; sh[1][threadIdx.x] = v;
@@ -615,20 +814,39 @@ __device__ __forceinline__ void ce_grad_body(const CeParams& p, const float* par
   const float L = sh[0][0], V = sh[1][0];
   if (blockIdx.x == 0 && threadIdx.x == 0) p.loss[0] = L / V;
   if (!p.dlogits) return;
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  for (int i = w; i < CE_ROWS; i += 4) {
-    const int r = blockIdx.x * CE_ROWS + i;
+#pragma unroll
+  for (int k = 0; k < NP; ++k) {
+    const int r = blockIdx.x * CE_ROWS + w + 4 * k;
     if (r >= p.M) break;
-    const int lab = p.labels[r];
-    const float wt = lab < 0 ? 0.f : p.weights[r];
-    const float f = wt / V * p.loss_scale;
-    for (int c = lane; c < p.C; c += 64)
-      p.dlogits[(long)r * p.ld_d + p.col0 + c] = f * (p.probs[(long)r * p.C + c] - (c == lab ? 1.f : 0.f));
+    const float f = (lab[k] < 0 ? 0.f : wt[k]) / V * p.loss_scale;
+    float* d = p.dlogits + (long)r * p.ld_d + p.col0;
+    if (lane < p.C) d[lane] = f * (pr0[k] - (lane == lab[k] ? 1.f : 0.f));
+    if (lane + 64 < p.C) d[lane + 64] = f * (pr1[k] - (lane + 64 == lab[k] ? 1.f : 0.f));
   }
 }
 __global__ __launch_bounds__(256) void ce_grad_kernel(CeParams p, const float* partial, int nparts) { ce_grad_body(p, partial, nparts); }
 __global__ __launch_bounds__(256) void ce_grad_multi_kernel(CeMulti mp, int nparts) {
   ce_grad_body(mp.h[blockIdx.y], mp.partial[blockIdx.y], nparts);
+}
+
+// ---------------------------------------------------------------- the loss tail in six launches (drn_mil_oicr_losses)
+// Launch A = WSDDN stage 0 and the softmax of every refinement head reading their logits from the predictor GEMM's split-K
+// partials (LogitsSrc): the separate reduce + bias launch and the separate softmax launch are gone, each logit is formed
+// and stored exactly once by the thread that needs it first.
+template <int LPR>
+__global__ __launch_bounds__(WsLanes<LPR>::NT) void mil_stage0_kernel(WsddnParams p, CeMulti cm, LogitsSrc src, int nb_ws,
+                                                                       int nb_ce) {
+  const int y = blockIdx.y;
+  if (y == 0 && blockIdx.x == 0 && threadIdx.x == 0 && src.seed_dev) *src.seed_dev += src.seed_inc;
+  if (y < p.n_img) {
+    if ((int)blockIdx.x >= nb_ws) return;
+    if (src.splits <= 8) wsddn_stage_body<LPR, 0, 1>(p, &src);
+    else wsddn_stage_body<LPR, 0, 2>(p, &src);
+    return;
+  }
+  if ((int)blockIdx.x >= nb_ce || threadIdx.x >= 256) return;  // the softmax body is written for four waves
+  if (src.splits <= 8) ce_rows_body<1>(cm.h[y - p.n_img], nullptr, &src);
+  else ce_rows_body<2>(cm.h[y - p.n_img], nullptr, &src);
 }
 
 // OICROutputs.box_reg_loss (fast_rcnn.py:1146-1211): foreground rows only, class-specific columns 4c..4c+3,
@@ -997,21 +1215,13 @@ int drn_oicr_targets(const float* prev_scores, long ld_s, const float* prev_boxe
 // All n_heads refinement branches in four launches (softmax of every head, pseudo-GT mining + labelling of every head,
 // CE partials, CE combine + gradient) instead of three per head.  Per-head outputs are [n_heads] x the single-head
 // shape, contiguous.  Non-regressing heads only (pgt boxes = decoded zero deltas of the proposals for heads >= 1).
-int drn_oicr_refine_chain(const float* logits, long ld, const int* col0s_host, int n_heads, int K, const float* scores0,
-                          long ld_s0, const float* props, const int* img_off, int n_img, const int* gt_classes,
-                          const int* gt_count, int gmax, const float* img_scores, const float* thresholds,
-                          const int* thr_labels, int nthr, float* probs, int* labels, float* weights, int* matched,
-                          float* gt_boxes, int* pgt_idx, float* pgt_boxes, float* dlogits, long ld_d, float* losses,
-                          float* scratch, int M, float loss_scale, void* stream) {
-  if (!logits || !col0s_host || !scores0 || !props || !img_off || !gt_classes || !gt_count || !img_scores || !probs ||
-      !labels || !weights || !matched || !gt_boxes || !pgt_idx || !pgt_boxes || !losses || !scratch)
-    return DRN_ERR_ARG;
-  if (n_heads < 1 || n_heads > MAX_CHAIN_HEADS || K < 1 || K + 1 > 128 || gmax < 1 || gmax > 128 || nthr < 1 || nthr > 3)
-    return DRN_ERR_ARG;
-  if (M <= 0 || n_img < 1) return M == 0 ? DRN_OK : DRN_ERR_ARG;
+static void chain_params(const float* logits, long ld, const int* col0s_host, int n_heads, int K, const float* scores0,
+                         long ld_s0, const float* props, const int* img_off, int n_img, const int* gt_classes,
+                         const int* gt_count, int gmax, const float* img_scores, const float* thresholds,
+                         const int* thr_labels, int nthr, float* probs, int* labels, float* weights, int* matched,
+                         float* gt_boxes, int* pgt_idx, float* pgt_boxes, float* dlogits, long ld_d, float* losses,
+                         float* scratch, int M, float loss_scale, TargetMulti& tm, CeMulti& probs_only, CeMulti& ce) {
   const int C = K + 1, nb = (M + CE_ROWS - 1) / CE_ROWS;
-  TargetMulti tm;
-  CeMulti probs_only, ce;
   for (int k = 0; k < n_heads; ++k) {
     float* pk = probs + (long)k * M * C;
     TargetParams& t = tm.h[k];
@@ -1030,11 +1240,85 @@ int drn_oicr_refine_chain(const float* logits, long ld, const int* col0s_host, i
     ce.h[k] = CeParams{logits, ld, col0s_host[k], C, t.labels, t.weights, pk, dlogits, ld_d, losses + k, M, loss_scale};
     ce.partial[k] = scratch + (long)k * 2 * nb;
   }
+}
+
+int drn_oicr_refine_chain(const float* logits, long ld, const int* col0s_host, int n_heads, int K, const float* scores0,
+                          long ld_s0, const float* props, const int* img_off, int n_img, const int* gt_classes,
+                          const int* gt_count, int gmax, const float* img_scores, const float* thresholds,
+                          const int* thr_labels, int nthr, float* probs, int* labels, float* weights, int* matched,
+                          float* gt_boxes, int* pgt_idx, float* pgt_boxes, float* dlogits, long ld_d, float* losses,
+                          float* scratch, int M, float loss_scale, void* stream) {
+  if (!logits || !col0s_host || !scores0 || !props || !img_off || !gt_classes || !gt_count || !img_scores || !probs ||
+      !labels || !weights || !matched || !gt_boxes || !pgt_idx || !pgt_boxes || !losses || !scratch)
+    return DRN_ERR_ARG;
+  if (n_heads < 1 || n_heads > MAX_CHAIN_HEADS || K < 1 || K + 1 > 128 || gmax < 1 || gmax > 128 || nthr < 1 || nthr > 3)
+    return DRN_ERR_ARG;
+  if (M <= 0 || n_img < 1) return M == 0 ? DRN_OK : DRN_ERR_ARG;
+  const int nb = (M + CE_ROWS - 1) / CE_ROWS;
+  TargetMulti tm;
+  CeMulti probs_only, ce;
+  chain_params(logits, ld, col0s_host, n_heads, K, scores0, ld_s0, props, img_off, n_img, gt_classes, gt_count, gmax,
+               img_scores, thresholds, thr_labels, nthr, probs, labels, weights, matched, gt_boxes, pgt_idx, pgt_boxes, dlogits,
+               ld_d, losses, scratch, M, loss_scale, tm, probs_only, ce);
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ce_rows_multi_kernel, dim3(nb, n_heads), dim3(256), 0, st, probs_only);
   hipLaunchKernelGGL(oicr_targets_multi_kernel, dim3(n_img, n_heads), dim3(1024), 0, st, tm);
   hipLaunchKernelGGL(ce_rows_multi_kernel, dim3(nb, n_heads), dim3(256), 0, st, ce);
   hipLaunchKernelGGL(ce_grad_multi_kernel, dim3(nb, n_heads), dim3(256), 0, st, ce, nb);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// The loss tail of a training step with non-regressing refinement heads in SIX launches instead of nine: the predictor's
+// split-K reduce + bias (drn_bias_act_fwd, fp32 out), drn_wsddn_fwd_bwd and drn_oicr_refine_chain, bit for bit.
+//   A  WSDDN stage 0 + the softmax of every refinement head, both reading the logits from the split-K partials
+//   B  WSDDN stage 1        C  WSDDN stage 2 (image scores, BCE, d cls / d det)
+//   D  pseudo-GT mining + labels of every head        E, F  CE partials; fixed-order combine + gradient
+// (E + F as ONE launch - every block counting V itself, the loss formed by the last-arriving block - was built and measured:
+// 21.6 us against 7.8 + 7.4; these kernels are a few dependent memory round trips each, not launch overhead, and the
+// last-arriver tail adds one more.  Likewise A as "materialise, barrier, run the stage": 22 us against 21 for the three
+// launches it replaced - profiles/r4_37.)
+// ws_scratch as drn_wsddn_fwd_bwd; ce_scratch as drn_oicr_refine_chain.  logits [M][ld] is an OUTPUT here: columns
+// c_cls..+K, c_det..+K and col0s[k]..+K+1 are written (all NH columns when the heads are exactly these).
+int drn_mil_oicr_losses(const float* partials, int splits, long split_stride, long ld_part, const float* bias,
+                        unsigned long long seed_inc, unsigned long long* seed_dev, float* logits, long ld, int c_cls,
+                        int c_det, int K, const int* img_off, int n_img, const float* gt_onehot, float* scores,
+                        float* row_softmax, float* img_scores, float* loss_part, float* ws_scratch, int max_rows,
+                        int mean_loss, const int* col0s_host, int n_heads, const float* props, const int* gt_classes,
+                        const int* gt_count, int gmax, const float* thresholds, const int* thr_labels, int nthr, float* probs,
+                        int* labels, float* weights, int* matched, float* gt_boxes, int* pgt_idx, float* pgt_boxes,
+                        float* losses, float* ce_scratch, float* dlogits, long ld_d, int M, float loss_scale,
+                        void* stream) {
+  if (!partials || !logits || !img_off || !gt_onehot || !scores || !row_softmax || !img_scores || !loss_part ||
+      !ws_scratch || !col0s_host || !props || !gt_classes || !gt_count || !probs || !labels || !weights || !matched ||
+      !gt_boxes || !pgt_idx || !pgt_boxes || !losses || !ce_scratch)
+    return DRN_ERR_ARG;
+  if (splits < 1 || K < 1 || K + 1 > 128 || n_img < 1 || max_rows < 1 || n_heads < 1 || n_heads > MAX_CHAIN_HEADS ||
+      gmax < 1 || gmax > 128 || nthr < 1 || nthr > 3 || M <= 0)
+    return DRN_ERR_ARG;
+  const int nb_ws = (max_rows + WS_ROWS - 1) / WS_ROWS, nb_ce = (M + CE_ROWS - 1) / CE_ROWS;
+  WsddnParams p{logits, ld, c_cls, c_det, K, img_off, gt_onehot, scores, row_softmax, img_scores, loss_part, dlogits, ld_d,
+                n_img, mean_loss, loss_scale, ws_scratch, nb_ws};
+  TargetMulti tm;
+  CeMulti probs_only, ce;
+  chain_params(logits, ld, col0s_host, n_heads, K, scores, K, props, img_off, n_img, gt_classes, gt_count, gmax, img_scores,
+               thresholds, thr_labels, nthr, probs, labels, weights, matched, gt_boxes, pgt_idx, pgt_boxes, dlogits, ld_d,
+               losses, ce_scratch, M, loss_scale, tm, probs_only, ce);
+  LogitsSrc src{partials, splits, split_stride, ld_part, bias, logits, ld, seed_dev, seed_inc};
+  hipStream_t st = (hipStream_t)stream;
+  dim3 gA(nb_ws > nb_ce ? nb_ws : nb_ce, n_img + n_heads), gW(nb_ws, n_img), bW(K <= 32 ? 256 : 1024);
+  if (K <= 32) {
+    hipLaunchKernelGGL((mil_stage0_kernel<32>), gA, bW, 0, st, p, probs_only, src, nb_ws, nb_ce);
+    hipLaunchKernelGGL((wsddn_stage_kernel<32, 1>), gW, bW, 0, st, p);
+    hipLaunchKernelGGL((wsddn_stage_kernel<32, 2>), gW, bW, 0, st, p);
+  } else {
+    hipLaunchKernelGGL((mil_stage0_kernel<64>), gA, bW, 0, st, p, probs_only, src, nb_ws, nb_ce);
+    hipLaunchKernelGGL((wsddn_stage_kernel<64, 1>), gW, bW, 0, st, p);
+    hipLaunchKernelGGL((wsddn_stage_kernel<64, 2>), gW, bW, 0, st, p);
+  }
+  hipLaunchKernelGGL(oicr_targets_multi_kernel, dim3(n_img, n_heads), dim3(1024), 0, st, tm);
+  hipLaunchKernelGGL(ce_rows_multi_kernel, dim3(nb_ce, n_heads), dim3(256), 0, st, ce);
+  hipLaunchKernelGGL(ce_grad_multi_kernel, dim3(nb_ce, n_heads), dim3(256), 0, st, ce, nb_ce);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

@@ -835,8 +835,17 @@ class _HeadEngine:
         bo, _ = self._seg[self.cols[0][0] + ".bias"]
         # (the logits pass has no dropout: given the counter it advances it - behind both dropout layers - instead of a
         # counter_add launch of its own on the heads' dependent chain)
-        self._linear_fwd(w["H2"], sh["Wh"], M, NH, kp(D2), self.arena_w[bo: bo + NH], False, w["logits"], None, None,
-                         2654435761 if seed_dev is not None else 0, 0.0, seed_dev)
+        logit_seed = 2654435761 if seed_dev is not None else 0
+        # drn_mil_oicr_losses: the predictor's split-K reduce + bias, WSDDN and the refinement cascade in six launches
+        # (nine as separate calls); taken when the heads are exactly cls / det / non-regressing OICR branches
+        fuse_tail = (training and not csc and getattr(self, "fused_loss_tail", True) and h.refine_K > 0 and
+                     getattr(h, "refine_mode", "oicr") != "pcl" and not any(h.refine_reg[: h.refine_K]) and
+                     NH == 2 * K + h.refine_K * (K + 1))
+        if fuse_tail:
+            logit_part = ops.gemm_nt(w["H2"], sh["Wh"], M, NH, kp(D2), splits=self._splits(M, NH, kp(D2), dtype))
+        else:
+            self._linear_fwd(w["H2"], sh["Wh"], M, NH, kp(D2), self.arena_w[bo: bo + NH], False, w["logits"], None, None,
+                             logit_seed, 0.0, seed_dev)
         col = {n: c for n, _, c, _ in self.cols}
         if not training:
             return w, col
@@ -845,9 +854,18 @@ class _HeadEngine:
                                      drop_p, fg_hook)
         # ---- losses (fused with their dlogits) ----
         dl = w["dlogits"]
-        scores, img_scores, loss_part = ops.wsddn_fwd_bwd(w["logits"], col["cls"], col["det"], K, img_off, n_img,
-                                                         gt["onehot"], dlogits=dl, mean_loss=h.box_predictor.mean_loss,
-                                                         max_rows=gt["max_rows"])
+        thr = h.proposal_matcher.thresholds[1:-1]
+        chain = None
+        if fuse_tail:
+            scores, img_scores, loss_part, chain = ops.mil_oicr_losses(
+                logit_part, self.arena_w[bo: bo + NH], w["logits"], col["cls"], col["det"], K, img_off, n_img, gt["onehot"],
+                [col["r%d" % k] for k in range(h.refine_K)], gt["props"], gt["classes"], gt["count"], thr,
+                h.proposal_matcher.labels, dlogits=dl, mean_loss=h.box_predictor.mean_loss, max_rows=gt["max_rows"],
+                seed_inc=logit_seed, seed_dev=seed_dev)
+        else:
+            scores, img_scores, loss_part = ops.wsddn_fwd_bwd(w["logits"], col["cls"], col["det"], K, img_off, n_img,
+                                                             gt["onehot"], dlogits=dl, mean_loss=h.box_predictor.mean_loss,
+                                                             max_rows=gt["max_rows"])
         for m in [h.box_predictor] + list(h.box_refinery[: h.refine_K]):
             assert m.loss_weight.get("loss_cls", 1.0) == 1.0, "loss_cls weight != 1 is not used by any config"
         loss_names = ["loss_cls"]
@@ -855,8 +873,6 @@ class _HeadEngine:
         head_cols = [("cls", 0), ("det", 0)]
         prev_scores, prev_boxes, prev_zero = scores, gt["props"], False
         aux = dict(scores=scores, img_scores=img_scores, targets=[])
-        thr = h.proposal_matcher.thresholds[1:-1]
-        chain = None
         pcl = getattr(h, "refine_mode", "oicr") == "pcl"
         if pcl and h.refine_K > 0:
             # PCLROIHeads (roi_heads_pcl.py:311-334): every branch's targets come from the previous branch's
@@ -873,7 +889,7 @@ class _HeadEngine:
                 loss_list.append(res[k]["loss"].view(()))
                 head_cols.append(("r%d" % k, len(loss_list) - 1))
                 aux["targets"].append(res[k])
-        elif h.refine_K > 0 and not any(h.refine_reg[: h.refine_K]):
+        elif chain is None and h.refine_K > 0 and not any(h.refine_reg[: h.refine_K]):
             # no branch regresses boxes: every branch's targets depend only on the previous branch's softmax of logits
             # that already exist, so the whole cascade is four launches (drn_oicr_refine_chain)
             chain = ops.oicr_refine_chain(w["logits"], [col["r%d" % k] for k in range(h.refine_K)], K, scores,

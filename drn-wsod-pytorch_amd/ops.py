@@ -441,6 +441,41 @@ def oicr_refine_chain(logits, col0s, K, scores0, props, img_off, n_img, gt_class
     return [({k: v[i] for k, v in out.items()}, probs[i], losses[i: i + 1]) for i in range(nh)]
 
 
+def mil_oicr_losses(partials, bias, logits, c_cls, c_det, K, img_off, n_img, gt_onehot, col0s, props, gt_classes,
+                    gt_count, thresholds=(0.5,), labels=(0, 1), dlogits=None, mean_loss=True, loss_scale=1.0,
+                    max_rows=None, seed_inc=0, seed_dev=None):
+    """drn_mil_oicr_losses: predictor split-K reduce + bias -> `logits` (written), WSDDN forward/backward and the whole
+    non-regressing refinement cascade in six launches.  Returns (scores, img_scores, loss_part, chain) with `chain` as
+    oicr_refine_chain returns it."""
+    M, dev, nh = props.shape[0], props.device, len(col0s)
+    max_rows = max_rows or M
+    gmax = gt_classes.shape[1]
+    nb = (M + 15) // 16
+    e = lambda shape, dt: torch.empty(shape, dtype=dt, device=dev)
+    scores, rowsm = e((M, K), torch.float32), e((M, K), torch.float32)
+    img_scores, loss_part = e((n_img, K), torch.float32), e((n_img,), torch.float32)
+    ws_scratch = e((n_img * ((max_rows + 31) // 32) * 384,), torch.float32)
+    probs = e((nh, M, K + 1), torch.float32)
+    out = dict(labels=e((nh, M), torch.int32), weights=e((nh, M), torch.float32), matched=e((nh, M), torch.int32),
+               gt_boxes=e((nh, M, 4), torch.float32), pgt_idx=e((nh, n_img, gmax), torch.int32),
+               pgt_boxes=e((nh, n_img, gmax, 4), torch.float32))
+    losses = e((nh,), torch.float32)
+    ce_scratch = e((nh * 2 * nb,), torch.float32)
+    th, lb, c0 = C.host_floats(thresholds), C.host_ints(labels), C.host_ints(col0s)
+    vp = lambda a: ctypes.cast(a, ctypes.c_void_p)
+    splits = partials.shape[0] if partials.dim() == 3 else 1
+    sstride = partials.stride(0) if partials.dim() == 3 else 0
+    C.call("drn_mil_oicr_losses", C.ptr(partials), splits, sstride, partials.stride(-2), C.ptr(bias), int(seed_inc),
+           C.ptr(seed_dev), C.ptr(logits), _2d(logits), c_cls, c_det, K, C.ptr(img_off), n_img, C.ptr(gt_onehot),
+           C.ptr(scores), C.ptr(rowsm), C.ptr(img_scores), C.ptr(loss_part), C.ptr(ws_scratch), int(max_rows),
+           int(mean_loss), vp(c0), nh, C.ptr(props), C.ptr(gt_classes), C.ptr(gt_count), gmax, vp(th), vp(lb),
+           len(thresholds), C.ptr(probs), C.ptr(out["labels"]), C.ptr(out["weights"]), C.ptr(out["matched"]),
+           C.ptr(out["gt_boxes"]), C.ptr(out["pgt_idx"]), C.ptr(out["pgt_boxes"]), C.ptr(losses), C.ptr(ce_scratch),
+           C.ptr(dlogits), _2d(dlogits) if dlogits is not None else 0, M, float(loss_scale), C.stream())
+    chain = [({k: v[i] for k, v in out.items()}, probs[i], losses[i: i + 1]) for i in range(nh)]
+    return scores, img_scores, loss_part, chain
+
+
 def softmax_ce(logits, col0, ncol, labels=None, weights=None, dlogits=None, loss_scale=1.0):
     M = logits.shape[0]
     probs = torch.empty((M, ncol), dtype=torch.float32, device=logits.device)

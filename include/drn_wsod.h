@@ -284,6 +284,24 @@ int drn_oicr_refine_chain(const float* logits, long ld, const int* col0s_host, i
                           float* gt_boxes, int* pgt_idx, float* pgt_boxes, float* dlogits, long ld_d, float* losses,
                           float* scratch, int M, float loss_scale, void* stream);
 
+/* The loss tail of one training step of OICRROIHeads._forward_box with non-regressing refinement branches
+ * (roi_heads_oicr.py:351-395: predictor bias -> WSDDNOutputs.losses -> the refinement cascade) in SIX launches:
+ * = drn_bias_act_fwd (fp32 logits from the predictor GEMM's split-K partials [splits][M][ld_part] + bias) +
+ * drn_wsddn_fwd_bwd + drn_oicr_refine_chain (nine), bit for bit: WSDDN stage 0 and the heads' softmax read their logits
+ * from the partials.  logits [M][ld] is an OUTPUT: columns c_cls..+K, c_det..+K and col0s_host[k]..+K+1 are written.
+ * seed_dev (optional): the device-side dropout counter this pass advances by seed_inc (what the fp32 drn_bias_act_fwd
+ * call without dropout does).  ws_scratch as drn_wsddn_fwd_bwd, ce_scratch as drn_oicr_refine_chain.  The WSDDN scores
+ * feed branch 0. */
+int drn_mil_oicr_losses(const float* partials, int splits, long split_stride, long ld_part, const float* bias,
+                        unsigned long long seed_inc, unsigned long long* seed_dev, float* logits, long ld, int c_cls,
+                        int c_det, int K, const int* img_off, int n_img, const float* gt_onehot, float* scores,
+                        float* row_softmax, float* img_scores, float* loss_part, float* ws_scratch, int max_rows,
+                        int mean_loss, const int* col0s_host, int n_heads, const float* props, const int* gt_classes,
+                        const int* gt_count, int gmax, const float* thresholds, const int* thr_labels, int nthr, float* probs,
+                        int* labels, float* weights, int* matched, float* gt_boxes, int* pgt_idx, float* pgt_boxes,
+                        float* losses, float* ce_scratch, float* dlogits, long ld_d, int M, float loss_scale,
+                        void* stream);
+
 /* OICROutputs.softmax_cross_entropy_loss (fast_rcnn.py:1087-1096,1128-1144), predict_probs (:1561-1575)
  * and the backward: loss = sum_r w_r CE_r / #{w_r > 1e-12}.  labels == NULL => probabilities only.
  * scratch: 2*ceil(M/16) floats (two-stage deterministic reduction), required with labels. */

@@ -389,6 +389,42 @@ def test_fc6_fused_tn_step_equals_unfused():
     load_package().set_precision("fp32")
 
 
+@pytest.mark.parametrize("n_img", [1, 2])
+def test_fused_loss_tail_step_equals_separate_calls(n_img):
+    """`_HeadEngine.fused_loss_tail` (default): the predictor's split-K reduce + bias, WSDDN and the refinement cascade as
+    drn_mil_oicr_losses (six launches) against the nine separate launches: three SGD steps with dropout (the counter-based
+    masks must stay in step too), every loss and the weight / momentum arenas bit for bit."""
+    from drn_wsod_pytorch_amd.engine import build_optimizer
+
+    kw = dict(arch="wsr50", out_feature="res4", res5_dilation=1, num_classes=20)
+    ocfg = O.OracleCfg(dropout=0.5, base_lr=2e-4, **kw)
+    b = O.synthetic_batch(n_img, 500, ocfg, seed=83)
+    batch = G.drn_inputs([dict(x, gt_boxes=torch.zeros(len(x["gt_classes"]), 4)) for x in b])
+    res = []
+    for fused in (False, True):
+        torch.manual_seed(11)
+        cfg, model = G.drn_model(ocfg, 3, "cuda", 5, "bf16")
+        model.train()
+        opt = build_optimizer(cfg, model)
+        eng = model.roi_heads._engine
+        eng.fused_loss_tail = fused
+        losses = []
+        for _ in range(3):
+            opt.zero_grad()
+            out = model(batch)
+            sum(out.values()).backward()
+            opt.step()
+            losses.append({k: float(v.detach()) for k, v in out.items()})
+        torch.cuda.synchronize()
+        res.append(dict(w=eng.arena_w.clone(), m=opt._mom.clone(), losses=losses, ctr=int(eng.seed_dev)))
+        del model, opt
+    assert res[0]["losses"] == res[1]["losses"], (res[0]["losses"], res[1]["losses"])
+    assert res[0]["ctr"] == res[1]["ctr"] != 0
+    for k in ("w", "m"):
+        assert torch.equal(res[0][k], res[1][k]), k
+    load_package().set_precision("fp32")
+
+
 def test_grad_accumulation_iter_size():
     """WSL.ITER_SIZE semantics (train_net.py:100-113): two backward() calls accumulate before one step."""
     ocfg, d, cfg, model = _setup("model_r50c4_tiny", "fp32")

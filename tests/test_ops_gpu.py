@@ -797,6 +797,63 @@ def test_oicr_refine_chain_equals_per_head_sequence(drn, K, M_per, nh):
     assert float(dl_a.abs().max()) > 0
 
 
+@pytest.mark.parametrize("K,M_per,nh,splits", [(20, [2000], 3, 8), (6, [90, 77], 2, 3), (80, [1500, 500], 4, 1),
+                                               (20, [37, 2000, 5], 3, 4)])
+def test_mil_oicr_losses_equals_separate_calls(drn, K, M_per, nh, splits):
+    """drn_mil_oicr_losses (six launches) == drn_bias_act_fwd (fp32 logits) + drn_wsddn_fwd_bwd + drn_oicr_refine_chain
+    (nine), bit for bit: logits, scores, image scores, losses, targets, probabilities, the gradient of the logits and
+    the dropout counter; run twice"""
+    M, n_img = sum(M_per), len(M_per)
+    rs = np.random.RandomState(91)
+    C_ = K + 1
+    NH = 2 * K + nh * C_
+    ldp = (NH + 7) // 8 * 8
+    col0s = [2 * K + k * C_ for k in range(nh)]
+    part = torch.from_numpy(rs.standard_normal((splits, M, ldp)).astype(np.float32)).to(DEV)
+    bias = torch.from_numpy(rs.standard_normal(NH).astype(np.float32)).to(DEV)
+    props = _boxes(M, 35).to(DEV)
+    gmax = 4
+    gcl = torch.zeros((n_img, gmax), dtype=torch.int32)
+    gcn = torch.zeros((n_img,), dtype=torch.int32)
+    oh = torch.zeros((n_img, K))
+    for i in range(n_img):
+        g = torch.unique(torch.from_numpy(rs.randint(0, K, 3)))
+        gcl[i, : len(g)] = g.int()
+        gcn[i] = len(g)
+        oh[i, g.long()] = 1
+    gcl, gcn, oh = gcl.to(DEV), gcn.to(DEV), oh.to(DEV)
+    off = torch.tensor([0] + list(np.cumsum(M_per)), dtype=torch.int32, device=DEV)
+    # ---- separate calls
+    lg_b = torch.zeros((M, ldp), device=DEV)
+    ctr_b = torch.full((1,), 5, dtype=torch.int64, device=DEV)
+    drn.bias_act_fwd(part, M, NH, bias, False, None, 12345, 0.0, out=lg_b, seed_dev=ctr_b)
+    dl_b = torch.zeros((M, ldp), device=DEV)
+    sc_b, is_b, lp_b = drn.wsddn_fwd_bwd(lg_b, 0, K, K, off, n_img, oh, dlogits=dl_b, max_rows=max(M_per))
+    chain_b = drn.oicr_refine_chain(lg_b, col0s, K, sc_b, props, off, n_img, gcl, gcn, is_b, dlogits=dl_b)
+    # ---- the fused tail, twice
+    for rep in range(2):
+        lg_a = torch.zeros((M, ldp), device=DEV)
+        dl_a = torch.zeros((M, ldp), device=DEV)
+        ctr_a = torch.full((1,), 5, dtype=torch.int64, device=DEV)
+        sc_a, is_a, lp_a, chain_a = drn.mil_oicr_losses(part, bias, lg_a, 0, K, K, off, n_img, oh, col0s, props, gcl, gcn,
+                                                        dlogits=dl_a, max_rows=max(M_per), seed_inc=12345, seed_dev=ctr_a)
+        assert torch.equal(lg_a[:, :NH], lg_b[:, :NH])
+        assert torch.equal(ctr_a, ctr_b) and int(ctr_a) == 5 + 12345
+        assert torch.equal(sc_a, sc_b) and torch.equal(is_a, is_b) and torch.equal(lp_a, lp_b)
+        for k in range(nh):
+            (ta, pa, la), (tb, pb, lb) = chain_a[k], chain_b[k]
+            for key in ("labels", "weights", "matched", "gt_boxes"):
+                assert torch.equal(ta[key], tb[key]), (k, key)
+            for i in range(n_img):
+                g = int(gcn[i])
+                assert torch.equal(ta["pgt_idx"][i, :g], tb["pgt_idx"][i, :g]), (k, i)
+                assert torch.equal(ta["pgt_boxes"][i, :g], tb["pgt_boxes"][i, :g]), (k, i)
+            assert torch.equal(pa, pb), k
+            assert torch.equal(la, lb), (k, float(la), float(lb))
+        assert torch.equal(dl_a, dl_b)
+    assert float(dl_a.abs().max()) > 0
+
+
 @pytest.mark.parametrize("K,M", [(20, 2000), (5, 77), (80, 4000)])
 def test_softmax_ce(drn, K, M):
     rs = np.random.RandomState(41)
