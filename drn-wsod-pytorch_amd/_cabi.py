@@ -46,6 +46,7 @@ _SIGS = {
     "drn_wsddn_fwd_bwd": "pliiipippppppl" + "pi" + "ifp",
     "drn_oicr_targets": "plpii" + "ppi" + "ppi" + "pi" + "ppi" + "pppppp" + "p",
     "drn_oicr_refine_chain": "plpiipl" + "ppipp" + "ip" + "ppi" + "ppppppp" + "plpp" + "ifp",
+    "drn_gemm_nt_act_bwd": "ppiiillppfplplppip",
     "drn_mil_oicr_losses": "pillp" + "Qp" + "pl" + "iii" + "pi" + "pppppp" + "ii" + "pi" + "ppp" + "i" + "pp" + "i" + "ppppppp"
                            + "pp" + "pl" + "ifp",
     "drn_softmax_ce": "pliipppplppifp",

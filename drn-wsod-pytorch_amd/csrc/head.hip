@@ -44,6 +44,9 @@ struct ActParams {
   int M, N; long ld_in; int relu; int accumulate_colsum;
   int rows_fwd;  // fwd: rows per block (64, or 4 for skinny outputs without a transposed copy)
   int in_bf16;   // bwd: grad_out holds bf16 (gradients flowing through the conv trunk in the bf16 mode)
+  // act_vec_kernel<true, KC > 0> (drn_gemm_nt_act_bwd): grad_out is not read but FORMED here, gA [M][lda] . gB [N][ldb]^T
+  // over K = 64 KC (bf16, K-major rows)
+  const bf16_t* gA; const bf16_t* gB; long lda, ldb;
 };
 
 // 64 columns x ROWS_PER_BLOCK rows per block (64x64 tiles through LDS for the transposed copy).
@@ -130,15 +133,76 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
 // 16-B loads of the fp32 input (per split), 8-B bf16 stores, the transposed copy leaves LDS in 16-B stores.  Same
 // arithmetic per element as act_kernel (split partials summed in order, bias, ReLU, mask / counter-based dropout;
 // backward: ReLU mask of the saved output, column scale, two-stage column sums); step +0.6 %.
+// KC > 0 (backward only): the block first FORMS its 64 x 64 tile of grad_out = gA . gB^T over K = 64 KC with the MFMA the
+// GEMM kernels use, k ascending (so every element is the bits drn_gemm_nt would have written), parks it in the LDS tile
+// and runs the unchanged backward on it: the fp32 [M][N] round trip through HBM and one launch disappear.  For SKINNY K
+// (the predictor's dX: K = 128, a 32-MB output for 2 GF): four waves, a 32 x 32 block each, operand fragments straight
+// from global memory (16 B per lane and k-step, all of them in flight at once).
 typedef float f32x4v __attribute__((ext_vector_type(4)));
-template <bool BWD>
+template <bool BWD, int KC = 0>
 __global__ __launch_bounds__(256) void act_vec_kernel(ActParams p) {
-  __shared__ __attribute__((aligned(16))) float t[64][68];
+  constexpr int LDS_AB = KC > 0 ? 2 * 64 * 128 * KC : 0, LDS_T = 64 * 68 * 4;
+  __shared__ __attribute__((aligned(16))) char lds_ab[LDS_AB > LDS_T ? LDS_AB : LDS_T];
+  float (*t)[68] = (float (*)[68])lds_ab;
   __shared__ float cs[16][64];
   const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
   const int n0 = blockIdx.x * 64 + tx * 4;
   const int mb0 = blockIdx.y * 64;
   const bool nok = n0 < p.N;  // N % 4 == 0: a column group is valid as a whole
+  // backward: the saved outputs / mask of this thread's four rows, fetched up front (clamped indices, unconditional loads):
+  // they do not depend on the gradient, and inside the row loop each row's loads would wait for the previous row's stores
+  uint2 svp[4] = {{0u, 0u}, {0u, 0u}, {0u, 0u}, {0u, 0u}};
+  f32x4v mkp[4];
+  if constexpr (BWD) {
+    const int nc = min(n0, p.N - 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long mc = min(mb0 + ty + 16 * k, p.M - 1);
+      mkp[k] = f32x4v{1.f, 1.f, 1.f, 1.f};
+      if (p.saved) svp[k] = *(const uint2*)((const bf16_t*)p.saved + mc * p.ld_out + nc);
+      if (p.mask) mkp[k] = *(const f32x4v*)(p.mask + mc * p.N + nc);
+    }
+  }
+  if constexpr (KC > 0) {
+    // operand tiles (64 rows x K of gA and of gB) through LDS: whole rows leave global memory in 16-byte pieces of
+    // consecutive lanes (a fragment read straight from global touches 32 rows x 32 B per instruction - 25 us for this
+    // launch, address-bound), the 16-byte k-slots of a row XOR-ed with its row so that the fragment reads - 32 rows at
+    // one slot - cover all banks.  The fp32 tile `t` reuses the A tile's space once the MFMAs are done.
+    constexpr int RB = 128 * KC, SL = 8 * KC;  // row bytes, 16-byte slots per row
+    char* la = lds_ab;
+    char* lb = lds_ab + 64 * RB;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6, wm = wv >> 1, wn = wv & 1;
+    i32x4_t ga[2 * KC], gb[2 * KC];
+#pragma unroll
+    for (int j = 0; j < 2 * KC; ++j) {  // rows past M / N are clamped: they only reach tile rows / columns nobody uses
+      const int c = threadIdx.x + 256 * j, row = c / SL, slot = c % SL;
+      ga[j] = *(const i32x4_t*)(p.gA + (long)min(mb0 + row, p.M - 1) * p.lda + 8 * slot);
+      gb[j] = *(const i32x4_t*)(p.gB + (long)min((int)blockIdx.x * 64 + row, p.N - 1) * p.ldb + 8 * slot);
+    }
+#pragma unroll
+    for (int j = 0; j < 2 * KC; ++j) {
+      const int c = threadIdx.x + 256 * j, row = c / SL, slot = c % SL;
+      *(i32x4_t*)(la + row * RB + ((slot ^ (row & 7)) << 4)) = ga[j];
+      *(i32x4_t*)(lb + row * RB + ((slot ^ (row & 7)) << 4)) = gb[j];
+    }
+    __syncthreads();
+    const int ra = wm * 32 + (lane & 31), rb = wn * 32 + (lane & 31);
+    f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4 * KC; ++ks) {
+      const int slot = 2 * ks + (lane >> 5);
+      const i32x4_t fa = *(const i32x4_t*)(la + ra * RB + ((slot ^ (ra & 7)) << 4));
+      const i32x4_t fb = *(const i32x4_t*)(lb + rb * RB + ((slot ^ (rb & 7)) << 4));
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, fa), __builtin_bit_cast(bf16x8_t, fb), acc, 0, 0, 0);
+    }
+    __syncthreads();  // everybody is done reading the operand tiles: `t` may overwrite them
+    // D layout: lane -> n = lane & 31, register r -> m = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) t[wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wn * 32 + (lane & 31)] = acc[r];
+    __syncthreads();
+  }
   float cscale[4] = {1.f, 1.f, 1.f, 1.f}, csum[4] = {0.f, 0.f, 0.f, 0.f};
   if (BWD && p.colscale && nok) {
 #pragma unroll
@@ -153,8 +217,8 @@ __global__ __launch_bounds__(256) void act_vec_kernel(ActParams p) {
   f32x4v bias4 = {0.f, 0.f, 0.f, 0.f};
   if (!BWD && p.bias && nok) bias4 = *(const f32x4v*)(p.bias + n0);
 #pragma unroll
-  for (int i = ty; i < 64; i += 16) {
-    const int m = mb0 + i;
+  for (int k = 0; k < 4; ++k) {
+    const int i = ty + 16 * k, m = mb0 + i;
     f32x4v v = {0.f, 0.f, 0.f, 0.f};
     if (m < p.M && nok) {
       if (!BWD) {
@@ -170,11 +234,11 @@ __global__ __launch_bounds__(256) void act_vec_kernel(ActParams p) {
           for (int e = 0; e < 4; ++e) v[e] *= drop_mult(seed, (uint64_t)m * p.N + n0 + e, p.drop_p);
         }
       } else {
-        for (int s = 0; s < p.splits; ++s) v += *(const f32x4v*)(p.in + (long)s * p.split_stride + (long)m * p.ld_in + n0);
-        f32x4v mk = {1.f, 1.f, 1.f, 1.f};
-        if (p.mask) mk = *(const f32x4v*)(p.mask + (long)m * p.N + n0);
-        uint2 sv = {0u, 0u};
-        if (p.saved) sv = *(const uint2*)((const bf16_t*)p.saved + (long)m * p.ld_out + n0);
+        if constexpr (KC > 0) v += *(const f32x4v*)&t[i][tx * 4];
+        else
+          for (int s = 0; s < p.splits; ++s) v += *(const f32x4v*)(p.in + (long)s * p.split_stride + (long)m * p.ld_in + n0);
+        const f32x4v mk = mkp[k];
+        const uint2 sv = svp[k];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[e] *= cscale[e];
@@ -1143,6 +1207,39 @@ int drn_bias_act_bwd_splits(const void* grad_out, int grad_dtype, long ld_in, in
   else if (out_dtype == DRN_BF16) hipLaunchKernelGGL((act_kernel<DRN_BF16, DRN_BF16, true>), grid, block, 0, st, p);
   else if (out_dtype == DRN_F32) hipLaunchKernelGGL((act_kernel<DRN_F32, DRN_F32, true>), grid, block, 0, st, p);
   else return DRN_ERR_ARG;
+  if (colsum)
+    hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, colpart, nparts, N, colsum,
+                       accumulate_colsum);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// drn_gemm_nt + drn_bias_act_bwd in one launch for a skinny contraction (K = 64, 128, 192 or 256; bf16 operands and
+// outputs): dpre = act'(saved_out) .* (A . B^T), its transposed copy and the column sums, bit for bit what the two calls
+// produce (the tile is formed with the same MFMA in the same k order; act_vec_kernel<true, K / 64>).
+int drn_gemm_nt_act_bwd(const void* A, const void* B, int M, int N, int K, long lda, long ldb, const void* saved_out,
+                        const float* mask, float drop_p, void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum,
+                        float* colpart, int accumulate_colsum, void* stream) {
+  if (!A || !B || M < 0 || N < 0 || K < 1 || (!dpre && !dpreT)) return DRN_ERR_ARG;
+  if (colsum && !colpart) return DRN_ERR_ARG;
+  if (M == 0 || N == 0) return DRN_OK;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (K % 64 != 0 || K > 256 || N % 64 != 0 || lda % 8 != 0 || ldb % 8 != 0 || lda < K || ldb < K || !al16(A) || !al16(B))
+    return DRN_ERR_UNSUPPORTED;
+  ActParams p{nullptr, 1, 0, nullptr, mask, 0ULL, drop_p, nullptr, (const char*)saved_out, (char*)dpre, ld_out,
+              (char*)dpreT, ld_outT, colsum, nullptr, nullptr, colpart, M, N, 0, 1, accumulate_colsum, 64, 0,
+              (const bf16_t*)A, (const bf16_t*)B, lda, ldb};
+  p.in = (const float*)A;  // (only its alignment is looked at below)
+  if (!act_vec_ok(p, DRN_BF16)) return DRN_ERR_UNSUPPORTED;
+  const int nparts = (M + ACT_ROWS - 1) / ACT_ROWS;
+  dim3 grid(N / 64, nparts), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  switch (K / 64) {
+    case 1: hipLaunchKernelGGL((act_vec_kernel<true, 1>), grid, block, 0, st, p); break;
+    case 2: hipLaunchKernelGGL((act_vec_kernel<true, 2>), grid, block, 0, st, p); break;
+    case 3: hipLaunchKernelGGL((act_vec_kernel<true, 3>), grid, block, 0, st, p); break;
+    default: hipLaunchKernelGGL((act_vec_kernel<true, 4>), grid, block, 0, st, p); break;
+  }
   if (colsum)
     hipLaunchKernelGGL(colsum_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, st, colpart, nparts, N, colsum,
                        accumulate_colsum);

@@ -1035,10 +1035,16 @@ class _HeadEngine:
         ops.bias_act_bwd(w["dlogits"], M, NH, colscale=colscale, colidx=colidx, dpre=w["dS"], dpreT=w["dST"],
                          **colsum_args(0, NH, self.arena_g[bo: bo + NH]))
         ops.gemm_nt(w["dST"], w["H2T"], NH, D2, Mp, out=self.arena_g[wo: wo + NH * D2].view(1, NH, D2), accumulate=acc)
-        ops.gemm_nt(w["dS"], sh["WhT"], M, D2, kp(NH), out=w["dH2"].view(1, M, D2))
-        # fc7
-        ops.bias_act_bwd(w["dH2"], M, D2, saved=w["H2"], mask=st["masks"][1] if st["masks"] else None,
-                         drop_p=st["drop_p"], dpre=w["dP2"], dpreT=w["dP2T"], **colsum_args(1, D2, self._gview("fc2.bias")))
+        # predictor dX + fc7's activation backward: one launch when the contraction is skinny (NH <= 256 columns) - the
+        # fp32 dH2 [M, D2] never goes to memory (drn_gemm_nt_act_bwd, bit-identical to the two calls)
+        m2 = st["masks"][1] if st["masks"] else None
+        cs2 = colsum_args(1, D2, self._gview("fc2.bias"))
+        if not (dtype == torch.bfloat16 and getattr(self, "fused_pred_dx", True) and
+                ops.gemm_nt_act_bwd(w["dS"], sh["WhT"], M, D2, kp(NH), saved=w["H2"], mask=m2, drop_p=st["drop_p"],
+                                    dpre=w["dP2"], dpreT=w["dP2T"], **cs2)):
+            ops.gemm_nt(w["dS"], sh["WhT"], M, D2, kp(NH), out=w["dH2"].view(1, M, D2))
+            ops.bias_act_bwd(w["dH2"], M, D2, saved=w["H2"], mask=m2, drop_p=st["drop_p"], dpre=w["dP2"], dpreT=w["dP2T"],
+                             **cs2)
         # fc7 dX: [M, D1] over K = D2 is too few 256x256 tiles for one pass (64 at R = 2000) - split K like the forward
         # GEMMs and let the activation backward behind it sum the partials (63 -> ~45 us at the bench shape)
         s1 = self._splits(M, D1, kp(D2), dtype) if getattr(self, "fc7_dx_split", True) else 1

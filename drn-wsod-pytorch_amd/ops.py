@@ -337,6 +337,27 @@ def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=Non
            int(accumulate_colsum), M, N, C.dt(ref.dtype), C.stream())
 
 
+def gemm_nt_act_bwd(A, B, M, N, K, saved=None, mask=None, drop_p=0.0, dpre=None, dpreT=None, colsum=None,
+                    accumulate_colsum=False, colpart=None):
+    """drn_gemm_nt_act_bwd: bias_act_bwd of the product A . B^T without the product going to memory (skinny K, bf16).
+    Returns False when the shape is outside the kernel's class (the caller then runs gemm_nt + bias_act_bwd)."""
+    ref = dpre if dpre is not None else dpreT
+    assert A.dtype == torch.bfloat16 and B.dtype == torch.bfloat16 and ref.dtype == torch.bfloat16
+    if saved is not None and dpre is not None:
+        assert _2d(saved) == _2d(dpre)
+    ld_out = _2d(dpre) if dpre is not None else (_2d(saved) if saved is not None else 0)
+    if colsum is not None and colpart is None:
+        colpart = torch.empty(((M + 63) // 64, N), dtype=torch.float32, device=A.device)
+    rc = C.lib().drn_gemm_nt_act_bwd(C.ptr(A), C.ptr(B), M, N, K, _2d(A), _2d(B), C.ptr(saved), C.ptr(mask), float(drop_p),
+                                     C.ptr(dpre), ld_out, C.ptr(dpreT), _2d(dpreT) if dpreT is not None else 0,
+                                     C.ptr(colsum), C.ptr(colpart), int(accumulate_colsum), C.stream())
+    if rc == -3:
+        return False
+    if rc != 0:
+        raise C.DrnError("drn_gemm_nt_act_bwd failed (%d)" % rc)
+    return True
+
+
 def colsum_reduce(colpart, nparts, N, colsum, accumulate=False):
     """finish the two-stage column sums that bias_act_bwd(colsum=None, colpart=...) left as per-block partials"""
     C.call("drn_colsum_reduce", C.ptr(colpart), int(nparts), int(N), C.ptr(colsum), int(accumulate), C.stream())

@@ -245,6 +245,15 @@ int drn_bias_act_bwd_splits(const void* grad_out, int grad_dtype, long ld_in, in
                             float drop_p, void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum,
                             float* colpart, int accumulate_colsum, int M, int N, int out_dtype, void* stream);
 
+/* drn_gemm_nt (fp32 out, one split) + drn_bias_act_bwd in ONE launch for a skinny contraction - the predictor's dX
+ * feeding fc7's activation backward (box_head.py:82-91 autograd behind fast_rcnn.py:493-527): dpre = act'(saved_out) .*
+ * (A [M][lda] . B [N][ldb]^T), its transposed copy and the bias-gradient column sums, bit for bit what the two calls
+ * produce; the fp32 [M][N] product never goes to memory.  bf16 operands and outputs, K in {64, 128, 192, 256},
+ * N % 64 == 0, 16-byte aligned rows; DRN_ERR_UNSUPPORTED otherwise (callers then run the two calls). */
+int drn_gemm_nt_act_bwd(const void* A, const void* B, int M, int N, int K, long lda, long ldb, const void* saved_out,
+                        const float* mask, float drop_p, void* dpre, long ld_out, void* dpreT, long ld_outT, float* colsum,
+                        float* colpart, int accumulate_colsum, void* stream);
+
 /* Second stage of drn_bias_act_bwd's column sums (bias gradients) on its own: with colsum == NULL and colpart != NULL
  * drn_bias_act_bwd only leaves the ceil(M/64) x N per-block partials; this adds them in a fixed order into colsum
  * (accumulate != 0: += ).  Lets the optimizer stream finish the bias gradients right in front of the SGD pass. */

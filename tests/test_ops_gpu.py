@@ -679,6 +679,43 @@ def test_bias_act_fwd_bwd(drn, dtype):
     assert abs(float((vals > 0).float().mean()) - 0.5) < 0.03
 
 
+@pytest.mark.parametrize("M,N,K,mode", [(2000, 4096, 128, "drop"), (77, 128, 64, "mask"), (300, 256, 256, "none"),
+                                         (1000, 192, 192, "drop")])
+def test_gemm_nt_act_bwd_equals_gemm_then_act_bwd(drn, M, N, K, mode):
+    """drn_gemm_nt_act_bwd (the predictor's dX with fc7's activation backward behind it, one launch, the fp32 product never
+    in memory) == drn_gemm_nt (fp32 out) + drn_bias_act_bwd, bit for bit: dpre, its transposed copy, the column sums"""
+    rs = np.random.RandomState(57)
+    A = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32) * 0.3).to(DEV).to(torch.bfloat16)
+    A[:, K - 20:] = 0  # the K padding of the real call
+    B = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32) * 0.3).to(DEV).to(torch.bfloat16)
+    saved = torch.from_numpy(np.maximum(rs.standard_normal((M, N)), 0).astype(np.float32)).to(DEV).to(torch.bfloat16)
+    mask = None
+    drop_p = 0.0
+    if mode == "mask":
+        mask = torch.from_numpy(((rs.rand(M, N) > 0.5) * 2.0).astype(np.float32)).to(DEV)
+    elif mode == "drop":
+        drop_p = 0.5
+    Mp = (M + 63) // 64 * 64
+    res = []
+    for fused in (False, True):
+        dpre = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
+        dpreT = torch.zeros((N, Mp), dtype=torch.bfloat16, device=DEV)
+        colsum = torch.full((N,), 0.25, device=DEV)
+        kw = dict(saved=saved if mode != "none" else None, mask=mask, drop_p=drop_p, dpre=dpre, dpreT=dpreT, colsum=colsum,
+                  accumulate_colsum=True)
+        if fused:
+            assert drn.gemm_nt_act_bwd(A, B, M, N, K, **kw)
+        else:
+            prod = drn.gemm_nt(A, B, M, N, K)
+            drn.bias_act_bwd(prod, M, N, **kw)
+        res.append((dpre, dpreT, colsum))
+    for a, b, name in zip(res[0], res[1], ("dpre", "dpreT", "colsum")):
+        assert torch.equal(a, b), name
+    assert float(res[1][0].float().abs().max()) > 0
+    # outside the kernel's class: refused, not mis-computed
+    assert drn.gemm_nt_act_bwd(A, B, M, N, 320, saved=saved, dpre=res[1][0]) is False
+
+
 # ------------------------------------------------------------------------------------------- MIL head
 def _head_inputs(M_per, K, seed):
     rs = np.random.RandomState(seed)
