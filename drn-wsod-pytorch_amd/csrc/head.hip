@@ -79,8 +79,19 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
   for (int mb = mb0; mb < mb1; mb += 64) {
     // (all 16 row steps of a thread unrolled: the skinny backward head - dlogits [2000 x 103] -> dS, dS^T, column sums, 64
     // workgroups - is latency-bound, its loads should all be in flight)
+    // backward of a single fp32 input: the thread's 16 rows are fetched up front, unconditionally (clamped indices) - under
+    // the row guard below every load is a branch of its own and waits for the previous row's store
+    float raw[16];
+    const bool pre = BWD && !p.in_bf16 && p.splits == 1;
+    if (pre) {
+      const int nc = min(n, p.N - 1);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) raw[k] = p.in[(long)min(mb + ty + 4 * k, p.M - 1) * p.ld_in + nc];
+    }
 #pragma unroll 16
-    for (int i = ty; i < RSTEP; i += 4) {
+    for (int k = 0; k < 16; ++k) {
+      const int i = ty + 4 * k;
+      if (i >= RSTEP) break;
       const int m = mb + i;
       float v = 0.f;
       if (m < p.M && n < p.N) {
@@ -93,6 +104,8 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
         } else {
           if (p.in_bf16) {
             v = bf16_to_f32(((const bf16_t*)p.in)[(long)m * p.ld_in + n]);
+          } else if (pre) {
+            v += raw[k];
           } else {
             for (int s = 0; s < p.splits; ++s) v += p.in[(long)s * p.split_stride + (long)m * p.ld_in + n];
           }
@@ -222,6 +235,8 @@ __global__ __launch_bounds__(256) void act_vec_kernel(ActParams p) {
     f32x4v v = {0.f, 0.f, 0.f, 0.f};
     if (m < p.M && nok) {
       if (!BWD) {
+        // (fetching the 4 rows x splits partials of a thread up front was tried here too: 17.6 -> 20.4 us - this pass is
+        // bandwidth-bound and lives on occupancy, unlike the latency-bound small kernels)
         for (int s = 0; s < p.splits; ++s) v += *(const f32x4v*)(p.in + (long)s * p.split_stride + (long)m * p.ld_in + n0);
         if (p.bias) v += bias4;
         if (p.relu) {
