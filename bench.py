@@ -34,7 +34,7 @@ sys.path.insert(0, ROOT)
 from __graft_entry__ import load_package  # noqa: E402
 
 METRIC = "images/sec training, VOC07 DRN-WSOD R50-C4 2k proposals, 1/2/4/8 GPUs"
-PMC_RECORD = "r3_02_pmc_fwd_pingpong.json"  # round 3: the ping-pong kernel, tools/pmc_attrib.sh (r2_22 / r1_04: the lock-step pipeline, same 1.44x)
+PMC_RECORD = "r4_50_pmc_fwd.json"  # round 4 re-run of tools/pmc_attrib.sh on the shipped ping-pong kernel (r3_02: the same kernel a round earlier, 1.44x / 0.77 busy)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # /opt/skills/guides/MI355X_MICROARCH.md: dense bf16 MFMA peak
 
 
@@ -673,7 +673,7 @@ def main():
                    "forward_launch": fwd_only}
             for k in ("traffic", "traffic_source", "mfma_util_pmc", "shader_clock_GHz_pmc", "l2_hit_rate_pmc", "mfma_util_source", "timed_in"):
                 fam[k] = roof.get(k)
-            fam["traffic_scope"] = "the forward launch (per launch, like forward_launch.achieved); dW: profiles/r3_15_pmc_dw_nt.json (1.32x)"
+            fam["traffic_scope"] = "the forward launch (per launch, like forward_launch.achieved); dW: profiles/r4_50_pmc_dw.json (1.32x)"
             fam["power_note"] = ("these launches run AT the 1400 W package cap with the shader clock throttled to 1.64-1.70 GHz; the "
                                  "same forward launch on zero-valued operands reaches 1645 TFLOP/s = 0.66 at 2.40 GHz "
                                  "(tools/power_probe.py, profiles/r4_03_power_probe.txt)")
