@@ -512,7 +512,8 @@ __device__ __forceinline__ void sgdp_apply_store(const SgdPipe& sp, const SgdReg
 
 // slabs [s0, s1), s0 < s1; slab s0 has been issued into stage 0 by pp_issue_first.  Every wave passes the same number of
 // barriers (wave row 1 one extra in front, wave row 0 one extra behind).
-// SGDP: the optimizer step of the previous tile rides along (above); needs s1 - s0 >= 32 and VAR == 1.
+// SGDP: the optimizer step of the previous tile rides along (above); VAR == 1.  s1 - s0 < 32: the chunks the loop has no
+// slab for follow it, exposed.
 template <int DT, int VAR, bool TN = false, bool SGDP = false>
 __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, __amdgpu_buffer_rsrc_t ra,
                                             __amdgpu_buffer_rsrc_t rb, const unsigned (&voa)[4], const unsigned (&vob)[4],
@@ -680,8 +681,27 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
     for (int s = s0; s < s1; ++s) slab(s, srA, srA);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the redundant tail fetches must land before LDS is reused
-  if constexpr (SGDP) {  // exactly 32 slabs: the last chunk (loaded in phase 1 of the last, odd slab) is still due
-    if (s1 - s0 == 32) sgdp_apply_store(*spp, srB, spp->off + 31u * spp->step);
+  if constexpr (SGDP) {
+    // <= 32 slabs: the chunk loaded in phase 1 of the last slab is still due (set A after an even slab index, B after an odd
+    // one).  FEWER than 32 slabs (fewer than 2048 proposals - real data): the loop carried one chunk per slab, chunks
+    // S .. 31 of the previous tile are left - four in flight per trip here, exposed (the registers of the fragment pipeline
+    // are dead at this point, the accumulators are not touched).
+    const unsigned S = (unsigned)(s1 - s0);
+    if (S <= 32) {
+      if (S & 1) sgdp_apply_store(*spp, srA, spp->off + (S - 1) * spp->step);
+      else sgdp_apply_store(*spp, srB, spp->off + (S - 1) * spp->step);
+    }
+    for (unsigned c = S; c < 32; c += 4) {
+      SgdRegs q[4];
+#pragma unroll
+      for (unsigned j = 0; j < 4; ++j) {
+        const unsigned cc = c + j < 32 ? c + j : 31;  // (clamped: a duplicate load, never applied)
+        sgdp_load(*spp, q[j], spp->off + cc * spp->step, spp->goff + cc * spp->gstep);
+      }
+#pragma unroll
+      for (unsigned j = 0; j < 4; ++j)
+        if (c + j < 32) sgdp_apply_store(*spp, q[j], spp->off + (c + j) * spp->step);
+    }
   }
   if (wm == 0) PP_BARRIER();
 #undef PP_PIECE
@@ -2287,9 +2307,10 @@ int drn_gemm_tn_sgd(const void* A, const void* Bt, void* grad_bucket, int M, int
   if ((lda * 2) % 16 != 0 || (ldb * 2) % 16 != 0 || lda < K || ldb < N || ldc < N || ld_w < N) return DRN_ERR_ARG;
   if ((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)grad_bucket | (uintptr_t)weights | (uintptr_t)momentum_buf | (uintptr_t)shadow) & 15))
     return DRN_ERR_ARG;
-  // shape class of the pipelined update: >= 32 K slabs (one 8-row chunk of the previous tile per slab), whole tiles, a bf16
-  // shadow, 32-bit byte offsets, enough tiles for the persistent grid, the ping-pong mainloop
-  if (K < 2048 || (K & 63) || (M & 255) || (N & 255) || !shadow || (ldc & 7) || (ld_w & 3) || g_pingpong != 1 ||
+  // shape class of the pipelined update: whole K slabs (one 8-row chunk of the previous tile rides in each; with fewer than 32
+  // slabs - fewer than 2048 proposals - the rest follows the mainloop, exposed), whole tiles, a bf16 shadow, 32-bit byte
+  // offsets, enough tiles for the persistent grid, the ping-pong mainloop
+  if (K < 128 || (K & 63) || (M & 255) || (N & 255) || !shadow || (ldc & 7) || (ld_w & 3) || g_pingpong != 1 ||
       (long)M * ld_w * 4 >= 0xFFFFFFF0L || (long)K * ldb * 2 >= 0xFFFFFFF0L)
     return DRN_ERR_UNSUPPORTED;
   const long tiles = (long)(M / 256) * (N / 256);

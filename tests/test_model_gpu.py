@@ -353,15 +353,16 @@ def test_fc6_column_slabs_equal_row_slabs(rounds):
     load_package().set_precision("fp32")
 
 
-def test_fc6_fused_tn_step_equals_unfused():
-    """Round 4: `FusedSGD.enable_fused_fc1_tn()` - the fc6 weight gradient's main columns and their optimizer step in ONE launch
+@pytest.mark.parametrize("R", [2000, 1361])
+def test_fc6_fused_tn_step_equals_unfused(R):
+    """(R = 1361: fewer than 32 K slabs - the chunks of a tile's update that find no slab follow the mainloop.)  Round 4: `FusedSGD.enable_fused_fc1_tn()` - the fc6 weight gradient's main columns and their optimizer step in ONE launch
     (drn_gemm_tn_sgd: every tile's update inside the next tile's mainloop) - against the default pipelined step (two row slabs +
     sgd_kernel on the optimizer stream) at the bench shape: three SGD steps, weight / momentum / bf16-shadow arenas bit for bit."""
     from drn_wsod_pytorch_amd.engine import build_optimizer
 
     kw = dict(arch="wsr50", out_feature="res4", res5_dilation=1, num_classes=20)
     ocfg = O.OracleCfg(dropout=0.0, base_lr=2e-4, **kw)
-    b = O.synthetic_batch(1, 2000, ocfg, seed=79)
+    b = O.synthetic_batch(1, R, ocfg, seed=79)
     batch = G.drn_inputs([dict(x, gt_boxes=torch.zeros(len(x["gt_classes"]), 4)) for x in b])
     res = []
     for fused in (False, True):

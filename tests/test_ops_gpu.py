@@ -1058,7 +1058,11 @@ def test_gemm_nt_sgd_equals_gemm_then_sgd(drn, dtype, M, N, K, wd):
 
 @pytest.mark.parametrize("M,N,wd,K,kb", [(1024, 20480, 5e-4, 2048, 2000), (768, 24576 + 256, 0.0, 2048, 2000),
                                          (2048, 8192 + 512, 1e-4, 2048, 2048), (1024, 20480, 5e-4, 4032, 4000),
-                                         (512, 40960 + 256, 1e-4, 2112, 2100)])
+                                         (512, 40960 + 256, 1e-4, 2112, 2100),
+                                         # fewer than 32 K slabs (fewer than 2048 proposals: real data) - the chunks of the previous
+                                         # tile that find no slab follow the mainloop
+                                         (1024, 20480, 5e-4, 1408, 1361), (768, 24576 + 256, 0.0, 576, 565),
+                                         (1024, 20480, 5e-4, 1984, 1947), (512, 40960 + 256, 1e-4, 128, 100)])
 def test_gemm_tn_sgd_equals_unfused_pair(drn, M, N, wd, K, kb):
     """Round 4: drn_gemm_tn_sgd - the fc6 weight gradient (TN form, bf16 bucket) with the optimizer step of every tile applied
     by the same launch, inside the NEXT tile's mainloop (loads / stores interleaved with the LDS-DMA pipeline on counted
@@ -1086,7 +1090,8 @@ def test_gemm_tn_sgd_equals_unfused_pair(drn, M, N, wd, K, kb):
         assert torch.equal(wa, wb) and torch.equal(ma, mb) and torch.equal(sa, sb), step
     assert not torch.equal(wa, w0)
     # outside the shape class nothing is launched
-    assert not drn.gemm_tn_sgd(A[:, :1024].contiguous(), Bt[:1024].contiguous(), M, N, 1024, 1024, gb, wb, mb, sb, seg_dev, 0.9, False)
+    if K >= 1088:  # (a contraction length that is not whole 64-element slabs)
+        assert not drn.gemm_tn_sgd(A[:, :1056].contiguous(), Bt[:1056].contiguous(), M, N, 1056, 1056, gb, wb, mb, sb, seg_dev, 0.9, False)
 
 
 # ------------------------------------------------------------------------------------------- conv trunk backward

@@ -29,7 +29,7 @@ B.init_weights(model, seed=0)
 model.train()
 opt = build_optimizer(cfg, model)
 dp = DataParallel(model)
-opt.enable_pipelined(dp)
+opt.enable_pipelined(dp, fused_tn={"0": False, "1": True}.get(os.environ.get("FUSED_TN", ""), None))  # FUSED_TN=0/1: A/B of the fused fc6 dW + SGD launch
 K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
 
 
