@@ -31,6 +31,10 @@ opt = build_optimizer(cfg, model)
 dp = DataParallel(model)
 opt.enable_pipelined(dp, fused_tn={"0": False, "1": True}.get(os.environ.get("FUSED_TN", ""), None))  # FUSED_TN=0/1: A/B of the fused fc6 dW + SGD launch
 K = cfg.MODEL.ROI_HEADS.NUM_CLASSES
+torch.manual_seed(int(os.environ.get("SEED", "1")))  # (the dropout masks are keyed by torch's seed: fixed, so that runs compare)
+for kv in filter(None, os.environ.get("TUNE", "").split(",")):  # TUNE=19=2,...: drn_tune knobs for A/B runs
+    from drn_wsod_pytorch_amd import ops as _ops
+    _ops.tune(int(kv.split("=")[0]), int(kv.split("=")[1]))
 
 
 def batch(seed, H, W, R):
