@@ -1247,6 +1247,25 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p_in, GemmP
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (SGDP && (p.c_bf16 & 2)) {
+          // (the fused dW + SGD launch: whole tiles only, and its 256 registers are spent anyway - four reads in flight per
+          // trip instead of one read, one wait, one store eight times over)
+#pragma unroll 1
+          for (int it = 0; it < 8; it += 4) {
+            i32x4_t v0, v1, v2, v3;
+            const int r0_ = (it * 512 + tid_e) >> 5, pc_ = tid_e & 31;  // rows r0_, r0_ + 16, + 32, + 48: the same (row & 31) parity class shifts by 16
+            asm volatile("ds_read_b128 %0, %4\n\tds_read_b128 %1, %5\n\tds_read_b128 %2, %6\n\tds_read_b128 %3, %7\n\ts_waitcnt lgkmcnt(0)"
+                         : "=&v"(v0), "=&v"(v1), "=&v"(v2), "=&v"(v3)
+                         : "v"(ep + (r0_) * 512 + ((pc_ ^ ((r0_) & 31)) << 4)), "v"(ep + (r0_ + 16) * 512 + ((pc_ ^ ((r0_ + 16) & 31)) << 4)),
+                           "v"(ep + (r0_ + 32) * 512 + ((pc_ ^ ((r0_ + 32) & 31)) << 4)), "v"(ep + (r0_ + 48) * 512 + ((pc_ ^ ((r0_ + 48) & 31)) << 4))
+                         : "memory");
+            bf16_t* dst = C16 + (long)(bm + half * 128 + r0_) * p.ldc + bn + pc_ * 8;
+            *(i32x4_t*)dst = v0;
+            *(i32x4_t*)(dst + 16 * p.ldc) = v1;
+            *(i32x4_t*)(dst + 32 * p.ldc) = v2;
+            *(i32x4_t*)(dst + 48 * p.ldc) = v3;
+          }
+        } else
 #pragma unroll 1
         for (int it = 0; it < 8; ++it) {
           const int idx = it * 512 + tid_e;
@@ -1985,6 +2004,7 @@ static int gemm256_group_rows(int M, int N, int splits) {
 }
 
 // number of workgroups of the persistent launch, or 0 when the one-tile grid should be used
+static int g_sgdp_ep4 = 1;  // drn_tune(DRN_TUNE_SGDP_EPILOGUE = 20): the fused dW + SGD launch's tile epilogue reads LDS four pieces at a time
 static int g_nwg = 0;  // drn_tune(DRN_TUNE_GEMM_NWG = 18): resident workgroups of persistent launches (0 = one per CU); for launches
                        // on a CU-masked stream (the GEMM on a subset of the CUs, an HBM-bound kernel on the others)
 static int persistent_grid(long total) {
@@ -2144,6 +2164,11 @@ int drn_tune(int knob, int value) {
   if (knob == 18) {  // DRN_TUNE_GEMM_NWG
     const int old = g_nwg;
     if (value >= 0 && value % 8 == 0 && value <= 4096) g_nwg = value;
+    return old;
+  }
+  if (knob == 20) {  // DRN_TUNE_SGDP_EPILOGUE
+    const int old = g_sgdp_ep4;
+    g_sgdp_ep4 = value != 0;
     return old;
   }
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
@@ -2319,7 +2344,7 @@ int drn_gemm_tn_sgd(const void* A, const void* Bt, void* grad_bucket, int M, int
   GemmParams p{(const char*)A, (const char*)Bt, (float*)grad_bucket, M, N, K, lda, ldb, ldc, K * 2 / 128, 0, 0,
                weights, momentum_buf, (bf16_t*)shadow, (const SgdSeg*)seg_dev, momentum, grad_scale, first_step};
   p.sgd_ld = ld_w;
-  p.c_bf16 = 1;
+  p.c_bf16 = g_sgdp_ep4 ? 3 : 1;  // (bit 1: four-at-a-time epilogue reads)
   p.nsplit = 1;
   p.gm = gemm256_group_rows(M, N, 1);
   p.kb_rows = kb_rows;
