@@ -2107,6 +2107,7 @@ __attribute__((visibility("hidden"))) int drn_roi_set_prefetch(int on);     // p
 __attribute__((visibility("hidden"))) int drn_roi_set_map64_a(int on);      // pool.hip
 __attribute__((visibility("hidden"))) int drn_roi_set_lds_kb(int kb);       // pool.hip
 __attribute__((visibility("hidden"))) int drn_roi_set_lane(int on);         // pool.hip
+__attribute__((visibility("hidden"))) int drn_roi_set_lane_reps(int reps);  // pool.hip
 int drn_tune(int knob, int value) {
   if (knob == 1) {  // DRN_TUNE_GEMM_PERSISTENT
     const int old = g_persistent;
@@ -2120,6 +2121,7 @@ int drn_tune(int knob, int value) {
   if (knob == 14) return drn_roi_set_map64_a(value);   // DRN_TUNE_ROI_MAP64_A
   if (knob == 15) return drn_roi_set_lds_kb(value);    // DRN_TUNE_ROI_LDS_KB
   if (knob == 19) return drn_roi_set_lane(value);      // DRN_TUNE_ROI_LANE
+  if (knob == 22) return drn_roi_set_lane_reps(value);  // DRN_TUNE_ROI_LANE_REPS
   if (knob == 17) {  // DRN_TUNE_CONV_CORESIDENT
     const int old = g_conv_coresident;
     g_conv_coresident = value != 0;

@@ -118,7 +118,8 @@ struct RoiParams {
   int pf;        // 64-ROI kernel: two map buffers, the next chunk's slice is fetched under this chunk's scan
   int t_c0;      // first channel whose rows of out_t are needed (drn_roi_pool_nhwc_t); kernels may write more
   int c_begin;   // 64-ROI kernel: first channel it handles (the lane-per-bin kernel writes A; this one then only the A^T tail)
-  int lane_g;    // lane-per-bin kernel: ROIs per block
+  int lane_g;    // lane-per-bin kernel: ROIs per group (one ROI per lane of every wave: <= 64)
+  int lane_reps;  // lane-per-bin kernel: groups a block walks with ONE staged slice (large maps: the staging is L2 traffic ~ groups x map)
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -954,15 +955,18 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
   const int nslice = p.C / (8 * NCK);
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int group = logical / nslice, sl = logical - group * nslice;
-  const int m0 = group * p.lane_g;
-  const int nr = min(p.lane_g, p.M - m0);
   const int c0 = sl * 8 * NCK;
   const int ph = lane / 7, pw = lane - ph * 7;
   const bool is_bin = lane < 49;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const unsigned cstride = (unsigned)HW * 16u;
-  // every wave keeps the group's ROIs in its lanes (lane l: ROI m0 + l; <= 64 per block): box corners on the map, image
-  // index, scale - one round of loads per block instead of a dependent scalar load chain per ROI; a ROI's values reach all
+  int cur_img = -1;
+  for (int rep = 0; rep < p.lane_reps; ++rep) {  // (the staged slice carries over from group to group while the image stays)
+  const int m0 = (group * p.lane_reps + rep) * p.lane_g;
+  if (m0 >= p.M) break;
+  const int nr = min(p.lane_g, p.M - m0);
+  // every wave keeps the group's ROIs in its lanes (lane l: ROI m0 + l; <= 64 per group): box corners on the map, image
+  // index, scale - one round of loads per group instead of a dependent scalar load chain per ROI; a ROI's values reach all
   // lanes through v_readlane (the ROI index is wave-uniform)
   int vx1 = 0, vy1 = 0, vx2 = 0, vy2 = 0, vimg = -1;
   float vmul = 1.f;
@@ -978,7 +982,6 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
   // runs of ROIs on the same image as a bit mask of run ends (one run in all but ragged batches)
   const int nxt = __shfl_down(vimg, 1, 64);
   const unsigned long long runs = __ballot(lane < nr && (lane + 1 >= nr || nxt != vimg));
-  int cur_img = -1;
   for (int r0 = 0; r0 < nr;) {
     const int b = __builtin_amdgcn_readlane(vimg, r0);
     const int r1 = r0 + __builtin_ctzll(runs >> r0) + 1;
@@ -1063,6 +1066,7 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
     }
     r0 = r1;
   }
+  }  // groups of this block
 }
 
 static int g_roi_lane = 1;  // drn_tune(DRN_TUNE_ROI_LANE = 19): 0 = the 64-ROI kernel writes A as before
@@ -1078,6 +1082,8 @@ static int roi_lane_chunks(int H, int W, int C) {
   return 0;
 }
 
+static int g_roi_lane_reps = 0;  // drn_tune(DRN_TUNE_ROI_LANE_REPS = 22): groups per block on one-block-per-CU maps (0 = default: 4, fewer while < 2 rounds of blocks)
+static int cu_count_pool_fwd();
 static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
   RoiParams p = p0;
   if (!g_roi_lane || p.C % 8) return false;
@@ -1098,11 +1104,21 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
   // ROIs per block: 32 (four per wave) - the staging of the slice is then ~1/8 of the block's output bytes at 14x14; large
   // maps (one chunk of 60+ KB per block) take 64 so that the slice is staged half as often
   p.lane_g = smem > 38 * 1024 ? 64 : 32;
-  const int ngroups = (p.M + p.lane_g - 1) / p.lane_g;
+  int ngroups = (p.M + p.lane_g - 1) / p.lane_g;
+  // one block per CU (slices beyond 76 KB): every group of 64 ROIs re-stages the slice from L2 - 32 groups x 64 slices x
+  // 120 KB = 250 MB at 50x76.  A block walks `lane_reps` groups with one staged slice as long as >= 2 rounds of blocks remain
+  p.lane_reps = 1;
+  if (smem > 76 * 1024) {
+    const long blocks1 = (long)ngroups * (p.C / (8 * nck));
+    int reps = g_roi_lane_reps > 0 ? g_roi_lane_reps : 4;
+    while (reps > 1 && blocks1 / reps < 2L * cu_count_pool_fwd()) reps >>= 1;
+    p.lane_reps = reps;
+    ngroups = (ngroups + reps - 1) / reps;
+  }
   const bool big = smem > 76 * 1024;  // one block per CU: 16 waves
-  // one block per CU (maps beyond ~4700 pixels): measured 372 vs 325 us for the 64-ROI kernel at 63x92, but 368 vs 415 us
-  // at 75x122, where that kernel stages its slice in two row bands - this kernel takes those (19=2 forces it everywhere)
-  if (big && per_chunk + (size_t)ROI_G64 * G64_PITCH <= (size_t)154 * 1024 && (int)g_roi_lane < 2) return false;
+  // (one block per CU - maps beyond ~4700 pixels: with a block per group of 64 ROIs this kernel measured 372 vs 325 us for the
+  // 64-ROI kernel at 63x92 and went there only for maps that kernel stages in two row bands; with four groups per staged
+  // slice it is 293 vs 330 us at 63x92 and 260 vs 368 us at 75x122 and takes every map whose chunk fits)
   const dim3 grid((unsigned)ngroups * (p.C / (8 * nck))), block(big ? 1024 : 512);
   p.out_t = nullptr;  // (A only; the caller launches the 64-ROI kernel for the A^T tail chunks)
   if (nck == 8) hipLaunchKernelGGL(roi_pool7_lane_kernel<8>, grid, block, smem, st, p);
@@ -1113,6 +1129,8 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
   return true;
 }
 
+static int cu_count_pool();
+static int cu_count_pool_fwd() { return cu_count_pool(); }
 static int cu_count_pool() {
   static int n = 0;
   if (!n) {
@@ -1306,6 +1324,11 @@ __attribute__((visibility("hidden"))) int drn_roi_set_lds_kb(int kb) {
   return old;
 }
 
+__attribute__((visibility("hidden"))) int drn_roi_set_lane_reps(int reps) {
+  const int old = g_roi_lane_reps;
+  if (reps >= 0 && reps <= 64) g_roi_lane_reps = reps;
+  return old;
+}
 __attribute__((visibility("hidden"))) int drn_roi_set_lane(int on) {
   const int old = g_roi_lane;
   g_roi_lane = on < 0 ? 0 : on > 2 ? 2 : on;

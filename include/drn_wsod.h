@@ -213,6 +213,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_FP8_K64 13 /* 0/1 (default 1): fp8 convolutions multiply with v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales; the fp8 MFMA rate) instead of the K = 16 non-scaled form (bf16 rate); same exact products, another fp32 summation order */
 #define DRN_TUNE_GEMM_NWG 18 /* resident workgroups of persistent 256x256 launches (multiple of 8; 0 = default: one per CU) - for launches on a CU-masked stream */
 #define DRN_TUNE_SGDP_EPILOGUE 20 /* 0/1 (default 1): the tile epilogue of drn_gemm_tn_sgd moves the bf16 gradient tile LDS -> global four 16-byte pieces per trip instead of one (A/B knob; bit-identical) */
+#define DRN_TUNE_ROI_LANE_REPS 22 /* lane-per-bin ROIPool on maps that leave one block per CU: groups of 64 ROIs a block walks with one staged map slice (0 = default: 4, halved while fewer than two rounds of blocks would remain; 1 = a block per group) */
 #define DRN_TUNE_ROI_LANE 19 /* 0/1 (default 1): the bf16 training operand A from the lane-per-bin ROIPool kernel (a wave per ROI, lane = bin: every channel leaves as one 98-byte run per store instruction); 0 = the 64-ROI kernel writes A */
 #define DRN_TUNE_CONV_PATCH 9 /* 0 = never use the LDS-resident-patch kernel for 3x3 / 64 -> 64 channel convs; 1 = default (maps of >= 32768 pixels); > 1 = that many pixels per image at least */
 int drn_tune(int knob, int value);
