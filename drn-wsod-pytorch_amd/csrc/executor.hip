@@ -27,7 +27,8 @@ int walk(const DrnTrunkOp* ops, int n_ops, int n_slots, int in_slot, int H, int 
     if (o.src < 0 || o.src >= n_slots || o.dst < 0 || o.dst >= n_slots || o.dst == o.src || !g[o.src].set) return DRN_ERR_ARG;
     const SlotGeom in = g[o.src];
     SlotGeom out;
-    if (o.kind == DRN_TRUNK_CONV) {
+    const int kind = o.kind & DRN_TRUNK_KIND_MASK;
+    if (kind == DRN_TRUNK_CONV) {
       if (in.c != o.cin || in.es != drn_esize(o.dtype)) return DRN_ERR_ARG;
       const int ho = (in.h + 2 * o.pad - o.dil * (o.ksize - 1) - 1) / o.stride + 1;
       const int wo = (in.w + 2 * o.pad - o.dil * (o.ksize - 1) - 1) / o.stride + 1;
@@ -38,7 +39,7 @@ int walk(const DrnTrunkOp* ops, int n_ops, int n_slots, int in_slot, int H, int 
         const SlotGeom& r = g[o.res];
         if (r.h != ho || r.w != wo || r.c != o.cout || r.es != drn_esize(o.res_dtype)) return DRN_ERR_ARG;
       }
-    } else if (o.kind == DRN_TRUNK_MAXPOOL) {
+    } else if (kind == DRN_TRUNK_MAXPOOL) {
       if (in.h < 2 || in.w < 2 || (o.stride != 1 && o.stride != 2)) return DRN_ERR_ARG;
       out = SlotGeom{(in.h - 2) / o.stride + 1, (in.w - 2) / o.stride + 1, in.c, in.es, true};
     } else {
@@ -79,9 +80,29 @@ int drn_trunk_forward(const DrnTrunkOp* ops, int n_ops, int n_slots, int in_slot
                       int C0, int in_dtype, void* stream) {
   if (!slots || Nb <= 0 || H <= 0 || W <= 0) return DRN_ERR_ARG;
   SlotGeom g[DRN_TRUNK_MAX_SLOTS];
+  int fused_tail = -1;  // index of an op that already ran as the 1x1 tail of the previous op's launch
   return walk(ops, n_ops, n_slots, in_slot, H, W, C0, in_dtype, g, [&](const DrnTrunkOp& o, const SlotGeom& in, const SlotGeom&) {
     if (!slots[o.src] || !slots[o.dst] || (o.res >= 0 && !slots[o.res])) return DRN_ERR_ARG;
-    if (o.kind == DRN_TRUNK_CONV)
+    const int idx = (int)(&o - ops);
+    if (idx == fused_tail) return DRN_OK;
+    if ((o.kind & DRN_TRUNK_FUSE_NEXT) && idx + 1 < n_ops) {
+      // 3x3 (64 -> 64) whose output only the next op - a 1x1 to 256 channels - reads: one launch on large maps
+      // (drn_conv3x3_pw_nhwc; bit-identical to the two), the two launches wherever that kernel does not apply
+      const DrnTrunkOp& n = ops[idx + 1];
+      const bool ok = (n.kind & DRN_TRUNK_KIND_MASK) == DRN_TRUNK_CONV && n.src == o.dst && o.res < 0 && o.ksize == 3 &&
+                      o.cin == 64 && o.cout == 64 && o.stride == 1 && o.pad == 1 && o.dil == 1 && n.ksize == 1 && n.cin == 64 &&
+                      n.cout == 256 && n.stride == 1 && n.pad == 0 && o.dtype == DRN_BF16 && o.out_dtype == DRN_BF16 &&
+                      n.dtype == DRN_BF16 && n.out_dtype == DRN_BF16 && (n.res < 0 || n.res_dtype == DRN_BF16) &&
+                      n.dst >= 0 && n.dst < n_slots && slots[n.dst] && (n.res < 0 || (n.res < n_slots && slots[n.res]));
+      if (ok) {
+        const int rc = drn_conv3x3_pw_nhwc(slots[o.src], o.w, o.scale, o.bias, o.relu, n.w, n.scale, n.bias,
+                                           n.res >= 0 ? slots[n.res] : nullptr, slots[n.dst], Nb, in.h, in.w, o.ldw, n.ldw,
+                                           n.res_mult, n.relu, stream);
+        if (rc == DRN_OK) { fused_tail = idx + 1; return DRN_OK; }
+        if (rc != DRN_ERR_UNSUPPORTED) return rc;
+      }
+    }
+    if ((o.kind & DRN_TRUNK_KIND_MASK) == DRN_TRUNK_CONV)
       return drn_conv2d_nhwc_q(slots[o.src], o.w, slots[o.dst], o.scale, o.bias, o.res >= 0 ? slots[o.res] : nullptr, Nb, in.h,
                                in.w, o.cin, o.cout, o.ksize, o.ksize, o.stride, o.pad, o.dil, o.ldw, o.cout, o.cout, o.relu,
                                o.dtype, o.out_dtype, o.res >= 0 ? o.res_dtype : o.out_dtype, o.res_mult, stream);

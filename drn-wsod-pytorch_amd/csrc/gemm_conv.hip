@@ -62,6 +62,12 @@ struct ConvParams {
   int out_dt, res_dt;
   float res_mult;
   int fp8_k64;  // fp8 operands: 1 = the K = 64 scaled MFMA (fp8 rate), 0 = the K = 16 form (DRN_TUNE_FP8_K64)
+  // conv3x3_c64_kernel<.., PW = true> (drn_conv3x3_pw_nhwc): a 1x1 convolution 64 -> 256 channels on this conv's output,
+  // which never leaves the chip - the tail of a res2 bottleneck.  Y / ldy / residual / ldres / res_mult then belong to THAT
+  // layer (256 channels), scale / bias / relu above to the 3x3, pw_* to the 1x1
+  const char* pw_w; long pw_ldw;  // [256][pw_ldw] K-major (64 input channels)
+  const float* pw_scale; const float* pw_bias;
+  int pw_relu;
 };
 
 template <int DT>
@@ -1553,11 +1559,18 @@ constexpr int P3_NCH = P3_PH * P3_PW * 8, P3_NIT = (P3_NCH + 255) / 256;  // 16-
 // PERSISTENT: one workgroup per CU keeps the weights in LDS and walks its XCD's share of the pixel blocks; the patch of
 // the NEXT block is fetched into registers while the current one is multiplied, so per block only the LDS store of the
 // patch, the MFMA phase and the epilogue (two 128-pixel halves staged as fp32 in the dead patch area) remain.
-template <bool RES>
+// PW = true (round 4, the tail of a res2 bottleneck as ONE kernel - resnet_ws.py:217-237 conv2 -> conv3 + shortcut): the
+// 3x3's output tile [256 pixels x 64 channels] (affine, ReLU, rounded to bf16 exactly as the 3x3 alone would store it) goes
+// to the dead patch area in A-fragment layout instead of to memory, and each wave multiplies its 64 pixels with the 1x1's
+// weights [256 x 64] (32 KB more of LDS, resident like the 3x3's) - four chunks of 64 output channels, each through the
+// same staged epilogue (affine, residual, ReLU, 16-byte stores).  Same MFMA and k order as the two kernels it replaces.
+constexpr int P3_PW_WTS = 256 * 128;
+template <bool RES, bool PW = false>
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* patch = smem;
   char* wts = smem + P3_PATCH;
+  [[maybe_unused]] char* w3s = smem + P3_PATCH + P3_WTS;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tiles_x = (p.Wo + P3_TW - 1) / P3_TW, tiles_y = (p.Ho + P3_TH - 1) / P3_TH;
   const int per_img = tiles_y * tiles_x, total = p.Nb * per_img;
@@ -1601,7 +1614,31 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
       }
     }
   }
+  if constexpr (PW) {  // the 1x1's weights: [256 cout][pw_ldw] (64 input channels = one 128-byte row) -> LDS [cout][128 B]
+    const long ldw3_b = p.pw_ldw * 2;
+    i32x4_t v[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c = it * 256 + tid;  // 0 .. 2047
+      v[it] = *(const i32x4_t*)(p.pw_w + (long)(c >> 3) * ldw3_b + (c & 7) * 16);
+    }
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int c = it * 256 + tid;
+      *(i32x4_t*)(w3s + swz(c >> 3, c & 7)) = v[it];
+    }
+  }
   const int lx = lane & 31, lh = lane >> 5;
+  [[maybe_unused]] float sc3[4][2], bi3[4][2];
+  if constexpr (PW) {
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        sc3[cb][j] = p.pw_scale ? p.pw_scale[cb * 64 + j * 32 + lx] : 1.f;
+        bi3[cb][j] = p.pw_bias ? p.pw_bias[cb * 64 + j * 32 + lx] : 0.f;
+      }
+  }
   // this lane's two output channels' affine, once per workgroup (inside the block loop each half of every epilogue paid
   // a global-load latency for them: one wave per SIMD hides nothing - 16 of 38 us on the stem layer at 800x1216)
   float sc2[2], bi2[2];
@@ -1653,6 +1690,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
     // epilogue: affine -> fp32 [128 pixels][64 channels] in the (dead) patch area, one half of the block at a time -> 8
     // channels per lane: residual, ReLU, 16-byte stores
     float* tile = (float*)patch;
+    auto epilogue = [&](f32x16_t (&ac)[2][2], const float (&sc_)[2], const float (&bi_)[2], int ch0, int relu_) {
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
       __syncthreads();  // patch reads (half 0) / the other half's tile reads (half 1) are done
@@ -1665,7 +1703,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
               const int ml = (wave & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              tile[ml * 64 + nl] = acc[i][j][r] * sc2[j] + bi2[j];
+              tile[ml * 64 + nl] = ac[i][j][r] * sc_[j] + bi_[j];
             }
         }
       }
@@ -1678,7 +1716,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
         for (int it = 0; it < 4; ++it) {
           const int idx = it * 256 + tid, ml = idx >> 3, cg = idx & 7;
           const int y = min(y0 + half * 4 + (ml >> 5), p.Ho - 1), x = min(x0 + (ml & 31), p.Wo - 1);
-          rv[it] = *(const i32x4_t*)((const bf16_t*)p.residual + (((long)n * p.Ho + y) * p.Wo + x) * p.ldres + cg * 8);
+          rv[it] = *(const i32x4_t*)((const bf16_t*)p.residual + (((long)n * p.Ho + y) * p.Wo + x) * p.ldres + ch0 + cg * 8);
         }
       }
       __syncthreads();
@@ -1697,10 +1735,55 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
             v[2 * e] += __builtin_bit_cast(float, w << 16) * p.res_mult;
             v[2 * e + 1] += __builtin_bit_cast(float, w & 0xffff0000u) * p.res_mult;
           }
-          if (p.relu) { v[2 * e] = fmaxf(v[2 * e], 0.f); v[2 * e + 1] = fmaxf(v[2 * e + 1], 0.f); }
+          if (relu_) { v[2 * e] = fmaxf(v[2 * e], 0.f); v[2 * e + 1] = fmaxf(v[2 * e + 1], 0.f); }
           o[e] = (int)((uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16));
         }
-        if (y < p.Ho && x < p.Wo) *(i32x4_t*)((bf16_t*)p.Y + m * p.ldy + cg * 8) = o;
+        if (y < p.Ho && x < p.Wo) *(i32x4_t*)((bf16_t*)p.Y + m * p.ldy + ch0 + cg * 8) = o;
+      }
+    }
+    };
+    if constexpr (!PW) {
+      epilogue(acc, sc2, bi2, 0, p.relu);
+    } else {
+      // the 3x3's output -> bf16 A fragments: rows = this wave's 64 pixels (wave * 64 + i * 32 + pixel), 128 B = 64 channels
+      __syncthreads();  // every wave is done reading the patch
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int ml = wave * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, nl = j * 32 + lx;
+            float v = acc[i][j][r] * sc2[j] + bi2[j];
+            if (p.relu) v = fmaxf(v, 0.f);
+            *(bf16_t*)(patch + swz(ml, nl >> 3) + (nl & 7) * 2) = f32_to_bf16(v);
+          }
+      i32x4_t ya[2][4];
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) ya[i][ks] = *(const i32x4_t*)(patch + swz(wave * 64 + i * 32 + lx, ks * 2 + lh));
+      // (the first barrier of the staged epilogue below comes before anybody writes the tile: every wave has its fragments by then)
+#pragma unroll
+      for (int cb = 0; cb < 4; ++cb) {  // (unrolled: sc3 / bi3 are register arrays)
+        f32x16_t a3[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) a3[i][j][r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          i32x4_t b3[2];
+#pragma unroll
+          for (int j = 0; j < 2; ++j) b3[j] = *(const i32x4_t*)(w3s + swz(cb * 64 + j * 32 + lx, ks * 2 + lh));
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) mma_step<DRN_BF16>(a3[i][j], ya[i][ks], b3[j]);
+        }
+        epilogue(a3, sc3[cb], bi3[cb], cb * 64, p.pw_relu);
       }
     }
     __syncthreads();  // tile reads done before the next block's patch overwrites the area
@@ -2046,6 +2129,23 @@ static int launch_conv3x3_c64(const ConvParams& p, hipStream_t st) {
   return DRN_OK;
 }
 
+static int launch_conv3x3_c64_pw(const ConvParams& p, hipStream_t st) {
+  const int tiles = p.Nb * ((p.Ho + P3_TH - 1) / P3_TH) * ((p.Wo + P3_TW - 1) / P3_TW);
+  constexpr int smem = P3_PATCH + P3_WTS + P3_PW_WTS;  // 146.5 KB: one workgroup per CU
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
+        hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DRN_ERR_LAUNCH;
+    attr = true;
+  }
+  const int nwg = tiles < cu_count() ? tiles : cu_count();
+  if (p.residual) hipLaunchKernelGGL((conv3x3_c64_kernel<true, true>), dim3(nwg), dim3(256), smem, st, p);
+  else hipLaunchKernelGGL((conv3x3_c64_kernel<false, true>), dim3(nwg), dim3(256), smem, st, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
 template <int DT, bool K64 = true>
 int launch_conv_k2(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
@@ -2376,6 +2476,24 @@ int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda,
 
 // NHWC conv + per-channel affine (folded FrozenBN or bias) + optional residual + optional ReLU; `dtype` is the element
 // type of x / w (fp32, bf16 or fp8 e4m3fn), y and the residual may be stored in another one (see include/drn_wsod.h).
+// The tail of a 64-channel bottleneck on a large map as ONE launch (conv3x3_c64_kernel<.., PW>): the 3x3's output never
+// goes to memory.  Same shape class as the LDS-resident-patch kernel takes on its own; anything else: DRN_ERR_UNSUPPORTED
+// (the caller runs the two convolutions).
+int drn_conv3x3_pw_nhwc(const void* x, const void* w2, const float* scale2, const float* bias2, int relu2, const void* w3,
+                        const float* scale3, const float* bias3, const void* residual, void* y, int Nb, int H, int W,
+                        long ldw2, long ldw3, float res_mult, int relu3, void* stream) {
+  if (!x || !w2 || !w3 || !y || Nb <= 0 || H <= 0 || W <= 0) return DRN_ERR_ARG;
+  auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
+  if (!g_conv_patch || g_conv_coresident || (long)H * W < g_conv_patch_min || (long)Nb * H * W * 128 >= 0xFFFFFFF0L ||
+      ldw2 < 9 * 64 || ldw3 < 64 || (ldw2 * 2) % 16 != 0 || (ldw3 * 2) % 16 != 0 || !al16(x) || !al16(w2) || !al16(w3) ||
+      !al16(y) || (residual && !al16(residual)))
+    return DRN_ERR_UNSUPPORTED;
+  ConvParams p{(const char*)x, (const char*)w2, (char*)y, scale2, bias2, (const char*)residual, Nb, H, W, 64, H, W,
+               64, 3, 3, 1, 1, 1, relu2, 9 * 64, ldw2, 256, 256, DRN_BF16, DRN_BF16, res_mult, 0,
+               (const char*)w3, ldw3, scale3, bias3, relu3};
+  return launch_conv3x3_c64_pw(p, (hipStream_t)stream);
+}
+
 int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale, const float* bias,
                       const void* residual, int Nb, int H, int W, int Cin, int Cout, int KH, int KW, int stride,
                       int pad, int dil, long ldw, long ldy, long ldres, int relu, int dtype, int out_dtype,

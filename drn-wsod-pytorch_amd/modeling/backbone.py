@@ -95,6 +95,22 @@ class _PlanBuilder:
             if o["res"] >= 0:
                 last[o["res"]] = i
         pinned = {0} | set(outputs.values())
+        # a 3x3 / 64 -> 64 conv whose output only the next op reads, a 1x1 conv to 256 channels (conv2 -> conv3 of a res2
+        # bottleneck, resnet_ws.py:217-237): flagged, the executor runs the pair as one launch on large maps
+        # (drn_conv3x3_pw_nhwc - the intermediate stays in LDS; bit-identical) and as two anywhere else
+        readers = {}
+        for o in self.ops:
+            for v in {o["src"], o["res"]} - {-1}:
+                readers[v] = readers.get(v, 0) + 1
+        bf = C.dt(torch.bfloat16)
+        for i in range(len(self.ops) - 1 if getattr(self, "fuse_tails", True) else 0):
+            o, n = self.ops[i], self.ops[i + 1]
+            if (o["kind"] == 0 and n["kind"] == 0 and o["ksize"] == 3 and o["cin"] == 64 and o["cout"] == 64 and o["stride"] == 1
+                    and o["pad"] == 1 and o["dil"] == 1 and o["res"] < 0 and n["ksize"] == 1 and n["cin"] == 64 and n["cout"] == 256
+                    and n["stride"] == 1 and n["pad"] == 0 and n["src"] == i + 1 and n["res"] != i + 1 and readers.get(i + 1) == 1
+                    and (i + 1) not in pinned and o["dtype"] == bf and o["out_dtype"] == bf and n["dtype"] == bf
+                    and n["out_dtype"] == bf and (n["res"] < 0 or n["res_dtype"] == bf)):
+                o["kind"] |= 0x100
         slot_of, free, n_slots = {0: 0}, [], 1
         arr = (C.DrnTrunkOp * max(len(self.ops), 1))()
         for i, o in enumerate(self.ops):
@@ -381,8 +397,10 @@ class BottleneckBlock(CNNBlockBase):
         return out
 
     def plan(self, b, x):
-        o2 = b.conv(self.conv2, b.conv(self.conv1, x, relu=True), relu=True)
+        # (the projection shortcut first: conv3 then follows conv2 directly, which is what the executor's fused tail - conv2 +
+        # conv3 as one launch on large maps - looks for; same ops, same results)
         sc = b.conv(self.shortcut, x) if self.shortcut is not None else x
+        o2 = b.conv(self.conv2, b.conv(self.conv1, x, relu=True), relu=True)
         out = b.conv(self.conv3, o2, res=sc, relu=True)
         return b.pool(out, self.pool_stride) if self.has_pool else out
 

@@ -59,6 +59,17 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
                       int pad, int dil, long ldw, long ldy, long ldres, int relu, int dtype, int out_dtype,
                       int res_dtype, float res_mult, void* stream);
 
+/* The tail of a 64-channel bottleneck block on a large map as ONE launch (BottleneckBlock.forward,
+ * projects/WSL/wsl/modeling/backbone/resnet_ws.py:217-237: conv2 -> relu -> conv3 -> + shortcut -> relu):
+ * y [Nb*H*W][256] = act3((conv1x1(act2(conv3x3(x) * scale2 + bias2)) * scale3 + bias3) + residual * res_mult), bf16;
+ * x [Nb][H][W][64], w2 [64][ldw2] (3x3, pad = dil = stride = 1, packed as for drn_conv2d_nhwc), w3 [256][ldw3] (1x1 over
+ * 64 channels), residual [Nb*H*W][256] or NULL.  The 3x3's output - rounded to bf16 exactly as drn_conv2d_nhwc would
+ * store it - stays in LDS: bit for bit the result of the two drn_conv2d_nhwc calls.  Maps of >= 32768 pixels per image
+ * (the LDS-resident-patch kernel's class); DRN_ERR_UNSUPPORTED otherwise (callers then run the two convolutions). */
+int drn_conv3x3_pw_nhwc(const void* x, const void* w2, const float* scale2, const float* bias2, int relu2, const void* w3,
+                        const float* scale3, const float* bias3, const void* residual, void* y, int Nb, int H, int W,
+                        long ldw2, long ldw3, float res_mult, int relu3, void* stream);
+
 /* nn.MaxPool2d(kernel_size=2, stride=s, padding=0), resnet_ws.py:214-215,403; vgg.py:99-100.  DRN_FP8: non-negative
  * (post-ReLU) values only - they order like their bytes. */
 int drn_maxpool2x2_nhwc(const void* x, void* y, int Nb, int H, int W, int C, int stride, int dtype, void* stream);
@@ -445,8 +456,10 @@ int drn_csc_loss(const float* logits, long ld, int c_cls, int c_det, int K, int 
 #define DRN_TRUNK_CONV 0
 #define DRN_TRUNK_MAXPOOL 1
 #define DRN_TRUNK_MAX_SLOTS 16
+#define DRN_TRUNK_KIND_MASK 0xff
+#define DRN_TRUNK_FUSE_NEXT 0x100 /* flag on a 3x3 / 64 -> 64 conv op: its output is read by the NEXT op alone, a 1x1 conv to 256 channels - the executor may run the pair as one drn_conv3x3_pw_nhwc launch (the dst slot is then not written) */
 typedef struct DrnTrunkOp {
-  int kind;           /* DRN_TRUNK_CONV | DRN_TRUNK_MAXPOOL */
+  int kind;           /* DRN_TRUNK_CONV | DRN_TRUNK_MAXPOOL, optionally | DRN_TRUNK_FUSE_NEXT */
   int src, dst, res;  /* slot indices; res = -1: no residual (conv only) */
   const void* w;      /* conv: packed weights [cout][ldw] as for drn_conv2d_nhwc_q */
   const float* scale; /* per-cout affine (folded FrozenBN / quantisation scales) or NULL */

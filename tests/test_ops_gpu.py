@@ -493,6 +493,32 @@ def test_conv2d_wave_k_split(drn, dtype, case):
         assert (ys[0].float() - tiled.float()).abs().max() <= 2 ** -7 * float(tiled.float().abs().max())
 
 
+@pytest.mark.parametrize("case", [(1, 203, 181, True), (2, 184, 192, True), (1, 181, 203, False)])
+def test_conv3x3_pw_equals_two_convs(drn, case):
+    """drn_conv3x3_pw_nhwc (the tail of a res2 bottleneck - 3x3 64 -> 64, ReLU, 1x1 64 -> 256, + shortcut, ReLU - as ONE launch,
+    the 3x3's output never in memory) == the two drn_conv2d_nhwc calls, bit for bit; ragged 8 x 32 pixel blocks, two images,
+    with and without the shortcut; a map below the kernel's class is refused."""
+    n, h, w, has_res = case
+    dtype = torch.bfloat16
+    x = _rnd((n, 64, h, w), 61)
+    w2 = _rnd((64, 64, 3, 3), 62, math.sqrt(2.0 / (64 * 9)))
+    w3 = _rnd((256, 64, 1, 1), 63, math.sqrt(2.0 / 64))
+    s2, b2 = (0.8 + 0.2 * torch.rand(64)).to(DEV), _rnd((64,), 64, 0.1).to(DEV)
+    s3, b3 = (0.8 + 0.2 * torch.rand(256)).to(DEV), _rnd((256,), 65, 0.1).to(DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    res = _rnd((n, h, w, 256), 66).to(DEV).to(dtype) if has_res else None
+    wp2, wp3 = _pack_w(w2, dtype, drn, 64), _pack_w(w3, dtype, drn, 64)
+    y2 = drn.conv2d_nhwc(xd, wp2, 64, 3, 3, 1, 1, 1, s2, b2, None, True)
+    ref = drn.conv2d_nhwc(y2, wp3, 256, 1, 1, 1, 0, 1, s3, b3, res, True)
+    got = drn.conv3x3_pw_nhwc(xd, wp2, s2, b2, True, wp3, s3, b3, res, 1.0, True)
+    torch.cuda.synchronize()
+    assert got is not None
+    assert torch.equal(got, ref), float((got.float() - ref.float()).abs().max())
+    assert float(ref.float().abs().max()) > 0
+    small = xd[:, :40, :40].contiguous()
+    assert drn.conv3x3_pw_nhwc(small, wp2, s2, b2, True, wp3, s3, b3, None, 1.0, True) is None
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("stride,hw", [(2, (56, 56)), (1, (28, 28)), (2, (13, 9)), (1, (5, 7))])
 def test_maxpool(drn, dtype, stride, hw):

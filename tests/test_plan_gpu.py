@@ -51,6 +51,26 @@ def test_plan_equals_per_layer_walk(name, precision):
     assert p["n_slots"] <= 7, p["n_slots"]  # image + output + a handful of reusable activations
 
 
+def test_plan_fused_bottleneck_tail_real_size():
+    """Round 4: on a real-size image the plan runs conv2 (3x3, 64 -> 64) + conv3 (1x1 to 256, + shortcut, ReLU) of every res2
+    bottleneck as ONE launch (DRN_TRUNK_FUSE_NEXT -> drn_conv3x3_pw_nhwc; the 3x3's output stays in LDS).  Against the
+    per-layer walk - two launches per pair - on the full-width WS-ResNet50-C4 trunk, bf16, one and two images: bit-identical
+    feature maps; three flagged ops in the plan; a small image takes the two-launch path of the same plan."""
+    from oracle import wsod_oracle as O
+
+    ocfg = O.OracleCfg(arch="wsr50", out_feature="res4", res5_dilation=1, num_classes=20)
+    cfg, model = G.drn_model(ocfg, 3, "cuda", 5, "bf16")
+    model.eval()
+    for x in _images(model, [(1, 800, 1216), (2, 608, 800), (1, 224, 224)], seed=3):
+        a, b = _both(model, x)
+        for k in a:
+            assert torch.equal(a[k], b[k]), (tuple(x.shape), k)
+            assert float(a[k].float().abs().max()) > 0
+    p = next(iter(model.backbone._plans.values()))
+    assert sum(1 for i in range(p["n_ops"]) if p["ops"][i].kind & 0x100) == 3
+    load_package().set_precision("fp32")
+
+
 def test_plan_follows_weight_updates():
     ocfg = G.MODEL_CASES["model_r50c4_tiny"]
     cfg, model = G.drn_model(ocfg, 3, "cuda", 5, "bf16")
