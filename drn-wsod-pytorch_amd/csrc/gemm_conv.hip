@@ -1565,6 +1565,9 @@ constexpr int P3_NCH = P3_PH * P3_PW * 8, P3_NIT = (P3_NCH + 255) / 256;  // 16-
 // weights [256 x 64] (32 KB more of LDS, resident like the 3x3's) - four chunks of 64 output channels, each through the
 // same staged epilogue (affine, residual, ReLU, 16-byte stores).  Same MFMA and k order as the two kernels it replaces.
 constexpr int P3_PW_WTS = 256 * 128;
+// LDS-only barrier: __syncthreads() also waits (vmcnt) for every global store and prefetch load in flight - the block loop
+// below used to drain its output stores and the next block's patch fetch at each of its barriers
+#define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
 template <bool RES, bool PW = false>
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1656,7 +1659,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
       const int c = it * 256 + tid;
       if (c < P3_NCH) *(i32x4_t*)(patch + swz(c >> 3, c & 7)) = pv[it];
     }
-    __syncthreads();
+    LDS_BARRIER();
     if (k + (int)gridDim.x < total) fetch(xcd_remap(k + gridDim.x, total), pv);  // lands under the MFMA phase
     f32x16_t acc[2][2];
 #pragma unroll
@@ -1689,43 +1692,38 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
     }
     // epilogue: affine -> fp32 [128 pixels][64 channels] in the (dead) patch area, one half of the block at a time -> 8
     // channels per lane: residual, ReLU, 16-byte stores
-    float* tile = (float*)patch;
+    // WAVE-PRIVATE and barrier-free (cycle counters on the first version - fp32 halves of the whole block staged by all
+    // four waves, two barriers per half - put 38 % of a block's time in the epilogue, one wave per SIMD hiding nothing): a wave
+    // stages one of its two 32-pixel output rows at a time as fp32 [32 pixels][64 channels] in its own 8.5 KB (row pitch 68
+    // floats: the two half-waves, four pixels apart, land on different banks), reads it back as 32-byte runs - LDS operations
+    // of one wave execute in order, so its own writes and reads need no barrier - adds the residual, ReLU, and stores 16-byte
+    // pieces of its own pixels' 128-byte rows.  The four waves run their epilogues independently.
+    constexpr int EP_PITCH = 68;
+    float* wtile = (float*)(patch + wave * (32 * EP_PITCH * 4));
     auto epilogue = [&](f32x16_t (&ac)[2][2], const float (&sc_)[2], const float (&bi_)[2], int ch0, int relu_) {
 #pragma unroll
-    for (int half = 0; half < 2; ++half) {
-      __syncthreads();  // patch reads (half 0) / the other half's tile reads (half 1) are done
-      if ((wave >> 1) == half) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-          const int nl = j * 32 + lx;
-#pragma unroll
-          for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-              const int ml = (wave & 1) * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-              tile[ml * 64 + nl] = ac[i][j][r] * sc_[j] + bi_[j];
-            }
-        }
-      }
-      // (the residual chunks of this half are requested BEFORE the barrier and all stores follow in one run: with the load
-      // inside the store loop the compiler's wait for it also waited for the previous iteration's store - eight exposed
-      // store latencies per block, 16 of 38 us on the stem layer at 800x1216)
+    for (int i = 0; i < 2; ++i) {
+      const int y = y0 + wave * 2 + i;
       i32x4_t rv[4];
       if constexpr (RES) {
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-          const int idx = it * 256 + tid, ml = idx >> 3, cg = idx & 7;
-          const int y = min(y0 + half * 4 + (ml >> 5), p.Ho - 1), x = min(x0 + (ml & 31), p.Wo - 1);
-          rv[it] = *(const i32x4_t*)((const bf16_t*)p.residual + (((long)n * p.Ho + y) * p.Wo + x) * p.ldres + ch0 + cg * 8);
+          const int idx = it * 64 + lane, ml = idx >> 3, cg = idx & 7;
+          const int yc = min(y, p.Ho - 1), xc = min(x0 + ml, p.Wo - 1);
+          rv[it] = *(const i32x4_t*)((const bf16_t*)p.residual + (((long)n * p.Ho + yc) * p.Wo + xc) * p.ldres + ch0 + cg * 8);
         }
       }
-      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+          wtile[((r & 3) + 8 * (r >> 2) + 4 * lh) * EP_PITCH + j * 32 + lx] = ac[i][j][r] * sc_[j] + bi_[j];
 #pragma unroll
       for (int it = 0; it < 4; ++it) {
-        const int idx = it * 256 + tid, ml = idx >> 3, cg = idx & 7;
-        const int y = y0 + half * 4 + (ml >> 5), x = x0 + (ml & 31);
+        const int idx = it * 64 + lane, ml = idx >> 3, cg = idx & 7;
+        const int x = x0 + ml;
         const long m = ((long)n * p.Ho + y) * p.Wo + x;
-        const f32x4_t lo = *(const f32x4_t*)(tile + ml * 64 + cg * 8), hi = *(const f32x4_t*)(tile + ml * 64 + cg * 8 + 4);
+        const f32x4_t lo = *(const f32x4_t*)(wtile + ml * EP_PITCH + cg * 8), hi = *(const f32x4_t*)(wtile + ml * EP_PITCH + cg * 8 + 4);
         float v[8] = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
         i32x4_t o;
 #pragma unroll
@@ -1743,10 +1741,11 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
     }
     };
     if constexpr (!PW) {
+      LDS_BARRIER();  // every wave is done reading the patch: the staging rows reuse its space
       epilogue(acc, sc2, bi2, 0, p.relu);
     } else {
       // the 3x3's output -> bf16 A fragments: rows = this wave's 64 pixels (wave * 64 + i * 32 + pixel), 128 B = 64 channels
-      __syncthreads();  // every wave is done reading the patch
+      LDS_BARRIER();  // every wave is done reading the patch
 #pragma unroll
       for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1763,7 +1762,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
       for (int i = 0; i < 2; ++i)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) ya[i][ks] = *(const i32x4_t*)(patch + swz(wave * 64 + i * 32 + lx, ks * 2 + lh));
-      // (the first barrier of the staged epilogue below comes before anybody writes the tile: every wave has its fragments by then)
+      LDS_BARRIER();  // every wave has its fragments: the staging rows below overlap the other waves' y2 rows
 #pragma unroll
       for (int cb = 0; cb < 4; ++cb) {  // (unrolled: sc3 / bi3 are register arrays)
         f32x16_t a3[2][2];
@@ -1786,10 +1785,11 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
         epilogue(a3, sc3[cb], bi3[cb], cb * 64, p.pw_relu);
       }
     }
-    __syncthreads();  // tile reads done before the next block's patch overwrites the area
+    LDS_BARRIER();  // tile reads done before the next block's patch overwrites the area
   }
 }
 
+#undef LDS_BARRIER
 // Mid-size layers (the res3 / res4 convs of a real-size image: a few hundred 64x64 tiles, 8 .. 72 K-slabs): one 64x64 tile
 // per CU on four waves is latency-bound (~0.5 us per slab), the 32x32 wave-K-split kernel moves 2x the operand bytes per
 // flop and runs into the L2 bandwidth (res4 3x3 on 3800 pixels: 952 workgroups x 36 slabs x 8 KB = 274 MB in 16 us).
