@@ -1579,16 +1579,26 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
   const int per_img = tiles_y * tiles_x, total = p.Nb * per_img;
   const __amdgpu_buffer_rsrc_t rsrc =
       __builtin_amdgcn_make_buffer_rsrc((void*)p.X, 0, (unsigned)((long)p.Nb * p.H * p.W * 128), 0x00020000);
+  // this thread's 16-byte chunks of a patch: position inside the patch and byte offset relative to the block's first output
+  // pixel, once per workgroup (26 VALU instructions per load otherwise - divisions, 64-bit products - 10 % of a block's cycles
+  // with one wave per SIMD); the buffer offsets are 32-bit (the launcher checks the tensor is < 4 GB)
+  int pyx[P3_NIT], poff[P3_NIT];
+#pragma unroll
+  for (int it = 0; it < P3_NIT; ++it) {
+    const int c = it * 256 + tid, pix = c >> 3, ch = c & 7;
+    const int py = pix / P3_PW, px = pix - py * P3_PW;
+    pyx[it] = c < P3_NCH ? (py | (px << 8)) : -1;
+    poff[it] = ((py - 1) * p.W + (px - 1)) * 128 + ch * 16;
+  }
   auto fetch = [&](int t, i32x4_t (&v)[P3_NIT]) {  // block t's patch -> registers (zero padding = out-of-range offsets)
     const int n = t / per_img, tt = t - n * per_img;
     const int y0 = (tt / tiles_x) * P3_TH, x0 = (tt % tiles_x) * P3_TW;
+    const int base = ((n * p.H + y0) * p.W + x0) * 128;
 #pragma unroll
     for (int it = 0; it < P3_NIT; ++it) {
-      const int c = it * 256 + tid, pix = c >> 3, ch = c & 7;
-      const int py = pix / P3_PW, px = pix - py * P3_PW;
-      const int iy = y0 - 1 + py, ix = x0 - 1 + px;
-      const bool ok = c < P3_NCH && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
-      const unsigned off = ok ? (unsigned)((((long)n * p.H + iy) * p.W + ix) * 128 + ch * 16) : 0xFFFFFFF0u;
+      const int iy = y0 - 1 + (pyx[it] & 0xff), ix = x0 - 1 + ((pyx[it] >> 8) & 0xff);
+      const bool ok = pyx[it] >= 0 && iy >= 0 && iy < p.H && ix >= 0 && ix < p.W;
+      const unsigned off = ok ? (unsigned)(base + poff[it]) : 0xFFFFFFF0u;
       v[it] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 0);
     }
   };
