@@ -18,7 +18,7 @@ _SIGS = {
     "drn_preprocess_nhwc": "piiipiiippip",
     "drn_conv2d_nhwc": "pppppp" + "iiiiiiiiii" + "lll" + "iip",
     "drn_conv2d_nhwc_q": "pppppp" + "iiiiiiiiii" + "lll" + "iiiifp",
-    "drn_conv3x3_pw_nhwc": "pppp" + "i" + "pppp" + "p" + "iii" + "ll" + "f" + "i" + "p",
+    "drn_conv3x3_pw_nhwc": "pppp" + "i" + "pppp" + "p" + "iii" + "ll" + "f" + "ii" + "p",
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
     "drn_roi_pool_nhwc_t": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiiip",

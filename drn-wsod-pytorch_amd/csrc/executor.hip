@@ -52,6 +52,12 @@ int walk(const DrnTrunkOp* ops, int n_ops, int n_slots, int in_slot, int H, int 
   return DRN_OK;
 }
 
+// op `pl` is the 2x2 / stride-2 max pool of conv op `c`'s output, into a slot that exists
+static bool pool_follows(const DrnTrunkOp& pl, const DrnTrunkOp& c, int n_slots, void* const* slots) {
+  return (pl.kind & DRN_TRUNK_KIND_MASK) == DRN_TRUNK_MAXPOOL && pl.stride == 2 && pl.src == c.dst && pl.dst >= 0 &&
+         pl.dst < n_slots && slots[pl.dst] && c.relu;
+}
+
 }  // namespace
 
 extern "C" {
@@ -80,11 +86,11 @@ int drn_trunk_forward(const DrnTrunkOp* ops, int n_ops, int n_slots, int in_slot
                       int C0, int in_dtype, void* stream) {
   if (!slots || Nb <= 0 || H <= 0 || W <= 0) return DRN_ERR_ARG;
   SlotGeom g[DRN_TRUNK_MAX_SLOTS];
-  int fused_tail = -1;  // index of an op that already ran as the 1x1 tail of the previous op's launch
+  int fused_tail = -1, fused_pool = -1;  // ops that already ran inside an earlier op's launch (the 1x1 tail, the max pool)
   return walk(ops, n_ops, n_slots, in_slot, H, W, C0, in_dtype, g, [&](const DrnTrunkOp& o, const SlotGeom& in, const SlotGeom&) {
     if (!slots[o.src] || !slots[o.dst] || (o.res >= 0 && !slots[o.res])) return DRN_ERR_ARG;
     const int idx = (int)(&o - ops);
-    if (idx == fused_tail) return DRN_OK;
+    if (idx == fused_tail || idx == fused_pool) return DRN_OK;
     if ((o.kind & DRN_TRUNK_FUSE_NEXT) && idx + 1 < n_ops) {
       // 3x3 (64 -> 64) whose output only the next op - a 1x1 to 256 channels - reads: one launch on large maps
       // (drn_conv3x3_pw_nhwc; bit-identical to the two), the two launches wherever that kernel does not apply
@@ -95,12 +101,32 @@ int drn_trunk_forward(const DrnTrunkOp* ops, int n_ops, int n_slots, int in_slot
                       n.dtype == DRN_BF16 && n.out_dtype == DRN_BF16 && (n.res < 0 || n.res_dtype == DRN_BF16) &&
                       n.dst >= 0 && n.dst < n_slots && slots[n.dst] && (n.res < 0 || (n.res < n_slots && slots[n.res]));
       if (ok) {
+        // ... and the max pool behind the 1x1, when that op is flagged too (the last block of res2): three ops, one launch
+        const bool pool = (n.kind & DRN_TRUNK_FUSE_POOL) && idx + 2 < n_ops && pool_follows(ops[idx + 2], n, n_slots, slots);
+        if (pool) {
+          const int rc = drn_conv3x3_pw_nhwc(slots[o.src], o.w, o.scale, o.bias, o.relu, n.w, n.scale, n.bias,
+                                             n.res >= 0 ? slots[n.res] : nullptr, slots[ops[idx + 2].dst], Nb, in.h, in.w, o.ldw,
+                                             n.ldw, n.res_mult, n.relu, 1, stream);
+          if (rc == DRN_OK) { fused_tail = idx + 1; fused_pool = idx + 2; return DRN_OK; }
+          if (rc != DRN_ERR_UNSUPPORTED) return rc;
+        }
         const int rc = drn_conv3x3_pw_nhwc(slots[o.src], o.w, o.scale, o.bias, o.relu, n.w, n.scale, n.bias,
                                            n.res >= 0 ? slots[n.res] : nullptr, slots[n.dst], Nb, in.h, in.w, o.ldw, n.ldw,
-                                           n.res_mult, n.relu, stream);
+                                           n.res_mult, n.relu, 0, stream);
         if (rc == DRN_OK) { fused_tail = idx + 1; return DRN_OK; }
         if (rc != DRN_ERR_UNSUPPORTED) return rc;
       }
+    }
+    if ((o.kind & DRN_TRUNK_FUSE_POOL) && !(o.kind & DRN_TRUNK_FUSE_NEXT) && idx + 1 < n_ops &&
+        (o.kind & DRN_TRUNK_KIND_MASK) == DRN_TRUNK_CONV && o.ksize == 3 && o.cin == 64 && o.cout == 64 && o.stride == 1 &&
+        o.pad == 1 && o.dil == 1 && o.relu && o.dtype == DRN_BF16 && o.out_dtype == DRN_BF16 &&
+        (o.res < 0 || o.res_dtype == DRN_BF16) && pool_follows(ops[idx + 1], o, n_slots, slots)) {
+      // a 3x3 / 64 -> 64 conv with the max pool behind it (the deep stem's last conv): the pooled map is all that is written
+      const int rc = drn_conv3x3_pw_nhwc(slots[o.src], o.w, o.scale, o.bias, o.relu, nullptr, nullptr, nullptr,
+                                         o.res >= 0 ? slots[o.res] : nullptr, slots[ops[idx + 1].dst], Nb, in.h, in.w, o.ldw, 0,
+                                         o.res_mult, 0, 1, stream);
+      if (rc == DRN_OK) { fused_pool = idx + 1; return DRN_OK; }
+      if (rc != DRN_ERR_UNSUPPORTED) return rc;
     }
     if ((o.kind & DRN_TRUNK_KIND_MASK) == DRN_TRUNK_CONV)
       return drn_conv2d_nhwc_q(slots[o.src], o.w, slots[o.dst], o.scale, o.bias, o.res >= 0 ? slots[o.res] : nullptr, Nb, in.h,

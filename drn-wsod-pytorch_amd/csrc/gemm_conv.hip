@@ -68,6 +68,9 @@ struct ConvParams {
   const char* pw_w; long pw_ldw;  // [256][pw_ldw] K-major (64 input channels)
   const float* pw_scale; const float* pw_bias;
   int pw_relu;
+  // conv3x3_c64_kernel<.., POOL = true>: nn.MaxPool2d(2, 2) on the (ReLU'd) output, in the epilogue - Y is the POOLED map
+  // [Nb][(Ho - 2) / 2 + 1][(Wo - 2) / 2 + 1][channels]; the full-resolution output is never written
+  int pool;
 };
 
 template <int DT>
@@ -1568,7 +1571,7 @@ constexpr int P3_PW_WTS = 256 * 128;
 // LDS-only barrier: __syncthreads() also waits (vmcnt) for every global store and prefetch load in flight - the block loop
 // below used to drain its output stores and the next block's patch fetch at each of its barriers
 #define LDS_BARRIER() do { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); } while (0)
-template <bool RES, bool PW = false>
+template <bool RES, bool PW = false, bool POOL = false>
 __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* patch = smem;
@@ -1711,6 +1714,7 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
     constexpr int EP_PITCH = 68;
     float* wtile = (float*)(patch + wave * (32 * EP_PITCH * 4));
     auto epilogue = [&](f32x16_t (&ac)[2][2], const float (&sc_)[2], const float (&bi_)[2], int ch0, int relu_) {
+    [[maybe_unused]] int keep[4][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int y = y0 + wave * 2 + i;
@@ -1746,7 +1750,33 @@ __global__ __launch_bounds__(256) void conv3x3_c64_kernel(ConvParams p) {
           if (relu_) { v[2 * e] = fmaxf(v[2 * e], 0.f); v[2 * e + 1] = fmaxf(v[2 * e + 1], 0.f); }
           o[e] = (int)((uint32_t)f32_to_bf16(v[2 * e]) | ((uint32_t)f32_to_bf16(v[2 * e + 1]) << 16));
         }
-        if (y < p.Ho && x < p.Wo) *(i32x4_t*)((bf16_t*)p.Y + m * p.ldy + ch0 + cg * 8) = o;
+        if constexpr (!POOL) {
+          if (y < p.Ho && x < p.Wo) *(i32x4_t*)((bf16_t*)p.Y + m * p.ldy + ch0 + cg * 8) = o;
+        } else {
+          // 2 x 2 / stride-2 maximum of the ReLU'd, bf16-rounded outputs (non-negative: their bit patterns order like
+          // integers): the wave's two output rows are one pooled row - vertical partner = the same thread's piece of row
+          // i = 0, horizontal partner (pixel ml ^ 1) = lane ^ 8
+          if (i == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) keep[it][e] = o[e];
+          } else {
+            typedef short s16x2p_t __attribute__((ext_vector_type(2)));
+            auto pkmax = [](int a, int b) {
+              return __builtin_bit_cast(int, __builtin_elementwise_max(__builtin_bit_cast(s16x2p_t, a), __builtin_bit_cast(s16x2p_t, b)));
+            };
+            int pe[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int mx = pkmax(keep[it][e], o[e]);
+              pe[e] = pkmax(mx, __shfl_xor(mx, 8, 64));
+            }
+            const i32x4_t po = {pe[0], pe[1], pe[2], pe[3]};
+            const int Hp = (p.Ho - 2) / 2 + 1, Wp = (p.Wo - 2) / 2 + 1;
+            const int yp = (y0 >> 1) + wave, xp = (x0 + ml) >> 1;
+            if ((ml & 1) == 0 && yp < Hp && xp < Wp)
+              *(i32x4_t*)((bf16_t*)p.Y + (((long)n * Hp + yp) * Wp + xp) * p.ldy + ch0 + cg * 8) = po;
+          }
+        }
       }
     }
     };
@@ -2139,21 +2169,29 @@ static int launch_conv3x3_c64(const ConvParams& p, hipStream_t st) {
   return DRN_OK;
 }
 
-static int launch_conv3x3_c64_pw(const ConvParams& p, hipStream_t st) {
-  const int tiles = p.Nb * ((p.Ho + P3_TH - 1) / P3_TH) * ((p.Wo + P3_TW - 1) / P3_TW);
-  constexpr int smem = P3_PATCH + P3_WTS + P3_PW_WTS;  // 146.5 KB: one workgroup per CU
+template <bool RES, bool PW, bool POOL>
+static int launch_c64_variant(const ConvParams& p, int nwg, int smem, hipStream_t st) {
   static bool attr = false;
   if (!attr) {
-    if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess ||
-        hipFuncSetAttribute((const void*)conv3x3_c64_kernel<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+    if (hipFuncSetAttribute((const void*)conv3x3_c64_kernel<RES, PW, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
       return DRN_ERR_LAUNCH;
     attr = true;
   }
-  const int nwg = tiles < cu_count() ? tiles : cu_count();
-  if (p.residual) hipLaunchKernelGGL((conv3x3_c64_kernel<true, true>), dim3(nwg), dim3(256), smem, st, p);
-  else hipLaunchKernelGGL((conv3x3_c64_kernel<false, true>), dim3(nwg), dim3(256), smem, st, p);
+  hipLaunchKernelGGL((conv3x3_c64_kernel<RES, PW, POOL>), dim3(nwg), dim3(256), smem, st, p);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
+}
+// the fused forms (drn_conv3x3_pw_nhwc): [3x3] [+ 1x1 to 256 channels] [+ 2x2 max pool]
+static int launch_conv3x3_c64_pw(const ConvParams& p, hipStream_t st) {
+  const int tiles = p.Nb * ((p.Ho + P3_TH - 1) / P3_TH) * ((p.Wo + P3_TW - 1) / P3_TW);
+  const bool pw = p.pw_w != nullptr, res = p.residual != nullptr, pool = p.pool != 0;
+  const int smem = P3_PATCH + P3_WTS + (pw ? P3_PW_WTS : 0);  // 117 / 146.5 KB: one workgroup per CU
+  const int nwg = tiles < cu_count() ? tiles : cu_count();
+#define C64_CASE(R_, W_, P_) if (res == R_ && pw == W_ && pool == P_) return launch_c64_variant<R_, W_, P_>(p, nwg, smem, st)
+  C64_CASE(false, true, false); C64_CASE(true, true, false); C64_CASE(false, true, true); C64_CASE(true, true, true);
+  C64_CASE(false, false, true); C64_CASE(true, false, true);
+#undef C64_CASE
+  return DRN_ERR_UNSUPPORTED;  // (no 1x1 and no pool: drn_conv2d_nhwc's own class)
 }
 
 template <int DT, bool K64 = true>
@@ -2486,21 +2524,24 @@ int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda,
 
 // NHWC conv + per-channel affine (folded FrozenBN or bias) + optional residual + optional ReLU; `dtype` is the element
 // type of x / w (fp32, bf16 or fp8 e4m3fn), y and the residual may be stored in another one (see include/drn_wsod.h).
-// The tail of a 64-channel bottleneck on a large map as ONE launch (conv3x3_c64_kernel<.., PW>): the 3x3's output never
-// goes to memory.  Same shape class as the LDS-resident-patch kernel takes on its own; anything else: DRN_ERR_UNSUPPORTED
-// (the caller runs the two convolutions).
+// The tail of a 64-channel bottleneck on a large map as ONE launch (conv3x3_c64_kernel<.., PW, POOL>): the 3x3's output never
+// goes to memory; w3 == NULL: no 1x1 stage (y has 64 channels, the residual - if any - too); pool: MaxPool2d(2, 2) in the
+// epilogue (needs the last ReLU).  Same shape class as the LDS-resident-patch kernel takes on its own; anything else:
+// DRN_ERR_UNSUPPORTED (the caller runs the separate launches).
 int drn_conv3x3_pw_nhwc(const void* x, const void* w2, const float* scale2, const float* bias2, int relu2, const void* w3,
                         const float* scale3, const float* bias3, const void* residual, void* y, int Nb, int H, int W,
-                        long ldw2, long ldw3, float res_mult, int relu3, void* stream) {
-  if (!x || !w2 || !w3 || !y || Nb <= 0 || H <= 0 || W <= 0) return DRN_ERR_ARG;
+                        long ldw2, long ldw3, float res_mult, int relu3, int pool, void* stream) {
+  if (!x || !w2 || !y || Nb <= 0 || H <= 0 || W <= 0) return DRN_ERR_ARG;
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   if (!g_conv_patch || g_conv_coresident || (long)H * W < g_conv_patch_min || (long)Nb * H * W * 128 >= 0xFFFFFFF0L ||
-      ldw2 < 9 * 64 || ldw3 < 64 || (ldw2 * 2) % 16 != 0 || (ldw3 * 2) % 16 != 0 || !al16(x) || !al16(w2) || !al16(w3) ||
-      !al16(y) || (residual && !al16(residual)))
+      ldw2 < 9 * 64 || (w3 && ldw3 < 64) || (ldw2 * 2) % 16 != 0 || (w3 && (ldw3 * 2) % 16 != 0) || !al16(x) || !al16(w2) ||
+      (w3 && !al16(w3)) || !al16(y) || (residual && !al16(residual)) || (!w3 && !pool) ||
+      (pool && (!(w3 ? relu3 : relu2) || H < 2 || W < 2)))
     return DRN_ERR_UNSUPPORTED;
+  const int cy = w3 ? 256 : 64;
   ConvParams p{(const char*)x, (const char*)w2, (char*)y, scale2, bias2, (const char*)residual, Nb, H, W, 64, H, W,
-               64, 3, 3, 1, 1, 1, relu2, 9 * 64, ldw2, 256, 256, DRN_BF16, DRN_BF16, res_mult, 0,
-               (const char*)w3, ldw3, scale3, bias3, relu3};
+               64, 3, 3, 1, 1, 1, relu2, 9 * 64, ldw2, cy, cy, DRN_BF16, DRN_BF16, res_mult, 0,
+               (const char*)w3, ldw3, scale3, bias3, relu3, pool};
   return launch_conv3x3_c64_pw(p, (hipStream_t)stream);
 }
 

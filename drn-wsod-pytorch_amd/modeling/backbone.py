@@ -111,6 +111,37 @@ class _PlanBuilder:
                     and (i + 1) not in pinned and o["dtype"] == bf and o["out_dtype"] == bf and n["dtype"] == bf
                     and n["out_dtype"] == bf and (n["res"] < 0 or n["res_dtype"] == bf)):
                 o["kind"] |= 0x100
+        # ... and a conv whose (ReLU'd, bf16) output only the next op reads, a 2x2 / stride-2 max pool: the deep stem's last 3x3
+        # (64 -> 64) and the 1x1 of a flagged pair - the pool then runs in that launch's epilogue (DRN_TRUNK_FUSE_POOL)
+        for i in range(len(self.ops) - 1 if getattr(self, "fuse_tails", True) else 0):
+            o, n = self.ops[i], self.ops[i + 1]
+            if (o["kind"] & 0xff) != 0 or n["kind"] != 1 or n["stride"] != 2 or n["src"] != i + 1 or readers.get(i + 1) != 1 \
+                    or (i + 1) in pinned or not o["relu"] or o["dtype"] != bf or o["out_dtype"] != bf:
+                continue
+            stem3 = (o["ksize"] == 3 and o["cin"] == 64 and o["cout"] == 64 and o["stride"] == 1 and o["pad"] == 1
+                     and o["dil"] == 1 and not (o["kind"] & 0x100) and (o["res"] < 0 or o["res_dtype"] == bf))
+            tail = i > 0 and (self.ops[i - 1]["kind"] & 0x100) != 0
+            if stem3 or tail:
+                o["kind"] |= 0x200
+        # a fused group is ONE launch: everything its ops read must stay alive until its LAST op has its output slot (the
+        # two-launch form may reuse conv2's input slot for conv3's output, or the shortcut's slot for the pooled map - the
+        # one-launch form reads those while it writes)
+        i = 0
+        while i < len(self.ops):
+            end = i
+            if self.ops[i]["kind"] & 0x100:
+                end = i + 1
+            if self.ops[end]["kind"] & 0x200:
+                end += 1
+            if end > i:
+                for q in range(i, end + 1):
+                    for v in {self.ops[q]["src"], self.ops[q]["res"]} - {-1}:
+                        if v <= i:  # (values defined inside the group are its private intermediates)
+                            last[v] = max(last.get(v, 0), end)
+            i = end + 1
+        free_at = {}
+        for v, i_last in last.items():
+            free_at.setdefault(i_last, []).append(v)
         slot_of, free, n_slots = {0: 0}, [], 1
         arr = (C.DrnTrunkOp * max(len(self.ops), 1))()
         for i, o in enumerate(self.ops):
@@ -126,8 +157,8 @@ class _PlanBuilder:
                     val = slot_of[val] if val >= 0 else -1
                 setattr(a, k, val)
             a.dst = slot
-            for val in {o["src"], o["res"]} - {-1}:
-                if last.get(val) == i and val not in pinned:
+            for val in sorted(free_at.get(i, ())):  # values whose last reader (or whose fused group) ends here
+                if val not in pinned:
                     free.append(slot_of[val])
             if dst_val not in last and dst_val not in pinned:  # never read (cannot happen in the built trunks)
                 free.append(slot)

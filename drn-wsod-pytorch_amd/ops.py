@@ -199,18 +199,21 @@ def conv2d_nhwc_q(x, w_packed, cout, kh, kw, stride, pad, dil, scale, bias, out_
     return y
 
 
-def conv3x3_pw_nhwc(x, w2_packed, scale2, bias2, relu2, w3_packed, scale3, bias3, residual=None, res_mult=1.0, relu3=True,
-                    out=None):
-    """drn_conv3x3_pw_nhwc: 3x3 (64 -> 64, pad 1) -> act -> 1x1 (64 -> 256) + residual -> act as one launch; x [N,H,W,64]
-    bf16.  Returns y [N,H,W,256], or None when the shape is outside the kernel's class (run the two convolutions)."""
+def conv3x3_pw_nhwc(x, w2_packed, scale2, bias2, relu2, w3_packed=None, scale3=None, bias3=None, residual=None, res_mult=1.0,
+                    relu3=True, pool=False, out=None):
+    """drn_conv3x3_pw_nhwc: 3x3 (64 -> 64, pad 1) -> act [-> 1x1 (64 -> 256) + residual -> act] [-> 2x2 / stride-2 max pool] as
+    one launch; x [N,H,W,64] bf16.  Returns y, or None when the shape is outside the kernel's class (run the separate ops)."""
     assert x.is_contiguous() and x.dim() == 4 and x.shape[3] == 64 and x.dtype == torch.bfloat16
     n, h, w, _ = x.shape
-    y = out if out is not None else torch.empty((n, h, w, 256), dtype=x.dtype, device=x.device)
+    cy = 256 if w3_packed is not None else 64
+    ho, wo = ((h - 2) // 2 + 1, (w - 2) // 2 + 1) if pool else (h, w)
+    y = out if out is not None else torch.empty((n, ho, wo, cy), dtype=x.dtype, device=x.device)
     if residual is not None:
-        assert residual.shape == y.shape and residual.is_contiguous() and residual.dtype == x.dtype
+        assert residual.shape == (n, h, w, cy) and residual.is_contiguous() and residual.dtype == x.dtype
     rc = C.lib().drn_conv3x3_pw_nhwc(C.ptr(x), C.ptr(w2_packed), C.ptr(scale2), C.ptr(bias2), int(relu2), C.ptr(w3_packed),
                                      C.ptr(scale3), C.ptr(bias3), C.ptr(residual), C.ptr(y), n, h, w, _2d(w2_packed),
-                                     _2d(w3_packed), float(res_mult), int(relu3), C.stream())
+                                     _2d(w3_packed) if w3_packed is not None else 0, float(res_mult), int(relu3), int(pool),
+                                     C.stream())
     if rc == -3:
         return None
     if rc != 0:

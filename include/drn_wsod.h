@@ -60,15 +60,19 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
                       int res_dtype, float res_mult, void* stream);
 
 /* The tail of a 64-channel bottleneck block on a large map as ONE launch (BottleneckBlock.forward,
- * projects/WSL/wsl/modeling/backbone/resnet_ws.py:217-237: conv2 -> relu -> conv3 -> + shortcut -> relu):
- * y [Nb*H*W][256] = act3((conv1x1(act2(conv3x3(x) * scale2 + bias2)) * scale3 + bias3) + residual * res_mult), bf16;
+ * projects/WSL/wsl/modeling/backbone/resnet_ws.py:217-237: conv2 -> relu -> conv3 -> + shortcut -> relu [-> max pool]):
+ * y = pool(act3((conv1x1(act2(conv3x3(x) * scale2 + bias2)) * scale3 + bias3) + residual * res_mult)), bf16;
  * x [Nb][H][W][64], w2 [64][ldw2] (3x3, pad = dil = stride = 1, packed as for drn_conv2d_nhwc), w3 [256][ldw3] (1x1 over
- * 64 channels), residual [Nb*H*W][256] or NULL.  The 3x3's output - rounded to bf16 exactly as drn_conv2d_nhwc would
- * store it - stays in LDS: bit for bit the result of the two drn_conv2d_nhwc calls.  Maps of >= 32768 pixels per image
- * (the LDS-resident-patch kernel's class); DRN_ERR_UNSUPPORTED otherwise (callers then run the two convolutions). */
+ * 64 channels), residual [Nb*H*W][256] or NULL, y [Nb*H*W][256].  The 3x3's output - rounded to bf16 exactly as
+ * drn_conv2d_nhwc would store it - stays in LDS: bit for bit the result of the separate calls.
+ * w3 == NULL: no 1x1 stage (the deep stem's last 3x3: y and the residual have 64 channels; needs pool).
+ * pool != 0: nn.MaxPool2d(2, 2) (resnet_ws.py:214-215) applied in the epilogue - y is the pooled map
+ * [Nb][(H - 2) / 2 + 1][(W - 2) / 2 + 1][channels], the full-resolution output is never written; needs the last ReLU.
+ * Maps of >= 32768 pixels per image (the LDS-resident-patch kernel's class); DRN_ERR_UNSUPPORTED otherwise (callers then
+ * run the separate launches). */
 int drn_conv3x3_pw_nhwc(const void* x, const void* w2, const float* scale2, const float* bias2, int relu2, const void* w3,
                         const float* scale3, const float* bias3, const void* residual, void* y, int Nb, int H, int W,
-                        long ldw2, long ldw3, float res_mult, int relu3, void* stream);
+                        long ldw2, long ldw3, float res_mult, int relu3, int pool, void* stream);
 
 /* nn.MaxPool2d(kernel_size=2, stride=s, padding=0), resnet_ws.py:214-215,403; vgg.py:99-100.  DRN_FP8: non-negative
  * (post-ReLU) values only - they order like their bytes. */
@@ -457,6 +461,7 @@ int drn_csc_loss(const float* logits, long ld, int c_cls, int c_det, int K, int 
 #define DRN_TRUNK_MAXPOOL 1
 #define DRN_TRUNK_MAX_SLOTS 16
 #define DRN_TRUNK_KIND_MASK 0xff
+#define DRN_TRUNK_FUSE_POOL 0x200 /* flag on a conv op: its output is read by the NEXT op alone, a 2x2 / stride-2 max pool - may run inside the conv's launch (drn_conv3x3_pw_nhwc with pool = 1; with DRN_TRUNK_FUSE_NEXT on the op before it: three ops, one launch) */
 #define DRN_TRUNK_FUSE_NEXT 0x100 /* flag on a 3x3 / 64 -> 64 conv op: its output is read by the NEXT op alone, a 1x1 conv to 256 channels - the executor may run the pair as one drn_conv3x3_pw_nhwc launch (the dst slot is then not written) */
 typedef struct DrnTrunkOp {
   int kind;           /* DRN_TRUNK_CONV | DRN_TRUNK_MAXPOOL, optionally | DRN_TRUNK_FUSE_NEXT */

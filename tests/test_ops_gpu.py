@@ -517,6 +517,15 @@ def test_conv3x3_pw_equals_two_convs(drn, case):
     assert float(ref.float().abs().max()) > 0
     small = xd[:, :40, :40].contiguous()
     assert drn.conv3x3_pw_nhwc(small, wp2, s2, b2, True, wp3, s3, b3, None, 1.0, True) is None
+    # ... with nn.MaxPool2d(2, 2) in the epilogue (odd heights / widths drop their last row / column): the pooled map only
+    gotp = drn.conv3x3_pw_nhwc(xd, wp2, s2, b2, True, wp3, s3, b3, res, 1.0, True, pool=True)
+    assert gotp is not None and torch.equal(gotp, drn.maxpool2x2_nhwc(ref, 2))
+    # ... and without the 1x1 stage (the deep stem's last 3x3 + pool); the 64-channel residual of a basic block
+    r64 = _rnd((n, h, w, 64), 67).to(DEV).to(dtype) if has_res else None
+    ref64 = drn.maxpool2x2_nhwc(drn.conv2d_nhwc(xd, wp2, 64, 3, 3, 1, 1, 1, s2, b2, r64, True), 2)
+    got64 = drn.conv3x3_pw_nhwc(xd, wp2, s2, b2, True, residual=r64, pool=True)
+    assert got64 is not None and torch.equal(got64, ref64)
+    assert drn.conv3x3_pw_nhwc(xd, wp2, s2, b2, False, pool=True) is None  # a pool without the ReLU in front is refused
 
 
 @pytest.mark.parametrize("dtype", DTYPES)
