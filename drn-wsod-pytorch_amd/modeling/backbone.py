@@ -8,6 +8,7 @@ Execution is MI355X-first: every block runs NHWC, each conv is one implicit-GEMM
 FrozenBN affine + residual add + ReLU fused in its epilogue, pools are vectorised NHWC kernels; the
 [N,C,H,W] tensors returned by forward() are channels-last views of those buffers."""
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -50,6 +51,9 @@ class _PlanBuilder:
     """Records the trunk's layer sequence as `DrnTrunkOp`s (include/drn_wsod.h) over VALUES (one per layer output), then
     maps the values to a handful of reusable activation slots by their last use.  The entries mirror what
     Conv2d.run_nhwc / _run_fp8 and _pool pass to the per-layer entry points, so a plan issues the same launches."""
+
+    # fused groups (3x3 + 1x1 tail, max pool in the conv's epilogue) flagged in the plans; DRN_FUSE_TAILS=0: A/B runs
+    fuse_tails = os.environ.get("DRN_FUSE_TAILS", "1") != "0"
 
     def __init__(self, in_dtype, in_channels):
         self.vals = [dict(dtype=in_dtype, scale=1.0, c=in_channels)]  # value 0: the (normalised, padded) image
