@@ -287,7 +287,7 @@ def main():
                     help="N=1 only: fc6 dW GEMM with the SGD update as its epilogue (drn_gemm_nt_sgd; measured "
                          "neutral: its HBM-heavy epilogues run in lock-step across CUs, see DESIGN.md)")
     ap.add_argument("--pool-overlap", type=int, default=0,
-                    help="1 = the next batch's pooling piece on its own stream beside the fc6 dW tail (the two operand sets alternate)")
+                    help="1 = the next batch's pooling piece on its own stream beside the fc6 dW tail (the two operand sets alternate); 2 = its pooling kernel beside the heads chain instead (both measured slower than the serial order)")
     ap.add_argument("--fused-tn", type=int, default=-1, choices=[-1, 0, 1],
                     help="N=1 (default -1 = the engine's choice: on for R50 / VGG16 trunks): fc6 dW + SGD in ONE launch with the update of each tile pipelined into the next tile's "
                          "mainloop (drn_gemm_tn_sgd); 0 = two row slabs + sgd_kernel on the optimizer stream (round 3)")
@@ -467,7 +467,7 @@ def main():
         stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead,
                                    trunk_pairs=(args.trunk_group if args.trunk_pairs else False), eager_fc6=not args.no_eager_fc6,
                                    stage_ahead=not args.no_stage_ahead, eager_pool=not args.graph_pool,
-                                   pool_overlap=bool(args.pool_overlap))
+                                   pool_overlap=int(args.pool_overlap))
         for k_, v_ in step_opts.items():
             setattr(stepper, k_, v_)
         try:

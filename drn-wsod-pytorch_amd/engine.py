@@ -1094,8 +1094,8 @@ class GraphedTrainStep:
         self._primed = False
         # pool_overlap: the next batch's pooling piece on its own stream beside the dW tail, the two fc6 operand sets
         # alternating (_run_pairs_overlap); needs the eager pieces around the heads graph
-        self.pool_overlap = bool(pool_overlap) and bool(split_tail) and self.eager_fc6 and self.eager_pool and \
-            self.trunk_pairs and self.engine.kshard is None
+        self.pool_overlap = int(pool_overlap) if (bool(pool_overlap) and bool(split_tail) and self.eager_fc6 and self.eager_pool
+                                                  and self.trunk_pairs and self.engine.kshard is None) else 0
         self._pool_stream = torch.cuda.Stream() if self.pool_overlap else None
         self._pool_done = None
         self._pooled_slot = [None, None]
@@ -1365,12 +1365,13 @@ class GraphedTrainStep:
         with torch.no_grad():
             self._pfeats[ps].copy_(self._pair_backbone(ps))
 
-    def _pair_pool_body(self, ps, half, slot=0):
+    def _pair_pool_body(self, ps, half, slot=0, stage=True):
         with torch.no_grad():
             n = self.n_img
             # in front of the pooling kernel (see _pool_next)
-            ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if self.stage_ahead else None,
-                                   self._gt_block if self.stage_ahead else None)
+            if stage:
+                ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if self.stage_ahead else None,
+                                       self._gt_block if self.stage_ahead else None)
             if self.engine.kshard is not None:
                 self.pooled = self.engine.pool_kshard(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next)
                 return
@@ -1391,6 +1392,8 @@ class GraphedTrainStep:
             main.wait_event(self._pool_done)  # this batch's operand set (pooled during the previous step)
         self._side.wait_stream(main)
         self.pooled = self._pooled_slot[t & 1]
+        if self.pool_overlap == 2:
+            return self._run_pairs_under_heads(eager, next_batch, *ahead)
         losses = self._heads(eager)
         ev_heads = torch.cuda.Event()
         ev_heads.record(main)
@@ -1427,6 +1430,65 @@ class GraphedTrainStep:
             if t % G == 0:
                 ps = (t // G + 1) % 2
                 self._side.wait_event(self._pool_done)  # (pair slot ps was last read by the pooling of batch t-1: long done)
+                self._pair_stage(ahead[G - 2: 2 * G - 2], ps)
+                self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
+                ev = torch.cuda.Event()
+                ev.record(self._side)
+                self._pdone[ps] = ev
+        if self.split_tail:
+            self.opt.step(1.0)
+        self._t = t + 1
+        return losses
+
+    def _run_pairs_under_heads(self, eager, next_batch, *ahead):
+        """pool_overlap = 2: the pooling KERNEL of batch t+1 beside the heads chain of step t instead of beside the dW tail.
+        The chain between the fc6 forward and the dW launch is ~0.25 ms of small, latency-bound launches (plus two mid-size
+        GEMMs) that leave most CUs and most of the power budget idle, and the pooling kernel needs nothing from step t: it reads
+        the staged proposals (`rois_next` / `obj_next`, written on the side stream at the top of the step), the next batch's
+        features (ready since its group's conv chain) and writes the OTHER operand set.  Only the copy of the staged proposals /
+        labels into the heads graph's input blocks has to wait for the graph - it follows it on the main stream."""
+        main = torch.cuda.current_stream()
+        t = self._t
+        eng = self.engine
+        G = self.G
+        ps_ = self._pool_stream
+        ps_.wait_stream(main)  # (rois_next / the label stage were last read at the end of the previous step, on the main stream)
+        with torch.cuda.stream(ps_):  # (not the side stream: a group's conv chain may be queued there)
+            self._stage_props(next_batch)
+            if self.stage_ahead:
+                self._stage_labels_ahead(next_batch, via_stage=True)
+            evp = torch.cuda.Event()
+            evp.record(ps_)
+        self._fc6_eager()
+        ev_fwd = torch.cuda.Event()
+        ev_fwd.record(main)  # the pooling starts when the fc6 forward - a GEMM at the power cap - is through
+        k1, h1 = ((t + 1) // G) % 2, (t + 1) % G
+        ps_.wait_event(ev_fwd)
+        ps_.wait_event(self._pdone[k1])
+        with torch.cuda.stream(ps_):
+            cur = self.pooled
+            self._pair_pool_body(k1, h1, slot=(t + 1) & 1, stage=False)
+            self._pooled_slot[(t + 1) & 1] = self.pooled
+            self.pooled = cur
+            self._pool_done = torch.cuda.Event()
+            self._pool_done.record(ps_)
+        if hasattr(self.opt, "join"):
+            self.opt.join()
+        losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
+        if self.split_tail:
+            tl = list(eng._tail)
+            tl[1], tl[6], tl[8] = self.pooled["AT"], self.pooled["A"], self.pooled.get("t_row0", 0)
+            eng._tail = tuple(tl)
+            eng.run_fc1_tail()
+        # the next heads graph's input blocks (proposal boxes, labels): behind this step's graph, their last reader
+        main.wait_event(evp)
+        with torch.no_grad():
+            ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if self.stage_ahead else None,
+                                   self._gt_block if self.stage_ahead else None)
+        with torch.cuda.stream(self._side):
+            if t % G == 0:
+                ps = (t // G + 1) % 2
+                self._side.wait_event(self._pool_done)
                 self._pair_stage(ahead[G - 2: 2 * G - 2], ps)
                 self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
                 ev = torch.cuda.Event()

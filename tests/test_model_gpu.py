@@ -515,7 +515,7 @@ def test_pool_overlap_schedule_equals_serial_pooling(precision):
     b2 = G.drn_inputs([alt2])
     seq = [b0, b1, b2, b0, b1, b1, b0, b2, b1, b0, b2, b2, b1]
     res = []
-    for overlap in (False, True):
+    for overlap in (0, 1, 2):  # 2: the pooling kernel beside the heads chain (issued behind the fc6 forward), not beside the tail
         cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, precision)
         model.roi_heads.box_head.dropout_p = 0.0
         model.train()
@@ -530,9 +530,10 @@ def test_pool_overlap_schedule_equals_serial_pooling(precision):
         torch.cuda.synchronize()
         res.append((out, model.roi_heads._engine.arena_w.clone()))
         del stepper, model, opt
-    for a, b in zip(res[0][0], res[1][0]):
-        assert a == b
-    assert torch.equal(res[0][1], res[1][1])
+    for other in (1, 2):
+        for a, b in zip(res[0][0], res[other][0]):
+            assert a == b, other
+        assert torch.equal(res[0][1], res[other][1]), other
     load_package().set_precision("fp32")
 
 
