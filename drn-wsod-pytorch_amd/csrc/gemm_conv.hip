@@ -16,6 +16,7 @@
 // F.conv2d + FrozenBatchNorm2d + relu_ + residual add (detectron2/layers/wrappers.py:94-99,
 // detectron2/layers/batch_norm.py:45-65, projects/WSL/wsl/modeling/backbone/resnet_ws.py:217-237).
 #include "drn_common.h"
+#include "conv_params.h"
 
 #include <type_traits>
 #include <utility>
@@ -47,31 +48,7 @@ struct GemmParams {
   int kb_rows;
 };
 
-struct ConvParams {
-  const char* X;
-  const char* Wt;   // [Cout][ldw] K-major, k = (kh*KW + kw)*Cin + ci
-  char* Y;          // [Nb*Ho*Wo][ldy]
-  const float* scale;  // per Cout (FrozenBN folded) or null => 1
-  const float* bias;   // per Cout or null => 0
-  const char* residual;  // same layout as Y, or null
-  int Nb, H, W, Cin, Ho, Wo, Cout, KH, KW, stride, pad, dil, relu;
-  int Ktot;  // KH*KW*Cin
-  long ldw, ldy, ldres;
-  // quantised trunk (drn_conv2d_nhwc_q): the output / residual element types may differ from the input's (bf16 stem ->
-  // fp8, fp8 -> bf16 feature map), and an fp8 residual carries its own per-tensor scale (res_mult = s_out / s_res)
-  int out_dt, res_dt;
-  float res_mult;
-  int fp8_k64;  // fp8 operands: 1 = the K = 64 scaled MFMA (fp8 rate), 0 = the K = 16 form (DRN_TUNE_FP8_K64)
-  // conv3x3_c64_kernel<.., PW = true> (drn_conv3x3_pw_nhwc): a 1x1 convolution 64 -> 256 channels on this conv's output,
-  // which never leaves the chip - the tail of a res2 bottleneck.  Y / ldy / residual / ldres / res_mult then belong to THAT
-  // layer (256 channels), scale / bias / relu above to the 3x3, pw_* to the 1x1
-  const char* pw_w; long pw_ldw;  // [256][pw_ldw] K-major (64 input channels)
-  const float* pw_scale; const float* pw_bias;
-  int pw_relu;
-  // conv3x3_c64_kernel<.., POOL = true>: nn.MaxPool2d(2, 2) on the (ReLU'd) output, in the epilogue - Y is the POOLED map
-  // [Nb][(Ho - 2) / 2 + 1][(Wo - 2) / 2 + 1][channels]; the full-resolution output is never written
-  int pool;
-};
+using drn_conv::ConvParams;
 
 template <int DT>
 __device__ __forceinline__ void mma_step(f32x16_t& acc, const i32x4_t& a, const i32x4_t& b) {
@@ -2238,6 +2215,10 @@ static long tail_split_main_cols(int M, int N, int splits, int nwg) {
 
 static int g_force_tile = 0;  // 0 = heuristic; 64 / 128 / 256 pin the tile (tuning + tests)
 
+// conv_ring.hip: the register-ring kernels (bf16, Cin % 64 == 0); DRN_ERR_UNSUPPORTED outside their class
+__attribute__((visibility("hidden"))) int drn_conv_ring_try(const ConvParams& p, int dtype, int cus, bool small_map, hipStream_t st);
+__attribute__((visibility("hidden"))) int drn_conv_ring_set(int v);
+
 extern "C" {
 
 // tuning/test hook: pin the GEMM tile (0 restores the heuristic). Returns the previous value.
@@ -2321,6 +2302,7 @@ int drn_tune(int knob, int value) {
     g_sgdp_ep4 = value != 0;
     return old;
   }
+  if (knob == 23) return drn_conv_ring_set(value);  // DRN_TUNE_CONV_RING
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
     const int old = g_group_rows;
     if (value >= 0 && value <= 64) g_group_rows = value;
@@ -2590,6 +2572,12 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
       (ldy & 7) == 0 && (((uintptr_t)y) & 15) == 0 && (!residual || ((ldres & 7) == 0 && (((uintptr_t)residual) & 15) == 0)) &&
       (ldw * 2) % 16 == 0 && (((uintptr_t)w) & 15) == 0)
     return launch_conv3x3_c64(p, st);
+  // everything beyond the latency-bound small maps: the register-ring kernels (conv_ring.hip; bf16, Cin % 64 == 0).  Decided on
+  // ONE image's geometry: the small-map kernels below add their K partials in another order
+  {
+    const int rc = drn_conv_ring_try(p, dtype, cu_count(), tiles64 <= cu_count() / 4, st);
+    if (rc != DRN_ERR_UNSUPPORTED) return rc;
+  }
   // two K-groups per 64x64 tile (conv_nhwc_k2_kernel): mid-size layers - more 64x64 tiles than the wave-K-split kernel
   // takes, at most one per CU (the kernel keeps one 512-thread workgroup per CU) - with an even slab count >= 8
   const long k2_max = g_conv_k2_tiles >= 0 ? g_conv_k2_tiles : cu_count();

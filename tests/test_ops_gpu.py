@@ -493,6 +493,60 @@ def test_conv2d_wave_k_split(drn, dtype, case):
         assert (ys[0].float() - tiled.float()).abs().max() <= 2 ** -7 * float(tiled.float().abs().max())
 
 
+@pytest.mark.parametrize("case", [(1, 50, 76, 256, 256, 3, 1, 1, 1, False, True),     # res4 3x3 at 800x1216 (36 slabs, 240 64x64 tiles)
+                                  (1, 50, 76, 512, 512, 3, 1, 2, 2, False, True),     # dilated res5 3x3 of the DC5 trunk (72 slabs)
+                                  (1, 50, 76, 1024, 256, 1, 1, 0, 1, False, True),    # res4 conv1
+                                  (1, 50, 76, 256, 1024, 1, 1, 0, 1, True, True),     # res4 conv3 + shortcut (4 slabs)
+                                  (1, 100, 152, 128, 128, 3, 1, 1, 1, False, True),   # res3 3x3
+                                  (1, 100, 152, 128, 512, 1, 1, 0, 1, True, True),    # res3 conv3: 2 slabs (< ring depth)
+                                  (1, 131, 97, 64, 72, 1, 1, 0, 1, True, False),      # ONE slab, ragged M and a ragged column tile
+                                  (2, 61, 67, 64, 136, 3, 2, 1, 1, True, True),       # stride 2, two images, Cout % 64 != 0
+                                  (3, 45, 52, 192, 200, 3, 1, 3, 3, False, False)])   # dilation 3, three slabs per tap
+def test_conv_ring_kernels(drn, case):
+    """conv_ring_kernel<64x64 | 128x128> (register ring of prefetched K slabs + two LDS stages behind ONE LDS-only barrier per
+    slab, im2col by per-lane buffer offsets on a per-row tap-validity mask; the bf16 trunk layers beyond the small maps) == the
+    register-staged tiled kernel bit for bit (same slab order, k-steps and MFMA per output element) for every tile shape, and
+    within bf16 rounding of F.conv2d; zero padding at every border, ragged M / Cout tiles, fewer slabs than ring slots,
+    stride, dilation, residual."""
+    n, h, w, cin, cout, k, stride, pad, dil, has_res, relu = case
+    dtype = torch.bfloat16
+    x = _rnd((n, cin, h, w), 35)
+    wt = _rnd((cout, cin, k, k), 36, math.sqrt(2.0 / (cin * k * k)))
+    scale, bias = (0.8 + 0.2 * torch.rand(cout)).to(DEV), _rnd((cout,), 37, 0.1).to(DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    ref = F.conv2d(_q(x, dtype), _q(wt, dtype), None, stride, pad, dil) * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1)
+    res = None
+    if has_res:
+        res = _rnd(tuple(ref.shape), 38)
+        ref = ref + _q(res, dtype)
+        res = res.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    if relu:
+        ref = F.relu(ref)
+    wp = _pack_w(wt, dtype, drn, cin)
+    run = lambda: drn.conv2d_nhwc(xd, wp, cout, k, k, stride, pad, dil, scale, bias, res, relu)
+    assert drn.tune(drn.TUNE_CONV_RING, 0) == 1
+    k2 = drn.tune(drn.TUNE_CONV_K2_TILES, 0)
+    ks = drn.tune(drn.TUNE_CONV_KSPLIT, 0)
+    try:
+        tiled = run()  # conv_nhwc_kernel<64x64 | 128x128>
+        ys = {}
+        for pin in (64, 128, 1):
+            drn.tune(drn.TUNE_CONV_RING, pin)
+            ys[pin] = run()
+        drn.tune(drn.TUNE_CONV_RING, 64)
+        again = run()
+    finally:
+        drn.tune(drn.TUNE_CONV_RING, 1)
+        drn.tune(drn.TUNE_CONV_K2_TILES, k2)
+        drn.tune(drn.TUNE_CONV_KSPLIT, ks)
+    torch.cuda.synchronize()
+    for pin, y in ys.items():
+        assert torch.equal(y, tiled), (pin, float((y.float() - tiled.float()).abs().max()))
+    assert torch.equal(again, tiled)
+    got = tiled.float().cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
+
+
 @pytest.mark.parametrize("case", [(1, 203, 181, True), (2, 184, 192, True), (1, 181, 203, False)])
 def test_conv3x3_pw_equals_two_convs(drn, case):
     """drn_conv3x3_pw_nhwc (the tail of a res2 bottleneck - 3x3 64 -> 64, ReLU, 1x1 64 -> 256, + shortcut, ReLU - as ONE launch,
