@@ -221,6 +221,59 @@ def hbm_rooflines(model, batch, R, device, ops, opt=None):
     return out
 
 
+def trunk_roofline(pkg, device, workload, hw=(800, 1216), reps=5):
+    """The frozen trunk of `workload` (r50c4: the constructed C4 trunk of BASELINE configs[1]; r50dc5: the SHIPPED recipe,
+    projects/WSL/configs/PascalVOC-Detection/oicr_WSR_50_DC5_1x.yaml - res4 / res5 dilated at stride 8) on ONE image of a real
+    training size, the whole conv chain as one drn_trunk_forward call (the path real data takes), timed in this run with HIP
+    events on the launch stream: algorithmic conv FLOPs / time against the dense bf16 MFMA peak."""
+    from drn_wsod_pytorch_amd.modeling import build_model
+
+    cfg = build_cfg(pkg, device)
+    if workload == "r50dc5":
+        cfg.merge_from_list(["MODEL.RESNETS.OUT_FEATURES", "['res5']", "MODEL.ROI_HEADS.IN_FEATURES", "['res5']",
+                             "MODEL.RESNETS.RES5_DILATION", "2"])
+    model = build_model(cfg)
+    init_weights(model, seed=0)
+    model.eval()
+    bb = model.backbone
+    h, w = hw
+    x = (torch.randn((1, h, w, 8), device=device) * 0.5).to(torch.bfloat16)
+    x[..., 3:] = 0
+    with torch.no_grad():
+        for _ in range(2):
+            bb._run_plan(x)
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        for _ in range(reps):
+            bb._run_plan(x)
+        b.record()
+        torch.cuda.synchronize()
+    us = a.elapsed_time(b) / reps * 1e3
+    # algorithmic FLOPs: walk the recorded plan (csrc/executor.hip) with the same geometry rules
+    p = bb._plan_for(torch.bfloat16, 8)
+    geo, gf, n_conv = {0: (h, w, 3)}, 0.0, 0
+    for i in range(p["n_ops"]):
+        o = p["ops"][i]
+        hh, ww, cc = geo[o.src]
+        if (o.kind & 0xff) == 0:
+            ho = (hh + 2 * o.pad - o.dil * (o.ksize - 1) - 1) // o.stride + 1
+            wo = (ww + 2 * o.pad - o.dil * (o.ksize - 1) - 1) // o.stride + 1
+            gf += 2.0 * ho * wo * o.cout * o.ksize * o.ksize * (cc if o.src == 0 else o.cin) / 1e9
+            geo[o.dst] = (ho, wo, o.cout)
+            n_conv += 1
+        else:
+            geo[o.dst] = ((hh - 2) // o.stride + 1, (ww - 2) // o.stride + 1, cc)
+    del model
+    ach = gf / us * 1e3  # GF / us = PFLOP/s
+    return {"trunk": {"r50c4": "WS-ResNet50 C4 (stem .. res4, stride 16)", "r50dc5": "WS-ResNet50 dilated C5 (stem .. res5, res4 / res5 "
+                      "dilated at stride 8: the shipped oicr_WSR_50_DC5 recipe)"}[workload], "image": "%dx%d" % (h, w),
+            "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TFLOPS,
+            "gflop": gf, "us": us, "conv_launches": n_conv, "ops_in_plan": int(p["n_ops"]),
+            "timed": "%d eager drn_trunk_forward calls (one C call walks the conv chain; launch gaps included), HIP events on the "
+                     "launch stream, in this run; per-layer tables: tools/conv_bench.py -> profiles/r5_*_conv_*.txt" % reps}
+
+
 def pmc_record(shape):
     """The committed PMC record of the roofline kernel (tools/pmc_attrib.sh: separate rocprofv3 --pmc passes over
     tools/pmc_gemm.py - SQ busy / wait split, LDS, L2 hit rate, FETCH_SIZE with the gfx950 x2 correction, WRITE_SIZE).
@@ -241,6 +294,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-side", action="store_true",
+                    help="skip the side measurements of the default run (trunk at 800x1216 for the C4 and the shipped DC5 recipe, the "
+                         "4-images-per-GPU step in a child process)")
     ap.add_argument("--workload", choices=["r50c4", "r50dc5", "r101c4_k80", "r50c4_fp8", "v16"], default="r50c4",
                     help="r50c4 = BASELINE configs[1], the headline metric; r50dc5 (configs[2]: WS-R50 dilated C5, use with "
                          "--proposals 4000), r101c4_k80 (configs[3]: WS-R101 C4, 80 classes) and r50c4_fp8 (configs[4]: the "
@@ -647,11 +703,17 @@ def main():
                 # (profiles/r4_24_pmc_dw_sgdp.json: PMC traffic 1.29x of it)
                 alg_ = (D1 + col_plan[0]) * Mp * 2.0 + D1 * col_plan[0] * 2.0 + nb_
                 e_["algorithmic_bytes"] = alg_
-                e_["hbm_frac_of_peak"] = alg_ / (e_["avg_launch_ms"] * 1e-3) / 8e12
-                e_["mfma_plus_hbm_frac"] = e_["frac"] + e_["hbm_frac_of_peak"]
-                e_["note"] = ("MFMA work and the fc6 optimizer pass share this launch under the 1400 W cap: FLOPs / time is not "
-                              "comparable with a GEMM-only launch (the unfused pair took 20 + 180 + 280 us of GEMM launches plus a "
-                              "229-us optimizer slab behind them for the same work)")
+                # the launch has TWO roofs; the binding one is whichever its algorithmic work takes longer on: 2.27 GB at 8 TB/s
+                # = 284 us against 411 GF at 2.5 PFLOP/s = 164 us - this launch is HBM-bound by its work
+                t_hbm_, t_mfma_ = alg_ / 8e12, e_["gflop_per_launch"] * 1e9 / (BF16_MFMA_PEAK_TFLOPS * 1e12)
+                e_["frac_mfma"] = e_["frac"]
+                e_["frac_hbm"] = alg_ / (e_["avg_launch_ms"] * 1e-3) / 8e12
+                e_["bound"] = "hbm" if t_hbm_ >= t_mfma_ else "mfma"
+                e_["roof_us"] = max(t_hbm_, t_mfma_) * 1e6
+                e_["frac_of_binding_roof"] = max(t_hbm_, t_mfma_) / (e_["avg_launch_ms"] * 1e-3)
+                e_["note"] = ("MFMA work and the fc6 optimizer pass share this launch under the 1400 W cap: `frac` (= frac_mfma, FLOPs / "
+                              "time / MFMA peak) is not comparable with a GEMM-only launch; the binding roof is `bound`, and "
+                              "frac_of_binding_roof = max(bytes / 8 TB/s, FLOPs / 2.5 PFLOP/s) / time (perfect overlap of the two)")
                 launches.append(e_)
         fused = entry("gemm_nt256_kernel<bf16, SGD> fc6 dW + optimizer epilogue", {("sgd", D1, K1, Mp)}, 2.0 * D1 * K1 * Rtot)
         if fused:
@@ -683,16 +745,16 @@ def main():
                 # 1.85 GB - comparable with round 3's family figure only together with the optimizer slabs that ran beside / behind it
                 gemm_only = [l for l in launches if "carries_optimizer_bytes" not in l]
                 fam["frac_note"] = ("the weight-gradient launch carries the fc6 optimizer pass (%.2f GB at %.0f GB/s inside the launch, "
-                                    "%.2f of the HBM peak by algorithmic bytes): `frac` divides the family's FLOPs by a duration that "
-                                    "also pays for those bytes; GEMM-only launches of the family: %.3f"
+                                    "%.2f of the HBM peak by algorithmic bytes - its binding roof): `frac` divides the family's FLOPs by a "
+                                    "duration that also pays for those bytes; GEMM-only launches of the family: %.3f"
                                     % (fz[0]["carries_optimizer_bytes"] / 1e9, fz[0]["optimizer_GBps_in_this_launch"],
-                                       fz[0]["hbm_frac_of_peak"],
+                                       fz[0]["frac_hbm"],
                                        (sum(l["gflop_per_launch"] for l in gemm_only) / 1e3 /
                                         (sum(l["avg_launch_ms"] for l in gemm_only) * 1e-3) / BF16_MFMA_PEAK_TFLOPS) if gemm_only else 0.0))
                 fam["frac_gemm_only_launches"] = ((sum(l["gflop_per_launch"] for l in gemm_only) / 1e3 /
                                                    (sum(l["avg_launch_ms"] for l in gemm_only) * 1e-3) / BF16_MFMA_PEAK_TFLOPS)
                                                   if gemm_only else None)
-                fam["fused_launch_mfma_plus_hbm_frac"] = fz[0]["mfma_plus_hbm_frac"]
+                fam["fused_launch"] = {k_: fz[0][k_] for k_ in ("bound", "frac_hbm", "frac_mfma", "frac_of_binding_roof", "roof_us", "avg_launch_ms")}
             roof = fam
         gf_step = step_gflop(args.workload, R, K1, D1, D2, NH, args.ims_per_gpu)
         step_tf = gf_step * 1e9 / (dt / args.steps) / 1e12
@@ -785,9 +847,14 @@ def main():
             if dwl:
                 ms = sum(l["avg_launch_ms"] for l in dwl)
                 gf = sum(l["gflop_per_launch"] for l in dwl)
-                cands.append({"kernel": "fc6 weight-gradient launches (gemm_nt256p_kernel<bf16> + the trailing-column launch), in step",
-                              "bound": "mfma", "us_per_step": ms * 1e3, "launches_per_step": len(dwl),
-                              "achieved": gf / ms, "unit": "TFLOP/s", "frac": gf / ms / BF16_MFMA_PEAK_TFLOPS})
+                c_ = {"kernel": "fc6 weight-gradient launches (gemm_nt256p_kernel<bf16> + the trailing-column launch), in step",
+                      "bound": "mfma", "us_per_step": ms * 1e3, "launches_per_step": len(dwl),
+                      "achieved": gf / ms, "unit": "TFLOP/s", "frac": gf / ms / BF16_MFMA_PEAK_TFLOPS}
+                fz_ = [l for l in dwl if "frac_hbm" in l]
+                if fz_:  # the fused dW + SGD launch: bound by its bytes (see its roofline_launches entry)
+                    c_.update({"bound": fz_[0]["bound"], "frac_mfma": c_["frac"], "frac_hbm": fz_[0]["frac_hbm"],
+                               "frac_of_binding_roof": fz_[0]["frac_of_binding_roof"]})
+                cands.append(c_)
             cands.append({"kernel": roof["forward_launch"]["kernel"] + ", in step", "bound": "mfma",
                           "us_per_step": roof["forward_launch"]["avg_launch_ms"] * 1e3, "launches_per_step": 1,
                           "achieved": roof["forward_launch"]["achieved"], "unit": "TFLOP/s", "frac": roof["forward_launch"]["frac"]})
@@ -802,6 +869,25 @@ def main():
                                   "achieved": e_["achieved"], "unit": "GB/s", "frac": e_["frac"]})
             roof["time_dominant_kernel"] = max(cands, key=lambda c: c["us_per_step"])
             roof["time_by_kernel_family"] = sorted(cands, key=lambda c: -c["us_per_step"])
+        if world == 1 and not args.no_side and args.workload == "r50c4" and args.ims_per_gpu == 1:
+            # SURVEY 8(d) side figures of the default run (never part of `value`): the trunk at a real training size - C4 and
+            # the shipped DC5 recipe - and the same step with 4 images per GPU
+            try:
+                out["roofline_trunk"] = [trunk_roofline(pkg, device, "r50c4"), trunk_roofline(pkg, device, "r50dc5")]
+            except Exception as ex:  # noqa: BLE001 - supporting evidence only
+                out["roofline_trunk"] = "unavailable: %r" % (ex,)
+            try:
+                import subprocess
+
+                r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--ims-per-gpu", "4", "--steps", "20", "--warmup", "3",
+                                     "--no-cpu-baseline", "--no-side"], capture_output=True, text=True, timeout=300)
+                j_ = json.loads([l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")][-1])
+                out["side_ims_per_gpu_4"] = {"value": j_["value"], "unit": "images/sec", "ms_per_step": j_["ms_per_step"], "steps": j_["steps"],
+                                             "roofline_step_frac": j_["roofline_step"]["frac"],
+                                             "how": "child process: python bench.py --ims-per-gpu 4 --steps 20 --warmup 3 (the same step with 4 "
+                                                    "images per GPU and iteration: SURVEY 8(d)'s 'one larger N')"}
+            except Exception as ex:  # noqa: BLE001 - supporting evidence only
+                out["side_ims_per_gpu_4"] = "unavailable: %r" % (ex,)
         out["timed_region_s"] = dt
         if dt < 0.2:
             out["timed_region_note"] = ("the timed region is %.0f ms (%d steps): shorter than clock / power transients; the default "
