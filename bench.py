@@ -315,11 +315,6 @@ def main():
                          "than two steps)")
     ap.add_argument("--slab-rows", default=None,
                     help="comma-separated row ends of the fc6 dW slabs (experiment knob; default = the engine's choice)")
-    ap.add_argument("--col-rounds", type=int, default=None,
-                    help="N=1: fc6 dW in COLUMN slabs of this many exact rounds of the persistent GEMM, each updated by the "
-                         "optimizer the moment it is queued (0 = the two row slabs of round 3)")
-    ap.add_argument("--peel-side", type=int, default=0,
-                    help="A/B: 1 = the joint peel of the fc6 dW on the optimizer stream instead of in front of the first slab")
     ap.add_argument("--ims-per-gpu", type=int, default=1,
                     help="images per GPU per iteration; 1 = the reference's operating point and the headline metric, "
                          "larger values are the side measurement SURVEY 8(d) asks for")
@@ -328,9 +323,7 @@ def main():
                          "measurement, not the headline metric)")
     ap.add_argument("--tune", default="", help="comma-separated knob=value pairs for drn_tune (A/B runs), e.g. 3=4")
     ap.add_argument("--engine-opt", default="", help="comma-separated attr=int pairs set on the head engine (A/B runs)")
-    ap.add_argument("--step-opt", default="", help="comma-separated attr=int pairs set on the GraphedTrainStep (A/B runs: late_join, stage_before_tail)")
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
-    ap.add_argument("--graph-pool", action="store_true", help="A/B: replay the pooling piece as its own graph instead of issuing it eagerly")
     ap.add_argument("--no-stage-ahead", action="store_true",
                     help="A/B: stage the next batch's proposals / labels on the main stream (round-2 order)")
     ap.add_argument("--no-eager-fc6", action="store_true",
@@ -339,11 +332,6 @@ def main():
     ap.add_argument("--no-launch-timing", action="store_true",
                     help="no HIP events around the eagerly issued GEMMs in the timed region (A/B: what the events cost)")
     ap.add_argument("--no-pipelined-sgd", action="store_true", help="plain optimizer.step() after backward")
-    ap.add_argument("--fused-sgd", action="store_true",
-                    help="N=1 only: fc6 dW GEMM with the SGD update as its epilogue (drn_gemm_nt_sgd; measured "
-                         "neutral: its HBM-heavy epilogues run in lock-step across CUs, see DESIGN.md)")
-    ap.add_argument("--pool-overlap", type=int, default=0,
-                    help="1 = the next batch's pooling piece on its own stream beside the fc6 dW tail (the two operand sets alternate); 2 = its pooling kernel beside the heads chain instead (both measured slower than the serial order)")
     ap.add_argument("--fused-tn", type=int, default=-1, choices=[-1, 0, 1],
                     help="N=1 (default -1 = the engine's choice: on for R50 / VGG16 trunks): fc6 dW + SGD in ONE launch with the update of each tile pipelined into the next tile's "
                          "mainloop (drn_gemm_tn_sgd); 0 = two row slabs + sgd_kernel on the optimizer stream (round 3)")
@@ -370,7 +358,9 @@ def main():
                     help="N > 1: sharded (default) = reduce-scatter of each fc6 gradient slab, SGD on the owned rows (1/N of "
                          "the optimizer traffic), all-gather of the updated bf16 rows; allreduce = DDP's all-reduce + "
                          "replicated update")
-    ap.add_argument("--kshard-wire", choices=["fp32", "bf16"], default="fp32",
+    ap.add_argument("--no-other-exchange", action="store_true",
+                    help="N > 1 with the K-sharded fc6: skip the 20 steps of the sharded gradient exchange timed after the headline region")
+    ap.add_argument("--kshard-wire", choices=["fp32", "bf16"], default="bf16",
                     help="--exchange fc6_kshard: dtype of the partial fc6 pre-activations on the wire (reduce-scatter)")
     ap.add_argument("--comm-dtype", choices=["bf16", "fp32"], default=None,
                     help="dtype of the fc6 weight-gradient buckets (HBM and xGMI); default bf16 = the compute dtype, the "
@@ -438,49 +428,61 @@ def main():
     model.train()
     for kv in filter(None, args.engine_opt.split(",")):
         setattr(model.roi_heads._engine, kv.split("=")[0], int(kv.split("=")[1]))
-    step_opts = dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in filter(None, args.step_opt.split(",")))
     opt = build_optimizer(cfg, model)
     dp = DataParallel(model, force_exchange=args.force_exchange)
     dp.broadcast_parameters(0)
-    selftest = None
-    if dp.exchange and not args.no_selftest:
-        # the step's collectives on scratch buffers of the real bucket sizes, 3 iterations each, BEFORE any warm-up: a wedged
-        # RCCL bootstrap / a missing peer mapping / a missing rank raises here with the collective's name instead of
-        # hanging the measurement (DataParallel.selftest polls every collective against a deadline)
-        d1_, k1_ = model.roi_heads.box_head.fc1.weight.shape
-        model.roi_heads._engine.ensure(torch.device(device))
-        o_fc1_ = model.roi_heads._engine._seg["fc1.weight"][0]
-        half_ = ((d1_ + 255) // 256 + 1) // 2 * 256
-        slabs_ = [(half_, k1_), (d1_ - half_, k1_)] if 0 < half_ < d1_ else [(d1_, k1_)]
-        selftest = dp.selftest({"small": o_fc1_, "slabs": slabs_}, iters=3, timeout=args.selftest_timeout,
-                               wire_dtype=torch.float32 if args.comm_dtype == "fp32" else torch.bfloat16)
-        if rank == 0:
-            print("[bench] collective self-test ok: " + ", ".join("%s %.2f ms (%.0f GB/s bus)" % (k, v["ms"], v["busbw_GBps"])
-                                                                  for k, v in selftest.items()), file=sys.stderr, flush=True)
     if args.fc1_nt:
         model.roi_heads._engine.fc1_tn = False
     if args.no_fc7_pair:
         model.roi_heads._engine.fc7_bwd_pair = False
     if args.fc7_dx_splits:
         model.roi_heads._engine.fc7_pair_dx_splits = args.fc7_dx_splits
-    opt.peel_on_opt_stream = bool(args.peel_side)
+    R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
     exchange = args.exchange
+    c_feat = 1024 if args.workload in ("r50c4", "r50c4_fp8", "r101c4_k80") else (2048 if args.workload == "r50dc5" else 512)
     if exchange is None and world > 1 and not args.no_pipelined_sgd and not args.no_graph:
         # round 4: for N > 1 the bench's fixed-shape batches take the K-sharded fc6 (no fc6 gradient exchange, no weight gather;
-        # priced 1.7x / 3.2x / 5.8-6.4x for N = 2 / 4 / 8 against 0.75x / 2.0-2.3x / 5.0-6.5x) when the channel
-        # count splits over the ranks into whole K slabs; --exchange sharded | allreduce select the gradient exchanges
-        c_feat = 1024 if args.workload in ("r50c4", "r50c4_fp8", "r101c4_k80") else (2048 if args.workload == "r50dc5" else 512)
+        # DESIGN 10.3 / 11.4) when the channel count splits over the ranks into whole K slabs; --exchange sharded | allreduce
+        # select the gradient exchanges.  Round 5: if its collectives or its warm-up fail, the run falls back (below).
         if c_feat % world == 0 and ((c_feat // world) * 49 * 2) % 128 == 0:
             exchange = "fc6_kshard"
-    if not args.no_pipelined_sgd:
-        # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
-        opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
-                             comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype],
-                             exchange=exchange, col_rounds=args.col_rounds,
-                             kshard_wire=torch.bfloat16 if args.kshard_wire == "bf16" else None, fused_tn={-1: None, 0: False, 1: True}[args.fused_tn])
-        if world == 1 and args.fused_sgd:
-            opt.enable_fused_fc1()  # one process: the fc6 gradient is consumed inside its GEMM's epilogue
-    R, K = args.proposals, cfg.MODEL.ROI_HEADS.NUM_CLASSES
+    selftest = None
+    fallback_from = []
+    if dp.exchange and not args.no_selftest:
+        # the step's collectives on scratch buffers of the real bucket sizes, 3 iterations each, BEFORE any warm-up: a wedged
+        # RCCL bootstrap / a missing peer mapping / a missing rank raises here with the collective's name instead of
+        # hanging the measurement (DataParallel.selftest polls every collective against a deadline).  Round 5: the K-sharded
+        # fc6's own collectives are part of it at their real sizes; if THEY fail while the gradient exchange's pass, the run
+        # takes the sharded gradient exchange instead of coming back empty.
+        d1_, k1_ = model.roi_heads.box_head.fc1.weight.shape
+        model.roi_heads._engine.ensure(torch.device(device))
+        o_fc1_ = model.roi_heads._engine._seg["fc1.weight"][0]
+        half_ = ((d1_ + 255) // 256 + 1) // 2 * 256
+        slabs_ = [(half_, k1_), (d1_ - half_, k1_)] if 0 < half_ < d1_ else [(d1_, k1_)]
+        wire_ = torch.float32 if args.comm_dtype == "fp32" else torch.bfloat16
+        selftest = dp.selftest({"small": o_fc1_, "slabs": slabs_}, iters=3, timeout=args.selftest_timeout, wire_dtype=wire_)
+        if exchange == "fc6_kshard":
+            fh_ = 224 // (16 if args.workload not in ("r50dc5", "v16") else 8)
+            m_ = R * args.ims_per_gpu
+            ks_spec = {"pack_bytes": args.ims_per_gpu * fh_ * fh_ * c_feat * 2 + m_ * 5 * 4 + m_ * 4, "M": m_, "D1": d1_,
+                       "wire_dtype": torch.bfloat16 if args.kshard_wire == "bf16" else torch.float32, "dp1_dtype": torch.bfloat16}
+            err_ = None
+            try:
+                if os.environ.get("DRN_BENCH_FAIL") == "kshard_selftest":
+                    raise RuntimeError("injected failure (DRN_BENCH_FAIL=kshard_selftest)")
+                selftest.update(dp.selftest({"small": 256, "slabs": [], "kshard": ks_spec}, iters=3, timeout=args.selftest_timeout,
+                                            wire_dtype=wire_))
+            except Exception as ex:  # noqa: BLE001 - the point of the guard
+                err_ = repr(ex)
+            flag_ = torch.tensor([0.0 if err_ else 1.0], device=device)
+            dist.all_reduce(flag_, op=dist.ReduceOp.MIN)
+            if float(flag_) < 1.0:
+                fallback_from.append({"exchange": "fc6_kshard", "stage": "collective self-test", "error": err_ or "failed on another rank"})
+                print("[bench] fc6_kshard self-test failed (%s): falling back to the sharded gradient exchange" % err_, file=sys.stderr, flush=True)
+                exchange = "sharded"
+        if rank == 0:
+            print("[bench] collective self-test ok: " + ", ".join("%s %.2f ms (%.0f GB/s bus)" % (k, v["ms"], v["busbw_GBps"])
+                                                                  for k, v in selftest.items()), file=sys.stderr, flush=True)
     batches = synthetic_batches(8, R, K, device, rank, pkg, args.ims_per_gpu)
     if args.workload == "r50c4_fp8":
         # BASELINE configs[4]: per-tensor activation scales from two images run in bf16, per-channel fp8 weights
@@ -501,59 +503,108 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # N > 1: the graphed step keeps the gradient exchange out of the capture (split tail); it needs the pipelined
-    # optimizer, whose hooks issue the collectives
-    use_graph = not args.no_graph and (not dp.exchange or not args.no_pipelined_sgd)
-    # HIP events around every GEMM launch (on the launching stream) during eager steps: the dominant kernel's
-    # average launch duration for the roofline object.  A replayed hipGraph cannot be bracketed per kernel, so with
-    # --graph these come from the eager warm-up steps of this same run (same buffers, same shapes).
-    ops.GEMM_TIMING = []
-    n_eager = max(args.warmup, 3) if use_graph else args.warmup
-    for i in range(n_eager):
-        last = step(i)
-    barrier()
-    timing = ops.GEMM_TIMING
-    if use_graph:
-        from drn_wsod_pytorch_amd.engine import GraphedTrainStep
+    n_ahead = 2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1
+    window = lambda j: [batches[(j + q) % len(batches)] for q in range(n_ahead)]
+    from drn_wsod_pytorch_amd.engine import GraphedTrainStep
 
-        ops.GEMM_TIMING = None
-        split = dp.exchange or (args.tail != "graph" and not args.no_pipelined_sgd)
-        # eager_fc6: the fc6 forward GEMM is issued eagerly in front of the heads graph (the fc6 dW slabs already are,
-        # behind it), so all three launches of the dominant kernel are bracketed by HIP events INSIDE the timed region
-        stepper = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead,
-                                   trunk_pairs=(args.trunk_group if args.trunk_pairs else False), eager_fc6=not args.no_eager_fc6,
-                                   stage_ahead=not args.no_stage_ahead, eager_pool=not args.graph_pool,
-                                   pool_overlap=int(args.pool_overlap))
-        for k_, v_ in step_opts.items():
-            setattr(stepper, k_, v_)
-        try:
-            for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
-                last = stepper.step(*[batches[(i + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
-        except Exception as ex:  # noqa: BLE001 - a failed capture must not cost the measurement: run the eager step
-            print("[bench] hipGraph capture failed (%r); falling back to the eager step" % (ex,), file=sys.stderr)
-            use_graph = False
-            model.roi_heads._engine.defer_fc1_tail = False
-    if use_graph:
+    def setup(ex):
+        """(re)configure the optimizer for exchange `ex`, run the eager warm-up steps (HIP events around every GEMM launch) and
+        build + warm the graphed step -> (use_graph, stepper, eager timing, last losses)"""
+        if not args.no_pipelined_sgd:
+            # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
+            opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,
+                                 comm_dtype={None: None, "bf16": torch.bfloat16, "fp32": torch.float32}[args.comm_dtype],
+                                 exchange=ex, kshard_wire=torch.bfloat16 if args.kshard_wire == "bf16" else None,
+                                 fused_tn={-1: None, 0: False, 1: True}[args.fused_tn])
+        if ex is not None and os.environ.get("DRN_BENCH_FAIL") == ex + "_warmup":
+            raise RuntimeError("injected failure (DRN_BENCH_FAIL=%s_warmup)" % ex)
+        # N > 1: the graphed step keeps the gradient exchange out of the capture (split tail); it needs the pipelined
+        # optimizer, whose hooks issue the collectives
+        use_g = not args.no_graph and (not dp.exchange or not args.no_pipelined_sgd)
+        # HIP events around every GEMM launch (on the launching stream) during eager steps: the dominant kernel's
+        # average launch duration for the roofline object.  A replayed hipGraph cannot be bracketed per kernel, so with
+        # --graph these come from the eager warm-up steps of this same run (same buffers, same shapes).
+        ops.GEMM_TIMING = []
+        last_ = None
+        for i in range(max(args.warmup, 3) if use_g else args.warmup):
+            last_ = step(i)
         barrier()
-        timing = []
-        hbm_timing = []
-        t0 = time.perf_counter()
-        for i in range(args.steps):
-            j = args.warmup + i
+        tim = ops.GEMM_TIMING
+        stp = None
+        if use_g:
+            ops.GEMM_TIMING = None
+            split = dp.exchange or (args.tail != "graph" and not args.no_pipelined_sgd)
+            # eager_fc6: the fc6 forward GEMM is issued eagerly in front of the heads graph (the fc6 dW launch already is,
+            # behind it), so the launches of the dominant kernel are bracketed by HIP events INSIDE the timed region
+            stp = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead,
+                                   trunk_pairs=(args.trunk_group if args.trunk_pairs else False), eager_fc6=not args.no_eager_fc6,
+                                   stage_ahead=not args.no_stage_ahead)
+            try:
+                for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
+                    last_ = stp.step(*window(i))
+            except Exception as ex_:  # noqa: BLE001 - a failed capture must not cost the measurement: run the eager step
+                if dp.exchange:
+                    raise  # (N > 1: every rank must take the same path - the exchange-level fallback decides)
+                print("[bench] hipGraph capture failed (%r); falling back to the eager step" % (ex_,), file=sys.stderr)
+                use_g, stp = False, None
+                model.roi_heads._engine.defer_fc1_tail = False
+        return use_g, stp, tim, last_
+
+    # N > 1: the exchange of record, then - if ITS warm-up fails on any rank - the sharded gradient exchange, then the plain
+    # all-reduce (VERDICT r4: the first real multi-GPU run must not come back empty); every rank takes the same decision
+    chain = [exchange]
+    if dp.exchange and exchange == "fc6_kshard":
+        chain += ["sharded", "allreduce"]
+    elif dp.exchange and exchange in (None, "sharded"):
+        chain += ["allreduce"]
+    for n_try, ex in enumerate(chain):
+        err_ = None
+        try:
+            use_graph, stepper, timing, last = setup(ex)
+        except Exception as e_:  # noqa: BLE001
+            if not dp.exchange or n_try == len(chain) - 1:
+                raise
+            err_ = repr(e_)
+        if dist.is_initialized():
+            flag_ = torch.tensor([0.0 if err_ else 1.0], device=device)
+            dist.all_reduce(flag_, op=dist.ReduceOp.MIN)
+            if float(flag_) < 1.0 and err_ is None:
+                err_ = "failed on another rank"
+                if stepper is not None:
+                    stepper.release()
+        if err_ is None:
+            exchange = ex
+            break
+        fallback_from.append({"exchange": ex, "stage": "warm-up", "error": err_})
+        print("[bench] exchange %s failed in its warm-up (%s): falling back to %s" % (ex, err_, chain[n_try + 1]), file=sys.stderr, flush=True)
+        model.roi_heads._engine.defer_fc1_tail = False
+        torch.cuda.synchronize()
+
+    def timed_region(stp, steps, with_events):
+        """`steps` graphed steps between two barriers -> (seconds, host enqueue seconds, GEMM timing, HBM timing, last losses)"""
+        barrier()
+        tim, hbm = [], []
+        t0_ = time.perf_counter()
+        last_ = None
+        for i in range(steps):
             # HIP events around the eagerly issued GEMMs on every 5th step of the timed region (every step costs 2.6 % of
             # the step rate, measured A/B on one box: 585 vs 601 img/s; sampled: within noise)
-            ops.GEMM_TIMING = timing if (not args.no_launch_timing and i % 5 == 2) else None
-            ops.HBM_TIMING = hbm_timing if (not args.no_launch_timing and i % 5 == 2) else None
-            last = stepper.step(*[batches[(j + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
-        t_enq = time.perf_counter() - t0
+            ops.GEMM_TIMING = tim if (with_events and i % 5 == 2) else None
+            ops.HBM_TIMING = hbm if (with_events and i % 5 == 2) else None
+            last_ = stp.step(*window(args.warmup + i))
+        t_enq_ = time.perf_counter() - t0_
         barrier()
-        dt = time.perf_counter() - t0
+        dt_ = time.perf_counter() - t0_
         ops.GEMM_TIMING = ops.HBM_TIMING = None
+        return dt_, t_enq_, tim, hbm, last_
+
+    other_exchange = None
+    if use_graph:
+        dt, t_enq, timing, hbm_timing, last = timed_region(stepper, args.steps, not args.no_launch_timing)
         # pure host cost of one step: six steps enqueued right after a sync (the 8-slot label ring cannot block yet)
         th = time.perf_counter()
         for i in range(6):
-            j = args.warmup + args.steps + i
-            last2 = stepper.step(*[batches[(j + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+            last2 = stepper.step(*window(args.warmup + args.steps + i))
         host_unblocked = (time.perf_counter() - th) / 6 * 1e3
         barrier()
         local_ms = None
@@ -564,13 +615,11 @@ def main():
             opt._exchange_on = False
             n_loc = min(args.steps, 50)
             for i in range(3):
-                j = args.warmup + args.steps + 6 + i
-                stepper.step(*[batches[(j + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+                stepper.step(*window(args.warmup + args.steps + 6 + i))
             barrier()
             tl = time.perf_counter()
             for i in range(n_loc):
-                j = args.warmup + args.steps + 9 + i
-                stepper.step(*[batches[(j + q) % len(batches)] for q in range(2 * args.trunk_group if args.trunk_pairs else max(args.lookahead, 2) + 1)])
+                stepper.step(*window(args.warmup + args.steps + 9 + i))
             barrier()
             local_ms = (time.perf_counter() - tl) / n_loc * 1e3
             if world > 1:
@@ -578,6 +627,24 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 local_ms = float(tt)
             opt._exchange_on = True
+        if dp.exchange and world > 1 and exchange == "fc6_kshard" and not args.no_other_exchange:
+            # the OTHER exchange on the same job, 20 steps, after the headline region (report both): the sharded
+            # gradient exchange (reduce-scatter per fc6 slab -> owned rows -> all-gather of the updated compute copy)
+            try:
+                opt.sync_master()  # every rank holds all columns again (a collective)
+                stepper.release()
+                model.roi_heads._engine.defer_fc1_tail = False
+                ug2, stp2, _, _ = setup("sharded")
+                if ug2:
+                    dt2, _, _, _, _ = timed_region(stp2, 20, False)
+                    if world > 1:
+                        t2_ = torch.tensor([dt2], device=device, dtype=torch.float64)
+                        dist.all_reduce(t2_, op=dist.ReduceOp.MAX)
+                        dt2 = float(t2_)
+                    other_exchange = {"exchange": "sharded", "steps": 20, "ms_per_step": dt2 / 20 * 1e3,
+                                      "value": world * args.ims_per_gpu * 20 / dt2, "unit": "images/sec"}
+            except Exception as ex_:  # noqa: BLE001 - supporting evidence only
+                other_exchange = "unavailable: %r" % (ex_,)
     else:
         ops.GEMM_TIMING = timing = []
         ops.HBM_TIMING = hbm_timing = []
@@ -715,9 +782,6 @@ def main():
                               "time / MFMA peak) is not comparable with a GEMM-only launch; the binding roof is `bound`, and "
                               "frac_of_binding_roof = max(bytes / 8 TB/s, FLOPs / 2.5 PFLOP/s) / time (perfect overlap of the two)")
                 launches.append(e_)
-        fused = entry("gemm_nt256_kernel<bf16, SGD> fc6 dW + optimizer epilogue", {("sgd", D1, K1, Mp)}, 2.0 * D1 * K1 * Rtot)
-        if fused:
-            launches.append(fused)
         # `roofline` (round 4): the fc6 GEMM FAMILY in the step - forward + every weight-gradient launch,
         # algorithmic FLOPs / the sum of their in-step launch durations - not its best launch; the forward launch alone stays
         # in `roofline.forward_launch` and in `roofline_launches`
@@ -792,6 +856,8 @@ def main():
                                   "RCCL reduce-scatter per fc6 dW row slab -> fused SGD on the owned rows -> all-gather of the "
                                   "updated compute copy; all-reduce for the small tensors" if getattr(opt, "_sharded", False)
                                   else "RCCL all-reduce per bucket (small tensors and fc6 dW row slabs)") + ", fc6_grad_dtype on the wire",
+                   "exchange": exchange, "fallback_from": fallback_from or None, "other_exchange": other_exchange,
+                   "kshard_wire": (args.kshard_wire if getattr(opt, "_kshard", False) else None),
                    "slab_ends": getattr(opt, "_slab_ends", None), "ranks": rank_info,
                    "selftest": selftest,
                    "step_ms_without_exchange": local_ms if use_graph else None,

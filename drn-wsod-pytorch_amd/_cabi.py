@@ -32,7 +32,6 @@ _SIGS = {
     "drn_roi_pool_backward_nhwc": "ppppp" + "iiiiii" + "f" + "l" + "iiiip",
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliiilip",
-    "drn_gemm_nt_sgd": "ppiiilli" + "ppplp" + "fifp",
     "drn_gemm_tn": "ppp" + "iiii" + "lll" + "iilip",
     "drn_gemm_tn_sgd": "ppp" + "iiii" + "lll" + "ppplp" + "fifp",
     "drn_gemm_nt_pair": ("ppp" + "iii" + "lll" + "ili") * 2 + "p",

@@ -279,26 +279,23 @@ __attribute__((visibility("hidden"))) int drn_conv_ring_set(int v) {
 }
 
 // Runs the convolution on the register-ring kernels when it is in their class; DRN_ERR_UNSUPPORTED otherwise (the caller
-// then takes the kernels of gemm_conv.hip).  `cus` = compute units of the device; `small_map`: ONE image of this layer is a
-// latency-bound small map (the wave-K-split kernel's class) - taken only when a tile is pinned (tests).
-__attribute__((visibility("hidden"))) int drn_conv_ring_try(const ConvParams& p, int dtype, int cus, bool small_map, hipStream_t st) {
-  if (!g_conv_ring || (small_map && g_conv_ring == 1) || dtype != DRN_BF16 || p.out_dt != DRN_BF16 ||
-      (p.residual && p.res_dt != DRN_BF16))
-    return DRN_ERR_UNSUPPORTED;
+// then takes the kernels of gemm_conv.hip).  `cus` = compute units of the device; `tiles64_one` = 64x64 tiles of ONE image of
+// this layer: the class is decided on one image's geometry, so a layer takes the same kernel family - the same fp32 summation
+// order - whether its image runs alone or in a batch (graphed trunk groups vs eager steps, 2 ranks vs 1).
+__attribute__((visibility("hidden"))) int drn_conv_ring_try(const ConvParams& p, int dtype, int cus, long tiles64_one, hipStream_t st) {
+  if (!g_conv_ring || dtype != DRN_BF16 || p.out_dt != DRN_BF16 || (p.residual && p.res_dt != DRN_BF16)) return DRN_ERR_UNSUPPORTED;
   if ((p.Cin & 63) || (p.Cout & 7) || p.KH * p.KW > 32 || (p.ldy & 7) || (p.residual && (p.ldres & 7))) return DRN_ERR_UNSUPPORTED;
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
   if (!al16(p.X) || !al16(p.Wt) || !al16(p.Y) || (p.residual && !al16(p.residual)) || (p.ldw * 2) % 16 != 0) return DRN_ERR_UNSUPPORTED;
   if ((long)p.Cout * p.ldw * 2 >= 0xFFFFFFF0L) return DRN_ERR_UNSUPPORTED;
-  const long M = (long)p.Nb * p.Ho * p.Wo;
   const int nslab = p.KH * p.KW * (p.Cin >> 6);
-  // Where the ring kernel wins (tools/conv_bench.py at 800x1216, profiles/r5_04_*): layers of >= 4 K slabs on up to ~4 rounds of
-  // 64x64 tiles - the res3 / res4 1x1 and 3x3 layers of a real image.  Single-slab 1x1s and the huge res2 maps are bound by
-  // their output traffic (the 128-wide tiles of gemm_conv.hip move fewer operand bytes there); every tile shape here gives the
-  // bits of the register-staged tiled kernel, so the choice may depend on the batch.
-  const long tiles64 = ((M + 63) / 64) * ((p.Cout + 63) / 64);
+  // Where the ring kernel wins (tools/conv_bench.py at 800x1216, profiles/r5_04_*, r5_12_*): layers of >= 4 K slabs on more
+  // than CUs / 4 and up to ~4 rounds of 64x64 tiles per image - the res3 / res4 1x1 and 3x3 layers of a real-size image.
+  // Single-slab 1x1s and the huge res2 maps are bound by their output traffic (the 128-wide tiles of gemm_conv.hip move fewer
+  // operand bytes there); maps of fewer than 1024 pixels (the 224x224 benchmark image) stay in the small-map kernels' class.
   int pick = g_conv_ring;
   if (pick == 1) {
-    if (nslab < 4 || tiles64 > 4L * cus) return DRN_ERR_UNSUPPORTED;
+    if (nslab < 4 || tiles64_one <= cus / 4 || tiles64_one > 4L * cus || (long)p.Ho * p.Wo < 1024) return DRN_ERR_UNSUPPORTED;
     pick = 64;
   }
   if (pick == 128) return launch_ring<128, 128, 3>(p, st);

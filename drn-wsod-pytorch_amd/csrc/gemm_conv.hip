@@ -32,7 +32,7 @@ struct GemmParams {
   int k_slabs_per_split;
   long c_split_stride;  // elements
   int accumulate;
-  // fused-optimizer epilogue (gemm_nt256_kernel<.., SGD=true>): C is never stored, the tile updates W in place
+  // fused optimizer step (drn_gemm_tn_sgd, SgdPipe): the previous tile's update rides in the next tile's mainloop
   float* sgd_w;
   float* sgd_mom;
   bf16_t* sgd_shadow;  // bf16 compute copy of W (same layout) or null
@@ -704,10 +704,6 @@ __device__ __forceinline__ void pp_mainloop(f32x16_t (&acc)[4][2], char* smem, _
 //     drain them).
 //   * operands are swapped in the MFMA (D^T = B.A^T) so a lane holds 4 consecutive output columns per register
 //     quad: the epilogue issues 16-B stores (4x fewer store instructions; the fc6 dW output is 411 MB).
-//   * SGD = true: the fc6 weight-gradient GEMM with the optimizer step as its epilogue.  The gradient tile stays in
-//     the accumulators and W / momentum / the bf16 shadow are updated in place (same arithmetic and order as
-//     sgd_kernel in head.hip), so the 411 MB gradient is neither written nor re-read and the HBM-bound optimizer
-//     pass over the largest tensor disappears as a separate launch.  Single-GPU, no-accumulation steps only.
 // Buffer descriptor of the TN operand's tile: Bt [kb_rows][ldb] from column bn on; rows beyond kb_rows (the K padding) and
 // everything behind the matrix read as zeros.  (Columns beyond N inside a row run into the next row: finite values that
 // only reach output columns >= N, which are never stored.)
@@ -717,7 +713,7 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_tn_rsrc(const char* B, in
   return __builtin_amdgcn_make_buffer_rsrc((void*)(B + (long)bn * es), 0, (unsigned)bytes, 0x00020000);
 }
 
-template <int DT, bool PIPE, bool SGD = false, int PP = 0, bool TN = false>
+template <int DT, bool PIPE, int PP = 0, bool TN = false>
 __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   constexpr int ES = DT == DRN_BF16 ? 2 : 4;
@@ -875,55 +871,6 @@ __global__ __launch_bounds__(512) void gemm_nt256_kernel(GemmParams p) {
     }
   }
   // D^T layout: lane -> m (A row) = lane&31, register r -> n = (r&3) + 8*(r>>2) + 4*(lane>>5)
-  if constexpr (SGD) {
-#pragma clang fp contract(off)
-    const float lr = p.sgd_seg->lr, wd = p.sgd_seg->wd;
-    const float momentum = p.sgd_momentum, gs = p.sgd_grad_scale;
-    const bool first = p.sgd_first_step != 0;
-#pragma unroll
-    for (int i = 0; i < MI; ++i) {
-      const int m = bm + wm * 128 + i * 32 + (lane & 31);
-      if (m >= p.M) continue;
-      const long row = (long)m * p.ldc;
-      f32x4_t pw[NJ][4], mm[NJ][4];
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = bn + (TN ? j * 128 + wn * 32 : wn * 64 + j * 32) + 8 * q + 4 * (lane >> 5);
-          pw[j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          mm[j][q] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-          if (n < p.N) {  // N % 4 == 0 (launcher): a 4-column group is inside or outside as a whole
-            pw[j][q] = *(const f32x4_t*)(p.sgd_w + row + n);
-            if (!first) mm[j][q] = *(const f32x4_t*)(p.sgd_mom + row + n);
-          }
-        }
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int n = bn + (TN ? j * 128 + wn * 32 : wn * 64 + j * 32) + 8 * q + 4 * (lane >> 5);
-          if (n >= p.N) continue;
-          f32x4_t nb, nw;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float d = acc[i][j][4 * q + e] * gs;
-            if (wd != 0.f) d = d + wd * pw[j][q][e];
-            nb[e] = first ? d : momentum * mm[j][q][e] + d;
-            nw[e] = pw[j][q][e] - lr * nb[e];
-          }
-          *(f32x4_t*)(p.sgd_mom + row + n) = nb;
-          *(f32x4_t*)(p.sgd_w + row + n) = nw;
-          if (p.sgd_shadow) {
-            uint2 o;
-            o.x = (uint32_t)f32_to_bf16(nw[0]) | ((uint32_t)f32_to_bf16(nw[1]) << 16);
-            o.y = (uint32_t)f32_to_bf16(nw[2]) | ((uint32_t)f32_to_bf16(nw[3]) << 16);
-            *(uint2*)(p.sgd_shadow + row + n) = o;
-          }
-        }
-    }
-    return;
-  }
   float* C = p.C + (long)split * p.c_split_stride;
   const bool vec_ok = (p.ldc & 3) == 0 && (((uintptr_t)C) & 15) == 0;
 #pragma unroll
@@ -981,7 +928,7 @@ struct GemmWork { int bm, bn, s0, s1, split; __amdgpu_buffer_rsrc_t ra, rb; };  
 // the fc7 weight gradient (128 tiles: half the CUs in one round) and the fc7 dX (64 tiles x 4 K-splits of half the
 // length), 46 + 41 us one after the other.  (Two concurrent launches on a forked stream do the same on paper and cost
 // 250 us in the captured step: the graph executor starts the branch late.)
-template <int DT, bool SGD, int PP = 0, bool TN = false, bool PAIR = false, bool SGDP = false>
+template <int DT, int PP = 0, bool TN = false, bool PAIR = false, bool SGDP = false>
 __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p_in, GemmParams p2_in, int pair_wg0) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const bool second = PAIR && (int)(blockIdx.x >> 3) >= pair_wg0;
@@ -1149,54 +1096,7 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p_in, GemmP
     }
     const int bm = cur.bm, bn = cur.bn;
     // D^T layout: lane -> m (A row) = lane&31, register r -> n = (r&3) + 8*(r>>2) + 4*(lane>>5)
-    if constexpr (SGD) {
-#pragma clang fp contract(off)
-      const float lr = p.sgd_seg->lr, wd = p.sgd_seg->wd;
-      const float momentum = p.sgd_momentum, gs = p.sgd_grad_scale;
-      const bool first = p.sgd_first_step != 0;
-#pragma unroll
-      for (int i = 0; i < MI; ++i) {
-        const int m = bm + wm * 128 + i * 32 + (lane & 31);
-        if (m >= p.M) continue;
-        const long row = (long)m * p.ldc;
-        f32x4_t pw[NJ][4], mm[NJ][4];
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int n = bn + (TN ? jj * 128 + wn * 32 : wn * 64 + jj * 32) + 8 * qq + 4 * (lane >> 5);
-            pw[jj][qq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            mm[jj][qq] = f32x4_t{0.f, 0.f, 0.f, 0.f};
-            if (n < p.N) {
-              pw[jj][qq] = *(const f32x4_t*)(p.sgd_w + row + n);
-              if (!first) mm[jj][qq] = *(const f32x4_t*)(p.sgd_mom + row + n);
-            }
-          }
-#pragma unroll
-        for (int jj = 0; jj < NJ; ++jj)
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int n = bn + (TN ? jj * 128 + wn * 32 : wn * 64 + jj * 32) + 8 * qq + 4 * (lane >> 5);
-            if (n >= p.N) continue;
-            f32x4_t nb, nw;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-              float d = acc[i][jj][4 * qq + e] * gs;
-              if (wd != 0.f) d = d + wd * pw[jj][qq][e];
-              nb[e] = first ? d : momentum * mm[jj][qq][e] + d;
-              nw[e] = pw[jj][qq][e] - lr * nb[e];
-            }
-            *(f32x4_t*)(p.sgd_mom + row + n) = nb;
-            *(f32x4_t*)(p.sgd_w + row + n) = nw;
-            if (p.sgd_shadow) {
-              uint2 o;
-              o.x = (uint32_t)f32_to_bf16(nw[0]) | ((uint32_t)f32_to_bf16(nw[1]) << 16);
-              o.y = (uint32_t)f32_to_bf16(nw[2]) | ((uint32_t)f32_to_bf16(nw[3]) << 16);
-              *(uint2*)(p.sgd_shadow + row + n) = o;
-            }
-          }
-      }
-    } else if (p.c_bf16 && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0) {
+    if (p.c_bf16 && (p.ldc & 7) == 0 && (((uintptr_t)p.C) & 15) == 0) {
       // bf16 output (the fc6 dW gradient bucket: one epilogue per 32 K-slabs, 128 KB per tile): the MFMA layout gives a
       // lane 4 consecutive columns of 32 DIFFERENT rows, i.e. 8-byte stores scattered over 32 lines per instruction.
       // The tile goes through the free LDS stage instead, one 128-row half at a time (64 KB), and leaves as 16-byte
@@ -1331,6 +1231,107 @@ __global__ __launch_bounds__(512) void gemm_nt256p_kernel(GemmParams p_in, GemmP
     }
   }
 }
+
+// ------------------------------------------------------------------------------------------------
+// 1x1 convolution (stride 1, no padding) of a LARGE map as a GEMM on the 256x256 ping-pong mainloop (round 5): the bf16
+// bottleneck 1x1s of the shipped dilated-C5 trunk at a real image size are [15000 x Cin] . [Cout x Cin]^T with Cout = 1024 /
+// 2048 - 236 / 472 tiles of 256 x 256 - and ran at 300-640 TFLOP/s on the 128x128 register-staged tile (profiles/r5_12_*).
+// A = the NHWC input itself (row = pixel), B = the packed weights; the epilogue is the conv's: per-channel affine (folded
+// FrozenBN), shortcut add, ReLU, bf16 store.  The accumulators leave through LDS as fp32, one 128-row half of the tile (128 KB
+// = both operand stages, free behind the mainloop) at a time, 16-byte chunk c of row r at c ^ (r & 15): a lane then owns 4
+// consecutive channels of one pixel, a wave instruction one whole 512-byte row - 8-byte shortcut loads and 8-byte stores of
+// complete rows instead of the MFMA layout's 32 rows x 16 bytes per instruction.
+// Same slab order, k-steps and MFMA per output element as the tiled conv kernels: bit-identical to them.
+__global__ __launch_bounds__(512) void conv1x1_pp_kernel(ConvParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int Mtot = p.Nb * p.Ho * p.Wo;
+  const int tiles_m = (Mtot + 255) / 256, tiles_n = (p.Cout + 255) / 256;
+  int tm, tn;
+  tile_coords(xcd_remap(blockIdx.x, tiles_m * tiles_n), tiles_m, tiles_n, tm, tn, 4);
+  const int bm = tm * 256, bn = tn * 256;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 2, wn = wave & 3;
+  const RowLoader la = make_row_loader(p.X, bm, Mtot, 256, (long)p.Cin * 2);
+  const RowLoader lb = make_row_loader(p.Wt, bn, p.Cout, 256, p.ldw * 2);
+  unsigned pva[4], pvb[4];
+  pp_offsets<false>(la.ld_bytes, lb.ld_bytes, tid, pva, pvb);
+  f32x16_t acc[4][2];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  const int nslab = p.Cin >> 6;
+  pp_issue_first(smem, la.rsrc, lb.rsrc, pva, pvb, wave, 0);
+  pp_mainloop<DRN_BF16, 1>(acc, smem, la.rsrc, lb.rsrc, pva, pvb, 0, nslab, lane, wave);
+  // D^T layout: lane -> m (A row) = lane & 31, register r -> n = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+  const int l31 = lane & 31, hi = lane >> 5;
+  float* tile = (float*)smem;  // [128][256] fp32, 16-byte chunks XOR-swizzled with the row
+  typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+  const int nn = bn + lane * 4;  // this lane's 4 channels in the read-back phase
+  const bool col_ok = nn < p.Cout;
+  f32x4_t sc = {1.f, 1.f, 1.f, 1.f}, bi = {0.f, 0.f, 0.f, 0.f};
+  if (col_ok && p.scale) sc = *(const f32x4_t*)(p.scale + nn);
+  if (col_ok && p.bias) bi = *(const f32x4_t*)(p.bias + nn);
+#pragma unroll 1
+  for (int half = 0; half < 2; ++half) {
+    __syncthreads();  // every wave is done with the operand stages / with the previous half
+    // shortcut rows of this half, fetched ahead of the staging: wave w owns rows w, w + 8, ... of the half
+    u32x2_t rv[16];
+    if (p.residual && col_ok) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int m = bm + half * 128 + q * 8 + wave;
+        rv[q] = *(const u32x2_t*)(p.residual + ((long)(m < Mtot ? m : Mtot - 1) * p.ldres + nn) * 2);
+      }
+    }
+    if (wm == half) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int row = i * 32 + l31;
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int c = wn * 16 + j * 8 + 2 * q + hi;  // 16-byte chunk = 4 channels
+            const f32x4_t v = {acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]};
+            *(f32x4_t*)(tile + row * 256 + ((c ^ (row & 15)) << 2)) = v;
+          }
+      }
+    }
+    __syncthreads();
+    if (col_ok) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = q * 8 + wave, m = bm + half * 128 + row;
+        if (m >= Mtot) break;
+        const f32x4_t a = *(const f32x4_t*)(tile + row * 256 + ((lane ^ (row & 15)) << 2));
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = a[e] * sc[e] + bi[e];
+        if (p.residual) {
+#pragma unroll
+          for (int e = 0; e < 2; ++e) {
+            v[2 * e] += __builtin_bit_cast(float, rv[q][e] << 16) * p.res_mult;
+            v[2 * e + 1] += __builtin_bit_cast(float, rv[q][e] & 0xffff0000u) * p.res_mult;
+          }
+        }
+        if (p.relu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        }
+        u32x2_t o;
+        o.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+        o.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+        *(u32x2_t*)(p.Y + ((long)m * p.ldy + nn) * 2) = o;
+      }
+    }
+  }
+}
+
+static int g_conv_pp = 1;  // drn_tune(DRN_TUNE_CONV_PP = 24): 0 = never run a 1x1 conv on the 256x256 ping-pong GEMM mainloop
 
 // Epilogue of the tiled conv kernels: per-channel affine (+ residual, ReLU) and the store.  `tid` = 0..255 within the
 // four waves that own the accumulators; `active` = false for waves that only take part in the barriers (the second
@@ -2017,11 +2018,11 @@ int launch_gemm(const GemmParams& p, int splits, hipStream_t st) {
   return DRN_OK;
 }
 
-template <int DT, bool PIPE, bool SGD = false, int PP = 0, bool TN = false>
+template <int DT, bool PIPE, int PP = 0, bool TN = false>
 int launch_gemm256(const GemmParams& p, int splits, hipStream_t st) {
   const int tiles = ((p.M + 255) / 256) * ((p.N + 255) / 256);
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256_kernel<DT, PIPE, SGD, PP, TN>;
+  auto k = gemm_nt256_kernel<DT, PIPE, PP, TN>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -2048,10 +2049,10 @@ static int cu_count() {
   return n;
 }
 
-template <int DT, bool SGD, int PP = 0, bool TN = false>
+template <int DT, int PP = 0, bool TN = false>
 int launch_gemm256p(const GemmParams& p, int nwg, hipStream_t st) {
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256p_kernel<DT, SGD, PP, TN>;
+  auto k = gemm_nt256p_kernel<DT, PP, TN>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -2065,7 +2066,7 @@ int launch_gemm256p(const GemmParams& p, int nwg, hipStream_t st) {
 
 static int launch_gemm256p_tn_sgdp(const GemmParams& p, int nwg, hipStream_t st) {
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256p_kernel<DRN_BF16, false, 1, true, false, true>;
+  auto k = gemm_nt256p_kernel<DRN_BF16, 1, true, false, true>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -2079,7 +2080,7 @@ static int launch_gemm256p_tn_sgdp(const GemmParams& p, int nwg, hipStream_t st)
 
 static int launch_gemm256p_pair(const GemmParams& p0, const GemmParams& p1, int nwg, int wg0, hipStream_t st) {
   constexpr int smem = 2 * 512 * 128;
-  auto k = gemm_nt256p_kernel<DRN_BF16, false, 1, false, true>;
+  auto k = gemm_nt256p_kernel<DRN_BF16, 1, false, true>;
   static bool attr = false;
   if (!attr) {
     if (hipFuncSetAttribute((const void*)k, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
@@ -2113,7 +2114,6 @@ static int persistent_grid(long total) {
   return (nwg >= 8 && total > nwg) ? nwg : 0;
 }
 
-static int g_conv_coresident = 0;  // drn_tune(DRN_TUNE_CONV_CORESIDENT = 17): 1 = only kernels that fit beside a 256x256 GEMM workgroup
 static int g_conv_ksplit = 1;  // drn_tune(DRN_TUNE_CONV_KSPLIT): 0 = never use the 32x32 wave-K-split kernel
 static int g_conv_patch = 1;  // drn_tune(DRN_TUNE_CONV_PATCH): 0 = never use conv3x3_c64_kernel; > 1 = minimum pixels per image
 static long g_conv_patch_min = 32768;
@@ -2180,6 +2180,21 @@ int launch_conv_k2(const ConvParams& p, hipStream_t st) {
   return DRN_OK;
 }
 
+static int launch_conv1x1_pp(const ConvParams& p, hipStream_t st) {
+  const long Mtot = (long)p.Nb * p.Ho * p.Wo;
+  const int tiles = (int)((Mtot + 255) / 256) * ((p.Cout + 255) / 256);
+  constexpr int smem = 2 * 512 * 128;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)conv1x1_pp_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, smem) != hipSuccess)
+      return DRN_ERR_LAUNCH;
+    attr = true;
+  }
+  hipLaunchKernelGGL(conv1x1_pp_kernel, dim3(tiles), dim3(512), smem, st, p);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
 template <int DT, int BM, int BN, bool K64 = true>
 int launch_conv(const ConvParams& p, hipStream_t st) {
   const int Mtot = p.Nb * p.Ho * p.Wo;
@@ -2216,7 +2231,7 @@ static long tail_split_main_cols(int M, int N, int splits, int nwg) {
 static int g_force_tile = 0;  // 0 = heuristic; 64 / 128 / 256 pin the tile (tuning + tests)
 
 // conv_ring.hip: the register-ring kernels (bf16, Cin % 64 == 0); DRN_ERR_UNSUPPORTED outside their class
-__attribute__((visibility("hidden"))) int drn_conv_ring_try(const ConvParams& p, int dtype, int cus, bool small_map, hipStream_t st);
+__attribute__((visibility("hidden"))) int drn_conv_ring_try(const ConvParams& p, int dtype, int cus, long tiles64_one, hipStream_t st);
 __attribute__((visibility("hidden"))) int drn_conv_ring_set(int v);
 
 extern "C" {
@@ -2251,11 +2266,6 @@ int drn_tune(int knob, int value) {
   if (knob == 15) return drn_roi_set_lds_kb(value);    // DRN_TUNE_ROI_LDS_KB
   if (knob == 19) return drn_roi_set_lane(value);      // DRN_TUNE_ROI_LANE
   if (knob == 22) return drn_roi_set_lane_reps(value);  // DRN_TUNE_ROI_LANE_REPS
-  if (knob == 17) {  // DRN_TUNE_CONV_CORESIDENT
-    const int old = g_conv_coresident;
-    g_conv_coresident = value != 0;
-    return old;
-  }
   if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
     const int old = g_conv_ksplit;
     g_conv_ksplit = value != 0;
@@ -2303,6 +2313,11 @@ int drn_tune(int knob, int value) {
     return old;
   }
   if (knob == 23) return drn_conv_ring_set(value);  // DRN_TUNE_CONV_RING
+  if (knob == 24) {  // DRN_TUNE_CONV_PP
+    const int old = g_conv_pp;
+    if (value >= 0) g_conv_pp = value;
+    return old;
+  }
   if (knob == 3) {  // DRN_TUNE_GEMM_GROUP_ROWS
     const int old = g_group_rows;
     if (value >= 0 && value <= 64) g_group_rows = value;
@@ -2370,14 +2385,14 @@ int drn_gemm_nt(const void* A, const void* B, void* C, int M, int N, int K, long
         if (rc != DRN_OK) return rc;
         p.N = (int)n0;
       }
-      if (dtype == DRN_BF16 && g_pingpong == 1) return launch_gemm256p<DRN_BF16, false, 1>(p, nwg, st);
-      if (dtype == DRN_BF16 && g_pingpong == 2) return launch_gemm256p<DRN_BF16, false, 2>(p, nwg, st);
-      if (dtype == DRN_BF16 && g_pingpong == 3) return launch_gemm256p<DRN_BF16, false, 3>(p, nwg, st);
-      return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, false>(p, nwg, st) : launch_gemm256p<DRN_F32, false>(p, nwg, st);
+      if (dtype == DRN_BF16 && g_pingpong == 1) return launch_gemm256p<DRN_BF16, 1>(p, nwg, st);
+      if (dtype == DRN_BF16 && g_pingpong == 2) return launch_gemm256p<DRN_BF16, 2>(p, nwg, st);
+      if (dtype == DRN_BF16 && g_pingpong == 3) return launch_gemm256p<DRN_BF16, 3>(p, nwg, st);
+      return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16>(p, nwg, st) : launch_gemm256p<DRN_F32>(p, nwg, st);
     }
-    if (dtype == DRN_BF16 && g_pingpong == 1) return launch_gemm256<DRN_BF16, true, false, 1>(p, splits, st);
-    if (dtype == DRN_BF16 && g_pingpong == 2) return launch_gemm256<DRN_BF16, true, false, 2>(p, splits, st);
-    if (dtype == DRN_BF16 && g_pingpong == 3) return launch_gemm256<DRN_BF16, true, false, 3>(p, splits, st);
+    if (dtype == DRN_BF16 && g_pingpong == 1) return launch_gemm256<DRN_BF16, true, 1>(p, splits, st);
+    if (dtype == DRN_BF16 && g_pingpong == 2) return launch_gemm256<DRN_BF16, true, 2>(p, splits, st);
+    if (dtype == DRN_BF16 && g_pingpong == 3) return launch_gemm256<DRN_BF16, true, 3>(p, splits, st);
     return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true>(p, splits, st) : launch_gemm256<DRN_F32, true>(p, splits, st);
   }
   // 64x64 tiles (4x the workgroups) when 128x128 tiles would not even give every CU one workgroup: these launches are
@@ -2410,8 +2425,8 @@ int drn_gemm_tn(const void* A, const void* Bt, void* C, int M, int N, int K, int
   p.kb_rows = kb_rows;
   hipStream_t st = (hipStream_t)stream;
   const long wg256 = (long)((M + 255) / 256) * ((N + 255) / 256) * splits;
-  if (const int nwg = persistent_grid(wg256)) return launch_gemm256p<DRN_BF16, false, 1, true>(p, nwg, st);
-  return launch_gemm256<DRN_BF16, true, false, 1, true>(p, splits, st);
+  if (const int nwg = persistent_grid(wg256)) return launch_gemm256p<DRN_BF16, 1, true>(p, nwg, st);
+  return launch_gemm256<DRN_BF16, true, 1, true>(p, splits, st);
 }
 
 // Two independent NT GEMMs (bf16 operands, fp32 outputs) in ONE persistent launch of the 256x256 ping-pong kernel: the
@@ -2483,27 +2498,6 @@ int drn_gemm_tn_sgd(const void* A, const void* Bt, void* grad_bucket, int M, int
   return launch_gemm256p_tn_sgdp(p, nwg, (hipStream_t)stream);
 }
 
-// W[M,N] <- SGD(W, momentum_buf, G = A[M,K] * B[N,K]^T) with G kept in registers.  See include/drn_wsod.h.
-int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda, long ldb, int dtype, float* weights,
-                    float* momentum_buf, void* shadow, long ld_w, const void* seg_dev, float momentum, int first_step,
-                    float grad_scale, void* stream) {
-  if (!A || !B || !weights || !momentum_buf || !seg_dev || M < 0 || N < 0 || K < 0) return DRN_ERR_ARG;
-  if (M == 0 || N == 0) return DRN_OK;
-  if (dtype != DRN_F32 && dtype != DRN_BF16) return DRN_ERR_ARG;
-  const int es = drn_esize(dtype);
-  if ((K * es) % 128 != 0 || (lda * es) % 16 != 0 || (ldb * es) % 16 != 0 || lda < K || ldb < K) return DRN_ERR_ARG;
-  if (((uintptr_t)A | (uintptr_t)B | (uintptr_t)weights | (uintptr_t)momentum_buf) & 15) return DRN_ERR_ARG;
-  if ((N & 3) || (ld_w & 3) || ld_w < N || (((uintptr_t)shadow) & 7)) return DRN_ERR_ARG;
-  GemmParams p{(const char*)A, (const char*)B, nullptr, M, N, K, lda, ldb, ld_w, K * es / 128, 0, 0,
-               weights, momentum_buf, (bf16_t*)shadow, (const SgdSeg*)seg_dev, momentum, grad_scale, first_step};
-  p.nsplit = 1;
-  p.gm = gemm256_group_rows(M, N, 1);
-  hipStream_t st = (hipStream_t)stream;
-  if (const int nwg = persistent_grid((long)((M + 255) / 256) * ((N + 255) / 256)))
-    return dtype == DRN_BF16 ? launch_gemm256p<DRN_BF16, true>(p, nwg, st) : launch_gemm256p<DRN_F32, true>(p, nwg, st);
-  return dtype == DRN_BF16 ? launch_gemm256<DRN_BF16, true, true>(p, 1, st) : launch_gemm256<DRN_F32, true, true>(p, 1, st);
-}
-
 // NHWC conv + per-channel affine (folded FrozenBN or bias) + optional residual + optional ReLU; `dtype` is the element
 // type of x / w (fp32, bf16 or fp8 e4m3fn), y and the residual may be stored in another one (see include/drn_wsod.h).
 // The tail of a 64-channel bottleneck on a large map as ONE launch (conv3x3_c64_kernel<.., PW, POOL>): the 3x3's output never
@@ -2515,7 +2509,7 @@ int drn_conv3x3_pw_nhwc(const void* x, const void* w2, const float* scale2, cons
                         long ldw2, long ldw3, float res_mult, int relu3, int pool, void* stream) {
   if (!x || !w2 || !y || Nb <= 0 || H <= 0 || W <= 0) return DRN_ERR_ARG;
   auto al16 = [](const void* q) { return (((uintptr_t)q) & 15) == 0; };
-  if (!g_conv_patch || g_conv_coresident || (long)H * W < g_conv_patch_min || (long)Nb * H * W * 128 >= 0xFFFFFFF0L ||
+  if (!g_conv_patch || (long)H * W < g_conv_patch_min || (long)Nb * H * W * 128 >= 0xFFFFFFF0L ||
       ldw2 < 9 * 64 || (w3 && ldw3 < 64) || (ldw2 * 2) % 16 != 0 || (w3 && (ldw3 * 2) % 16 != 0) || !al16(x) || !al16(w2) ||
       (w3 && !al16(w3)) || !al16(y) || (residual && !al16(residual)) || (!w3 && !pool) ||
       (pool && (!(w3 ? relu3 : relu2) || H < 2 || W < 2)))
@@ -2559,14 +2553,6 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   const long ks_max = g_conv_ks_tiles > 0 ? g_conv_ks_tiles : (nslab >= 32 ? cu_count() : cu_count() / 4);
   // LDS-resident patch + weights for the 64-channel 3x3 layers of large maps (conv3x3_c64_kernel; 117 KB of LDS, so only
   // where the trunk is not meant to share CUs with the heads' GEMMs: maps of >= 32k pixels)
-  if (g_conv_coresident) {  // A/B: the trunk made of kernels with <= 16 KB of LDS and <= ~100 VGPRs only (64x64 single-stage
-    // tile, 32x32 wave-K-split), which share a CU with a resident 256x256 GEMM workgroup instead of waiting for it
-    if (g_conv_ksplit && tiles64 <= ks_max && nslab >= 8 && Nb <= 64)
-      return dtype == DRN_BF16 ? launch_conv_ks<DRN_BF16>(p, st)
-             : dtype == DRN_FP8 ? launch_conv_ks<DRN_FP8>(p, st) : launch_conv_ks<DRN_F32>(p, st);
-    return dtype == DRN_BF16 ? launch_conv<DRN_BF16, 64, 64>(p, st)
-           : dtype == DRN_FP8 ? launch_conv<DRN_FP8, 64, 64>(p, st) : launch_conv<DRN_F32, 64, 64>(p, st);
-  }
   if (g_conv_patch && dtype == DRN_BF16 && out_dtype == DRN_BF16 && (!residual || res_dtype == DRN_BF16) && Cin == 64 &&
       Cout == 64 && KH == 3 && KW == 3 && stride == 1 && dil == 1 && pad == 1 && (long)Ho * Wo >= g_conv_patch_min &&
       (ldy & 7) == 0 && (((uintptr_t)y) & 15) == 0 && (!residual || ((ldres & 7) == 0 && (((uintptr_t)residual) & 15) == 0)) &&
@@ -2574,8 +2560,20 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
     return launch_conv3x3_c64(p, st);
   // everything beyond the latency-bound small maps: the register-ring kernels (conv_ring.hip; bf16, Cin % 64 == 0).  Decided on
   // ONE image's geometry: the small-map kernels below add their K partials in another order
+  // 1x1 / stride 1 convs to >= 256 channels with >= 100 tiles of 256x256 per image: the GEMM ping-pong mainloop with the conv
+  // epilogue (conv1x1_pp_kernel; the dilated-C5 trunk's 1x1s to 512 / 1024 / 2048 channels and the res2 1x1s to 256 channels
+  // at a real image size).  Threshold measured (profiles/r5_17_conv1x1_pp_threshold_*.txt): at 59-60 tiles - res4 of the C4
+  // trunk, the DC5 trunk's 1x1s to 256 channels - a 256x256 tile per CU on a quarter of the chip loses to the small tiles, at
+  // 118 it wins; a 64-channel output wastes three quarters of the tile.  Decided on ONE image's geometry; same bits as the
+  // tiled kernels either way.
+  if (g_conv_pp && dtype == DRN_BF16 && out_dtype == DRN_BF16 && (!residual || res_dtype == DRN_BF16) && KH == 1 && KW == 1 &&
+      stride == 1 && pad == 0 && (Cin & 63) == 0 && (Cout & 7) == 0 && (ldy & 3) == 0 && (!residual || (ldres & 3) == 0) &&
+      (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)residual) & 15) == 0 && (ldw * 2) % 16 == 0 &&
+      (long)Cout * ldw * 2 < 0xFFFFFFF0L && (Cout >= 256 || g_conv_pp > 1) &&
+      (((long)Ho * Wo + 255) / 256) * ((Cout + 255) / 256) >= (g_conv_pp > 1 ? g_conv_pp : 100))
+    return launch_conv1x1_pp(p, st);
   {
-    const int rc = drn_conv_ring_try(p, dtype, cu_count(), tiles64 <= cu_count() / 4, st);
+    const int rc = drn_conv_ring_try(p, dtype, cu_count(), tiles64, st);
     if (rc != DRN_ERR_UNSUPPORTED) return rc;
   }
   // two K-groups per 64x64 tile (conv_nhwc_k2_kernel): mid-size layers - more 64x64 tiles than the wave-K-split kernel

@@ -115,8 +115,7 @@ class FusedSGD:
         return self._segs_dev, self._nseg
 
     # ---- pipelined mode: the update of a gradient bucket starts as soon as the bucket is final ----------------
-    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None, exchange=None, col_rounds=None, kshard_wire=None,
-                         fused_tn=None):
+    def enable_pipelined(self, dp=None, slab_rows=None, comm_dtype=None, exchange=None, kshard_wire=None, fused_tn=None):
         """ITER_SIZE == 1 only.  The explicit backward finishes gradients in a known order: first every small tensor
         (predictors, fc7, fc6 bias), then fc6.weight in row slabs.  In pipelined mode each bucket is (all-reduced when
         N > 1 and then) updated by the SGD kernel on a second stream the moment its dW GEMM is queued, so the HBM-bound
@@ -159,8 +158,13 @@ class FusedSGD:
         # updates only the owned columns (_HeadEngine.kshard).  The small tensors keep the all-reduce.  Fixed-shape batches,
         # eager steps.
         self._kshard = exchange == "fc6_kshard" and dp is not None and dp.exchange
+        e.kshard, e.fc1_fused_cols = None, None  # (re-entrant: bench.py falls back from one exchange to the next)
         if self._kshard:
-            e.kshard = dict(group=dp.group, world=world, rank=dist.get_rank(dp.group), wire=kshard_wire)
+            import weakref
+
+            me = weakref.ref(self)
+            e.kshard = dict(group=dp.group, world=world, rank=dist.get_rank(dp.group), wire=kshard_wire,
+                            sync=lambda: me() is not None and me().sync_master())
             e.fc1_fused_cols = self._fused_fc1_cols if (fused_tn is None or fused_tn) else None
             slab_rows = [d1]
         self._sharded = world > 1 and exchange not in ("allreduce", "fc6_kshard")
@@ -195,18 +199,10 @@ class FusedSGD:
             self._install_state_dict_hook()
         self._slab_ends = slab_rows
         e.fc1_slab_ends = slab_rows
-        # col_rounds (single process): the fc6 dW in column slabs of that many exact rounds of the persistent GEMM, each
-        # updated by drn_sgd_step_block the moment it is queued (_HeadEngine.fc1_col_rounds); None = keep the engine's value
-        if col_rounds is not None:
-            e.fc1_col_rounds = 0 if (dp is not None and dp.exchange) else int(col_rounds)
         e.grad_ready_hook = self._on_grad_ready
         e.defer_colsum = True
         self._dp, self._pipelined = dp, True
         self._opt_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
-        # the joint peel of the fc6 dW (run_fc1_tail) may run on the optimizer stream, off the main stream's chain:
-        # single-process schedule only (with an exchange that stream carries the collectives, which must not queue behind it)
-        e.fc1_peel_stream = self._opt_stream if (getattr(self, "peel_on_opt_stream", False) and
-                                                 not (dp is not None and dp.exchange)) else None
         self._bucket_segs = {}
         # with an exchange the optimizer stream carries only the link-bound all-reduces (one event per bucket); the
         # HBM-bound SGD launches are issued by step() on the caller's stream, each behind its bucket's event, so the
@@ -236,19 +232,8 @@ class FusedSGD:
                 fused_tn = len(self.model.backbone.conv_modules()) <= 64
             except Exception:  # noqa: BLE001
                 fused_tn = True
-        if fused_tn and not self._exchange_on and e.fc1_grad_bucket is not None and not col_rounds:
+        if fused_tn and not self._exchange_on and e.fc1_grad_bucket is not None:
             self.enable_fused_fc1_tn()
-
-    def enable_fused_fc1(self):
-        """Single process, ITER_SIZE == 1, on top of the pipelined mode: the fc6 weight gradient (the largest tensor by
-        far: D1 x C*49) is consumed by the optimizer inside the dW GEMM's epilogue (drn_gemm_nt_sgd), so it is never
-        written to or read back from HBM and its share of the optimizer pass needs no launch of its own.  Same
-        arithmetic as the SGD kernel; `fc1.weight.grad` is not materialised in this mode."""
-        if not getattr(self, "_pipelined", False):
-            raise DrnError("enable_pipelined() first")
-        if self._dp is not None and self._dp.world > 1:
-            raise DrnError("fused fc6 dW+SGD is a single-process mode: with N > 1 the gradient must be all-reduced")
-        self.engine.fc1_fused_update = self._fused_fc1
 
     def enable_fused_fc1_tn(self):
         """Single process, ITER_SIZE == 1, bf16 mode, on top of the pipelined mode (round 4): the fc6 weight gradient's main
@@ -292,16 +277,6 @@ class FusedSGD:
         if ok:
             self._master_stale = True
         return ok
-
-    def _fused_fc1(self, dPT, AT, D1, K1, Mp):
-        e = self.engine
-        if self._mom is None:
-            self._mom = torch.zeros_like(e.arena_w)
-        segs, _ = self._bucket_table(("fc1", 0, D1))
-        o, n = e._seg["fc1.weight"]
-        view = lambda t: t[o: o + n].view(D1, K1)
-        ops.gemm_nt_sgd(dPT, AT, D1, K1, Mp, view(e.arena_w), view(self._mom),
-                        view(e.arena_s) if e.arena_s is not None else None, segs, self.momentum, self._steps == 0, 1.0)
 
     def _bucket_table(self, what):
         groups = [g for g in self.param_groups if g["used"]]
@@ -450,8 +425,10 @@ class FusedSGD:
             try:
                 work.wait(timeout=datetime.timedelta(seconds=self.sync_timeout))
                 return
-            except Exception:  # noqa: BLE001 - timeout / peer missing: the error below says what to do
-                t0 = time.monotonic() - self.sync_timeout - 1.0
+            except Exception as ex:  # noqa: BLE001 - timeout / peer failure: the group is unusable either way
+                raise DrnError("%s is a collective in the sharded exchange: the rendezvous on rank %d failed or timed out "
+                               "after %.0f s (%s).  Call it on EVERY rank, or train with exchange='allreduce'"
+                               % (what, dist.get_rank(self._dp.group), self.sync_timeout, ex)) from ex
         while not work.is_completed():
             if time.monotonic() - t0 > self.sync_timeout:
                 raise DrnError("%s is a collective in the sharded exchange (every rank holds the fp32 master / momentum "
@@ -488,14 +465,12 @@ class FusedSGD:
 
     def _on_grad_ready(self, what):
         e = self.engine
-        if what != "small":
-            self._fc1_on_opt_stream = True  # fc6's update (or a part of it) runs on the optimizer stream this step: step() must join
         if self._mom is None:
             self._mom = torch.zeros_like(e.arena_w)
         if what[0] == "fc1b":
             if self._exchange_on and not getattr(self, "_kshard", False):
-                raise DrnError("column slabs of the fc6 weight gradient (fc1_col_rounds) are a single-process schedule; "
-                               "with a gradient exchange the slabs are row ranges")
+                raise DrnError("block updates of the fc6 weight gradient are a single-process / K-sharded schedule; with a "
+                               "gradient exchange the slabs are row ranges")
             # the block kernel takes the whole tensor's table entry (lr / wd on the device) + the block's bounds
             segs, nseg = self._bucket_table(("fc1", 0, self.model.roi_heads.box_head.fc1.weight.shape[0]))
         else:
@@ -520,7 +495,7 @@ class FusedSGD:
         e = self.engine
         world = self._dp.world if self._dp is not None else 1
         if what[0] == "fc1b":
-            # a rectangular block of fc1.weight (column slabs of the dW GEMM, _HeadEngine.fc1_col_rounds)
+            # a rectangular block of fc1.weight (the trailing columns of the fused dW launch; the K-sharded fc6's owned columns)
             _, r0, r1, c0, c1 = what
             k1 = self.model.roi_heads.box_head.fc1.weight.shape[1]
             ops.sgd_step_block(e.arena_w, self._mom, bucket if bucket is not None else e.arena_g, segs, r0, r1 - r0, c0,
@@ -556,18 +531,7 @@ class FusedSGD:
                 p.grad = None
         self.engine._grads_valid = False
 
-    def join(self):
-        """the caller's stream waits for the optimizer stream (see step(join=False))"""
-        if getattr(self, "_join_pending", False):
-            torch.cuda.current_stream().wait_stream(self._opt_stream)
-            self._join_pending = False
-
-    def step(self, grad_scale=1.0, join=True):
-        """join=False (pipelined mode without an exchange; GraphedTrainStep with the eager fc6 forward): the optimizer
-        stream - by then only the small tensors' chain: bias column sums, their SGD launch, the K-major twins of fc7 / the
-        predictors - is NOT joined here; the caller calls join() in front of the first reader of those weights (the heads
-        graph), so that chain runs beside the next batch's pooling and fc6 forward instead of in front of them.  (With
-        fc6's update inside its dW launch, which holds every CU, the chain only starts when that launch ends.)"""
+    def step(self, grad_scale=1.0):
         e = self.engine
         if not e._grads_valid:
             raise DrnError("optimizer.step() before any backward()")
@@ -593,14 +557,9 @@ class FusedSGD:
                 for g in gathered:
                     cur.wait_event(g)
                 self._deferred = []
-            elif join or getattr(self, "_fc1_on_opt_stream", False) or e.arena_s is None:
-                # every bucket was already updated on the optimizer stream during backward(): join it
-                # (also whenever fc6's own update ran there - the next fc6 forward reads it - or the forward re-casts shadows)
-                cur.wait_stream(self._opt_stream)
-                self._join_pending = False
             else:
-                self._join_pending = True
-            self._fc1_on_opt_stream = False
+                # every bucket was already updated on the optimizer stream during backward(): join it
+                cur.wait_stream(self._opt_stream)
             self._steps += 1
             e.mark_dirty(shadow_fresh=e.arena_s is not None)
             return
@@ -822,7 +781,8 @@ class DataParallel:
         collective and the rank instead of hanging the job.  Checks the arithmetic too (every rank
         contributes rank + 1).  Returns {collective: {"bytes", "ms", "algbw_GBps", "busbw_GBps"}} with the NCCL-tests
         bus-bandwidth convention (all-reduce 2 (N-1)/N, reduce-scatter / all-gather (N-1)/N of the buffer).
-        buckets: {"small": elements, "slabs": [(rows, cols), ...]}"""
+        buckets: {"small": elements, "slabs": [(rows, cols), ...], "kshard": None | {"pack_bytes", "M", "D1", "wire_dtype",
+        "dp1_dtype"}}"""
         import time
 
         if not (dist.is_available() and dist.is_initialized()):
@@ -905,6 +865,44 @@ class DataParallel:
                 raise DrnError("RCCL self-test: all_gather returned %r in the last rank's rows, expected %r" % (
                     float(full[rows - 1, cols - 1]), float(W)))
             del full, mine
+        ks = buckets.get("kshard")
+        if ks:
+            # the K-sharded fc6's own collectives at their real sizes: all-gather of the packed feature map /
+            # proposals, reduce-scatter of the partial pre-activation [N*M x D1] in the wire dtype, all-gather of dP1 [M x D1]
+            nb, M, D1 = int(ks["pack_bytes"]), int(ks["M"]), int(ks["D1"])
+            pk, pk_all = torch.empty((nb,), dtype=torch.uint8, device=dev), torch.empty((W, nb), dtype=torch.uint8, device=dev)
+
+            def ag_pack():
+                pk.fill_(rank + 1)
+                return dist.all_gather_into_tensor(pk_all.view(-1), pk, group=g, async_op=True)
+
+            out["all_gather feature pack (fc6_kshard)"] = timed(ag_pack, "all_gather of the packed feature map / proposals (%d bytes)" % nb,
+                                                                 W * nb, (W - 1.0) / W)
+            if int(pk_all[W - 1, nb - 1]) != W:
+                raise DrnError("RCCL self-test: all_gather of the feature pack returned %r, expected %r" % (int(pk_all[W - 1, nb - 1]), W))
+            wdt = ks.get("wire_dtype", torch.float32)
+            part, h1 = torch.empty((W * M, D1), dtype=wdt, device=dev), torch.empty((M, D1), dtype=wdt, device=dev)
+
+            def rs_h1():
+                part.fill_(rank + 1.0)
+                return dist.reduce_scatter_tensor(h1.view(-1), part.view(-1), group=g, async_op=True)
+
+            out["reduce_scatter H1 partials (fc6_kshard)"] = timed(rs_h1, "reduce_scatter of the fc6 partial pre-activation [%d x %d] (%s)"
+                                                                   % (W * M, D1, str(wdt).replace("torch.", "")),
+                                                                   part.numel() * part.element_size(), (W - 1.0) / W)
+            if float(h1[0, 0]) != exp:
+                raise DrnError("RCCL self-test: reduce_scatter of H1 returned %r, expected %r" % (float(h1[0, 0]), exp))
+            ddt = ks.get("dp1_dtype", torch.bfloat16)
+            dp1, dp1_all = torch.empty((M, D1), dtype=ddt, device=dev), torch.empty((W, M, D1), dtype=ddt, device=dev)
+
+            def ag_dp1():
+                dp1.fill_(rank + 1.0)
+                return dist.all_gather_into_tensor(dp1_all.view(-1), dp1.view(-1), group=g, async_op=True)
+
+            out["all_gather dP1 (fc6_kshard)"] = timed(ag_dp1, "all_gather of dP1 [%d x %d]" % (M, D1),
+                                                        dp1_all.numel() * dp1_all.element_size(), (W - 1.0) / W)
+            if float(dp1_all[W - 1, M - 1, D1 - 1]) != float(W):
+                raise DrnError("RCCL self-test: all_gather of dP1 returned %r, expected %r" % (float(dp1_all[W - 1, M - 1, D1 - 1]), float(W)))
         return out
 
     def finish(self):
@@ -1021,7 +1019,7 @@ class GraphedTrainStep:
     _needs_frozen_trunk = True
 
     def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False,
-                 eager_fc6=False, stage_ahead=True, eager_pool=True, pool_overlap=False):
+                 eager_fc6=False, stage_ahead=True):
         if getattr(model, "cpg", False):
             raise DrnError("CSCROIHeads decides per step, on the host, which class maps to compute: eager steps only")
         if self._needs_frozen_trunk and any(p.requires_grad for p in model.backbone.parameters()):
@@ -1037,10 +1035,9 @@ class GraphedTrainStep:
         # stream (False = the round-2 order, kept for A/B runs: proposals in front of the pooling graph on the main
         # stream, labels at the start of their own step, i.e. between the pooling kernel and the fc6 forward)
         self.stage_ahead = bool(stage_ahead)
-        # eager_pool: the pooling piece (two small copies + the pooling kernel) is issued eagerly instead of replayed as
-        # its own graph (lookahead >= 2 / pairs): a graph's hand-over to the next launch costs more than an eager launch gap
-        # (+0.65 % same-box A/B, profiles/r2_39_eager_pool_ab.txt); False = the graph (kept for A/B runs)
-        self.eager_pool = bool(eager_pool)
+        # (lookahead >= 2 / trunk groups) the pooling piece - one staging launch + the pooling kernel - is issued eagerly: a
+        # graph's hand-over to the next launch costs more than an eager launch gap (+0.65 %, profiles/r2_39_eager_pool_ab.txt;
+        # the graphed form of the piece was removed in round 5)
         # trunk_pairs: ONE conv chain per TWO batches (t+2 and t+3, launched on even steps): the chain is latency-bound,
         # so two images cost what one costs and the per-image chain time halves - for trunks whose chain is as long as
         # the step (WS-R101).  step() then takes (batch, next, t+2, t+3).
@@ -1092,18 +1089,10 @@ class GraphedTrainStep:
         self.losses = None
         self._side = torch.cuda.Stream()
         self._primed = False
-        # pool_overlap: the next batch's pooling piece on its own stream beside the dW tail, the two fc6 operand sets
-        # alternating (_run_pairs_overlap); needs the eager pieces around the heads graph
-        self.pool_overlap = int(pool_overlap) if (bool(pool_overlap) and bool(split_tail) and self.eager_fc6 and self.eager_pool
-                                                  and self.trunk_pairs and self.engine.kshard is None) else 0
-        self._pool_stream = torch.cuda.Stream() if self.pool_overlap else None
-        self._pool_done = None
-        self._pooled_slot = [None, None]
         self.split_tail = bool(split_tail)
-        if self.engine.kshard is not None and not (self.split_tail and self.eager_fc6 and self.eager_pool and
-                                                   (lookahead >= 2 or trunk_pairs)):
+        if self.engine.kshard is not None and not (self.split_tail and self.eager_fc6 and (lookahead >= 2 or trunk_pairs)):
             raise DrnError("K-sharded fc6 holds collectives in the pooling piece, behind the fc6 GEMM and in the dW tail: "
-                           "GraphedTrainStep(split_tail=True, eager_fc6=True, eager_pool=True, lookahead >= 2 or trunk_pairs)")
+                           "GraphedTrainStep(split_tail=True, eager_fc6=True, lookahead >= 2 or trunk_pairs)")
         self.engine.defer_fc1_tail = self.split_tail
         self.engine.pool_sets_pinned = None  # a new step captures anew: the previous owner's pin (if any) is void
         self.engine.pool_sets_pin_owner = None
@@ -1211,13 +1200,6 @@ class GraphedTrainStep:
         the two must agree - a re-allocation in between (an inference pass used to replace the sets) would
         make the replayed graph read freed memory without any error."""
         ptrs = (self.pooled["A"].data_ptr(), self.pooled["AT"].data_ptr())
-        if self.pool_overlap:  # (no captured kernel reads the operand sets in this mode: fc6 forward and dW tail are eager)
-            if not getattr(self, "_primed", False):
-                self.engine.pool_sets_pinned = (self.pooled["A"].dtype, True)
-                import weakref
-
-                self.engine.pool_sets_pin_owner = weakref.ref(self)
-            return
         if not getattr(self, "_primed", False):
             self._pool_ptrs = ptrs
             self.engine.pool_sets_pinned = (self.pooled["A"].dtype, True)
@@ -1246,8 +1228,6 @@ class GraphedTrainStep:
     def _heads(self, eager):
         """fc6 forward (eager, when timed) + the heads graph of the current batch on the current stream"""
         self._fc6_eager()
-        if hasattr(self.opt, "join"):
-            self.opt.join()  # (late_join) the small tensors' update chain: its first reader is the heads graph, not the fc6 forward
         return self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
 
     def _fc6_eager(self):
@@ -1306,7 +1286,7 @@ class GraphedTrainStep:
             self._stage_props(next_batch)
         main.wait_event(self._bb_done[s1])
         self._bb_done[sL] = ev
-        self._pool_body(s1) if (eager or self.eager_pool) else self.g_pool2[s1].replay()
+        self._pool_body(s1)
         if self.split_tail:
             self.opt.step(1.0)
         self._t = t + 1
@@ -1337,15 +1317,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
         self.g_bb2 = [torch.cuda.CUDAGraph() for _ in range(L)]
-        self.g_pool2 = [torch.cuda.CUDAGraph() for _ in range(L)]
         for sl in range(L):
             with torch.cuda.graph(self.g_bb2[sl], capture_error_mode="thread_local"):
                 self._bb_body(sl)
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.losses = self._main_body()
-        for sl in range(L if not self.eager_pool else 0):
-            with torch.cuda.graph(self.g_pool2[sl], capture_error_mode="thread_local"):
-                self._pool_body(sl)
         self._primed = True
         return first
 
@@ -1365,168 +1341,36 @@ class GraphedTrainStep:
         with torch.no_grad():
             self._pfeats[ps].copy_(self._pair_backbone(ps))
 
-    def _pair_pool_body(self, ps, half, slot=0, stage=True):
+    def _pair_pool_body(self, ps, half):
         with torch.no_grad():
             n = self.n_img
             # in front of the pooling kernel (see _pool_next)
-            if stage:
-                ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if self.stage_ahead else None,
-                                       self._gt_block if self.stage_ahead else None)
+            ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if self.stage_ahead else None,
+                                   self._gt_block if self.stage_ahead else None)
             if self.engine.kshard is not None:
                 self.pooled = self.engine.pool_kshard(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next)
                 return
             self.pooled = self.engine.pool(self._pfeats[ps][half * n: (half + 1) * n], self.rois_next, self.obj_next, True,
-                                           slot=slot)
+                                           slot=0)
             self._check_pooled()
-
-    def _run_pairs_overlap(self, eager, next_batch, *ahead):
-        """_run_pairs with the pooling piece of batch t+1 BESIDE the fc6 dW tail of step t (pool_overlap; round 4): the two
-        fc6 operand sets of the head engine alternate (batch t lives in set t & 1), so the pooling launch no longer has to
-        wait for the dW - the last reader of its own set was step t-1's.  It is issued on a stream of its own behind the
-        heads graph (the proposal / label blocks it overwrites are that graph's inputs) and runs under the power-capped
-        dW + optimizer launch, where an HBM-bound kernel costs its energy share instead of its stand-alone time."""
-        main = torch.cuda.current_stream()
-        t = self._t
-        eng = self.engine
-        if self._pool_done is not None:
-            main.wait_event(self._pool_done)  # this batch's operand set (pooled during the previous step)
-        self._side.wait_stream(main)
-        self.pooled = self._pooled_slot[t & 1]
-        if self.pool_overlap == 2:
-            return self._run_pairs_under_heads(eager, next_batch, *ahead)
-        losses = self._heads(eager)
-        ev_heads = torch.cuda.Event()
-        ev_heads.record(main)
-        with torch.cuda.stream(self._side):
-            evp = None
-            if self.stage_ahead:
-                self._stage_props(next_batch)
-                self._stage_labels_ahead(next_batch, via_stage=True)
-                evp = torch.cuda.Event()
-                evp.record(self._side)
-        if evp is None:
-            self._stage_props(next_batch)
-        G = self.G
-        k1, h1 = ((t + 1) // G) % 2, (t + 1) % G
-        ps_ = self._pool_stream
-        ps_.wait_event(ev_heads)
-        if evp is not None:
-            ps_.wait_event(evp)
-        ps_.wait_event(self._pdone[k1])
-        with torch.cuda.stream(ps_):
-            cur = self.pooled
-            self._pair_pool_body(k1, h1, slot=(t + 1) & 1)
-            self._pooled_slot[(t + 1) & 1] = self.pooled
-            self.pooled = cur
-            self._pool_done = torch.cuda.Event()
-            self._pool_done.record(ps_)
-        if self.split_tail:
-            # the captured backward recorded the operand set it was captured with: hand the tail this step's
-            tl = list(eng._tail)
-            tl[1], tl[6], tl[8] = self.pooled["AT"], self.pooled["A"], self.pooled.get("t_row0", 0)
-            eng._tail = tuple(tl)
-            eng.run_fc1_tail()
-        with torch.cuda.stream(self._side):
-            if t % G == 0:
-                ps = (t // G + 1) % 2
-                self._side.wait_event(self._pool_done)  # (pair slot ps was last read by the pooling of batch t-1: long done)
-                self._pair_stage(ahead[G - 2: 2 * G - 2], ps)
-                self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
-                ev = torch.cuda.Event()
-                ev.record(self._side)
-                self._pdone[ps] = ev
-        if self.split_tail:
-            self.opt.step(1.0)
-        self._t = t + 1
-        return losses
-
-    def _run_pairs_under_heads(self, eager, next_batch, *ahead):
-        """pool_overlap = 2: the pooling KERNEL of batch t+1 beside the heads chain of step t instead of beside the dW tail.
-        The chain between the fc6 forward and the dW launch is ~0.25 ms of small, latency-bound launches (plus two mid-size
-        GEMMs) that leave most CUs and most of the power budget idle, and the pooling kernel needs nothing from step t: it reads
-        the staged proposals (`rois_next` / `obj_next`, written on the side stream at the top of the step), the next batch's
-        features (ready since its group's conv chain) and writes the OTHER operand set.  Only the copy of the staged proposals /
-        labels into the heads graph's input blocks has to wait for the graph - it follows it on the main stream."""
-        main = torch.cuda.current_stream()
-        t = self._t
-        eng = self.engine
-        G = self.G
-        ps_ = self._pool_stream
-        ps_.wait_stream(main)  # (rois_next / the label stage were last read at the end of the previous step, on the main stream)
-        with torch.cuda.stream(ps_):  # (not the side stream: a group's conv chain may be queued there)
-            self._stage_props(next_batch)
-            if self.stage_ahead:
-                self._stage_labels_ahead(next_batch, via_stage=True)
-            evp = torch.cuda.Event()
-            evp.record(ps_)
-        self._fc6_eager()
-        ev_fwd = torch.cuda.Event()
-        ev_fwd.record(main)  # the pooling starts when the fc6 forward - a GEMM at the power cap - is through
-        k1, h1 = ((t + 1) // G) % 2, (t + 1) % G
-        ps_.wait_event(ev_fwd)
-        ps_.wait_event(self._pdone[k1])
-        with torch.cuda.stream(ps_):
-            cur = self.pooled
-            self._pair_pool_body(k1, h1, slot=(t + 1) & 1, stage=False)
-            self._pooled_slot[(t + 1) & 1] = self.pooled
-            self.pooled = cur
-            self._pool_done = torch.cuda.Event()
-            self._pool_done.record(ps_)
-        if hasattr(self.opt, "join"):
-            self.opt.join()
-        losses = self._main_body() if eager else (self.g_main.replay(), self.losses)[1]
-        if self.split_tail:
-            tl = list(eng._tail)
-            tl[1], tl[6], tl[8] = self.pooled["AT"], self.pooled["A"], self.pooled.get("t_row0", 0)
-            eng._tail = tuple(tl)
-            eng.run_fc1_tail()
-        # the next heads graph's input blocks (proposal boxes, labels): behind this step's graph, their last reader
-        main.wait_event(evp)
-        with torch.no_grad():
-            ops.stage_heads_inputs(self.rois_next, self.props, self._gt_stage if self.stage_ahead else None,
-                                   self._gt_block if self.stage_ahead else None)
-        with torch.cuda.stream(self._side):
-            if t % G == 0:
-                ps = (t // G + 1) % 2
-                self._side.wait_event(self._pool_done)
-                self._pair_stage(ahead[G - 2: 2 * G - 2], ps)
-                self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
-                ev = torch.cuda.Event()
-                ev.record(self._side)
-                self._pdone[ps] = ev
-        if self.split_tail:
-            self.opt.step(1.0)
-        self._t = t + 1
-        return losses
 
     def _run_pairs(self, eager, next_batch, *ahead):
         """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % 2.  Even t: the conv chain of pair t/2 + 1
         (batches t+2, t+3) starts on the side stream - its slot was last read by the pooling of batch t-1.  Every t: the
         pooling of batch t+1 reads its half of its pair's features (pair (t+1)/2, launched at step 2 ((t+1)/2) - 2)."""
-        if self.pool_overlap:
-            return self._run_pairs_overlap(eager, next_batch, *ahead)
         G = self.G
         main = torch.cuda.current_stream()
         t = self._t
         self._side.wait_stream(main)
         losses = self._heads(eager)
-        early = self.split_tail and self.stage_ahead and getattr(self, "stage_before_tail", False)
         evp = None
-        if early:
-            # (round 4, A/B knob - measured neutral, profiles/r4_21) the proposal / label staging of batch t+1 BEFORE the dW tail:
-            # the fused dW + SGD launch holds every CU for ~0.5 ms and tiny copies queued behind it only start when it ends
-            with torch.cuda.stream(self._side):
-                self._stage_props(next_batch)
-                self._stage_labels_ahead(next_batch, via_stage=True)
-                evp = torch.cuda.Event()
-                evp.record(self._side)
         if self.split_tail:
             self.engine.run_fc1_tail()
         with torch.cuda.stream(self._side):
             # proposals of batch t+1 on the side stream (ordered behind step t-1's pooling graph, their last reader, by the
             # wait above; in front of the conv chain): three small launches that sat between the last dW slab and the
             # pooling graph on the main stream (22 us in the timeline)
-            if self.stage_ahead and not early:
+            if self.stage_ahead:
                 self._stage_props(next_batch)
                 self._stage_labels_ahead(next_batch, via_stage=True)  # -> _gt_stage; the pooling graph hands them on
                 evp = torch.cuda.Event()
@@ -1544,10 +1388,9 @@ class GraphedTrainStep:
             self._stage_props(next_batch)
         k1, h1 = ((t + 1) // G) % 2, (t + 1) % G
         main.wait_event(self._pdone[k1])
-        self._pair_pool_body(k1, h1) if (eager or self.eager_pool) else self.g_ppool[k1][h1].replay()
+        self._pair_pool_body(k1, h1)
         if self.split_tail:
-            late = self.eager_fc6 and getattr(self, "late_join", False) and not getattr(self.opt, "_exchange_on", False)
-            self.opt.step(1.0, join=not late)
+            self.opt.step(1.0)
         self._t = t + 1
         return losses
 
@@ -1563,7 +1406,6 @@ class GraphedTrainStep:
             self._pfeats[1] = torch.zeros_like(self._pfeats[0])
             self._stage_props(b0)
             self._pair_pool_body(0, 0)
-            self._pooled_slot[0] = self.pooled
         self._pdone[0] = torch.cuda.Event()
         self._pdone[0].record(main)
         self._stage_labels(b0)
@@ -1574,16 +1416,11 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
         self.g_pbb = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
-        self.g_ppool = [[torch.cuda.CUDAGraph() for _ in range(G)] for _ in range(2)]
         for ps in (0, 1):
             with torch.cuda.graph(self.g_pbb[ps], capture_error_mode="thread_local"):
                 self._pair_bb_body(ps)
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):
             self.losses = self._main_body()
-        for ps in ((0, 1) if not self.eager_pool else ()):
-            for h in range(G):
-                with torch.cuda.graph(self.g_ppool[ps][h], capture_error_mode="thread_local"):
-                    self._pair_pool_body(ps, h)
         self._primed = True
         return first
 

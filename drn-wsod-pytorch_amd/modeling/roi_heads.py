@@ -538,7 +538,7 @@ class _HeadEngine:
         return [(a, b) for a, b in zip([0] + list(ends[:-1]), ends) if a < b]
 
     def _fc1_use_tn(self, dtype):
-        return (self.fc1_tn and dtype == torch.bfloat16 and getattr(self, "fc1_fused_update", None) is None
+        return (self.fc1_tn and dtype == torch.bfloat16
                 and self._tn_selfcheck())
 
     _tn_ok = None
@@ -569,20 +569,12 @@ class _HeadEngine:
             cls._tn_ok = bool(ok)
         return cls._tn_ok
 
-    # round 4: the fc6 weight gradient in COLUMN slabs of `fc1_col_rounds` exact rounds of the persistent GEMM each (0 = row
-    # slabs).  All tile rows x (rounds * CUs / tile rows) tile columns = rounds * CUs tiles per launch, so a slab costs no
-    # partial round whatever its width; its optimizer update (drn_sgd_step_block, the pipelined optimizer's hook) starts
-    # one round behind the GEMM instead of half the GEMM behind it (two row slabs), and only the LAST slab's update - 1/6
-    # of the 2-GB pass at R50-C4 - is exposed behind the GEMM.  (Row slabs cannot be made this fine: a slab of 2 tile rows
-    # is 392 tiles = 1.53 rounds, i.e. two rounds with the second half empty - the '4 slabs' experiment of round 3.)
-    fc1_col_rounds = 0
-
     def _fc1_col_plan(self, dtype, D1, K1):
-        """(n_main, slab width in columns) of the column-slab form, or None when it does not apply: TN operand form, a
-        gradient bucket or the arena as the destination, whole 256-column tiles"""
-        r = int(getattr(self, "fc1_col_rounds", 0) or 0)
+        """(n_main, slab width in columns) of the fused dW + SGD launch (drn_gemm_tn_sgd), or None when it does not apply: TN
+        operand form, a bf16 gradient bucket, whole 256-row tiles.  (Round 4 also ran the unfused dW in column slabs of exact
+        rounds with a block update per slab - measured neutral twice, profiles/r4_01_col_slabs_ab.txt - removed in round 5.)"""
         if getattr(self, "fc1_fused_tn", None) is not None and D1 % 256 == 0:
-            # fused dW + SGD launch (drn_gemm_tn_sgd): ONE slab of all exact rounds, the rest are the trailing columns
+            # ONE slab of all exact rounds, the rest are the trailing columns
             tiles_m = D1 // 256
             ncu = getattr(self, "_ncu", None)
             if ncu is None:
@@ -596,17 +588,7 @@ class _HeadEngine:
                 nt = K1 // 256
             if nt > 0 and self._fc1_use_tn(dtype):
                 return nt * 256, nt * 256
-        if r <= 0 or not self._fc1_use_tn(dtype) or getattr(self, "fc1_fused_update", None) is not None:
-            return None
-        tiles_m = (D1 + 255) // 256
-        ncu = getattr(self, "_ncu", None)
-        if ncu is None:
-            ncu = self._ncu = torch.cuda.get_device_properties(self.arena_w.device).multi_processor_count
-        wt = (r * ncu) // tiles_m
-        if wt < 1 or (r * ncu) % tiles_m or K1 // 256 < wt:
-            return None
-        n_main = (K1 // 256) // wt * wt * 256
-        return n_main, wt * 256
+        return None
 
     def _fc1_tail_row0(self, dtype, D1, K1):
         """first row of A^T the fc6 dW still reads: the smallest main-column count over the row slabs (the columns from
@@ -788,6 +770,13 @@ class _HeadEngine:
         fg_hook = getattr(self, "feature_grad_hook", None) if training else None
         csc = training and getattr(h, "csc_head", False)
         kshard = training and self.kshard is not None
+        if self.kshard is not None and not training:
+            # an evaluation forward reads ALL K columns of fc1.weight, and every rank has only updated its own block since
+            # the last gather: gather the owners' columns first.  That is a collective - every rank has to run the
+            # evaluation, like every rank has to checkpoint - guarded by the optimizer's fail-fast rendezvous.
+            sync = self.kshard.get("sync")
+            if sync is not None:
+                sync()
         if kshard:
             if fg_hook is not None or csc:
                 raise DrnError("fc6 K-sharding needs a frozen trunk (FREEZE_AT = 5) and the OICR / WSDDN / PCL heads")
@@ -1124,111 +1113,80 @@ class _HeadEngine:
         hook = getattr(self, "grad_ready_hook", None)
         if hook is not None:
             hook("small")  # everything except fc1.weight is final: the DP engine starts reducing it now
-        fused = getattr(self, "fc1_fused_update", None)
         bucket = getattr(self, "fc1_grad_bucket", None)  # [D1, K1] exchange buffer (bf16 or fp32) instead of the arena
-        if fused is not None and not acc:
-            # the optimizer consumes this gradient inside the GEMM epilogue: fc1.weight.grad is never materialised
-            if at_row0 > 0:
-                raise DrnError("the fused fc6 update needs the whole A^T; this batch was pooled before it was enabled")
-            fused(dP1T, AT, D1, K1, Mp)
-        else:
-            if fused is not None or (bucket is not None and acc):
-                raise DrnError("fused / bucketed fc6 gradient cannot be combined with gradient accumulation")
-            gw = bucket if bucket is not None else self._gview("fc1.weight", (D1, K1))
-            if self.kshard is not None:
-                if acc:
-                    raise DrnError("fc6 K-sharding cannot be combined with gradient accumulation")
-                self._fc6_tail_kshard(self._tail_w, M, D1, K1, dP1T.dtype, gw, hook)
-                self._grads_valid = True
-                self._pool_current_done = True
-                for name, p, o, n, used in self.segments:
-                    if used and p.grad is None and name != "fc1.weight":
-                        p.grad = self.arena_g[o: o + n].view(p.shape)
-                return
-            # Tail balancing peels the same trailing columns off every equal-height slab (drn_gemm_nt: a small-tile launch
-            # in front of each persistent one - 14 + 22 us and two launch gaps per step for two slabs).  When all slabs
-            # agree on the split, ONE launch computes the peeled columns of all rows first and the slabs' main columns -
-            # exact rounds - follow; same kernels' arithmetic per element (tile size does not change the summation order)
-            n0 = K1
-            slabs = self._fc1_slabs(D1)
-            tn = self._fc1_use_tn(dP1T.dtype)
-            if at_row0 > 0 and not tn:
-                raise DrnError("this batch was pooled for the TN form of the fc6 weight gradient (A^T rows below %d were "
-                               "not written) but the backward runs the NT form: fc1_tn / the fused update changed in "
-                               "between" % at_row0)
-            plan = None if acc else self._fc1_col_plan(dP1T.dtype, D1, K1)
-            if plan is not None:
-                # column slabs: the trailing columns that do not fill a slab first (small-tile NT launch on the A^T tail rows,
-                # all fc6 rows), then slabs of exact rounds straight from A; every piece is announced as a block
-                # ("fc1b", r0, r1, c0, c1) the moment its GEMM is queued
-                n_main, wcols = plan
-                if n_main < at_row0:
-                    raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (n_main, at_row0))
-                if n_main < K1:
-                    side = getattr(self, "fc1_peel_stream", None)
-                    if side is not None and not torch.cuda.is_current_stream_capturing():
-                        # the trailing columns off the main stream's chain: small-tile GEMM + their block update on the
-                        # optimizer stream, beside the main launch (under its drain, where the matrix pipes idle)
-                        ev = torch.cuda.Event()
-                        ev.record(torch.cuda.current_stream())
-                        side.wait_event(ev)
-                        with torch.cuda.stream(side):
-                            ops.gemm_nt(dP1T, AT[n_main:], D1, K1 - n_main, Mp, out=gw[:, n_main:].unsqueeze(0))
-                            if hook is not None:
-                                hook(("fc1b", 0, D1, n_main, K1))
-                    else:
-                        ops.gemm_nt(dP1T, AT[n_main:], D1, K1 - n_main, Mp, out=gw[:, n_main:].unsqueeze(0))
-                        if hook is not None:
-                            hook(("fc1b", 0, D1, n_main, K1))
-                ftn = getattr(self, "fc1_fused_tn", None)
-                for c0 in range(0, n_main, wcols):
-                    c1 = min(n_main, c0 + wcols)
-                    if ftn is not None and c0 == 0 and c1 == n_main and bucket is not None and \
-                            ftn(dP1T, A, D1, n_main, Mp, M, gw):
-                        continue  # gradient AND update done by the one launch (drn_gemm_tn_sgd)
-                    ops.gemm_tn(dP1T, A[:, c0:c1], D1, c1 - c0, Mp, M, out=gw[:, c0:c1].unsqueeze(0))
-                    if hook is not None:
-                        hook(("fc1b", 0, D1, c0, c1))
-                slabs = []
-            if getattr(self, "fc1_joint_peel", 1) and len(slabs) > 1 and not acc:
-                cols = {ops.gemm_nt_main_cols(b - a, K1) for a, b in slabs}
-                if len(cols) == 1 and 0 < min(cols) < K1:
-                    n0 = cols.pop()
-                    if n0 < at_row0:
-                        raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (n0, at_row0))
-                    side = getattr(self, "fc1_peel_stream", None)
-                    if side is not None and not torch.cuda.is_current_stream_capturing():
-                        # round 4: the peeled columns (512 short small-tile workgroups, 20 us) leave the main stream's dependent
-                        # chain - they run on the optimizer stream beside the first slab's persistent launch (they share its
-                        # CUs like the trunk's conv workgroups do) and in front of every slab's update, which that stream
-                        # carries in order
-                        ev = torch.cuda.Event()
-                        ev.record(torch.cuda.current_stream())
-                        side.wait_event(ev)
-                        with torch.cuda.stream(side):
-                            ops.gemm_nt(dP1T, AT[n0:], D1, K1 - n0, Mp, out=gw[:, n0:].unsqueeze(0))
-                    else:
-                        ops.gemm_nt(dP1T, AT[n0:], D1, K1 - n0, Mp, out=gw[:, n0:].unsqueeze(0))
-            for r0, r1 in slabs:
-                if tn:
-                    # main columns (exact rounds of the persistent kernel) straight from A; a slab whose peel was not part
-                    # of a joint launch peels its own trailing columns through the NT small-tile kernel first
-                    m0 = min(n0, ops.gemm_nt_main_cols(r1 - r0, K1))
-                    if m0 < n0:
-                        if m0 < at_row0:
-                            raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (m0, at_row0))
-                        ops.gemm_nt(dP1T[r0:r1], AT[m0:n0], r1 - r0, n0 - m0, Mp, out=gw[r0:r1, m0:n0].unsqueeze(0),
-                                    accumulate=acc)
-                    if m0 > 0:
-                        ops.gemm_tn(dP1T[r0:r1], A[:, :m0], r1 - r0, m0, Mp, M, out=gw[r0:r1, :m0].unsqueeze(0),
-                                    accumulate=acc)
-                else:
-                    ops.gemm_nt(dP1T[r0:r1], AT[:n0], r1 - r0, n0, Mp, out=gw[r0:r1, :n0].unsqueeze(0), accumulate=acc)
+        if bucket is not None and acc:
+            raise DrnError("a bucketed fc6 gradient cannot be combined with gradient accumulation")
+        gw = bucket if bucket is not None else self._gview("fc1.weight", (D1, K1))
+        if self.kshard is not None:
+            if acc:
+                raise DrnError("fc6 K-sharding cannot be combined with gradient accumulation")
+            self._fc6_tail_kshard(self._tail_w, M, D1, K1, dP1T.dtype, gw, hook)
+            self._grads_valid = True
+            self._pool_current_done = True
+            for name, p, o, n, used in self.segments:
+                if used and p.grad is None and name != "fc1.weight":
+                    p.grad = self.arena_g[o: o + n].view(p.shape)
+            return
+        # Tail balancing peels the same trailing columns off every equal-height slab (drn_gemm_nt: a small-tile launch
+        # in front of each persistent one - 14 + 22 us and two launch gaps per step for two slabs).  When all slabs
+        # agree on the split, ONE launch computes the peeled columns of all rows first and the slabs' main columns -
+        # exact rounds - follow; same kernels' arithmetic per element (tile size does not change the summation order)
+        n0 = K1
+        slabs = self._fc1_slabs(D1)
+        tn = self._fc1_use_tn(dP1T.dtype)
+        if at_row0 > 0 and not tn:
+            raise DrnError("this batch was pooled for the TN form of the fc6 weight gradient (A^T rows below %d were "
+                           "not written) but the backward runs the NT form: fc1_tn / the fused update changed in "
+                           "between" % at_row0)
+        plan = None if acc else self._fc1_col_plan(dP1T.dtype, D1, K1)
+        if plan is not None:
+            # column slabs: the trailing columns that do not fill a slab first (small-tile NT launch on the A^T tail rows,
+            # all fc6 rows), then slabs of exact rounds straight from A; every piece is announced as a block
+            # ("fc1b", r0, r1, c0, c1) the moment its GEMM is queued
+            n_main, wcols = plan
+            if n_main < at_row0:
+                raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (n_main, at_row0))
+            if n_main < K1:
+                ops.gemm_nt(dP1T, AT[n_main:], D1, K1 - n_main, Mp, out=gw[:, n_main:].unsqueeze(0))
                 if hook is not None:
-                    hook(("fc1", r0, r1))
+                    hook(("fc1b", 0, D1, n_main, K1))
+            ftn = getattr(self, "fc1_fused_tn", None)
+            for c0 in range(0, n_main, wcols):
+                c1 = min(n_main, c0 + wcols)
+                if ftn is not None and c0 == 0 and c1 == n_main and bucket is not None and \
+                        ftn(dP1T, A, D1, n_main, Mp, M, gw):
+                    continue  # gradient AND update done by the one launch (drn_gemm_tn_sgd)
+                ops.gemm_tn(dP1T, A[:, c0:c1], D1, c1 - c0, Mp, M, out=gw[:, c0:c1].unsqueeze(0))
+                if hook is not None:
+                    hook(("fc1b", 0, D1, c0, c1))
+            slabs = []
+        if getattr(self, "fc1_joint_peel", 1) and len(slabs) > 1 and not acc:
+            cols = {ops.gemm_nt_main_cols(b - a, K1) for a, b in slabs}
+            if len(cols) == 1 and 0 < min(cols) < K1:
+                n0 = cols.pop()
+                if n0 < at_row0:
+                    raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (n0, at_row0))
+                ops.gemm_nt(dP1T, AT[n0:], D1, K1 - n0, Mp, out=gw[:, n0:].unsqueeze(0))
+        for r0, r1 in slabs:
+            if tn:
+                # main columns (exact rounds of the persistent kernel) straight from A; a slab whose peel was not part
+                # of a joint launch peels its own trailing columns through the NT small-tile kernel first
+                m0 = min(n0, ops.gemm_nt_main_cols(r1 - r0, K1))
+                if m0 < n0:
+                    if m0 < at_row0:
+                        raise DrnError("A^T rows %d.. are needed, the pooling launch wrote them from %d on" % (m0, at_row0))
+                    ops.gemm_nt(dP1T[r0:r1], AT[m0:n0], r1 - r0, n0 - m0, Mp, out=gw[r0:r1, m0:n0].unsqueeze(0),
+                                accumulate=acc)
+                if m0 > 0:
+                    ops.gemm_tn(dP1T[r0:r1], A[:, :m0], r1 - r0, m0, Mp, M, out=gw[r0:r1, :m0].unsqueeze(0),
+                                accumulate=acc)
+            else:
+                ops.gemm_nt(dP1T[r0:r1], AT[:n0], r1 - r0, n0, Mp, out=gw[r0:r1, :n0].unsqueeze(0), accumulate=acc)
+            if hook is not None:
+                hook(("fc1", r0, r1))
         self._grads_valid = True
         self._pool_current_done = True  # the last reader of this batch's A^T has been issued
-        skip = fused is not None or bucket is not None
+        skip = bucket is not None
         for name, p, o, n, used in self.segments:
             if used and p.grad is None and not (skip and name == "fc1.weight"):
                 p.grad = self.arena_g[o: o + n].view(p.shape)

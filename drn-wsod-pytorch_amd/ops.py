@@ -39,6 +39,7 @@ def gemm_set_tile(tile):
 
 TUNE_GEMM_PERSISTENT, TUNE_SGD_GRID, TUNE_GEMM_GROUP_ROWS, TUNE_ROI_MAP64, TUNE_CONV_KSPLIT, TUNE_GEMM_TAIL_SPLIT, TUNE_CONV_KS_TILES, TUNE_CONV_K2_TILES, TUNE_CONV_PATCH = 1, 2, 3, 4, 5, 6, 7, 8, 9
 TUNE_CONV_RING = 23
+TUNE_CONV_PP = 24
 TUNE_ROI_CPB, TUNE_ROI_PREFETCH, TUNE_GEMM_PINGPONG, TUNE_FP8_K64, TUNE_ROI_MAP64_A, TUNE_ROI_LDS_KB = 10, 11, 12, 13, 14, 15
 
 
@@ -150,22 +151,6 @@ def gemm_nt_main_cols(M, N, splits=1):
     """columns [0, n0) that drn_gemm_nt keeps for its persistent launch (n0 == N: no tail balancing for this shape)"""
     fn = C.lib().drn_gemm_nt_main_cols
     return int(fn(int(M), int(N), int(splits)))
-
-
-def gemm_nt_sgd(A, B, M, N, K, weights, mom, shadow, seg_dev, momentum, first_step, grad_scale=1.0):
-    """weights[M,N] <- SGD step with the gradient A[M,:K] @ B[N,:K]^T, which is never materialised."""
-    assert A.dtype == B.dtype and weights.dtype == torch.float32 and mom.dtype == torch.float32
-    assert weights.is_contiguous() and mom.is_contiguous() and weights.shape == (M, N) and mom.shape == (M, N)
-    if shadow is not None:
-        assert shadow.dtype == torch.bfloat16 and shadow.is_contiguous() and shadow.shape == (M, N)
-    if GEMM_TIMING is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    C.call("drn_gemm_nt_sgd", C.ptr(A), C.ptr(B), M, N, K, _2d(A), _2d(B), C.dt(A.dtype), C.ptr(weights), C.ptr(mom),
-           C.ptr(shadow), N, C.ptr(seg_dev), float(momentum), int(bool(first_step)), float(grad_scale), C.stream())
-    if GEMM_TIMING is not None:
-        e1.record()
-        GEMM_TIMING.append((e0, e1, 2.0 * M * N * K, ("sgd", M, N, K)))
 
 
 def conv2d_nhwc(x, w_packed, cout, kh, kw, stride=1, pad=0, dil=1, scale=None, bias=None, residual=None, relu=False):

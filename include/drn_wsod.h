@@ -178,17 +178,6 @@ int drn_gemm_nt_pair(const void* A0, const void* B0, void* C0, int M0, int N0, i
 int drn_gemm_tn(const void* A, const void* Bt, void* C, int M, int N, int K, int kb_rows, long lda, long ldb, long ldc,
                 int c_dtype, int splits, long c_split_stride, int accumulate, void* stream);
 
-/* The weight-gradient contraction of a Linear layer with the optimizer step as its epilogue
- * (torch.autograd's dW = dY^T X of F.linear followed by torch.optim.SGD.step on that tensor,
- * detectron2/solver/build.py:93-137 builds the optimizer; plain_train_net/train_loop.py:232-236 calls it):
- *   G = A[M][K] * B[N][K]^T;  d = G*grad_scale + wd*W;  buf = first_step ? d : momentum*buf + d;  W -= lr*buf
- * with G kept in registers (never stored), W/buf fp32 [M][ld_w] updated in place, `shadow` (optional) the bf16
- * compute copy of W refreshed in the same pass.  lr/wd are read on the device from seg_dev (one drn_sgd_step
- * table row).  Valid only when nothing else contributes to this gradient (one process, no accumulation). */
-int drn_gemm_nt_sgd(const void* A, const void* B, int M, int N, int K, long lda, long ldb, int dtype, float* weights,
-                    float* momentum_buf, void* shadow, long ld_w, const void* seg_dev, float momentum, int first_step,
-                    float grad_scale, void* stream);
-
 /* The same pair of reference operations (dW = dY^T X of box_head.py:82-91's fc1 through torch.autograd, then
  * torch.optim.SGD.step on it: detectron2/solver/build.py:93-137, projects/WSL/tools/train_net.py:104-113) in the TN operand
  * form of drn_gemm_tn and with the gradient rounded to bf16 exactly as the unfused pair does (drn_gemm_tn into a bf16 bucket,
@@ -222,7 +211,6 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_ROI_CPB 10 /* 64-ROI ROIPool: most 8-channel chunks one workgroup walks (power of two, default 1; halved until two workgroups per CU remain): bin bounds / item table once per workgroup - faster stand-alone (4-8), slower inside the training step */
 #define DRN_TUNE_ROI_PREFETCH 11 /* 0/1 (default 1): 64-ROI ROIPool keeps two map-slice buffers and fetches the next chunk's slice under the scan */
 #define DRN_TUNE_GEMM_PINGPONG 12 /* 0/1 (default 1): bf16 256x256 GEMMs run the ping-pong mainloop - the two waves of a SIMD half a phase apart, four [reads + DMA | 8 MFMAs] phases per K slab, half-tile LDS-DMA spread over the slab; bit-identical to the lock-step pipeline it replaces (0) */
-#define DRN_TUNE_CONV_CORESIDENT 17 /* 0/1 (default 0): convolutions only on the kernels that share a CU with a resident 256x256 GEMM workgroup (64x64 single-stage tile, 32x32 wave-K-split) - A/B for the trunk beside the fc6 GEMMs at real image sizes */
 #define DRN_TUNE_ROI_LDS_KB 15 /* 60..154 (default 154): LDS a 64-ROI pooling block may take for map slice + tile; 76 stages larger maps in row bands so that two blocks share a CU */
 #define DRN_TUNE_ROI_MAP64_A 14 /* 0/1 (default 0): the 64-ROI ROIPool kernel also when only A is asked for (no A^T) */
 #define DRN_TUNE_FP8_K64 13 /* 0/1 (default 1): fp8 convolutions multiply with v_mfma_scale_f32_32x32x64_f8f6f4 (unit scales; the fp8 MFMA rate) instead of the K = 16 non-scaled form (bf16 rate); same exact products, another fp32 summation order */
@@ -231,6 +219,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_ROI_LANE_REPS 22 /* lane-per-bin ROIPool on maps that leave one block per CU: groups of 64 ROIs a block walks with one staged map slice (0 = default: 4, halved while fewer than two rounds of blocks would remain; 1 = a block per group) */
 #define DRN_TUNE_ROI_LANE 19 /* 0/1 (default 1): the bf16 training operand A from the lane-per-bin ROIPool kernel (a wave per ROI, lane = bin: every channel leaves as one 98-byte run per store instruction); 0 = the 64-ROI kernel writes A */
 #define DRN_TUNE_CONV_RING 23 /* register-ring conv kernels (conv_ring.hip; bf16, Cin % 64 == 0, layers beyond the latency-bound small maps): 0 = off (the tiles of gemm_conv.hip), 1 = default (tile by cost model), 64 / 96 / 128 = pin the 64x64 / 128x64 / 128x128 tile; every tile gives the same bits as the 64x64 / 128x128 tiled kernel */
+#define DRN_TUNE_CONV_PP 24 /* 1x1 / stride-1 bf16 convs of large maps on the 256x256 ping-pong GEMM mainloop with the conv epilogue (conv1x1_pp_kernel): 0 = off, 1 = default (Cout >= 256 and >= 100 tiles of 256x256 per image), n > 1 = at least n tiles, any Cout; same bits as the tiled kernels */
 #define DRN_TUNE_CONV_PATCH 9 /* 0 = never use the LDS-resident-patch kernel for 3x3 / 64 -> 64 channel convs; 1 = default (maps of >= 32768 pixels); > 1 = that many pixels per image at least */
 int drn_tune(int knob, int value);
 

@@ -77,6 +77,17 @@ def _worker(rank, world, port, comm, exchange, q, precision="fp32"):
             for _ in range(3):
                 out = stepper.step(mine, mine, mine, mine)
                 losses.append({k: float(v.detach()) for k, v in out.items()})
+        ev_scores = None
+        if exchange == "fc6_kshard" and not graphed_ks:
+            #  an evaluation forward between K-sharded training steps reads every column of fc1.weight: it must
+            # gather the other rank's columns first (a collective: both ranks evaluate) - both ranks then see the SAME scores
+            assert opt._master_stale
+            model.eval()
+            with torch.no_grad():
+                _, sc, _ = model.inference(batches[0], do_postprocess=False)
+            ev_scores = sc[0].float().cpu().numpy().copy()
+            assert not opt._master_stale
+            model.train()
         opt.sync_master()  # sharded exchange: the fp32 master rows the other rank owns (a collective; no-op otherwise)
         torch.cuda.synchronize()
         sd = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.requires_grad}  # by value
@@ -85,11 +96,11 @@ def _worker(rank, world, port, comm, exchange, q, precision="fp32"):
             for _, _, o, n, used in e.segments:
                 if used:
                     assert torch.equal(e.arena_s[o: o + n], e.arena_w[o: o + n].to(torch.bfloat16)), "stale shadow rows"
-        q.put((rank, "ok", sd, losses))
+        q.put((rank, "ok", sd, losses, ev_scores))
     except Exception as ex:  # noqa: BLE001
         import traceback
 
-        q.put((rank, "FAIL: %r\n%s" % (ex, traceback.format_exc()), None, None))
+        q.put((rank, "FAIL: %r\n%s" % (ex, traceback.format_exc()), None, None, None))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()
@@ -118,6 +129,8 @@ def test_two_rank_step_equals_mean_gradient_training(comm, exchange):
 
     for n in res[0][2]:
         assert np.array_equal(res[0][2][n], res[1][2][n]), n
+    if res[0][4] is not None:  # evaluation between K-sharded steps: gathered weights -> the same scores on both ranks
+        assert np.array_equal(res[0][4], res[1][4]) and np.isfinite(res[0][4]).all()
     if exchange.endswith("+wire16"):
         # bf16 partial pre-activations on the wire perturb H1 by 2^-9 relative - in this fp32-precision fixture (a tiny,
         # ill-conditioned net) that is a different trajectory after three steps (measured 2e-3 .. 4e-2 on fc2.weight), so
@@ -202,11 +215,11 @@ def _worker_full(rank, world, port, q):
         assert stepper.g_opt is not None and stepper.g_trunk is not None  # heads all-reduce runs under the trunk-backward graph
         torch.cuda.synchronize()
         sd = {n: p.detach().cpu().numpy().copy() for n, p in model.named_parameters() if p.requires_grad}
-        q.put((rank, "ok", sd, losses))
+        q.put((rank, "ok", sd, losses, None))
     except Exception as ex:  # noqa: BLE001
         import traceback
 
-        q.put((rank, "FAIL: %r\n%s" % (ex, traceback.format_exc()), None, None))
+        q.put((rank, "FAIL: %r\n%s" % (ex, traceback.format_exc()), None, None, None))
     finally:
         if dist.is_initialized():
             dist.destroy_process_group()

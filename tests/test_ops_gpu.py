@@ -501,7 +501,9 @@ def test_conv2d_wave_k_split(drn, dtype, case):
                                   (1, 100, 152, 128, 512, 1, 1, 0, 1, True, True),    # res3 conv3: 2 slabs (< ring depth)
                                   (1, 131, 97, 64, 72, 1, 1, 0, 1, True, False),      # ONE slab, ragged M and a ragged column tile
                                   (2, 61, 67, 64, 136, 3, 2, 1, 1, True, True),       # stride 2, two images, Cout % 64 != 0
-                                  (3, 45, 52, 192, 200, 3, 1, 3, 3, False, False)])   # dilation 3, three slabs per tap
+                                  (3, 45, 52, 192, 200, 3, 1, 3, 3, False, False),    # dilation 3, three slabs per tap
+                                  (4, 28, 28, 512, 512, 3, 1, 2, 2, False, True),     # a trunk group of four 224x224 images: dilated res5
+                                  (4, 28, 28, 512, 2048, 1, 1, 0, 1, True, True)])    # ... and its 1x1 to 2048 channels
 def test_conv_ring_kernels(drn, case):
     """conv_ring_kernel<64x64 | 128x128> (register ring of prefetched K slabs + two LDS stages behind ONE LDS-only barrier per
     slab, im2col by per-lane buffer offsets on a per-row tap-validity mask; the bf16 trunk layers beyond the small maps) == the
@@ -544,6 +546,52 @@ def test_conv_ring_kernels(drn, case):
         assert torch.equal(y, tiled), (pin, float((y.float() - tiled.float()).abs().max()))
     assert torch.equal(again, tiled)
     got = tiled.float().cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("case", [(1, 99, 151, 256, 1024, True, True),     # dilated-C5 res4 conv3 + shortcut at 800x1216: 59 x 4 tiles, 4 slabs
+                                  (1, 99, 151, 512, 2048, True, True),     # res5 conv3 + shortcut: two rounds of tiles
+                                  (1, 99, 151, 1024, 2048, False, True),   # res5 projection shortcut (16 slabs)
+                                  (2, 131, 97, 64, 520, True, False),      # ONE slab, ragged M, a ragged last column tile, two images
+                                  (1, 160, 200, 128, 1000, False, True)])  # Cout % 256 != 0
+def test_conv1x1_pp_kernel(drn, case):
+    """conv1x1_pp_kernel - a 1x1 / stride-1 bf16 conv of a large map as a GEMM on the 256x256 ping-pong mainloop with the conv
+    epilogue (affine, shortcut, ReLU through an fp32 LDS tile, 8-byte row stores) - == the register-staged tiled kernel bit for
+    bit (same slab order, k-steps and MFMA per output element) and within bf16 rounding of F.conv2d."""
+    n, h, w, cin, cout, has_res, relu = case
+    dtype = torch.bfloat16
+    x = _rnd((n, cin, h, w), 45)
+    wt = _rnd((cout, cin, 1, 1), 46, math.sqrt(2.0 / cin))
+    scale, bias = (0.8 + 0.2 * torch.rand(cout)).to(DEV), _rnd((cout,), 47, 0.1).to(DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    ref = F.conv2d(_q(x, dtype), _q(wt, dtype)) * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1)
+    res = None
+    if has_res:
+        res = _rnd(tuple(ref.shape), 48)
+        ref = ref + _q(res, dtype)
+        res = res.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    if relu:
+        ref = F.relu(ref)
+    wp = _pack_w(wt, dtype, drn, cin)
+    run = lambda: drn.conv2d_nhwc(xd, wp, cout, 1, 1, 1, 0, 1, scale, bias, res, relu)
+    assert drn.tune(drn.TUNE_CONV_PP, 0) == 1
+    ring = drn.tune(drn.TUNE_CONV_RING, 0)
+    k2 = drn.tune(drn.TUNE_CONV_K2_TILES, 0)
+    ks = drn.tune(drn.TUNE_CONV_KSPLIT, 0)
+    try:
+        tiled = run()  # conv_nhwc_kernel<128x128>
+        drn.tune(drn.TUNE_CONV_PP, 2)  # (any layer of >= 2 tiles)
+        y = run()
+        again = run()
+    finally:
+        drn.tune(drn.TUNE_CONV_PP, 1)
+        drn.tune(drn.TUNE_CONV_RING, ring)
+        drn.tune(drn.TUNE_CONV_K2_TILES, k2)
+        drn.tune(drn.TUNE_CONV_KSPLIT, ks)
+    torch.cuda.synchronize()
+    assert torch.equal(y, tiled), float((y.float() - tiled.float()).abs().max())
+    assert torch.equal(again, y)
+    got = y.float().cpu().permute(0, 3, 1, 2)
     assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
 
 
@@ -1111,38 +1159,6 @@ def test_sgd_step_block_equals_flat(drn, gdt):
     assert not torch.equal(wb[n0: n0 + rows * ld], w[n0: n0 + rows * ld])
     with pytest.raises(Exception):
         drn.sgd_step_block(wb, mb, ga, seg_dev, 0, rows, 2, 8, ld, 0.9, False, shadow=sb, grad_off=goff)  # c0 % 4 != 0
-
-
-@pytest.mark.parametrize("dtype", DTYPES)
-@pytest.mark.parametrize("M,N,K,wd", [(300, 520, 200, 1e-4), (512, 1024, 2000, 0.0), (77, 36, 64, 5e-4),
-                                      (2300, 8192, 128, 1e-4)])  # last: 288 tiles > #CUs -> the persistent kernel
-def test_gemm_nt_sgd_equals_gemm_then_sgd(drn, dtype, M, N, K, wd):
-    """dW GEMM with the optimizer step as its epilogue == drn_gemm_nt(256 tile) followed by drn_sgd_step, bit for
-    bit (weights, momentum, bf16 shadow), over a first step and two momentum steps; ragged M/N edges included."""
-    rs = np.random.RandomState(5)
-    Kp = drn.kpad(K, dtype)
-    w0 = torch.from_numpy(rs.standard_normal((M, N)).astype(np.float32)).to(DEV)
-    seg = np.zeros(1, dtype=[("off", "<i8"), ("cnt", "<i8"), ("lr", "<f4"), ("wd", "<f4")])
-    seg[0] = (0, M * N, 0.01, wd)
-    seg_dev = torch.from_numpy(seg.view(np.uint8)).to(DEV)
-    wa, ma = w0.clone(), torch.zeros_like(w0)
-    wb, mb = w0.clone(), torch.zeros_like(w0)
-    sa = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
-    sb = torch.zeros((M, N), dtype=torch.bfloat16, device=DEV)
-    old = drn.gemm_set_tile(256)
-    try:
-        for step in range(3):
-            A = torch.zeros((M, Kp), dtype=dtype, device=DEV)
-            B = torch.zeros((N, Kp), dtype=dtype, device=DEV)
-            A[:, :K] = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32)).to(DEV).to(dtype)
-            B[:, :K] = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32)).to(DEV).to(dtype)
-            g = drn.gemm_nt(A, B, M, N, Kp)[0].contiguous()
-            drn.sgd_step(wa.view(-1), ma.view(-1), g.view(-1), seg_dev, 1, 0.9, step == 0, shadow=sa.view(-1))
-            drn.gemm_nt_sgd(A, B, M, N, Kp, wb, mb, sb, seg_dev, 0.9, step == 0)
-            assert torch.equal(wa, wb) and torch.equal(ma, mb) and torch.equal(sa, sb), step
-    finally:
-        drn.gemm_set_tile(old)
-    assert not torch.equal(wa, w0)
 
 
 @pytest.mark.parametrize("M,N,wd,K,kb", [(1024, 20480, 5e-4, 2048, 2000), (768, 24576 + 256, 0.0, 2048, 2000),

@@ -3,7 +3,7 @@ shortest edge 480-1200, aspect ratios 0.5-2, 500-2000 proposals after filtering)
 Reports wall time per step, host enqueue time per step and GPU-busy time per step (HIP events), i.e. whether this
 path is host-bound at real image sizes.  Same model / optimizer / pipelined SGD as bench.py; the next batch's frozen
 trunk is prefetched on the side stream (model.prefetch_features) like in bench.py's eager step.
-  python tools/eager_shapes_bench.py [steps]"""
+  python tools/eager_shapes_bench.py [steps]      (WORKLOAD=r50dc5: the shipped DC5 recipe instead of the constructed R50-C4 model)"""
 import os
 import sys
 import time
@@ -24,6 +24,8 @@ from drn_wsod_pytorch_amd.structures import Boxes, Instances
 dev = "cuda:0"
 steps = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 cfg = B.build_cfg(pkg, dev)
+if os.environ.get("WORKLOAD", "r50c4") == "r50dc5":  # the shipped recipe's trunk (oicr_WSR_50_DC5_1x.yaml): res4 / res5 dilated at stride 8
+    cfg.merge_from_list(["MODEL.RESNETS.OUT_FEATURES", "['res5']", "MODEL.ROI_HEADS.IN_FEATURES", "['res5']", "MODEL.RESNETS.RES5_DILATION", "2"])
 model = build_model(cfg)
 B.init_weights(model, seed=0)
 model.train()

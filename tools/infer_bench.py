@@ -1,5 +1,5 @@
 """Inference (eval) pass of R50-C4 at TTA-like image sizes: wall time per image and the top kernels.
-INFER_SIZES="688x920,224x224" picks the sizes, INFER_PLAN=0 runs the trunk layer by layer instead of through its launch plan."""
+INFER_SIZES="688x920,224x224" picks the sizes, WORKLOAD=r50dc5 the shipped DC5 recipe, INFER_PLAN=0 runs the trunk layer by layer instead of through its launch plan."""
 import os
 import sys
 import time
@@ -16,6 +16,8 @@ from drn_wsod_pytorch_amd.modeling import build_model
 from drn_wsod_pytorch_amd.structures import Boxes, Instances
 
 cfg = bench.build_cfg(pkg, "cuda")
+if os.environ.get("WORKLOAD", "r50c4") == "r50dc5":  # the shipped recipe's trunk (oicr_WSR_50_DC5_1x.yaml): res4 / res5 dilated at stride 8
+    cfg.merge_from_list(["MODEL.RESNETS.OUT_FEATURES", "['res5']", "MODEL.ROI_HEADS.IN_FEATURES", "['res5']", "MODEL.RESNETS.RES5_DILATION", "2"])
 model = build_model(cfg)
 bench.init_weights(model, seed=0)
 model.eval()
