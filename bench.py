@@ -510,6 +510,7 @@ def main():
     def setup(ex):
         """(re)configure the optimizer for exchange `ex`, run the eager warm-up steps (HIP events around every GEMM launch) and
         build + warm the graphed step -> (use_graph, stepper, eager timing, last losses)"""
+        opt.zero_grad()  # (a re-configuration behind graphed steps: no gradient is pending)
         if not args.no_pipelined_sgd:
             # ITER_SIZE = 1: per-bucket (all-reduce +) SGD under the remaining dW GEMMs
             opt.enable_pipelined(dp, slab_rows=[int(x) for x in args.slab_rows.split(",")] if args.slab_rows else None,

@@ -16,6 +16,7 @@ _T = {"p": ctypes.c_void_p, "i": ctypes.c_int, "l": ctypes.c_long, "f": ctypes.c
 # signature strings follow include/drn_wsod.h argument for argument
 _SIGS = {
     "drn_preprocess_nhwc": "piiipiiippip",
+    "drn_resize_bilinear_u8": "piiipiippippiip",
     "drn_conv2d_nhwc": "pppppp" + "iiiiiiiiii" + "lll" + "iip",
     "drn_conv2d_nhwc_q": "pppppp" + "iiiiiiiiii" + "lll" + "iiiifp",
     "drn_conv3x3_pw_nhwc": "pppp" + "i" + "pppp" + "p" + "iii" + "ll" + "f" + "ii" + "p",

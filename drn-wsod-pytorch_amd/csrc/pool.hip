@@ -32,6 +32,50 @@ __global__ void preprocess_kernel(const float* __restrict__ img, int C, int H, i
   }
 }
 
+// Pillow's BILINEAR resample of an 8-bit image (ResizeTransform.apply_image, detectron2/data/transforms/transform.py:101-122, calls
+// PIL.Image.resize(..., BILINEAR) for uint8 images; the 16 augmented images of one TTA image take ~0.4 s of it on the host,
+// projects/WSL/wsl/modeling/test_time_augmentation_avg.py:68-137).  Pillow resamples in two integer passes - horizontal, the
+// result rounded to 8 bits, then vertical - with per-output-position windows [xmin, xmin + n) and coefficients scaled by 2^22
+// (Resample.c: precompute_coeffs / normalize_coeffs_8bpc; the host computes them with Pillow's own double arithmetic); here
+// one thread forms one output pixel: the horizontal results of its vertical window's rows on the fly, rounded exactly as
+// Pillow stores them, then the vertical sum.  Output: fp32 [C][Ho][Wo] (the integers 0 .. 255), optionally mirrored
+// (HFlipTransform) - what preprocess_kernel reads.
+__global__ void resize_u8_kernel(const unsigned char* __restrict__ src, int H, int W, int C, float* __restrict__ dst, int Ho,
+                                 int Wo, const int* __restrict__ xb, const int* __restrict__ xk, int ksx,
+                                 const int* __restrict__ yb, const int* __restrict__ yk, int ksy, int flip) {
+  constexpr int PB = 22, HALF = 1 << (PB - 1);
+  const long total = (long)Ho * Wo;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int xx = (int)(i % Wo), yy = (int)(i / Wo);
+    const int xmin = xb ? xb[2 * xx] : xx, xn = xb ? xb[2 * xx + 1] : 1;
+    const int ymin = yb ? yb[2 * yy] : yy, yn = yb ? yb[2 * yy + 1] : 1;
+    int acc[4] = {HALF, HALF, HALF, HALF};
+    for (int y = 0; y < yn; ++y) {
+      const unsigned char* row = src + ((long)(ymin + y) * W + xmin) * C;
+      int h[4];
+      if (xb) {
+        int a[4] = {HALF, HALF, HALF, HALF};
+        for (int x = 0; x < xn; ++x) {
+          const int k = xk[(long)xx * ksx + x];
+          for (int c = 0; c < C; ++c) a[c] += (int)row[x * C + c] * k;
+        }
+        for (int c = 0; c < C; ++c) h[c] = min(max(a[c] >> PB, 0), 255);
+      } else {
+        for (int c = 0; c < C; ++c) h[c] = row[c];
+      }
+      if (yb) {
+        const int k = yk[(long)yy * ksy + y];
+        for (int c = 0; c < C; ++c) acc[c] += h[c] * k;
+      } else {
+        for (int c = 0; c < C; ++c) acc[c] = h[c];
+      }
+    }
+    const int xo = flip ? Wo - 1 - xx : xx;
+    for (int c = 0; c < C; ++c)
+      dst[((long)c * Ho + yy) * Wo + xo] = (float)(yb ? min(max(acc[c] >> PB, 0), 255) : acc[c]);
+  }
+}
+
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4_t;
 
 // one thread = one 16-B channel vector of one output pixel
@@ -1345,6 +1389,18 @@ __attribute__((visibility("hidden"))) int drn_roi_set_map64(int on) {
   const int old = g_roi_map64;
   g_roi_map64 = on == 1 ? 512 : (on == 0 || on == 256 || on == 512 || on == 1024) ? on : old;
   return old;
+}
+
+int drn_resize_bilinear_u8(const void* src_hwc, int H, int W, int C, float* dst_chw, int Ho, int Wo, const int* xbounds,
+                           const int* xcoef, int ksx, const int* ybounds, const int* ycoef, int ksy, int flip, void* stream) {
+  if (!src_hwc || !dst_chw || H <= 0 || W <= 0 || C < 1 || C > 4 || Ho <= 0 || Wo <= 0) return DRN_ERR_ARG;
+  if ((xbounds && (!xcoef || ksx < 1)) || (ybounds && (!ycoef || ksy < 1))) return DRN_ERR_ARG;
+  if ((!xbounds && Wo != W) || (!ybounds && Ho != H)) return DRN_ERR_ARG;  // no pass in a direction: the size stays
+  const long total = (long)Ho * Wo;
+  hipLaunchKernelGGL(resize_u8_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const unsigned char*)src_hwc, H, W, C, dst_chw, Ho, Wo, xbounds, xcoef, ksx, ybounds, ycoef, ksy, flip);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
 }
 
 int drn_preprocess_nhwc(const float* img_chw, int C, int H, int W, void* out_nhwc, int Hp, int Wp, int Cp,

@@ -59,14 +59,22 @@ def _apply_box(boxes, sx, sy, flip_w):
     if flip_w is not None:
         c[:, 0] = flip_w - c[:, 0]
     c = c.reshape(-1, 4, 2)
-    return np.concatenate((c.min(axis=1), c.max(axis=1)), axis=1)
+    # (element-wise minima / maxima of the four corners: ndarray.min(axis=1) over the short middle axis took 3 ms per call on the
+    # GPU box's host - 97 of the 101 ms of a 16-augmentation mapper call; same values, min / max are exact)
+    lo = np.minimum(np.minimum(c[:, 0], c[:, 1]), np.minimum(c[:, 2], c[:, 3]))
+    hi = np.maximum(np.maximum(c[:, 0], c[:, 1]), np.maximum(c[:, 2], c[:, 3]))
+    return np.concatenate((lo, hi), axis=1)
 
 
 class DatasetMapperTTAAVG:
     """test_time_augmentation_avg.py:68-137: dataset dict -> list of augmented dataset dicts (len(min_sizes) x
     (2 if flip else 1)); each carries "tta" = (sx, sy, flip_w) of the INVERSE box transform instead of a TransformList."""
 
-    def __init__(self, cfg):
+    def __init__(self, cfg, device=None):
+        # device (round 5): resize + flip of uint8 images run on that device (drn_resize_bilinear_u8: Pillow's integer
+        # BILINEAR resample restated - bit-identical images) instead of 8 PIL resizes on the host per image, which took
+        # ~0.4 s of a 0.41-s TTA call (tools/tta_bench.py, profiles/r5_20_tta.txt); None = the host path
+        self.device = device
         self.min_sizes = cfg.TEST.AUG.MIN_SIZES
         self.max_size = cfg.TEST.AUG.MAX_SIZE
         self.flip = cfg.TEST.AUG.FLIP
@@ -74,18 +82,26 @@ class DatasetMapperTTAAVG:
         self.proposal_topk = cfg.DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST if cfg.MODEL.LOAD_PROPOSALS else None
 
     def __call__(self, dataset_dict):
+        return list(self._augmented(dataset_dict))
+
+    def _augmented(self, dataset_dict):
         img = dataset_dict["image"].detach().cpu().permute(1, 2, 0).numpy()
         h, w = img.shape[:2]
         if (dataset_dict["height"], dataset_dict["width"]) != (h, w):
             raise DrnError("TTA on an already resized input (pre_tfm of the reference) is off this path")
-        ret = []
+        on_dev = self.device is not None and img.dtype == np.uint8
+        if on_dev:
+            src = torch.from_numpy(np.ascontiguousarray(img)).to(self.device, non_blocking=True)  # [H, W, 3] uint8, once
         for size in self.min_sizes:
             nh, nw = resize_shortest_edge_shape(h, w, size, self.max_size)
-            rimg = _resize_image(np.copy(img), nh, nw)
+            rimg = None if on_dev else _resize_image(np.copy(img), nh, nw)
             for flipped in ([False, True] if self.flip else [False]):
-                im = np.flip(rimg, axis=1) if flipped else rimg
                 dic = {k: v for k, v in dataset_dict.items() if k not in ("image", "proposals")}
-                dic["image"] = torch.from_numpy(np.ascontiguousarray(im.transpose(2, 0, 1)))
+                if on_dev:
+                    dic["image"] = ops.resize_bilinear_u8(src, nh, nw, flip=flipped)  # fp32 [3, nh, nw] of the same bytes
+                else:
+                    im = np.flip(rimg, axis=1) if flipped else rimg
+                    dic["image"] = torch.from_numpy(np.ascontiguousarray(im.transpose(2, 0, 1)))
                 dic["tta"] = (w * 1.0 / nw, h * 1.0 / nh, float(nw) if flipped else -1.0)
                 if self.proposal_topk is not None:
                     # transform_proposals (:27-65)
@@ -101,8 +117,7 @@ class DatasetMapperTTAAVG:
                     p.proposal_boxes = boxes[: self.proposal_topk]
                     p.objectness_logits = logits[: self.proposal_topk]
                     dic["proposals"] = p
-                ret.append(dic)
-        return ret
+                yield dic
 
 
 class GeneralizedRCNNWithTTAAVG(nn.Module):
@@ -123,7 +138,7 @@ class GeneralizedRCNNWithTTAAVG(nn.Module):
             raise DrnError("augmented images have different sizes and the averages need one prediction set per "
                            "augmentation: batch_size must stay 1 (the reference's default)")
         self.model = model
-        self.tta_mapper = tta_mapper if tta_mapper is not None else DatasetMapperTTAAVG(cfg)
+        self.tta_mapper = tta_mapper if tta_mapper is not None else DatasetMapperTTAAVG(cfg, device=model.device)
         self.batch_size = batch_size
 
     def __call__(self, batched_inputs):
@@ -162,6 +177,8 @@ class GeneralizedRCNNWithTTAAVG(nn.Module):
     def _inference_one_image(self, input):
         orig_shape = (input["height"], input["width"])
         with torch.no_grad():
+            # (queueing each augmentation's pass while the host prepares the next one was built and measured: 261 vs 86 ms per
+            # image - the host work between the launches stretches the dependent chain; all augmentations first, then the passes)
             augmented_inputs = self.tta_mapper(input)
             all_boxes, all_scores = self._get_augmented_boxes(augmented_inputs)
             # _merge_detections (:296-309) = fast_rcnn_inference_single_image on the averages

@@ -228,6 +228,65 @@ def preprocess_nhwc(images, mean, std, dtype, cpad):
     return out, [(int(i.shape[1]), int(i.shape[2])) for i in images]
 
 
+def pil_bilinear_coeffs(in_size, out_size):
+    """Pillow's resampling windows and 22-bit coefficients of a BILINEAR resize of `in_size` positions to `out_size`
+    (Resample.c: precompute_coeffs + normalize_coeffs_8bpc), with Pillow's double arithmetic in Pillow's operation order:
+    -> (bounds int32 [out, 2] = (first source position, count), coef int32 [out, ksize], ksize)"""
+    import numpy as np
+
+    scale = float(in_size) / out_size
+    fscale = scale if scale >= 1.0 else 1.0
+    support = 1.0 * fscale  # (the triangle filter's support is 1)
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / fscale
+    center = 0.0 + (np.arange(out_size, dtype=np.float64) + 0.5) * scale
+    xmin = np.maximum((center - support + 0.5).astype(np.int64), 0)  # (int) truncates, and the operands are > -1
+    xmax = np.minimum((center + support + 0.5).astype(np.int64), in_size) - xmin
+    kk = np.zeros((out_size, ksize), dtype=np.float64)
+    ww = np.zeros(out_size, dtype=np.float64)
+    for x in range(ksize):  # (column by column: the same summation order as Pillow's loop over x)
+        a = np.abs(((x + xmin).astype(np.float64) - center + 0.5) * ss)
+        w = np.where((a < 1.0) & (x < xmax), 1.0 - a, 0.0)
+        kk[:, x] = w
+        ww = ww + w
+    nz = ww != 0.0
+    kk[nz] = kk[nz] / ww[nz, None]
+    coef = np.where(kk < 0, (-0.5 + kk * (1 << 22)).astype(np.int64), (0.5 + kk * (1 << 22)).astype(np.int64)).astype(np.int32)
+    return np.stack([xmin, xmax], 1).astype(np.int32), coef, ksize
+
+
+_RESIZE_COEFFS = {}
+
+
+def resize_bilinear_u8(img_hwc, new_h, new_w, flip=False, out=None):
+    """img_hwc: uint8 [H, W, C] device tensor -> fp32 [C, new_h, new_w] holding exactly the bytes
+    PIL.Image.fromarray(img).resize((new_w, new_h), BILINEAR) produces (mirrored left-right when `flip`): ResizeTransform
+    [+ HFlipTransform] of the TTA mapper on the device (drn_resize_bilinear_u8)."""
+    assert img_hwc.dtype == torch.uint8 and img_hwc.dim() == 3 and img_hwc.is_contiguous() and img_hwc.is_cuda
+    h, w, c = img_hwc.shape
+    dev = img_hwc.device
+
+    def tables(n_in, n_out):
+        if n_in == n_out:
+            return None, None, 0
+        key = (n_in, n_out, dev)
+        t = _RESIZE_COEFFS.get(key)
+        if t is None:
+            if len(_RESIZE_COEFFS) > 256:
+                _RESIZE_COEFFS.clear()
+            b, k, ks = pil_bilinear_coeffs(n_in, n_out)
+            t = _RESIZE_COEFFS[key] = (torch.from_numpy(b).to(dev), torch.from_numpy(k).to(dev), ks)
+        return t
+
+    xb, xk, ksx = tables(w, new_w)
+    yb, yk, ksy = tables(h, new_h)
+    if out is None:
+        out = torch.empty((c, new_h, new_w), dtype=torch.float32, device=dev)
+    C.call("drn_resize_bilinear_u8", C.ptr(img_hwc), h, w, c, C.ptr(out), new_h, new_w, C.ptr(xb), C.ptr(xk), ksx, C.ptr(yb),
+           C.ptr(yk), ksy, int(bool(flip)), C.stream())
+    return out
+
+
 def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, aligned=False, out=None, out_dtype=None,
                   want_argmax=False, out_t=None, t_first_channel=0):
     """feat [N,H,W,C]; rois [M,5] f32; -> out [M, ld] (first C*P*P columns valid, k = c*P*P + bin); out_t (optional,

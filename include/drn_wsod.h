@@ -36,6 +36,18 @@ extern "C" {
 int drn_preprocess_nhwc(const float* img_chw, int C, int H, int W, void* out_nhwc, int Hp, int Wp, int Cp,
                         const float* mean3_host, const float* std3_host, int dtype, void* stream);
 
+/* ResizeTransform.apply_image on an 8-bit image (detectron2/data/transforms/transform.py:101-122: PIL.Image.resize(size,
+ * BILINEAR)) [+ HFlipTransform], as DatasetMapperTTAAVG applies them 16 times per image
+ * (projects/WSL/wsl/modeling/test_time_augmentation_avg.py:68-137), on the device.  Pillow (un-vendored, un-pinned dependency
+ * of the reference; its published algorithm - Resample.c - is restated, and pinned bit for bit against the installed Pillow by
+ * the tests): a horizontal then a vertical integer pass; output position i reads source positions [bounds[2i], bounds[2i] +
+ * bounds[2i+1]) with coefficients coef[i * ks + j] scaled by 2^22, each pass rounds ((1 << 21) + sum) >> 22 and clips to 8 bits.
+ * The caller computes bounds / coef with Pillow's double arithmetic (host side: ops.pil_bilinear_coeffs) and passes them as
+ * DEVICE pointers; a NULL bounds pointer skips that pass (its size must not change).
+ * src_hwc uint8 [H][W][C] (C <= 4), dst_chw fp32 [C][Ho][Wo] holding the integers 0 .. 255; flip != 0 mirrors the columns. */
+int drn_resize_bilinear_u8(const void* src_hwc, int H, int W, int C, float* dst_chw, int Ho, int Wo, const int* xbounds,
+                           const int* xcoef, int ksx, const int* ybounds, const int* ycoef, int ksy, int flip, void* stream);
+
 /* Conv2d.forward = F.conv2d -> FrozenBatchNorm2d -> relu_ [+ residual add before the relu],
  * detectron2/layers/wrappers.py:94-99, detectron2/layers/batch_norm.py:45-65,
  * projects/WSL/wsl/modeling/backbone/resnet_ws.py:217-237, vgg.py:104-122.

@@ -1053,6 +1053,63 @@ def tta_resize_image(img_hwc, new_h, new_w):
     return t[0].permute(1, 2, 0).numpy()
 
 
+def pil_bilinear_coeffs(in_size, out_size):
+    """Pillow's Resample.c (precompute_coeffs with the BILINEAR = triangle filter of support 1, normalize_coeffs_8bpc), restated
+    loop for loop: -> (bounds [(first source position, count)] per output position, integer coefficients scaled by 2^22).
+    Pillow is an un-vendored dependency of the reference (detectron2/data/transforms/transform.py:101-122 calls
+    PIL.Image.resize(..., BILINEAR)); pinned against the installed Pillow and against the reference-generated augmented
+    images of tests/golden/tta_r50c4_tiny.npz (tests/test_oracle_golden.py)."""
+    import math
+
+    scale = float(in_size) / out_size
+    fscale = max(scale, 1.0)
+    support = 1.0 * fscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    ss = 1.0 / fscale
+    bounds, coef = [], []
+    for xx in range(out_size):
+        center = 0.0 + (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        k, ww = [0.0] * ksize, 0.0
+        for x in range(xmax):
+            a = abs((x + xmin - center + 0.5) * ss)
+            w = 1.0 - a if a < 1.0 else 0.0
+            k[x] = w
+            ww += w
+        if ww != 0.0:
+            for x in range(xmax):
+                k[x] /= ww
+        bounds.append((xmin, xmax))
+        coef.append([int(-0.5 + v * (1 << 22)) if v < 0 else int(0.5 + v * (1 << 22)) for v in k])
+    return bounds, coef
+
+
+def pil_bilinear_resize_u8(img_hwc, new_h, new_w):
+    """PIL.Image.fromarray(img).resize((new_w, new_h), BILINEAR) for an 8-bit [H, W, C] image without Pillow: horizontal pass
+    (result rounded and clipped to 8 bits), then vertical pass (ImagingResample, 8bpc paths)."""
+    import numpy as np
+
+    def one_pass(x, axis, n_out):
+        n_in = x.shape[axis]
+        if n_in == n_out:
+            return x
+        bounds, coef = pil_bilinear_coeffs(n_in, n_out)
+        x = np.moveaxis(x, axis, 0)
+        out = np.empty((n_out,) + x.shape[1:], dtype=np.int64)
+        for i, ((lo, n), k) in enumerate(zip(bounds, coef)):
+            acc = np.full(x.shape[1:], 1 << 21, dtype=np.int64)
+            for j in range(n):
+                acc += x[lo + j] * k[j]
+            out[i] = np.clip(acc >> 22, 0, 255)
+        return np.moveaxis(out, 0, axis)
+
+    x = np.asarray(img_hwc).astype(np.int64)
+    x = one_pass(x, 1, new_w)
+    x = one_pass(x, 0, new_h)
+    return x.astype(np.uint8)
+
+
 def tta_apply_box(boxes, steps):
     """Transform.apply_box through a TransformList: the 4 corners go through every transform's apply_coords (float32
     array x python float, i.e. float32 arithmetic), the result is their axis-aligned bounding box.

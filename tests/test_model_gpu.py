@@ -747,12 +747,18 @@ def test_tta_matches_reference_golden():
     prop.objectness_logits = torch.from_numpy(d["objectness_logits"])
     inp = {"image": img, "proposals": prop, "height": H, "width": W}
     tta = GeneralizedRCNNWithTTAAVG(cfg, model)
+    assert tta.tta_mapper.device is not None  # (round 5) resize + flip on the device: the same BYTES as the reference's PIL images
+    from drn_wsod_pytorch_amd.modeling.tta import DatasetMapperTTAAVG
+
+    for mapper in (tta.tta_mapper, DatasetMapperTTAAVG(cfg)):  # device path (default), host path
+        augs = mapper(inp)
+        assert len(augs) == int(d["n_aug"])
+        for i, a in enumerate(augs):
+            assert a["image"].is_cuda == (mapper.device is not None)
+            assert np.array_equal(a["image"].cpu().numpy().astype(np.float32), d["aug%d_image" % i].astype(np.float32)), i
+            assert np.array_equal(a["proposals"].proposal_boxes.tensor.numpy(), d["aug%d_boxes" % i]), i
+            assert np.array_equal(a["proposals"].objectness_logits.numpy(), d["aug%d_obj" % i]), i
     augs = tta.tta_mapper(inp)
-    assert len(augs) == int(d["n_aug"])
-    for i, a in enumerate(augs):
-        assert np.array_equal(a["image"].numpy(), d["aug%d_image" % i]), i
-        assert np.array_equal(a["proposals"].proposal_boxes.tensor.numpy(), d["aug%d_boxes" % i]), i
-        assert np.array_equal(a["proposals"].objectness_logits.numpy(), d["aug%d_obj" % i]), i
     with torch.no_grad():
         avg_b, avg_s = tta._get_augmented_boxes(augs)
     assert np.allclose(avg_s.cpu().numpy(), d["avg_scores"], rtol=1e-4, atol=1e-6)

@@ -549,6 +549,27 @@ def test_conv_ring_kernels(drn, case):
     assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("shape", [(375, 500, 480, 640), (375, 500, 1152, 1536), (333, 500, 864, 1297), (500, 375, 240, 180),
+                                   (37, 53, 37, 90), (64, 48, 21, 48), (50, 60, 173, 60)])
+def test_resize_bilinear_u8_equals_pillow(drn, shape):
+    """drn_resize_bilinear_u8 (ResizeTransform [+ HFlipTransform] of the TTA mapper on the device) == Pillow's
+    Image.resize(BILINEAR) and the oracle's restatement of it, byte for byte: up- and down-scaling, a direction left
+    unchanged, mirrored output."""
+    from PIL import Image
+
+    h, w, nh, nw = shape
+    rs = np.random.RandomState(h * 7 + nw)
+    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+    assert np.array_equal(O.pil_bilinear_resize_u8(img, nh, nw), ref)
+    src = torch.from_numpy(img).to(DEV)
+    got = drn.resize_bilinear_u8(src, nh, nw)
+    assert got.dtype == torch.float32 and tuple(got.shape) == (3, nh, nw)
+    assert np.array_equal(got.cpu().numpy(), ref.transpose(2, 0, 1).astype(np.float32))
+    flipped = drn.resize_bilinear_u8(src, nh, nw, flip=True)
+    assert np.array_equal(flipped.cpu().numpy(), np.flip(ref, axis=1).transpose(2, 0, 1).astype(np.float32))
+
+
 @pytest.mark.parametrize("case", [(1, 99, 151, 256, 1024, True, True),     # dilated-C5 res4 conv3 + shortcut at 800x1216: 59 x 4 tiles, 4 slabs
                                   (1, 99, 151, 512, 2048, True, True),     # res5 conv3 + shortcut: two rounds of tiles
                                   (1, 99, 151, 1024, 2048, False, True),   # res5 projection shortcut (16 slabs)

@@ -388,6 +388,40 @@ def test_tta_golden():
     assert np.allclose(b.numpy(), d["det_boxes"], rtol=1e-6, atol=1e-4)
 
 
+def test_pil_bilinear_restatement():
+    """oracle.pil_bilinear_resize_u8 (Pillow's integer BILINEAR resample, restated for the device-side TTA mapper) == the
+    installed Pillow bit for bit (up- and down-scaling, one direction unchanged), == the augmented images the REFERENCE's own
+    mapper produced (tests/golden/tta_r50c4_tiny.npz), and the product's vectorised coefficient tables
+    (ops.pil_bilinear_coeffs) == the oracle's loop-for-loop ones."""
+    from PIL import Image
+
+    from __graft_entry__ import load_package
+
+    load_package()
+    from drn_wsod_pytorch_amd import ops
+
+    rs = np.random.RandomState(0)
+    for h, w, nh, nw in [(375, 500, 480, 640), (333, 500, 864, 1297), (500, 375, 240, 180), (37, 53, 37, 90), (64, 48, 21, 48),
+                         (50, 60, 173, 60)]:
+        img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+        ref = np.asarray(Image.fromarray(img).resize((nw, nh), Image.BILINEAR))
+        assert np.array_equal(O.pil_bilinear_resize_u8(img, nh, nw), ref), (h, w, nh, nw)
+    for n_in, n_out in [(375, 480), (500, 1536), (500, 180), (97, 96), (64, 21)]:
+        b, k, ks = ops.pil_bilinear_coeffs(n_in, n_out)
+        ob, ok = O.pil_bilinear_coeffs(n_in, n_out)
+        assert ks == len(ok[0]) and np.array_equal(b, np.asarray(ob)) and np.array_equal(k, np.asarray(ok)), (n_in, n_out)
+    d = G.load("tta_r50c4_tiny")
+    img = np.ascontiguousarray(d["image_u8"].transpose(1, 2, 0))
+    n = 0
+    for i in range(int(d["n_aug"])):
+        a = d["aug%d_image" % i]  # [3, nh, nw] uint8, even i: not flipped (FLIP = True: pairs of (plain, mirrored))
+        if i % 2 == 0:
+            got = O.pil_bilinear_resize_u8(img, a.shape[1], a.shape[2]).transpose(2, 0, 1)
+            assert np.array_equal(got, a), i
+            n += 1
+    assert n >= 1
+
+
 def test_pcl_targets_and_loss_golden():
     """PCL: oracle/pcl_oracle.py against the reference's own PCL() (third_party/pcl.py) and its
     pcl_loss_cpu.cpp, on the golden cases where the reference's scikit-learn draw and numpy tie order coincide with

@@ -33,7 +33,7 @@ for wl in os.environ.get("TTA_WORKLOADS", "r50c4,r50dc5").split(","):
     bench.init_weights(model, seed=0)
     model.eval()
     g = torch.Generator().manual_seed(1)
-    img = torch.randint(0, 256, (3, H, W), generator=g).float()
+    img = torch.randint(0, 256, (3, H, W), generator=g).to(torch.uint8)  # (uint8 like a decoded image: the mapper resizes it with PIL, as the reference does)
     x0 = torch.rand(R, generator=g) * (W - 60)
     y0 = torch.rand(R, generator=g) * (H - 60)
     bw = 20 + torch.rand(R, generator=g) * (W - x0 - 20) * 0.6
