@@ -2560,18 +2560,21 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
     return launch_conv3x3_c64(p, st);
   // everything beyond the latency-bound small maps: the register-ring kernels (conv_ring.hip; bf16, Cin % 64 == 0).  Decided on
   // ONE image's geometry: the small-map kernels below add their K partials in another order
-  // 1x1 / stride 1 convs to >= 256 channels with >= 100 tiles of 256x256 per image: the GEMM ping-pong mainloop with the conv
-  // epilogue (conv1x1_pp_kernel; the dilated-C5 trunk's 1x1s to 512 / 1024 / 2048 channels and the res2 1x1s to 256 channels
-  // at a real image size).  Threshold measured (profiles/r5_17_conv1x1_pp_threshold_*.txt): at 59-60 tiles - res4 of the C4
-  // trunk, the DC5 trunk's 1x1s to 256 channels - a 256x256 tile per CU on a quarter of the chip loses to the small tiles, at
-  // 118 it wins; a 64-channel output wastes three quarters of the tile.  Decided on ONE image's geometry; same bits as the
-  // tiled kernels either way.
+  // 1x1 / stride 1 convs to >= 256 channels of a large map: the GEMM ping-pong mainloop with the conv epilogue
+  // (conv1x1_pp_kernel; the dilated-C5 trunk's 1x1s to 512 / 1024 / 2048 channels and the res2 1x1s to 256 channels at a real
+  // image size).  Class measured (profiles/r5_17_conv1x1_pp_threshold_*.txt, r5_19_conv_800.txt): from ~3/4 of the CUs' worth
+  // of 256x256 tiles per image on it wins at any K; at 100-191 tiles - half the chip holds a tile - only with a long K loop
+  // (>= 16 slabs: 2048 -> 512 at 118 tiles 47 -> 44 us, but 128 -> 512 at 120 tiles 12 -> 15 us); at 59-60 tiles (res4 of the
+  // C4 trunk, the DC5 trunk's 1x1s to 256 channels) the small tiles win; a 64-channel output wastes three quarters of the
+  // tile.  Decided on ONE image's geometry; same bits as the tiled kernels either way.
   if (g_conv_pp && dtype == DRN_BF16 && out_dtype == DRN_BF16 && (!residual || res_dtype == DRN_BF16) && KH == 1 && KW == 1 &&
       stride == 1 && pad == 0 && (Cin & 63) == 0 && (Cout & 7) == 0 && (ldy & 3) == 0 && (!residual || (ldres & 3) == 0) &&
       (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)residual) & 15) == 0 && (ldw * 2) % 16 == 0 &&
-      (long)Cout * ldw * 2 < 0xFFFFFFF0L && (Cout >= 256 || g_conv_pp > 1) &&
-      (((long)Ho * Wo + 255) / 256) * ((Cout + 255) / 256) >= (g_conv_pp > 1 ? g_conv_pp : 100))
-    return launch_conv1x1_pp(p, st);
+      (long)Cout * ldw * 2 < 0xFFFFFFF0L) {
+    const long t256 = (((long)Ho * Wo + 255) / 256) * ((Cout + 255) / 256);
+    if (g_conv_pp > 1 ? t256 >= g_conv_pp : (Cout >= 256 && (t256 >= 192 || (t256 >= 100 && (Cin >> 6) >= 16))))
+      return launch_conv1x1_pp(p, st);
+  }
   {
     const int rc = drn_conv_ring_try(p, dtype, cu_count(), tiles64, st);
     if (rc != DRN_ERR_UNSUPPORTED) return rc;

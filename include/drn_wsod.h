@@ -231,7 +231,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_ROI_LANE_REPS 22 /* lane-per-bin ROIPool on maps that leave one block per CU: groups of 64 ROIs a block walks with one staged map slice (0 = default: 4, halved while fewer than two rounds of blocks would remain; 1 = a block per group) */
 #define DRN_TUNE_ROI_LANE 19 /* 0/1 (default 1): the bf16 training operand A from the lane-per-bin ROIPool kernel (a wave per ROI, lane = bin: every channel leaves as one 98-byte run per store instruction); 0 = the 64-ROI kernel writes A */
 #define DRN_TUNE_CONV_RING 23 /* register-ring conv kernels (conv_ring.hip; bf16, Cin % 64 == 0, layers beyond the latency-bound small maps): 0 = off (the tiles of gemm_conv.hip), 1 = default (tile by cost model), 64 / 96 / 128 = pin the 64x64 / 128x64 / 128x128 tile; every tile gives the same bits as the 64x64 / 128x128 tiled kernel */
-#define DRN_TUNE_CONV_PP 24 /* 1x1 / stride-1 bf16 convs of large maps on the 256x256 ping-pong GEMM mainloop with the conv epilogue (conv1x1_pp_kernel): 0 = off, 1 = default (Cout >= 256 and >= 100 tiles of 256x256 per image), n > 1 = at least n tiles, any Cout; same bits as the tiled kernels */
+#define DRN_TUNE_CONV_PP 24 /* 1x1 / stride-1 bf16 convs of large maps on the 256x256 ping-pong GEMM mainloop with the conv epilogue (conv1x1_pp_kernel): 0 = off, 1 = default (Cout >= 256 and >= 192 tiles of 256x256 per image, or >= 100 tiles with K >= 1024), n > 1 = at least n tiles, any Cout; same bits as the tiled kernels */
 #define DRN_TUNE_CONV_PATCH 9 /* 0 = never use the LDS-resident-patch kernel for 3x3 / 64 -> 64 channel convs; 1 = default (maps of >= 32768 pixels); > 1 = that many pixels per image at least */
 int drn_tune(int knob, int value);
 
