@@ -987,8 +987,14 @@ __global__ __launch_bounds__(JMAX >= 13 ? 256 : JMAX >= 7 ? 512 : 1024, JMAX >= 
 //     maximum): uniform trip counts, no divergence, nothing waits per pixel.
 // LDS: [NCK][H*W][16 B] (8 channels of a pixel, order-mapped bf16), staged once per run of same-image ROIs of the block.
 // Bit-identical to the kernels above (same maxima, same fp32 scaling, same RNE conversion).  15 of 64 lanes idle.
-template <int NCK, int NWV = 8>
+// VD (round 5): dwords of one LDS cell - 4 = 8 channels of a pixel in 16 bytes (every map whose 8-channel slice fits the LDS),
+// 2 = 4 channels in 8 bytes: maps of up to ~19 700 cells, i.e. the shipped dilated-C5 recipe's stride-8 feature map of a
+// real-size image (99 x 151 at 800 x 1216: an 8-channel slice is 240 KB).  Those maps used to fall to the 64-ROI kernel in
+// row bands: 1.95 ms per pooling launch at R = 2000, 46 % of a DC5 inference pass (profiles/r5_25_infer800_r50dc5_kernel_stats.txt).
+template <int NCK, int NWV = 8, int VD = 4>
 __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
+  typedef int cellv __attribute__((ext_vector_type(VD)));
+  constexpr int CB = VD * 4, CH = VD * 2;  // bytes / channels of a cell
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = p.H * p.W;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -996,14 +1002,14 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
   // window pixels per trip of the scan: with one or two chunks per block (large maps: windows of 4-15 pixels a side) four
   // clamped pixels of a row go out together - four independent LDS reads in flight instead of one per trip
   constexpr int UNR = NCK <= 2 ? 4 : 1;
-  const int nslice = p.C / (8 * NCK);
+  const int nslice = p.C / (CH * NCK);
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
   const int group = logical / nslice, sl = logical - group * nslice;
-  const int c0 = sl * 8 * NCK;
+  const int c0 = sl * CH * NCK;
   const int ph = lane / 7, pw = lane - ph * 7;
   const bool is_bin = lane < 49;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned cstride = (unsigned)HW * 16u;
+  const unsigned cstride = (unsigned)HW * (unsigned)CB;
   int cur_img = -1;
   for (int rep = 0; rep < p.lane_reps; ++rep) {  // (the staged slice carries over from group to group while the image stays)
   const int m0 = (group * p.lane_reps + rep) * p.lane_g;
@@ -1037,10 +1043,10 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
       const char* fb = p.feat + ((long)b * HW * p.C + c0) * 2;
       for (int idx = tid; idx < HW * NCK; idx += NW * 64) {
         const int px = idx / NCK, c = idx - px * NCK;
-        i32x4_t x = *(const i32x4_t*)(fb + (long)px * p.C * 2 + c * 16);
+        cellv x = *(const cellv*)(fb + (long)px * p.C * 2 + c * CB);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
-        *(i32x4_t*)(smem + ((long)c * HW + px) * 16) = x;
+        for (int e = 0; e < VD; ++e) x[e] = bf16x2_order(x[e]);
+        *(cellv*)(smem + ((long)c * HW + px) * CB) = x;
       }
       __syncthreads();
       cur_img = b;
@@ -1061,32 +1067,47 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
       while (__ballot(max_nh < nh) != 0) ++max_nh;
       while (__ballot(max_nw < nw) != 0) ++max_nw;
       const int lo = (int)0x80008000u;
-      i32x4_t acc[NCK];
+      cellv acc[NCK];
 #pragma unroll
-      for (int c = 0; c < NCK; ++c) acc[c] = i32x4_t{lo, lo, lo, lo};
+      for (int c = 0; c < NCK; ++c)
+#pragma unroll
+        for (int e = 0; e < VD; ++e) acc[c][e] = lo;
       // (built and measured: the same loops with every read PREDICATED on the lane's own window instead of clamped - a third
       // of the LDS bytes - are slower at every map size, 61 -> 67 us at 14x14 and 350 -> 404 us at 63x92: the exec-mask
       // bookkeeping and the re-initialised operands cost more issue slots than the reads cost LDS cycles)
-      for (int hi = 0; hi < max_nh; ++hi) {
-        const int hr = min(max(min(hs + hi, he - 1), 0), p.H - 1);
-        const unsigned arow = lds0 + (unsigned)(hr * p.W) * 16u;
-        const int wlast = min(max(we - 1, 0), p.W - 1), wfirst = min(max(ws, 0), p.W - 1);
+      // UNRH window rows per trip (4-channel cells - the largest maps, windows of 5-20 pixels a side: two rows x four clamped
+      // pixels = eight independent LDS reads in flight instead of four; the scan of those maps is bound by the reads' latency,
+      // not by LDS bandwidth: 1432 us against ~270 us of LDS cycles at 99x151, profiles/r5_26_*)
+      constexpr int UNRH = VD == 2 ? 2 : 1;
+      const int wlast = min(max(we - 1, 0), p.W - 1), wfirst = min(max(ws, 0), p.W - 1);
+      for (int hi = 0; hi < max_nh; hi += UNRH) {
+        unsigned arow[UNRH];
+#pragma unroll
+        for (int v = 0; v < UNRH; ++v) {
+          const int hr = min(max(min(hs + hi + v, he - 1), 0), p.H - 1);
+          arow[v] = lds0 + (unsigned)(hr * p.W) * (unsigned)CB;
+        }
         for (int wi = 0; wi < max_nw; wi += UNR) {
-          i32x4_t x[UNR][NCK];
+          cellv x[UNRH][UNR][NCK];
 #pragma unroll
           for (int u = 0; u < UNR; ++u) {
             const int wc = min(wfirst + wi + u, wlast);  // clamped: a pixel read twice does not change a maximum
-            const unsigned a = arow + (unsigned)wc * 16u;
 #pragma unroll
-            for (int c = 0; c < NCK; ++c)
-              x[u][c] = *(__attribute__((address_space(3))) const i32x4_t*)(uintptr_t)(a + (unsigned)c * cstride);
+            for (int v = 0; v < UNRH; ++v) {
+              const unsigned a = arow[v] + (unsigned)wc * (unsigned)CB;
+#pragma unroll
+              for (int c = 0; c < NCK; ++c)
+                x[v][u][c] = *(__attribute__((address_space(3))) const cellv*)(uintptr_t)(a + (unsigned)c * cstride);
+            }
           }
 #pragma unroll
-          for (int u = 0; u < UNR; ++u)
+          for (int v = 0; v < UNRH; ++v)
 #pragma unroll
-            for (int c = 0; c < NCK; ++c)
+            for (int u = 0; u < UNR; ++u)
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[c][e] = pk_max_i16(acc[c][e], x[u][c][e]);
+              for (int c = 0; c < NCK; ++c)
+#pragma unroll
+                for (int e = 0; e < VD; ++e) acc[c][e] = pk_max_i16(acc[c][e], x[v][u][c][e]);
         }
       }
       if (is_bin) {
@@ -1095,7 +1116,7 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
 #pragma unroll
         for (int c = 0; c < NCK; ++c)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
+          for (int e = 0; e < VD; ++e) {
             // (an empty bin is +0 in both halves; one packed conversion - v_cvt_pk_bf16_f32, RNE like f32_to_bf16 - and the
             // two halves of its result leave through global_store_short / global_store_short_d16_hi)
             const uint32_t y = empty ? 0u : (uint32_t)bf16x2_order(acc[c][e]);
@@ -1103,8 +1124,8 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             const f32x2_t f = f32x2_t{__builtin_bit_cast(float, y << 16), __builtin_bit_cast(float, y & 0xffff0000u)} * mul;
             const uint32_t o = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
-            dst[(c * 8 + 2 * e) * 49] = (bf16_t)(o & 0xffffu);
-            dst[(c * 8 + 2 * e + 1) * 49] = (bf16_t)(o >> 16);
+            dst[(c * CH + 2 * e) * 49] = (bf16_t)(o & 0xffffu);
+            dst[(c * CH + 2 * e + 1) * 49] = (bf16_t)(o >> 16);
           }
       }
     }
@@ -1131,8 +1152,14 @@ static int cu_count_pool_fwd();
 static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
   RoiParams p = p0;
   if (!g_roi_lane || p.C % 8) return false;
-  const size_t per_chunk = (size_t)p.H * p.W * 16;
-  const int nck = roi_lane_chunks(p.H, p.W, p.C);
+  size_t per_chunk = (size_t)p.H * p.W * 16;
+  int nck = roi_lane_chunks(p.H, p.W, p.C);
+  int vd = 4;
+  if (!nck && p.C % 4 == 0 && (size_t)p.H * p.W * 8 <= 154 * 1024) {  // 4-channel cells: one 8-byte-per-pixel chunk per block
+    nck = 1;
+    vd = 2;
+    per_chunk = (size_t)p.H * p.W * 8;
+  }
   if (!nck) return false;
   const size_t smem = per_chunk * nck;
   static bool attr = false;
@@ -1141,7 +1168,9 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
         hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
         hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
-        hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+        hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<1, 16>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<1, 16, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
       return false;
     attr = true;
   }
@@ -1153,8 +1182,11 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
   // 120 KB = 250 MB at 50x76.  A block walks `lane_reps` groups with one staged slice as long as >= 2 rounds of blocks remain
   p.lane_reps = 1;
   if (smem > 76 * 1024) {
-    const long blocks1 = (long)ngroups * (p.C / (8 * nck));
-    int reps = g_roi_lane_reps > 0 ? g_roi_lane_reps : 4;
+    const long blocks1 = (long)ngroups * (p.C / (2 * vd * nck));
+    // (4-channel cells - the DC5 stride-8 map: a slice is staged 8 bytes per 4-KB pixel, i.e. a whole 128-byte line per cell from
+    // the Infinity Cache: 7.9 GB per launch with 4 groups per staged slice; with all of a slice's groups on one block - still
+    // two rounds of blocks - the launch went from 1242 to 948 us, profiles/r5_28_*)
+    int reps = g_roi_lane_reps > 0 ? g_roi_lane_reps : (vd == 2 ? 32 : 4);
     while (reps > 1 && blocks1 / reps < 2L * cu_count_pool_fwd()) reps >>= 1;
     p.lane_reps = reps;
     ngroups = (ngroups + reps - 1) / reps;
@@ -1163,9 +1195,12 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
   // (one block per CU - maps beyond ~4700 pixels: with a block per group of 64 ROIs this kernel measured 372 vs 325 us for the
   // 64-ROI kernel at 63x92 and went there only for maps that kernel stages in two row bands; with four groups per staged
   // slice it is 293 vs 330 us at 63x92 and 260 vs 368 us at 75x122 and takes every map whose chunk fits)
-  const dim3 grid((unsigned)ngroups * (p.C / (8 * nck))), block(big ? 1024 : 512);
+  const dim3 grid((unsigned)ngroups * (p.C / (2 * vd * nck))), block(big ? 1024 : 512);
   p.out_t = nullptr;  // (A only; the caller launches the 64-ROI kernel for the A^T tail chunks)
-  if (nck == 8) hipLaunchKernelGGL(roi_pool7_lane_kernel<8>, grid, block, smem, st, p);
+  if (vd == 2) {
+    if (big) hipLaunchKernelGGL((roi_pool7_lane_kernel<1, 16, 2>), grid, block, smem, st, p);
+    else hipLaunchKernelGGL((roi_pool7_lane_kernel<1, 8, 2>), grid, block, smem, st, p);
+  } else if (nck == 8) hipLaunchKernelGGL(roi_pool7_lane_kernel<8>, grid, block, smem, st, p);
   else if (nck == 4) hipLaunchKernelGGL(roi_pool7_lane_kernel<4>, grid, block, smem, st, p);
   else if (nck == 2) hipLaunchKernelGGL(roi_pool7_lane_kernel<2>, grid, block, smem, st, p);
   else if (big) hipLaunchKernelGGL((roi_pool7_lane_kernel<1, 16>), grid, block, smem, st, p);

@@ -744,7 +744,8 @@ def test_roi_pool_transposed_tail_hint(drn, C, H, W, R, t0):
 
 @pytest.mark.parametrize("C,H,W,R,t0,n_img", [(1024, 14, 14, 2000, 1003, 1), (128, 14, 14, 83, 117, 3), (64, 28, 28, 200, 58, 2),
                                               (128, 50, 76, 300, 120, 2), (16, 63, 92, 130, 15, 2), (24, 40, 37, 65, 22, 4),
-                                              (16, 75, 122, 130, 15, 2), (64, 14, 14, 100, 0, 2)])
+                                              (16, 75, 122, 130, 15, 2), (64, 14, 14, 100, 0, 2),
+                                              (64, 99, 151, 140, 58, 2)])  # the DC5 stride-8 map of an 800x1216 image: 4-channel LDS cells
 def test_roi_pool_lane_kernel_equals_map64(drn, C, H, W, R, t0, n_img):
     """Round 4: the lane-per-bin kernel (a wave per ROI, lane = bin, every channel one 98-byte store run; DRN_TUNE_ROI_LANE)
     writes the bf16 training operand A; the 64-ROI kernel keeps only the A^T tail.  Against the 64-ROI kernel alone and
