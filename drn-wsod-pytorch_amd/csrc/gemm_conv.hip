@@ -2476,9 +2476,11 @@ int drn_gemm_tn_sgd(const void* A, const void* Bt, void* grad_bucket, int M, int
   if (!A || !Bt || !grad_bucket || !weights || !momentum_buf || !seg_dev || M <= 0 || N <= 0 || K <= 0 || kb_rows < 0 ||
       kb_rows > K)
     return DRN_ERR_ARG;
-  if ((lda * 2) % 16 != 0 || (ldb * 2) % 16 != 0 || lda < K || ldb < N || ldc < N || ld_w < N) return DRN_ERR_ARG;
-  if ((((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)grad_bucket | (uintptr_t)weights | (uintptr_t)momentum_buf | (uintptr_t)shadow) & 15))
-    return DRN_ERR_ARG;
+  if (lda < K || ldb < N || ldc < N || ld_w < N) return DRN_ERR_ARG;
+  // (alignment is part of the shape class, not an argument error: the caller's unfused pair takes such buffers - ADVICE r4)
+  if ((lda * 2) % 16 != 0 || (ldb * 2) % 16 != 0 ||
+      (((uintptr_t)A | (uintptr_t)Bt | (uintptr_t)grad_bucket | (uintptr_t)weights | (uintptr_t)momentum_buf | (uintptr_t)shadow) & 15))
+    return DRN_ERR_UNSUPPORTED;
   // shape class of the pipelined update: whole K slabs (one 8-row chunk of the previous tile rides in each; with fewer than 32
   // slabs - fewer than 2048 proposals - the rest follows the mainloop, exposed), whole tiles, a bf16 shadow, 32-bit byte
   // offsets, enough tiles for the persistent grid, the ping-pong mainloop

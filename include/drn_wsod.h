@@ -198,8 +198,10 @@ int drn_gemm_tn(const void* A, const void* Bt, void* C, int M, int N, int K, int
  * is applied by the SAME launch: every workgroup of the persistent 256x256 kernel updates the tile it finished last while it
  * multiplies the next one (one 8-row chunk per K slab, loads / stores interleaved with the LDS-DMA pipeline), so the
  * optimizer's HBM traffic is a steady stream under the MFMA work and the gradient is read back from L2.  Bit-identical to
- * the unfused pair.  Shape class: K >= 2048 (at least 32 K slabs: 1985+ proposals), M, N multiples of 256, bf16 shadow given;
- * DRN_ERR_UNSUPPORTED otherwise (callers then run the unfused pair). */
+ * the unfused pair.  Shape class: K >= 128 with K % 64 == 0 (with fewer than 32 K slabs - fewer than 1985 proposals - the
+ * chunks of a tile's update that find no slab follow the mainloop, exposed), M, N multiples of 256, a bf16 shadow, 16-byte
+ * aligned pointers and pitches, more tiles than compute units; DRN_ERR_UNSUPPORTED for everything outside it (callers then run
+ * the unfused pair), DRN_ERR_ARG only for null / negative arguments. */
 int drn_gemm_tn_sgd(const void* A, const void* Bt, void* grad_bucket, int M, int N, int K, int kb_rows, long lda, long ldb,
                     long ldc, float* weights, float* momentum_buf, void* shadow, long ld_w, const void* seg_dev,
                     float momentum, int first_step, float grad_scale, void* stream);
