@@ -628,24 +628,6 @@ def main():
                 dist.all_reduce(tt, op=dist.ReduceOp.MAX)
                 local_ms = float(tt)
             opt._exchange_on = True
-        if dp.exchange and world > 1 and exchange == "fc6_kshard" and not args.no_other_exchange:
-            # the OTHER exchange on the same job, 20 steps, after the headline region (report both): the sharded
-            # gradient exchange (reduce-scatter per fc6 slab -> owned rows -> all-gather of the updated compute copy)
-            try:
-                opt.sync_master()  # every rank holds all columns again (a collective)
-                stepper.release()
-                model.roi_heads._engine.defer_fc1_tail = False
-                ug2, stp2, _, _ = setup("sharded")
-                if ug2:
-                    dt2, _, _, _, _ = timed_region(stp2, 20, False)
-                    if world > 1:
-                        t2_ = torch.tensor([dt2], device=device, dtype=torch.float64)
-                        dist.all_reduce(t2_, op=dist.ReduceOp.MAX)
-                        dt2 = float(t2_)
-                    other_exchange = {"exchange": "sharded", "steps": 20, "ms_per_step": dt2 / 20 * 1e3,
-                                      "value": world * args.ims_per_gpu * 20 / dt2, "unit": "images/sec"}
-            except Exception as ex_:  # noqa: BLE001 - supporting evidence only
-                other_exchange = "unavailable: %r" % (ex_,)
     else:
         ops.GEMM_TIMING = timing = []
         ops.HBM_TIMING = hbm_timing = []
@@ -965,6 +947,39 @@ def main():
             else:  # the oracle leg is timed on the BASELINE workload only (its config is the R50-C4 / K = 20 model)
                 out["cpu_baseline"] = None
                 out["cpu_baseline_note"] = "side workload: the CPU port is timed on the r50c4 workload only (default run)"
+    if use_graph and dp.exchange and world > 1 and exchange == "fc6_kshard" and not args.no_other_exchange:
+        # the OTHER exchange on the same job, 20 steps, AFTER everything the JSON line needs has been measured (report
+        # both): the sharded gradient exchange (reduce-scatter per fc6 slab -> owned rows -> all-gather of the updated compute
+        # copy).  A watchdog prints the line without it if this phase wedges - it must never cost the headline measurement.
+        import threading
+
+        def _bail():
+            if rank == 0:
+                out["grad_exchange"]["other_exchange"] = "timed out after 240 s (the headline measurement above is complete)"
+                sys.stdout.flush()
+                print(json.dumps(out), flush=True)
+            os._exit(0)
+
+        dog = threading.Timer(240.0, _bail)
+        dog.daemon = True
+        dog.start()
+        try:
+            opt.sync_master()  # every rank holds all columns again (a collective)
+            stepper.release()
+            model.roi_heads._engine.defer_fc1_tail = False
+            ug2, stp2, _, _ = setup("sharded")
+            if ug2:
+                dt2, _, _, _, _ = timed_region(stp2, 20, False)
+                t2_ = torch.tensor([dt2], device=device, dtype=torch.float64)
+                dist.all_reduce(t2_, op=dist.ReduceOp.MAX)
+                dt2 = float(t2_)
+                other_exchange = {"exchange": "sharded", "steps": 20, "ms_per_step": dt2 / 20 * 1e3,
+                                  "value": world * args.ims_per_gpu * 20 / dt2, "unit": "images/sec"}
+        except Exception as ex_:  # noqa: BLE001 - supporting evidence only
+            other_exchange = "unavailable: %r" % (ex_,)
+        dog.cancel()
+        if rank == 0:
+            out["grad_exchange"]["other_exchange"] = other_exchange
     if dist.is_initialized():
         dist.destroy_process_group()
     if rank == 0:
