@@ -164,6 +164,20 @@ def _worker(rank, world, port, q):
                 assert res["reduce_scatter fc6 slab %d" % i]["ms"] > 0 and res["all_gather fc6 slab %d" % i]["busbw_GBps"] > 0
             else:
                 assert "reduce_scatter fc6 slab %d" % i not in res  # the step falls back to the all-reduce there
+        # (round 5) ... and the K-sharded fc6's own collectives, which bench.py adds for N > 1: packed feature all-gather,
+        # reduce-scatter of the [N*M x D1] partial pre-activations in the wire dtype, all-gather of dP1
+        res = dp.selftest({"small": 16, "slabs": [], "kshard": {"pack_bytes": 1000, "M": 24, "D1": d1, "wire_dtype": torch.float32,
+                                                                   "dp1_dtype": torch.bfloat16}}, iters=1, timeout=30.0)
+        for key_ in ("all_gather feature pack (fc6_kshard)", "reduce_scatter H1 partials (fc6_kshard)", "all_gather dP1 (fc6_kshard)"):
+            assert res[key_]["ms"] > 0, key_
+        assert res["reduce_scatter H1 partials (fc6_kshard)"]["bytes"] == 2 * 24 * d1 * 4
+        # re-entrant exchange selection (bench.py's fallback chain): K-sharded -> sharded -> all-reduce on one optimizer
+        opt.enable_pipelined(dp, comm_dtype=torch.float32, exchange="fc6_kshard")
+        assert opt._kshard and e.kshard is not None and e.kshard["world"] == 2 and callable(e.kshard["sync"])
+        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.float32, exchange="sharded")
+        assert not opt._kshard and e.kshard is None and opt._sharded
+        opt.enable_pipelined(dp, slab_rows=[16, 40, d1], comm_dtype=torch.float32, exchange="allreduce")
+        assert not opt._kshard and not opt._sharded and e.kshard is None
         q.put((rank, "ok"))
     except Exception as ex:  # noqa: BLE001
         import traceback
