@@ -164,6 +164,7 @@ struct RoiParams {
   int c_begin;   // 64-ROI kernel: first channel it handles (the lane-per-bin kernel writes A; this one then only the A^T tail)
   int lane_g;    // lane-per-bin kernel: ROIs per group (one ROI per lane of every wave: <= 64)
   int lane_reps;  // lane-per-bin kernel: groups a block walks with ONE staged slice (large maps: the staging is L2 traffic ~ groups x map)
+  int walk;       // walking lane-per-bin kernel: consecutive channel chunks a block walks with the bin bounds of its ROIs in registers
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -1132,6 +1133,186 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
     r0 = r1;
   }
   }  // groups of this block
+}
+
+// 7x7 ROIPool, lane-per-bin, WALKING variant (round 5) for maps whose 8-channel slice leaves at most two blocks per CU
+// (43x58 and larger: test-time scales, real-size training images).  What the kernel above spends per (ROI, chunk) item
+// there (one chunk per block, so nothing is shared between chunks): ~100 VALU instructions of bookkeeping - box corners
+// through v_readlane, two divisions, four floor / ceil / clamp chains, two ballot loops for the wave's largest window -
+// in front of a scan of ~16 LDS reads (~130 instructions) and an epilogue of ~60: the launch is VALU-issue bound
+// (460 CU cycles per item at 50x76 against 119 at 14x14, where the stores bound it).  Here a block keeps its ROIs and walks
+// `p.walk` CONSECUTIVE channel chunks itself, re-staging the slice between them:
+//   * the bookkeeping runs once per ROI and block: per ROI three VGPRs hold the lane's window as LDS byte offsets
+//     (first row / first column, rows - 1, columns - 1, the empty flag) and the wave's largest window;
+//   * the scan forms an address with one v_min + one v_mad / v_lshl_add per read;
+//   * the walked chunks are the 16-byte pieces of ONE 128-byte line per pixel (walk = 8): the first chunk's staging brings
+//     the lines into the XCD's L2, the other seven hit there - the kernel above sends every piece's line request to the
+//     Infinity Cache from a different block.
+// Same maxima over the same pixels, same scaling / conversion as the kernels above: bit-identical outputs.
+// NSG: sub-groups of 64 ROIs per block (ROIs reach a wave through its lanes: 64 at a time); RPS = 64 / NWV ROIs per wave and
+// sub-group.
+template <int NWV, int NSG, int VD>
+__global__ __launch_bounds__(NWV * 64) void roi_pool7_walk_kernel(RoiParams p) {
+  typedef int cellv __attribute__((ext_vector_type(VD)));
+  constexpr int CB = VD * 4, CH = VD * 2, NT = NWV * 64, RPS = 64 / NWV, RPW = RPS * NSG;
+  constexpr int UNR = 4, UNRH = VD == 2 ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = p.H * p.W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int ncg = p.C / (CH * p.walk);  // chunk groups
+  const int ngroups = gridDim.x / ncg;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  // chunk-group major: the blocks of one XCD share few slices (L2: 32 CUs x 2 blocks x one 60-KB slice would be 4 MB)
+  const int cg = logical / ngroups, group = logical - cg * ngroups;
+  const int ph = lane / 7, pw = lane - ph * 7;
+  const bool is_bin = lane < 49;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned WCB = (unsigned)p.W * CB;
+  const int m0 = group * (64 * NSG);
+  // ---- once per block: the windows of this wave's ROIs -------------------------------------------------------------------
+  unsigned s_row[RPW], s_col[RPW], s_uni[RPW];
+  float s_mul[RPW];
+  int vimg[NSG];
+  unsigned long long runs[NSG];
+  int nrs[NSG];
+#pragma unroll
+  for (int sg = 0; sg < NSG; ++sg) {
+    const int ms = m0 + sg * 64;
+    const int nr = max(min(64, p.M - ms), 0);
+    nrs[sg] = nr;
+    int vx1 = 0, vy1 = 0, vx2 = 0, vy2 = 0;
+    float vmul = 1.f;
+    vimg[sg] = -1;
+    if (lane < nr) {
+      const float* roi = p.rois + 5 * (long)(ms + lane);
+      vimg[sg] = (int)roi[0];
+      vx1 = (int)roundf(roi[1] * p.scale);
+      vy1 = (int)roundf(roi[2] * p.scale);
+      vx2 = (int)roundf(roi[3] * p.scale);
+      vy2 = (int)roundf(roi[4] * p.scale);
+      vmul = p.obj ? p.obj[ms + lane] + 1.f : 1.f;
+    }
+    const int nxt = __shfl_down(vimg[sg], 1, 64);
+    runs[sg] = __ballot(lane < nr && (lane + 1 >= nr || nxt != vimg[sg]));
+#pragma unroll
+    for (int q = 0; q < RPS; ++q) {
+      const int j = sg * RPS + q;
+      const int r = wave + NWV * q;
+      s_row[j] = s_col[j] = s_uni[j] = 0;
+      s_mul[j] = 1.f;
+      if (r < nr) {
+        const int x1 = __builtin_amdgcn_readlane(vx1, r), y1 = __builtin_amdgcn_readlane(vy1, r);
+        const int x2 = __builtin_amdgcn_readlane(vx2, r), y2 = __builtin_amdgcn_readlane(vy2, r);
+        s_mul[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vmul), r));
+        const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+        const float bin_h = (float)rh / 7.f, bin_w = (float)rw / 7.f;
+        const int hs = min(max((int)floorf((float)ph * bin_h) + y1, 0), p.H);
+        const int he = min(max((int)ceilf((float)(ph + 1) * bin_h) + y1, 0), p.H);
+        const int ws = min(max((int)floorf((float)pw * bin_w) + x1, 0), p.W);
+        const int we = min(max((int)ceilf((float)(pw + 1) * bin_w) + x1, 0), p.W);
+        const bool empty = he <= hs || we <= ws;
+        const int nh = (is_bin && !empty) ? he - hs : 0, nw = (is_bin && !empty) ? we - ws : 0;
+        int max_nh = 0, max_nw = 0;  // the wave's largest window (uniform)
+        while (__ballot(max_nh < nh) != 0) ++max_nh;
+        while (__ballot(max_nw < nw) != 0) ++max_nw;
+        // a lane without a window (empty bin, lanes 49..63) reads some valid pixel and drops it
+        s_row[j] = (unsigned)min(hs, p.H - 1) * WCB | (unsigned)max(nh - 1, 0) << 20;
+        s_col[j] = (unsigned)min(ws, p.W - 1) * CB | (unsigned)max(nw - 1, 0) << 20 | (empty ? 0x80000000u : 0u);
+        s_uni[j] = (unsigned)max_nh | (unsigned)max_nw << 16;
+      }
+    }
+  }
+  // ---- the walk -----------------------------------------------------------------------------------------------------------
+  bool staged = false;
+  for (int cc = 0; cc < p.walk; ++cc) {
+    const int chunk = cg * p.walk + cc;
+    int cur_img = -1;
+#pragma unroll
+    for (int sg = 0; sg < NSG; ++sg) {
+      const int nr = nrs[sg];
+      for (int r0 = 0; r0 < nr;) {
+        const int b = __builtin_amdgcn_readlane(vimg[sg], r0);
+        const int r1 = r0 + __builtin_ctzll(runs[sg] >> r0) + 1;
+        if (b != cur_img) {
+          if (staged) {
+            // every wave is done with the previous slice: its LDS reads have returned (their data went into the stores).  A raw
+            // barrier - __syncthreads() would also drain the A stores just issued (vmcnt)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+          }
+          const char* fb = p.feat + ((long)b * HW * p.C + (long)chunk * CH) * 2;
+          constexpr int SB = 8;  // loads in flight per thread
+          for (int base = tid; base < HW; base += NT * SB) {
+            cellv x[SB];
+#pragma unroll
+            for (int k = 0; k < SB; ++k) x[k] = *(const cellv*)(fb + (long)min(base + k * NT, HW - 1) * p.C * 2);
+#pragma unroll
+            for (int k = 0; k < SB; ++k) {
+#pragma unroll
+              for (int e = 0; e < VD; ++e) x[k][e] = bf16x2_order(x[k][e]);
+              if (base + k * NT < HW) *(cellv*)(smem + (long)(base + k * NT) * CB) = x[k];
+            }
+          }
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          staged = true;
+          cur_img = b;
+        }
+#pragma unroll
+        for (int q = 0; q < RPS; ++q) {
+          const int j = sg * RPS + q;
+          const int r = wave + NWV * q;
+          if (r >= r0 && r < r1) {
+            const unsigned uni = __builtin_amdgcn_readfirstlane(s_uni[j]);
+            const int max_nh = uni & 0xffff, max_nw = uni >> 16;
+            const unsigned nhm1 = s_row[j] >> 20, nwm1 = s_col[j] >> 20 & 0x7ff;
+            const unsigned org = lds0 + (s_row[j] & 0xfffff) + (s_col[j] & 0xfffff);
+            const bool empty = (int)s_col[j] < 0;
+            const int lo = (int)0x80008000u;
+            cellv acc;
+#pragma unroll
+            for (int e = 0; e < VD; ++e) acc[e] = lo;
+            for (int hi = 0; hi < max_nh; hi += UNRH) {
+              unsigned arow[UNRH];
+#pragma unroll
+              for (int v = 0; v < UNRH; ++v) arow[v] = org + min((unsigned)(hi + v), nhm1) * WCB;
+              for (int wi = 0; wi < max_nw; wi += UNR) {
+                cellv x[UNRH][UNR];
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) {
+                  const unsigned co = min((unsigned)(wi + u), nwm1) * CB;
+#pragma unroll
+                  for (int v = 0; v < UNRH; ++v)
+                    x[v][u] = *(__attribute__((address_space(3))) const cellv*)(uintptr_t)(arow[v] + co);
+                }
+#pragma unroll
+                for (int v = 0; v < UNRH; ++v)
+#pragma unroll
+                  for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                    for (int e = 0; e < VD; ++e) acc[e] = pk_max_i16(acc[e], x[v][u][e]);
+              }
+            }
+            if (is_bin) {
+              bf16_t* dst = (bf16_t*)p.out + (long)(m0 + sg * 64 + r) * p.ld_out + (long)chunk * CH * 49 + lane;
+              const float mul = s_mul[j];
+#pragma unroll
+              for (int e = 0; e < VD; ++e) {
+                const uint32_t y = empty ? 0u : (uint32_t)bf16x2_order(acc[e]);
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                const f32x2_t f = f32x2_t{__builtin_bit_cast(float, y << 16), __builtin_bit_cast(float, y & 0xffff0000u)} * mul;
+                const uint32_t o = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+                dst[(2 * e) * 49] = (bf16_t)(o & 0xffffu);
+                dst[(2 * e + 1) * 49] = (bf16_t)(o >> 16);
+              }
+            }
+          }
+        }
+        r0 = r1;
+      }
+    }
+  }
 }
 
 static int g_roi_lane = 1;  // drn_tune(DRN_TUNE_ROI_LANE = 19): 0 = the 64-ROI kernel writes A as before
