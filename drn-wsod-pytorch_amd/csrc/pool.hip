@@ -164,7 +164,9 @@ struct RoiParams {
   int c_begin;   // 64-ROI kernel: first channel it handles (the lane-per-bin kernel writes A; this one then only the A^T tail)
   int lane_g;    // lane-per-bin kernel: ROIs per group (one ROI per lane of every wave: <= 64)
   int lane_reps;  // lane-per-bin kernel: groups a block walks with ONE staged slice (large maps: the staging is L2 traffic ~ groups x map)
-  int walk;       // walking lane-per-bin kernel: consecutive channel chunks a block walks with the bin bounds of its ROIs in registers
+  int walk;       // walking lane-per-bin kernel: consecutive channel chunks a block walks with ONE window table of its ROIs
+  int walk_wp;    // its LDS row pitch in cells (odd)
+  unsigned walk_wmagic;  // ceil(2^32 / W): pixel -> row by one v_mul_hi
 };
 
 constexpr int RP_CH = 64;    // channels per block = one wave-wide line of NHWC
@@ -1136,93 +1138,121 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
 }
 
 // 7x7 ROIPool, lane-per-bin, WALKING variant (round 5) for maps whose 8-channel slice leaves at most two blocks per CU
-// (43x58 and larger: test-time scales, real-size training images).  What the kernel above spends per (ROI, chunk) item
-// there (one chunk per block, so nothing is shared between chunks): ~100 VALU instructions of bookkeeping - box corners
-// through v_readlane, two divisions, four floor / ceil / clamp chains, two ballot loops for the wave's largest window -
-// in front of a scan of ~16 LDS reads (~130 instructions) and an epilogue of ~60: the launch is VALU-issue bound
-// (460 CU cycles per item at 50x76 against 119 at 14x14, where the stores bound it).  Here a block keeps its ROIs and walks
-// `p.walk` CONSECUTIVE channel chunks itself, re-staging the slice between them:
-//   * the bookkeeping runs once per ROI and block: per ROI three VGPRs hold the lane's window as LDS byte offsets
-//     (first row / first column, rows - 1, columns - 1, the empty flag) and the wave's largest window;
-//   * the scan forms an address with one v_min + one v_mad / v_lshl_add per read;
-//   * the walked chunks are the 16-byte pieces of ONE 128-byte line per pixel (walk = 8): the first chunk's staging brings
-//     the lines into the XCD's L2, the other seven hit there - the kernel above sends every piece's line request to the
-//     Infinity Cache from a different block.
+// (43x58 and larger: test-time scales, real-size training images).  Knock-outs of the kernel above at 50x76 / R = 2000
+// (profiles/r5_32_roi_walk_knockouts.txt): 71 us of its 215 are the staging (one 16-byte piece of every pixel's 2-KB line per
+// load - and one load, one wait, one LDS write per trip), ~90 us the scan, ~27 us the stores; the scan is instruction-issue
+// bound (conflict-free or broadcast LDS addresses: -10 %; six more VALU instructions per read: +18 %), and with ROIs sorted by
+// size the launch takes 1.6x as long - whatever unit waits for its largest ROIs sets the time.  Here
+//   * a block keeps its group of ROIs and walks `p.walk` CONSECUTIVE channel chunks, re-staging the slice between them: the
+//     walked chunks are the 16-byte pieces of ONE 128-byte line per pixel (walk = 8), so the first chunk's staging brings the
+//     lines into the XCD's L2 and the other seven hit there; eight loads are in flight per thread;
+//   * the bin bounds are computed once per block into an LDS table: per ROI 7 row entries (first row's LDS offset, rows - 1)
+//     and 7 column entries (first column's offset, columns - 1) - a lane fetches the two entries of its bin, 72 bytes per ROI
+//     instead of ~100 VALU instructions per (ROI, chunk);
+//   * the waves of a block take ROIs from a shared counter (one LDS atomic per ROI and chunk, fetched one ROI ahead) instead
+//     of a fixed share: the barrier at the end of a chunk waits for one ROI, not for the wave with the largest eight;
+//   * the slice's rows have an ODD pitch in cells: W is even for every map here, so rows alone moved a lane by even cell
+//     counts (4-byte banks: 16-byte cells map to 16 bank groups).
 // Same maxima over the same pixels, same scaling / conversion as the kernels above: bit-identical outputs.
-// NSG: sub-groups of 64 ROIs per block (ROIs reach a wave through its lanes: 64 at a time); RPS = 64 / NWV ROIs per wave and
-// sub-group.
-template <int NWV, int NSG, int VD>
+// NSG: sub-groups of 64 ROIs per block (image indices of a sub-group sit in the lanes of every wave).
+constexpr int WALK_TAB = 18;  // table dwords per ROI: [0..7] rows by ph, [8..15] columns by pw, [16] largest window, [17] scale
+template <int NWV, int NSG, int VD, int SB>  // SB: slice cells per thread (>= ceil(H * W / threads))
 __global__ __launch_bounds__(NWV * 64) void roi_pool7_walk_kernel(RoiParams p) {
   typedef int cellv __attribute__((ext_vector_type(VD)));
-  constexpr int CB = VD * 4, CH = VD * 2, NT = NWV * 64, RPS = 64 / NWV, RPW = RPS * NSG;
+  constexpr int CB = VD * 4, CH = VD * 2, NT = NWV * 64, G = 64 * NSG;
   constexpr int UNR = 4, UNRH = VD == 2 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = p.H * p.W;
-  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int Wp = p.walk_wp;  // LDS row pitch in cells
   const int ncg = p.C / (CH * p.walk);  // chunk groups
   const int ngroups = gridDim.x / ncg;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);
-  // chunk-group major: the blocks of one XCD share few slices (L2: 32 CUs x 2 blocks x one 60-KB slice would be 4 MB)
+  // chunk-group major: the blocks of one XCD share few slices
   const int cg = logical / ngroups, group = logical - cg * ngroups;
-  const int ph = lane / 7, pw = lane - ph * 7;
+  const int ph = lane / 7, pw = lane - ph * 7;  // (lanes 49..63: ph = 7 / 8 / 9 -> the table's entry 7, an empty row)
   const bool is_bin = lane < 49;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
-  const unsigned WCB = (unsigned)p.W * CB;
-  const int m0 = group * (64 * NSG);
-  // ---- once per block: the windows of this wave's ROIs -------------------------------------------------------------------
-  unsigned s_row[RPW], s_col[RPW], s_uni[RPW];
-  float s_mul[RPW];
-  int vimg[NSG];
+  const unsigned WCB = (unsigned)Wp * CB;
+  unsigned* tab = (unsigned*)(smem + (size_t)p.H * Wp * CB);
+  unsigned* ctr = tab + G * WALK_TAB;
+  const int m0 = group * G;
+  // ---- once per block: the window table ---------------------------------------------------------------------------------
+  for (int t = tid; t < G * 8; t += NT) {
+    const int rl = t >> 3, e = t & 7;
+    const int m = m0 + rl;
+    unsigned rowe = 0x80000000u, cole = 0x80000000u;
+    int nh = 0, nw = 0;
+    float mul = 1.f;
+    if (m < p.M && e < 7) {
+      const float* roi = p.rois + 5 * (long)m;
+      const int x1 = (int)roundf(roi[1] * p.scale), y1 = (int)roundf(roi[2] * p.scale);
+      const int x2 = (int)roundf(roi[3] * p.scale), y2 = (int)roundf(roi[4] * p.scale);
+      mul = p.obj ? p.obj[m] + 1.f : 1.f;
+      const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+      const float bin_h = (float)rh / 7.f, bin_w = (float)rw / 7.f;
+      const int hs = min(max((int)floorf((float)e * bin_h) + y1, 0), p.H);
+      const int he = min(max((int)ceilf((float)(e + 1) * bin_h) + y1, 0), p.H);
+      const int ws = min(max((int)floorf((float)e * bin_w) + x1, 0), p.W);
+      const int we = min(max((int)ceilf((float)(e + 1) * bin_w) + x1, 0), p.W);
+      nh = max(he - hs, 0);
+      nw = max(we - ws, 0);
+      // (an empty row / column of bins reads some valid pixel and drops it)
+      rowe = (unsigned)min(hs, p.H - 1) * WCB | (unsigned)max(nh - 1, 0) << 20 | (nh == 0 ? 0x80000000u : 0u);
+      cole = (unsigned)min(ws, p.W - 1) * CB | (unsigned)max(nw - 1, 0) << 20 | (nw == 0 ? 0x80000000u : 0u);
+    }
+    // the ROI's largest window: over its 8 entries = 8 consecutive lanes
+#pragma unroll
+    for (int d = 1; d < 8; d <<= 1) {
+      nh = max(nh, __shfl_xor(nh, d, 64));
+      nw = max(nw, __shfl_xor(nw, d, 64));
+    }
+    tab[rl * WALK_TAB + e] = rowe;
+    tab[rl * WALK_TAB + 8 + e] = cole;
+    if (e == 0) {
+      tab[rl * WALK_TAB + 16] = (unsigned)nh | (unsigned)nw << 16;
+      tab[rl * WALK_TAB + 17] = __builtin_bit_cast(unsigned, mul);
+    }
+  }
+  // image runs of every sub-group, as a bit mask of run ends (one run in all but ragged batches)
+  int vimg[NSG], nrs[NSG];
   unsigned long long runs[NSG];
-  int nrs[NSG];
 #pragma unroll
   for (int sg = 0; sg < NSG; ++sg) {
     const int ms = m0 + sg * 64;
     const int nr = max(min(64, p.M - ms), 0);
     nrs[sg] = nr;
-    int vx1 = 0, vy1 = 0, vx2 = 0, vy2 = 0;
-    float vmul = 1.f;
-    vimg[sg] = -1;
-    if (lane < nr) {
-      const float* roi = p.rois + 5 * (long)(ms + lane);
-      vimg[sg] = (int)roi[0];
-      vx1 = (int)roundf(roi[1] * p.scale);
-      vy1 = (int)roundf(roi[2] * p.scale);
-      vx2 = (int)roundf(roi[3] * p.scale);
-      vy2 = (int)roundf(roi[4] * p.scale);
-      vmul = p.obj ? p.obj[ms + lane] + 1.f : 1.f;
-    }
+    vimg[sg] = lane < nr ? (int)p.rois[5 * (long)(ms + lane)] : -1;
     const int nxt = __shfl_down(vimg[sg], 1, 64);
     runs[sg] = __ballot(lane < nr && (lane + 1 >= nr || nxt != vimg[sg]));
-#pragma unroll
-    for (int q = 0; q < RPS; ++q) {
-      const int j = sg * RPS + q;
-      const int r = wave + NWV * q;
-      s_row[j] = s_col[j] = s_uni[j] = 0;
-      s_mul[j] = 1.f;
-      if (r < nr) {
-        const int x1 = __builtin_amdgcn_readlane(vx1, r), y1 = __builtin_amdgcn_readlane(vy1, r);
-        const int x2 = __builtin_amdgcn_readlane(vx2, r), y2 = __builtin_amdgcn_readlane(vy2, r);
-        s_mul[j] = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, vmul), r));
-        const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
-        const float bin_h = (float)rh / 7.f, bin_w = (float)rw / 7.f;
-        const int hs = min(max((int)floorf((float)ph * bin_h) + y1, 0), p.H);
-        const int he = min(max((int)ceilf((float)(ph + 1) * bin_h) + y1, 0), p.H);
-        const int ws = min(max((int)floorf((float)pw * bin_w) + x1, 0), p.W);
-        const int we = min(max((int)ceilf((float)(pw + 1) * bin_w) + x1, 0), p.W);
-        const bool empty = he <= hs || we <= ws;
-        const int nh = (is_bin && !empty) ? he - hs : 0, nw = (is_bin && !empty) ? we - ws : 0;
-        int max_nh = 0, max_nw = 0;  // the wave's largest window (uniform)
-        while (__ballot(max_nh < nh) != 0) ++max_nh;
-        while (__ballot(max_nw < nw) != 0) ++max_nw;
-        // a lane without a window (empty bin, lanes 49..63) reads some valid pixel and drops it
-        s_row[j] = (unsigned)min(hs, p.H - 1) * WCB | (unsigned)max(nh - 1, 0) << 20;
-        s_col[j] = (unsigned)min(ws, p.W - 1) * CB | (unsigned)max(nw - 1, 0) << 20 | (empty ? 0x80000000u : 0u);
-        s_uni[j] = (unsigned)max_nh | (unsigned)max_nw << 16;
-      }
-    }
   }
   // ---- the walk -----------------------------------------------------------------------------------------------------------
+  // one image in the whole group (every batch but ragged ones): the NEXT chunk's slice is fetched into registers under this
+  // chunk's scan - two blocks of a CU start together and run the same phases, so without it both stage (the memory pipe busy,
+  // VALU idle) and both scan (the reverse) at the same time
+  bool single = true;
+#pragma unroll
+  for (int sg = 0; sg < NSG; ++sg)
+    single = single && __ballot(lane < nrs[sg] && vimg[sg] != __builtin_amdgcn_readlane(vimg[0], 0)) == 0;
+  cellv pf[SB];
+  auto load_slice = [&](int b, int chunk) {
+    const char* fb = p.feat + ((long)b * HW * p.C + (long)chunk * CH) * 2;
+    // (no branch around a load or a write, not even a uniform one: the wait-count pass then puts s_waitcnt vmcnt(0) in front of
+    // every load; a thread past the end re-reads / re-writes the last cell)
+#pragma unroll
+    for (int k = 0; k < SB; ++k) pf[k] = *(const cellv*)(fb + (long)min(tid + k * NT, HW - 1) * p.C * 2);
+  };
+  auto write_slice = [&]() {
+#pragma unroll
+    for (int k = 0; k < SB; ++k) {
+      cellv x = pf[k];
+#pragma unroll
+      for (int e = 0; e < VD; ++e) x[e] = bf16x2_order(x[e]);
+      const unsigned px = (unsigned)min(tid + k * NT, HW - 1), py = __umulhi(px, p.walk_wmagic);  // px / W
+      *(cellv*)(smem + (size_t)(py * Wp + (px - py * p.W)) * CB) = x;
+    }
+  };
+  if (single && nrs[0] > 0) load_slice(__builtin_amdgcn_readlane(vimg[0], 0), cg * p.walk);
   bool staged = false;
   for (int cc = 0; cc < p.walk; ++cc) {
     const int chunk = cg * p.walk + cc;
@@ -1233,79 +1263,76 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_walk_kernel(RoiParams p) {
       for (int r0 = 0; r0 < nr;) {
         const int b = __builtin_amdgcn_readlane(vimg[sg], r0);
         const int r1 = r0 + __builtin_ctzll(runs[sg] >> r0) + 1;
-        if (b != cur_img) {
-          if (staged) {
-            // every wave is done with the previous slice: its LDS reads have returned (their data went into the stores).  A raw
-            // barrier - __syncthreads() would also drain the A stores just issued (vmcnt)
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-          }
-          const char* fb = p.feat + ((long)b * HW * p.C + (long)chunk * CH) * 2;
-          constexpr int SB = 8;  // loads in flight per thread
-          for (int base = tid; base < HW; base += NT * SB) {
-            cellv x[SB];
-#pragma unroll
-            for (int k = 0; k < SB; ++k) x[k] = *(const cellv*)(fb + (long)min(base + k * NT, HW - 1) * p.C * 2);
-#pragma unroll
-            for (int k = 0; k < SB; ++k) {
-#pragma unroll
-              for (int e = 0; e < VD; ++e) x[k][e] = bf16x2_order(x[k][e]);
-              if (base + k * NT < HW) *(cellv*)(smem + (long)(base + k * NT) * CB) = x[k];
-            }
-          }
+        // every wave is done with the previous run (slice and counter): its LDS reads have returned (their data went into the
+        // stores).  Raw barriers - __syncthreads() would also drain the A stores just issued (vmcnt)
+        if (staged) {
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
-          staged = true;
-          cur_img = b;
         }
+        if (tid == 0) *ctr = (unsigned)r0;
+        bool fresh = false;
+        if (b != cur_img) {
+          if (!single) load_slice(b, chunk);
+          write_slice();
+          cur_img = b;
+          fresh = true;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        staged = true;
+        if (single && fresh && cc + 1 < p.walk) load_slice(b, chunk + 1);
+        // ROIs r0 .. r1-1 of this sub-group, taken from the counter one ahead of the one being scanned
+        unsigned nxt = 0;
+        if (lane == 0) nxt = atomicAdd(ctr, 1u);
+        for (;;) {
+          const int r = __builtin_amdgcn_readfirstlane(nxt);
+          if (r >= r1) break;
+          if (lane == 0) nxt = atomicAdd(ctr, 1u);
+          const unsigned* te = tab + (sg * 64 + r) * WALK_TAB;
+          const unsigned rowe = te[ph > 7 ? 7 : ph], cole = te[8 + pw];
+          const unsigned uni = __builtin_amdgcn_readfirstlane(te[16]);
+          const float mul = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(te[17]));
+          const int max_nh = uni & 0xffff, max_nw = uni >> 16;
+          const unsigned nhm1 = rowe >> 20 & 0x7ff, nwm1 = cole >> 20 & 0x7ff;
+          const unsigned org = lds0 + (rowe & 0xfffff) + (cole & 0xfffff);
+          const bool empty = (int)(rowe | cole) < 0;
+          const int lo = (int)0x80008000u;
+          cellv acc;
 #pragma unroll
-        for (int q = 0; q < RPS; ++q) {
-          const int j = sg * RPS + q;
-          const int r = wave + NWV * q;
-          if (r >= r0 && r < r1) {
-            const unsigned uni = __builtin_amdgcn_readfirstlane(s_uni[j]);
-            const int max_nh = uni & 0xffff, max_nw = uni >> 16;
-            const unsigned nhm1 = s_row[j] >> 20, nwm1 = s_col[j] >> 20 & 0x7ff;
-            const unsigned org = lds0 + (s_row[j] & 0xfffff) + (s_col[j] & 0xfffff);
-            const bool empty = (int)s_col[j] < 0;
-            const int lo = (int)0x80008000u;
-            cellv acc;
+          for (int e = 0; e < VD; ++e) acc[e] = lo;
+          for (int hi = 0; hi < max_nh; hi += UNRH) {
+            unsigned arow[UNRH];
 #pragma unroll
-            for (int e = 0; e < VD; ++e) acc[e] = lo;
-            for (int hi = 0; hi < max_nh; hi += UNRH) {
-              unsigned arow[UNRH];
+            for (int v = 0; v < UNRH; ++v) arow[v] = org + min((unsigned)(hi + v), nhm1) * WCB;
+            for (int wi = 0; wi < max_nw; wi += UNR) {
+              cellv x[UNRH][UNR];
 #pragma unroll
-              for (int v = 0; v < UNRH; ++v) arow[v] = org + min((unsigned)(hi + v), nhm1) * WCB;
-              for (int wi = 0; wi < max_nw; wi += UNR) {
-                cellv x[UNRH][UNR];
-#pragma unroll
-                for (int u = 0; u < UNR; ++u) {
-                  const unsigned co = min((unsigned)(wi + u), nwm1) * CB;
-#pragma unroll
-                  for (int v = 0; v < UNRH; ++v)
-                    x[v][u] = *(__attribute__((address_space(3))) const cellv*)(uintptr_t)(arow[v] + co);
-                }
+              for (int u = 0; u < UNR; ++u) {
+                const unsigned co = min((unsigned)(wi + u), nwm1) * CB;
 #pragma unroll
                 for (int v = 0; v < UNRH; ++v)
-#pragma unroll
-                  for (int u = 0; u < UNR; ++u)
-#pragma unroll
-                    for (int e = 0; e < VD; ++e) acc[e] = pk_max_i16(acc[e], x[v][u][e]);
+                  x[v][u] = *(__attribute__((address_space(3))) const cellv*)(uintptr_t)(arow[v] + co);
               }
+#pragma unroll
+              for (int v = 0; v < UNRH; ++v)
+#pragma unroll
+                for (int u = 0; u < UNR; ++u)
+#pragma unroll
+                  for (int e = 0; e < VD; ++e) acc[e] = pk_max_i16(acc[e], x[v][u][e]);
             }
-            if (is_bin) {
-              bf16_t* dst = (bf16_t*)p.out + (long)(m0 + sg * 64 + r) * p.ld_out + (long)chunk * CH * 49 + lane;
-              const float mul = s_mul[j];
+          }
+          if (is_bin) {
+            bf16_t* dst = (bf16_t*)p.out + (long)(m0 + sg * 64 + r) * p.ld_out + (long)chunk * CH * 49 + lane;
 #pragma unroll
-              for (int e = 0; e < VD; ++e) {
-                const uint32_t y = empty ? 0u : (uint32_t)bf16x2_order(acc[e]);
-                typedef float f32x2_t __attribute__((ext_vector_type(2)));
-                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-                const f32x2_t f = f32x2_t{__builtin_bit_cast(float, y << 16), __builtin_bit_cast(float, y & 0xffff0000u)} * mul;
-                const uint32_t o = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
-                dst[(2 * e) * 49] = (bf16_t)(o & 0xffffu);
-                dst[(2 * e + 1) * 49] = (bf16_t)(o >> 16);
-              }
+            for (int e = 0; e < VD; ++e) {
+              // (an empty bin is +0 in both halves; one packed conversion - v_cvt_pk_bf16_f32, RNE like f32_to_bf16)
+              const uint32_t y = empty ? 0u : (uint32_t)bf16x2_order(acc[e]);
+              typedef float f32x2_t __attribute__((ext_vector_type(2)));
+              typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+              const f32x2_t f = f32x2_t{__builtin_bit_cast(float, y << 16), __builtin_bit_cast(float, y & 0xffff0000u)} * mul;
+              const uint32_t o = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+              dst[(2 * e) * 49] = (bf16_t)(o & 0xffffu);
+              dst[(2 * e + 1) * 49] = (bf16_t)(o >> 16);
             }
           }
         }
@@ -1328,6 +1355,7 @@ static int roi_lane_chunks(int H, int W, int C) {
   return 0;
 }
 
+static int g_roi_walk_nsg = 2;  // (experiment) sub-groups of 64 ROIs per block of the walking kernel on one-block-per-CU maps
 static int g_roi_lane_reps = 0;  // drn_tune(DRN_TUNE_ROI_LANE_REPS = 22): groups per block on one-block-per-CU maps (0 = default: 4, fewer while < 2 rounds of blocks)
 static int cu_count_pool_fwd();
 static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
@@ -1354,6 +1382,52 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
         hipFuncSetAttribute((const void*)roi_pool7_lane_kernel<1, 8, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
       return false;
     attr = true;
+  }
+  if (nck == 1 && vd == 4 && g_roi_lane != 2 && p.W >= 2) {
+    // one chunk per block: the walking kernel
+    static bool wattr = false;
+    if (!wattr) {
+      const void* fs[] = {(const void*)roi_pool7_walk_kernel<8, 1, 4, 5>,  (const void*)roi_pool7_walk_kernel<8, 1, 4, 8>,
+                          (const void*)roi_pool7_walk_kernel<8, 1, 4, 10>, (const void*)roi_pool7_walk_kernel<16, 1, 4, 6>,
+                          (const void*)roi_pool7_walk_kernel<16, 1, 4, 10>, (const void*)roi_pool7_walk_kernel<16, 2, 4, 6>,
+                          (const void*)roi_pool7_walk_kernel<16, 2, 4, 10>};
+      for (const void* f : fs)
+        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+      wattr = true;
+    }
+    const size_t lds_max = 160 * 1024;
+    int wp = p.W | 1;
+    auto need = [&](int nsg_, int wp_) { return (size_t)p.H * wp_ * 16 + (size_t)64 * nsg_ * WALK_TAB * 4 + 16; };
+    if (need(1, wp) > lds_max) wp = p.W;
+    if (need(1, wp) > lds_max) return false;
+    const bool big1 = need(1, wp) > 80 * 1024;  // one block per CU: 16 waves
+    const int nsg = big1 && g_roi_walk_nsg == 2 && need(2, wp) <= lds_max ? 2 : 1;
+    const size_t wsmem = need(nsg, wp);
+    const int ngr = (p.M + 64 * nsg - 1) / (64 * nsg);
+    const int nchunks = p.C / 8;
+    int walk = g_roi_lane_reps > 0 ? g_roi_lane_reps : 8;
+    // (default: halved while the grid would leave more than ~15 % of the block slots of one round empty)
+    const long slots = (long)cu_count_pool_fwd() * (big1 ? 1 : wsmem > 53 * 1024 ? 2 : 3);
+    while (walk > 1 && (nchunks % walk != 0 || (g_roi_lane_reps <= 0 && (long)ngr * (nchunks / walk) * 20 < slots * 17))) walk >>= 1;
+    p.walk = walk;
+    p.walk_wp = wp;
+    p.walk_wmagic = (unsigned)((0x100000000ull + (unsigned)p.W - 1) / (unsigned)p.W);
+    p.out_t = nullptr;
+    const dim3 wgrid((unsigned)ngr * (nchunks / walk)), wblock(big1 ? 1024 : 512);
+    const int cells = p.H * p.W, nt = big1 ? 1024 : 512, sb = (cells + nt - 1) / nt;
+    if (sb > 10) return false;
+    if (!big1) {
+      if (sb <= 5) hipLaunchKernelGGL((roi_pool7_walk_kernel<8, 1, 4, 5>), wgrid, wblock, wsmem, st, p);
+      else if (sb <= 8) hipLaunchKernelGGL((roi_pool7_walk_kernel<8, 1, 4, 8>), wgrid, wblock, wsmem, st, p);
+      else hipLaunchKernelGGL((roi_pool7_walk_kernel<8, 1, 4, 10>), wgrid, wblock, wsmem, st, p);
+    } else if (nsg == 2) {
+      if (sb <= 6) hipLaunchKernelGGL((roi_pool7_walk_kernel<16, 2, 4, 6>), wgrid, wblock, wsmem, st, p);
+      else hipLaunchKernelGGL((roi_pool7_walk_kernel<16, 2, 4, 10>), wgrid, wblock, wsmem, st, p);
+    } else {
+      if (sb <= 6) hipLaunchKernelGGL((roi_pool7_walk_kernel<16, 1, 4, 6>), wgrid, wblock, wsmem, st, p);
+      else hipLaunchKernelGGL((roi_pool7_walk_kernel<16, 1, 4, 10>), wgrid, wblock, wsmem, st, p);
+    }
+    return true;
   }
   // ROIs per block: 32 (four per wave) - the staging of the slice is then ~1/8 of the block's output bytes at 14x14; large
   // maps (one chunk of 60+ KB per block) take 64 so that the slice is staged half as often
@@ -1591,7 +1665,8 @@ __attribute__((visibility("hidden"))) int drn_roi_set_lane_reps(int reps) {
 }
 __attribute__((visibility("hidden"))) int drn_roi_set_lane(int on) {
   const int old = g_roi_lane;
-  g_roi_lane = on < 0 ? 0 : on > 2 ? 2 : on;
+  g_roi_walk_nsg = on == 3 ? 1 : 2;
+  g_roi_lane = on < 0 ? 0 : on == 3 ? 1 : on > 2 ? 2 : on;
   return old;
 }
 

@@ -745,7 +745,8 @@ def test_roi_pool_transposed_tail_hint(drn, C, H, W, R, t0):
 @pytest.mark.parametrize("C,H,W,R,t0,n_img", [(1024, 14, 14, 2000, 1003, 1), (128, 14, 14, 83, 117, 3), (64, 28, 28, 200, 58, 2),
                                               (128, 50, 76, 300, 120, 2), (16, 63, 92, 130, 15, 2), (24, 40, 37, 65, 22, 4),
                                               (16, 75, 122, 130, 15, 2), (64, 14, 14, 100, 0, 2),
-                                              (64, 99, 151, 140, 58, 2)])  # the DC5 stride-8 map of an 800x1216 image: 4-channel LDS cells
+                                              (64, 99, 151, 140, 58, 2),  # the DC5 stride-8 map of an 800x1216 image: 4-channel LDS cells
+                                              (128, 63, 92, 300, 120, 3), (64, 43, 58, 150, 58, 3)])  # walking kernel, ragged image runs
 def test_roi_pool_lane_kernel_equals_map64(drn, C, H, W, R, t0, n_img):
     """Round 4: the lane-per-bin kernel (a wave per ROI, lane = bin, every channel one 98-byte store run; DRN_TUNE_ROI_LANE)
     writes the bf16 training operand A; the 64-ROI kernel keeps only the A^T tail.  Against the 64-ROI kernel alone and
@@ -759,8 +760,13 @@ def test_roi_pool_lane_kernel_equals_map64(drn, C, H, W, R, t0, n_img):
     fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
     k = C * P * P
     res = {}
-    for lane in (2, 1, 0):  # 2: also for maps that leave one block per CU (default 1 hands most of those to the 64-ROI kernel)
+    # 1: default - maps with one chunk per block take the WALKING kernel (round 5: a window table per block, ROIs from a shared
+    # counter, the block walks consecutive chunks); 3: the same with 64 instead of 128 ROIs per block on one-block-per-CU maps and
+    # 8 chunks per block forced (the default shortens the walk on grids as small as a test's); 2: the round-4 kernel for those
+    # maps; 0: the 64-ROI kernel
+    for lane in (3, 2, 1, 0):
         old = drn.tune(19, lane)
+        old22 = drn.tune(22, 8) if lane == 3 else None
         try:
             a = torch.full((R, drn.kpad(k, dtype)), 3.0, dtype=dtype, device=DEV)
             a[:, k:] = 0
@@ -770,9 +776,11 @@ def test_roi_pool_lane_kernel_equals_map64(drn, C, H, W, R, t0, n_img):
             res[lane] = (a, t)
         finally:
             drn.tune(19, old)
+            if old22 is not None:
+                drn.tune(22, old22)
     ref, _ = O.roi_pool_forward(_q(feat, dtype), rois, P, scale)
     ref = _q(ref * (obj + 1).view(-1, 1, 1, 1), dtype).reshape(R, -1)
-    for lane in (2, 1):
+    for lane in (3, 2, 1):
         assert torch.equal(res[lane][0], res[0][0]), lane
         assert torch.equal(res[lane][0][:, :k].float().cpu(), ref), lane
         assert torch.equal(res[lane][1][t0 * 49:, :R], res[lane][0][:, t0 * 49: k].t()), lane
