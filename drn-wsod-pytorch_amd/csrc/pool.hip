@@ -1160,6 +1160,8 @@ template <int NWV, int NSG, int VD, int SB>  // SB: slice cells per thread (>= c
 __global__ __launch_bounds__(NWV * 64) void roi_pool7_walk_kernel(RoiParams p) {
   typedef int cellv __attribute__((ext_vector_type(VD)));
   constexpr int CB = VD * 4, CH = VD * 2, NT = NWV * 64, G = 64 * NSG;
+  // (two window rows per trip - eight reads in flight - measured slower for 8-channel cells: 187 vs 174 us at 50x76, the rows are
+  // rounded up to pairs)
   constexpr int UNR = 4, UNRH = VD == 2 ? 2 : 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int HW = p.H * p.W;
@@ -1321,6 +1323,9 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_walk_kernel(RoiParams p) {
                   for (int e = 0; e < VD; ++e) acc[e] = pk_max_i16(acc[e], x[v][u][e]);
             }
           }
+          // (built and measured: the item's 8 x 49 values - one 784-byte run of A - through a per-wave LDS scratch as ONE 16-byte store
+          // per lane instead of eight 2-byte stores: 176.0 vs 173.8 us at 50x76, 137 vs 125 at 43x58 (the scratch costs the third
+          // block per CU) - eight ds_write_b16 + a ds_read_b128 take the issue slots the eight stores took)
           if (is_bin) {
             bf16_t* dst = (bf16_t*)p.out + (long)(m0 + sg * 64 + r) * p.ld_out + (long)chunk * CH * 49 + lane;
 #pragma unroll
@@ -1355,7 +1360,7 @@ static int roi_lane_chunks(int H, int W, int C) {
   return 0;
 }
 
-static int g_roi_walk_nsg = 2;  // (experiment) sub-groups of 64 ROIs per block of the walking kernel on one-block-per-CU maps
+static int g_roi_walk_nsg = 2;  // sub-groups of 64 ROIs per block of the walking kernel on one-block-per-CU maps (tests: DRN_TUNE_ROI_LANE = 3 -> 1)
 static int g_roi_lane_reps = 0;  // drn_tune(DRN_TUNE_ROI_LANE_REPS = 22): groups per block on one-block-per-CU maps (0 = default: 4, fewer while < 2 rounds of blocks)
 static int cu_count_pool_fwd();
 static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
@@ -1383,12 +1388,13 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
       return false;
     attr = true;
   }
-  if (nck == 1 && vd == 4 && g_roi_lane != 2 && p.W >= 2) {
+  if (nck == 1 && vd == 4 && g_roi_lane != 2 && p.W >= 2 && (size_t)p.H * p.W * 16 + 64 * WALK_TAB * 4 + 16 <= 160 * 1024 &&
+      (p.H * p.W + 1023) / 1024 <= 10) {
     // one chunk per block: the walking kernel
     static bool wattr = false;
     if (!wattr) {
-      const void* fs[] = {(const void*)roi_pool7_walk_kernel<8, 1, 4, 5>,  (const void*)roi_pool7_walk_kernel<8, 1, 4, 8>,
-                          (const void*)roi_pool7_walk_kernel<8, 1, 4, 10>, (const void*)roi_pool7_walk_kernel<16, 1, 4, 6>,
+      const void* fs[] = {(const void*)roi_pool7_walk_kernel<8, 1, 4, 5>,   (const void*)roi_pool7_walk_kernel<8, 1, 4, 8>,
+                          (const void*)roi_pool7_walk_kernel<8, 1, 4, 10>,  (const void*)roi_pool7_walk_kernel<16, 1, 4, 6>,
                           (const void*)roi_pool7_walk_kernel<16, 1, 4, 10>, (const void*)roi_pool7_walk_kernel<16, 2, 4, 6>,
                           (const void*)roi_pool7_walk_kernel<16, 2, 4, 10>};
       for (const void* f : fs)
@@ -1396,26 +1402,36 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
       wattr = true;
     }
     const size_t lds_max = 160 * 1024;
-    int wp = p.W | 1;
+    // slice + window table + counter
     auto need = [&](int nsg_, int wp_) { return (size_t)p.H * wp_ * 16 + (size_t)64 * nsg_ * WALK_TAB * 4 + 16; };
-    if (need(1, wp) > lds_max) wp = p.W;
-    if (need(1, wp) > lds_max) return false;
-    const bool big1 = need(1, wp) > 80 * 1024;  // one block per CU: 16 waves
-    const int nsg = big1 && g_roi_walk_nsg == 2 && need(2, wp) <= lds_max ? 2 : 1;
+    const bool big1 = need(1, p.W | 1) > 80 * 1024;  // one block per CU: 16 waves
+    // the largest maps: first the odd pitch goes, then the second sub-group of ROIs
+    int wp = p.W | 1, nsg = big1 && g_roi_walk_nsg == 2 ? 2 : 1;
+    if (need(nsg, wp) > lds_max) wp = p.W;
+    if (need(nsg, wp) > lds_max) nsg = 1;
     const size_t wsmem = need(nsg, wp);
     const int ngr = (p.M + 64 * nsg - 1) / (64 * nsg);
     const int nchunks = p.C / 8;
-    int walk = g_roi_lane_reps > 0 ? g_roi_lane_reps : 8;
-    // (default: halved while the grid would leave more than ~15 % of the block slots of one round empty)
-    const long slots = (long)cu_count_pool_fwd() * (big1 ? 1 : wsmem > 53 * 1024 ? 2 : 3);
-    while (walk > 1 && (nchunks % walk != 0 || (g_roi_lane_reps <= 0 && (long)ngr * (nchunks / walk) * 20 < slots * 17))) walk >>= 1;
+    // chunks per block: 8 (the pieces of one 128-byte line per pixel) unless fewer fill the rounds of blocks better - a VALU-bound
+    // block per CU (two of the 8-wave blocks), so a grid of 1.5 rounds takes the time of 2 (75x122 / R = 1500: 12 groups x 16
+    // chunk groups = 192 blocks: 244 us; 2 chunks per block = 768 blocks = 3 rounds: 204 us, profiles/r5_40_roi_walk_big.txt)
+    const long slots = (long)cu_count_pool_fwd() * (big1 ? 1 : 2);
+    int walk = 1;
+    double best = -1.0;
+    for (int w = 8, lg = 0; w >= 1; w >>= 1, ++lg) {
+      if (nchunks % w != 0) continue;
+      if (g_roi_lane_reps > 0 && w > g_roi_lane_reps) continue;
+      const long grid = (long)ngr * (nchunks / w);
+      const double score = (double)grid / (double)((grid + slots - 1) / slots * slots) * (1.0 - 0.015 * lg);
+      if (g_roi_lane_reps > 0) { walk = w; break; }  // (knob: the largest admissible walk <= its value)
+      if (score > best) best = score, walk = w;
+    }
     p.walk = walk;
     p.walk_wp = wp;
     p.walk_wmagic = (unsigned)((0x100000000ull + (unsigned)p.W - 1) / (unsigned)p.W);
     p.out_t = nullptr;
     const dim3 wgrid((unsigned)ngr * (nchunks / walk)), wblock(big1 ? 1024 : 512);
     const int cells = p.H * p.W, nt = big1 ? 1024 : 512, sb = (cells + nt - 1) / nt;
-    if (sb > 10) return false;
     if (!big1) {
       if (sb <= 5) hipLaunchKernelGGL((roi_pool7_walk_kernel<8, 1, 4, 5>), wgrid, wblock, wsmem, st, p);
       else if (sb <= 8) hipLaunchKernelGGL((roi_pool7_walk_kernel<8, 1, 4, 8>), wgrid, wblock, wsmem, st, p);
