@@ -1156,8 +1156,8 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
 // Same maxima over the same pixels, same scaling / conversion as the kernels above: bit-identical outputs.
 // NSG: sub-groups of 64 ROIs per block (image indices of a sub-group sit in the lanes of every wave).
 constexpr int WALK_TAB = 18;  // table dwords per ROI: [0..7] rows by ph, [8..15] columns by pw, [16] largest window, [17] scale
-template <int NWV, int NSG, int VD, int SB>  // SB: slice cells per thread (>= ceil(H * W / threads))
-__global__ __launch_bounds__(NWV * 64) void roi_pool7_walk_kernel(RoiParams p) {
+template <int NWV, int NSG, int VD, int SB, int OCC = 1>  // SB: slice cells per thread (>= ceil(H * W / threads)); OCC: blocks per CU the registers must allow
+__global__ __launch_bounds__(NWV * 64, OCC) void roi_pool7_walk_kernel(RoiParams p) {
   typedef int cellv __attribute__((ext_vector_type(VD)));
   constexpr int CB = VD * 4, CH = VD * 2, NT = NWV * 64, G = 64 * NSG;
   // (two window rows per trip - eight reads in flight - measured slower for 8-channel cells: 187 vs 174 us at 50x76, the rows are
@@ -1391,22 +1391,13 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
   if (nck == 1 && vd == 4 && g_roi_lane != 2 && p.W >= 2 && (size_t)p.H * p.W * 16 + 64 * WALK_TAB * 4 + 16 <= 160 * 1024 &&
       (p.H * p.W + 1023) / 1024 <= 10) {
     // one chunk per block: the walking kernel
-    static bool wattr = false;
-    if (!wattr) {
-      const void* fs[] = {(const void*)roi_pool7_walk_kernel<8, 1, 4, 5>,   (const void*)roi_pool7_walk_kernel<8, 1, 4, 8>,
-                          (const void*)roi_pool7_walk_kernel<8, 1, 4, 10>,  (const void*)roi_pool7_walk_kernel<16, 1, 4, 6>,
-                          (const void*)roi_pool7_walk_kernel<16, 1, 4, 10>, (const void*)roi_pool7_walk_kernel<16, 2, 4, 6>,
-                          (const void*)roi_pool7_walk_kernel<16, 2, 4, 10>};
-      for (const void* f : fs)
-        if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
-      wattr = true;
-    }
     const size_t lds_max = 160 * 1024;
     // slice + window table + counter
     auto need = [&](int nsg_, int wp_) { return (size_t)p.H * wp_ * 16 + (size_t)64 * nsg_ * WALK_TAB * 4 + 16; };
     const bool big1 = need(1, p.W | 1) > 80 * 1024;  // one block per CU: 16 waves
     // the largest maps: first the odd pitch goes, then the second sub-group of ROIs
-    int wp = p.W | 1, nsg = big1 && g_roi_walk_nsg == 2 ? 2 : 1;
+    // 128 ROIs per block (64 with DRN_TUNE_ROI_LANE = 3, for tests) where the table fits: half the stagings and barriers per item
+    int wp = p.W | 1, nsg = g_roi_walk_nsg == 2 && (big1 || need(2, wp) <= 80 * 1024) ? 2 : 1;
     if (need(nsg, wp) > lds_max) wp = p.W;
     if (need(nsg, wp) > lds_max) nsg = 1;
     const size_t wsmem = need(nsg, wp);
@@ -1430,19 +1421,26 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
     p.walk_wp = wp;
     p.walk_wmagic = (unsigned)((0x100000000ull + (unsigned)p.W - 1) / (unsigned)p.W);
     p.out_t = nullptr;
-    const dim3 wgrid((unsigned)ngr * (nchunks / walk)), wblock(big1 ? 1024 : 512);
-    const int cells = p.H * p.W, nt = big1 ? 1024 : 512, sb = (cells + nt - 1) / nt;
-    if (!big1) {
-      if (sb <= 5) hipLaunchKernelGGL((roi_pool7_walk_kernel<8, 1, 4, 5>), wgrid, wblock, wsmem, st, p);
-      else if (sb <= 8) hipLaunchKernelGGL((roi_pool7_walk_kernel<8, 1, 4, 8>), wgrid, wblock, wsmem, st, p);
-      else hipLaunchKernelGGL((roi_pool7_walk_kernel<8, 1, 4, 10>), wgrid, wblock, wsmem, st, p);
-    } else if (nsg == 2) {
-      if (sb <= 6) hipLaunchKernelGGL((roi_pool7_walk_kernel<16, 2, 4, 6>), wgrid, wblock, wsmem, st, p);
-      else hipLaunchKernelGGL((roi_pool7_walk_kernel<16, 2, 4, 10>), wgrid, wblock, wsmem, st, p);
+    // block shape: one block per CU -> 16 waves; two blocks per CU -> 16-wave blocks (eight waves per SIMD, <= 64 VGPRs) for slices
+    // of up to 3072 cells, else 8-wave blocks (43x58: 111.9 vs 122.5 us; 50x76: 170.6 vs 161.9 us - profiles/r5_47_roi_walk_nsg2.txt)
+    const bool w16 = !big1 && p.H * p.W <= 3072;
+    const int cells = p.H * p.W, nt = big1 || w16 ? 1024 : 512, sb = (cells + nt - 1) / nt;
+    const dim3 wgrid((unsigned)ngr * (nchunks / walk)), wblock(nt);
+    const void* fn = nullptr;
+#define WALK_PICK(NWV_, NSG_, SB_, OCC_) fn = (const void*)roi_pool7_walk_kernel<NWV_, NSG_, 4, SB_, OCC_>
+    if (w16) {
+      if (nsg == 2) WALK_PICK(16, 2, 3, 2); else WALK_PICK(16, 1, 3, 2);
+    } else if (!big1) {
+      if (nsg == 2) { if (sb <= 8) WALK_PICK(8, 2, 8, 1); else WALK_PICK(8, 2, 10, 1); }
+      else { if (sb <= 8) WALK_PICK(8, 1, 8, 1); else WALK_PICK(8, 1, 10, 1); }
     } else {
-      if (sb <= 6) hipLaunchKernelGGL((roi_pool7_walk_kernel<16, 1, 4, 6>), wgrid, wblock, wsmem, st, p);
-      else hipLaunchKernelGGL((roi_pool7_walk_kernel<16, 1, 4, 10>), wgrid, wblock, wsmem, st, p);
+      if (nsg == 2) { if (sb <= 6) WALK_PICK(16, 2, 6, 1); else WALK_PICK(16, 2, 10, 1); }
+      else { if (sb <= 6) WALK_PICK(16, 1, 6, 1); else WALK_PICK(16, 1, 10, 1); }
     }
+#undef WALK_PICK
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+    void* args[] = {(void*)&p};
+    if (hipLaunchKernel(fn, wgrid, wblock, args, wsmem, st) != hipSuccess) return false;
     return true;
   }
   // ROIs per block: 32 (four per wave) - the staging of the slice is then ~1/8 of the block's output bytes at 14x14; large
