@@ -23,6 +23,7 @@ _SIGS = {
     "drn_maxpool2x2_nhwc": "ppiiiiiip",
     "drn_roi_pool_nhwc": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiip",
     "drn_roi_pool_nhwc_t": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiiip",
+    "drn_roi_pool_nhwc_ws": "pppppp" + "iiiiii" + "f" + "ll" + "iiiiii" + "plp",
     "drn_tta_accumulate": "ppppllfffiip",
     "drn_pcl_adjacency": "pifpp",
     "drn_pcl_refine": "pipiipipppip" + "ppppppppppi" + "ppp",
@@ -102,6 +103,8 @@ def lib():
         _lib.drn_detect_workspace_bytes.restype = ctypes.c_long
         _lib.drn_gemm_nt_main_cols.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int]
         _lib.drn_gemm_nt_main_cols.restype = ctypes.c_long
+        _lib.drn_roi_pool_workspace_bytes.argtypes = [ctypes.c_int] * 10
+        _lib.drn_roi_pool_workspace_bytes.restype = ctypes.c_long
         for kv in filter(None, os.environ.get("DRN_TUNE", "").split(",")):  # A/B runs: DRN_TUNE="5=0,4=1024" (drn_tune knobs)
             k, v = kv.split("=")
             _lib.drn_tune(int(k), int(v))
@@ -109,7 +112,7 @@ def lib():
 
 
 def exported_symbols():
-    return sorted(list(_SIGS) + ["drn_detect_workspace_bytes", "drn_gemm_nt_main_cols"])
+    return sorted(list(_SIGS) + ["drn_detect_workspace_bytes", "drn_gemm_nt_main_cols", "drn_roi_pool_workspace_bytes"])
 
 
 _ERR = {-1: "invalid argument", -2: "kernel launch failure", -3: "unsupported"}

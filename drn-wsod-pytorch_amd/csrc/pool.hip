@@ -166,6 +166,7 @@ struct RoiParams {
   int lane_reps;  // lane-per-bin kernel: groups a block walks with ONE staged slice (large maps: the staging is L2 traffic ~ groups x map)
   int walk;       // walking lane-per-bin kernel: consecutive channel chunks a block walks with ONE window table of its ROIs
   int walk_wp;    // its LDS row pitch in cells (odd)
+  const char* cm;  // its chunk-major, order-mapped copy of the map ([N][C/8][H*W] cells of 16 bytes) or null
   unsigned walk_wmagic;  // ceil(2^32 / W): pixel -> row by one v_mul_hi
 };
 
@@ -1137,6 +1138,33 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
   }  // groups of this block
 }
 
+// Chunk-major copy of a bf16 NHWC map for the walking kernel below: [N][H*W][C] -> [N][C/8][H*W] cells of 16 bytes (8 channels of a
+// pixel), values already order-mapped (bf16x2_order).  A staged slice is then ONE contiguous run instead of 16 bytes of every
+// pixel's 2-KB line (64 lines per wave instruction: ~28 us of a 156-us pooling launch at 50x76 - profiles/r5_32_roi_walk_knockouts.txt).
+// 32 pixels x 32 chunks per block through LDS: 512-byte runs on both sides.
+__global__ __launch_bounds__(256) void roi_chunk_major_kernel(const char* __restrict__ feat, char* __restrict__ cm, int HW, int C) {
+  __shared__ i32x4_t tile[32][33];
+  const int nchunks = C >> 3;
+  const int px0 = blockIdx.x * 32, ch0 = blockIdx.y * 32, img = blockIdx.z;
+  const char* src = feat + (long)img * HW * C * 2;
+  char* dst = cm + (long)img * nchunks * HW * 16;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + 256 * i, pl = idx >> 5, cl = idx & 31;
+    i32x4_t x = {0, 0, 0, 0};
+    if (px0 + pl < HW && ch0 + cl < nchunks) x = *(const i32x4_t*)(src + ((long)(px0 + pl) * C + (ch0 + cl) * 8) * 2);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) x[e] = bf16x2_order(x[e]);
+    tile[pl][cl] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + 256 * i, cl = idx >> 5, pl = idx & 31;
+    if (px0 + pl < HW && ch0 + cl < nchunks) *(i32x4_t*)(dst + ((long)(ch0 + cl) * HW + px0 + pl) * 16) = tile[pl][cl];
+  }
+}
+
 // 7x7 ROIPool, lane-per-bin, WALKING variant (round 5) for maps whose 8-channel slice leaves at most two blocks per CU
 // (43x58 and larger: test-time scales, real-size training images).  Knock-outs of the kernel above at 50x76 / R = 2000
 // (profiles/r5_32_roi_walk_knockouts.txt): 71 us of its 215 are the staging (one 16-byte piece of every pixel's 2-KB line per
@@ -1237,19 +1265,23 @@ __global__ __launch_bounds__(NWV * 64, OCC) void roi_pool7_walk_kernel(RoiParams
   for (int sg = 0; sg < NSG; ++sg)
     single = single && __ballot(lane < nrs[sg] && vimg[sg] != __builtin_amdgcn_readlane(vimg[0], 0)) == 0;
   cellv pf[SB];
+  // source of a slice: the chunk-major, order-mapped copy when the caller gave a workspace (one contiguous run), else the NHWC
+  // map itself (16 bytes of every pixel's line)
+  const bool from_cm = p.cm != nullptr;
+  const long src_pitch = from_cm ? CB : (long)p.C * 2;
   auto load_slice = [&](int b, int chunk) {
-    const char* fb = p.feat + ((long)b * HW * p.C + (long)chunk * CH) * 2;
+    const char* fb = from_cm ? p.cm + ((long)b * (p.C / CH) + chunk) * HW * CB : p.feat + ((long)b * HW * p.C + (long)chunk * CH) * 2;
     // (no branch around a load or a write, not even a uniform one: the wait-count pass then puts s_waitcnt vmcnt(0) in front of
     // every load; a thread past the end re-reads / re-writes the last cell)
 #pragma unroll
-    for (int k = 0; k < SB; ++k) pf[k] = *(const cellv*)(fb + (long)min(tid + k * NT, HW - 1) * p.C * 2);
+    for (int k = 0; k < SB; ++k) pf[k] = *(const cellv*)(fb + (long)min(tid + k * NT, HW - 1) * src_pitch);
   };
   auto write_slice = [&]() {
 #pragma unroll
     for (int k = 0; k < SB; ++k) {
       cellv x = pf[k];
 #pragma unroll
-      for (int e = 0; e < VD; ++e) x[e] = bf16x2_order(x[e]);
+      for (int e = 0; e < VD; ++e) x[e] = from_cm ? x[e] : bf16x2_order(x[e]);
       const unsigned px = (unsigned)min(tid + k * NT, HW - 1), py = __umulhi(px, p.walk_wmagic);  // px / W
       *(cellv*)(smem + (size_t)(py * Wp + (px - py * p.W)) * CB) = x;
     }
@@ -1363,7 +1395,8 @@ static int roi_lane_chunks(int H, int W, int C) {
 static int g_roi_walk_nsg = 2;  // sub-groups of 64 ROIs per block of the walking kernel on one-block-per-CU maps (tests: DRN_TUNE_ROI_LANE = 3 -> 1)
 static int g_roi_lane_reps = 0;  // drn_tune(DRN_TUNE_ROI_LANE_REPS = 22): groups per block on one-block-per-CU maps (0 = default: 4, fewer while < 2 rounds of blocks)
 static int cu_count_pool_fwd();
-static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
+static bool roi_walk_applies(int H, int W, int C);
+static bool launch_roi_lane(const RoiParams& p0, hipStream_t st, void* ws = nullptr, size_t ws_bytes = 0) {
   RoiParams p = p0;
   if (!g_roi_lane || p.C % 8) return false;
   size_t per_chunk = (size_t)p.H * p.W * 16;
@@ -1388,8 +1421,7 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
       return false;
     attr = true;
   }
-  if (nck == 1 && vd == 4 && g_roi_lane != 2 && p.W >= 2 && (size_t)p.H * p.W * 16 + 64 * WALK_TAB * 4 + 16 <= 160 * 1024 &&
-      (p.H * p.W + 1023) / 1024 <= 10) {
+  if (nck == 1 && vd == 4 && g_roi_lane != 2 && roi_walk_applies(p.H, p.W, p.C)) {
     // one chunk per block: the walking kernel
     const size_t lds_max = 160 * 1024;
     // slice + window table + counter
@@ -1421,6 +1453,12 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
     p.walk_wp = wp;
     p.walk_wmagic = (unsigned)((0x100000000ull + (unsigned)p.W - 1) / (unsigned)p.W);
     p.out_t = nullptr;
+    p.cm = nullptr;
+    if (ws && ws_bytes >= (size_t)p.N * p.H * p.W * p.C * 2 && (((uintptr_t)ws) & 15) == 0) {
+      const dim3 cgrid((p.H * p.W + 31) / 32, (nchunks + 31) / 32, p.N);
+      hipLaunchKernelGGL(roi_chunk_major_kernel, cgrid, dim3(256), 0, st, p.feat, (char*)ws, p.H * p.W, p.C);
+      p.cm = (const char*)ws;
+    }
     // block shape: one block per CU -> 16 waves; two blocks per CU -> 16-wave blocks (eight waves per SIMD, <= 64 VGPRs) for slices
     // of up to 3072 cells, else 8-wave blocks (43x58: 111.9 vs 122.5 us; 50x76: 170.6 vs 161.9 us - profiles/r5_47_roi_walk_nsg2.txt)
     const bool w16 = !big1 && p.H * p.W <= 3072;
@@ -1475,6 +1513,12 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st) {
   else if (big) hipLaunchKernelGGL((roi_pool7_lane_kernel<1, 16>), grid, block, smem, st, p);
   else hipLaunchKernelGGL(roi_pool7_lane_kernel<1>, grid, block, smem, st, p);
   return true;
+}
+
+// maps the walking kernel takes: one 8-channel chunk per block (roi_lane_chunks == 1 beyond the 38-KB class) that fits with its table
+static bool roi_walk_applies(int H, int W, int C) {
+  return C % 8 == 0 && W >= 2 && roi_lane_chunks(H, W, C) == 1 &&
+         (size_t)H * W * 16 + 64 * WALK_TAB * 4 + 16 <= 160 * 1024 && (H * W + 1023) / 1024 <= 10;
 }
 
 static int cu_count_pool();
@@ -1823,6 +1867,10 @@ int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* object
                         int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
                         long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
                         int t_first_channel, void* stream);
+int drn_roi_pool_nhwc_ws(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
+                         int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
+                         long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
+                         int t_first_channel, void* workspace, long workspace_bytes, void* stream);
 
 // mode 0 = RoIPool, 1 = ROIAlign. in_dtype = feature dtype, out_dtype = pooled dtype.
 int drn_roi_pool_nhwc(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
@@ -1839,7 +1887,25 @@ int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* object
                         int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
                         long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
                         int t_first_channel, void* stream) {
+  return drn_roi_pool_nhwc_ws(feat, rois, objectness, out, out_t, argmax, N, H, W, C, P, M, spatial_scale, ld_out, ld_out_t, mode,
+                              sampling_ratio, aligned, in_dtype, out_dtype, t_first_channel, nullptr, 0, stream);
+}
+
+// Bytes of workspace with which drn_roi_pool_nhwc_ws pools this shape faster (0: the shape takes a kernel that needs none).
+long drn_roi_pool_workspace_bytes(int N, int H, int W, int C, int P, int M, int mode, int has_argmax, int in_dtype, int out_dtype) {
+  if (N < 1 || H < 1 || W < 1 || C < 1) return 0;
+  if (mode != 0 || P != 7 || has_argmax || in_dtype != DRN_BF16 || out_dtype != DRN_BF16 || M < ROI_G64 || C % G64_CH != 0) return 0;
+  return g_roi_lane != 0 && g_roi_lane != 2 && roi_walk_applies(H, W, C) ? (long)N * H * W * C * 2 : 0;
+}
+
+// The same with a caller-owned workspace (drn_roi_pool_workspace_bytes; null / too small: as without): maps whose 8-channel slice
+// leaves one chunk per block are first copied chunk-major into it, so that the walking kernel stages contiguous runs.
+int drn_roi_pool_nhwc_ws(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
+                         int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
+                         long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
+                         int t_first_channel, void* workspace, long workspace_bytes, void* stream) {
   if (!feat || !rois || !out || P < 1 || P * P > RP_MAXBIN || M < 0 || (mode != 0 && mode != 1)) return DRN_ERR_ARG;
+  if (workspace_bytes < 0) return DRN_ERR_ARG;
   if (t_first_channel < 0) return DRN_ERR_ARG;
   if (ld_out < (long)C * P * P || (out_t && ld_out_t < M)) return DRN_ERR_ARG;
   if (M == 0) return DRN_OK;
@@ -1867,7 +1933,7 @@ int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* object
         // instruction - cost 40 us for 4.7 MB at the bench shape; the 64-ROI kernel's full lines cost ~8 us as a launch)
         const int cb = out_t ? p.t_c0 / G64_CH * G64_CH : C;
         const bool few_t = !out_t || (long)(C - cb) * 8 <= C;
-        if (few_t && C % G64_CH == 0 && launch_roi_lane(p, st)) {
+        if (few_t && C % G64_CH == 0 && launch_roi_lane(p, st, workspace, (size_t)workspace_bytes)) {
           done = true;
           if (out_t && cb < C) {
             RoiParams q = p;

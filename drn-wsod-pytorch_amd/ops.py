@@ -287,6 +287,9 @@ def resize_bilinear_u8(img_hwc, new_h, new_w, flip=False, out=None):
     return out
 
 
+ROI_WORKSPACE = True  # tools / tests: False = pool without the chunk-major scratch copy (same results)
+
+
 def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, aligned=False, out=None, out_dtype=None,
                   want_argmax=False, out_t=None, t_first_channel=0):
     """feat [N,H,W,C]; rois [M,5] f32; -> out [M, ld] (first C*P*P columns valid, k = c*P*P + bin); out_t (optional,
@@ -303,9 +306,14 @@ def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, al
     if HBM_TIMING is not None:  # bench.py: HIP events on the launching stream around this launch
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    C.call("drn_roi_pool_nhwc_t", C.ptr(feat), C.ptr(rois), C.ptr(objectness), C.ptr(out), C.ptr(out_t), C.ptr(arg), n, h,
+    # scratch for the chunk-major copy of large maps (drn_roi_pool_nhwc_ws): from torch's caching allocator on the current stream,
+    # nothing is kept between calls; 0 bytes for every shape whose kernel does not use one (the bench shape among them)
+    ws_bytes = C.lib().drn_roi_pool_workspace_bytes(n, h, w, c, P, m, mode, int(want_argmax), C.dt(feat.dtype), C.dt(out.dtype))
+    ws = torch.empty((ws_bytes,), dtype=torch.uint8, device=feat.device) if ws_bytes > 0 and ROI_WORKSPACE else None
+    C.call("drn_roi_pool_nhwc_ws", C.ptr(feat), C.ptr(rois), C.ptr(objectness), C.ptr(out), C.ptr(out_t), C.ptr(arg), n, h,
            w, c, P, m, float(scale), _2d(out), _2d(out_t) if out_t is not None else 0, mode, sampling_ratio,
-           int(aligned), C.dt(feat.dtype), C.dt(out.dtype), int(t_first_channel), C.stream())
+           int(aligned), C.dt(feat.dtype), C.dt(out.dtype), int(t_first_channel), C.ptr(ws), ws_bytes if ws is not None else 0,
+           C.stream())
     if HBM_TIMING is not None:
         e1.record()
         es = esize(out.dtype)

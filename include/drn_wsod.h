@@ -139,6 +139,19 @@ int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* object
                         long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
                         int t_first_channel, void* stream);
 
+/* drn_roi_pool_nhwc_t with a caller-owned scratch buffer (round 5).  Feature maps whose 8-channel slice leaves one chunk per
+ * workgroup (43x58 cells and more: test-time scales, real-size training images; poolers.py:191-226 at those sizes) are first
+ * copied chunk-major - [N][C/8][H*W] cells of 16 bytes - into `workspace`, so that the pooling kernel stages contiguous runs
+ * instead of 16 bytes of every pixel's line (50x76 / R = 2000: 156 -> ~130 us).  drn_roi_pool_workspace_bytes returns the size
+ * that helps for a shape (0: no workspace is used); workspace NULL or smaller: exactly drn_roi_pool_nhwc_t.  The workspace
+ * is read and written on `stream` only and holds nothing between calls; results are bit-identical with and without it. */
+long drn_roi_pool_workspace_bytes(int N, int H, int W, int C, int P, int M, int mode, int has_argmax, int in_dtype,
+                                  int out_dtype);
+int drn_roi_pool_nhwc_ws(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
+                         int32_t* argmax, int N, int H, int W, int C, int P, int M, float spatial_scale, long ld_out,
+                         long ld_out_t, int mode, int sampling_ratio, int aligned, int in_dtype, int out_dtype,
+                         int t_first_channel, void* workspace, long workspace_bytes, void* stream);
+
 
 /* Backward of the above w.r.t. the feature map: torchvision RoIPool's backward (scatter to the arg-max the forward
  * returned) and roi_align_backward (detectron2/layers/csrc/ROIAlign/ROIAlign.h:93-128, ROIAlign_cuda.cu:141-250),

@@ -764,9 +764,11 @@ def test_roi_pool_lane_kernel_equals_map64(drn, C, H, W, R, t0, n_img):
     # counter, the block walks consecutive chunks); 3: the same with 64 instead of 128 ROIs per block on one-block-per-CU maps and
     # 8 chunks per block forced (the default shortens the walk on grids as small as a test's); 2: the round-4 kernel for those
     # maps; 0: the 64-ROI kernel
+    # (lane 1 pools through the chunk-major scratch copy where the walking kernel takes the map - drn_roi_pool_nhwc_ws -, lane 3 without)
     for lane in (3, 2, 1, 0):
         old = drn.tune(19, lane)
         old22 = drn.tune(22, 8) if lane == 3 else None
+        drn.ROI_WORKSPACE = lane != 3
         try:
             a = torch.full((R, drn.kpad(k, dtype)), 3.0, dtype=dtype, device=DEV)
             a[:, k:] = 0
@@ -776,6 +778,7 @@ def test_roi_pool_lane_kernel_equals_map64(drn, C, H, W, R, t0, n_img):
             res[lane] = (a, t)
         finally:
             drn.tune(19, old)
+            drn.ROI_WORKSPACE = True
             if old22 is not None:
                 drn.tune(22, old22)
     ref, _ = O.roi_pool_forward(_q(feat, dtype), rois, P, scale)

@@ -7,8 +7,9 @@ dev = "cuda"
 for kv in sys.argv[1:]:  # tune knobs: 15=76 (LDS budget), 4=1024 (threads), 10=4 (chunks per block) ...
     ops.tune(*[int(x) for x in kv.split("=")])
 TAIL = os.environ.get("ROI_TAIL", "1") == "1"  # round-3 step: A + the A^T rows of channels >= 1000 (0: all of A^T)
+ops.ROI_WORKSPACE = os.environ.get("ROI_WS", "1") == "1"  # 0: without the chunk-major scratch copy (drn_roi_pool_nhwc_ws)
 ALONE = os.environ.get("ROI_A_ALONE", "0") == "1"  # A alone (no A^T): what the training step (round 4 on) and inference launch
-for (H, W, R) in ((14, 14, 2000), (43, 58, 1800), (50, 76, 2000), (63, 92, 1947), (75, 122, 1500)):
+for (H, W, R) in ((14, 14, 2000), (36, 50, 1800), (43, 58, 1800), (50, 76, 2000), (63, 92, 1947), (75, 122, 1500)):
     C = 1024
     feat = torch.randn((1, H, W, C), device=dev).to(torch.bfloat16)
     g = torch.Generator().manual_seed(0)
