@@ -21,6 +21,8 @@ from ..structures import Boxes, Instances
 
 __all__ = ["DatasetMapperTTAAVG", "GeneralizedRCNNWithTTAAVG", "resize_shortest_edge_shape"]
 
+UPLOAD_PROPOSALS_ONCE = True  # tools: False = each pass uploads its own proposals (pageable copies: a host sync per pass)
+
 
 def resize_shortest_edge_shape(h, w, size, max_size):
     """ResizeShortestEdge.get_transform, augmentation_impl.py:164-174"""
@@ -82,7 +84,41 @@ class DatasetMapperTTAAVG:
         self.proposal_topk = cfg.DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST if cfg.MODEL.LOAD_PROPOSALS else None
 
     def __call__(self, dataset_dict):
-        return list(self._augmented(dataset_dict))
+        out = list(self._augmented(dataset_dict))
+        if self.device is not None and self.proposal_topk is not None and UPLOAD_PROPOSALS_ONCE:
+            self._upload_proposals(out)
+        return out
+
+    def _upload_proposals(self, dics):
+        """Device path: the transformed proposals of ALL augmentations go to the device in ONE pinned, asynchronous copy (boxes and
+        objectness logits side by side); each augmentation's Instances then holds views of it.  Sixteen pageable H2D copies inside
+        the passes each waited for the stream's queued work - the host could not run ahead of the GPU."""
+        parts = [(d["proposals"].proposal_boxes.tensor, d["proposals"].objectness_logits) for d in dics]
+        n = sum(int(b.shape[0]) for b, _ in parts)
+        if getattr(self, "_pin", None) is None or self._pin.shape[0] < 5 * n:
+            self._pin = torch.empty((max(5 * n, 1),), dtype=torch.float32).pin_memory()
+            self._pin_ev = None
+        if self._pin_ev is not None:
+            self._pin_ev.synchronize()  # the previous call's copy has left the staging buffer (normally long done)
+        hb, hl = self._pin[: 4 * n].view(n, 4), self._pin[4 * n: 5 * n]  # [all boxes | all logits]: every view below is contiguous
+        o = 0
+        for b, l in parts:
+            k = int(b.shape[0])
+            hb[o: o + k] = b
+            hl[o: o + k] = l
+            o += k
+        dev = self._pin[: 5 * n].to(self.device, non_blocking=True)
+        self._pin_ev = torch.cuda.Event()
+        self._pin_ev.record()
+        db, dl = dev[: 4 * n].view(n, 4), dev[4 * n: 5 * n]
+        o = 0
+        for d, (b, _) in zip(dics, parts):
+            k = int(b.shape[0])
+            p = Instances(d["proposals"].image_size)
+            p.proposal_boxes = Boxes(db[o: o + k])
+            p.objectness_logits = dl[o: o + k]
+            d["proposals"] = p
+            o += k
 
     def _augmented(self, dataset_dict):
         img = dataset_dict["image"].detach().cpu().permute(1, 2, 0).numpy()

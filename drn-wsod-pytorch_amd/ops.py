@@ -594,10 +594,19 @@ def box_reg_loss(logits, col0, K, labels, props, gt_boxes, weights=(10.0, 10.0, 
     return loss
 
 
+_COL0_DEV = {}
+COL0_CACHE = True  # tools: False = the column table is uploaded per call (a host sync per inference pass)
+
+
 def mean_softmax(logits, col0s, ncol, bg_first=False):
     M = logits.shape[0]
     probs = torch.empty((M, ncol), dtype=torch.float32, device=logits.device)
-    cd = torch.tensor(list(col0s), dtype=torch.int32, device=logits.device)
+    # the column table lives on the device once per (columns, device): built per call it was a pageable H2D copy, which waits for
+    # the stream's queued work - every inference pass ended in a host sync (1.3 ms of a TTA pass, profiles/r5_53_tta_host_profile.txt)
+    key = (tuple(int(c) for c in col0s), str(logits.device))
+    cd = _COL0_DEV.get(key) if COL0_CACHE else None
+    if cd is None:
+        cd = _COL0_DEV[key] = torch.tensor(list(key[0]), dtype=torch.int32, device=logits.device)
     C.call("drn_mean_softmax", C.ptr(logits), _2d(logits), C.ptr(cd), len(col0s), ncol, C.ptr(probs), M, int(bg_first),
            C.stream())
     return probs

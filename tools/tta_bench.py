@@ -43,6 +43,20 @@ for wl in os.environ.get("TTA_WORKLOADS", "r50c4,r50dc5").split(","):
     p.objectness_logits = torch.rand(R, generator=g)
     inp = {"image": img, "proposals": p, "height": H, "width": W}
     tta = GeneralizedRCNNWithTTAAVG(cfg, model)
+    if os.environ.get("TTA_SYNC_AB", "1") == "1":  # same-box A/B of the per-pass host syncs removed in round 5
+        import drn_wsod_pytorch_amd.modeling.tta as tta_mod
+        import drn_wsod_pytorch_amd.ops as ops_mod
+        for flag in (False, True, False, True):
+            tta_mod.UPLOAD_PROPOSALS_ONCE = ops_mod.COL0_CACHE = flag
+            for _ in range(2):
+                tta([inp])
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(5):
+                tta([inp])
+            torch.cuda.synchronize()
+            print("%s: per-pass uploads %s: whole call %.1f ms" % (wl, "batched / cached" if flag else "per pass (syncs)",
+                                                                   (time.perf_counter() - t0) / 5 * 1e3), flush=True)
     for _ in range(2):
         out = tta([inp])
     torch.cuda.synchronize()
