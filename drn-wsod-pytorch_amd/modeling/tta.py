@@ -21,7 +21,7 @@ from ..structures import Boxes, Instances
 
 __all__ = ["DatasetMapperTTAAVG", "GeneralizedRCNNWithTTAAVG", "resize_shortest_edge_shape"]
 
-UPLOAD_PROPOSALS_ONCE = True  # tools: False = each pass uploads its own proposals (pageable copies: a host sync per pass)
+VECTORISED_MAPPER = True  # tools: False = the per-augmentation mapper (its proposals are uploaded inside each pass)
 
 
 def resize_shortest_edge_shape(h, w, size, max_size):
@@ -84,41 +84,87 @@ class DatasetMapperTTAAVG:
         self.proposal_topk = cfg.DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST if cfg.MODEL.LOAD_PROPOSALS else None
 
     def __call__(self, dataset_dict):
-        out = list(self._augmented(dataset_dict))
-        if self.device is not None and self.proposal_topk is not None and UPLOAD_PROPOSALS_ONCE:
-            self._upload_proposals(out)
-        return out
+        img = dataset_dict["image"]
+        if self.device is not None and img.dtype == torch.uint8 and VECTORISED_MAPPER:
+            return self._augmented_device(dataset_dict)
+        return list(self._augmented(dataset_dict))
 
-    def _upload_proposals(self, dics):
-        """Device path: the transformed proposals of ALL augmentations go to the device in ONE pinned, asynchronous copy (boxes and
-        objectness logits side by side); each augmentation's Instances then holds views of it.  Sixteen pageable H2D copies inside
-        the passes each waited for the stream's queued work - the host could not run ahead of the GPU."""
-        parts = [(d["proposals"].proposal_boxes.tensor, d["proposals"].objectness_logits) for d in dics]
-        n = sum(int(b.shape[0]) for b, _ in parts)
+    def _augmented_device(self, dataset_dict):
+        """The device path in one sweep: the image goes up once and is resized / flipped there (drn_resize_bilinear_u8); the proposal
+        transform of ALL augmentations (transform_proposals, :27-65: scale, flip, bounding box of the corners, clip, drop empty boxes,
+        top-k) is ONE set of float32 numpy operations on an [A, R, 4] block - the same operations on the same values as _apply_box
+        / Boxes.clip / Boxes.nonempty per augmentation, so the same bits - written into a pinned staging buffer and uploaded in ONE
+        asynchronous copy; each augmentation's Instances holds views of it.  (Per augmentation this was ~30 small numpy / torch calls
+        and a pageable H2D copy inside its pass, which waits for the stream's queued work: 16-40 ms of host time per image on the GPU
+        boxes' hosts, more than the 16 device passes take - profiles/r5_56_tta_batch.txt.)"""
+        img = dataset_dict["image"].detach().cpu().permute(1, 2, 0).numpy()
+        h, w = img.shape[:2]
+        if (dataset_dict["height"], dataset_dict["width"]) != (h, w):
+            raise DrnError("TTA on an already resized input (pre_tfm of the reference) is off this path")
+        src = torch.from_numpy(np.ascontiguousarray(img)).to(self.device, non_blocking=True)  # [H, W, 3] uint8, once
+        augs = [(resize_shortest_edge_shape(h, w, size, self.max_size), fl) for size in self.min_sizes
+                for fl in ([False, True] if self.flip else [False])]
+        out = []
+        for (nh, nw), fl in augs:
+            dic = {k: v for k, v in dataset_dict.items() if k not in ("image", "proposals")}
+            dic["image"] = ops.resize_bilinear_u8(src, nh, nw, flip=fl)  # fp32 [3, nh, nw] of the same bytes
+            dic["tta"] = (w * 1.0 / nw, h * 1.0 / nh, float(nw) if fl else -1.0)
+            out.append(dic)
+        if self.proposal_topk is None:
+            return out
+        prop = dataset_dict["proposals"]
+        b = prop.proposal_boxes.tensor.detach().cpu().numpy().astype(np.float32, copy=False).reshape(-1, 4)
+        logit = prop.objectness_logits.detach().cpu().numpy()
+        A, R = len(augs), b.shape[0]
+        f32 = np.float32
+        sx = np.array([nw * 1.0 / w for (nh, nw), _ in augs], dtype=np.float64).astype(f32).reshape(A, 1, 1)
+        sy = np.array([nh * 1.0 / h for (nh, nw), _ in augs], dtype=np.float64).astype(f32).reshape(A, 1, 1)
+        cx = b[:, [0, 2, 0, 2]][None] * sx  # [A, R, 4] corner xs (x0, x1, x0, x1), float32 x float32 like `c[:, 0] * sx`
+        cy = b[:, [1, 1, 3, 3]][None] * sy
+        flipped = np.array([fl for _, fl in augs])
+        fw = np.array([nw for (nh, nw), _ in augs], dtype=f32).reshape(A, 1, 1)
+        if flipped.any():
+            cx[flipped] = fw[flipped] - cx[flipped]
+        x0, x1 = cx.min(axis=2), cx.max(axis=2)  # (min / max are exact: any order)
+        y0, y1 = cy.min(axis=2), cy.max(axis=2)
+        fh = np.array([nh for (nh, nw), _ in augs], dtype=f32).reshape(A, 1)
+        fw = fw.reshape(A, 1)
+        x0, x1 = np.minimum(np.maximum(x0, f32(0)), fw), np.minimum(np.maximum(x1, f32(0)), fw)  # Boxes.clip
+        y0, y1 = np.minimum(np.maximum(y0, f32(0)), fh), np.minimum(np.maximum(y1, f32(0)), fh)
+        keep = ((x1 - x0) > 0) & ((y1 - y0) > 0)  # Boxes.nonempty(threshold=0)
+        boxes = np.stack((x0, y0, x1, y1), axis=2)  # [A, R, 4]
+        k = self.proposal_topk
+        cnt = [min(int(keep[a].sum()), k) for a in range(A)]
+        n = sum(cnt)
         if getattr(self, "_pin", None) is None or self._pin.shape[0] < 5 * n:
             self._pin = torch.empty((max(5 * n, 1),), dtype=torch.float32).pin_memory()
             self._pin_ev = None
         if self._pin_ev is not None:
             self._pin_ev.synchronize()  # the previous call's copy has left the staging buffer (normally long done)
-        hb, hl = self._pin[: 4 * n].view(n, 4), self._pin[4 * n: 5 * n]  # [all boxes | all logits]: every view below is contiguous
+        pin = self._pin.numpy()
+        hb, hl = pin[: 4 * n].reshape(n, 4), pin[4 * n: 5 * n]  # [all boxes | all logits]: every device view below is contiguous
         o = 0
-        for b, l in parts:
-            k = int(b.shape[0])
-            hb[o: o + k] = b
-            hl[o: o + k] = l
-            o += k
+        for a in range(A):
+            c = cnt[a]
+            if keep[a].all():
+                hb[o: o + c] = boxes[a, :c]
+                hl[o: o + c] = logit[:c]
+            else:
+                hb[o: o + c] = boxes[a][keep[a]][:c]
+                hl[o: o + c] = logit[keep[a]][:c]
+            o += c
         dev = self._pin[: 5 * n].to(self.device, non_blocking=True)
         self._pin_ev = torch.cuda.Event()
         self._pin_ev.record()
         db, dl = dev[: 4 * n].view(n, 4), dev[4 * n: 5 * n]
         o = 0
-        for d, (b, _) in zip(dics, parts):
-            k = int(b.shape[0])
-            p = Instances(d["proposals"].image_size)
-            p.proposal_boxes = Boxes(db[o: o + k])
-            p.objectness_logits = dl[o: o + k]
-            d["proposals"] = p
-            o += k
+        for a, ((nh, nw), _) in enumerate(augs):
+            p = Instances((nh, nw))
+            p.proposal_boxes = Boxes(db[o: o + cnt[a]])
+            p.objectness_logits = dl[o: o + cnt[a]]
+            out[a]["proposals"] = p
+            o += cnt[a]
+        return out
 
     def _augmented(self, dataset_dict):
         img = dataset_dict["image"].detach().cpu().permute(1, 2, 0).numpy()
@@ -170,9 +216,8 @@ class GeneralizedRCNNWithTTAAVG(nn.Module):
         assert not self.cfg.MODEL.KEYPOINT_ON, "TTA for keypoint is not supported yet"
         if self.cfg.MODEL.MASK_ON:
             raise DrnError("mask heads are off the DRN-WSOD path")
-        if batch_size != 1:
-            raise DrnError("augmented images have different sizes and the averages need one prediction set per "
-                           "augmentation: batch_size must stay 1 (the reference's default)")
+        if batch_size < 1:
+            raise DrnError("batch_size must be >= 1")
         self.model = model
         self.tta_mapper = tta_mapper if tta_mapper is not None else DatasetMapperTTAAVG(cfg, device=model.device)
         self.batch_size = batch_size
@@ -193,21 +238,28 @@ class GeneralizedRCNNWithTTAAVG(nn.Module):
         acc_b = acc_s = None
         n = len(augmented_inputs)
         heads = self.model.roi_heads
-        for i, inp in enumerate(augmented_inputs):
-            sx, sy, flip_w = inp["tta"]
-            # the per-pass detections are never used here (the reference computes and drops them): skip the inference tail
-            prev, heads.scores_only = getattr(heads, "scores_only", False), True
-            try:
-                _, scores, boxes = self.model.inference([{k: v for k, v in inp.items() if k != "tta"}], do_postprocess=False)
-            finally:
-                heads.scores_only = prev
-            b, s = boxes[0][0].contiguous(), scores[0][0].contiguous()
-            if acc_b is None:
-                acc_b, acc_s = torch.empty_like(b), torch.empty_like(s)
-            elif acc_b.shape != b.shape:
-                raise DrnError("augmentations kept different numbers of proposals (%s vs %s): the averages are "
-                               "undefined (the reference fails in torch.cat here)" % (tuple(acc_b.shape), tuple(b.shape)))
-            ops.tta_accumulate(b, s, acc_b, acc_s, np.float32(sx), np.float32(sy), flip_w, i == 0, n if i == n - 1 else 0)
+        # _batch_inference (:200-225): consecutive augmentations in groups of `batch_size` through ONE model.inference (the mapper
+        # emits each size's plain and flipped image next to each other, so batch_size = 2 batches same-size pairs: one conv chain
+        # per pair); the averages are accumulated per augmentation in the mapper's order either way
+        prev, heads.scores_only = getattr(heads, "scores_only", False), True
+        try:
+            for g0 in range(0, n, self.batch_size):
+                group = augmented_inputs[g0: g0 + self.batch_size]
+                # the per-pass detections are never used here (the reference computes and drops them): skip the inference tail
+                _, scores, boxes = self.model.inference([{k: v for k, v in inp.items() if k != "tta"} for inp in group],
+                                                        do_postprocess=False)
+                for j, inp in enumerate(group):
+                    i = g0 + j
+                    sx, sy, flip_w = inp["tta"]
+                    b, s = boxes[j][0].contiguous(), scores[j][0].contiguous()
+                    if acc_b is None:
+                        acc_b, acc_s = torch.empty_like(b), torch.empty_like(s)
+                    elif acc_b.shape != b.shape:
+                        raise DrnError("augmentations kept different numbers of proposals (%s vs %s): the averages are "
+                                       "undefined (the reference fails in torch.cat here)" % (tuple(acc_b.shape), tuple(b.shape)))
+                    ops.tta_accumulate(b, s, acc_b, acc_s, np.float32(sx), np.float32(sy), flip_w, i == 0, n if i == n - 1 else 0)
+        finally:
+            heads.scores_only = prev
         return acc_b, acc_s
 
     def _inference_one_image(self, input):

@@ -769,7 +769,56 @@ def test_tta_matches_reference_golden():
     assert np.array_equal(out.pred_classes.cpu().numpy(), d["det_classes"])
     assert np.allclose(out.scores.cpu().numpy(), d["det_scores"], rtol=1e-4, atol=1e-6)
     assert np.allclose(out.pred_boxes.tensor.cpu().numpy(), d["det_boxes"], rtol=1e-5, atol=1e-3)
+    # batch_size = 2 (test_time_augmentation_avg.py:200-225): each size's plain and flipped image in ONE model.inference - the same
+    # averages and detections within the same bounds (the convs of a 2-image batch may take other tiles: not bit for bit)
+    tta2 = GeneralizedRCNNWithTTAAVG(cfg, model, batch_size=2)
+    with torch.no_grad():
+        avg_b2, avg_s2 = tta2._get_augmented_boxes(tta2.tta_mapper(inp))
+    assert np.allclose(avg_s2.cpu().numpy(), d["avg_scores"], rtol=1e-4, atol=1e-6)
+    assert np.allclose(avg_b2.cpu().numpy(), d["avg_boxes"], rtol=1e-5, atol=1e-3)
+    out2 = tta2([inp])[0]["instances"]
+    assert np.array_equal(out2.pred_classes.cpu().numpy(), d["det_classes"])
+    assert np.allclose(out2.scores.cpu().numpy(), d["det_scores"], rtol=1e-4, atol=1e-6)
     load_package().set_precision("fp32")
+
+
+def test_tta_mapper_vectorised_equals_per_augmentation():
+    """Round 5: the device mapper transforms the proposals of all augmentations in one [A, R, 4] numpy sweep and uploads them in one
+    pinned copy.  Against the per-augmentation mapper (the reference's transform_proposals order: scale, flip, corner bounding box,
+    clip, drop empty, top-k) bit for bit - boxes that leave the image, zero-width / zero-height boxes, a top-k that cuts."""
+    import drn_wsod_pytorch_amd.modeling.tta as tta_mod
+    from drn_wsod_pytorch_amd.structures import Boxes, Instances
+
+    cfg = G.drn_model(G.MODEL_CASES["model_r50c4_tiny"], 0, "cuda", 5, "fp32")[0]
+    cfg.merge_from_list(["TEST.AUG.ENABLED", "True", "TEST.AUG.MIN_SIZES", "(96, 120, 176)", "TEST.AUG.MAX_SIZE", "200", "TEST.AUG.FLIP", "True",
+                         "DATASETS.PRECOMPUTED_PROPOSAL_TOPK_TEST", "700"])
+    rng = np.random.default_rng(5)
+    H, W, R = 75, 100, 900
+    b = np.stack([rng.uniform(-8, W, R), rng.uniform(-8, H, R), rng.uniform(0, W + 12, R), rng.uniform(0, H + 12, R)], 1).astype(np.float32)
+    b[:40, 2] = b[:40, 0]  # zero width
+    b[40:70, 3] = b[40:70, 1]  # zero height
+    b[70:90] = np.array([W + 5, 3, W + 9, 9], np.float32)  # outside: empty after the clip
+    prop = Instances((H, W))
+    prop.proposal_boxes = Boxes(torch.from_numpy(b))
+    prop.objectness_logits = torch.from_numpy(rng.standard_normal(R).astype(np.float32))
+    inp = {"image": torch.from_numpy(rng.integers(0, 256, (3, H, W), dtype=np.uint8)), "proposals": prop, "height": H, "width": W}
+    mapper = tta_mod.DatasetMapperTTAAVG(cfg, device=torch.device("cuda"))
+    got = mapper(inp)
+    tta_mod.VECTORISED_MAPPER = False
+    try:
+        ref = mapper(inp)
+    finally:
+        tta_mod.VECTORISED_MAPPER = True
+    assert len(got) == len(ref) == 6
+    kept = set()
+    for a, r in zip(got, ref):
+        assert a["tta"] == r["tta"] and a["proposals"].image_size == r["proposals"].image_size
+        assert torch.equal(a["image"], r["image"])
+        assert a["proposals"].proposal_boxes.tensor.is_cuda
+        assert np.array_equal(a["proposals"].proposal_boxes.tensor.cpu().numpy(), r["proposals"].proposal_boxes.tensor.cpu().numpy())
+        assert np.array_equal(a["proposals"].objectness_logits.cpu().numpy(), r["proposals"].objectness_logits.cpu().numpy())
+        kept.add(len(a["proposals"]))
+    assert max(kept) == 700 or min(kept) < R  # the top-k or the empty-box filter really cut
 
 
 def test_tta_accumulate_matches_host_transform():

@@ -42,12 +42,12 @@ for wl in os.environ.get("TTA_WORKLOADS", "r50c4,r50dc5").split(","):
     p.proposal_boxes = Boxes(torch.stack([x0, y0, x0 + bw, y0 + bh], 1))
     p.objectness_logits = torch.rand(R, generator=g)
     inp = {"image": img, "proposals": p, "height": H, "width": W}
-    tta = GeneralizedRCNNWithTTAAVG(cfg, model)
-    if os.environ.get("TTA_SYNC_AB", "1") == "1":  # same-box A/B of the per-pass host syncs removed in round 5
+    tta = GeneralizedRCNNWithTTAAVG(cfg, model, batch_size=int(os.environ.get("TTA_BATCH", "1")))
+    if os.environ.get("TTA_SYNC_AB", "0") == "1":  # same-box A/B of the per-pass host syncs removed in round 5
         import drn_wsod_pytorch_amd.modeling.tta as tta_mod
         import drn_wsod_pytorch_amd.ops as ops_mod
         for flag in (False, True, False, True):
-            tta_mod.UPLOAD_PROPOSALS_ONCE = ops_mod.COL0_CACHE = flag
+            tta_mod.VECTORISED_MAPPER = ops_mod.COL0_CACHE = flag
             for _ in range(2):
                 tta([inp])
             torch.cuda.synchronize()
@@ -80,8 +80,8 @@ for wl in os.environ.get("TTA_WORKLOADS", "r50c4,r50dc5").split(","):
         torch.cuda.synchronize()
     passes = (time.perf_counter() - t0) / n
     sizes = sorted({tuple(a["image"].shape[1:]) for a in aug})
-    print("%s: %d passes per image (%s .. %s), R = %d: whole call %.1f ms = %.2f img/s; mapper (host) %.1f ms; the %d device passes + "
-          "averaging %.1f ms = %.2f ms per pass; %d detections" % (wl, len(aug), "%dx%d" % sizes[0], "%dx%d" % sizes[-1], R, full * 1e3, 1.0 / full,
+    print("%s (batch_size %d): %d augmentations per image (%s .. %s), R = %d: whole call %.1f ms = %.2f img/s; mapper (host) %.1f ms; the %d device passes + "
+          "averaging %.1f ms = %.2f ms per augmentation; %d detections" % (wl, tta.batch_size, len(aug), "%dx%d" % sizes[0], "%dx%d" % sizes[-1], R, full * 1e3, 1.0 / full,
                                                           mapper * 1e3, len(aug), passes * 1e3, passes * 1e3 / len(aug),
                                                           len(out[0]["instances"])), flush=True)
     del model, tta
