@@ -61,34 +61,53 @@ __global__ __launch_bounds__(1024) void candidates_kernel(CandParams p) {
   }
   if (threadIdx.x == 0) base = 0;
   __syncthreads();
+  // threshold + ordered compaction of the R x K scores: a thread takes EPT CONSECUTIVE entries (row-major order = thread order =
+  // output order), so one round of the block covers 1024 x EPT entries - 5 rounds of three barriers at R x K = 40 000 instead of
+  // 40 (150 -> ~30 us of every image's inference tail, profiles/r5_63_infer480_kernel_stats.txt)
+  constexpr int EPT = 8;
   const long total = (long)p.R * p.K;
-  for (long start = 0; start < total; start += 1024) {
-    const long i = start + threadIdx.x;
-    bool flag = false;
-    int r = 0, c = 0;
-    float s = 0.f;
-    if (i < total) {
-      r = i / p.K; c = i - (long)r * p.K;
-      s = p.scores[(long)r * (p.K + 1) + c];
-      flag = p.rowmap[r] >= 0 && s > p.thresh;
+  for (long start = 0; start < total; start += 1024 * EPT) {
+    const long i0 = start + (long)threadIdx.x * EPT;
+    unsigned flags = 0;
+    float sv[EPT];
+    int n_mine = 0;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e) {
+      const long i = i0 + e;
+      sv[e] = 0.f;
+      if (i < total) {
+        const int r = (int)(i / p.K), c = (int)(i - (long)r * p.K);
+        sv[e] = p.scores[(long)r * (p.K + 1) + c];
+        if (p.rowmap[r] >= 0 && sv[e] > p.thresh) flags |= 1u << e, ++n_mine;
+      }
     }
-    const unsigned long long bal = __ballot(flag);
-    const int wprefix = __popcll(bal & ((1ULL << lane) - 1ULL));
-    if (lane == 0) wcnt[w] = __popcll(bal);
+    // exclusive prefix of n_mine over the wave's lanes, then over the waves
+    int incl = n_mine;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const int u = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += u;
+    }
+    if (lane == 63) wcnt[w] = incl;
     __syncthreads();
-    int woff = 0;
-    for (int q = 0; q < w; ++q) woff += wcnt[q];
-    int tot = 0;
-    for (int q = 0; q < 16; ++q) tot += wcnt[q];
-    const int pos = base + woff + wprefix;
-    if (flag && pos < p.cap) {
-      const float* b = p.boxes + (long)r * 4 * p.nreg + (p.nreg == 1 ? 0 : 4 * c);
-      const float x1 = fminf(fmaxf(b[0], 0.f), p.img_w), y1 = fminf(fmaxf(b[1], 0.f), p.img_h);
-      const float x2 = fminf(fmaxf(b[2], 0.f), p.img_w), y2 = fminf(fmaxf(b[3], 0.f), p.img_h);
-      p.c_box[4 * (long)pos] = x1; p.c_box[4 * (long)pos + 1] = y1; p.c_box[4 * (long)pos + 2] = x2; p.c_box[4 * (long)pos + 3] = y2;
-      p.c_score[pos] = s; p.c_row[pos] = p.rowmap[r]; p.c_cls[pos] = c;
-      mymax = fmaxf(mymax, fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
-    }
+    int woff = 0, tot = 0;
+    for (int q = 0; q < 16; ++q) { if (q < w) woff += wcnt[q]; tot += wcnt[q]; }
+    int pos = base + woff + incl - n_mine;
+#pragma unroll
+    for (int e = 0; e < EPT; ++e)
+      if (flags >> e & 1) {
+        if (pos < p.cap) {
+          const long i = i0 + e;
+          const int r = (int)(i / p.K), c = (int)(i - (long)r * p.K);
+          const float* b = p.boxes + (long)r * 4 * p.nreg + (p.nreg == 1 ? 0 : 4 * c);
+          const float x1 = fminf(fmaxf(b[0], 0.f), p.img_w), y1 = fminf(fmaxf(b[1], 0.f), p.img_h);
+          const float x2 = fminf(fmaxf(b[2], 0.f), p.img_w), y2 = fminf(fmaxf(b[3], 0.f), p.img_h);
+          p.c_box[4 * (long)pos] = x1; p.c_box[4 * (long)pos + 1] = y1; p.c_box[4 * (long)pos + 2] = x2; p.c_box[4 * (long)pos + 3] = y2;
+          p.c_score[pos] = sv[e]; p.c_row[pos] = p.rowmap[r]; p.c_cls[pos] = c;
+          mymax = fmaxf(mymax, fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
+        }
+        ++pos;
+      }
     __syncthreads();
     if (threadIdx.x == 0) base += tot;
     __syncthreads();
