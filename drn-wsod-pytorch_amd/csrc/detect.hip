@@ -27,27 +27,36 @@ struct CandParams {
   int* rowmap;    // [R] scratch: index of row r among the finite rows, or -1
 };
 
-// single block; ordered compaction via wave ballots + block prefix over 1024-element chunks
-__global__ __launch_bounds__(1024) void candidates_kernel(CandParams p) {
+// finite-row filter (fast_rcnn.py:108-111), one wave per row over many blocks: rowmap[r] = 0 (all K+1 scores and 4*nreg box
+// coordinates finite) or -1.  Inside the single-block kernel below this was 101 loads per thread, each waiting for the previous one's
+// verdict (`&& finite`), from ONE CU: ~120 of that kernel's 150 us (profiles/r5_63_infer480_kernel_stats.txt).
+__global__ __launch_bounds__(256) void rows_finite_kernel(CandParams p) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= p.R) return;
+  const float* srow = p.scores + (long)r * (p.K + 1);
+  const float* brow = p.boxes + (long)r * 4 * p.nreg;
+  bool finite = true;
+  for (int k = lane; k <= p.K; k += 64) finite = finite && isfinite(srow[k]);
+  for (int k = lane; k < 4 * p.nreg; k += 64) finite = finite && isfinite(brow[k]);
+  const bool all = __ballot(!finite) == 0;
+  if (lane == 0) p.rowmap[r] = all ? 0 : -1;
+}
+
+// single block: the rows that passed rows_finite_kernel, numbered in order - rows with any non-finite box or score are dropped BEFORE
+// indexing (fast_rcnn.py:108-111), so every later row index refers to the compacted arrays
+__global__ __launch_bounds__(1024) void rows_number_kernel(CandParams p) {
   __shared__ int wcnt[16];
   __shared__ int base;
-  __shared__ float wmax[16];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  if (threadIdx.x == 0) base = 0;
-  float mymax = -INFINITY;
+  if (threadIdx.x == 0) {
+    base = 0;
+    p.maxcoord[0] = -INFINITY;
+  }
   __syncthreads();
-  // finite-row filter (fast_rcnn.py:108-111): rows with any non-finite box or score are dropped BEFORE
-  // indexing, so every later row index refers to the compacted arrays
   for (int start = 0; start < p.R; start += 1024) {
     const int r = start + threadIdx.x;
-    bool finite = false;
-    if (r < p.R) {
-      finite = true;
-      const float* srow = p.scores + (long)r * (p.K + 1);
-      for (int k = 0; k <= p.K && finite; ++k) finite = isfinite(srow[k]);
-      const float* brow = p.boxes + (long)r * 4 * p.nreg;
-      for (int k = 0; k < 4 * p.nreg && finite; ++k) finite = isfinite(brow[k]);
-    }
+    const bool finite = r < p.R && p.rowmap[r] >= 0;
     const unsigned long long bal = __ballot(finite);
     const int wprefix = __popcll(bal & ((1ULL << lane) - 1ULL));
     if (lane == 0) wcnt[w] = __popcll(bal);
@@ -59,67 +68,78 @@ __global__ __launch_bounds__(1024) void candidates_kernel(CandParams p) {
     if (threadIdx.x == 0) base += tot;
     __syncthreads();
   }
-  if (threadIdx.x == 0) base = 0;
-  __syncthreads();
-  // threshold + ordered compaction of the R x K scores: a thread takes EPT CONSECUTIVE entries (row-major order = thread order =
-  // output order), so one round of the block covers 1024 x EPT entries - 5 rounds of three barriers at R x K = 40 000 instead of
-  // 40 (150 -> ~30 us of every image's inference tail, profiles/r5_63_infer480_kernel_stats.txt)
-  constexpr int EPT = 8;
+}
+
+// threshold + ordered compaction of the R x K scores (row-major = nonzero order) over many blocks: a tile of CAND_TILE consecutive
+// entries per block, a thread takes CAND_EPT CONSECUTIVE entries (entry order = thread order = output order).  Pass 0 leaves
+// every tile's count, pass 1 places a tile behind the sum of the counts in front of it - the output is a function of the input
+// alone, as in the single-block form this replaces (150 us per image from one CU: 40 000 entries, 280 000 scattered 4-byte stores;
+// profiles/r5_63_infer480_kernel_stats.txt).  The largest candidate coordinate is an atomic max on the bits of non-negative
+// floats (the boxes are clipped to the image first): exact whatever the order.
+constexpr int CAND_THREADS = 256, CAND_EPT = 8, CAND_TILE = CAND_THREADS * CAND_EPT;
+template <int PASS>
+__global__ __launch_bounds__(CAND_THREADS) void candidates_kernel(CandParams p, int* tile_cnt, int ntiles) {
+  __shared__ int wcnt[CAND_THREADS / 64];
+  __shared__ int sbase;
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   const long total = (long)p.R * p.K;
-  for (long start = 0; start < total; start += 1024 * EPT) {
-    const long i0 = start + (long)threadIdx.x * EPT;
-    unsigned flags = 0;
-    float sv[EPT];
-    int n_mine = 0;
+  const long i0 = (long)blockIdx.x * CAND_TILE + (long)threadIdx.x * CAND_EPT;
+  unsigned flags = 0;
+  float sv[CAND_EPT];
+  int n_mine = 0;
 #pragma unroll
-    for (int e = 0; e < EPT; ++e) {
-      const long i = i0 + e;
-      sv[e] = 0.f;
-      if (i < total) {
-        const int r = (int)(i / p.K), c = (int)(i - (long)r * p.K);
-        sv[e] = p.scores[(long)r * (p.K + 1) + c];
-        if (p.rowmap[r] >= 0 && sv[e] > p.thresh) flags |= 1u << e, ++n_mine;
-      }
+  for (int e = 0; e < CAND_EPT; ++e) {
+    const long i = i0 + e;
+    sv[e] = 0.f;
+    if (i < total) {
+      const int r = (int)(i / p.K), c = (int)(i - (long)r * p.K);
+      sv[e] = p.scores[(long)r * (p.K + 1) + c];
+      if (p.rowmap[r] >= 0 && sv[e] > p.thresh) flags |= 1u << e, ++n_mine;
     }
-    // exclusive prefix of n_mine over the wave's lanes, then over the waves
-    int incl = n_mine;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const int u = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += u;
-    }
-    if (lane == 63) wcnt[w] = incl;
-    __syncthreads();
-    int woff = 0, tot = 0;
-    for (int q = 0; q < 16; ++q) { if (q < w) woff += wcnt[q]; tot += wcnt[q]; }
-    int pos = base + woff + incl - n_mine;
-#pragma unroll
-    for (int e = 0; e < EPT; ++e)
-      if (flags >> e & 1) {
-        if (pos < p.cap) {
-          const long i = i0 + e;
-          const int r = (int)(i / p.K), c = (int)(i - (long)r * p.K);
-          const float* b = p.boxes + (long)r * 4 * p.nreg + (p.nreg == 1 ? 0 : 4 * c);
-          const float x1 = fminf(fmaxf(b[0], 0.f), p.img_w), y1 = fminf(fmaxf(b[1], 0.f), p.img_h);
-          const float x2 = fminf(fmaxf(b[2], 0.f), p.img_w), y2 = fminf(fmaxf(b[3], 0.f), p.img_h);
-          p.c_box[4 * (long)pos] = x1; p.c_box[4 * (long)pos + 1] = y1; p.c_box[4 * (long)pos + 2] = x2; p.c_box[4 * (long)pos + 3] = y2;
-          p.c_score[pos] = sv[e]; p.c_row[pos] = p.rowmap[r]; p.c_cls[pos] = c;
-          mymax = fmaxf(mymax, fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
-        }
-        ++pos;
-      }
-    __syncthreads();
-    if (threadIdx.x == 0) base += tot;
-    __syncthreads();
   }
-  mymax = wave_max(mymax);
-  if (lane == 0) wmax[w] = mymax;
+  // inclusive prefix of n_mine over the wave's lanes, then over the block's waves
+  int incl = n_mine;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const int u = __shfl_up(incl, o, 64);
+    if (lane >= o) incl += u;
+  }
+  if (lane == 63) wcnt[w] = incl;
+  if (PASS == 1 && threadIdx.x == 0) {
+    int b = 0;
+    for (int t = 0; t < (int)blockIdx.x; ++t) b += tile_cnt[t];
+    sbase = b;
+  }
   __syncthreads();
-  if (threadIdx.x == 0) {
-    float m = -INFINITY;
-    for (int q = 0; q < 16; ++q) m = fmaxf(m, wmax[q]);
-    p.maxcoord[0] = m;
-    p.count[0] = base < p.cap ? base : p.cap;
+  int woff = 0, tot = 0;
+  for (int q = 0; q < CAND_THREADS / 64; ++q) { if (q < w) woff += wcnt[q]; tot += wcnt[q]; }
+  if (PASS == 0) {
+    if (threadIdx.x == 0) tile_cnt[blockIdx.x] = tot;
+    return;
+  }
+  int pos = sbase + woff + incl - n_mine;
+  float mymax = -INFINITY;
+#pragma unroll
+  for (int e = 0; e < CAND_EPT; ++e)
+    if (flags >> e & 1) {
+      if (pos < p.cap) {
+        const long i = i0 + e;
+        const int r = (int)(i / p.K), c = (int)(i - (long)r * p.K);
+        const float* b = p.boxes + (long)r * 4 * p.nreg + (p.nreg == 1 ? 0 : 4 * c);
+        const float x1 = fminf(fmaxf(b[0], 0.f), p.img_w), y1 = fminf(fmaxf(b[1], 0.f), p.img_h);
+        const float x2 = fminf(fmaxf(b[2], 0.f), p.img_w), y2 = fminf(fmaxf(b[3], 0.f), p.img_h);
+        p.c_box[4 * (long)pos] = x1; p.c_box[4 * (long)pos + 1] = y1; p.c_box[4 * (long)pos + 2] = x2; p.c_box[4 * (long)pos + 3] = y2;
+        p.c_score[pos] = sv[e]; p.c_row[pos] = p.rowmap[r]; p.c_cls[pos] = c;
+        mymax = fmaxf(mymax, fmaxf(fmaxf(x1, y1), fmaxf(x2, y2)));
+      }
+      ++pos;
+    }
+  mymax = wave_max(mymax);
+  // (clipped coordinates are >= 0, or NaN-free by the finite filter: their bit patterns order like the values; -inf stays for "none")
+  if (lane == 0 && mymax >= 0.f) atomicMax((int*)p.maxcoord, __builtin_bit_cast(int, mymax));
+  if ((int)blockIdx.x == ntiles - 1 && threadIdx.x == 0) {
+    const int n = sbase + tot;
+    p.count[0] = n < p.cap ? n : p.cap;
   }
 }
 
@@ -415,7 +435,17 @@ int drn_detect_topk(const float* boxes, const float* scores, int R, int K, int n
   Ws k = carve(workspace, workspace_bytes, cap);
   CandParams cp{boxes, scores, R, K, nreg, img_h, img_w, score_thresh, k.c_box, k.c_score, k.c_row, k.c_cls, k.count,
                 k.maxcoord, cap, (int*)k.key0};  // key0 doubles as the row map until the sort's second pass overwrites it
-  hipLaunchKernelGGL(candidates_kernel, dim3(1), dim3(1024), 0, st, cp);
+  if (R > 0) hipLaunchKernelGGL(rows_finite_kernel, dim3((R + 3) / 4), dim3(256), 0, st, cp);
+  hipLaunchKernelGGL(rows_number_kernel, dim3(1), dim3(1024), 0, st, cp);
+  const long total = (long)R * K;
+  const int ntiles = (int)((total + CAND_TILE - 1) / CAND_TILE);
+  if (ntiles > SORT_BINS) return DRN_ERR_UNSUPPORTED;  // (8M scores per image; the tile counts live in the sort's histogram area)
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(candidates_kernel<0>, dim3(ntiles), dim3(CAND_THREADS), 0, st, cp, k.hist, ntiles);
+    hipLaunchKernelGGL(candidates_kernel<1>, dim3(ntiles), dim3(CAND_THREADS), 0, st, cp, k.hist, ntiles);
+  } else {
+    hipMemsetAsync(k.count, 0, sizeof(int), st);
+  }
   // stable descending order of the live candidates: (score, index) -> key1/order -> key0/val0 -> key1/order
   const int tiles = sort_tiles(cap);
   const int shifts[3] = {0, 11, 22}, bits[3] = {11, 11, 10};
