@@ -3,10 +3,14 @@ the pooling kernels of steady-state steps, plus the idle gaps longer than a thre
 usage: prof_busy.py <dir> [gap_us=20]"""
 import glob
 import re
+import os
 import sqlite3
 import sys
 
-db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from prof_db import main_db
+
+db = main_db(sys.argv[1])
 gap_us = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
 cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, start, end, queue_id from kernels order by start"))

@@ -2,10 +2,14 @@
 duration and mean start-to-start period (= duration + the gap to the next launch).  usage: prof_runs.py <dir> [name-filter]"""
 import glob
 import re
+import os
 import sqlite3
 import sys
 
-db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from prof_db import main_db
+
+db = main_db(sys.argv[1])
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, start, end, grid_x, workgroup_x from kernels order by start"))

@@ -2,13 +2,16 @@
 with different grids are different shapes of the workload (the 256x256 GEMM serves the fc6 forward, the fc6 dW slabs and
 fc7), so rows are split by (kernel, grid): `wgs` = workgroups per launch as x*y."""
 import glob
+import os
 import sqlite3
 import sys
 
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from prof_db import main_db
+
 
 def main(path, out=None):
-    dbs = glob.glob(path + "/**/*.db", recursive=True)
-    assert dbs, "no rocpd database under " + path
+    dbs = [main_db(path)]
     cur = sqlite3.connect(dbs[0]).cursor()
     rows = cur.execute("select name, grid_x / max(workgroup_x, 1), grid_y / max(workgroup_y, 1), count(*), "
                        "sum(end-start)/1e3, avg(end-start)/1e3, min(end-start)/1e3, max(end-start)/1e3 from kernels "

@@ -2,10 +2,14 @@
 usage: prof_timeline.py <dir> [number_of_steps]"""
 import glob
 import re
+import os
 import sqlite3
 import sys
 
-db = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from prof_db import main_db
+
+db = main_db(sys.argv[1])
 back = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 cur = sqlite3.connect(db).cursor()
 rows = list(cur.execute("select name, start, end, queue_id, grid_x, grid_y, workgroup_x from kernels order by start"))
