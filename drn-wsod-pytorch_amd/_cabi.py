@@ -31,6 +31,7 @@ _SIGS = {
     "drn_maxpool2x2_bwd_nhwc": "pppiiiiiip",
     "drn_add": "ppplip",
     "drn_stage_heads_inputs": "ppippip",
+    "drn_stage_rois": "ppfpppip",
     "drn_roi_pool_backward_nhwc": "ppppp" + "iiiiii" + "f" + "l" + "iiiip",
     "drn_transpose2d": "ppiilliip",
     "drn_gemm_nt": "pppiiillliiilip",

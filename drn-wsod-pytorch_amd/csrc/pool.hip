@@ -1831,6 +1831,17 @@ int drn_maxpool2x2_bwd_nhwc(const void* x, const void* dy, void* dx, int Nb, int
 // props[M][4] <- rois[M][1:5] and (optional) words_dst[n_words] <- words_src: the two hand-overs from the staged next
 // batch to the buffers the heads read (proposal boxes for pseudo-GT mining / IoU labelling; the image-level label block),
 // in ONE launch in front of the pooling kernel.  See include/drn_wsod.h.
+__global__ void stage_rois_kernel(const float* __restrict__ boxes, const float* __restrict__ logits, float batch_index,
+                                  float* __restrict__ rois, float* __restrict__ obj, float* __restrict__ props, int M) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M) return;
+  const float x0 = boxes[4 * (long)i], y0 = boxes[4 * (long)i + 1], x1 = boxes[4 * (long)i + 2], y1 = boxes[4 * (long)i + 3];
+  float* r = rois + 5 * (long)i;
+  r[0] = batch_index; r[1] = x0; r[2] = y0; r[3] = x1; r[4] = y1;
+  if (props) { float* q = props + 4 * (long)i; q[0] = x0; q[1] = y0; q[2] = x1; q[3] = y1; }
+  if (obj) obj[i] = logits[i];
+}
+
 __global__ void stage_heads_kernel(const float* __restrict__ rois, float* __restrict__ props, int M,
                                    const int* __restrict__ words_src, int* __restrict__ words_dst, int n_words) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1845,6 +1856,20 @@ int drn_stage_heads_inputs(const float* rois, float* props, int M, const int* wo
   if (n == 0) return DRN_OK;
   hipLaunchKernelGGL(stage_heads_kernel, dim3(grid_for(n, 256)), dim3(256), 0, (hipStream_t)stream, rois, props, M,
                      words_src, words_dst, n_words);
+  DRN_CHECK_LAUNCH();
+  return DRN_OK;
+}
+
+// boxes [M][4] + objectness logits [M] of ONE image -> the pooler's rois [M][5] = (batch index, x0, y0, x1, y1)
+// (convert_boxes_to_pooler_format, detectron2/modeling/poolers.py:69-96), a contiguous copy of the logits and of the boxes:
+// one launch for what was torch.full + two torch.cat + two copies in front of every forward
+int drn_stage_rois(const float* boxes, const float* logits, float batch_index, float* rois, float* obj, float* props, int M,
+                   void* stream) {
+  if (M < 0 || (M > 0 && (!boxes || !rois))) return DRN_ERR_ARG;
+  if ((obj != nullptr) != (logits != nullptr)) return DRN_ERR_ARG;
+  if (M == 0) return DRN_OK;
+  hipLaunchKernelGGL(stage_rois_kernel, dim3(grid_for(M, 256)), dim3(256), 0, (hipStream_t)stream, boxes, logits, batch_index,
+                     rois, obj, props, M);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

@@ -1295,9 +1295,23 @@ class OICRROIHeads(ROIHeads):
         nhwc = feat.permute(0, 2, 3, 1)
         if not nhwc.is_contiguous() or nhwc.dtype != compute_dtype():
             nhwc = to_nhwc(feat, compute_dtype())
+        self._props = None
+        if len(proposals) == 1:
+            # one image (every shipped config trains and tests with one image per GPU): rois, logits and the boxes' contiguous
+            # copy in ONE launch instead of torch.full + two torch.cat + three copies in front of every forward
+            b, l = proposals[0].proposal_boxes.tensor, proposals[0].objectness_logits
+            if b.is_cuda and b.dtype == torch.float32 and l.dtype == torch.float32 and b.is_contiguous() and l.is_contiguous():
+                rois, obj, props = ops.stage_rois(b, l, 0.0)
+                self._props = (rois, props)  # (tied to THIS rois tensor: a prefetch of a later batch may gather in between)
+                return nhwc, rois, obj
         rois = convert_boxes_to_pooler_format([p.proposal_boxes for p in proposals]).float().contiguous()
         obj = torch.cat([p.objectness_logits for p in proposals], dim=0).float().contiguous()
         return nhwc, rois, obj
+
+    def _take_props(self, rois):
+        """the proposal boxes as a contiguous [M, 4] tensor: the copy _gather_inputs made in its staging launch, else a slice copy"""
+        p, self._props = getattr(self, "_props", None), None
+        return p[1] if p is not None and p[0] is rois and p[1] is not None else rois[:, 1:].contiguous()
 
     def _zero_onehot(self, n_img, K, dev):
         z = getattr(self, "_zero_oh", None)
@@ -1310,7 +1324,8 @@ class OICRROIHeads(ROIHeads):
         if getattr(self._engine, "kshard", None) is not None:
             return None  # K-sharded fc6: the operand is built from every rank's features inside the forward
         nhwc, rois, obj = self._gather_inputs(features, proposals)
-        return dict(rois=rois, obj=obj, pooled=self._engine.pool(nhwc, rois, obj, self.training, prefetch=True))
+        return dict(rois=rois, obj=obj, props=self._take_props(rois),
+                    pooled=self._engine.pool(nhwc, rois, obj, self.training, prefetch=True))
 
     def forward(self, images, features, proposals, targets=None, prefetched=None):
         """roi_heads_oicr.py:248-291."""
@@ -1334,6 +1349,7 @@ class OICRROIHeads(ROIHeads):
         self._prefetched = None
         if pre is not None:
             nhwc, rois, obj, pooled = None, pre["rois"], pre["obj"], pre["pooled"]
+            self._props = (rois, pre.get("props"))
         else:
             nhwc, rois, obj = self._gather_inputs(features, proposals)
             pooled = None
@@ -1351,7 +1367,7 @@ class OICRROIHeads(ROIHeads):
             off = torch.tensor([0] + list(torch.tensor(nper).cumsum(0).tolist()), dtype=torch.int32)
             gt = dict(onehot=oh.to(dev, non_blocking=True), classes=gcl.to(dev, non_blocking=True),
                       count=torch.tensor([len(g) for g in ints], dtype=torch.int32).to(dev, non_blocking=True),
-                      props=rois[:, 1:].contiguous(), max_rows=max(nper))
+                      props=self._take_props(rois), max_rows=max(nper))
             losses, state = self._engine.forward(nhwc, rois, obj, True, off.to(dev, non_blocking=True), n_img, gt,
                                                  pooled=pooled)
             self.pred_class_img_logits = state["aux"]["img_scores"]
@@ -1365,7 +1381,7 @@ class OICRROIHeads(ROIHeads):
             return losses
         w, col = self._engine.forward(nhwc, rois, obj, False, pooled=pooled)
         heads = [k for k in range(self.refine_K)]
-        props = rois[:, 1:].contiguous()
+        props = self._take_props(rois)
         last = self.box_refinery[-1] if self.refine_K else self.box_predictor
         if self.refine_K == 0:
             # WSDDNROIHeads (roi_heads_wsddn.py:305-309 -> WSDDNOutputLayers.inference, fast_rcnn.py:587-608): the MIL

@@ -323,6 +323,21 @@ def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, al
     return (out, arg) if want_argmax else out
 
 
+def stage_rois(boxes, logits, batch_index=0.0):
+    """boxes [M, 4] f32 (+ logits [M] f32 or None) of ONE image -> (rois [M, 5], obj [M] or None, props [M, 4]) in one launch
+    (drn_stage_rois: convert_boxes_to_pooler_format + the contiguous copies the heads read)"""
+    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.shape[1] == 4
+    M = boxes.shape[0]
+    rois = torch.empty((M, 5), dtype=torch.float32, device=boxes.device)
+    props = torch.empty((M, 4), dtype=torch.float32, device=boxes.device)
+    obj = None
+    if logits is not None:
+        assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape[0] == M
+        obj = torch.empty((M,), dtype=torch.float32, device=boxes.device)
+    C.call("drn_stage_rois", C.ptr(boxes), C.ptr(logits), float(batch_index), C.ptr(rois), C.ptr(obj), C.ptr(props), M, C.stream())
+    return rois, obj, props
+
+
 def im2col_t(x, cin, kh, kw, stride, pad, dil, out=None):
     """x [N,H,W,Cpad] NHWC -> [cin*kh*kw, kpad(N*Ho*Wo)] (row (ci*kh + i)*kw + j), zero padded columns."""
     n, h, w, cp = x.shape

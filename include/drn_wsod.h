@@ -115,6 +115,12 @@ int drn_add(const void* a, const void* b, void* out, long n, int dtype, void* st
 int drn_stage_heads_inputs(const float* rois, float* props, int M, const int* words_src, int* words_dst, int n_words,
                            void* stream);
 
+/* convert_boxes_to_pooler_format for ONE image (detectron2/modeling/poolers.py:69-96) in one launch: boxes [M][4] (+ objectness
+ * logits [M] or NULL) -> rois [M][5] = (batch_index, x0, y0, x1, y1), obj [M] (NULL iff logits is NULL) and, when props != NULL, a
+ * contiguous copy of the boxes for the pseudo-GT mining / box decoding (roi_heads_oicr.py:320-421 reads `proposals` there). */
+int drn_stage_rois(const float* boxes, const float* logits, float batch_index, float* rois, float* obj, float* props, int M,
+                   void* stream);
+
 /* ---- region pooling -------------------------------------------------------------------------- */
 
 /* ROIPooler.forward single-level path, detectron2/modeling/poolers.py:191-226:

@@ -804,6 +804,19 @@ def test_roi_align(drn, dtype, aligned, sr):
     assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), float((got - ref).abs().max())
 
 
+def test_stage_rois_equals_pooler_format(drn):
+    """drn_stage_rois (one launch) == convert_boxes_to_pooler_format + the contiguous copies (poolers.py:69-96), bit for bit"""
+    g = torch.Generator().manual_seed(3)
+    for M in (1, 77, 2000):
+        boxes = (torch.rand((M, 4), generator=g) * 500).to(DEV)
+        logits = torch.randn(M, generator=g).to(DEV)
+        rois, obj, props = drn.stage_rois(boxes, logits, 3.0)
+        ref = torch.cat((torch.full((M, 1), 3.0, device=DEV), boxes), dim=1)
+        assert torch.equal(rois, ref) and torch.equal(obj, logits) and torch.equal(props, boxes)
+        rois2, obj2, props2 = drn.stage_rois(boxes, None)
+        assert obj2 is None and torch.equal(rois2[:, 1:], boxes) and (rois2[:, 0] == 0).all() and torch.equal(props2, boxes)
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 def test_transpose_cast(drn, dtype):
     x = _rnd((130, 75), 15)
