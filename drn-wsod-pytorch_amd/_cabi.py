@@ -41,6 +41,7 @@ _SIGS = {
     "drn_gemm_set_tile": "i",
     "drn_tune": "ii",
     "drn_bias_act_fwd": "pilppQpfplpliiliip",
+    "drn_linear_act_fwd": "pppp" + "Qpf" + "plpl" + "iii" + "ll" + "ip",
     "drn_counter_add": "pQp",
     "drn_colsum_reduce": "piipip",
     "drn_bias_act_bwd": "pilppppfplplppiiiip",

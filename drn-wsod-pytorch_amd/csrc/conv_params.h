@@ -1,5 +1,5 @@
 // Parameter block of the NHWC convolution kernels (gemm_conv.hip: register-staged tiles, LDS-resident 3x3 / 64-channel
-// kernel; conv_dma.hip: the LDS-DMA ring kernels).  Host-built, passed by value.
+// kernel; conv_ring.hip: the register-ring kernels; pp8.hip: the eight-wave 128x128 kernel).  Host-built, passed by value.
 #pragma once
 
 namespace drn_conv {

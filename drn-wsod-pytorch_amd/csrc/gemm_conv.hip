@@ -2233,6 +2233,9 @@ static int g_force_tile = 0;  // 0 = heuristic; 64 / 128 / 256 pin the tile (tun
 // conv_ring.hip: the register-ring kernels (bf16, Cin % 64 == 0); DRN_ERR_UNSUPPORTED outside their class
 __attribute__((visibility("hidden"))) int drn_conv_ring_try(const ConvParams& p, int dtype, int cus, long tiles64_one, hipStream_t st);
 __attribute__((visibility("hidden"))) int drn_conv_ring_set(int v);
+// pp8.hip: the eight-wave 128x128 kernel (bf16, Cin % 64 == 0); DRN_ERR_UNSUPPORTED outside its class
+__attribute__((visibility("hidden"))) int drn_pp8_conv_try(const ConvParams& p, int dtype, int cus, hipStream_t st);
+__attribute__((visibility("hidden"))) int drn_pp8_set(int knob, int v);
 
 extern "C" {
 
@@ -2313,6 +2316,7 @@ int drn_tune(int knob, int value) {
     return old;
   }
   if (knob == 23) return drn_conv_ring_set(value);  // DRN_TUNE_CONV_RING
+  if (knob >= 25 && knob <= 29) return drn_pp8_set(knob, value);  // DRN_TUNE_PP8, _STAGES, _VARIANT, _PROFILE, _WIDE
   if (knob == 24) {  // DRN_TUNE_CONV_PP
     const int old = g_conv_pp;
     if (value >= 0) g_conv_pp = value;
@@ -2569,6 +2573,10 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
   // (>= 16 slabs: 2048 -> 512 at 118 tiles 47 -> 44 us, but 128 -> 512 at 120 tiles 12 -> 15 us); at 59-60 tiles (res4 of the
   // C4 trunk, the DC5 trunk's 1x1s to 256 channels) the small tiles win; a 64-channel output wastes three quarters of the
   // tile.  Decided on ONE image's geometry; same bits as the tiled kernels either way.
+  if (drn_pp8_set(25, -1) == 2) {  // (A/B pin: every layer in the eight-wave kernel's class takes it)
+    const int rc = drn_pp8_conv_try(p, dtype, cu_count(), st);
+    if (rc != DRN_ERR_UNSUPPORTED) return rc;
+  }
   if (g_conv_pp && dtype == DRN_BF16 && out_dtype == DRN_BF16 && (!residual || res_dtype == DRN_BF16) && KH == 1 && KW == 1 &&
       stride == 1 && pad == 0 && (Cin & 63) == 0 && (Cout & 7) == 0 && (ldy & 3) == 0 && (!residual || (ldres & 3) == 0) &&
       (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)residual) & 15) == 0 && (ldw * 2) % 16 == 0 &&
@@ -2578,7 +2586,9 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
       return launch_conv1x1_pp(p, st);
   }
   {
-    const int rc = drn_conv_ring_try(p, dtype, cu_count(), tiles64, st);
+    int rc = drn_pp8_conv_try(p, dtype, cu_count(), st);
+    if (rc != DRN_ERR_UNSUPPORTED) return rc;
+    rc = drn_conv_ring_try(p, dtype, cu_count(), tiles64, st);
     if (rc != DRN_ERR_UNSUPPORTED) return rc;
   }
   // two K-groups per 64x64 tile (conv_nhwc_k2_kernel): mid-size layers - more 64x64 tiles than the wave-K-split kernel

@@ -17,15 +17,7 @@
 
 namespace {
 
-// ---------------------------------------------------------------- counter-based dropout mask
-__device__ __forceinline__ uint32_t hash32(uint64_t x) {
-  x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
-  return (uint32_t)x;
-}
-__device__ __forceinline__ float drop_mult(uint64_t seed, uint64_t idx, float p) {
-  const float u = (hash32(seed * 0x9E3779B97F4A7C15ULL + idx) >> 8) * (1.0f / 16777216.0f);
-  return u < p ? 0.f : 1.f / (1.f - p);
-}
+// (the counter-based dropout mask: drn_drop_rule / drn_drop_mult of drn_common.h)
 
 struct ActParams {
   const float* in;     // fwd: split-K partials [splits][M][ld_in]; bwd: upstream grad [M][ld_in]
@@ -74,6 +66,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
     cscale = ci >= 0 ? p.colscale[ci] : 0.f;
   }
   const unsigned long long seed = p.seed + ((!BWD && p.seed_dev) ? p.seed_dev[0] : 0ULL);
+  [[maybe_unused]] const DrnDropRule drop = drn_drop_rule(seed, p.drop_p);
   if (!BWD && p.seed_dev && p.drop_p <= 0.f && !p.mask && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     *const_cast<unsigned long long*>(p.seed_dev) += p.seed;  // no dropout here: this launch ADVANCES the mask counter
   for (int mb = mb0; mb < mb1; mb += 64) {
@@ -100,7 +93,7 @@ __global__ __launch_bounds__(256) void act_kernel(ActParams p) {
           if (p.bias) v += p.bias[n];
           if (p.relu) v = fmaxf(v, 0.f);
           if (p.mask) v *= p.mask[(long)m * p.N + n];
-          else if (p.drop_p > 0.f) v *= drop_mult(seed, (uint64_t)m * p.N + n, p.drop_p);
+          else if (p.drop_p > 0.f) v *= drn_drop_mult(drop, (unsigned long long)m * p.N + n);
         } else {
           if (p.in_bf16) {
             v = bf16_to_f32(((const bf16_t*)p.in)[(long)m * p.ld_in + n]);
@@ -225,6 +218,7 @@ __global__ __launch_bounds__(256) void act_vec_kernel(ActParams p) {
     }
   }
   const unsigned long long seed = p.seed + ((!BWD && p.seed_dev) ? p.seed_dev[0] : 0ULL);
+  [[maybe_unused]] const DrnDropRule drop = drn_drop_rule(seed, p.drop_p);
   if (!BWD && p.seed_dev && p.drop_p <= 0.f && !p.mask && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0)
     *const_cast<unsigned long long*>(p.seed_dev) += p.seed;  // no dropout here: this launch ADVANCES the mask counter
   f32x4v bias4 = {0.f, 0.f, 0.f, 0.f};
@@ -245,8 +239,10 @@ __global__ __launch_bounds__(256) void act_vec_kernel(ActParams p) {
         }
         if (p.mask) v *= *(const f32x4v*)(p.mask + (long)m * p.N + n0);
         else if (p.drop_p > 0.f) {
+          float dm[4];
+          drn_drop_mult4(drop, (unsigned long long)m * p.N + n0, dm);  // (N % 4 == 0 and n0 % 4 == 0: an aligned group)
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] *= drop_mult(seed, (uint64_t)m * p.N + n0 + e, p.drop_p);
+          for (int e = 0; e < 4; ++e) v[e] *= dm[e];
         }
       } else {
         if constexpr (KC > 0) v += *(const f32x4v*)&t[i][tx * 4];

@@ -613,7 +613,13 @@ class _HeadEngine:
         nslab = K * ops.esize(dtype) // 128
         return max(1, min(1024 // max(tiles, 1), max(1, nslab // 8), 16))
 
-    def _linear_fwd(self, A, Wt, M, N, K, bias, relu, out, outT, mask, seed, drop_p, seed_dev=None):
+    def _linear_fwd(self, A, Wt, M, N, K, bias, relu, out, outT, mask, seed, drop_p, seed_dev=None, fused=False):
+        # fused (fc7, bf16): GEMM + bias + ReLU + dropout + the transposed copy as ONE launch of the eight-wave 128x128 kernel
+        # (drn_linear_act_fwd) - no split-K partials, no second pass; outside that kernel's class the two-launch form below
+        if (fused and A.dtype == torch.bfloat16 and getattr(self, "fused_fc7_fwd", True) and out is not None and
+                out.dtype == torch.bfloat16 and
+                ops.linear_act_fwd(A, Wt, M, N, K, bias, relu, mask, seed, drop_p, out=out, outT=outT, seed_dev=seed_dev)):
+            return
         s = self._splits(M, N, K, A.dtype)
         part = ops.gemm_nt(A, Wt, M, N, K, splits=s)
         ops.bias_act_fwd(part, M, N, bias, relu, mask, seed, drop_p, out=out, outT=outT, seed_dev=seed_dev)
@@ -820,7 +826,7 @@ class _HeadEngine:
             self._linear_fwd(w["A"], sh["W1v"], M, D1, kp(K1), fc1.bias.data, True, w["H1"],
                              w["H1T"] if training else None, masks[0] if masks else None, seed, drop_p, seed_dev)
         self._linear_fwd(w["H1"], sh["W2"], M, D2, kp(D1), fc2.bias.data, True, w["H2"], w["H2T"] if training else None,
-                         masks[1] if masks else None, seed + 0x9E3779B1, drop_p, seed_dev)
+                         masks[1] if masks else None, seed + 0x9E3779B1, drop_p, seed_dev, fused=True)
         bo, _ = self._seg[self.cols[0][0] + ".bias"]
         # (the logits pass has no dropout: given the counter it advances it - behind both dropout layers - instead of a
         # counter_add launch of its own on the heads' dependent chain)

@@ -40,6 +40,7 @@ def gemm_set_tile(tile):
 TUNE_GEMM_PERSISTENT, TUNE_SGD_GRID, TUNE_GEMM_GROUP_ROWS, TUNE_ROI_MAP64, TUNE_CONV_KSPLIT, TUNE_GEMM_TAIL_SPLIT, TUNE_CONV_KS_TILES, TUNE_CONV_K2_TILES, TUNE_CONV_PATCH = 1, 2, 3, 4, 5, 6, 7, 8, 9
 TUNE_CONV_RING = 23
 TUNE_CONV_PP = 24
+TUNE_PP8, TUNE_PP8_STAGES, TUNE_PP8_VARIANT, TUNE_PP8_PROFILE, TUNE_PP8_WIDE = 25, 26, 27, 28, 29
 TUNE_ROI_CPB, TUNE_ROI_PREFETCH, TUNE_GEMM_PINGPONG, TUNE_FP8_K64, TUNE_ROI_MAP64_A, TUNE_ROI_LDS_KB = 10, 11, 12, 13, 14, 15
 
 
@@ -405,6 +406,21 @@ def bias_act_fwd(partials, M, N, bias=None, relu=True, mask=None, seed=0, drop_p
            float(drop_p),
            C.ptr(out), _2d(out) if out is not None else 0, C.ptr(outT), _2d(outT) if outT is not None else 0, M, N,
            partials.stride(-2), int(relu), C.dt(ref.dtype), C.stream())
+
+
+def linear_act_fwd(A, W, M, N, K, bias=None, relu=True, mask=None, seed=0, drop_p=0.0, out=None, outT=None, seed_dev=None):
+    """drn_linear_act_fwd: out [M, N] (bf16) = dropout(relu(A[M,:K] @ W[N,:K]^T + bias)) and optionally its transpose, ONE launch
+    (no split-K partials, no second pass).  Returns False when the shape is outside the kernel's class (the caller then runs
+    gemm_nt + bias_act_fwd)."""
+    assert A.dtype == W.dtype == torch.bfloat16 and out is not None and out.dtype == torch.bfloat16
+    rc = C.lib().drn_linear_act_fwd(C.ptr(A), C.ptr(W), C.ptr(bias), C.ptr(mask), int(seed), C.ptr(seed_dev), float(drop_p),
+                                    C.ptr(out), _2d(out), C.ptr(outT), _2d(outT) if outT is not None else 0, M, N, K, _2d(A),
+                                    _2d(W), int(relu), C.stream())
+    if rc == -3:
+        return False
+    if rc != 0:
+        raise C.DrnError("drn_linear_act_fwd failed (%d)" % rc)
+    return True
 
 
 def bias_act_bwd(grad_out, M, N, saved=None, mask=None, drop_p=0.0, colscale=None, dpre=None, dpreT=None, colsum=None,

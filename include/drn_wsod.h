@@ -251,10 +251,26 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_SGDP_EPILOGUE 20 /* 0/1 (default 1): the tile epilogue of drn_gemm_tn_sgd moves the bf16 gradient tile LDS -> global four 16-byte pieces per trip instead of one (A/B knob; bit-identical) */
 #define DRN_TUNE_ROI_LANE_REPS 22 /* lane-per-bin ROIPool on maps that leave one block per CU: groups of 64 ROIs a block walks with one staged map slice (0 = default: 4, halved while fewer than two rounds of blocks would remain; 1 = a block per group) */
 #define DRN_TUNE_ROI_LANE 19 /* 0/1 (default 1): the bf16 training operand A from the lane-per-bin ROIPool kernel (a wave per ROI, lane = bin: every channel leaves as one 98-byte run per store instruction); 0 = the 64-ROI kernel writes A */
-#define DRN_TUNE_CONV_RING 23 /* register-ring conv kernels (conv_ring.hip; bf16, Cin % 64 == 0, layers beyond the latency-bound small maps): 0 = off (the tiles of gemm_conv.hip), 1 = default (tile by cost model), 64 / 96 / 128 = pin the 64x64 / 128x64 / 128x128 tile; every tile gives the same bits as the 64x64 / 128x128 tiled kernel */
+#define DRN_TUNE_CONV_RING 23 /* register-ring conv kernels (conv_ring.hip; bf16, Cin % 64 == 0, layers beyond the latency-bound small maps): 0 = off (the tiles of gemm_conv.hip), 1 = default (64x64 tile, class by measurement), 64 / 128 = pin the 64x64 / 128x128 tile (any other value is ignored: drn_tune returns the unchanged setting); every tile gives the same bits as the 64x64 / 128x128 tiled kernel */
 #define DRN_TUNE_CONV_PP 24 /* 1x1 / stride-1 bf16 convs of large maps on the 256x256 ping-pong GEMM mainloop with the conv epilogue (conv1x1_pp_kernel): 0 = off, 1 = default (Cout >= 256 and >= 192 tiles of 256x256 per image, or >= 100 tiles with K >= 1024), n > 1 = at least n tiles, any Cout; same bits as the tiled kernels */
 #define DRN_TUNE_CONV_PATCH 9 /* 0 = never use the LDS-resident-patch kernel for 3x3 / 64 -> 64 channel convs; 1 = default (maps of >= 32768 pixels); > 1 = that many pixels per image at least */
+#define DRN_TUNE_PP8 25 /* eight-wave ping-pong kernel (pp8.hip: 128x128 or 256x128 tile, two waves per SIMD half a phase apart; bf16 convs with Cin % 64 == 0 and drn_linear_act_fwd): 0 = off, 1 = default class (measured per layer shape, see drn_pp8_conv_try), 2 = every layer in the kernel's class; same bits as the tiled kernels */
+#define DRN_TUNE_PP8_STAGES 26 /* 3 / 4 / 5 (default 5): 32-KB LDS stages of the 128x128 form's ring = 1 / 2 / 3 K slabs in flight (A/B knob; bit-identical) */
+#define DRN_TUNE_PP8_VARIANT 27 /* schedule variant of that kernel (A/B knob; bit-identical): 0 = a slab's four DMA pieces in the fragment-read phase, 1 (default) = two there and two between the MFMAs, 2 = all between the MFMAs, + 4 = no s_setprio around the MFMAs, + 8 = profile build (shader-clock split of the mainloop) */
+#define DRN_TUNE_PP8_PROFILE 28 /* any value: print (stderr) and clear the per-phase shader-clock sums the profile builds (DRN_TUNE_PP8_VARIANT + 8) accumulated for workgroup 0; returns 0 */
+#define DRN_TUNE_PP8_WIDE 29 /* the 256x128 form of that kernel (wave tile 64x64, three 48-KB stages): 0 = never, 1 = default (layers that give it >= 5/8 of the CUs' worth of tiles per image), 2 = always */
 int drn_tune(int knob, int value);
+
+/* relu_(fc(x)) + F.dropout(p) of DiscriminativeAdaptionNeck.forward (projects/WSL/wsl/modeling/roi_heads/box_head.py:82-91)
+ * as ONE launch for bf16 operands: out [M][ld_out] (bf16) = dropout(relu(A [M][lda] . W [N][ldw]^T + bias)), and optionally
+ * its transpose outT [N][ld_outT] (rows m >= M of outT are left untouched).  Same dropout rule as drn_bias_act_fwd (explicit
+ * mask [M][N], else counter-based from seed (+ *seed_dev) when drop_p > 0; this entry never advances the counter); the
+ * product is accumulated over K in one fp32 chain per element (= drn_gemm_nt with splits == 1 followed by
+ * drn_bias_act_fwd, bit for bit).  K % 64 == 0, N % 8 == 0, 16-byte aligned rows; DRN_ERR_UNSUPPORTED outside that class
+ * (the caller then runs the two-launch form). */
+int drn_linear_act_fwd(const void* A, const void* W, const float* bias, const float* mask, unsigned long long seed,
+                       const unsigned long long* seed_dev, float drop_p, void* out, long ld_out, void* outT, long ld_outT,
+                       int M, int N, int K, long lda, long ldw, int relu, void* stream);
 
 /* relu_(fc(x)) + F.dropout(p), box_head.py:88-90: sums split-K partials, adds bias, ReLU, dropout
  * (explicit multiplier mask [M][N] if given, else counter-based mask from seed (+ *seed_dev) when drop_p > 0; a launch

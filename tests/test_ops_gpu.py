@@ -529,6 +529,7 @@ def test_conv_ring_kernels(drn, case):
     assert drn.tune(drn.TUNE_CONV_RING, 0) == 1
     k2 = drn.tune(drn.TUNE_CONV_K2_TILES, 0)
     ks = drn.tune(drn.TUNE_CONV_KSPLIT, 0)
+    p8 = drn.tune(drn.TUNE_PP8, 0)
     try:
         tiled = run()  # conv_nhwc_kernel<64x64 | 128x128>
         ys = {}
@@ -541,12 +542,140 @@ def test_conv_ring_kernels(drn, case):
         drn.tune(drn.TUNE_CONV_RING, 1)
         drn.tune(drn.TUNE_CONV_K2_TILES, k2)
         drn.tune(drn.TUNE_CONV_KSPLIT, ks)
+        drn.tune(drn.TUNE_PP8, p8)
     torch.cuda.synchronize()
     for pin, y in ys.items():
         assert torch.equal(y, tiled), (pin, float((y.float() - tiled.float()).abs().max()))
     assert torch.equal(again, tiled)
     got = tiled.float().cpu().permute(0, 3, 1, 2)
     assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
+
+
+PP8_CASES = [(1, 99, 151, 256, 256, 3, 1, 2, 2, False, True),    # dilated-C5 res4 3x3 at 800x1216: 117 x 2 tiles, 36 slabs
+             (1, 50, 76, 512, 512, 3, 1, 2, 2, False, True),     # dilated res5 3x3 (72 slabs)
+             (1, 50, 76, 1024, 256, 1, 1, 0, 1, False, True),    # res4 conv1 (16 slabs)
+             (1, 50, 76, 256, 1024, 1, 1, 0, 1, True, True),     # res4 conv3 + shortcut (4 slabs)
+             (1, 100, 152, 128, 128, 3, 1, 1, 1, False, True),   # res3 3x3
+             (1, 100, 152, 128, 512, 1, 1, 0, 1, True, True),    # two slabs: fewer than the ring holds
+             (1, 131, 97, 64, 72, 1, 1, 0, 1, True, False),      # ONE slab, ragged M and a ragged column tile
+             (2, 61, 67, 64, 136, 3, 2, 1, 1, True, True),       # stride 2, two images, Cout % 128 != 0
+             (3, 45, 52, 192, 200, 3, 1, 3, 3, False, False),    # dilation 3, three slabs per tap
+             (4, 28, 28, 512, 2048, 1, 1, 0, 1, True, True)]     # a trunk group of four 224x224 images
+
+
+@pytest.mark.parametrize("case", PP8_CASES)
+def test_pp8_conv_kernel(drn, case):
+    """pp8_kernel<conv> (pp8.hip: 128x128 or 256x128 tile on EIGHT waves, the two waves of a SIMD half a phase apart, LDS-DMA ring
+    of 3 / 4 / 5 stages, im2col by per-lane source offsets with out-of-range zero fill) == the register-staged tiled kernel bit
+    for bit (same slab order, k-steps and MFMA per output element) at every ring depth, schedule variant and tile shape, run to
+    run, and within bf16 rounding of F.conv2d; zero padding at every border, ragged M / Cout tiles, fewer slabs than ring stages, stride, dilation, residual."""
+    n, h, w, cin, cout, k, stride, pad, dil, has_res, relu = case
+    dtype = torch.bfloat16
+    x = _rnd((n, cin, h, w), 75)
+    wt = _rnd((cout, cin, k, k), 76, math.sqrt(2.0 / (cin * k * k)))
+    scale, bias = (0.8 + 0.2 * torch.rand(cout)).to(DEV), _rnd((cout,), 77, 0.1).to(DEV)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    ref = F.conv2d(_q(x, dtype), _q(wt, dtype), None, stride, pad, dil) * scale.cpu().view(1, -1, 1, 1) + bias.cpu().view(1, -1, 1, 1)
+    res = None
+    if has_res:
+        res = _rnd(tuple(ref.shape), 78)
+        ref = ref + _q(res, dtype)
+        res = res.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    if relu:
+        ref = F.relu(ref)
+    wp = _pack_w(wt, dtype, drn, cin)
+    run = lambda: drn.conv2d_nhwc(xd, wp, cout, k, k, stride, pad, dil, scale, bias, res, relu)
+    assert drn.tune(drn.TUNE_PP8, 0) == 1
+    ring = drn.tune(drn.TUNE_CONV_RING, 0)
+    k2 = drn.tune(drn.TUNE_CONV_K2_TILES, 0)
+    ks = drn.tune(drn.TUNE_CONV_KSPLIT, 0)
+    cpp = drn.tune(drn.TUNE_CONV_PP, 0)
+    try:
+        tiled = run()  # conv_nhwc_kernel<64x64 | 128x128>
+        drn.tune(drn.TUNE_PP8, 2)
+        ys = {}
+        for stages, variant, wide in ((3, 0, 0), (4, 0, 0), (4, 1, 0), (5, 0, 0), (5, 2, 0), (5, 5, 0), (5, 1, 0), (5, 1, 2), (5, 1, 1)):
+            drn.tune(drn.TUNE_PP8_STAGES, stages)
+            drn.tune(drn.TUNE_PP8_VARIANT, variant)
+            drn.tune(drn.TUNE_PP8_WIDE, wide)  # 2: the 256x128 form (three 48-KB stages) whatever the tile count
+            ys[(stages, variant, wide)] = [run() for _ in range(3)]
+    finally:
+        drn.tune(drn.TUNE_PP8, 1)
+        drn.tune(drn.TUNE_PP8_STAGES, 5)
+        drn.tune(drn.TUNE_PP8_VARIANT, 1)
+        drn.tune(drn.TUNE_PP8_WIDE, 1)
+        drn.tune(drn.TUNE_CONV_RING, ring)
+        drn.tune(drn.TUNE_CONV_K2_TILES, k2)
+        drn.tune(drn.TUNE_CONV_KSPLIT, ks)
+        drn.tune(drn.TUNE_CONV_PP, cpp)
+    torch.cuda.synchronize()
+    for stages, lst in ys.items():
+        for y in lst:
+            assert torch.equal(y, tiled), (stages, float((y.float() - tiled.float()).abs().max()))
+    got = tiled.float().cpu().permute(0, 3, 1, 2)
+    assert torch.allclose(got, ref, rtol=2 ** -7, atol=2e-2), float((got - ref).abs().max())
+
+
+@pytest.mark.parametrize("M,N,K,mode,relu", [(2000, 4096, 2048, "drop", True),   # fc7 of R50-C4 at the bench shape: 16 x 32 tiles
+                                              (1937, 520, 192, "mask", True),     # ragged M, a ragged column tile, three slabs
+                                              (300, 256, 64, "none", False),      # ONE slab, no activation
+                                              (77, 136, 4096, "drop", True)])     # fewer rows than a tile, deep K
+def test_linear_act_fwd_equals_gemm_then_act(drn, M, N, K, mode, relu):
+    """drn_linear_act_fwd (relu_(fc(x)) + dropout as ONE launch of the eight-wave kernel, box_head.py:88-90) == drn_gemm_nt
+    (splits = 1, fp32 out) + drn_bias_act_fwd, bit for bit: the bf16 output and its transposed copy (whose rows beyond M stay
+    untouched), explicit mask / counter-based dropout with the device-side counter / no dropout, at every ring depth."""
+    rs = np.random.RandomState(91)
+    dt = torch.bfloat16
+    Kp = drn.kpad(K + 24, dt)  # a row pitch beyond K
+    A = torch.zeros((M, Kp), dtype=dt, device=DEV)
+    A[:, :K] = torch.from_numpy(rs.standard_normal((M, K)).astype(np.float32) * 0.3).to(DEV).to(dt)
+    W = torch.zeros((N, Kp), dtype=dt, device=DEV)
+    W[:, :K] = torch.from_numpy(rs.standard_normal((N, K)).astype(np.float32) * (1.0 / math.sqrt(K))).to(DEV).to(dt)
+    bias = torch.from_numpy(rs.standard_normal((N,)).astype(np.float32) * 0.1).to(DEV)
+    mask, drop_p, seed, seed_dev = None, 0.0, 0, None
+    if mode == "mask":
+        mask = torch.from_numpy(((rs.rand(M, N) > 0.5) * 2.0).astype(np.float32)).to(DEV)
+    elif mode == "drop":
+        drop_p, seed = 0.5, 0x1234567
+        seed_dev = torch.full((1,), 41, dtype=torch.int64, device=DEV)
+    Mp = drn.kpad(M, dt)
+    outs = []
+    for fused in (0, (3, 0), (4, 0), (5, 0), (5, 2), (5, 1)):  # (ring stages, 256x128 form)
+        out = torch.zeros((M, N), dtype=dt, device=DEV)
+        outT = torch.full((N, Mp), 7.0, dtype=dt, device=DEV)
+        kw = dict(bias=bias, relu=relu, mask=mask, seed=seed, drop_p=drop_p, out=out, outT=outT, seed_dev=seed_dev)
+        if fused:
+            drn.tune(drn.TUNE_PP8_STAGES, fused[0])
+            drn.tune(drn.TUNE_PP8_WIDE, fused[1])
+            try:
+                assert drn.linear_act_fwd(A, W, M, N, K, **kw)
+            finally:
+                drn.tune(drn.TUNE_PP8_STAGES, 5)
+                drn.tune(drn.TUNE_PP8_WIDE, 1)
+        else:
+            drn.bias_act_fwd(drn.gemm_nt(A, W, M, N, K), M, N, **kw)
+        outs.append((out, outT))
+    torch.cuda.synchronize()
+    for o, oT in outs[1:]:
+        assert torch.equal(o, outs[0][0])
+        assert torch.equal(oT, outs[0][1])
+    assert torch.equal(outs[0][1][:, :M].t().contiguous(), outs[0][0])
+    assert bool((outs[1][1][:, M:] == 7.0).all())
+    if seed_dev is not None:
+        assert int(seed_dev.item()) == 41  # a dropout launch reads the counter, only the logits pass advances it
+    ref = A[:, :K].float().cpu() @ W[:, :K].float().cpu().t() + bias.cpu()
+    if relu:
+        ref = F.relu(ref)
+    if mode == "none":
+        assert torch.allclose(outs[1][0].float().cpu(), ref, rtol=2 ** -7, atol=2e-2)
+    elif mode == "mask":
+        assert torch.allclose(outs[1][0].float().cpu(), ref * mask.cpu(), rtol=2 ** -7, atol=2e-2)
+    else:
+        keep = (outs[1][0].float().cpu() != 0) | (ref == 0)
+        assert abs(float(keep.float().mean()) - (0.5 + 0.5 * float((ref == 0).float().mean()))) < 0.02
+        assert torch.allclose(outs[1][0].float().cpu()[keep], (2 * ref)[keep], rtol=2 ** -7, atol=2e-2)
+    # outside the kernel's class: refused, not mis-computed
+    assert drn.linear_act_fwd(A, W, M, N, K - 32, out=outs[0][0]) is False
 
 
 @pytest.mark.parametrize("shape", [(375, 500, 480, 640), (375, 500, 1152, 1536), (333, 500, 864, 1297), (500, 375, 240, 180),
@@ -599,6 +728,7 @@ def test_conv1x1_pp_kernel(drn, case):
     ring = drn.tune(drn.TUNE_CONV_RING, 0)
     k2 = drn.tune(drn.TUNE_CONV_K2_TILES, 0)
     ks = drn.tune(drn.TUNE_CONV_KSPLIT, 0)
+    p8 = drn.tune(drn.TUNE_PP8, 0)
     try:
         tiled = run()  # conv_nhwc_kernel<128x128>
         drn.tune(drn.TUNE_CONV_PP, 2)  # (any layer of >= 2 tiles)
@@ -606,6 +736,7 @@ def test_conv1x1_pp_kernel(drn, case):
         again = run()
     finally:
         drn.tune(drn.TUNE_CONV_PP, 1)
+        drn.tune(drn.TUNE_PP8, p8)
         drn.tune(drn.TUNE_CONV_RING, ring)
         drn.tune(drn.TUNE_CONV_K2_TILES, k2)
         drn.tune(drn.TUNE_CONV_KSPLIT, ks)
