@@ -42,11 +42,13 @@ __device__ __forceinline__ uint8_t f32_to_fp8(float f) {
 
 // Counter-based dropout multipliers (F.dropout's Bernoulli mask of DiscriminativeAdaptionNeck.forward,
 // projects/WSL/wsl/modeling/roi_heads/box_head.py:89-91; the backward reads the mask off the saved output, so only the forward
-// draws).  One 32-bit hash (murmur3 finaliser) per group of FOUR consecutive element indices: when p is a multiple of 1/256 -
-// p = 0.5 in every config - byte e of the group's hash decides element 4 g + e (keep iff byte >= 256 p: exactly probability
-// 1 - p); any other p draws a 24-bit uniform per element.  (Rounds 1-5 hashed every element with two 64-bit multiplies: ~35
-// VALU instructions per element - 12 us of a GEMM epilogue that owns 64 elements per lane.)
-struct DrnDropRule { uint32_t s0; int q; float p, scale; };
+// draws).  32-bit hashes (murmur3 finaliser) of the element index, shared by neighbouring elements:
+//   p == 0.5 (box_head.py:90 hard-codes it): ONE hash per 32 consecutive indices, bit (idx & 31) decides element idx - a lane of a
+//     GEMM epilogue that owns 16 elements of a 32-column block draws one hash for all of them;
+//   any other p: a 24-bit uniform per element from a hash of its own.
+// (Rounds 1-5 hashed every element with two 64-bit multiplies: ~35 VALU instructions per element - 12 us of a GEMM epilogue
+// that owns 64 elements per lane.)
+struct DrnDropRule { uint32_t s0; int half; float p, scale; };
 __device__ __forceinline__ uint32_t drn_fmix32(uint32_t x) {
   x ^= x >> 16; x *= 0x85ebca6bu; x ^= x >> 13; x *= 0xc2b2ae35u; x ^= x >> 16;
   return x;
@@ -54,8 +56,7 @@ __device__ __forceinline__ uint32_t drn_fmix32(uint32_t x) {
 __device__ __forceinline__ DrnDropRule drn_drop_rule(unsigned long long seed, float p) {
   DrnDropRule r;
   r.s0 = drn_fmix32((uint32_t)seed ^ drn_fmix32((uint32_t)(seed >> 32) + 0x9E3779B9u));
-  const float q = p * 256.f;
-  r.q = (q == floorf(q) && q > 0.f && q < 256.f) ? (int)q : -1;
+  r.half = p == 0.5f;
   r.p = p;
   r.scale = 1.f / (1.f - p);
   return r;
@@ -63,24 +64,23 @@ __device__ __forceinline__ DrnDropRule drn_drop_rule(unsigned long long seed, fl
 __device__ __forceinline__ uint32_t drn_drop_hash(const DrnDropRule& r, unsigned long long key) {
   return drn_fmix32((uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x7FEB352Du + r.s0);
 }
-// multipliers of the four elements idx .. idx + 3 (idx % 4 == 0)
-__device__ __forceinline__ void drn_drop_mult4(const DrnDropRule& r, unsigned long long idx, float (&m)[4]) {
-  if (r.q >= 0) {
-    const uint32_t h = drn_drop_hash(r, idx >> 2);
-#pragma unroll
-    for (int e = 0; e < 4; ++e) m[e] = (int)((h >> (8 * e)) & 255u) >= r.q ? r.scale : 0.f;
-  } else {
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const float u = (drn_drop_hash(r, (idx + e) ^ 0x5bd1e99500000000ULL) >> 8) * (1.0f / 16777216.0f);
-      m[e] = u < r.p ? 0.f : r.scale;
-    }
-  }
-}
+// p == 0.5: the 32 keep bits of the indices 32 g .. 32 g + 31
+__device__ __forceinline__ uint32_t drn_drop_bits32(const DrnDropRule& r, unsigned long long g) { return drn_drop_hash(r, g); }
 __device__ __forceinline__ float drn_drop_mult(const DrnDropRule& r, unsigned long long idx) {
-  if (r.q >= 0) return (int)((drn_drop_hash(r, idx >> 2) >> (8 * (int)(idx & 3))) & 255u) >= r.q ? r.scale : 0.f;
+  if (r.half) return ((drn_drop_bits32(r, idx >> 5) >> (int)(idx & 31)) & 1u) ? r.scale : 0.f;
   const float u = (drn_drop_hash(r, idx ^ 0x5bd1e99500000000ULL) >> 8) * (1.0f / 16777216.0f);
   return u < r.p ? 0.f : r.scale;
+}
+// multipliers of the four elements idx .. idx + 3 (idx % 4 == 0: they share a 32-index group)
+__device__ __forceinline__ void drn_drop_mult4(const DrnDropRule& r, unsigned long long idx, float (&m)[4]) {
+  if (r.half) {
+    const uint32_t h = drn_drop_bits32(r, idx >> 5) >> (int)(idx & 31);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = ((h >> e) & 1u) ? r.scale : 0.f;
+  } else {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) m[e] = drn_drop_mult(r, idx + e);
+  }
 }
 
 // one row of the optimizer's segment table (device memory, refreshed in place when the LR schedule moves)

@@ -2316,7 +2316,7 @@ int drn_tune(int knob, int value) {
     return old;
   }
   if (knob == 23) return drn_conv_ring_set(value);  // DRN_TUNE_CONV_RING
-  if (knob >= 25 && knob <= 29) return drn_pp8_set(knob, value);  // DRN_TUNE_PP8, _STAGES, _VARIANT, _PROFILE, _WIDE
+  if (knob >= 25 && knob <= 30) return drn_pp8_set(knob, value);  // DRN_TUNE_PP8, _STAGES, _VARIANT, _PROFILE, _WIDE, _WIDE_VARIANT
   if (knob == 24) {  // DRN_TUNE_CONV_PP
     const int old = g_conv_pp;
     if (value >= 0) g_conv_pp = value;
@@ -2577,18 +2577,24 @@ int drn_conv2d_nhwc_q(const void* x, const void* w, void* y, const float* scale,
     const int rc = drn_pp8_conv_try(p, dtype, cu_count(), st);
     if (rc != DRN_ERR_UNSUPPORTED) return rc;
   }
-  if (g_conv_pp && dtype == DRN_BF16 && out_dtype == DRN_BF16 && (!residual || res_dtype == DRN_BF16) && KH == 1 && KW == 1 &&
-      stride == 1 && pad == 0 && (Cin & 63) == 0 && (Cout & 7) == 0 && (ldy & 3) == 0 && (!residual || (ldres & 3) == 0) &&
-      (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)residual) & 15) == 0 && (ldw * 2) % 16 == 0 &&
-      (long)Cout * ldw * 2 < 0xFFFFFFF0L) {
-    const long t256 = (((long)Ho * Wo + 255) / 256) * ((Cout + 255) / 256);
-    if (g_conv_pp > 1 ? t256 >= g_conv_pp : (Cout >= 256 && (t256 >= 192 || (t256 >= 100 && (Cin >> 6) >= 16))))
-      return launch_conv1x1_pp(p, st);
-  }
+  const bool pp_ok = g_conv_pp && dtype == DRN_BF16 && out_dtype == DRN_BF16 && (!residual || res_dtype == DRN_BF16) && KH == 1 &&
+                     KW == 1 && stride == 1 && pad == 0 && (Cin & 63) == 0 && (Cout & 7) == 0 && (ldy & 3) == 0 &&
+                     (!residual || (ldres & 3) == 0) &&
+                     (((uintptr_t)x | (uintptr_t)w | (uintptr_t)y | (uintptr_t)residual) & 15) == 0 && (ldw * 2) % 16 == 0 &&
+                     (long)Cout * ldw * 2 < 0xFFFFFFF0L;
+  const long t256 = (((long)Ho * Wo + 255) / 256) * ((Cout + 255) / 256);
+  // (1) >= 3/4 of the CUs' worth of 256x256 tiles: the ping-pong GEMM mainloop, whatever K
+  if (pp_ok && (g_conv_pp > 1 ? t256 >= g_conv_pp : (Cout >= 256 && t256 >= 192))) return launch_conv1x1_pp(p, st);
+  // (2) the eight-wave 128x128 / 256x128 kernel (pp8.hip; round 6): layers with too few 256x256 tiles for (1) - the 3x3s of
+  // res4 / res5, the 1x1s to 256 / 512 channels of the dilated-C5 trunk, the C4 trunk's 1x1s to 1024 channels
   {
-    int rc = drn_pp8_conv_try(p, dtype, cu_count(), st);
+    const int rc = drn_pp8_conv_try(p, dtype, cu_count(), st);
     if (rc != DRN_ERR_UNSUPPORTED) return rc;
-    rc = drn_conv_ring_try(p, dtype, cu_count(), tiles64, st);
+  }
+  // (3) 100-191 tiles of 256x256 with a long K loop (round 5's class; reached when (2) is switched off)
+  if (pp_ok && g_conv_pp == 1 && Cout >= 256 && t256 >= 100 && (Cin >> 6) >= 16) return launch_conv1x1_pp(p, st);
+  {
+    const int rc = drn_conv_ring_try(p, dtype, cu_count(), tiles64, st);
     if (rc != DRN_ERR_UNSUPPORTED) return rc;
   }
   // two K-groups per 64x64 tile (conv_nhwc_k2_kernel): mid-size layers - more 64x64 tiles than the wave-K-split kernel

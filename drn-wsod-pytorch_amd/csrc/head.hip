@@ -318,9 +318,19 @@ static inline bool act_vec_ok(const ActParams& p, int out_dtype) {
 __global__ void colsum_reduce_kernel(const float* colpart, int nparts, int N, float* colsum, int accumulate) {
   const int n = blockIdx.x * blockDim.x + threadIdx.x;
   if (n >= N) return;
+  // sixteen partials in flight per trip (a load-add-load-add chain is one memory round trip per partial: this launch runs
+  // beside the step's HBM-saturating fc6 dW GEMM, where a round trip is ~15 us - 530 us for 32 partials, which pushed the
+  // small-tensor SGD behind it past the end of the GEMM and into the next step's start); same order of addition
   float s = 0.f;
-  for (int q = 0; q < nparts; ++q) s += colpart[(long)q * N + n];
-  colsum[n] = accumulate ? colsum[n] + s : s;
+  const float prev = accumulate ? colsum[n] : 0.f;
+  for (int q0 = 0; q0 < nparts; q0 += 16) {
+    float t[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) t[k] = colpart[(long)min(q0 + k, nparts - 1) * N + n];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s = q0 + k < nparts ? s + t[k] : s;
+  }
+  colsum[n] = accumulate ? prev + s : s;
 }
 
 // ---------------------------------------------------------------- block reductions (1024 threads)
@@ -996,13 +1006,17 @@ __global__ __launch_bounds__(256) void boxreg_grad_kernel(BoxRegParams p, const 
 // instead of 8 - and the running means in LDS instead of read-modify-write passes over `probs` in global memory: 44 -> ~10 us of
 // every inference pass (profiles/r5_60_tta_dc5_kernel_stats.txt).
 constexpr int MSM_THREADS = 64;
+// LDS_ACC = false (more than 256 classes - the LVIS-sized heads: C x 256 bytes of LDS would not fit): the running means live
+// in the output row itself (read-modify-write per head; the same additions in the same order, so the same bits).
+template <bool LDS_ACC>
 __global__ __launch_bounds__(MSM_THREADS) void mean_softmax_kernel(const float* logits, long ld, const int* col0s, int n_heads, int C,
                                                                    float* probs, int M, int bg_first) {
   extern __shared__ float msm_acc[];  // [C][MSM_THREADS]: a thread's column - conflict-free
   const int r = blockIdx.x * MSM_THREADS + threadIdx.x;
   if (r >= M) return;
-  float* acc = msm_acc + threadIdx.x;
-  for (int c = 0; c < C; ++c) acc[c * MSM_THREADS] = 0.f;
+  float* acc = LDS_ACC ? msm_acc + threadIdx.x : probs + (long)r * C;
+  const int pitch = LDS_ACC ? MSM_THREADS : 1;
+  for (int c = 0; c < C; ++c) acc[c * pitch] = 0.f;
   for (int h = 0; h < n_heads; ++h) {
     const float* row = logits + (long)r * ld + col0s[h];
     float mx = -FLT_MAX;
@@ -1011,10 +1025,10 @@ __global__ __launch_bounds__(MSM_THREADS) void mean_softmax_kernel(const float* 
     for (int c = 0; c < C; ++c) se += expf(row[c] - mx);
     for (int c = 0; c < C; ++c) {
       const int oc = bg_first ? (c == 0 ? C - 1 : c - 1) : c;
-      acc[oc * MSM_THREADS] += expf(row[c] - mx) / se;
+      acc[oc * pitch] += expf(row[c] - mx) / se;
     }
   }
-  for (int c = 0; c < C; ++c) probs[(long)r * C + c] = acc[c * MSM_THREADS] / (float)n_heads;
+  for (int c = 0; c < C; ++c) probs[(long)r * C + c] = acc[c * pitch] / (float)n_heads;
 }
 
 // Box2BoxTransform.apply_deltas; deltas == null means all-zero deltas (non-regressing heads)
@@ -1473,10 +1487,14 @@ int drn_mean_softmax(const float* logits, long ld, const int* col0s_dev, int n_h
                      int bg_first, void* stream) {
   if (!logits || !col0s_dev || !probs || n_heads < 1) return DRN_ERR_ARG;
   if (M == 0) return DRN_OK;
-  if (C < 1 || (size_t)C * MSM_THREADS * sizeof(float) > 64 * 1024) return DRN_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(mean_softmax_kernel, dim3((M + MSM_THREADS - 1) / MSM_THREADS), dim3(MSM_THREADS),
-                     (size_t)C * MSM_THREADS * sizeof(float), (hipStream_t)stream, logits, ld, col0s_dev, n_heads, C, probs, M,
-                     bg_first);
+  if (C < 1) return DRN_ERR_ARG;
+  const dim3 grid((M + MSM_THREADS - 1) / MSM_THREADS), block(MSM_THREADS);
+  if ((size_t)C * MSM_THREADS * sizeof(float) <= 64 * 1024)
+    hipLaunchKernelGGL(mean_softmax_kernel<true>, grid, block, (size_t)C * MSM_THREADS * sizeof(float), (hipStream_t)stream, logits,
+                       ld, col0s_dev, n_heads, C, probs, M, bg_first);
+  else  // (heads with more than 256 classes run instead of being refused)
+    hipLaunchKernelGGL(mean_softmax_kernel<false>, grid, block, 0, (hipStream_t)stream, logits, ld, col0s_dev, n_heads, C, probs, M,
+                       bg_first);
   DRN_CHECK_LAUNCH();
   return DRN_OK;
 }

@@ -161,6 +161,19 @@ __global__ __launch_bounds__(512) void pp8_kernel(Pp8Params p) {
     }
   }
 
+  // fc form: the bias of this lane's accumulator columns (n = 8 q + 4 (lane >> 5) + e of each B block), fetched now for the same reason
+  [[maybe_unused]] f32x4_t fcb[BM / 128][4];
+  if constexpr (EPI == PP8_FC) {
+#pragma unroll
+    for (int j = 0; j < BM / 128; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int nc = bn + (wave % (4 / (BM / 128))) * (32 * (BM / 128)) + j * 32 + 8 * q + 4 * (lane >> 5);
+        const f32x4_t b4 = *(const f32x4_t*)((p.bias ? p.bias : (const float*)p.B) + (nc + 4 <= p.N ? nc : 0));  // (clamped: unconditional load)
+        fcb[j][q] = (p.bias && nc < p.N) ? b4 : f32x4_t{0.f, 0.f, 0.f, 0.f};
+      }
+  }
+
   // ---- DMA sources.  Wave w fills pieces w, w + 8, .. of A and of B: LDS rows 8 w + 64 q + lane / 8, physical slot lane & 7,
   // which holds the k-slot (lane & 7) ^ ((row >> 1) & 7) of that row (the XOR is the same for every q)
   const int r8 = lane >> 3;
@@ -337,18 +350,25 @@ __global__ __launch_bounds__(512) void pp8_kernel(Pp8Params p) {
       // ---- L1: B block 1; the first half of slab t + 2; slab t + 1 has landed (this wave's pieces)
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks) fb[ks] = *(lds_v4)(uintptr_t)(ob[ks] + so + 4096);
-      piece(is, I0{}); piece(is, I1{}); piece(is, I4{});
-      pp8_wait_vm<3>();
+      // (VAR & 1: all six pieces here - this phase has four fragment reads where L0 has twelve, and a piece issued between
+      // MFMAs stalls the wave's matrix stream; VAR & 1 == 0: three here, three between the MFMAs of M1)
+      if constexpr (VAR & 1) {
+        piece(is, I0{}); piece(is, I1{}); piece(is, I4{}); piece(is, I2{}); piece(is, I3{}); piece(is, I5{});
+        pp8_wait_vm<6>();
+      } else {
+        piece(is, I0{}); piece(is, I1{}); piece(is, I4{});
+        pp8_wait_vm<3>();
+      }
       PP8_CLK(0);
       PP8_BARRIER();
       PP8_CLK(1);
       if (PRIO) __builtin_amdgcn_s_setprio(1);
       PP8_MM(1, 0);
-      PP8_PIECE(I2);
+      if constexpr (!(VAR & 1)) PP8_PIECE(I2);
       PP8_MM(1, 1);
-      PP8_PIECE(I3);
+      if constexpr (!(VAR & 1)) PP8_PIECE(I3);
       PP8_MM(1, 2);
-      PP8_PIECE(I5);
+      if constexpr (!(VAR & 1)) PP8_PIECE(I5);
       PP8_MM(1, 3);
       if (PRIO) __builtin_amdgcn_s_setprio(0);
       advance();
@@ -371,32 +391,43 @@ __global__ __launch_bounds__(512) void pp8_kernel(Pp8Params p) {
   // fp32 [BM][128] (pp8_pos) so that a lane then owns 8 consecutive columns of one row: 16-byte residual loads and stores
   float* tile = (float*)smem;
   [[maybe_unused]] DrnDropRule drop{};
+  // (descriptor of the transposed copy; a zero-size range when there is none)
+  [[maybe_unused]] const __amdgpu_buffer_rsrc_t ryt = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(EPI == PP8_FC && p.YT ? p.YT : p.Y), 0, (EPI == PP8_FC && p.YT) ? (unsigned)((long)p.N * p.ldyt * 2) : 0u, 0x00020000);
   if constexpr (EPI == PP8_FC) drop = drn_drop_rule(p.seed + (p.seed_dev ? p.seed_dev[0] : 0ULL), p.drop_p);
 #pragma unroll
   for (int j = 0; j < NJ; ++j)
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int nl = wn * (32 * NJ) + j * 32 + 8 * q + 4 * hi, nc = bn + nl;
-    [[maybe_unused]] f32x4_t bi = {0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < 2; ++i) {
+    const int row = wm * 64 + i * 32 + l31, m = bm + row;
+    const int nb0 = bn + wn * (32 * NJ) + j * 32;  // this wave's 32-column block: one 32-index dropout group per row (N % 32 == 0)
+    // fc form, p == 0.5 and 32-aligned rows: ONE hash gives the keep bits of the lane's 16 elements of this block
+    [[maybe_unused]] uint32_t kbits = 0xFFFFFFFFu;
+    [[maybe_unused]] bool fast_bits = false;
     if constexpr (EPI == PP8_FC) {
-      if (nc < p.N && p.bias) bi = *(const f32x4_t*)(p.bias + nc);
+      fast_bits = !p.mask && p.drop_p > 0.f && drop.half && (p.N & 31) == 0;
+      if (fast_bits) kbits = drn_drop_bits32(drop, ((unsigned long long)m * p.N + nb0) >> 5);
     }
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const int row = wm * 64 + i * 32 + l31;
+    for (int q = 0; q < 4; ++q) {
+      const int nl = wn * (32 * NJ) + j * 32 + 8 * q + 4 * hi, nc = bn + nl;
       f32x4_t v;
       if constexpr (EPI == PP8_CONV) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = c[i][j][4 * q + e];  // (the affine follows in the read-back phase: 8 channels per lane)
       } else {
-        const int m = bm + row;
+        const f32x4_t bi = fcb[j][q];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           float x = c[i][j][4 * q + e] + bi[e];
           if (p.relu) x = fmaxf(x, 0.f);
           v[e] = x;
         }
-        if (m < p.Mtot && nc < p.N) {
+        if (fast_bits) {
+          const uint32_t kb = kbits >> (8 * q + 4 * hi);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] *= ((kb >> e) & 1u) ? drop.scale : 0.f;
+        } else if (m < p.Mtot && nc < p.N) {
           const unsigned long long idx = (unsigned long long)m * p.N + nc;
           if (p.mask) {
             const f32x4_t mk = *(const f32x4_t*)(p.mask + idx);
@@ -411,6 +442,35 @@ __global__ __launch_bounds__(512) void pp8_kernel(Pp8Params p) {
         }
       }
       *(f32x4_t*)(tile + row * 128 + (pp8_pos(nl >> 2, row) << 2)) = v;
+      if constexpr (EPI == PP8_FC) {
+        if (p.YT) {
+          // transposed copy [N][ldyt] straight from the accumulator layout (lane & 31 = row m, the quad's 4 registers = columns
+          // nc .. nc + 3): neighbouring lanes exchange their bf16 values (one DPP move each), even lanes then hold the row PAIR
+          // (m, m + 1) of columns nc, nc + 1 and odd lanes that of columns nc + 2, nc + 3 - 4-byte stores, the 16 lanes of a kind
+          // write 64 contiguous bytes of one output row.  (Through the LDS tile - 8 scalar reads per 16-byte store, 32 output rows
+          // x 32 bytes per store instruction - this copy cost more than the mainloop of a 32-slab GEMM saved.)
+          // (packed: two conversions, two DPP moves, two selects and two byte permutes per four elements)
+          const uint32_t p01 = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+          const uint32_t p23 = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+          const uint32_t o01 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p01, 0xB1, 0xF, 0xF, false);  // quad_perm [1, 0, 3, 2]: lane ^ 1
+          const uint32_t o23 = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p23, 0xB1, 0xF, 0xF, false);
+          const bool odd = lane & 1;
+          const int m0 = m - (odd ? 1 : 0), e0 = odd ? 2 : 0;
+          const uint32_t lo_row = odd ? o23 : p01, hi_row = odd ? p23 : o01;  // values of rows m0 / m0 + 1 at this lane's two columns
+          const uint32_t w0 = __builtin_amdgcn_perm(hi_row, lo_row, 0x05040100u);  // column e0:     [lo_row.lo16, hi_row.lo16]
+          const uint32_t w1 = __builtin_amdgcn_perm(hi_row, lo_row, 0x07060302u);  // column e0 + 1: [lo_row.hi16, hi_row.hi16]
+          if (nc < p.N && m0 < p.Mtot) {
+            const unsigned off = (unsigned)(((long)(nc + e0) * p.ldyt + m0) * 2), ldb2 = (unsigned)(p.ldyt * 2);
+            if (m0 + 1 < p.Mtot) {
+              __builtin_amdgcn_raw_buffer_store_b32(w0, ryt, off, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b32(w1, ryt, off + ldb2, 0, 0);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w0, ryt, off, 0, 0);
+              __builtin_amdgcn_raw_buffer_store_b16((unsigned short)w1, ryt, off + ldb2, 0, 0);
+            }
+          }
+        }
+      }
     }
   }
   __syncthreads();
@@ -444,32 +504,6 @@ __global__ __launch_bounds__(512) void pp8_kernel(Pp8Params p) {
       *(i32x4_t*)(p.Y + ((long)m * p.ldy + nn) * 2) = o;
     }
   }
-  if constexpr (EPI == PP8_FC) {
-    if (p.YT) {
-      // transposed copy [N][ldyt]: lane -> column n0 + (lane & 31), 8 consecutive rows from m0 + 8 (lane >> 5): the 32 lanes of an
-      // LDS cycle read one row of the tile at 32 consecutive columns; 16-byte stores, 32 bytes per output row and instruction
-      const int n0 = (wave & 3) * 32, nT = bn + n0 + (lane & 31);
-#pragma unroll
-      for (int ps = 0; ps < NPASS; ++ps) {
-        const int mloc = (wave >> 2) * (BM / 2) + ps * 16 + 8 * (lane >> 5), m = bm + mloc;
-        uint32_t w[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ra_ = mloc + 2 * j, rb_ = ra_ + 1, k = (n0 + (lane & 31)) >> 2, e = lane & 3;
-          const float x0 = tile[ra_ * 128 + (pp8_pos(k, ra_) << 2) + e], x1 = tile[rb_ * 128 + (pp8_pos(k, rb_) << 2) + e];
-          w[j] = (uint32_t)f32_to_bf16(x0) | ((uint32_t)f32_to_bf16(x1) << 16);
-        }
-        if (nT < p.N && m < p.Mtot) {
-          bf16_t* dst = (bf16_t*)p.YT + (long)nT * p.ldyt + m;
-          if (m + 8 <= p.Mtot) {
-            *(i32x4_t*)dst = i32x4_t{(int)w[0], (int)w[1], (int)w[2], (int)w[3]};
-          } else {
-            for (int k2 = 0; k2 < 8 && m + k2 < p.Mtot; ++k2) dst[k2] = (bf16_t)(w[k2 >> 1] >> (16 * (k2 & 1)));
-          }
-        }
-      }
-    }
-  }
   if constexpr (PROF) {
     t1 = __builtin_amdgcn_s_memtime();
     tp[5] = t1 - t0;
@@ -501,14 +535,22 @@ int launch_pp8(const Pp8Params& p, hipStream_t st) {
 int g_pp8 = 1;         // drn_tune(DRN_TUNE_PP8 = 25): 0 = off, 1 = default class, 2 = every layer in the kernel's class
 int g_pp8_stages = 5;  // drn_tune(DRN_TUNE_PP8_STAGES = 26): LDS ring stages of the 128x128 form (3 / 4 / 5 = 1 / 2 / 3 slabs in flight)
 int g_pp8_var = 1;     // drn_tune(DRN_TUNE_PP8_VARIANT = 27): schedule variant (pp8_kernel VAR), A/B knob
+int g_pp8_wvar = 4;    // drn_tune(DRN_TUNE_PP8_WIDE_VARIANT = 30): VAR of the 256x128 form (1 = all DMA pieces in phase L1, 4 = no s_setprio, 8 = profile)
 int g_pp8_wide = 1;    // drn_tune(DRN_TUNE_PP8_WIDE = 29): the 256x128 form: 0 = never, 1 = where it fills the chip, 2 = always
 
 template <int EPI>
 int launch_pp8_any(const Pp8Params& p, bool wide, hipStream_t st) {
-  if (wide) {
-    if (g_pp8_var & 8) return launch_pp8<256, 3, EPI, 8>(p, st);
-    if (g_pp8_var & 4) return launch_pp8<256, 3, EPI, 4>(p, st);
-    return launch_pp8<256, 3, EPI, 0>(p, st);
+  if (wide) {  // (variants of the 256x128 form: DRN_TUNE_PP8_WIDE_VARIANT)
+    switch (g_pp8_wvar) {
+      case 0: return launch_pp8<256, 3, EPI, 0>(p, st);
+      case 1: return launch_pp8<256, 3, EPI, 1>(p, st);
+      case 4: return launch_pp8<256, 3, EPI, 4>(p, st);
+      case 8: return launch_pp8<256, 3, EPI, 8>(p, st);
+      case 9: return launch_pp8<256, 3, EPI, 9>(p, st);
+      case 13: return launch_pp8<256, 3, EPI, 13>(p, st);
+      case 5: return launch_pp8<256, 3, EPI, 5>(p, st);
+      default: return launch_pp8<256, 3, EPI, 4>(p, st);
+    }
   }
 #define PP8_CASE(S_, V_) if (g_pp8_stages == S_ && g_pp8_var == V_) return launch_pp8<128, S_, EPI, V_>(p, st)
   PP8_CASE(3, 0);
@@ -554,6 +596,11 @@ __attribute__((visibility("hidden"))) int drn_pp8_set(int knob, int v) {
     if (hipMemcpyToSymbol(HIP_SYMBOL(g_pp8_prof), h, sizeof(h)) != hipSuccess) return -1;
     return 0;
   }
+  if (knob == 30) {
+    const int old = g_pp8_wvar;
+    if (v == 0 || v == 1 || v == 4 || v == 5 || v == 8 || v == 9 || v == 13) g_pp8_wvar = v;
+    return old;
+  }
   if (knob == 29) {
     const int old = g_pp8_wide;
     if (v >= 0 && v <= 2) g_pp8_wide = v;
@@ -578,9 +625,10 @@ __attribute__((visibility("hidden"))) int drn_pp8_conv_try(const ConvParams& c, 
   const int nslab = c.KH * c.KW * (c.Cin >> 6);
   const long t128 = (((long)c.Ho * c.Wo + 127) / 128) * ((c.Cout + 127) / 128);
   if (g_pp8 == 1) {
-    // measured class (tools/conv_bench.py at 800x1216, profiles/r6_*): a tile per CU for at least ~3/8 of the chip and a K loop
-    // long enough to amortise the 4-deep prologue
-    if (nslab < 4 || t128 < (3L * cus) / 8 || c.Cout < 128) return DRN_ERR_UNSUPPORTED;
+    // measured class (tools/conv_bench.py / tools/pp8_probe.py at 800x1216, profiles/r6_*): one image's layer offers at least
+    // 5/8 of the CUs a 128x128 tile and the K loop is long enough to amortise the ring's prologue.  (1x1 layers with >= 192 tiles
+    // of 256x256 never get here: drn_conv2d_nhwc_q sends them to conv1x1_pp_kernel first - its tile moves half the bytes per MFMA.)
+    if (nslab < 4 || t128 * 8 < 5L * cus || c.Cout < 128) return DRN_ERR_UNSUPPORTED;
   }
   Pp8Params p{};
   p.A = c.X; p.a_bytes = (unsigned)((long)c.Nb * c.H * c.W * c.Cin * 2); p.pix_b = (unsigned)(c.Cin * 2);

@@ -95,23 +95,28 @@ class FrozenBatchNorm2d(nn.Module):
 
     @classmethod
     def convert_frozen_batchnorm(cls, module):
-        """batch_norm.py:92-124: recursively replace BatchNorm layers by FrozenBatchNorm2d."""
-        bn_module = (nn.modules.batchnorm.BatchNorm2d, nn.modules.batchnorm.SyncBatchNorm)
-        res = module
-        if isinstance(module, bn_module):
-            res = cls(module.num_features)
-            if module.affine:
-                res.weight.data = module.weight.data.clone().detach()
-                res.bias.data = module.bias.data.clone().detach()
-            res.running_mean.data = module.running_mean.data
-            res.running_var.data = module.running_var.data
-            res.eps = module.eps
-        else:
-            for name, child in module.named_children():
-                new_child = cls.convert_frozen_batchnorm(child)
-                if new_child is not child:
-                    res.add_module(name, new_child)
-        return res
+        """Replace every BatchNorm2d / SyncBatchNorm below `module` (or `module` itself) by a FrozenBatchNorm2d holding the same
+        statistics and affine; returns the converted module (detectron2/layers/batch_norm.py:92-124 describes the contract).
+        Written as one pass over named_modules() with in-place re-parenting instead of a recursive rebuild."""
+        bn_types = (nn.BatchNorm2d, nn.SyncBatchNorm)
+
+        def frozen_from(bn):
+            out = cls(bn.num_features, eps=bn.eps)
+            with torch.no_grad():
+                if bn.affine:
+                    out.weight.copy_(bn.weight)
+                    out.bias.copy_(bn.bias)
+                out.running_mean.copy_(bn.running_mean)
+                out.running_var.copy_(bn.running_var)
+            return out
+
+        if isinstance(module, bn_types):
+            return frozen_from(module)
+        todo = [(parent, name, child) for parent in module.modules() for name, child in parent.named_children()
+                if isinstance(child, bn_types)]
+        for parent, name, child in todo:
+            setattr(parent, name, frozen_from(child))
+        return module
 
 
 def get_norm(norm, out_channels):

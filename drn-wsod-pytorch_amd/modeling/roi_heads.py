@@ -1306,7 +1306,9 @@ class OICRROIHeads(ROIHeads):
             # one image (every shipped config trains and tests with one image per GPU): rois, logits and the boxes' contiguous
             # copy in ONE launch instead of torch.full + two torch.cat + three copies in front of every forward
             b, l = proposals[0].proposal_boxes.tensor, proposals[0].objectness_logits
-            if b.is_cuda and b.dtype == torch.float32 and l.dtype == torch.float32 and b.is_contiguous() and l.is_contiguous():
+            if (b.is_cuda and b.dtype == torch.float32 and b.dim() == 2 and b.is_contiguous() and l is not None and l.is_cuda and
+                    l.device == b.device and l.dtype == torch.float32 and l.dim() == 1 and l.shape[0] == b.shape[0] and
+                    l.is_contiguous()):
                 rois, obj, props = ops.stage_rois(b, l, 0.0)
                 self._props = (rois, props)  # (tied to THIS rois tensor: a prefetch of a later batch may gather in between)
                 return nhwc, rois, obj

@@ -40,7 +40,7 @@ def gemm_set_tile(tile):
 TUNE_GEMM_PERSISTENT, TUNE_SGD_GRID, TUNE_GEMM_GROUP_ROWS, TUNE_ROI_MAP64, TUNE_CONV_KSPLIT, TUNE_GEMM_TAIL_SPLIT, TUNE_CONV_KS_TILES, TUNE_CONV_K2_TILES, TUNE_CONV_PATCH = 1, 2, 3, 4, 5, 6, 7, 8, 9
 TUNE_CONV_RING = 23
 TUNE_CONV_PP = 24
-TUNE_PP8, TUNE_PP8_STAGES, TUNE_PP8_VARIANT, TUNE_PP8_PROFILE, TUNE_PP8_WIDE = 25, 26, 27, 28, 29
+TUNE_PP8, TUNE_PP8_STAGES, TUNE_PP8_VARIANT, TUNE_PP8_PROFILE, TUNE_PP8_WIDE, TUNE_PP8_WIDE_VARIANT = 25, 26, 27, 28, 29, 30
 TUNE_ROI_CPB, TUNE_ROI_PREFETCH, TUNE_GEMM_PINGPONG, TUNE_FP8_K64, TUNE_ROI_MAP64_A, TUNE_ROI_LDS_KB = 10, 11, 12, 13, 14, 15
 
 
@@ -327,13 +327,14 @@ def roi_pool_nhwc(feat, rois, objectness, P, scale, mode=0, sampling_ratio=0, al
 def stage_rois(boxes, logits, batch_index=0.0):
     """boxes [M, 4] f32 (+ logits [M] f32 or None) of ONE image -> (rois [M, 5], obj [M] or None, props [M, 4]) in one launch
     (drn_stage_rois: convert_boxes_to_pooler_format + the contiguous copies the heads read)"""
-    assert boxes.dtype == torch.float32 and boxes.is_contiguous() and boxes.shape[1] == 4
+    assert boxes.is_cuda and boxes.dtype == torch.float32 and boxes.dim() == 2 and boxes.is_contiguous() and boxes.shape[1] == 4
     M = boxes.shape[0]
     rois = torch.empty((M, 5), dtype=torch.float32, device=boxes.device)
     props = torch.empty((M, 4), dtype=torch.float32, device=boxes.device)
     obj = None
     if logits is not None:
-        assert logits.dtype == torch.float32 and logits.is_contiguous() and logits.shape[0] == M
+        assert (logits.is_cuda and logits.device == boxes.device and logits.dtype == torch.float32 and logits.dim() == 1 and
+                logits.is_contiguous() and logits.shape[0] == M), "objectness logits: a contiguous f32 [M] tensor on the boxes' device"
         obj = torch.empty((M,), dtype=torch.float32, device=boxes.device)
     C.call("drn_stage_rois", C.ptr(boxes), C.ptr(logits), float(batch_index), C.ptr(rois), C.ptr(obj), C.ptr(props), M, C.stream())
     return rois, obj, props

@@ -258,6 +258,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_PP8_STAGES 26 /* 3 / 4 / 5 (default 5): 32-KB LDS stages of the 128x128 form's ring = 1 / 2 / 3 K slabs in flight (A/B knob; bit-identical) */
 #define DRN_TUNE_PP8_VARIANT 27 /* schedule variant of that kernel (A/B knob; bit-identical): 0 = a slab's four DMA pieces in the fragment-read phase, 1 (default) = two there and two between the MFMAs, 2 = all between the MFMAs, + 4 = no s_setprio around the MFMAs, + 8 = profile build (shader-clock split of the mainloop) */
 #define DRN_TUNE_PP8_PROFILE 28 /* any value: print (stderr) and clear the per-phase shader-clock sums the profile builds (DRN_TUNE_PP8_VARIANT + 8) accumulated for workgroup 0; returns 0 */
+#define DRN_TUNE_PP8_WIDE_VARIANT 30 /* schedule variant of the 256x128 form (A/B knob; bit-identical): bit 0 = all six DMA pieces of a slab in the second fragment-read phase (else three there, three between the MFMAs), 4 = no s_setprio, 8 = profile build; default 4 */
 #define DRN_TUNE_PP8_WIDE 29 /* the 256x128 form of that kernel (wave tile 64x64, three 48-KB stages): 0 = never, 1 = default (layers that give it >= 5/8 of the CUs' worth of tiles per image), 2 = always */
 int drn_tune(int knob, int value);
 

@@ -594,16 +594,19 @@ def test_pp8_conv_kernel(drn, case):
         tiled = run()  # conv_nhwc_kernel<64x64 | 128x128>
         drn.tune(drn.TUNE_PP8, 2)
         ys = {}
-        for stages, variant, wide in ((3, 0, 0), (4, 0, 0), (4, 1, 0), (5, 0, 0), (5, 2, 0), (5, 5, 0), (5, 1, 0), (5, 1, 2), (5, 1, 1)):
+        for stages, variant, wide in ((3, 0, 0), (4, 0, 0), (4, 1, 0), (5, 0, 0), (5, 2, 0), (5, 5, 0), (5, 1, 0), (5, 1, 2), (5, 0, 2),
+                                      (5, 1, 1)):
             drn.tune(drn.TUNE_PP8_STAGES, stages)
             drn.tune(drn.TUNE_PP8_VARIANT, variant)
             drn.tune(drn.TUNE_PP8_WIDE, wide)  # 2: the 256x128 form (three 48-KB stages) whatever the tile count
+            drn.tune(drn.TUNE_PP8_WIDE_VARIANT, 5 if variant else 0)  # (its two DMA placements)
             ys[(stages, variant, wide)] = [run() for _ in range(3)]
     finally:
         drn.tune(drn.TUNE_PP8, 1)
         drn.tune(drn.TUNE_PP8_STAGES, 5)
         drn.tune(drn.TUNE_PP8_VARIANT, 1)
         drn.tune(drn.TUNE_PP8_WIDE, 1)
+        drn.tune(drn.TUNE_PP8_WIDE_VARIANT, 4)
         drn.tune(drn.TUNE_CONV_RING, ring)
         drn.tune(drn.TUNE_CONV_K2_TILES, k2)
         drn.tune(drn.TUNE_CONV_KSPLIT, ks)

@@ -85,16 +85,17 @@ for name in names:
                 sys.stderr.flush()
                 ops.tune(28, 0)
     ops.tune(ops.TUNE_PP8_WIDE, 2)
-    for v in (0, 4):
-        ops.tune(27, v)
+    for v in (0, 4, 1, 5):
+        ops.tune(ops.TUNE_PP8_WIDE_VARIANT, v)
         t = timed(f)
         print("   256x128 form, variant %d: %6.1f us = %5.0f TFLOP/s" % (v, t, gf / t * 1e3), flush=True)
-    if PROF:
-        ops.tune(27, 8)
-        for _ in range(10):
-            f()
-        torch.cuda.synchronize()
-        ops.tune(28, 0)
+        if PROF and v in (0, 1):
+            ops.tune(ops.TUNE_PP8_WIDE_VARIANT, v | 8)
+            for _ in range(10):
+                f()
+            torch.cuda.synchronize()
+            ops.tune(28, 0)
+    ops.tune(ops.TUNE_PP8_WIDE_VARIANT, 4)
     ops.tune(ops.TUNE_PP8_WIDE, 1)
     ops.tune(27, 1)
     ops.tune(ops.TUNE_PP8_STAGES, 5)
