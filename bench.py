@@ -100,6 +100,37 @@ def init_weights(model, seed):
         t.copy_(v.to(t.device))
 
 
+def calibrate_fc6(model, batch):
+    """init_weights' scales were chosen on the 224 x 224 / C4 workload; another trunk (the dilated C5 recipe: 2048 channels at
+    stride 8) or a real image size changes the magnitude of the pooled features, and a timing run on saturated / diverged values
+    is not a measurement (a DC5 rotation ended at loss_cls_r0 = 918, r1 = r2 = 0).  One training forward on `batch`,
+    then fc6's weights are rescaled so that its surviving activations have unit RMS - what the C4 calibration gives.  Returns
+    the factor applied."""
+    was = model.training
+    model.train()
+    model(batch)
+    st = model.roi_heads._last_state
+    h1 = st["w"]["H1"][: st["M"]].float()
+    keep = h1 > 0
+    rms = float(h1[keep].pow(2).mean().sqrt()) / (2.0 if st["drop_p"] > 0 else 1.0) if bool(keep.any()) else 1.0
+    f = 1.0 / max(rms, 1e-6)
+    fc1 = model.roi_heads.box_head.fc1
+    with torch.no_grad():
+        fc1.weight.mul_(f)
+        fc1.bias.mul_(f)
+    model.train(was)  # (the engine's bf16 weight copies are keyed by the parameters' versions: refreshed at the next forward)
+    return f
+
+
+def assert_sane_losses(losses, where):
+    """a timing tool's last loss dict: finite, the MIL loss off its saturation values, refinement losses neither 0 nor huge"""
+    vals = {k: float(v) for k, v in losses.items()}
+    bad = [k for k, v in vals.items() if not math.isfinite(v) or v > 50.0 or (k.startswith("loss_cls_r") and v <= 0.0)]
+    if bad:
+        raise RuntimeError("%s: degenerate losses %s - the timing would be taken on saturated values" % (where, vals))
+    return vals
+
+
 def synthetic_batches(n_batches, R, K, device, rank, pkg, ims=1):
     """SURVEY §8(d): image uint8-valued f32 [3,224,224]; proposals x0,y0 ~ U[0,184), w,h ~ U[20, 224-x0|y0];
     objectness ~ U[0,1) sorted descending; 1..3 distinct GT classes; seed = 1234 + 1000*rank + iter."""
@@ -295,8 +326,8 @@ def main():
     ap.add_argument("--proposals", type=int, default=2000)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-side", action="store_true",
-                    help="skip the side measurements of the default run (trunk at 800x1216 for the C4 and the shipped DC5 recipe, the "
-                         "4-images-per-GPU step in a child process)")
+                    help="skip the side measurements of the default run (trunk at 800x1216 for the C4 and the shipped DC5 recipe; child "
+                         "processes: the 4-images-per-GPU step, BASELINE's other configs on one GPU, the eager real-shape rotation)")
     ap.add_argument("--workload", choices=["r50c4", "r50dc5", "r101c4_k80", "r50c4_fp8", "v16"], default="r50c4",
                     help="r50c4 = BASELINE configs[1], the headline metric; r50dc5 (configs[2]: WS-R50 dilated C5, use with "
                          "--proposals 4000), r101c4_k80 (configs[3]: WS-R101 C4, 80 classes) and r50c4_fp8 (configs[4]: the "
@@ -935,18 +966,46 @@ def main():
                 out["roofline_trunk"] = [trunk_roofline(pkg, device, "r50c4"), trunk_roofline(pkg, device, "r50dc5")]
             except Exception as ex:  # noqa: BLE001 - supporting evidence only
                 out["roofline_trunk"] = "unavailable: %r" % (ex,)
-            try:
-                import subprocess
+            # side measurements in child processes, 20 steps each, behind the headline (never part of `value`): the same step with
+            # 4 images per GPU (SURVEY 8(d)'s "one larger N"), BASELINE configs[2] / [3] / [0] / [4] on one GPU, and the EAGER
+            # variable-shape step (16 VOC-like (H, W, R) in rotation) of the C4 model and of the shipped dilated-C5 recipe
+            import subprocess
 
-                r_ = subprocess.run([sys.executable, os.path.abspath(__file__), "--ims-per-gpu", "4", "--steps", "20", "--warmup", "3",
-                                     "--no-cpu-baseline", "--no-side"], capture_output=True, text=True, timeout=300)
-                j_ = json.loads([l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")][-1])
-                out["side_ims_per_gpu_4"] = {"value": j_["value"], "unit": "images/sec", "ms_per_step": j_["ms_per_step"], "steps": j_["steps"],
-                                             "roofline_step_frac": j_["roofline_step"]["frac"],
-                                             "how": "child process: python bench.py --ims-per-gpu 4 --steps 20 --warmup 3 (the same step with 4 "
-                                                    "images per GPU and iteration: SURVEY 8(d)'s 'one larger N')"}
+            def child(argv, env=None, timeout=300):
+                e_ = dict(os.environ)
+                e_.update(env or {})
+                r_ = subprocess.run([sys.executable] + argv, capture_output=True, text=True, timeout=timeout, env=e_)
+                lines = [l_ for l_ in r_.stdout.splitlines() if l_.startswith("{")]
+                if not lines:
+                    raise RuntimeError("no JSON line (rc %d): %s" % (r_.returncode, r_.stderr[-300:]))
+                return json.loads(lines[-1])
+
+            me = os.path.abspath(__file__)
+            sides = [("side_ims_per_gpu_4", ["--ims-per-gpu", "4"], "the same step with 4 images per GPU and iteration"),
+                     ("side_r50dc5_r4000", ["--workload", "r50dc5", "--proposals", "4000"], "BASELINE configs[2] on one GPU: WS-R50 dilated C5, R = 4000"),
+                     ("side_r101c4_k80", ["--workload", "r101c4_k80"], "BASELINE configs[3] on one GPU: WS-R101 C4, 80 classes"),
+                     ("side_v16", ["--workload", "v16"], "BASELINE configs[0]'s model at full size: VGG16 dilated conv5, DAN_DIM [4096, 4096]"),
+                     ("side_r50c4_fp8", ["--workload", "r50c4_fp8"], "BASELINE configs[4] on one GPU: the R50-C4 trunk on the fp8 MFMA conv path")]
+            for key_, extra_, what_ in sides:
+                try:
+                    j_ = child([me] + extra_ + ["--steps", "20", "--warmup", "3", "--no-cpu-baseline", "--no-side"])
+                    out[key_] = {"value": j_["value"], "unit": "images/sec", "ms_per_step": j_["ms_per_step"], "steps": j_["steps"],
+                                 "roofline_step_frac": j_["roofline_step"]["frac"],
+                                 "how": "child process: python bench.py %s --steps 20 --warmup 3 (%s)" % (" ".join(extra_), what_)}
+                except Exception as ex:  # noqa: BLE001 - supporting evidence only
+                    out[key_] = "unavailable: %r" % (ex,)
+            try:
+                tool_ = os.path.join(os.path.dirname(me), "tools", "eager_shapes_bench.py")
+                rs_ = []
+                for wl_ in ("r50c4", "r50dc5"):
+                    j_ = child([tool_, "32"], env={"WORKLOAD": wl_, "JSON": "1"})
+                    rs_.append({"workload": wl_, "ms_per_step": j_["ms_per_step"], "host_enqueue_ms_per_step": j_["host_enqueue_ms_per_step"],
+                                "steps": j_["steps"], "losses_at_the_end": j_["losses"]})
+                out["side_real_shapes"] = {"what": "the EAGER training step over 16 rotating VOC-like (H, W, R): shortest edge 480-1200, "
+                                                   "500-2000 proposals (tools/eager_shapes_bench.py; fc6 calibrated per trunk, losses checked)",
+                                           "runs": rs_}
             except Exception as ex:  # noqa: BLE001 - supporting evidence only
-                out["side_ims_per_gpu_4"] = "unavailable: %r" % (ex,)
+                out["side_real_shapes"] = "unavailable: %r" % (ex,)
         out["timed_region_s"] = dt
         if dt < 0.2:
             out["timed_region_note"] = ("the timed region is %.0f ms (%d steps): shorter than clock / power transients; "

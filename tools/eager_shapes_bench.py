@@ -65,6 +65,10 @@ for i in range(16):
     R = int(torch.randint(500, 2001, (1,), generator=g))
     shapes.append((H, W, R))
 batches = [batch(100 + i, *s) for i, s in enumerate(shapes)]
+#  the weight scales of bench.init_weights belong to the 224 x 224 / C4 workload: calibrate fc6 on a real-size batch of
+# THIS trunk, and check the losses before a time is printed
+print("fc6 calibration factor on %d x %d: %.3f" % (shapes[0][0], shapes[0][1], B.calibrate_fc6(model, batches[0])))
+opt.zero_grad()
 
 
 def step(i):
@@ -100,8 +104,14 @@ dt = time.perf_counter() - t0
 pix = sum(s[0] * s[1] for s in shapes) / len(shapes)
 print("eager step, %d distinct (H, W, R) in rotation (mean %.0f x %.0f pixels, mean R %.0f):" %
       (len(shapes), pix ** 0.5, pix ** 0.5, sum(s[2] for s in shapes) / len(shapes)))
+sane = B.assert_sane_losses(last, "eager rotation (%s)" % os.environ.get("WORKLOAD", "r50c4"))
 print("  wall %.3f ms/step (%.1f img/s)   host enqueue %.3f ms/step   losses %s" %
-      (dt / steps * 1e3, steps / dt, t_enq / steps * 1e3, {k: round(float(v), 4) for k, v in last.items()}))
+      (dt / steps * 1e3, steps / dt, t_enq / steps * 1e3, {k: round(v, 4) for k, v in sane.items()}))
+if os.environ.get("JSON", "0") == "1":  # bench.py's side_real_shapes child
+    import json
+    print(json.dumps({"workload": os.environ.get("WORKLOAD", "r50c4"), "ms_per_step": dt / steps * 1e3, "host_enqueue_ms_per_step": t_enq / steps * 1e3,
+                      "steps": steps, "shapes": len(shapes), "mean_pixels": pix, "losses": sane}))
+    sys.exit(0)
 # the same shapes one by one: eager vs host time
 for (H, W, R), b in list(zip(shapes, batches))[:6]:
     drain()
