@@ -1138,6 +1138,120 @@ __global__ __launch_bounds__(NWV * 64) void roi_pool7_lane_kernel(RoiParams p) {
   }  // groups of this block
 }
 
+// 7x7 ROIAlign, LANE-PER-BIN (round 6): bf16 in / bf16 out, the forward of detectron2/layers/roi_align.py:22-59 ->
+// ROIAlign_forward (detectron2/layers/csrc/ROIAlign/ROIAlign_cuda.cu:65-139; pre_calc + accumulate of ROIAlign_cpu.cpp), fused with
+// the objectness scaling like the RoIPool kernels.  The generic kernel (roi_kernel MODE 1: block = ROI x 64 channels, lane =
+// channel) computes every sample's four bilinear weights - ~40 VALU instructions of float clamping - once per LANE, i.e. 64
+// times per 64 channels, and fetches its four taps from global memory per sample: 455-500 us for 2000 ROIs on the 14x14x1024
+// map, 0.05 of the HBM roof (profiles/r6_11_roi_align.txt).  Here, as in roi_pool7_lane_kernel: a block stages NCK 8-channel
+// slices of the whole map in LDS once per group of ROIs, a WAVE owns one ROI and lane l < 49 owns bin l; the sampling grid
+// (gh x gw, adaptive or fixed) is uniform over the ROI, a sample's weights and its four cell addresses are computed ONCE per
+// bin and serve all NCK x 8 channels of the block's slices (4 x NCK 16-byte LDS reads, 7 fp32 operations per channel), and a
+// channel's 49 bins leave as one 98-byte run per store instruction.
+// Same operations on the same values in the same order as roi_kernel<.., 1> (w = hy * hx ..; ((w1 v1 + w2 v2) + w3 v3) + w4 v4;
+// samples outside [-1, H] x [-1, W] skipped; acc / count * (objectness + 1); one RNE conversion): bit-identical outputs.
+template <int NCK>
+__global__ __launch_bounds__(512) void roi_align7_lane_kernel(RoiParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = p.H * p.W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int NW = 8;
+  const int nslice = p.C / (8 * NCK);
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);
+  const int group = logical / nslice, sl = logical - group * nslice;
+  const int c0 = sl * 8 * NCK;
+  const int ph = lane / 7, pw = lane - ph * 7;
+  const bool is_bin = lane < 49;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned cstride = (unsigned)HW * 16u;
+  const int m0 = group * p.lane_g;
+  if (m0 >= p.M) return;
+  const int nr = min(p.lane_g, p.M - m0);
+  // the group's ROIs in the lanes of every wave (lane l: ROI m0 + l)
+  float fx1 = 0.f, fy1 = 0.f, fx2 = 0.f, fy2 = 0.f, vmul = 1.f;
+  int vimg = -1;
+  if (lane < nr) {
+    const float* roi = p.rois + 5 * (long)(m0 + lane);
+    vimg = (int)roi[0];
+    fx1 = roi[1]; fy1 = roi[2]; fx2 = roi[3]; fy2 = roi[4];
+    vmul = p.obj ? p.obj[m0 + lane] + 1.f : 1.f;
+  }
+  const int nxt = __shfl_down(vimg, 1, 64);
+  const unsigned long long runs = __ballot(lane < nr && (lane + 1 >= nr || nxt != vimg));
+  auto bcast = [&](float v, int r) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), r)); };
+  int cur_img = -1;
+  for (int r0 = 0; r0 < nr;) {
+    const int b = __builtin_amdgcn_readlane(vimg, r0);
+    const int r1 = r0 + __builtin_ctzll(runs >> r0) + 1;
+    if (b != cur_img) {
+      if (cur_img >= 0) __syncthreads();
+      const char* fb = p.feat + ((long)b * HW * p.C + c0) * 2;
+      for (int idx = tid; idx < HW * NCK; idx += NW * 64) {
+        const int px = idx / NCK, c = idx - px * NCK;
+        *(i32x4_t*)(smem + ((long)c * HW + px) * 16) = *(const i32x4_t*)(fb + (long)px * p.C * 2 + c * 16);
+      }
+      __syncthreads();
+      cur_img = b;
+    }
+    for (int r = r0 + wave; r < r1; r += NW) {
+      const float off = p.aligned ? 0.5f : 0.f;
+      const float sw = bcast(fx1, r) * p.scale - off, sh = bcast(fy1, r) * p.scale - off;
+      const float ew = bcast(fx2, r) * p.scale - off, eh = bcast(fy2, r) * p.scale - off;
+      const float mul = bcast(vmul, r);
+      float rw = ew - sw, rh = eh - sh;
+      if (!p.aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+      const float bin_h = rh / 7.f, bin_w = rw / 7.f;
+      const int gh = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(rh / 7);
+      const int gw = p.sampling_ratio > 0 ? p.sampling_ratio : (int)ceilf(rw / 7);
+      const float count = (float)max(gh * gw, 1);
+      float acc[NCK][8];
+#pragma unroll
+      for (int c = 0; c < NCK; ++c)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[c][e] = 0.f;
+      for (int iy = 0; iy < gh; ++iy) {
+        const float yy = sh + ph * bin_h + (float)(iy + .5f) * bin_h / (float)gh;
+        for (int ix = 0; ix < gw; ++ix) {
+          const float xx = sw + pw * bin_w + (float)(ix + .5f) * bin_w / (float)gw;
+          float x = xx, y = yy;
+          if (!is_bin || y < -1.0f || y > p.H || x < -1.0f || x > p.W) continue;
+          if (y <= 0) y = 0;
+          if (x <= 0) x = 0;
+          int yl = (int)y, xl = (int)x, yh, xh;
+          if (yl >= p.H - 1) { yh = yl = p.H - 1; y = (float)yl; } else yh = yl + 1;
+          if (xl >= p.W - 1) { xh = xl = p.W - 1; x = (float)xl; } else xh = xl + 1;
+          const float ly = y - yl, lx = x - xl, hy = 1.f - ly, hx = 1.f - lx;
+          const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+          const unsigned a1 = lds0 + (unsigned)(yl * p.W + xl) * 16u, a2 = lds0 + (unsigned)(yl * p.W + xh) * 16u;
+          const unsigned a3 = lds0 + (unsigned)(yh * p.W + xl) * 16u, a4 = lds0 + (unsigned)(yh * p.W + xh) * 16u;
+          typedef __attribute__((address_space(3))) const i32x4_t* lds_v4;
+#pragma unroll
+          for (int c = 0; c < NCK; ++c) {
+            const i32x4_t q1 = *(lds_v4)(uintptr_t)(a1 + (unsigned)c * cstride), q2 = *(lds_v4)(uintptr_t)(a2 + (unsigned)c * cstride);
+            const i32x4_t q3 = *(lds_v4)(uintptr_t)(a3 + (unsigned)c * cstride), q4 = *(lds_v4)(uintptr_t)(a4 + (unsigned)c * cstride);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+              auto f = [&](const i32x4_t& q) {
+                const uint32_t wd = (uint32_t)q[e >> 1];
+                return __builtin_bit_cast(float, (e & 1) ? (wd & 0xffff0000u) : (wd << 16));
+              };
+              acc[c][e] += w1 * f(q1) + w2 * f(q2) + w3 * f(q3) + w4 * f(q4);
+            }
+          }
+        }
+      }
+      if (is_bin) {
+        bf16_t* dst = (bf16_t*)p.out + (long)(m0 + r) * p.ld_out + (long)c0 * 49 + lane;
+#pragma unroll
+        for (int c = 0; c < NCK; ++c)
+#pragma unroll
+          for (int e = 0; e < 8; ++e) dst[(c * 8 + e) * 49] = f32_to_bf16(acc[c][e] / count * mul);
+      }
+    }
+    r0 = r1;
+  }
+}
+
 // Chunk-major copy of a bf16 NHWC map for the walking kernel below: [N][H*W][C] -> [N][C/8][H*W] cells of 16 bytes (8 channels of a
 // pixel), values already order-mapped (bf16x2_order).  A staged slice is then ONE contiguous run instead of 16 bytes of every
 // pixel's 2-KB line (64 lines per wave instruction: ~28 us of a 156-us pooling launch at 50x76 - profiles/r5_32_roi_walk_knockouts.txt).
@@ -1512,6 +1626,33 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st, void* ws = null
   else if (nck == 2) hipLaunchKernelGGL(roi_pool7_lane_kernel<2>, grid, block, smem, st, p);
   else if (big) hipLaunchKernelGGL((roi_pool7_lane_kernel<1, 16>), grid, block, smem, st, p);
   else hipLaunchKernelGGL(roi_pool7_lane_kernel<1>, grid, block, smem, st, p);
+  return true;
+}
+
+// ROIAlign through roi_align7_lane_kernel; false when no 8-channel slice of the map fits the LDS
+static bool launch_roi_align_lane(const RoiParams& p0, hipStream_t st) {
+  RoiParams p = p0;
+  if (p.C % 8) return false;
+  int nck = roi_lane_chunks(p.H, p.W, p.C);
+  if (!nck) return false;
+  // (64 fp32 accumulators per lane at 8 chunks: 4 chunks per block keep the wave under 128 registers - two blocks per CU)
+  if (nck > 4) nck = 4;
+  const size_t smem = (size_t)p.H * p.W * 16 * nck;
+  static bool attr = false;
+  if (!attr) {
+    if (hipFuncSetAttribute((const void*)roi_align7_lane_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_align7_lane_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess ||
+        hipFuncSetAttribute((const void*)roi_align7_lane_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 156 * 1024) != hipSuccess)
+      return false;
+    attr = true;
+  }
+  p.lane_g = smem > 38 * 1024 ? 64 : 32;
+  const int ngroups = (p.M + p.lane_g - 1) / p.lane_g;
+  const dim3 grid((unsigned)ngroups * (p.C / (8 * nck))), block(512);
+  p.out_t = nullptr;
+  if (nck == 4) hipLaunchKernelGGL(roi_align7_lane_kernel<4>, grid, block, smem, st, p);
+  else if (nck == 2) hipLaunchKernelGGL(roi_align7_lane_kernel<2>, grid, block, smem, st, p);
+  else hipLaunchKernelGGL(roi_align7_lane_kernel<1>, grid, block, smem, st, p);
   return true;
 }
 
@@ -1989,6 +2130,12 @@ int drn_roi_pool_nhwc_ws(const void* feat, const float* rois, const float* objec
         return DRN_OK;
       }
     }
+  }
+  // ROIAlign, bf16 -> bf16, P = 7, channels in chunks of 8, a slice of the map in LDS: the lane-per-bin form
+  if (mode == 1 && P == 7 && !out_t && in_dtype == DRN_BF16 && out_dtype == DRN_BF16 && g_roi_lane && (((uintptr_t)feat) & 15) == 0 &&
+      M >= 32 && launch_roi_align_lane(p, st)) {
+    DRN_CHECK_LAUNCH();
+    return DRN_OK;
   }
   if (out_t) {  // general shapes: pool into `out`, then the transpose pass
     p.out_t = nullptr;

@@ -6,6 +6,8 @@
   GraphedFullStep    trainable trunk: forward, losses, backward, optimizer as one graph (two with a gradient exchange between)
 
 Split out of engine.py in round 5; `engine` re-exports both names."""
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -389,8 +391,20 @@ class GraphedTrainStep:
         self._side.wait_stream(main)
         losses = self._heads(eager)
         evp = None
+        probe = os.environ.get("DRN_PROBE_TAIL_FILL")  # experiment (tools/README: tail window of the fused dW launch)
+        if probe:
+            if not hasattr(self, "_probe_s"):
+                self._probe_s = torch.cuda.Stream()
+                self._probe_buf = torch.empty((int(probe) << 20,), dtype=torch.uint8, device=self.props.device)
+            pe = torch.cuda.Event()
+            pe.record(main)
         if self.split_tail:
             self.engine.run_fc1_tail()
+        if probe:
+            with torch.cuda.stream(self._probe_s):
+                self._probe_s.wait_event(pe)
+                self._probe_buf.fill_(1)  # as many bytes as the pooling launch writes: does the dW launch's last round have room for them?
+            main.wait_stream(self._probe_s)
         with torch.cuda.stream(self._side):
             # proposals of batch t+1 on the side stream (ordered behind step t-1's pooling graph, their last reader, by the
             # wait above; in front of the conv chain): three small launches that sat between the last dW slab and the

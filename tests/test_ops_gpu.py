@@ -938,6 +938,40 @@ def test_roi_align(drn, dtype, aligned, sr):
     assert torch.allclose(got, ref, rtol=1e-5, atol=1e-5), float((got - ref).abs().max())
 
 
+@pytest.mark.parametrize("C,H,W,R,n_img,aligned,sr", [(64, 14, 14, 2000, 1, True, 0),    # the bench map: 8 chunks fit, four per block
+                                                      (72, 27, 27, 300, 2, False, 0),   # ragged image runs, C = 9 chunks, ROIAlign (not V2)
+                                                      (16, 50, 76, 333, 1, True, 2),    # fixed sampling grid, one chunk per block
+                                                      (32, 37, 41, 257, 3, True, 0)])   # three images, odd map
+def test_roi_align_lane_kernel(drn, C, H, W, R, n_img, aligned, sr):
+    """roi_align7_lane_kernel (bf16 ROIAlign, wave per ROI, lane = bin, the sample's weights computed once per bin for all the
+    block's channels) == the generic one-lane-per-channel kernel bit for bit, and == the oracle (pinned to the reference's own
+    ROIAlign_cpu.cpp by tests/test_oracle_golden.py) on the bf16-rounded map within one bf16 rounding of the fp32 result;
+    objectness scaling, boxes leaving the map, ragged image runs."""
+    scale, P, dt = 1.0 / 16, 7, torch.bfloat16
+    feat = _rnd((n_img, C, H, W), 23)
+    rois = _rois(R, n_img, W / scale, H / scale, 24)
+    rois = rois[torch.argsort(rois[:, 0], stable=True)]  # (batches arrive image by image)
+    rois[::17, 1] -= 40.0   # boxes that leave the map: samples outside [-1, W] are skipped
+    rois[5::29, 4] += 90.0
+    obj = torch.rand(R)
+    fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(dt)
+    run = lambda: drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale, mode=1, sampling_ratio=sr, aligned=aligned)
+    lane = run()
+    again = run()
+    old = drn.tune(drn.TUNE_ROI_LANE, 0)
+    try:
+        generic = run()
+    finally:
+        drn.tune(drn.TUNE_ROI_LANE, old)
+    torch.cuda.synchronize()
+    k = C * P * P
+    assert torch.equal(lane[:, :k], generic[:, :k]), float((lane[:, :k].float() - generic[:, :k].float()).abs().max())
+    assert torch.equal(again, lane)
+    ref = O.roi_align_forward(_q(feat, dt), rois, P, scale, sr, aligned).reshape(R, -1) * (obj + 1).view(-1, 1)
+    got = lane[:, :k].float().cpu()
+    assert torch.allclose(got, ref, rtol=2 ** -7, atol=1e-3), float((got - ref).abs().max())
+
+
 def test_stage_rois_equals_pooler_format(drn):
     """drn_stage_rois (one launch) == convert_boxes_to_pooler_format + the contiguous copies (poolers.py:69-96), bit for bit"""
     g = torch.Generator().manual_seed(3)
