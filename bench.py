@@ -473,7 +473,7 @@ def main():
     c_feat = 1024 if args.workload in ("r50c4", "r50c4_fp8", "r101c4_k80") else (2048 if args.workload == "r50dc5" else 512)
     if exchange is None and world > 1 and not args.no_pipelined_sgd and not args.no_graph:
         # round 4: for N > 1 the bench's fixed-shape batches take the K-sharded fc6 (no fc6 gradient exchange, no weight gather;
-        # DESIGN 10.3 / 11.4) when the channel count splits over the ranks into whole K slabs; --exchange sharded | allreduce
+        # HISTORY 10.3 / 11.4) when the channel count splits over the ranks into whole K slabs; --exchange sharded | allreduce
         # select the gradient exchanges.  Round 5: if its collectives or its warm-up fail, the run falls back (below).
         if c_feat % world == 0 and ((c_feat // world) * 49 * 2) % 128 == 0:
             exchange = "fc6_kshard"

@@ -1871,7 +1871,7 @@ __global__ __launch_bounds__(512) void conv_nhwc_k2_kernel(ConvParams p) {  // (
 // whatever the prefetch depth (measured: ring depth 3 / 4 / 5 and division-free addressing all within 5 %), so a 36-slab
 // 3 x 3 conv took 23 us on 196 pixels.  Here the chain per slab is a quarter of that and there are 4x the workgroups.
 // (Splitting K over workgroups instead - partial tiles in HBM, last arriver reduces - was built and measured slower
-// than no split: the cross-XCD coherence of the partials costs more than the split saves)
+// than no split: the cross-XCD coherence of the partials costs more than the split saves; HISTORY.md section 5.)
 template <int DT, bool K64 = true>
 __global__ __launch_bounds__(256) void conv_nhwc_ks_kernel(ConvParams p) {
   __shared__ __attribute__((aligned(16))) char smem[4 * 32 * 32 * 4];  // one 8-KB operand stage, then 4 partial tiles

@@ -10,7 +10,7 @@
 // Why.  The mid-size layers of the trunk (res3 / res4 / res5 of an 800x1216 image: 3800-15200 rows x 128-2048 columns) and
 // fc7 ([2000 x 2048] . [4096 x 2048]^T) offer a few hundred 128x128 tiles: too few for the 256x256 ping-pong GEMM (one tile
 // per 2-4 CUs), and on four-wave 64x64 / 128x128 tiles each SIMD has ONE wave that does its loads, its fragment reads and its
-// MFMAs strictly in turn (MFMA pipes 7-32 % busy).  Here a 128x128 tile is worked by eight waves as 2 (M) x 4 (N)
+// MFMAs strictly in turn (HISTORY 11.1: MFMA pipes 7-32 % busy).  Here a 128x128 tile is worked by eight waves as 2 (M) x 4 (N)
 // wave tiles of 64x32 - two MFMA 32x32 accumulators per wave - and a K slab (128 bytes per row) is ONE phase pair
 //     [12 fragment reads + 4 LDS-DMA pieces + the wait that retires the next slab]  barrier  [8 MFMAs, s_setprio 1]  barrier
 // The two waves of a SIMD (wave w and w + 4 = the two rows of the wave layout) run one barrier interval apart: while one
