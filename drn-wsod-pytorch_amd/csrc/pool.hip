@@ -1493,6 +1493,308 @@ __global__ __launch_bounds__(NWV * 64, OCC) void roi_pool7_walk_kernel(RoiParams
   }
 }
 
+// 7x7 ROIPool from a SPARSE TABLE of block maxima (round 6) - the maps whose slice leaves room for 4 channels per cell only (the
+// shipped dilated-C5 recipe's stride-8 map of a real-size image: 99 x 151 x 2048, ~3750 cells per ROI).  The window kernels above
+// read every cell of every ROI: 15.4 G bf16 elements through LDS and a packed maximum per two of them, 920 us for 2000 ROIs
+// (roi_pool7_lane_kernel<1, 16, 2>, profiles/r6_11_roi_align.txt) - a compute bound that no schedule removes.  A maximum is
+// idempotent, so the windows can share work instead: with T[k][l][y][x] = max over rows y .. y + 2^k - 1 and columns x .. x + 2^l - 1,
+// a bin [hs, he) x [ws, we) whose sides are within [2^k, 2^(k+1)] x [2^l, 2^(l+1)] is the maximum of FOUR table cells
+// (rows hs and he - 2^k, columns ws and we - 2^l: the blocks overlap, which a maximum does not mind) instead of ~77.  A ROI's 49
+// bins differ by at most one row / column, so ONE level pair (k, l) = floor(log2) of its smallest non-empty bin serves all of
+// them (2^k <= nh <= 2^k + 1 <= 2^(k+1)); ROIs clipped by the map edge or beyond level 4 (bins of 32+ cells) take
+// ceil(nh / 2^k) x ceil(nw / 2^l) cells in a loop.  Work per block = (4-channel slice, image, l):
+//   * the ROIs of its class are listed (by k) in LDS from the one-byte class codes roi_st_prep_kernel left; no ROI: exit;
+//   * the slice - one contiguous run of the chunk-major, order-mapped copy of the map - lands in LDS and l doubling steps
+//     along the rows make T[0][l] in place (a thread keeps its cells in registers: per step one LDS read of the partner
+//     cell, one barrier, one write, one barrier);
+//   * for k = 0 .. 4: doubling steps down the columns up to level k, then the waves pool the listed ROIs of level k: wave = ROI,
+//     lane = bin as in roi_pool7_lane_kernel (every channel leaves as one 98-byte run), the bin's four cell coordinates come
+//     packed in ONE dword per lane from the record the prep kernel wrote (fetched eight ROIs at a time).
+// 30 doubling steps per slice serve ALL ROIs (~2.5 LDS passes over the slice each) against ~77 reads per (ROI, bin) before.
+// Same maxima over the same cells, same scaling and conversion: bit-identical to the other RoIPool kernels.
+constexpr int ST_LEVELS = 5;  // levels 0 .. 4: blocks of 1 .. 16 rows / columns
+constexpr int ST_BATCH = 8;   // ROI records a wave fetches per round
+
+// One wave per ROI: the record [64 dwords] - lanes 0 .. 48: y0 | y1 << 8 | x0 << 16 | x1 << 24 (first / last block row, first / last
+// block column of the bin at the ROI's level; an empty bin: y0 = 1 > y1 = 0), lane 60: most blocks per bin (rows | columns << 8),
+// lane 62: the objectness scale, lane 63: k | l << 4 - and the class byte (image * 5 + l) * 5 + k (255: image index out of range).
+__global__ __launch_bounds__(256) void roi_st_prep_kernel(RoiParams p, unsigned* __restrict__ rec, unsigned char* __restrict__ cls) {
+  const int lane = threadIdx.x & 63;
+  const int m = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (m >= p.M) return;
+  const float* roi = p.rois + 5 * (long)m;
+  const int b = (int)roi[0];
+  const int x1 = (int)roundf(roi[1] * p.scale), y1 = (int)roundf(roi[2] * p.scale);
+  const int x2 = (int)roundf(roi[3] * p.scale), y2 = (int)roundf(roi[4] * p.scale);
+  const float mul = p.obj ? p.obj[m] + 1.f : 1.f;
+  const int rw = max(x2 - x1 + 1, 1), rh = max(y2 - y1 + 1, 1);
+  const float bin_h = (float)rh / 7.f, bin_w = (float)rw / 7.f;
+  const int ph = lane / 7, pw = lane - ph * 7;
+  const bool is_bin = lane < 49;
+  const int hs = min(max((int)floorf((float)ph * bin_h) + y1, 0), p.H);
+  const int he = min(max((int)ceilf((float)(ph + 1) * bin_h) + y1, 0), p.H);
+  const int ws = min(max((int)floorf((float)pw * bin_w) + x1, 0), p.W);
+  const int we = min(max((int)ceilf((float)(pw + 1) * bin_w) + x1, 0), p.W);
+  const int nh = he - hs, nw = we - ws;
+  const bool empty = !is_bin || nh <= 0 || nw <= 0;
+  int hmin = is_bin && nh > 0 ? nh : 0x7fff, wmin = is_bin && nw > 0 ? nw : 0x7fff;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    hmin = min(hmin, __shfl_xor(hmin, o, 64));
+    wmin = min(wmin, __shfl_xor(wmin, o, 64));
+  }
+  if (hmin == 0x7fff) hmin = 1;
+  if (wmin == 0x7fff) wmin = 1;
+  const int k = min(31 - __builtin_clz(hmin), ST_LEVELS - 1), l = min(31 - __builtin_clz(wmin), ST_LEVELS - 1);
+  int nr = empty ? 0 : (nh + (1 << k) - 1) >> k, nc = empty ? 0 : (nw + (1 << l) - 1) >> l;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    nr = max(nr, __shfl_xor(nr, o, 64));
+    nc = max(nc, __shfl_xor(nc, o, 64));
+  }
+  unsigned r = 1u;  // empty: y0 = 1, y1 = 0, x0 = x1 = 0
+  if (!empty) r = (unsigned)hs | (unsigned)(he - (1 << k)) << 8 | (unsigned)ws << 16 | (unsigned)(we - (1 << l)) << 24;
+  if (lane == 60) r = (unsigned)nr | (unsigned)nc << 8;
+  if (lane == 61) r = (unsigned)b;
+  if (lane == 62) r = __builtin_bit_cast(unsigned, mul);
+  if (lane == 63) r = (unsigned)k | (unsigned)l << 4;
+  rec[(long)m * 64 + lane] = r;
+  if (lane == 0) cls[m] = (b >= 0 && b < p.N) ? (unsigned char)((b * ST_LEVELS + l) * ST_LEVELS + k) : (unsigned char)255;
+}
+
+// chunk-major copy with cells of VD dwords (roi_chunk_major_kernel is the VD = 4 form; kept separate: its 16-byte tile is the
+// walking kernel's measured path)
+template <int VD>
+__global__ __launch_bounds__(256) void roi_chunk_major_vd_kernel(const char* __restrict__ feat, char* __restrict__ cm, int HW, int C) {
+  typedef int cellv __attribute__((ext_vector_type(VD)));
+  constexpr int CB = VD * 4, CH = VD * 2;
+  __shared__ cellv tile[32][33];
+  const int nchunks = C / CH;
+  const int px0 = blockIdx.x * 32, ch0 = blockIdx.y * 32, img = blockIdx.z;
+  const char* src = feat + (long)img * HW * C * 2;
+  char* dst = cm + (long)img * nchunks * HW * CB;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + 256 * i, pl = idx >> 5, cl = idx & 31;
+    cellv x;
+#pragma unroll
+    for (int e = 0; e < VD; ++e) x[e] = 0;
+    if (px0 + pl < HW && ch0 + cl < nchunks) x = *(const cellv*)(src + ((long)(px0 + pl) * C + (ch0 + cl) * CH) * 2);
+#pragma unroll
+    for (int e = 0; e < VD; ++e) x[e] = bf16x2_order(x[e]);
+    tile[pl][cl] = x;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = threadIdx.x + 256 * i, cl = idx >> 5, pl = idx & 31;
+    if (px0 + pl < HW && ch0 + cl < nchunks) *(cellv*)(dst + ((long)(ch0 + cl) * HW + px0 + pl) * CB) = tile[pl][cl];
+  }
+}
+
+template <int VD, int SB>  // SB: slice cells per thread (>= ceil(H * W / 1024))
+__global__ __launch_bounds__(1024) void roi_pool7_st_kernel(RoiParams p, const unsigned* __restrict__ rec, const unsigned char* __restrict__ cls) {
+  typedef int cellv __attribute__((ext_vector_type(VD)));
+  typedef __attribute__((address_space(3))) const cellv* lds_cell_t;
+  constexpr int CB = VD * 4, CH = VD * 2, NT = 1024, NW = 16;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int HW = p.H * p.W, W = p.W;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned short* list = (unsigned short*)(smem + (size_t)HW * CB);
+  int* cnt = (int*)(list + ((p.M + 7) & ~7));  // [0..4] ROIs per level, [8..12] fill cursors
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int nbl = p.N * ST_LEVELS;
+  const int logical = xcd_remap(blockIdx.x, gridDim.x);  // the blocks of one slice (its images and levels) share an XCD's L2
+  const int sl = logical / nbl, bl = logical - sl * nbl;
+  const int b = bl / ST_LEVELS, l = bl - b * ST_LEVELS;
+  const int c0 = sl * CH;
+  // ---- the ROIs of this (image, l), by k ------------------------------------------------------------------------------------
+  if (tid < 16) cnt[tid] = 0;
+  __syncthreads();
+  for (int m = tid; m < p.M; m += NT) {
+    const unsigned d = (unsigned)cls[m] - (unsigned)(bl * ST_LEVELS);
+    if (d < (unsigned)ST_LEVELS) atomicAdd(&cnt[d], 1);
+  }
+  __syncthreads();
+  int start[ST_LEVELS + 1];
+  start[0] = 0;
+#pragma unroll
+  for (int k = 0; k < ST_LEVELS; ++k) start[k + 1] = start[k] + __builtin_amdgcn_readfirstlane(cnt[k]);
+  if (start[ST_LEVELS] == 0) return;
+  // ---- the slice: one contiguous run of the chunk-major copy -> registers -> LDS --------------------------------------------
+  cellv own[SB];
+  const char* src = p.cm + ((long)b * (p.C / CH) + sl) * HW * CB;
+#pragma unroll
+  for (int j = 0; j < SB; ++j) own[j] = *(const cellv*)(src + (long)min(tid + j * NT, HW - 1) * CB);
+  for (int m = tid; m < p.M; m += NT) {
+    const unsigned d = (unsigned)cls[m] - (unsigned)(bl * ST_LEVELS);
+    if (d < (unsigned)ST_LEVELS) {
+      int st0 = start[0];
+#pragma unroll
+      for (int k = 1; k < ST_LEVELS; ++k) st0 = d == (unsigned)k ? start[k] : st0;
+      list[st0 + atomicAdd(&cnt[8 + d], 1)] = (unsigned short)m;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < SB; ++j) *(cellv*)(smem + (size_t)min(tid + j * NT, HW - 1) * CB) = own[j];
+  __syncthreads();
+  // ---- l doubling steps along the rows --------------------------------------------------------------------------------------
+  if (l > 0) {
+    int xs[SB];
+#pragma unroll
+    for (int j = 0; j < SB; ++j) {
+      const unsigned i = (unsigned)min(tid + j * NT, HW - 1);
+      xs[j] = (int)(i - __umulhi(i, p.walk_wmagic) * (unsigned)W);
+    }
+    for (int s = 1; s < (1 << l); s <<= 1) {
+      cellv o[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int i = min(tid + j * NT, HW - 1);
+        o[j] = *(lds_cell_t)(uintptr_t)(lds0 + (unsigned)(xs[j] + s < W ? i + s : i) * CB);
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j)
+#pragma unroll
+        for (int e = 0; e < VD; ++e) own[j][e] = pk_max_i16(own[j][e], o[j][e]);
+      __syncthreads();
+#pragma unroll
+      for (int j = 0; j < SB; ++j) *(cellv*)(smem + (size_t)min(tid + j * NT, HW - 1) * CB) = own[j];
+      __syncthreads();
+    }
+  }
+  // ---- level by level down the columns; the ROIs of each level ------------------------------------------------------------------
+  const int T = 1 << l;
+  int curk = 0;
+#pragma unroll 1
+  for (int k = 0; k < ST_LEVELS; ++k) {
+    int seg0 = start[0], seg1 = start[1];
+#pragma unroll
+    for (int q = 1; q < ST_LEVELS; ++q) {
+      seg0 = k == q ? start[q] : seg0;
+      seg1 = k == q ? start[q + 1] : seg1;
+    }
+    if (seg0 == seg1) continue;
+    for (; curk < k; ++curk) {
+      const int sw = (1 << curk) * W;
+      cellv o[SB];
+#pragma unroll
+      for (int j = 0; j < SB; ++j) {
+        const int i = min(tid + j * NT, HW - 1);
+        o[j] = *(lds_cell_t)(uintptr_t)(lds0 + (unsigned)(i + sw < HW ? i + sw : i) * CB);
+      }
+#pragma unroll
+      for (int j = 0; j < SB; ++j)
+#pragma unroll
+        for (int e = 0; e < VD; ++e) own[j][e] = pk_max_i16(own[j][e], o[j][e]);
+      __syncthreads();  // (also: every wave is done pooling the previous level out of the table)
+#pragma unroll
+      for (int j = 0; j < SB; ++j) *(cellv*)(smem + (size_t)min(tid + j * NT, HW - 1) * CB) = own[j];
+      __syncthreads();
+    }
+    const int S = 1 << k;
+    for (int base = seg0 + wave; base < seg1; base += NW * ST_BATCH) {
+      int my = 0;
+      if (lane < ST_BATCH) my = list[min(base + lane * NW, seg1 - 1)];
+      unsigned rq[ST_BATCH];
+#pragma unroll
+      for (int q = 0; q < ST_BATCH; ++q) rq[q] = rec[(long)__builtin_amdgcn_readlane(my, q) * 64 + lane];
+#pragma unroll
+      for (int q = 0; q < ST_BATCH; ++q) {
+        if (base + q * NW >= seg1) break;
+        const int m = __builtin_amdgcn_readlane(my, q);
+        const unsigned r = rq[q];
+        const unsigned meta = (unsigned)__builtin_amdgcn_readlane((int)r, 60);
+        const float mul = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)r, 62));
+        const int max_nr = meta & 0xff, max_nc = meta >> 8 & 0xff;
+        const int y0 = r & 0xff, y1 = r >> 8 & 0xff, x0 = r >> 16 & 0xff, x1 = r >> 24;
+        const bool empty = y1 < y0;
+        cellv acc;
+        if (max_nr <= 2 && max_nc <= 2) {
+          const unsigned r0 = (unsigned)(y0 * W), r1 = (unsigned)(y1 * W);
+          const cellv a = *(lds_cell_t)(uintptr_t)(lds0 + (r0 + (unsigned)x0) * CB);
+          const cellv bq = *(lds_cell_t)(uintptr_t)(lds0 + (r0 + (unsigned)x1) * CB);
+          const cellv c = *(lds_cell_t)(uintptr_t)(lds0 + (r1 + (unsigned)x0) * CB);
+          const cellv d = *(lds_cell_t)(uintptr_t)(lds0 + (r1 + (unsigned)x1) * CB);
+#pragma unroll
+          for (int e = 0; e < VD; ++e) acc[e] = pk_max_i16(pk_max_i16(a[e], bq[e]), pk_max_i16(c[e], d[e]));
+        } else {
+#pragma unroll
+          for (int e = 0; e < VD; ++e) acc[e] = (int)0x80008000u;
+          for (int i = 0; i < max_nr; ++i) {
+            const unsigned row = (unsigned)(min(y0 + i * S, y1) * W);
+            for (int j = 0; j < max_nc; ++j) {
+              const cellv x = *(lds_cell_t)(uintptr_t)(lds0 + (row + (unsigned)min(x0 + j * T, x1)) * CB);
+#pragma unroll
+              for (int e = 0; e < VD; ++e) acc[e] = pk_max_i16(acc[e], x[e]);
+            }
+          }
+        }
+        if (lane < 49) {
+          bf16_t* dst = (bf16_t*)p.out + (long)m * p.ld_out + (long)c0 * 49 + lane;
+#pragma unroll
+          for (int e = 0; e < VD; ++e) {
+            const uint32_t y = empty ? 0u : (uint32_t)bf16x2_order(acc[e]);
+            typedef float f32x2_t __attribute__((ext_vector_type(2)));
+            typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+            const f32x2_t f = f32x2_t{__builtin_bit_cast(float, y << 16), __builtin_bit_cast(float, y & 0xffff0000u)} * mul;
+            const uint32_t o = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
+            dst[(2 * e) * 49] = (bf16_t)(o & 0xffffu);
+            dst[(2 * e + 1) * 49] = (bf16_t)(o >> 16);
+          }
+        }
+      }
+    }
+  }
+}
+
+static int g_roi_st = 1;  // drn_tune(DRN_TUNE_ROI_ST = 31): 0 = off, 1 = maps of 4-channel cells (default), 2 = also every map whose 8-channel slice fits
+static size_t roi_st_align(size_t x) { return (x + 255) & ~(size_t)255; }
+// cells of VD dwords for this map under the sparse-table kernel (0: not its shape)
+static int roi_st_vd(int N, int H, int W, int C, int M) {
+  if (!g_roi_st || H < 2 || H > 255 || W < 2 || W > 255 || N < 1 || N > 10 || M < 64 || M > 16384) return 0;
+  const size_t extra = (size_t)((M + 7) & ~7) * 2 + 64;
+  const size_t hw = (size_t)H * W;
+  if (hw > 20 * 1024) return 0;
+  const bool fits8 = C % 8 == 0 && hw * 16 + extra <= 160 * 1024, fits4 = C % 4 == 0 && hw * 8 + extra <= 160 * 1024;
+  if (g_roi_st == 2 && fits8) return 4;
+  // default: only the maps the window kernels take with 4-channel cells (no 8-channel slice in 154 KB)
+  if (hw * 16 > 154 * 1024 && fits4) return 2;
+  return 0;
+}
+static size_t roi_st_ws_bytes(int N, int H, int W, int C, int M) {
+  return roi_st_align((size_t)N * H * W * C * 2) + roi_st_align((size_t)M * 256) + roi_st_align((size_t)M);
+}
+static bool launch_roi_st(const RoiParams& p0, hipStream_t st, void* ws, size_t ws_bytes) {
+  RoiParams p = p0;
+  const int vd = roi_st_vd(p.N, p.H, p.W, p.C, p.M);
+  if (!vd || !ws || (((uintptr_t)ws) & 15) || ws_bytes < roi_st_ws_bytes(p.N, p.H, p.W, p.C, p.M)) return false;
+  char* cm = (char*)ws;
+  unsigned* rec = (unsigned*)(cm + roi_st_align((size_t)p.N * p.H * p.W * p.C * 2));
+  unsigned char* cls = (unsigned char*)rec + roi_st_align((size_t)p.M * 256);
+  const int HW = p.H * p.W, ch = vd * 2, nchunks = p.C / ch;
+  const int sb = (HW + 1023) / 1024;
+  const void* fn = nullptr;
+#define ST_PICK(VD_, SB_) fn = (const void*)roi_pool7_st_kernel<VD_, SB_>
+  if (vd == 2) { if (sb <= 10) ST_PICK(2, 10); else if (sb <= 15) ST_PICK(2, 15); else ST_PICK(2, 20); }
+  else { if (sb <= 5) ST_PICK(4, 5); else ST_PICK(4, 10); }
+#undef ST_PICK
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
+  hipLaunchKernelGGL(roi_st_prep_kernel, dim3((p.M + 3) / 4), dim3(256), 0, st, p, rec, cls);
+  const dim3 cgrid((HW + 31) / 32, (nchunks + 31) / 32, p.N);
+  if (vd == 2) hipLaunchKernelGGL(roi_chunk_major_vd_kernel<2>, cgrid, dim3(256), 0, st, p.feat, cm, HW, p.C);
+  else hipLaunchKernelGGL(roi_chunk_major_vd_kernel<4>, cgrid, dim3(256), 0, st, p.feat, cm, HW, p.C);
+  p.cm = cm;
+  p.walk_wmagic = (unsigned)((0x100000000ull + (unsigned)p.W - 1) / (unsigned)p.W);
+  p.out_t = nullptr;
+  const size_t smem = (size_t)HW * vd * 4 + (size_t)((p.M + 7) & ~7) * 2 + 64;
+  const dim3 grid((unsigned)nchunks * p.N * ST_LEVELS), block(1024);
+  const unsigned* rec_c = rec;
+  const unsigned char* cls_c = cls;
+  void* args[] = {(void*)&p, (void*)&rec_c, (void*)&cls_c};
+  return hipLaunchKernel(fn, grid, block, args, smem, st) == hipSuccess;
+}
+
 static int g_roi_lane = 1;  // drn_tune(DRN_TUNE_ROI_LANE = 19): 0 = the 64-ROI kernel writes A as before
 // A (all channels) through the lane-per-bin kernel; false when the map slice of even ONE chunk does not fit
 // chunks per block: as many as fit 38 KB (four 8-wave blocks per CU), else 76 KB (two), else one chunk in <= 154 KB; 0: none fits
@@ -1522,6 +1824,7 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st, void* ws = null
     per_chunk = (size_t)p.H * p.W * 8;
   }
   if (!nck) return false;
+  if (launch_roi_st(p, st, ws, ws_bytes)) return true;  // large maps: four table cells per bin instead of the window's ~77
   const size_t smem = per_chunk * nck;
   static bool attr = false;
   if (!attr) {
@@ -1869,6 +2172,12 @@ __attribute__((visibility("hidden"))) int drn_roi_set_lane(int on) {
   return old;
 }
 
+__attribute__((visibility("hidden"))) int drn_roi_set_st(int on) {
+  const int old = g_roi_st;
+  if (on >= 0 && on <= 2) g_roi_st = on;
+  return old;
+}
+
 __attribute__((visibility("hidden"))) int drn_roi_set_prefetch(int on) {
   const int old = g_roi_pf;
   g_roi_pf = on != 0;
@@ -2061,6 +2370,7 @@ int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* object
 long drn_roi_pool_workspace_bytes(int N, int H, int W, int C, int P, int M, int mode, int has_argmax, int in_dtype, int out_dtype) {
   if (N < 1 || H < 1 || W < 1 || C < 1) return 0;
   if (mode != 0 || P != 7 || has_argmax || in_dtype != DRN_BF16 || out_dtype != DRN_BF16 || M < ROI_G64 || C % G64_CH != 0) return 0;
+  if (g_roi_lane != 0 && roi_st_vd(N, H, W, C, M)) return (long)roi_st_ws_bytes(N, H, W, C, M);
   return g_roi_lane != 0 && g_roi_lane != 2 && roi_walk_applies(H, W, C) ? (long)N * H * W * C * 2 : 0;
 }
 

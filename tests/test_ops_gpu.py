@@ -924,6 +924,77 @@ def test_roi_pool_lane_kernel_equals_map64(drn, C, H, W, R, t0, n_img):
         assert torch.equal(res[lane][1][t0 * 49:, :R], res[0][1][t0 * 49:, :R]), lane
 
 
+def _rois_st(R, n_img, imw, imh, seed):
+    """boxes for the sparse-table kernel's cases: every size from a few pixels to the whole image (bins of 1 .. 36 cells: all
+    five levels and, beyond 32, the block loop), boxes hanging over every edge (clipped bins: a ROI's smallest bin sets its level,
+    the others loop), boxes outside, degenerate boxes, .5 rounding cases"""
+    rs = np.random.RandomState(seed)
+    w, h = np.exp(rs.rand(R) * np.log(imw / 4.0)) * 4.0, np.exp(rs.rand(R) * np.log(imh / 4.0)) * 4.0
+    x0, y0 = rs.rand(R) * (imw - w), rs.rand(R) * (imh - h)
+    r = np.stack([rs.randint(0, n_img, R), x0, y0, x0 + w, y0 + h], 1)
+    q = R // 8
+    r[:q, 1] -= imw * 0.3 * rs.rand(q)       # over the left / top edge
+    r[:q, 2] -= imh * 0.3 * rs.rand(q)
+    r[q:2 * q, 3] += imw * 0.3 * rs.rand(q)  # over the right / bottom edge
+    r[q:2 * q, 4] += imh * 0.3 * rs.rand(q)
+    r[2 * q, 1:] = [0, 0, imw, imh]          # the whole image
+    r[2 * q + 1, 1:] = [-50, -50, -40, -40]  # outside
+    r[2 * q + 2, 1:] = [12.0, 20.0, 12.0, 20.0]
+    r[2 * q + 3, 1:] = [imw + 10, 5, imw + 90, 80]
+    r[2 * q + 4, 1:] = [-30, imh * 0.5, imw + 30, imh * 0.5 + 3]  # a full-width sliver
+    return torch.from_numpy(r.astype(np.float32))
+
+
+@pytest.mark.parametrize("C,H,W,R,n_img,st,scale", [(64, 99, 151, 300, 2, 1, 0.125),  # the DC5 stride-8 map: 4-channel cells, 15 cells per thread
+                                                   (16, 120, 160, 200, 1, 1, 0.125),  # the largest slice that fits (20 cells per thread)
+                                                   (8, 70, 255, 300, 3, 1, 0.125),    # 255 columns: bins of 36 cells - three blocks of 16
+                                                   (8, 81, 101, 120, 10, 2, 0.125),   # ten images, 8-channel cells
+                                                   (32, 63, 92, 300, 2, 2, 0.0625),   # forced: 8-channel cells (10 cells per thread)
+                                                   (64, 43, 58, 200, 3, 2, 0.0625),   # ... 5 cells per thread
+                                                   (16, 30, 40, 64, 1, 2, 0.0625)])
+def test_roi_pool_sparse_table_kernel(drn, C, H, W, R, n_img, st, scale):
+    """Round 6: RoIPool from a sparse table of block maxima (roi_pool7_st_kernel; DRN_TUNE_ROI_ST) - four table cells per bin
+    instead of every cell of the window.  Against the window kernels (knob 0) and the oracle, bit for bit; with and without the
+    objectness scale; without the workspace the entry takes the window kernels (same result)."""
+    dtype, P = torch.bfloat16, 7
+    feat = _rnd((n_img, C, H, W), 51)
+    rois = _rois_st(R, n_img, W / scale, H / scale, 52)
+    obj = torch.rand(R)
+    fd = feat.permute(0, 2, 3, 1).contiguous().to(DEV).to(dtype)
+    k = C * P * P
+    lib = drn.C.lib()
+    res = {}
+    for knob in (0, st):
+        old = drn.tune(drn.TUNE_ROI_ST, knob)
+        try:
+            want = lib.drn_roi_pool_workspace_bytes(n_img, H, W, C, P, R, 0, 0, drn.C.dt(dtype), drn.C.dt(dtype))
+            if knob:
+                assert want >= n_img * H * W * C * 2 + R * 257, "the shape must take the sparse-table kernel"
+            a = torch.full((R, drn.kpad(k, dtype)), 3.0, dtype=dtype, device=DEV)
+            a[:, k:] = 0
+            drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale, out=a)
+            b = drn.roi_pool_nhwc(fd, rois.to(DEV), None, P, scale)
+            torch.cuda.synchronize()
+            res[knob] = (a, b)
+        finally:
+            drn.tune(drn.TUNE_ROI_ST, old)
+    ref, _ = O.roi_pool_forward(_q(feat, dtype), rois, P, scale)
+    ref1 = _q(ref * (obj + 1).view(-1, 1, 1, 1), dtype).reshape(R, -1)
+    assert torch.equal(res[st][0], res[0][0])
+    assert torch.equal(res[st][1], res[0][1])
+    assert torch.equal(res[st][0][:, :k].float().cpu(), ref1)
+    assert torch.equal(res[st][1][:, :k].float().cpu(), _q(ref, dtype).reshape(R, -1))
+    assert (res[st][0][:, k:] == 0).all()
+    old = drn.tune(drn.TUNE_ROI_ST, st)
+    drn.ROI_WORKSPACE = False
+    try:
+        c = drn.roi_pool_nhwc(fd, rois.to(DEV), obj.to(DEV), P, scale)
+    finally:
+        drn.ROI_WORKSPACE = True
+        drn.tune(drn.TUNE_ROI_ST, old)
+    assert torch.equal(c, res[0][0])
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("aligned,sr", [(False, 0), (True, 0), (True, 2)])
 def test_roi_align(drn, dtype, aligned, sr):
