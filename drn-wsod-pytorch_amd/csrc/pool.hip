@@ -1592,7 +1592,8 @@ __global__ __launch_bounds__(256) void roi_chunk_major_vd_kernel(const char* __r
   }
 }
 
-template <int VD, int SB>  // SB: slice cells per thread (>= ceil(H * W / 1024))
+__device__ unsigned long long g_st_prof[8];  // PROF builds (tools/roi_st_probe.py): shader-clock cycles of block phases as thread 0 sees them
+template <int VD, int SB, bool PROF = false>  // SB: slice cells per thread (>= ceil(H * W / 1024))
 __global__ __launch_bounds__(1024) void roi_pool7_st_kernel(RoiParams p, const unsigned* __restrict__ rec, const unsigned char* __restrict__ cls) {
   typedef int cellv __attribute__((ext_vector_type(VD)));
   typedef __attribute__((address_space(3))) const cellv* lds_cell_t;
@@ -1602,12 +1603,18 @@ __global__ __launch_bounds__(1024) void roi_pool7_st_kernel(RoiParams p, const u
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   unsigned short* list = (unsigned short*)(smem + (size_t)HW * CB);
   int* cnt = (int*)(list + ((p.M + 7) & ~7));  // [0..4] ROIs per level, [8..12] fill cursors
+  constexpr int SCR = (CH * 98 + 15) & ~15;    // a wave's output run of one ROI: CH channels x 49 bins
+  char* scr = (char*)(cnt + 16) + wave * SCR;
+  const int last = (HW - 1) * CB;              // byte offset of the slice's last cell
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int nbl = p.N * ST_LEVELS;
   const int logical = xcd_remap(blockIdx.x, gridDim.x);  // the blocks of one slice (its images and levels) share an XCD's L2
   const int sl = logical / nbl, bl = logical - sl * nbl;
   const int b = bl / ST_LEVELS, l = bl - b * ST_LEVELS;
   const int c0 = sl * CH;
+  unsigned long long tp[5] = {0, 0, 0, 0, 0}, t0 = 0, t1;
+  if constexpr (PROF) t0 = __builtin_amdgcn_s_memtime();
+#define ST_CLK(K) do { if constexpr (PROF) { t1 = __builtin_amdgcn_s_memtime(); tp[K] += t1 - t0; t0 = t1; } } while (0)
   // ---- the ROIs of this (image, l), by k ------------------------------------------------------------------------------------
   if (tid < 16) cnt[tid] = 0;
   __syncthreads();
@@ -1621,6 +1628,7 @@ __global__ __launch_bounds__(1024) void roi_pool7_st_kernel(RoiParams p, const u
 #pragma unroll
   for (int k = 0; k < ST_LEVELS; ++k) start[k + 1] = start[k] + __builtin_amdgcn_readfirstlane(cnt[k]);
   if (start[ST_LEVELS] == 0) return;
+  ST_CLK(0);
   // ---- the slice: one contiguous run of the chunk-major copy -> registers -> LDS --------------------------------------------
   cellv own[SB];
   const char* src = p.cm + ((long)b * (p.C / CH) + sl) * HW * CB;
@@ -1638,31 +1646,28 @@ __global__ __launch_bounds__(1024) void roi_pool7_st_kernel(RoiParams p, const u
 #pragma unroll
   for (int j = 0; j < SB; ++j) *(cellv*)(smem + (size_t)min(tid + j * NT, HW - 1) * CB) = own[j];
   __syncthreads();
-  // ---- l doubling steps along the rows --------------------------------------------------------------------------------------
-  if (l > 0) {
-    int xs[SB];
+  ST_CLK(1);
+  // ---- doubling steps: cell i takes the maximum with cell i + stride (stride = s cells along a row, s * W cells down a column).
+  // No edge cases: a partner beyond the row's end is the next row's cell, one beyond the map the last cell - real values in cells
+  // that cover no valid block (x + 2s > W or y + 2s > H: never looked up, never the partner of a valid cell at a later level)
+  int off[SB];
 #pragma unroll
-    for (int j = 0; j < SB; ++j) {
-      const unsigned i = (unsigned)min(tid + j * NT, HW - 1);
-      xs[j] = (int)(i - __umulhi(i, p.walk_wmagic) * (unsigned)W);
-    }
-    for (int s = 1; s < (1 << l); s <<= 1) {
-      cellv o[SB];
+  for (int j = 0; j < SB; ++j) off[j] = min(tid + j * NT, HW - 1) * CB;
+  auto step = [&](int stride_bytes) {
+    cellv o[SB];
 #pragma unroll
-      for (int j = 0; j < SB; ++j) {
-        const int i = min(tid + j * NT, HW - 1);
-        o[j] = *(lds_cell_t)(uintptr_t)(lds0 + (unsigned)(xs[j] + s < W ? i + s : i) * CB);
-      }
+    for (int j = 0; j < SB; ++j) o[j] = *(lds_cell_t)(uintptr_t)(lds0 + (unsigned)min(off[j] + stride_bytes, last));
 #pragma unroll
-      for (int j = 0; j < SB; ++j)
+    for (int j = 0; j < SB; ++j)
 #pragma unroll
-        for (int e = 0; e < VD; ++e) own[j][e] = pk_max_i16(own[j][e], o[j][e]);
-      __syncthreads();
+      for (int e = 0; e < VD; ++e) own[j][e] = pk_max_i16(own[j][e], o[j][e]);
+    __syncthreads();  // every partner has been read (and: every wave is done pooling the previous level out of the table)
 #pragma unroll
-      for (int j = 0; j < SB; ++j) *(cellv*)(smem + (size_t)min(tid + j * NT, HW - 1) * CB) = own[j];
-      __syncthreads();
-    }
-  }
+    for (int j = 0; j < SB; ++j) *(cellv*)(smem + off[j]) = own[j];
+    __syncthreads();
+  };
+  for (int s = 1; s < (1 << l); s <<= 1) step(s * CB);
+  ST_CLK(2);
   // ---- level by level down the columns; the ROIs of each level ------------------------------------------------------------------
   const int T = 1 << l;
   int curk = 0;
@@ -1675,23 +1680,8 @@ __global__ __launch_bounds__(1024) void roi_pool7_st_kernel(RoiParams p, const u
       seg1 = k == q ? start[q + 1] : seg1;
     }
     if (seg0 == seg1) continue;
-    for (; curk < k; ++curk) {
-      const int sw = (1 << curk) * W;
-      cellv o[SB];
-#pragma unroll
-      for (int j = 0; j < SB; ++j) {
-        const int i = min(tid + j * NT, HW - 1);
-        o[j] = *(lds_cell_t)(uintptr_t)(lds0 + (unsigned)(i + sw < HW ? i + sw : i) * CB);
-      }
-#pragma unroll
-      for (int j = 0; j < SB; ++j)
-#pragma unroll
-        for (int e = 0; e < VD; ++e) own[j][e] = pk_max_i16(own[j][e], o[j][e]);
-      __syncthreads();  // (also: every wave is done pooling the previous level out of the table)
-#pragma unroll
-      for (int j = 0; j < SB; ++j) *(cellv*)(smem + (size_t)min(tid + j * NT, HW - 1) * CB) = own[j];
-      __syncthreads();
-    }
+    for (; curk < k; ++curk) step((W << curk) * CB);
+    ST_CLK(3);
     const int S = 1 << k;
     for (int base = seg0 + wave; base < seg1; base += NW * ST_BATCH) {
       int my = 0;
@@ -1708,10 +1698,10 @@ __global__ __launch_bounds__(1024) void roi_pool7_st_kernel(RoiParams p, const u
         const float mul = __builtin_bit_cast(float, __builtin_amdgcn_readlane((int)r, 62));
         const int max_nr = meta & 0xff, max_nc = meta >> 8 & 0xff;
         const int y0 = r & 0xff, y1 = r >> 8 & 0xff, x0 = r >> 16 & 0xff, x1 = r >> 24;
-        const bool empty = y1 < y0;
+        const int keep = y1 < y0 ? 0 : -1;  // an empty bin is +0
         cellv acc;
         if (max_nr <= 2 && max_nc <= 2) {
-          const unsigned r0 = (unsigned)(y0 * W), r1 = (unsigned)(y1 * W);
+          const unsigned r0 = __umul24((unsigned)y0, (unsigned)W), r1 = __umul24((unsigned)y1, (unsigned)W);
           const cellv a = *(lds_cell_t)(uintptr_t)(lds0 + (r0 + (unsigned)x0) * CB);
           const cellv bq = *(lds_cell_t)(uintptr_t)(lds0 + (r0 + (unsigned)x1) * CB);
           const cellv c = *(lds_cell_t)(uintptr_t)(lds0 + (r1 + (unsigned)x0) * CB);
@@ -1722,7 +1712,7 @@ __global__ __launch_bounds__(1024) void roi_pool7_st_kernel(RoiParams p, const u
 #pragma unroll
           for (int e = 0; e < VD; ++e) acc[e] = (int)0x80008000u;
           for (int i = 0; i < max_nr; ++i) {
-            const unsigned row = (unsigned)(min(y0 + i * S, y1) * W);
+            const unsigned row = __umul24((unsigned)min(y0 + i * S, y1), (unsigned)W);
             for (int j = 0; j < max_nc; ++j) {
               const cellv x = *(lds_cell_t)(uintptr_t)(lds0 + (row + (unsigned)min(x0 + j * T, x1)) * CB);
 #pragma unroll
@@ -1730,37 +1720,56 @@ __global__ __launch_bounds__(1024) void roi_pool7_st_kernel(RoiParams p, const u
             }
           }
         }
+        // the ROI's CH x 49 values are ONE run of A: through the wave's LDS scratch (2-byte writes at [channel][bin]) they leave as
+        // one 8- / 16-byte store per lane instead of CH 2-byte stores (a wave's LDS operations execute in order: the scratch is
+        // reused from ROI to ROI without a wait)
         if (lane < 49) {
-          bf16_t* dst = (bf16_t*)p.out + (long)m * p.ld_out + (long)c0 * 49 + lane;
+          unsigned short* sp = (unsigned short*)scr + lane;
 #pragma unroll
           for (int e = 0; e < VD; ++e) {
-            const uint32_t y = empty ? 0u : (uint32_t)bf16x2_order(acc[e]);
+            const uint32_t y = (uint32_t)(bf16x2_order(acc[e]) & keep);
             typedef float f32x2_t __attribute__((ext_vector_type(2)));
             typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
             const f32x2_t f = f32x2_t{__builtin_bit_cast(float, y << 16), __builtin_bit_cast(float, y & 0xffff0000u)} * mul;
             const uint32_t o = __builtin_bit_cast(uint32_t, __builtin_convertvector(f, bf16x2_t));
-            dst[(2 * e) * 49] = (bf16_t)(o & 0xffffu);
-            dst[(2 * e + 1) * 49] = (bf16_t)(o >> 16);
+            sp[(2 * e) * 49] = (unsigned short)(o & 0xffffu);
+            sp[(2 * e + 1) * 49] = (unsigned short)(o >> 16);
           }
+          const cellv v = *(const volatile cellv*)(scr + lane * CB);
+          *(cellv*)(p.out + ((long)m * p.ld_out + (long)c0 * 49) * 2 + lane * CB) = v;
         }
       }
     }
+    if constexpr (PROF) {
+      __syncthreads();  // (a profile build waits for the level's slowest wave here; the product waits in the next step)
+      ST_CLK(4);
+    }
   }
+  if constexpr (PROF) {
+    if (tid == 0) {
+      for (int q = 0; q < 5; ++q) atomicAdd(&g_st_prof[q], tp[q]);
+      atomicAdd(&g_st_prof[5], 1ull);
+      atomicAdd(&g_st_prof[6], (unsigned long long)start[ST_LEVELS]);
+    }
+  }
+#undef ST_CLK
 }
 
-static int g_roi_st = 1;  // drn_tune(DRN_TUNE_ROI_ST = 31): 0 = off, 1 = maps of 4-channel cells (default), 2 = also every map whose 8-channel slice fits
+static int g_roi_st_prof = 0;  // drn_tune(31, 10 / 11): profile builds on / off; (31, 12): print and clear the counters
+static int g_roi_st = 1;  // drn_tune(DRN_TUNE_ROI_ST = 31): 0 = off, 1 = where it is faster (default: large maps with enough ROIs), 2 = every map whose slice fits
 static size_t roi_st_align(size_t x) { return (x + 255) & ~(size_t)255; }
 // cells of VD dwords for this map under the sparse-table kernel (0: not its shape)
 static int roi_st_vd(int N, int H, int W, int C, int M) {
   if (!g_roi_st || H < 2 || H > 255 || W < 2 || W > 255 || N < 1 || N > 10 || M < 64 || M > 16384) return 0;
-  const size_t extra = (size_t)((M + 7) & ~7) * 2 + 64;
   const size_t hw = (size_t)H * W;
   if (hw > 20 * 1024) return 0;
-  const bool fits8 = C % 8 == 0 && hw * 16 + extra <= 160 * 1024, fits4 = C % 4 == 0 && hw * 8 + extra <= 160 * 1024;
-  if (g_roi_st == 2 && fits8) return 4;
-  // default: only the maps the window kernels take with 4-channel cells (no 8-channel slice in 154 KB)
-  if (hw * 16 > 154 * 1024 && fits4) return 2;
-  return 0;
+  const size_t list = (size_t)((M + 7) & ~7) * 2 + 64;  // ROI list + counters; then a 400- / 784-byte scratch per wave
+  const bool fits8 = C % 8 == 0 && hw * 16 + list + 16 * 784 <= 160 * 1024, fits4 = C % 4 == 0 && hw * 8 + list + 16 * 400 <= 160 * 1024;
+  if (g_roi_st == 2) return fits8 ? 4 : fits4 ? 2 : 0;
+  // default: where the table's fixed cost (staging + <= 8 doubling steps per block, ~HW) is below what the window kernels spend
+  // reading every ROI's cells (~M x ROI area): profiles/r6_17_roi_st.txt, r6_18 (R = 250 / 1000 / 4000)
+  if (fits8) return (M >= 600 && hw >= 3000) || (M >= 1500 && hw >= 1800) ? 4 : 0;
+  return fits4 && M >= 400 ? 2 : 0;
 }
 static size_t roi_st_ws_bytes(int N, int H, int W, int C, int M) {
   return roi_st_align((size_t)N * H * W * C * 2) + roi_st_align((size_t)M * 256) + roi_st_align((size_t)M);
@@ -1779,6 +1788,8 @@ static bool launch_roi_st(const RoiParams& p0, hipStream_t st, void* ws, size_t 
   if (vd == 2) { if (sb <= 10) ST_PICK(2, 10); else if (sb <= 15) ST_PICK(2, 15); else ST_PICK(2, 20); }
   else { if (sb <= 5) ST_PICK(4, 5); else ST_PICK(4, 10); }
 #undef ST_PICK
+  if (g_roi_st_prof && vd == 2 && sb > 10 && sb <= 15) fn = (const void*)roi_pool7_st_kernel<2, 15, true>;
+  if (g_roi_st_prof && vd == 4 && sb > 5) fn = (const void*)roi_pool7_st_kernel<4, 10, true>;
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
   hipLaunchKernelGGL(roi_st_prep_kernel, dim3((p.M + 3) / 4), dim3(256), 0, st, p, rec, cls);
   const dim3 cgrid((HW + 31) / 32, (nchunks + 31) / 32, p.N);
@@ -1787,7 +1798,7 @@ static bool launch_roi_st(const RoiParams& p0, hipStream_t st, void* ws, size_t 
   p.cm = cm;
   p.walk_wmagic = (unsigned)((0x100000000ull + (unsigned)p.W - 1) / (unsigned)p.W);
   p.out_t = nullptr;
-  const size_t smem = (size_t)HW * vd * 4 + (size_t)((p.M + 7) & ~7) * 2 + 64;
+  const size_t smem = (size_t)HW * vd * 4 + (size_t)((p.M + 7) & ~7) * 2 + 64 + 16 * (vd == 2 ? 400 : 784);
   const dim3 grid((unsigned)nchunks * p.N * ST_LEVELS), block(1024);
   const unsigned* rec_c = rec;
   const unsigned char* cls_c = cls;
@@ -2175,6 +2186,16 @@ __attribute__((visibility("hidden"))) int drn_roi_set_lane(int on) {
 __attribute__((visibility("hidden"))) int drn_roi_set_st(int on) {
   const int old = g_roi_st;
   if (on >= 0 && on <= 2) g_roi_st = on;
+  if (on == 10 || on == 11) g_roi_st_prof = on == 10;
+  if (on == 12) {
+    unsigned long long h[8];
+    if (hipDeviceSynchronize() != hipSuccess || hipMemcpyFromSymbol(h, HIP_SYMBOL(g_st_prof), sizeof(h)) != hipSuccess) return -1;
+    const double n = h[5] ? (double)h[5] : 1.0;
+    fprintf(stderr, "roi_st profile: %llu blocks, %.1f ROIs each | shader-clock cycles per block: scan %.0f  slice %.0f  row steps %.0f  column steps %.0f  pooling %.0f\n",
+            h[5], (double)h[6] / n, h[0] / n, h[1] / n, h[2] / n, h[3] / n, h[4] / n);
+    for (auto& x : h) x = 0;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_st_prof), h, sizeof(h)) != hipSuccess) return -1;
+  }
   return old;
 }
 

@@ -945,9 +945,10 @@ def _rois_st(R, n_img, imw, imh, seed):
     return torch.from_numpy(r.astype(np.float32))
 
 
-@pytest.mark.parametrize("C,H,W,R,n_img,st,scale", [(64, 99, 151, 300, 2, 1, 0.125),  # the DC5 stride-8 map: 4-channel cells, 15 cells per thread
-                                                   (16, 120, 160, 200, 1, 1, 0.125),  # the largest slice that fits (20 cells per thread)
-                                                   (8, 70, 255, 300, 3, 1, 0.125),    # 255 columns: bins of 36 cells - three blocks of 16
+@pytest.mark.parametrize("C,H,W,R,n_img,st,scale", [(64, 99, 151, 400, 2, 1, 0.125),  # the DC5 stride-8 map: 4-channel cells, 15 cells per thread
+                                                   (16, 118, 160, 400, 1, 1, 0.125),  # the largest slices that fit (20 cells per thread)
+                                                   (8, 70, 255, 400, 3, 1, 0.125),    # 255 columns: bins of 36 cells - three blocks of 16
+                                                   (16, 50, 76, 640, 1, 1, 0.0625),   # default rule: 8-channel cells from 3000 cells x 600 ROIs
                                                    (8, 81, 101, 120, 10, 2, 0.125),   # ten images, 8-channel cells
                                                    (32, 63, 92, 300, 2, 2, 0.0625),   # forced: 8-channel cells (10 cells per thread)
                                                    (64, 43, 58, 200, 3, 2, 0.0625),   # ... 5 cells per thread
