@@ -1762,9 +1762,12 @@ static size_t roi_st_align(size_t x) { return (x + 255) & ~(size_t)255; }
 static int roi_st_vd(int N, int H, int W, int C, int M) {
   if (!g_roi_st || H < 2 || H > 255 || W < 2 || W > 255 || N < 1 || N > 10 || M < 64 || M > 16384) return 0;
   const size_t hw = (size_t)H * W;
-  if (hw > 20 * 1024) return 0;
-  const size_t list = (size_t)((M + 7) & ~7) * 2 + 64;  // ROI list + counters; then a 400- / 784-byte scratch per wave
+  if (hw > 30 * 1024) return 0;
+  const size_t list = (size_t)((M + 7) & ~7) * 2 + 64;  // ROI list + counters; then a 208- / 400- / 784-byte scratch per wave
   const bool fits8 = C % 8 == 0 && hw * 16 + list + 16 * 784 <= 160 * 1024, fits4 = C % 4 == 0 && hw * 8 + list + 16 * 400 <= 160 * 1024;
+  // 2 channels per cell: the stride-8 maps of the largest test-time scales (1200 x 1600: 150 x 200 cells), twice the blocks
+  const bool fits2 = C % 2 == 0 && hw * 4 + list + 16 * 208 <= 160 * 1024;
+  if (!fits8 && !fits4) return fits2 && (g_roi_st == 2 || M >= 400) ? 1 : 0;
   if (g_roi_st == 2) return fits8 ? 4 : fits4 ? 2 : 0;
   // default: where the table's fixed cost (staging + <= 8 doubling steps per block, ~HW) is below what the window kernels spend
   // reading every ROI's cells (~M x ROI area): profiles/r6_17_roi_st.txt, r6_18 (R = 250 / 1000 / 4000)
@@ -1785,7 +1788,8 @@ static bool launch_roi_st(const RoiParams& p0, hipStream_t st, void* ws, size_t 
   const int sb = (HW + 1023) / 1024;
   const void* fn = nullptr;
 #define ST_PICK(VD_, SB_) fn = (const void*)roi_pool7_st_kernel<VD_, SB_>
-  if (vd == 2) { if (sb <= 10) ST_PICK(2, 10); else if (sb <= 15) ST_PICK(2, 15); else ST_PICK(2, 20); }
+  if (vd == 1) { if (sb <= 20) ST_PICK(1, 20); else ST_PICK(1, 30); }
+  else if (vd == 2) { if (sb <= 10) ST_PICK(2, 10); else if (sb <= 15) ST_PICK(2, 15); else ST_PICK(2, 20); }
   else { if (sb <= 5) ST_PICK(4, 5); else ST_PICK(4, 10); }
 #undef ST_PICK
   if (g_roi_st_prof && vd == 2 && sb > 10 && sb <= 15) fn = (const void*)roi_pool7_st_kernel<2, 15, true>;
@@ -1793,12 +1797,13 @@ static bool launch_roi_st(const RoiParams& p0, hipStream_t st, void* ws, size_t 
   if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return false;
   hipLaunchKernelGGL(roi_st_prep_kernel, dim3((p.M + 3) / 4), dim3(256), 0, st, p, rec, cls);
   const dim3 cgrid((HW + 31) / 32, (nchunks + 31) / 32, p.N);
-  if (vd == 2) hipLaunchKernelGGL(roi_chunk_major_vd_kernel<2>, cgrid, dim3(256), 0, st, p.feat, cm, HW, p.C);
+  if (vd == 1) hipLaunchKernelGGL(roi_chunk_major_vd_kernel<1>, cgrid, dim3(256), 0, st, p.feat, cm, HW, p.C);
+  else if (vd == 2) hipLaunchKernelGGL(roi_chunk_major_vd_kernel<2>, cgrid, dim3(256), 0, st, p.feat, cm, HW, p.C);
   else hipLaunchKernelGGL(roi_chunk_major_vd_kernel<4>, cgrid, dim3(256), 0, st, p.feat, cm, HW, p.C);
   p.cm = cm;
   p.walk_wmagic = (unsigned)((0x100000000ull + (unsigned)p.W - 1) / (unsigned)p.W);
   p.out_t = nullptr;
-  const size_t smem = (size_t)HW * vd * 4 + (size_t)((p.M + 7) & ~7) * 2 + 64 + 16 * (vd == 2 ? 400 : 784);
+  const size_t smem = (size_t)HW * vd * 4 + (size_t)((p.M + 7) & ~7) * 2 + 64 + 16 * (vd == 1 ? 208 : vd == 2 ? 400 : 784);
   const dim3 grid((unsigned)nchunks * p.N * ST_LEVELS), block(1024);
   const unsigned* rec_c = rec;
   const unsigned char* cls_c = cls;
@@ -1834,8 +1839,8 @@ static bool launch_roi_lane(const RoiParams& p0, hipStream_t st, void* ws = null
     vd = 2;
     per_chunk = (size_t)p.H * p.W * 8;
   }
-  if (!nck) return false;
   if (launch_roi_st(p, st, ws, ws_bytes)) return true;  // large maps: four table cells per bin instead of the window's ~77
+  if (!nck) return false;
   const size_t smem = per_chunk * nck;
   static bool attr = false;
   if (!attr) {

@@ -949,6 +949,8 @@ def _rois_st(R, n_img, imw, imh, seed):
                                                    (16, 118, 160, 400, 1, 1, 0.125),  # the largest slices that fit (20 cells per thread)
                                                    (8, 70, 255, 400, 3, 1, 0.125),    # 255 columns: bins of 36 cells - three blocks of 16
                                                    (16, 50, 76, 640, 1, 1, 0.0625),   # default rule: 8-channel cells from 3000 cells x 600 ROIs
+                                                   (8, 150, 200, 400, 2, 1, 0.125),   # 1200 x 1600 at stride 8: 2-channel cells, 30 cells per thread
+                                                   (8, 140, 145, 400, 1, 1, 0.125),   # ... 20 cells per thread
                                                    (8, 81, 101, 120, 10, 2, 0.125),   # ten images, 8-channel cells
                                                    (32, 63, 92, 300, 2, 2, 0.0625),   # forced: 8-channel cells (10 cells per thread)
                                                    (64, 43, 58, 200, 3, 2, 0.0625),   # ... 5 cells per thread

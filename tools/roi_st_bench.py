@@ -31,7 +31,7 @@ def timeit(fn, n=10):
 
 
 print("%-16s %-12s %10s %10s %8s" % ("map", "ROI_ST", "us", "GB/s", "of 8 TB/s"))
-for (H, W, C, stride) in ((99, 151, 2048, 8), (75, 122, 2048, 8), (120, 160, 2048, 8), (50, 76, 1024, 16), (63, 92, 1024, 16), (38, 50, 1024, 16)):
+for (H, W, C, stride) in ((99, 151, 2048, 8), (75, 122, 2048, 8), (120, 160, 2048, 8), (150, 200, 2048, 8), (50, 76, 1024, 16), (63, 92, 1024, 16), (38, 50, 1024, 16)):
     rs = np.random.RandomState(0)
     iw, ih = W * stride, H * stride
     x0, y0 = rs.rand(R) * (iw - 40), rs.rand(R) * (ih - 40)
