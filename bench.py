@@ -281,6 +281,31 @@ def trunk_roofline(pkg, device, workload, hw=(800, 1216), reps=5):
         b.record()
         torch.cuda.synchronize()
     us = a.elapsed_time(b) / reps * 1e3
+    # the same chain as ONE replayed hipGraph - how the graphed training step runs the trunk (graphed.py: g_pbb): the ~50 launches
+    # follow each other without the eager launch gaps
+    us_graph = None
+    try:
+        with torch.no_grad():
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(side):
+                bb._run_plan(x)
+                with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                    y_ = bb._run_plan(x)
+            torch.cuda.current_stream().wait_stream(side)
+            for _ in range(2):
+                g.replay()
+            torch.cuda.synchronize()
+            a.record()
+            for _ in range(reps):
+                g.replay()
+            b.record()
+            torch.cuda.synchronize()
+            us_graph = a.elapsed_time(b) / reps * 1e3
+            del g, y_
+    except Exception as ex:  # noqa: BLE001 - a side figure must not cost the bench line
+        us_graph = "unavailable: %r" % (ex,)
     # algorithmic FLOPs: walk the recorded plan (csrc/executor.hip) with the same geometry rules
     p = bb._plan_for(torch.bfloat16, 8)
     geo, gf, n_conv = {0: (h, w, 3)}, 0.0, 0
@@ -300,9 +325,12 @@ def trunk_roofline(pkg, device, workload, hw=(800, 1216), reps=5):
     return {"trunk": {"r50c4": "WS-ResNet50 C4 (stem .. res4, stride 16)", "r50dc5": "WS-ResNet50 dilated C5 (stem .. res5, res4 / res5 "
                       "dilated at stride 8: the shipped oicr_WSR_50_DC5 recipe)"}[workload], "image": "%dx%d" % (h, w),
             "bound": "mfma", "achieved": ach, "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": ach / BF16_MFMA_PEAK_TFLOPS,
-            "gflop": gf, "us": us, "conv_launches": n_conv, "ops_in_plan": int(p["n_ops"]),
+            "gflop": gf, "us": us, "us_graph_replay": us_graph,
+            "frac_graph_replay": (gf / us_graph * 1e3 / BF16_MFMA_PEAK_TFLOPS) if isinstance(us_graph, float) else None,
+            "conv_launches": n_conv, "ops_in_plan": int(p["n_ops"]),
             "timed": "%d eager drn_trunk_forward calls (one C call walks the conv chain; launch gaps included), HIP events on the "
-                     "launch stream, in this run; per-layer tables: tools/conv_bench.py -> profiles/r5_*_conv_*.txt" % reps}
+                     "launch stream, in this run (`us`, `frac`); `us_graph_replay`: the same chain captured once and replayed as a hipGraph, the "
+                     "way the graphed training step runs the trunk; per-layer tables: tools/conv_bench.py -> profiles/r6_05_conv_800.txt" % reps}
 
 
 def pmc_record(shape):

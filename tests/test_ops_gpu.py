@@ -998,6 +998,37 @@ def test_roi_pool_sparse_table_kernel(drn, C, H, W, R, n_img, st, scale):
     assert torch.equal(c, res[0][0])
 
 
+@pytest.mark.parametrize("C,H,W,R", [(2048, 99, 151, 2000),   # the shipped recipe's res5 map of an 800 x 1216 image, every channel
+                                     (256, 150, 200, 3000),    # 1200 x 1600 (largest test-time scale): 2-channel cells
+                                     (1024, 50, 76, 2000)])    # the C4 map of the same image
+def test_roi_pool_sparse_table_full_size(drn, C, H, W, R):
+    """The sparse-table kernel at BASELINE's real-image sizes (too large for the CPU oracle in a test): bit-identical to the
+    window kernels on the same inputs, and the size-independent properties of a max pool - a constant map pools to the
+    constant times the objectness scale wherever a bin is not empty, and pooling is monotone (max(a, b) pooled >= a pooled)."""
+    dtype, P, scale = torch.bfloat16, 7, 0.125
+    g = torch.Generator().manual_seed(7)
+    fd = (torch.randn((1, H, W, C), generator=g) * 0.5).to(DEV).to(dtype)
+    rois = _rois_st(R, 1, W / scale, H / scale, 53).to(DEV)
+    obj = torch.rand(R, generator=g).to(DEV)
+    k = C * P * P
+    outs = {}
+    for knob in (0, 1):
+        old = drn.tune(drn.TUNE_ROI_ST, knob)
+        try:
+            outs[knob] = drn.roi_pool_nhwc(fd, rois, obj, P, scale)
+        finally:
+            drn.tune(drn.TUNE_ROI_ST, old)
+    assert drn.C.lib().drn_roi_pool_workspace_bytes(1, H, W, C, P, R, 0, 0, drn.C.dt(dtype), drn.C.dt(dtype)) >= H * W * C * 2 + R * 257
+    assert torch.equal(outs[1], outs[0])
+    const = drn.roi_pool_nhwc(torch.full_like(fd, 1.5), rois, obj, P, scale)[:, :k].float().view(R, C, 49)
+    want = (torch.tensor(1.5, device=DEV) * (obj + 1)).to(dtype).float().view(R, 1, 1)
+    assert bool(((const == want) | (const == 0)).all())
+    assert torch.equal(const[:, 0], const[:, C - 1])  # emptiness is a property of the bin, not of the channel
+    hi = drn.roi_pool_nhwc(torch.maximum(fd, fd.flip(1)), rois, None, P, scale)[:, :k].float()
+    lo = drn.roi_pool_nhwc(fd, rois, None, P, scale)[:, :k].float()
+    assert bool((hi >= lo).all())
+
+
 @pytest.mark.parametrize("dtype", DTYPES)
 @pytest.mark.parametrize("aligned,sr", [(False, 0), (True, 0), (True, 2)])
 def test_roi_align(drn, dtype, aligned, sr):
