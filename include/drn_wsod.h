@@ -148,9 +148,13 @@ int drn_roi_pool_nhwc_t(const void* feat, const float* rois, const float* object
 /* drn_roi_pool_nhwc_t with a caller-owned scratch buffer (round 5).  Feature maps whose 8-channel slice leaves one chunk per
  * workgroup (43x58 cells and more: test-time scales, real-size training images; poolers.py:191-226 at those sizes) are first
  * copied chunk-major - [N][C/8][H*W] cells of 16 bytes - into `workspace`, so that the pooling kernel stages contiguous runs
- * instead of 16 bytes of every pixel's line (50x76 / R = 2000: 156 -> ~130 us).  drn_roi_pool_workspace_bytes returns the size
- * that helps for a shape (0: no workspace is used); workspace NULL or smaller: exactly drn_roi_pool_nhwc_t.  The workspace
- * is read and written on `stream` only and holds nothing between calls; results are bit-identical with and without it. */
+ * instead of 16 bytes of every pixel's line (50x76 / R = 2000: 156 -> ~130 us).  Round 6: large maps with enough ROIs (the rule
+ * is DRN_TUNE_ROI_ST's) are pooled from a SPARSE TABLE of block maxima built in LDS out of that copy - four table cells per bin
+ * instead of every cell of its window (the stride-8 dilated-C5 map of an 800x1216 image, R = 2000: 929 -> 314 us; 1200x1600:
+ * 4433 -> 677 us); the workspace then also holds a 256-byte record and a class byte per ROI.  drn_roi_pool_workspace_bytes
+ * returns the size that helps for a shape (0: no workspace is used); workspace NULL or smaller: exactly drn_roi_pool_nhwc_t.
+ * The workspace is read and written on `stream` only and holds nothing between calls; results are bit-identical with and
+ * without it. */
 long drn_roi_pool_workspace_bytes(int N, int H, int W, int C, int P, int M, int mode, int has_argmax, int in_dtype,
                                   int out_dtype);
 int drn_roi_pool_nhwc_ws(const void* feat, const float* rois, const float* objectness, void* out, void* out_t,
