@@ -385,6 +385,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="disable hipGraph replay of the step")
     ap.add_argument("--no-stage-ahead", action="store_true",
                     help="A/B: stage the next batch's proposals / labels on the main stream (round-2 order)")
+    ap.add_argument("--no-ring", action="store_true",
+                    help="A/B: the side stream of the graphed step waits for the main stream at the start of every step (the schedule "
+                         "before round 6) instead of the host-throttled ring of staging sets / trunk slots")
     ap.add_argument("--no-eager-fc6", action="store_true",
                     help="keep the fc6 forward GEMM inside the captured heads graph (it is then timed on the eager warm-up "
                          "steps only)")
@@ -597,7 +600,7 @@ def main():
             # eager_fc6: the fc6 forward GEMM is issued eagerly in front of the heads graph (the fc6 dW launch already is,
             # behind it), so the launches of the dominant kernel are bracketed by HIP events INSIDE the timed region
             stp = GraphedTrainStep(model, opt, batches[0], split_tail=split, lookahead=args.lookahead,
-                                   trunk_pairs=(args.trunk_group if args.trunk_pairs else False), eager_fc6=not args.no_eager_fc6,
+                                   trunk_pairs=(args.trunk_group if args.trunk_pairs else False), eager_fc6=not args.no_eager_fc6, ring=not args.no_ring,
                                    stage_ahead=not args.no_stage_ahead)
             try:
                 for i in range(args.warmup + 1):  # the first call is the eager step that primes + captures the graph
@@ -897,6 +900,9 @@ def main():
                "host_ms_per_step_unblocked": host_unblocked if use_graph else None, "hipgraph": bool(use_graph),
                "trunk_schedule": ("groups: one conv chain per %d batches, %d batches ahead" % (args.trunk_group, args.trunk_group) if args.trunk_pairs
                                   else "lookahead %d" % args.lookahead) if use_graph else "eager prefetch of the next batch",
+               "side_stream_schedule": (("ring: %d staging sets / %d trunk slots, no wait of the side stream on the main stream, host <= %d steps ahead "
+                                         "of the heads" % (stepper.RING_SETS, stepper.RING_SLOTS, stepper.RING_LAG)) if getattr(stepper, "_ring_on", False)
+                                        else "the side stream waits for the main stream at the start of every step") if use_graph else None,
                "fc6_grad_dtype": str(getattr(opt, "_comm_dtype", torch.float32)).replace("torch.", ""),
                "grad_exchange": None if not dp.exchange else {
                    "collective": ("fc6 sharded along K over the ranks: all-gather of the feature maps / proposals -> this rank's channel "

@@ -480,6 +480,8 @@ class FusedSGD:
         ev = torch.cuda.Event()
         ev.record(cur)
         self._opt_stream.wait_event(ev)
+        if what == "small":
+            self.small_ready_event = ev  # (graphed.py: recorded behind the step's heads; the graphed step's host-side throttle waits on old ones)
         with torch.cuda.stream(self._opt_stream):
             if what == "small":
                 e.flush_colsums()  # bias gradients: second stage of their column sums, off the backward's critical path

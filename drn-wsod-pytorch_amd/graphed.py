@@ -46,7 +46,7 @@ class GraphedTrainStep:
     _needs_frozen_trunk = True
 
     def __init__(self, model, optimizer, example_batch, split_tail=False, lookahead=1, trunk_pairs=False,
-                 eager_fc6=False, stage_ahead=True):
+                 eager_fc6=False, stage_ahead=True, ring=True):
         if getattr(model, "cpg", False):
             raise DrnError("CSCROIHeads decides per step, on the host, which class maps to compute: eager steps only")
         if self._needs_frozen_trunk and any(p.requires_grad for p in model.backbone.parameters()):
@@ -96,18 +96,32 @@ class GraphedTrainStep:
         for n in self.nper:
             off.append(off[-1] + n)
         mk = lambda: torch.zeros((M, 5), dtype=torch.float32, device=dev)
-        self.rois, self.rois_next = mk(), mk()
-        for t in (self.rois, self.rois_next):
+        # Proposals / objectness / labels of the NEXT batch are staged on the side stream and read by the pooling piece at the end
+        # of the step.  RING (round 6, trunk groups on one GPU): RING_SETS staging sets and RING_SLOTS trunk-feature slots, and
+        # the side stream does NOT wait for the main stream at all - any such wait, even on an event that completed two steps
+        # ago, costs ~1 % of the step (profiles/r6_40_side_wait_experiments.txt).  What a wait guaranteed - the previous reader of
+        # a set / slot is done before the side stream overwrites it - the HOST guarantees instead: before it enqueues step t it
+        # waits (a no-op in steady state: it runs ~1 step ahead) for the event the optimizer stream already waits on, recorded
+        # behind the heads of step t - RING_LAG.  Set (t + 1) % RING_SETS was last read at the end of step t - RING_SETS, trunk slot
+        # q % RING_SLOTS by the pooling launches of group q - RING_SLOTS (the last at the end of step t + 2G - 2 - G RING_SLOTS):
+        # both in front of heads(t - RING_LAG) when RING_SETS >= RING_LAG + 1 and G RING_SLOTS >= 2G - 1 + RING_LAG.
+        self.RING_LAG, self.RING_SETS, self.RING_SLOTS = 3, 4, 3
+        self.rois, self._rois_nb = mk(), [mk() for _ in range(self.RING_SETS)]
+        for t in [self.rois] + self._rois_nb:
             for i in range(n_img):
                 t[off[i]: off[i + 1], 0] = float(i)
         self.obj = torch.zeros((M,), dtype=torch.float32, device=dev)
-        self.obj_next = torch.zeros((M,), dtype=torch.float32, device=dev)
+        self._obj_nb = [torch.zeros((M,), dtype=torch.float32, device=dev) for _ in range(self.RING_SETS)]
+        self._ring_want = bool(ring)  # (False: the side stream waits for the main stream at the start of every step, as before round 6)
+        self._ring_on = False  # (set by _prime_pairs)
+        self._nb = 0          # the staging set in use (0 for every schedule but the ring)
+        self._ring_evs = []   # events behind the heads of the last steps (oldest first)
         self.props = torch.zeros((M, 4), dtype=torch.float32, device=dev)
         # image-level labels live in ONE device block (one H2D copy per step): [onehot f32 | classes i32 | count i32]
         self._gt_block = torch.zeros((2 * n_img * K + n_img,), dtype=torch.int32, device=dev)
         # labels of the NEXT batch land here (H2D on the side stream); the pooling graph moves them into the block the
         # heads graph reads - a node inside a graph instead of an eager copy with two launch gaps on the main stream
-        self._gt_stage = torch.zeros_like(self._gt_block)
+        self._gt_nb = [torch.zeros_like(self._gt_block) for _ in range(self.RING_SETS)]
         nk = n_img * K
         self.gt = dict(onehot=self._gt_block[:nk].view(torch.float32).view(n_img, K),
                        classes=self._gt_block[nk: 2 * nk].view(n_img, K), count=self._gt_block[2 * nk:],
@@ -134,6 +148,18 @@ class GraphedTrainStep:
         self._primed = False
 
     # ---- host side of one step: stage inputs into the static buffers (tiny async copies) -----------------------
+    @property
+    def rois_next(self):
+        return self._rois_nb[self._nb]
+
+    @property
+    def obj_next(self):
+        return self._obj_nb[self._nb]
+
+    @property
+    def _gt_stage(self):
+        return self._gt_nb[self._nb]
+
     def _stage_labels(self, batch, dst=None):
         """Image-level labels of the CURRENT batch.  They are built on the host and go through a ring of PINNED
         staging buffers so the H2D copies are truly asynchronous - a pageable source would block the host until the
@@ -382,13 +408,20 @@ class GraphedTrainStep:
             self._check_pooled()
 
     def _run_pairs(self, eager, next_batch, *ahead):
-        """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % 2.  Even t: the conv chain of pair t/2 + 1
+        """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % P (P = 2, or RING_SLOTS under the ring schedule).  Even t: the conv chain of pair t/2 + 1
         (batches t+2, t+3) starts on the side stream - its slot was last read by the pooling of batch t-1.  Every t: the
         pooling of batch t+1 reads its half of its pair's features (pair (t+1)/2, launched at step 2 ((t+1)/2) - 2)."""
         G = self.G
         main = torch.cuda.current_stream()
         t = self._t
-        self._side.wait_stream(main)
+        ring = self._ring_on and not eager
+        if ring:
+            while len(self._ring_evs) > self.RING_LAG - 1:
+                self._ring_evs.pop(0).synchronize()  # heads(t - RING_LAG) are done: every earlier reader of the set / slot written below
+            self._nb = (t + 1) % self.RING_SETS
+        else:
+            self._side.wait_stream(main)
+        P = self.RING_SLOTS if self._ring_on else 2
         losses = self._heads(eager)
         evp = None
         probe = os.environ.get("DRN_PROBE_TAIL_FILL")  # experiment (tools/README: tail window of the fused dW launch)
@@ -400,6 +433,12 @@ class GraphedTrainStep:
             pe.record(main)
         if self.split_tail:
             self.engine.run_fc1_tail()
+        if ring:
+            ev = getattr(self.opt, "small_ready_event", None)  # FusedSGD._on_grad_ready("small"): between the heads graph and the dW launch
+            if ev is None:
+                raise DrnError("the ring schedule needs the pipelined optimizer's hook on the fc6 tail")
+            self.opt.small_ready_event = None
+            self._ring_evs.append(ev)
         if probe:
             with torch.cuda.stream(self._probe_s):
                 self._probe_s.wait_event(pe)
@@ -415,7 +454,7 @@ class GraphedTrainStep:
                 evp = torch.cuda.Event()
                 evp.record(self._side)
             if t % G == 0:
-                ps = (t // G + 1) % 2
+                ps = (t // G + 1) % P
                 self._pair_stage(ahead[G - 2: 2 * G - 2], ps)  # batches t+G .. t+2G-1 (ahead[0] is batch t+2)
                 self._pair_bb_body(ps) if eager else self.g_pbb[ps].replay()
                 ev = torch.cuda.Event()
@@ -425,7 +464,7 @@ class GraphedTrainStep:
             main.wait_event(evp)
         else:
             self._stage_props(next_batch)
-        k1, h1 = ((t + 1) // G) % 2, (t + 1) % G
+        k1, h1 = ((t + 1) // G) % P, (t + 1) % G
         main.wait_event(self._pdone[k1])
         self._pair_pool_body(k1, h1)
         if self.split_tail:
@@ -437,12 +476,17 @@ class GraphedTrainStep:
         self.heads.train()
         main = torch.cuda.current_stream()
         G = self.G
-        self._pimages = [[im.clone() for _ in range(G) for im in self.image] for _ in range(2)]
-        self._pfeats, self._pdone = [None, None], [None, None]
+        # the ring: one GPU, the eager fc6 tail with the pipelined optimizer's hook (its event is the throttle's)
+        self._ring_on = (self.engine.kshard is None and self.split_tail and getattr(self.engine, "grad_ready_hook", None) is not None
+                         and self._ring_want)
+        P = self.RING_SLOTS if self._ring_on else 2
+        self._pimages = [[im.clone() for _ in range(G) for im in self.image] for _ in range(P)]
+        self._pfeats, self._pdone = [None] * P, [None] * P
         with torch.no_grad():
             self._pair_stage([b0, b1] + list(ahead[: G - 2]), 0)
             self._pfeats[0] = self._pair_backbone(0).clone()
-            self._pfeats[1] = torch.zeros_like(self._pfeats[0])
+            for ps in range(1, P):
+                self._pfeats[ps] = torch.zeros_like(self._pfeats[0])
             self._stage_props(b0)
             self._pair_pool_body(0, 0)
         self._pdone[0] = torch.cuda.Event()
@@ -454,8 +498,8 @@ class GraphedTrainStep:
         self.opt.zero_grad()
         torch.cuda.synchronize()
         self.g_main = torch.cuda.CUDAGraph()
-        self.g_pbb = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
-        for ps in (0, 1):
+        self.g_pbb = [torch.cuda.CUDAGraph() for _ in range(P)]
+        for ps in range(P):
             with torch.cuda.graph(self.g_pbb[ps], capture_error_mode="thread_local"):
                 self._pair_bb_body(ps)
         with torch.cuda.graph(self.g_main, capture_error_mode="thread_local"):

@@ -139,6 +139,48 @@ def _rel(a, b, floor):
     return float(np.abs(a - b).max() / max(np.abs(b).max(), floor))
 
 
+def test_ring_schedule_full_size_equals_waiting_schedule():
+    """Round 6: bench.py's default schedule - GraphedTrainStep(ring=True): the side stream never waits for the main stream,
+    RING_SETS staging sets and RING_SLOTS trunk slots, the host at most RING_LAG steps ahead of the heads - against the waiting
+    schedule (ring=False) at BASELINE configs[1]'s size, where a step is GPU-bound (1.2 ms of device work against 0.4 ms of host
+    work: the host DOES run ahead; with one staging set or without the throttle the same 60 steps end on different losses).
+    Sixty steps without a sync over eight distinct batches: every loss of every step the same bits."""
+    from drn_wsod_pytorch_amd.engine import GraphedTrainStep, build_optimizer
+
+    kw, R = CASES["r50c4_r2000_k20"]
+    ocfg = O.OracleCfg(dropout=0.5, base_lr=2e-4, **kw)
+    batches = [O.synthetic_batch(1, R, ocfg, seed=977 + 31 * i) for i in range(8)]
+    steps, group = 60, 4
+    order = [(i * 5 + i // 7) % 8 for i in range(steps + 2 * group)]
+    results = []
+    for ring in (False, True):
+        cfg, model = G.drn_model(ocfg, SEED, "cuda", 5, "bf16")
+        model.train()
+        opt = build_optimizer(cfg, model)
+        opt.enable_pipelined()
+        ins = [G.drn_inputs([dict(b, gt_boxes=torch.zeros(len(b["gt_classes"]), 4)) for b in bb]) for bb in batches]
+        for bb in ins:
+            for x in bb:
+                x["image"] = x["image"].cuda()
+                x["proposals"].proposal_boxes.tensor = x["proposals"].proposal_boxes.tensor.cuda()
+                x["proposals"].objectness_logits = x["proposals"].objectness_logits.cuda()
+        seq = [ins[i] for i in order]
+        stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True, trunk_pairs=group, eager_fc6=True, ring=ring)
+        out = []
+        for t in range(steps):
+            losses = stepper.step(*seq[t: t + 2 * group])
+            out.append(torch.stack([losses[k].detach().clone().reshape(()) for k in sorted(losses)]))  # (a device copy, no sync)
+        assert stepper._ring_on == ring
+        torch.cuda.synchronize()
+        results.append(torch.stack(out).cpu())
+        stepper.release()
+        del stepper, model, opt
+        torch.cuda.empty_cache()
+    load_package().set_precision("fp32")
+    assert torch.isfinite(results[0]).all()
+    assert torch.equal(results[0], results[1])
+
+
 @pytest.mark.parametrize("case", list(CASES))
 def test_bench_mode_full_size_vs_oracles(case):
     kw, R = CASES[case]

@@ -454,6 +454,54 @@ def test_hipgraph_step_equals_eager(lookahead):
             assert abs(e[k] - g[k]) <= 1e-5 * max(abs(e[k]), 1e-3), (k, e[k], g[k])
 
 
+@pytest.mark.parametrize("group", [2, 4])
+def test_ring_schedule_equals_waiting_schedule(group):
+    """Round 6: under the ring schedule (GraphedTrainStep(ring=True), bench.py's default) the side stream never waits for the
+    main stream - RING_SETS staging sets and RING_SLOTS trunk-feature slots, and the host stays at most RING_LAG steps ahead of the
+    heads.  Thirty steps enqueued WITHOUT a sync (the host runs ahead as far as the schedule lets it) over a batch sequence that is
+    not periodic in 2, 3 or 4 must give the losses of the waiting schedule bit for bit, step by step: a set or slot overwritten
+    before its reader ran pairs a step with another batch's proposals / labels / features.  (This tiny model is host-bound - it pins
+    the slot / set arithmetic for groups of 2 and 4; the GPU-bound case is tests/test_bench_mode_gpu.py::test_ring_schedule_full_size_*.)"""
+    from drn_wsod_pytorch_amd.engine import GraphedTrainStep, build_optimizer
+
+    name = "model_r50c4_tiny"
+    d = G.load(name)
+    ocfg = G.MODEL_CASES[name]
+    base = G.batch_from(d)
+    b0 = G.drn_inputs([base[0]])
+    alt = dict(base[0])
+    alt["image"] = (255.0 - base[0]["image"]).contiguous()
+    alt["objectness_logits"] = base[0]["objectness_logits"].flip(0).contiguous()
+    b1 = G.drn_inputs([alt])
+    alt2 = dict(base[0])
+    alt2["image"] = base[0]["image"].flip(2).contiguous()
+    alt2["proposal_boxes"] = base[0]["proposal_boxes"].flip(0).contiguous()
+    alt2["gt_classes"] = (base[0]["gt_classes"] + 1) % ocfg.num_classes
+    b2 = G.drn_inputs([alt2])
+    pat = [b0, b1, b2, b0, b1, b1, b0, b2, b1, b0, b2, b2, b0, b1, b0, b2, b2, b1, b1, b0]
+    steps = 30
+    seq = [pat[(i * 7 + i // 5) % len(pat)] for i in range(steps + 2 * group)]
+    results = []
+    for ring in (False, True):
+        cfg, model = G.drn_model(ocfg, int(d["seed"]), "cuda", 5, "fp32")
+        model.roi_heads.box_head.dropout_p = 0.0
+        model.train()
+        opt = build_optimizer(cfg, model)
+        opt.enable_pipelined()
+        stepper = GraphedTrainStep(model, opt, seq[0], split_tail=True, trunk_pairs=(True if group == 2 else group), eager_fc6=True, ring=ring)
+        out = []
+        for i in range(steps):
+            losses = stepper.step(*seq[i: i + 2 * group])
+            out.append(torch.stack([losses[k].detach().clone().reshape(()) for k in sorted(losses)]))  # (no sync: a device copy)
+        assert stepper._ring_on == ring
+        torch.cuda.synchronize()
+        results.append(torch.stack(out).cpu())
+        stepper.release()
+    assert torch.isfinite(results[0]).all()
+    assert len({tuple(r.tolist()) for r in results[0]}) > steps // 2  # the sequence really changes the losses from step to step
+    assert torch.equal(results[0], results[1])
+
+
 @pytest.mark.parametrize("comm,lookahead", [("fp32", 1), ("bf16", 1), ("fp32", 2), ("fp32", "pairs")])
 def test_split_tail_exchange_step_equals_eager(comm, lookahead):
     """The N>1 step on one GPU: a 1-rank RCCL group with the exchange forced on, GraphedTrainStep(split_tail=True)
