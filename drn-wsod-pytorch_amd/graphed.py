@@ -408,8 +408,9 @@ class GraphedTrainStep:
             self._check_pooled()
 
     def _run_pairs(self, eager, next_batch, *ahead):
-        """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % P (P = 2, or RING_SLOTS under the ring schedule).  Even t: the conv chain of pair t/2 + 1
-        (batches t+2, t+3) starts on the side stream - its slot was last read by the pooling of batch t-1.  Every t: the
+        """Step t.  Batches 2k and 2k+1 form pair k, living in pair slot k % P (P = 2, or RING_SLOTS under the ring schedule).
+        Even t: the conv chain of pair t/2 + 1 (batches t+2, t+3) starts on the side stream - with P = 2 its slot was last read by
+        the pooling of batch t-1.  Every t: the
         pooling of batch t+1 reads its half of its pair's features (pair (t+1)/2, launched at step 2 ((t+1)/2) - 2)."""
         G = self.G
         main = torch.cuda.current_stream()
@@ -445,8 +446,8 @@ class GraphedTrainStep:
                 self._probe_buf.fill_(1)  # as many bytes as the pooling launch writes: does the dW launch's last round have room for them?
             main.wait_stream(self._probe_s)
         with torch.cuda.stream(self._side):
-            # proposals of batch t+1 on the side stream (ordered behind step t-1's pooling graph, their last reader, by the
-            # wait above; in front of the conv chain): three small launches that sat between the last dW slab and the
+            # proposals of batch t+1 on the side stream (behind the last reader of their staging set: the wait above, or under
+            # the ring schedule the host's throttle; in front of the conv chain): three small launches that sat between the last dW slab and the
             # pooling graph on the main stream (22 us in the timeline)
             if self.stage_ahead:
                 self._stage_props(next_batch)
