@@ -2256,6 +2256,7 @@ __attribute__((visibility("hidden"))) int drn_roi_set_lds_kb(int kb);       // p
 __attribute__((visibility("hidden"))) int drn_roi_set_lane(int on);         // pool.hip
 __attribute__((visibility("hidden"))) int drn_roi_set_lane_reps(int reps);  // pool.hip
 __attribute__((visibility("hidden"))) int drn_roi_set_st(int on);             // pool.hip
+__attribute__((visibility("hidden"))) int drn_msm_set_wave(int on);           // head.hip
 int drn_tune(int knob, int value) {
   if (knob == 1) {  // DRN_TUNE_GEMM_PERSISTENT
     const int old = g_persistent;
@@ -2271,6 +2272,7 @@ int drn_tune(int knob, int value) {
   if (knob == 19) return drn_roi_set_lane(value);      // DRN_TUNE_ROI_LANE
   if (knob == 22) return drn_roi_set_lane_reps(value);  // DRN_TUNE_ROI_LANE_REPS
   if (knob == 31) return drn_roi_set_st(value);         // DRN_TUNE_ROI_ST
+  if (knob == 32) return drn_msm_set_wave(value);       // DRN_TUNE_MSM_WAVE
   if (knob == 5) {  // DRN_TUNE_CONV_KSPLIT
     const int old = g_conv_ksplit;
     g_conv_ksplit = value != 0;

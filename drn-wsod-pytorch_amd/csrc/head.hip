@@ -1031,6 +1031,39 @@ __global__ __launch_bounds__(MSM_THREADS) void mean_softmax_kernel(const float* 
   for (int c = 0; c < C; ++c) probs[(long)r * C + c] = acc[c * pitch] / (float)n_heads;
 }
 
+// The same for C <= 64 (every shipped head: 21 / 81 ... up to 64 columns), WAVE per row and lane = class (round 6): the thread-per-row
+// form above walks its row three times per head with dependent, uncoalesced loads - 44 us per call at R = 2000, a 4-block launch
+// (profiles/r6_30_tta_dc5_kernel_stats.txt: 1.8 % of a TTA image's kernel time).  Here a row is one coalesced load per head, the
+// maximum a wave reduction (order-free), and the denominator is summed by every lane in CLASS ORDER from the lanes' values
+// (v_readlane, c ascending) - the additions of the form above in the same order on the same values: bit-identical.
+__global__ __launch_bounds__(256) void mean_softmax_wave_kernel(const float* logits, long ld, const int* col0s, int n_heads, int C,
+                                                                float* probs, int M, int bg_first) {
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= M) return;
+  float acc = 0.f;
+  for (int h = 0; h < n_heads; ++h) {
+    const float* row = logits + (long)r * ld + col0s[h];
+    const float x = lane < C ? row[lane] : -FLT_MAX;
+    const float mx = wave_max(x);
+    const float e = lane < C ? expf(x - mx) : 0.f;
+    float se = 0.f;
+    for (int c = 0; c < C; ++c) se += __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, e), c));
+    acc += e / se;
+  }
+  if (lane < C) {
+    const int oc = bg_first ? (lane == 0 ? C - 1 : lane - 1) : lane;
+    probs[(long)r * C + oc] = acc / (float)n_heads;
+  }
+}
+
+static int g_msm_wave = 1;  // drn_tune(DRN_TUNE_MSM_WAVE = 32): 0 = the thread-per-row kernel also for C <= 64 (tests, A/B)
+extern "C" __attribute__((visibility("hidden"))) int drn_msm_set_wave(int on) {
+  const int old = g_msm_wave;
+  g_msm_wave = on != 0;
+  return old;
+}
+
 // Box2BoxTransform.apply_deltas; deltas == null means all-zero deltas (non-regressing heads)
 __global__ void apply_deltas_kernel(const float* deltas, long ld_d, const float* boxes, float* out, int M, int K,
                                     float wx, float wy, float ww, float wh, float clampv) {
@@ -1489,7 +1522,10 @@ int drn_mean_softmax(const float* logits, long ld, const int* col0s_dev, int n_h
   if (M == 0) return DRN_OK;
   if (C < 1) return DRN_ERR_ARG;
   const dim3 grid((M + MSM_THREADS - 1) / MSM_THREADS), block(MSM_THREADS);
-  if ((size_t)C * MSM_THREADS * sizeof(float) <= 64 * 1024)
+  if (C <= 64 && g_msm_wave)
+    hipLaunchKernelGGL(mean_softmax_wave_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, logits, ld, col0s_dev, n_heads, C,
+                       probs, M, bg_first);
+  else if ((size_t)C * MSM_THREADS * sizeof(float) <= 64 * 1024)
     hipLaunchKernelGGL(mean_softmax_kernel<true>, grid, block, (size_t)C * MSM_THREADS * sizeof(float), (hipStream_t)stream, logits,
                        ld, col0s_dev, n_heads, C, probs, M, bg_first);
   else  // (heads with more than 256 classes run instead of being refused)

@@ -40,6 +40,7 @@ def gemm_set_tile(tile):
 TUNE_GEMM_PERSISTENT, TUNE_SGD_GRID, TUNE_GEMM_GROUP_ROWS, TUNE_ROI_MAP64, TUNE_CONV_KSPLIT, TUNE_GEMM_TAIL_SPLIT, TUNE_CONV_KS_TILES, TUNE_CONV_K2_TILES, TUNE_CONV_PATCH = 1, 2, 3, 4, 5, 6, 7, 8, 9
 TUNE_CONV_RING = 23
 TUNE_ROI_ST = 31
+TUNE_MSM_WAVE = 32
 TUNE_ROI_LANE = 19
 TUNE_CONV_PP = 24
 TUNE_PP8, TUNE_PP8_STAGES, TUNE_PP8_VARIANT, TUNE_PP8_PROFILE, TUNE_PP8_WIDE, TUNE_PP8_WIDE_VARIANT = 25, 26, 27, 28, 29, 30

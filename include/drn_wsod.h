@@ -254,6 +254,7 @@ int drn_gemm_set_tile(int tile);
 #define DRN_TUNE_GEMM_NWG 18 /* resident workgroups of persistent 256x256 launches (multiple of 8; 0 = default: one per CU) - for launches on a CU-masked stream */
 #define DRN_TUNE_SGDP_EPILOGUE 20 /* 0/1 (default 1): the tile epilogue of drn_gemm_tn_sgd moves the bf16 gradient tile LDS -> global four 16-byte pieces per trip instead of one (A/B knob; bit-identical) */
 #define DRN_TUNE_ROI_LANE_REPS 22 /* lane-per-bin ROIPool on maps that leave one block per CU: groups of 64 ROIs a block walks with one staged map slice (0 = default: 4, halved while fewer than two rounds of blocks would remain; 1 = a block per group) */
+#define DRN_TUNE_MSM_WAVE 32 /* 0/1 (default 1): drn_mean_softmax for heads of <= 64 columns as a wave per row / lane per class (one coalesced load per head, the denominator summed in class order: bit-identical); 0 = the thread-per-row kernel */
 #define DRN_TUNE_ROI_ST 31 /* RoIPool from a sparse table of block maxima (four table cells per bin instead of the window's cells; needs the workspace of drn_roi_pool_workspace_bytes): 0 = off, 1 (default) = where it beats the window kernels (maps of >= 1800 cells with >= 1500 ROIs, >= 3000 cells with >= 600 ROIs, and every map whose LDS slice holds only 4 channels per cell - the dilated-C5 stride-8 map of a real-size image - with >= 400 ROIs), 2 = every map whose slice fits (>= 64 ROIs) */
 #define DRN_TUNE_ROI_LANE 19 /* 0/1 (default 1): the bf16 training operand A from the lane-per-bin ROIPool kernel (a wave per ROI, lane = bin: every channel leaves as one 98-byte run per store instruction); 0 = the 64-ROI kernel writes A */
 #define DRN_TUNE_CONV_RING 23 /* register-ring conv kernels (conv_ring.hip; bf16, Cin % 64 == 0, layers beyond the latency-bound small maps): 0 = off (the tiles of gemm_conv.hip), 1 = default (64x64 tile, class by measurement), 64 / 128 = pin the 64x64 / 128x128 tile (any other value is ignored: drn_tune returns the unchanged setting); every tile gives the same bits as the 64x64 / 128x128 tiled kernel */

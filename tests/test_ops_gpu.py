@@ -1367,6 +1367,16 @@ def test_softmax_ce(drn, K, M):
     p2 = drn.mean_softmax(logits.to(DEV), [0, 3, 7], K + 1).cpu()
     ref = sum(F.softmax(logits[:, c: c + K + 1], -1) for c in (0, 3, 7)) / 3
     assert torch.allclose(p2, ref, rtol=1e-5, atol=1e-9)
+    # (round 6) the wave-per-row kernel sums the denominator in class order like the thread-per-row one: the same bits
+    p2b = drn.mean_softmax(logits.to(DEV), [0, 3, 7], K + 1, bg_first=True).cpu()
+    old = drn.tune(drn.TUNE_MSM_WAVE, 0)
+    try:
+        p3 = drn.mean_softmax(logits.to(DEV), [0, 3, 7], K + 1).cpu()
+        p3b = drn.mean_softmax(logits.to(DEV), [0, 3, 7], K + 1, bg_first=True).cpu()
+    finally:
+        drn.tune(drn.TUNE_MSM_WAVE, old)
+    assert torch.equal(p2, p3) and torch.equal(p2b, p3b)
+    assert torch.equal(p2b[:, :-1], p2[:, 1:]) and torch.equal(p2b[:, -1], p2[:, 0])
 
 
 def test_apply_deltas_bit_exact(drn):
